@@ -1,0 +1,350 @@
+"""Tensor-level entry points over the C-ABI library — the stand-in for `maskrcnn_benchmark._C`.
+
+The first block mirrors the reference's pybind surface one-to-one (reference:
+maskrcnn_benchmark/csrc/vision.cpp:7-15): `nms`, `roi_align_forward`, `roi_align_backward`,
+`sigmoid_focalloss_forward`, `sigmoid_focalloss_backward` with the same argument order and meaning.
+The second block exposes the kernels the reference gets from ATen (conv / pooling / SGD) and the fused DA
+head tails.  PyTorch is used here only for device memory and the current HIP stream.
+
+Layout contract: 4-D activations are logical NCHW tensors in torch.channels_last memory format (physical
+NHWC), weights are logical [Cout,Cin,KH,KW] in channels_last (physical [Cout,KH,KW,Cin]).  Inputs in any
+other layout are converted (one copy); outputs are always channels_last.
+"""
+import ctypes
+
+import torch
+
+from . import _lib
+from ._lib import ConvDesc
+
+CL = torch.channels_last
+
+# NMS tie rule used by default: the reference's CPU build suppresses on IoU >= thr, its CUDA build on
+# IoU > thr (csrc/cpu/nms_cpu.cpp:60 vs csrc/cuda/nms.cu:60).  The oracle available without CUDA is the CPU
+# rule, so that is the default; set to 1 to reproduce the CUDA build.
+NMS_TIE_RULE = 0
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _p(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else None
+
+
+def _dev(t, name):
+    if not isinstance(t, torch.Tensor) or not t.is_cuda:
+        raise _lib.DadetError(
+            "%s must be a tensor on the HIP device: the da_detect_amd operators have no CPU path" % name)
+    if t.dtype != torch.float32:
+        raise _lib.DadetError("%s must be float32, got %s" % (name, t.dtype))
+    return t
+
+
+def _nhwc(t):
+    """physical NHWC view of a logical NCHW tensor (copies only when the layout differs)"""
+    return t.contiguous(memory_format=CL)
+
+
+def _workspace(nbytes, device):
+    return torch.empty(max(int(nbytes), 16), dtype=torch.uint8, device=device)
+
+
+# ------------------------------------------------------------------------------------------------
+# reference `_C` surface
+# ------------------------------------------------------------------------------------------------
+def nms_with_count(dets, scores, threshold, max_keep=-1, tie_rule=None):
+    """device-resident result: (keep_buffer int64[n], num_keep int32[1]); no host sync."""
+    _dev(dets, "dets"), _dev(scores, "scores")
+    n = dets.shape[0]
+    dets = dets.contiguous()
+    scores = scores.contiguous()
+    keep = torch.empty(n, dtype=torch.int64, device=dets.device)
+    count = torch.empty(1, dtype=torch.int32, device=dets.device)
+    nbytes = ctypes.c_size_t(0)
+    _lib.call("dadet_nms_workspace_bytes", n, ctypes.byref(nbytes))
+    ws = _workspace(nbytes.value, dets.device)
+    rule = NMS_TIE_RULE if tie_rule is None else tie_rule
+    _lib.call("dadet_nms", _p(dets), _p(scores), n, float(threshold), int(rule), int(max_keep), _p(ws),
+              ctypes.c_size_t(ws.numel()), _p(keep), _p(count), _stream())
+    return keep, count
+
+
+def nms(dets, scores, threshold):
+    """_C.nms(dets[N,4], scores[N], thr) -> int64[K] kept original indices, ascending (nms.h:10-28)."""
+    if dets.numel() == 0:
+        return torch.empty(0, dtype=torch.int64, device=dets.device)
+    keep, count = nms_with_count(dets, scores, threshold)
+    return keep[: int(count.item())]
+
+
+def roi_align_forward(input, rois, spatial_scale, pooled_height, pooled_width, sampling_ratio):
+    """_C.roi_align_forward -> [R,C,ph,pw] (ROIAlign.h:11-25)."""
+    _dev(input, "input"), _dev(rois, "rois")
+    B, C, H, W = input.shape
+    R = rois.shape[0]
+    x = _nhwc(input)
+    rois = rois.contiguous()
+    out = torch.empty((R, C, pooled_height, pooled_width), dtype=torch.float32, device=input.device,
+                      memory_format=CL)
+    _lib.call("dadet_roi_align_forward", _p(x), _p(rois), _p(out), B, C, H, W, R, pooled_height,
+              pooled_width, float(spatial_scale), int(sampling_ratio), _stream())
+    return out
+
+
+def roi_align_backward(grad, rois, spatial_scale, pooled_height, pooled_width, batch_size, channels,
+                       height, width, sampling_ratio):
+    """_C.roi_align_backward -> [B,C,H,W] (ROIAlign.h:27-45)."""
+    _dev(grad, "grad"), _dev(rois, "rois")
+    g = _nhwc(grad)
+    rois = rois.contiguous()
+    gin = torch.zeros((batch_size, channels, height, width), dtype=torch.float32, device=grad.device,
+                      memory_format=CL)
+    _lib.call("dadet_roi_align_backward", _p(g), _p(rois), _p(gin), batch_size, channels, height, width,
+              rois.shape[0], pooled_height, pooled_width, float(spatial_scale), int(sampling_ratio),
+              _stream())
+    return gin
+
+
+def sigmoid_focalloss_forward(logits, targets, num_classes, gamma, alpha):
+    """_C.sigmoid_focalloss_forward(logits[N,C], targets[N] int32, C, gamma, alpha) -> [N,C]"""
+    _dev(logits, "logits")
+    logits = logits.contiguous()
+    targets = targets.contiguous().to(torch.int32)
+    out = torch.empty_like(logits)
+    _lib.call("dadet_sigmoid_focal_loss_forward", _p(logits), _p(targets), _p(out), logits.shape[0],
+              int(num_classes), float(gamma), float(alpha), _stream())
+    return out
+
+
+def sigmoid_focalloss_backward(logits, targets, d_losses, num_classes, gamma, alpha):
+    _dev(logits, "logits")
+    logits = logits.contiguous()
+    targets = targets.contiguous().to(torch.int32)
+    d_losses = d_losses.contiguous()
+    out = torch.empty_like(logits)
+    _lib.call("dadet_sigmoid_focal_loss_backward", _p(logits), _p(targets), _p(d_losses), _p(out),
+              logits.shape[0], int(num_classes), float(gamma), float(alpha), _stream())
+    return out
+
+
+# ------------------------------------------------------------------------------------------------
+# convolution family
+# ------------------------------------------------------------------------------------------------
+def _desc(N, H, W, Cin, Cout, KH, KW, stride, pad, Ho, Wo, OutH=None, OutW=None, os=1, relu_mode=0):
+    return ConvDesc(N, H, W, Cin, Cout, KH, KW, stride, pad, Ho, Wo, Ho if OutH is None else OutH,
+                    Wo if OutW is None else OutW, os, relu_mode)
+
+
+def conv_out_size(H, W, KH, KW, stride, pad):
+    return (H + 2 * pad - KH) // stride + 1, (W + 2 * pad - KW) // stride + 1
+
+
+def conv_forward(x, w, scale=None, bias=None, addend=None, mask_ref=None, stride=1, pad=0, relu_mode=0,
+                 out=None, out_spatial_stride=1, out_hw=None, out_size=None):
+    """y = act(conv(x, w) * scale + bias + addend); see dadet_conv_forward in include/dadet.h.
+
+    x [N,Cin,H,W] channels_last, w [Cout,Cin,KH,KW] channels_last.  `out_size` overrides (Ho, Wo) (used
+    by the stem whose kernel is zero-padded to 7x8).  With out_spatial_stride > 1 the result is scattered
+    into `out` (or a fresh zero tensor) of spatial size out_hw.
+    """
+    _dev(x, "x"), _dev(w, "w")
+    N, Cin, H, W = x.shape
+    Cout, Cin_w, KH, KW = w.shape
+    assert Cin == Cin_w, "conv_forward: channel mismatch %d vs %d" % (Cin, Cin_w)
+    x = _nhwc(x)
+    w = _nhwc(w)
+    Ho, Wo = out_size if out_size is not None else conv_out_size(H, W, KH, KW, stride, pad)
+    if out_spatial_stride > 1:
+        OutH, OutW = out_hw
+        if out is None:
+            out = torch.zeros((N, Cout, OutH, OutW), dtype=torch.float32, device=x.device, memory_format=CL)
+    else:
+        OutH, OutW = Ho, Wo
+        if out is None:
+            out = torch.empty((N, Cout, Ho, Wo), dtype=torch.float32, device=x.device, memory_format=CL)
+    assert out.is_contiguous(memory_format=CL) or out.dim() != 4 or min(out.shape[1:]) == 1 or \
+        out.is_contiguous(), "conv_forward: out must be channels_last"
+    if addend is not None:
+        addend = _nhwc(addend) if addend is not out else addend
+    if mask_ref is not None:
+        mask_ref = _nhwc(mask_ref)
+    d = _desc(N, H, W, Cin, Cout, KH, KW, stride, pad, Ho, Wo, OutH, OutW, out_spatial_stride, relu_mode)
+    _lib.call("dadet_conv_forward", ctypes.byref(d), _p(x), _p(w), _p(scale), _p(bias), _p(addend),
+              _p(mask_ref), _p(out), _stream())
+    return out
+
+
+def conv_weight_transpose(w, scale=None):
+    """[Cout,Cin,KH,KW] -> data-gradient weights [Cin,Cout,KH,KW] (flipped taps, `scale[cout]` folded in)."""
+    _dev(w, "w")
+    Cout, Cin, KH, KW = w.shape
+    w = _nhwc(w)
+    wt = torch.empty((Cin, Cout, KH, KW), dtype=torch.float32, device=w.device, memory_format=CL)
+    _lib.call("dadet_conv_weight_transpose", _p(w), _p(scale), _p(wt), Cout, KH, KW, Cin, _stream())
+    return wt
+
+
+def conv_wgrad(x, gy, weight_shape, stride=1, pad=0, out_scale=None, dw=None, accumulate=False):
+    """dw[co,ci,r,s] = out_scale[co] * sum_m gy[m,co] * x[gather(m,r,s),ci]  (channels_last weight layout)."""
+    _dev(x, "x"), _dev(gy, "gy")
+    N, Cin, H, W = x.shape
+    Cout, Cin_w, KH, KW = weight_shape
+    assert Cin == Cin_w
+    x = _nhwc(x)
+    gy = _nhwc(gy)
+    Ho, Wo = gy.shape[2], gy.shape[3]
+    if dw is None:
+        dw = torch.empty((Cout, Cin, KH, KW), dtype=torch.float32, device=x.device, memory_format=CL)
+        accumulate = False
+    d = _desc(N, H, W, Cin, Cout, KH, KW, stride, pad, Ho, Wo)
+    nbytes = ctypes.c_size_t(0)
+    _lib.call("dadet_conv_wgrad_workspace_bytes", ctypes.byref(d), ctypes.byref(nbytes))
+    ws = _workspace(nbytes.value, x.device)
+    _lib.call("dadet_conv_wgrad", ctypes.byref(d), _p(x), _p(gy), _p(out_scale), _p(dw),
+              1 if accumulate else 0, _p(ws), ctypes.c_size_t(ws.numel()), _stream())
+    return dw
+
+
+def relu_bn_backward(g, y=None, scale=None, want_unscaled=False):
+    """(g * (y > 0)) and optionally that times scale[c]; returns (g_masked or None, g_scaled)."""
+    _dev(g, "g")
+    g = _nhwc(g) if g.dim() == 4 else g.contiguous()
+    C = g.shape[1]
+    rows = g.numel() // C
+    yy = None
+    if y is not None:
+        yy = _nhwc(y) if y.dim() == 4 else y.contiguous()
+    g_out = torch.empty_like(g) if want_unscaled else None
+    g_scaled = torch.empty_like(g)
+    _lib.call("dadet_relu_bn_backward", _p(g), _p(yy), _p(scale), _p(g_out), _p(g_scaled), rows, C,
+              _stream())
+    return g_out, g_scaled
+
+
+def colsum(g):
+    """sum over every axis but channels of a channels_last / [M,C] tensor -> [C]"""
+    _dev(g, "g")
+    g = _nhwc(g) if g.dim() == 4 else g.contiguous()
+    C = g.shape[1]
+    rows = g.numel() // C
+    out = torch.empty(C, dtype=torch.float32, device=g.device)
+    nbytes = ctypes.c_size_t(0)
+    _lib.call("dadet_colsum_workspace_bytes", rows, C, ctypes.byref(nbytes))
+    ws = _workspace(nbytes.value, g.device)
+    _lib.call("dadet_colsum", _p(g), _p(out), rows, C, _p(ws), ctypes.c_size_t(ws.numel()), _stream())
+    return out
+
+
+def channel_affine(x, scale, bias, relu=False):
+    _dev(x, "x")
+    x = _nhwc(x)
+    C = x.shape[1]
+    y = torch.empty_like(x)
+    _lib.call("dadet_channel_affine", _p(x), _p(scale), _p(bias), _p(y), x.numel() // C, C,
+              1 if relu else 0, _stream())
+    return y
+
+
+def maxpool3x3s2(x):
+    _dev(x, "x")
+    x = _nhwc(x)
+    N, C, H, W = x.shape
+    Ho, Wo = (H + 2 - 3) // 2 + 1, (W + 2 - 3) // 2 + 1
+    y = torch.empty((N, C, Ho, Wo), dtype=torch.float32, device=x.device, memory_format=CL)
+    _lib.call("dadet_maxpool3x3s2_forward", _p(x), _p(y), N, H, W, C, Ho, Wo, _stream())
+    return y
+
+
+def avgpool_forward(x):
+    """[R,C,h,w] channels_last -> [R,C] (mean over h*w)"""
+    _dev(x, "x")
+    x = _nhwc(x)
+    R, C, h, w = x.shape
+    y = torch.empty((R, C), dtype=torch.float32, device=x.device)
+    _lib.call("dadet_avgpool_forward", _p(x), _p(y), R, h * w, C, _stream())
+    return y
+
+
+def avgpool_backward(gy, h, w):
+    _dev(gy, "gy")
+    gy = gy.contiguous()
+    R, C = gy.shape
+    gx = torch.empty((R, C, h, w), dtype=torch.float32, device=gy.device, memory_format=CL)
+    _lib.call("dadet_avgpool_backward", _p(gy), _p(gx), R, h * w, C, _stream())
+    return gx
+
+
+def nchw3_to_nhwc4(x):
+    """[N,3,H,W] contiguous NCHW image batch -> [N,4,H,W] channels_last (4th channel zero)"""
+    _dev(x, "x")
+    x = x.contiguous()
+    N, C, H, W = x.shape
+    assert C == 3
+    y = torch.empty((N, 4, H, W), dtype=torch.float32, device=x.device, memory_format=CL)
+    _lib.call("dadet_nchw3_to_nhwc4", _p(x), _p(y), N, H, W, _stream())
+    return y
+
+
+def rpn_decode_clip(deltas_nhwc, anchors, topk_idx, weights, xform_clip, im_w, im_h):
+    """decode + clip the top-k anchors of ONE image.  deltas_nhwc: [H,W,A*4] (any view whose storage is
+    that order), anchors [H*W*A,4], topk_idx int64[K] -> boxes [K,4]."""
+    K = topk_idx.shape[0]
+    out = torch.empty((K, 4), dtype=torch.float32, device=anchors.device)
+    wx, wy, ww, wh = weights
+    _lib.call("dadet_rpn_decode_clip", _p(deltas_nhwc), _p(anchors), _p(topk_idx), K, float(wx), float(wy),
+              float(ww), float(wh), float(xform_clip), float(im_w), float(im_h), _p(out), _stream())
+    return out
+
+
+def da_img_head_loss_forward(t, w2, b2, labels, num_images, rows_per_image):
+    """t [M,C1] (physical), w2 [C1], b2 [1], labels [num_images] -> (logits [M], sums [num_images,2])"""
+    C1 = w2.numel()
+    M = num_images * rows_per_image
+    logits = torch.empty(M, dtype=torch.float32, device=t.device)
+    sums = torch.zeros((num_images, 2), dtype=torch.float32, device=t.device)
+    _lib.call("dadet_da_img_head_loss_forward", _p(t), _p(w2), _p(b2), _p(labels), _p(logits), _p(sums),
+              num_images, rows_per_image, C1, _stream())
+    return logits, sums
+
+
+def da_img_head_loss_backward(t, w2, logits, labels, coef, num_images, rows_per_image, need_x=True):
+    C1 = w2.numel()
+    g_t_w = torch.empty_like(t)
+    g_t_x = torch.empty_like(t) if need_x else None
+    g_w2 = torch.zeros(C1, dtype=torch.float32, device=t.device)
+    g_b2 = torch.zeros(1, dtype=torch.float32, device=t.device)
+    _lib.call("dadet_da_img_head_loss_backward", _p(t), _p(w2), _p(logits), _p(labels), _p(coef),
+              _p(g_t_w), _p(g_t_x), _p(g_w2), _p(g_b2), num_images, rows_per_image, C1, _stream())
+    return g_t_w, g_t_x, g_w2, g_b2
+
+
+def triplet_w_forward(a, p, n, margin, eps=1e-6):
+    """a, p, n: [1,C,H,W] channels_last maps -> (loss mean over C*H, dist [H*C,2])"""
+    a, p, n = _nhwc(a), _nhwc(p), _nhwc(n)
+    _, C, H, W = a.shape
+    dist = torch.empty((H * C, 2), dtype=torch.float32, device=a.device)
+    loss_sum = torch.zeros(1, dtype=torch.float32, device=a.device)
+    _lib.call("dadet_triplet_w_forward", _p(a), _p(p), _p(n), H, W, C, float(margin), float(eps), _p(dist),
+              _p(loss_sum), _stream())
+    return loss_sum / float(H * C), dist
+
+
+def triplet_w_backward(a, p, n, dist, g_scale, margin, eps=1e-6, need=(True, True, True)):
+    a, p, n = _nhwc(a), _nhwc(p), _nhwc(n)
+    _, C, H, W = a.shape
+    ga = torch.empty_like(a) if need[0] else None
+    gp = torch.empty_like(p) if need[1] else None
+    gn = torch.empty_like(n) if need[2] else None
+    _lib.call("dadet_triplet_w_backward", _p(a), _p(p), _p(n), _p(dist), _p(g_scale), H, W, C, float(margin),
+              float(eps), _p(ga), _p(gp), _p(gn), _stream())
+    return ga, gp, gn
+
+
+def device_info():
+    cu, khz, hbm = ctypes.c_int(0), ctypes.c_int(0), ctypes.c_size_t(0)
+    name = ctypes.create_string_buffer(64)
+    _lib.call("dadet_device_info", ctypes.byref(cu), ctypes.byref(khz), ctypes.byref(hbm), name, 64)
+    return {"cu_count": cu.value, "clock_khz": khz.value, "hbm_bytes": hbm.value,
+            "arch": name.value.decode()}

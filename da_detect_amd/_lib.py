@@ -1,0 +1,96 @@
+"""ctypes binding of libdadet_hip.so (C-ABI in include/dadet.h).
+
+The library is the product: there is no CPU / eager fallback.  Importing this module never fails (so the
+host-side logic can be unit-tested without a GPU), but the first operator call raises loudly when the
+shared object has not been built or no HIP device is visible.
+"""
+import ctypes
+import os
+from ctypes import POINTER, c_char_p, c_float, c_int, c_int32, c_int64, c_size_t, c_void_p
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libdadet_hip.so")
+_lib = None
+
+
+class ConvDesc(ctypes.Structure):
+    """mirror of dadet_conv_desc (include/dadet.h)"""
+
+    _fields_ = [(n, c_int) for n in (
+        "N", "H", "W", "Cin", "Cout", "KH", "KW", "stride", "pad", "Ho", "Wo", "OutH", "OutW",
+        "out_spatial_stride", "relu_mode")]
+
+
+class SgdEntry(ctypes.Structure):
+    """mirror of dadet_sgd_entry (include/dadet.h)"""
+
+    _fields_ = [("p", c_void_p), ("g", c_void_p), ("buf", c_void_p), ("numel", c_int64),
+                ("lr", c_float), ("weight_decay", c_float)]
+
+
+# name -> argtypes ; every function returns int (status) unless listed in _RESTYPES
+_P = c_void_p
+_SIGNATURES = {
+    "dadet_version": [],
+    "dadet_device_info": [POINTER(c_int), POINTER(c_int), POINTER(c_size_t), c_char_p, c_int],
+    "dadet_nms_workspace_bytes": [c_int, POINTER(c_size_t)],
+    "dadet_nms": [_P, _P, c_int, c_float, c_int, c_int, _P, c_size_t, _P, _P, _P],
+    "dadet_roi_align_forward": [_P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_float, c_int, _P],
+    "dadet_roi_align_backward": [_P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_float, c_int, _P],
+    "dadet_sigmoid_focal_loss_forward": [_P, _P, _P, c_int, c_int, c_float, c_float, _P],
+    "dadet_sigmoid_focal_loss_backward": [_P, _P, _P, _P, c_int, c_int, c_float, c_float, _P],
+    "dadet_conv_forward": [POINTER(ConvDesc), _P, _P, _P, _P, _P, _P, _P, _P],
+    "dadet_conv_wgrad_workspace_bytes": [POINTER(ConvDesc), POINTER(c_size_t)],
+    "dadet_conv_wgrad": [POINTER(ConvDesc), _P, _P, _P, _P, c_int, _P, c_size_t, _P],
+    "dadet_conv_weight_transpose": [_P, _P, _P, c_int, c_int, c_int, c_int, _P],
+    "dadet_relu_bn_backward": [_P, _P, _P, _P, _P, c_int64, c_int, _P],
+    "dadet_colsum_workspace_bytes": [c_int64, c_int, POINTER(c_size_t)],
+    "dadet_colsum": [_P, _P, c_int64, c_int, _P, c_size_t, _P],
+    "dadet_channel_affine": [_P, _P, _P, _P, c_int64, c_int, c_int, _P],
+    "dadet_maxpool3x3s2_forward": [_P, _P, c_int, c_int, c_int, c_int, c_int, c_int, _P],
+    "dadet_avgpool_forward": [_P, _P, c_int, c_int, c_int, _P],
+    "dadet_avgpool_backward": [_P, _P, c_int, c_int, c_int, _P],
+    "dadet_nchw3_to_nhwc4": [_P, _P, c_int, c_int, c_int, _P],
+    "dadet_rpn_decode_clip": [_P, _P, _P, c_int, c_float, c_float, c_float, c_float, c_float, c_float, c_float, _P, _P],
+    "dadet_da_img_head_loss_forward": [_P, _P, _P, _P, _P, _P, c_int, c_int, c_int, _P],
+    "dadet_da_img_head_loss_backward": [_P, _P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, _P],
+    "dadet_triplet_w_forward": [_P, _P, _P, c_int, c_int, c_int, c_float, c_float, _P, _P, _P],
+    "dadet_triplet_w_backward": [_P, _P, _P, _P, _P, c_int, c_int, c_int, c_float, c_float, _P, _P, _P, _P],
+    "dadet_sgd_step": [_P, c_int, c_int64, c_float, c_int, c_float, _P],
+}
+_RESTYPES = {"dadet_last_error": c_char_p}
+EXPORTED_SYMBOLS = sorted(list(_SIGNATURES) + ["dadet_last_error"])
+
+
+class DadetError(RuntimeError):
+    pass
+
+
+def load():
+    """dlopen the library and attach prototypes; raises DadetError when it is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise DadetError(
+            "libdadet_hip.so is not built (%s). Run `python -c 'import __graft_entry__ as g; g.build()'` "
+            "or `make -C da_detect_amd/csrc`. There is no CPU fallback for the product path." % LIB_PATH)
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, argtypes in _SIGNATURES.items():
+        fn = getattr(lib, name)
+        fn.argtypes = argtypes
+        fn.restype = c_int
+    lib.dadet_last_error.argtypes = []
+    lib.dadet_last_error.restype = c_char_p
+    _lib = lib
+    return lib
+
+
+def check(rc, what=""):
+    if rc != 0:
+        msg = load().dadet_last_error()
+        raise DadetError("%s failed (status %d): %s" % (what or "dadet call", rc, (msg or b"").decode()))
+
+
+def call(name, *args):
+    check(getattr(load(), name)(*args), name)

@@ -1,0 +1,556 @@
+// Implicit-GEMM convolution (forward / data-gradient / weight-gradient) on the gfx950 fp32 matrix
+// pipe (v_mfma_f32_32x32x2_f32: exact fp32, k-ordered fmaf chain — guide §3), NHWC activations,
+// [Cout][KH][KW][Cin] weights.
+//
+// Stands in for the ATen conv2d / linear calls of the reference hot path and fuses what the reference
+// runs as separate elementwise passes around them:
+//   forward : conv -> FrozenBatchNorm2d affine (layers/batch_norm.py:19-24) -> (+ residual) -> relu_
+//             (modeling/backbone/resnet.py:294-314, :331-336), conv + bias + relu (rpn/rpn.py:39-46,
+//             da_heads/da_heads.py:32-37), nn.Linear (+relu) (da_heads.py:61-68, roi_box_predictors.py:28-33)
+//   dgrad   : the same kernel run on the output gradient with the flipped/transposed weights, with the
+//             upstream ReLU gating and the residual-gradient add fused into the epilogue
+//   wgrad   : dW = gY^T * im2col(X), split over the (huge) N*Ho*Wo reduction axis, deterministic two-pass.
+//
+// GEMM view (forward): C[m][n] = sum_k A[m][k] * B[n][k],  m = (img, ho, wo), n = cout, k = (r, s, cin).
+// Both operands are K-contiguous in HBM (NHWC rows / KRSC rows), so a K-tile of 32 is one 128-byte run
+// per row: each lane moves 16 B, a wavefront covers 8 rows x 128 B.  Tiles are staged through LDS with a
+// +4-float row pad (row stride 36 floats): the MFMA fragment reads are ds_read_b128 (4 consecutive k per
+// lane, the k-slot order is permuted identically for A and B so the product is unchanged) and are
+// bank-conflict free for the 16-lane service groups of ds_read_b128 (36*i mod 64 is a permutation of the
+// 16 quad-slots); the staging writes are ds_write_b128 of 8 contiguous lanes per row.
+// A 256-thread workgroup = 4 wavefronts as 2x2, each wavefront owns a (TM*32)x(TN*32) block of the
+// output tile, accumulators live in registers (16 fp32 per 32x32 block).  K loop: register prefetch of
+// tile t+1 is issued before the MFMAs of tile t, LDS is double buffered, one barrier per K-tile.
+// Workgroup ids are remapped so that each XCD (private L2) walks a contiguous range of m-tiles.
+#include "common.h"
+
+namespace dadet {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int BK = 32;          // K-tile
+constexpr int LDS_STRIDE = 36;  // floats per staged row (32 + 4 pad, keeps 16-byte alignment)
+
+struct ConvArgs {
+  const float* x;
+  const float* w;
+  const float* scale;
+  const float* bias;
+  const float* addend;
+  const float* mask_ref;
+  float* y;
+  int N, H, W, Cin, Cout, KH, KW, stride, pad, Ho, Wo, OutH, OutW, os, relu_mode;
+  int M, K;        // GEMM rows, reduction length
+  int tiles_m, tiles_n;
+};
+
+template <int TM, int TN>
+__global__ __launch_bounds__(256) void conv_fwd_kernel(const ConvArgs a) {
+  constexpr int BM = 2 * TM * 32, BN = 2 * TN * 32;
+  constexpr int A_LOADS = BM / 32, B_LOADS = BN / 32;  // float4 loads per thread per K-tile
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* As = reinterpret_cast<float*>(smem);                 // [2][BM][LDS_STRIDE]
+  float* Bs = As + 2 * BM * LDS_STRIDE;                       // [2][BN][LDS_STRIDE]
+
+  const int nwg = a.tiles_m * a.tiles_n;
+  const int tile = xcd_remap(blockIdx.x, nwg);
+  const int bm0 = (tile / a.tiles_n) * BM;
+  const int bn0 = (tile % a.tiles_n) * BN;
+
+  const int t = threadIdx.x;
+  const int lane = t & 63, wave = t >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int lcol = t & 7;    // float4 column of the K-tile this thread stages
+  const int lrow = t >> 3;   // first staged row (0..31)
+
+  // per staged A row: image pixel base and top-left input coordinate
+  int pixbase[A_LOADS], hi0[A_LOADS], wi0[A_LOADS];
+  const int HoWo = a.Ho * a.Wo;
+#pragma unroll
+  for (int i = 0; i < A_LOADS; ++i) {
+    const int m = bm0 + lrow + 32 * i;
+    if (m < a.M) {
+      const int img = m / HoWo;
+      const int rem = m - img * HoWo;
+      const int ho = rem / a.Wo;
+      const int wo = rem - ho * a.Wo;
+      pixbase[i] = img * a.H * a.W;
+      hi0[i] = ho * a.stride - a.pad;
+      wi0[i] = wo * a.stride - a.pad;
+    } else {
+      pixbase[i] = 0;
+      hi0[i] = -(1 << 28);  // fails every bounds check
+      wi0[i] = 0;
+    }
+  }
+
+  float4 ra[A_LOADS], rb[B_LOADS];
+  const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+
+  auto load_tile = [&](int kt) {
+    const int kk = kt * BK + lcol * 4;
+    const bool kvalid = kk < a.K;
+    const int tap = kk / a.Cin;
+    const int c = kk - tap * a.Cin;
+    const int r = tap / a.KW;
+    const int s = tap - r * a.KW;
+#pragma unroll
+    for (int i = 0; i < A_LOADS; ++i) {
+      const int hi = hi0[i] + r, wi = wi0[i] + s;
+      const bool ok = kvalid && (unsigned)hi < (unsigned)a.H && (unsigned)wi < (unsigned)a.W;
+      const int64_t off = ((int64_t)(pixbase[i] + hi * a.W + wi)) * a.Cin + c;
+      ra[i] = ok ? *reinterpret_cast<const float4*>(a.x + off) : zero4;
+    }
+#pragma unroll
+    for (int i = 0; i < B_LOADS; ++i) {
+      const int n = bn0 + lrow + 32 * i;
+      const bool ok = kvalid && n < a.Cout;
+      rb[i] = ok ? *reinterpret_cast<const float4*>(a.w + (int64_t)n * a.K + kk) : zero4;
+    }
+  };
+  auto store_tile = [&](int buf) {
+    float* Ab = As + buf * BM * LDS_STRIDE;
+    float* Bb = Bs + buf * BN * LDS_STRIDE;
+#pragma unroll
+    for (int i = 0; i < A_LOADS; ++i)
+      *reinterpret_cast<float4*>(Ab + (lrow + 32 * i) * LDS_STRIDE + lcol * 4) = ra[i];
+#pragma unroll
+    for (int i = 0; i < B_LOADS; ++i)
+      *reinterpret_cast<float4*>(Bb + (lrow + 32 * i) * LDS_STRIDE + lcol * 4) = rb[i];
+  };
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  const int nk = (a.K + BK - 1) / BK;
+  load_tile(0);
+  store_tile(0);
+  __syncthreads();
+
+  const int frag_row = lane & 31;        // row of the 32-row fragment this lane feeds
+  const int frag_k = (lane >> 5) * 4;    // which 4-float half of each 8-float k-group
+  int buf = 0;
+  for (int kt = 0; kt < nk; ++kt) {
+    if (kt + 1 < nk) load_tile(kt + 1);  // global loads in flight during the MFMAs below
+    const float* Ab = As + buf * BM * LDS_STRIDE + (wm * TM * 32 + frag_row) * LDS_STRIDE + frag_k;
+    const float* Bb = Bs + buf * BN * LDS_STRIDE + (wn * TN * 32 + frag_row) * LDS_STRIDE + frag_k;
+#pragma unroll
+    for (int j = 0; j < BK / 8; ++j) {
+      float4 fa[TM], fb[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+        fa[i] = *reinterpret_cast<const float4*>(Ab + i * 32 * LDS_STRIDE + j * 8);
+#pragma unroll
+      for (int i = 0; i < TN; ++i)
+        fb[i] = *reinterpret_cast<const float4*>(Bb + i * 32 * LDS_STRIDE + j * 8);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+#pragma unroll
+        for (int im = 0; im < TM; ++im)
+#pragma unroll
+          for (int in = 0; in < TN; ++in) {
+            const float av = e == 0 ? fa[im].x : e == 1 ? fa[im].y : e == 2 ? fa[im].z : fa[im].w;
+            const float bv = e == 0 ? fb[in].x : e == 1 ? fb[in].y : e == 2 ? fb[in].z : fb[in].w;
+            acc[im][in] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[im][in], 0, 0, 0);
+          }
+      }
+    }
+    if (kt + 1 < nk) store_tile(buf ^ 1);
+    __syncthreads();
+    buf ^= 1;
+  }
+
+  // epilogue: D layout of the 32x32 MFMA — col = lane & 31, row = (reg & 3) + 8*(reg >> 2) + 4*(lane >> 5)
+  const int col_in = lane & 31;
+  const int row_hi = 4 * (lane >> 5);
+#pragma unroll
+  for (int in = 0; in < TN; ++in) {
+    const int n = bn0 + wn * TN * 32 + in * 32 + col_in;
+    if (n >= a.Cout) continue;
+    const float sc = a.scale ? a.scale[n] : 1.f;
+    const float bi = a.bias ? a.bias[n] : 0.f;
+#pragma unroll
+    for (int im = 0; im < TM; ++im) {
+#pragma unroll
+      for (int reg = 0; reg < 16; ++reg) {
+        const int m = bm0 + wm * TM * 32 + im * 32 + (reg & 3) + 8 * (reg >> 2) + row_hi;
+        if (m >= a.M) continue;
+        int64_t orow = m;
+        if (a.os != 1) {
+          const int img = m / HoWo;
+          const int rem = m - img * HoWo;
+          const int ho = rem / a.Wo;
+          const int wo = rem - ho * a.Wo;
+          orow = ((int64_t)img * a.OutH + (int64_t)ho * a.os) * a.OutW + (int64_t)wo * a.os;
+        }
+        const int64_t off = orow * a.Cout + n;
+        float v = acc[im][in][reg];
+        if (a.scale) v = v * sc;
+        if (a.bias) v = v + bi;
+        if (a.addend) v = v + a.addend[off];
+        if (a.relu_mode == 1) v = fmaxf(v, 0.f);
+        else if (a.relu_mode == 2) v = (a.mask_ref[off] > 0.f) ? v : 0.f;
+        a.y[off] = v;
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// weight gradient.  GEMM view: D[co][kc] = sum_m gY[m][co] * Xg[m][kc], kc = (r, s, ci).
+// Both operands are staged as [32 m-rows][128 columns] (their natural HBM orientation, 16 B per lane
+// along the channel axis); MFMA fragments are ds_read_b32 down the columns — consecutive lanes hit
+// consecutive banks, so no padding is needed.  grid = (co tiles * kc tiles, m splits).
+struct WgradArgs {
+  const float* x;
+  const float* gy;
+  const float* out_scale;
+  float* out;       // dw (splits == 1) or workspace [splits][Cout][K]
+  int N, H, W, Cin, Cout, KH, KW, stride, pad, Ho, Wo;
+  int M, K;
+  int tiles_co, tiles_kc, splits, rows_per_split;  // rows_per_split is a multiple of 32
+  int direct;       // 1: write dw with scale / accumulate applied here
+  int accumulate;
+};
+
+__global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs a) {
+  constexpr int TILE = 128, RK = 32;  // output tile 128x128, 32 m-rows per step
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* Gs = reinterpret_cast<float*>(smem);   // [2][RK][TILE]  gY rows
+  float* Xs = Gs + 2 * RK * TILE;               // [2][RK][TILE]  gathered X rows
+
+  const int tile = xcd_remap(blockIdx.x, a.tiles_co * a.tiles_kc);
+  const int co0 = (tile / a.tiles_kc) * TILE;
+  const int kc0 = (tile % a.tiles_kc) * TILE;
+  const int split = blockIdx.y;
+  const int m_begin = split * a.rows_per_split;
+  int m_end = m_begin + a.rows_per_split;
+  if (m_end > a.M) m_end = a.M;
+
+  const int t = threadIdx.x;
+  const int lane = t & 63, wave = t >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int lcol = t & 31;   // float4 column (0..31) of the 128-wide row
+  const int lrow = t >> 5;   // 0..7 ; rows lrow + 8*i
+
+  // this thread's X column -> (tap, channel) is fixed for the whole kernel
+  const int kk = kc0 + lcol * 4;
+  const bool kvalid = kk < a.K;
+  const int tap = kk / a.Cin;
+  const int ci = kk - tap * a.Cin;
+  const int r = tap / a.KW;
+  const int s = tap - r * a.KW;
+  const int co = co0 + lcol * 4;
+  const bool covalid = co < a.Cout;  // Cout % 4 == 0 is required by the host wrapper
+  const int HoWo = a.Ho * a.Wo;
+
+  float4 rg[4], rx[4];
+  const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+  auto load_tile = [&](int m0) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int m = m0 + lrow + 8 * i;
+      const bool mv = m < m_end;
+      rg[i] = (mv && covalid) ? *reinterpret_cast<const float4*>(a.gy + (int64_t)m * a.Cout + co) : zero4;
+      bool ok = mv && kvalid;
+      int64_t off = 0;
+      if (ok) {
+        const int img = m / HoWo;
+        const int rem = m - img * HoWo;
+        const int ho = rem / a.Wo;
+        const int wo = rem - ho * a.Wo;
+        const int hi = ho * a.stride - a.pad + r;
+        const int wi = wo * a.stride - a.pad + s;
+        ok = (unsigned)hi < (unsigned)a.H && (unsigned)wi < (unsigned)a.W;
+        off = ((int64_t)(img * a.H + hi) * a.W + wi) * a.Cin + ci;
+      }
+      rx[i] = ok ? *reinterpret_cast<const float4*>(a.x + off) : zero4;
+    }
+  };
+  auto store_tile = [&](int buf) {
+    float* Gb = Gs + buf * RK * TILE;
+    float* Xb = Xs + buf * RK * TILE;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      *reinterpret_cast<float4*>(Gb + (lrow + 8 * i) * TILE + lcol * 4) = rg[i];
+      *reinterpret_cast<float4*>(Xb + (lrow + 8 * i) * TILE + lcol * 4) = rx[i];
+    }
+  };
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  const int nsteps = (m_end - m_begin + RK - 1) / RK;
+  if (nsteps > 0) {
+    load_tile(m_begin);
+    store_tile(0);
+  }
+  __syncthreads();
+  const int fcol = lane & 31, fk = lane >> 5;
+  int buf = 0;
+  for (int st = 0; st < nsteps; ++st) {
+    if (st + 1 < nsteps) load_tile(m_begin + (st + 1) * RK);
+    const float* Gb = Gs + buf * RK * TILE + wm * 64 + fcol;
+    const float* Xb = Xs + buf * RK * TILE + wn * 64 + fcol;
+#pragma unroll
+    for (int k2 = 0; k2 < RK / 2; ++k2) {
+      const int row = 2 * k2 + fk;
+      const float g0 = Gb[row * TILE], g1 = Gb[row * TILE + 32];
+      const float x0 = Xb[row * TILE], x1 = Xb[row * TILE + 32];
+      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(g0, x0, acc[0][0], 0, 0, 0);
+      acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(g0, x1, acc[0][1], 0, 0, 0);
+      acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(g1, x0, acc[1][0], 0, 0, 0);
+      acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(g1, x1, acc[1][1], 0, 0, 0);
+    }
+    if (st + 1 < nsteps) store_tile(buf ^ 1);
+    __syncthreads();
+    buf ^= 1;
+  }
+
+  float* out = a.direct ? a.out : a.out + (size_t)split * a.Cout * a.K;
+  const int col_in = lane & 31, row_hi = 4 * (lane >> 5);
+#pragma unroll
+  for (int in = 0; in < 2; ++in) {
+    const int kc = kc0 + wn * 64 + in * 32 + col_in;
+    if (kc >= a.K) continue;
+#pragma unroll
+    for (int im = 0; im < 2; ++im)
+#pragma unroll
+      for (int reg = 0; reg < 16; ++reg) {
+        const int c = co0 + wm * 64 + im * 32 + (reg & 3) + 8 * (reg >> 2) + row_hi;
+        if (c >= a.Cout) continue;
+        const size_t off = (size_t)c * a.K + kc;
+        float v = acc[im][in][reg];
+        if (a.direct) {
+          if (a.out_scale) v = v * a.out_scale[c];
+          if (a.accumulate) v = v + out[off];
+        }
+        out[off] = v;
+      }
+  }
+}
+
+__global__ void wgrad_reduce_kernel(const float4* __restrict__ part, const float* __restrict__ out_scale,
+                                    float4* __restrict__ dw, int64_t total4, int K4, int splits,
+                                    int accumulate) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total4;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    float4 s = part[i];
+    for (int p = 1; p < splits; ++p) {
+      const float4 v = part[(int64_t)p * total4 + i];
+      s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+    }
+    if (out_scale) {
+      const float sc = out_scale[i / K4];
+      s.x *= sc; s.y *= sc; s.z *= sc; s.w *= sc;
+    }
+    if (accumulate) {
+      const float4 o = dw[i];
+      s.x += o.x; s.y += o.y; s.z += o.z; s.w += o.w;
+    }
+    dw[i] = s;
+  }
+}
+
+// wt[ci][KH-1-r][KW-1-s][co] = w[co][r][s][ci] * scale[co]
+// 32x32 LDS tile transpose between the co axis and the ci axis for one (r,s) tap.
+__global__ __launch_bounds__(256) void weight_transpose_kernel(const float* __restrict__ w,
+                                                               const float* __restrict__ scale,
+                                                               float* __restrict__ wt, int Cout, int KH,
+                                                               int KW, int Cin) {
+  __shared__ float tile[32][33];
+  const int tap = blockIdx.z;
+  const int r = tap / KW, s = tap % KW;
+  const int tapT = (KH - 1 - r) * KW + (KW - 1 - s);
+  const int ci0 = blockIdx.x * 32, co0 = blockIdx.y * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+  const int64_t K = (int64_t)KH * KW * Cin, Kt = (int64_t)KH * KW * Cout;
+  for (int j = ty; j < 32; j += 8) {
+    const int co = co0 + j, ci = ci0 + tx;
+    float v = 0.f;
+    if (co < Cout && ci < Cin) {
+      v = w[(int64_t)co * K + (int64_t)tap * Cin + ci];
+      if (scale) v = v * scale[co];
+    }
+    tile[j][tx] = v;
+  }
+  __syncthreads();
+  for (int j = ty; j < 32; j += 8) {
+    const int ci = ci0 + j, co = co0 + tx;
+    if (co < Cout && ci < Cin) wt[(int64_t)ci * Kt + (int64_t)tapT * Cout + co] = tile[tx][j];
+  }
+}
+
+static int conv_desc_check(const dadet_conv_desc* d, const char* who) {
+  DADET_REQUIRE(d, "%s: null descriptor", who);
+  DADET_REQUIRE(d->N >= 0 && d->H > 0 && d->W > 0 && d->Cin > 0 && d->Cout > 0 && d->KH > 0 && d->KW > 0 &&
+                    d->stride > 0 && d->pad >= 0 && d->Ho > 0 && d->Wo > 0,
+                "%s: bad dims", who);
+  DADET_REQUIRE(d->Cin % 4 == 0, "%s: Cin=%d must be a multiple of 4 (pad the channel axis)", who, d->Cin);
+  DADET_REQUIRE((int64_t)d->N * d->H * d->W * d->Cin < (1LL << 31) &&
+                    (int64_t)d->N * d->Ho * d->Wo < (1LL << 31),
+                "%s: tensor too large for 32-bit pixel indexing", who);
+  return DADET_OK;
+}
+
+}  // namespace dadet
+
+using namespace dadet;
+
+static bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+template <int TM, int TN>
+static int launch_fwd(ConvArgs& a, hipStream_t st) {
+  constexpr int BM = 2 * TM * 32, BN = 2 * TN * 32;
+  a.tiles_m = ceil_div(a.M, BM);
+  a.tiles_n = ceil_div(a.Cout, BN);
+  const size_t lds = sizeof(float) * 2 * (BM + BN) * LDS_STRIDE;
+  static bool attr_set = false;
+  if (!attr_set && lds > 48 * 1024) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_fwd_kernel<TM, TN>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) {
+      set_error("conv_forward: hipFuncSetAttribute: %s", hipGetErrorString(e));
+      return DADET_ELAUNCH;
+    }
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((conv_fwd_kernel<TM, TN>), dim3(a.tiles_m * a.tiles_n), dim3(256), lds, st, a);
+  return check_launch("conv_forward");
+}
+
+extern "C" int dadet_conv_forward(const dadet_conv_desc* d, const float* x, const float* w,
+                                  const float* scale, const float* bias, const float* addend,
+                                  const float* mask_ref, float* y, void* stream) {
+  int rc = conv_desc_check(d, "conv_forward");
+  if (rc) return rc;
+  if (d->N == 0) return DADET_OK;
+  DADET_REQUIRE(x && w && y && al16(x) && al16(w), "conv_forward: x / w must be non-null and 16-byte aligned");
+  DADET_REQUIRE(d->relu_mode >= 0 && d->relu_mode <= 2, "conv_forward: relu_mode");
+  DADET_REQUIRE(d->relu_mode != 2 || mask_ref, "conv_forward: relu_mode 2 needs mask_ref");
+  const int os = d->out_spatial_stride > 0 ? d->out_spatial_stride : 1;
+  DADET_REQUIRE(os == 1 ? (d->OutH == d->Ho && d->OutW == d->Wo)
+                        : ((d->Ho - 1) * os < d->OutH && (d->Wo - 1) * os < d->OutW),
+                "conv_forward: OutH/OutW inconsistent with Ho/Wo and out_spatial_stride");
+  ConvArgs a;
+  a.x = x; a.w = w; a.scale = scale; a.bias = bias; a.addend = addend; a.mask_ref = mask_ref; a.y = y;
+  a.N = d->N; a.H = d->H; a.W = d->W; a.Cin = d->Cin; a.Cout = d->Cout; a.KH = d->KH; a.KW = d->KW;
+  a.stride = d->stride; a.pad = d->pad; a.Ho = d->Ho; a.Wo = d->Wo; a.OutH = d->OutH; a.OutW = d->OutW;
+  a.os = os; a.relu_mode = d->relu_mode;
+  a.M = d->N * d->Ho * d->Wo;
+  a.K = d->KH * d->KW * d->Cin;
+  hipStream_t st = as_stream(stream);
+  // tile choice: widest tile whose grid still gives every CU about two workgroups
+  const int64_t t128 = (int64_t)ceil_div(a.M, 128) * ceil_div(a.Cout, 128);
+  if (a.Cout > 64 && t128 >= 2 * kNumCU) return launch_fwd<2, 2>(a, st);
+  if (a.Cout > 32) {
+    const int64_t t64 = (int64_t)ceil_div(a.M, 128) * ceil_div(a.Cout, 64);
+    if (t64 >= kNumCU || a.M <= 64 * 64) return launch_fwd<2, 1>(a, st);
+    return launch_fwd<1, 1>(a, st);
+  }
+  return launch_fwd<2, 1>(a, st);
+}
+
+static void wgrad_plan(const dadet_conv_desc* d, int* tiles_co, int* tiles_kc, int* splits, int* rps) {
+  const int M = d->N * d->Ho * d->Wo, K = d->KH * d->KW * d->Cin;
+  *tiles_co = ceil_div(d->Cout, 128);
+  *tiles_kc = ceil_div(K, 128);
+  const int tiles = (*tiles_co) * (*tiles_kc);
+  int want = ceil_div(3 * kNumCU, tiles);       // ~3 workgroups per CU in total
+  const int max_splits = ceil_div(M, 256);      // at least 8 K-steps per split
+  if (want > max_splits) want = max_splits;
+  if (want < 1) want = 1;
+  int rows = ceil_div(M, want);
+  rows = ceil_div(rows, 32) * 32;
+  *rps = rows;
+  *splits = ceil_div(M, rows);
+}
+
+extern "C" int dadet_conv_wgrad_workspace_bytes(const dadet_conv_desc* d, size_t* bytes_out) {
+  int rc = conv_desc_check(d, "conv_wgrad_workspace_bytes");
+  if (rc) return rc;
+  DADET_REQUIRE(bytes_out, "conv_wgrad_workspace_bytes: null out");
+  if (d->N == 0) { *bytes_out = 0; return DADET_OK; }
+  int tco, tkc, splits, rps;
+  wgrad_plan(d, &tco, &tkc, &splits, &rps);
+  *bytes_out = splits > 1 ? sizeof(float) * (size_t)splits * d->Cout * d->KH * d->KW * d->Cin : 0;
+  return DADET_OK;
+}
+
+extern "C" int dadet_conv_wgrad(const dadet_conv_desc* d, const float* x, const float* gy,
+                                const float* out_scale, float* dw, int accumulate, void* workspace,
+                                size_t workspace_bytes, void* stream) {
+  int rc = conv_desc_check(d, "conv_wgrad");
+  if (rc) return rc;
+  DADET_REQUIRE(dw, "conv_wgrad: null dw");
+  hipStream_t st = as_stream(stream);
+  const int K = d->KH * d->KW * d->Cin;
+  if (d->N == 0) {
+    if (!accumulate) (void)hipMemsetAsync(dw, 0, sizeof(float) * (size_t)d->Cout * K, st);
+    return check_launch("conv_wgrad(empty)");
+  }
+  DADET_REQUIRE(x && gy && al16(x) && al16(gy) && al16(dw), "conv_wgrad: pointers must be 16-byte aligned");
+  DADET_REQUIRE(d->Cout % 4 == 0, "conv_wgrad: Cout=%d must be a multiple of 4", d->Cout);
+  WgradArgs a;
+  a.x = x; a.gy = gy; a.out_scale = out_scale;
+  a.N = d->N; a.H = d->H; a.W = d->W; a.Cin = d->Cin; a.Cout = d->Cout; a.KH = d->KH; a.KW = d->KW;
+  a.stride = d->stride; a.pad = d->pad; a.Ho = d->Ho; a.Wo = d->Wo;
+  a.M = d->N * d->Ho * d->Wo; a.K = K;
+  wgrad_plan(d, &a.tiles_co, &a.tiles_kc, &a.splits, &a.rows_per_split);
+  a.accumulate = accumulate;
+  if (a.splits == 1) {
+    a.direct = 1;
+    a.out = dw;
+  } else {
+    const size_t need = sizeof(float) * (size_t)a.splits * d->Cout * K;
+    if (!workspace || workspace_bytes < need) {
+      set_error("conv_wgrad: workspace %zu < required %zu", workspace_bytes, need);
+      return DADET_EWORKSPACE;
+    }
+    a.direct = 0;
+    a.out = static_cast<float*>(workspace);
+  }
+  const size_t lds = sizeof(float) * 2 * 2 * 32 * 128;  // 64 KB
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad_kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) {
+      set_error("conv_wgrad: hipFuncSetAttribute: %s", hipGetErrorString(e));
+      return DADET_ELAUNCH;
+    }
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(conv_wgrad_kernel, dim3(a.tiles_co * a.tiles_kc, a.splits), dim3(256), lds, st, a);
+  rc = check_launch("conv_wgrad");
+  if (rc) return rc;
+  if (a.splits > 1) {
+    const int64_t total4 = (int64_t)d->Cout * K / 4;
+    int64_t blocks = ceil_div64(total4, 256);
+    if (blocks > kMaxStreamBlocks) blocks = kMaxStreamBlocks;
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((int)blocks), dim3(256), 0, st,
+                       reinterpret_cast<const float4*>(workspace), out_scale, reinterpret_cast<float4*>(dw),
+                       total4, K / 4, a.splits, accumulate);
+    rc = check_launch("conv_wgrad(reduce)");
+  }
+  return rc;
+}
+
+extern "C" int dadet_conv_weight_transpose(const float* w, const float* scale, float* wt, int Cout, int KH,
+                                           int KW, int Cin, void* stream) {
+  DADET_REQUIRE(w && wt && Cout > 0 && KH > 0 && KW > 0 && Cin > 0, "conv_weight_transpose: bad args");
+  DADET_REQUIRE(KH * KW <= 65535, "conv_weight_transpose: kernel too large");
+  hipLaunchKernelGGL(weight_transpose_kernel, dim3(ceil_div(Cin, 32), ceil_div(Cout, 32), KH * KW),
+                     dim3(256), 0, as_stream(stream), w, scale, wt, Cout, KH, KW, Cin);
+  return check_launch("conv_weight_transpose");
+}

@@ -1,0 +1,450 @@
+// HBM-bound helpers of the DA Faster R-CNN training path (NHWC fp32, gfx950).
+// Every kernel moves 16 B per lane with lanes along the channel axis and a capped grid-stride launch.
+// Each entry point cites the reference code it stands in for.
+#include "common.h"
+#include <float.h>
+
+namespace dadet {
+
+static inline int stream_blocks(int64_t work_items, int threads) {
+  int64_t b = ceil_div64(work_items, threads);
+  if (b > kMaxStreamBlocks) b = kMaxStreamBlocks;
+  if (b < 1) b = 1;
+  return (int)b;
+}
+
+// ---- ReLU (+ FrozenBN scale) backward -------------------------------------------------------
+// reference: F.relu_ + FrozenBatchNorm2d.forward (layers/batch_norm.py:19-24) differentiated by autograd.
+__global__ void relu_bn_backward_kernel(const float4* __restrict__ g, const float4* __restrict__ y,
+                                        const float4* __restrict__ scale, float4* __restrict__ g_out,
+                                        float4* __restrict__ g_scaled, int64_t total4, int C4) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total4;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    const float4 gv = g[i];
+    float4 r = gv;
+    if (y) {
+      const float4 yv = y[i];
+      r.x = yv.x > 0.f ? gv.x : 0.f;
+      r.y = yv.y > 0.f ? gv.y : 0.f;
+      r.z = yv.z > 0.f ? gv.z : 0.f;
+      r.w = yv.w > 0.f ? gv.w : 0.f;
+    }
+    if (g_out) g_out[i] = r;
+    if (g_scaled) {
+      float4 s = r;
+      if (scale) {
+        const float4 sc = scale[i % C4];
+        s.x *= sc.x; s.y *= sc.y; s.z *= sc.z; s.w *= sc.w;
+      }
+      g_scaled[i] = s;
+    }
+  }
+}
+
+// ---- column sum (bias gradient) -------------------------------------------------------------
+// partial[s][c] = sum over the s-th row slab; deterministic two-pass.
+__global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __restrict__ g,
+                                                             float* __restrict__ partial, int64_t rows,
+                                                             int C, int64_t rows_per_split) {
+  // block: 64 columns x 4 row lanes
+  __shared__ float red[4][64];
+  const int col = blockIdx.x * 64 + (threadIdx.x & 63);
+  const int rl = threadIdx.x >> 6;
+  const int64_t r0 = (int64_t)blockIdx.y * rows_per_split;
+  int64_t r1 = r0 + rows_per_split;
+  if (r1 > rows) r1 = rows;
+  float acc = 0.f;
+  if (col < C)
+    for (int64_t r = r0 + rl; r < r1; r += 4) acc += g[r * C + col];
+  red[rl][threadIdx.x & 63] = acc;
+  __syncthreads();
+  if (rl == 0 && col < C) {
+    const int l = threadIdx.x & 63;
+    partial[(size_t)blockIdx.y * C + col] = (red[0][l] + red[1][l]) + (red[2][l] + red[3][l]);
+  }
+}
+__global__ void colsum_final_kernel(const float* __restrict__ partial, float* __restrict__ out, int C,
+                                    int splits) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  float acc = 0.f;
+  for (int s = 0; s < splits; ++s) acc += partial[(size_t)s * C + c];
+  out[c] = acc;
+}
+static int colsum_splits(int64_t rows, int C) {
+  const int col_blocks = ceil_div(C, 64);
+  int64_t want = ceil_div64(kNumCU * 4, col_blocks);
+  int64_t max_by_rows = ceil_div64(rows, 64);
+  if (want > max_by_rows) want = max_by_rows;
+  if (want < 1) want = 1;
+  if (want > 1024) want = 1024;
+  return (int)want;
+}
+
+// ---- per-channel affine (standalone FrozenBatchNorm2d) ---------------------------------------
+__global__ void channel_affine_kernel(const float4* __restrict__ x, const float4* __restrict__ scale,
+                                      const float4* __restrict__ bias, float4* __restrict__ y,
+                                      int64_t total4, int C4, int relu) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total4;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    const int c = (int)(i % C4);
+    const float4 xv = x[i], s = scale[c], b = bias[c];
+    float4 r;
+    r.x = xv.x * s.x + b.x; r.y = xv.y * s.y + b.y; r.z = xv.z * s.z + b.z; r.w = xv.w * s.w + b.w;
+    if (relu) {
+      r.x = fmaxf(r.x, 0.f); r.y = fmaxf(r.y, 0.f); r.z = fmaxf(r.z, 0.f); r.w = fmaxf(r.w, 0.f);
+    }
+    y[i] = r;
+  }
+}
+
+// ---- 3x3 / stride 2 / pad 1 max pool (BaseStem, resnet.py:335) -------------------------------
+__global__ void maxpool3x3s2_kernel(const float4* __restrict__ x, float4* __restrict__ y, int N, int H,
+                                    int W, int C4, int Ho, int Wo) {
+  const int64_t total = (int64_t)N * Ho * Wo * C4;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    const int c = (int)(i % C4);
+    int64_t p = i / C4;
+    const int wo = (int)(p % Wo);
+    p /= Wo;
+    const int ho = (int)(p % Ho);
+    const int n = (int)(p / Ho);
+    float4 m = make_float4(-FLT_MAX, -FLT_MAX, -FLT_MAX, -FLT_MAX);
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+      const int hi = ho * 2 - 1 + r;
+      if (hi < 0 || hi >= H) continue;
+#pragma unroll
+      for (int s = 0; s < 3; ++s) {
+        const int wi = wo * 2 - 1 + s;
+        if (wi < 0 || wi >= W) continue;
+        const float4 v = x[((int64_t)(n * H + hi) * W + wi) * C4 + c];
+        m.x = fmaxf(m.x, v.x); m.y = fmaxf(m.y, v.y); m.z = fmaxf(m.z, v.z); m.w = fmaxf(m.w, v.w);
+      }
+    }
+    y[i] = m;
+  }
+}
+
+// ---- global average pool over HW (nn.AvgPool2d(7) on 7x7 maps) --------------------------------
+// sums in raster order like ATen's avg_pool2d CPU kernel (sum then divide by the window size).
+__global__ void avgpool_fwd_kernel(const float4* __restrict__ x, float4* __restrict__ y, int R, int HW,
+                                   int C4) {
+  const int64_t total = (int64_t)R * C4;
+  const float inv = (float)HW;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    const int c = (int)(i % C4);
+    const int64_t r = i / C4;
+    float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int p = 0; p < HW; ++p) {
+      const float4 v = x[(r * HW + p) * C4 + c];
+      a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+    }
+    a.x /= inv; a.y /= inv; a.z /= inv; a.w /= inv;
+    y[i] = a;
+  }
+}
+__global__ void avgpool_bwd_kernel(const float4* __restrict__ gy, float4* __restrict__ gx, int R, int HW,
+                                   int C4) {
+  const int64_t total = (int64_t)R * HW * C4;
+  const float inv = (float)HW;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    const int c = (int)(i % C4);
+    const int64_t r = i / ((int64_t)HW * C4);
+    float4 g = gy[r * C4 + c];
+    g.x /= inv; g.y /= inv; g.z /= inv; g.w /= inv;
+    gx[i] = g;
+  }
+}
+
+// ---- NCHW(3) -> NHWC(4) staging for the stem -------------------------------------------------
+__global__ void nchw3_to_nhwc4_kernel(const float* __restrict__ x, float4* __restrict__ y, int N,
+                                      int64_t HW) {
+  const int64_t total = (int64_t)N * HW;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t n = i / HW, p = i % HW;
+    const float* b = x + n * 3 * HW + p;
+    y[i] = make_float4(b[0], b[HW], b[2 * HW], 0.f);
+  }
+}
+
+// ---- RPN decode + clip ----------------------------------------------------------------------
+// reference: BoxCoder.decode (modeling/box_coder.py:52-95) then BoxList.clip_to_image
+// (structures/bounding_box.py:214-224), in the reference's operation order.
+__global__ void rpn_decode_clip_kernel(const float4* __restrict__ deltas, const float4* __restrict__ anchors,
+                                       const int64_t* __restrict__ topk_idx, int K, float wx, float wy,
+                                       float ww, float wh, float xform_clip, float im_w, float im_h,
+                                       float4* __restrict__ out) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= K) return;
+  const int64_t a = topk_idx[k];
+  const float4 b = anchors[a];
+  const float4 d = deltas[a];
+  const float width = b.z - b.x + 1.f;
+  const float height = b.w - b.y + 1.f;
+  const float ctr_x = b.x + 0.5f * width;
+  const float ctr_y = b.y + 0.5f * height;
+  const float dx = d.x / wx, dy = d.y / wy;
+  float dw = d.z / ww, dh = d.w / wh;
+  dw = fminf(dw, xform_clip);
+  dh = fminf(dh, xform_clip);
+  const float pcx = dx * width + ctr_x;
+  const float pcy = dy * height + ctr_y;
+  const float pw = expf(dw) * width;
+  const float ph = expf(dh) * height;
+  float x1 = pcx - 0.5f * pw;
+  float y1 = pcy - 0.5f * ph;
+  float x2 = pcx + 0.5f * pw - 1.f;
+  float y2 = pcy + 0.5f * ph - 1.f;
+  x1 = fminf(fmaxf(x1, 0.f), im_w - 1.f);
+  y1 = fminf(fmaxf(y1, 0.f), im_h - 1.f);
+  x2 = fminf(fmaxf(x2, 0.f), im_w - 1.f);
+  y2 = fminf(fmaxf(y2, 0.f), im_h - 1.f);
+  out[k] = make_float4(x1, y1, x2, y2);
+}
+
+// ---- sigmoid focal loss (reference: csrc/cuda/SigmoidFocalLoss_cuda.cu:21-101) ----------------
+__global__ void focal_fwd_kernel(const float* __restrict__ logits, const int* __restrict__ targets,
+                                 float* __restrict__ losses, int64_t total, int C, float gamma,
+                                 float alpha) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    const int n = (int)(i / C), d = (int)(i % C);
+    const int t = targets[n];
+    const float c1 = (t == (d + 1)) ? 1.f : 0.f;
+    const float c2 = ((t >= 0) & (t != (d + 1))) ? 1.f : 0.f;
+    const float zn = 1.f - alpha, zp = alpha;
+    const float x = logits[i];
+    const float p = 1.f / (1.f + expf(-x));
+    const float term1 = powf(1.f - p, gamma) * logf(fmaxf(p, FLT_MIN));
+    const float xpos = (x >= 0.f) ? 1.f : 0.f;
+    const float term2 = powf(p, gamma) * (-1.f * x * xpos - logf(1.f + expf(x - 2.f * x * xpos)));
+    float l = 0.f;
+    l += -c1 * term1 * zp;
+    l += -c2 * term2 * zn;
+    losses[i] = l;
+  }
+}
+__global__ void focal_bwd_kernel(const float* __restrict__ logits, const int* __restrict__ targets,
+                                 const float* __restrict__ d_losses, float* __restrict__ d_logits,
+                                 int64_t total, int C, float gamma, float alpha) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    const int n = (int)(i / C), d = (int)(i % C);
+    const int t = targets[n];
+    const float c1 = (t == (d + 1)) ? 1.f : 0.f;
+    const float c2 = ((t >= 0) & (t != (d + 1))) ? 1.f : 0.f;
+    const float zn = 1.f - alpha, zp = alpha;
+    const float x = logits[i];
+    const float p = 1.f / (1.f + expf(-x));
+    const float term1 = powf(1.f - p, gamma) * (1.f - p - (p * gamma * logf(fmaxf(p, FLT_MIN))));
+    const float xpos = (x >= 0.f) ? 1.f : 0.f;
+    const float term2 =
+        powf(p, gamma) * ((-1.f * x * xpos - logf(1.f + expf(x - 2.f * x * xpos))) * (1.f - p) * gamma - p);
+    float g = 0.f;
+    g += -c1 * term1 * zp;
+    g += -c2 * term2 * zn;
+    d_logits[i] = g * d_losses[i];
+  }
+}
+
+// ---- fused multi-tensor SGD -------------------------------------------------------------------
+// reference: torch.optim.SGD.step over solver/build.py:7-20's one-group-per-tensor list.
+// grid.y = tensor, grid.x strides over that tensor's elements.
+__global__ void sgd_kernel(const dadet_sgd_entry* __restrict__ table, float momentum, int first_step,
+                           float grad_scale) {
+  const dadet_sgd_entry e = table[blockIdx.y];
+  const int64_t n = e.numel;
+  const float lr = e.lr, wd = e.weight_decay;
+  const bool vec = ((reinterpret_cast<uintptr_t>(e.p) | reinterpret_cast<uintptr_t>(e.g) |
+                     reinterpret_cast<uintptr_t>(e.buf)) & 15) == 0;
+  const int64_t n4 = vec ? n / 4 : 0;
+  float4* p4 = reinterpret_cast<float4*>(e.p);
+  const float4* g4 = reinterpret_cast<const float4*>(e.g);
+  float4* b4 = reinterpret_cast<float4*>(e.buf);
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    float4 p = p4[i];
+    const float4 g = g4[i];
+    float4 d, b;
+    d.x = g.x * grad_scale + wd * p.x; d.y = g.y * grad_scale + wd * p.y;
+    d.z = g.z * grad_scale + wd * p.z; d.w = g.w * grad_scale + wd * p.w;
+    if (first_step) {
+      b = d;
+    } else {
+      b = b4[i];
+      b.x = momentum * b.x + d.x; b.y = momentum * b.y + d.y;
+      b.z = momentum * b.z + d.z; b.w = momentum * b.w + d.w;
+    }
+    b4[i] = b;
+    p.x -= lr * b.x; p.y -= lr * b.y; p.z -= lr * b.z; p.w -= lr * b.w;
+    p4[i] = p;
+  }
+  for (int64_t i = n4 * 4 + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    float p = e.p[i];
+    const float d = e.g[i] * grad_scale + wd * p;
+    const float b = first_step ? d : momentum * e.buf[i] + d;
+    e.buf[i] = b;
+    e.p[i] = p - lr * b;
+  }
+}
+
+}  // namespace dadet
+
+using namespace dadet;
+
+static bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+extern "C" int dadet_relu_bn_backward(const float* g, const float* y, const float* scale, float* g_out,
+                                      float* g_scaled, int64_t rows, int C, void* stream) {
+  DADET_REQUIRE(rows >= 0 && C > 0 && C % 4 == 0, "relu_bn_backward: C=%d must be a multiple of 4", C);
+  if (rows == 0) return DADET_OK;
+  DADET_REQUIRE(g && (g_out || g_scaled), "relu_bn_backward: null pointer");
+  DADET_REQUIRE(aligned16(g) && aligned16(y) && aligned16(scale) && aligned16(g_out) && aligned16(g_scaled),
+                "relu_bn_backward: pointers must be 16-byte aligned");
+  const int64_t total4 = rows * (C / 4);
+  hipLaunchKernelGGL(relu_bn_backward_kernel, dim3(stream_blocks(total4, 256)), dim3(256), 0,
+                     as_stream(stream), reinterpret_cast<const float4*>(g),
+                     reinterpret_cast<const float4*>(y), reinterpret_cast<const float4*>(scale),
+                     reinterpret_cast<float4*>(g_out), reinterpret_cast<float4*>(g_scaled), total4, C / 4);
+  return check_launch("relu_bn_backward");
+}
+
+extern "C" int dadet_colsum_workspace_bytes(int64_t rows, int C, size_t* bytes_out) {
+  DADET_REQUIRE(rows >= 0 && C > 0 && bytes_out, "colsum_workspace_bytes: bad args");
+  *bytes_out = rows == 0 ? 0 : sizeof(float) * (size_t)colsum_splits(rows, C) * C;
+  return DADET_OK;
+}
+
+extern "C" int dadet_colsum(const float* g, float* out, int64_t rows, int C, void* workspace,
+                            size_t workspace_bytes, void* stream) {
+  DADET_REQUIRE(rows >= 0 && C > 0 && out, "colsum: bad args");
+  hipStream_t st = as_stream(stream);
+  if (rows == 0) {
+    (void)hipMemsetAsync(out, 0, sizeof(float) * C, st);
+    return check_launch("colsum(empty)");
+  }
+  const int splits = colsum_splits(rows, C);
+  if (workspace_bytes < sizeof(float) * (size_t)splits * C || !workspace) {
+    set_error("colsum: workspace too small");
+    return DADET_EWORKSPACE;
+  }
+  const int64_t rps = ceil_div64(rows, splits);
+  hipLaunchKernelGGL(colsum_partial_kernel, dim3(ceil_div(C, 64), splits), dim3(256), 0, st, g,
+                     static_cast<float*>(workspace), rows, C, rps);
+  hipLaunchKernelGGL(colsum_final_kernel, dim3(ceil_div(C, 256)), dim3(256), 0, st,
+                     static_cast<const float*>(workspace), out, C, splits);
+  return check_launch("colsum");
+}
+
+extern "C" int dadet_channel_affine(const float* x, const float* scale, const float* bias, float* y,
+                                    int64_t rows, int C, int relu, void* stream) {
+  DADET_REQUIRE(rows >= 0 && C > 0 && C % 4 == 0, "channel_affine: C=%d must be a multiple of 4", C);
+  if (rows == 0) return DADET_OK;
+  DADET_REQUIRE(x && scale && bias && y, "channel_affine: null pointer");
+  DADET_REQUIRE(aligned16(x) && aligned16(scale) && aligned16(bias) && aligned16(y),
+                "channel_affine: pointers must be 16-byte aligned");
+  const int64_t total4 = rows * (C / 4);
+  hipLaunchKernelGGL(channel_affine_kernel, dim3(stream_blocks(total4, 256)), dim3(256), 0,
+                     as_stream(stream), reinterpret_cast<const float4*>(x),
+                     reinterpret_cast<const float4*>(scale), reinterpret_cast<const float4*>(bias),
+                     reinterpret_cast<float4*>(y), total4, C / 4, relu);
+  return check_launch("channel_affine");
+}
+
+extern "C" int dadet_maxpool3x3s2_forward(const float* x, float* y, int N, int H, int W, int C, int Ho,
+                                          int Wo, void* stream) {
+  DADET_REQUIRE(N >= 0 && H > 0 && W > 0 && C > 0 && C % 4 == 0, "maxpool: bad dims");
+  DADET_REQUIRE(Ho == (H + 2 - 3) / 2 + 1 && Wo == (W + 2 - 3) / 2 + 1, "maxpool: Ho/Wo mismatch");
+  if (N == 0) return DADET_OK;
+  DADET_REQUIRE(x && y && aligned16(x) && aligned16(y), "maxpool: bad pointers");
+  const int64_t total = (int64_t)N * Ho * Wo * (C / 4);
+  hipLaunchKernelGGL(maxpool3x3s2_kernel, dim3(stream_blocks(total, 256)), dim3(256), 0, as_stream(stream),
+                     reinterpret_cast<const float4*>(x), reinterpret_cast<float4*>(y), N, H, W, C / 4, Ho,
+                     Wo);
+  return check_launch("maxpool3x3s2");
+}
+
+extern "C" int dadet_avgpool_forward(const float* x, float* y, int R, int HW, int C, void* stream) {
+  DADET_REQUIRE(R >= 0 && HW > 0 && C > 0 && C % 4 == 0, "avgpool: bad dims");
+  if (R == 0) return DADET_OK;
+  DADET_REQUIRE(x && y && aligned16(x) && aligned16(y), "avgpool: bad pointers");
+  hipLaunchKernelGGL(avgpool_fwd_kernel, dim3(stream_blocks((int64_t)R * (C / 4), 256)), dim3(256), 0,
+                     as_stream(stream), reinterpret_cast<const float4*>(x), reinterpret_cast<float4*>(y), R,
+                     HW, C / 4);
+  return check_launch("avgpool_forward");
+}
+extern "C" int dadet_avgpool_backward(const float* gy, float* gx, int R, int HW, int C, void* stream) {
+  DADET_REQUIRE(R >= 0 && HW > 0 && C > 0 && C % 4 == 0, "avgpool_backward: bad dims");
+  if (R == 0) return DADET_OK;
+  DADET_REQUIRE(gy && gx && aligned16(gy) && aligned16(gx), "avgpool_backward: bad pointers");
+  hipLaunchKernelGGL(avgpool_bwd_kernel, dim3(stream_blocks((int64_t)R * HW * (C / 4), 256)), dim3(256), 0,
+                     as_stream(stream), reinterpret_cast<const float4*>(gy), reinterpret_cast<float4*>(gx),
+                     R, HW, C / 4);
+  return check_launch("avgpool_backward");
+}
+
+extern "C" int dadet_nchw3_to_nhwc4(const float* x, float* y, int N, int H, int W, void* stream) {
+  DADET_REQUIRE(N >= 0 && H > 0 && W > 0, "nchw3_to_nhwc4: bad dims");
+  if (N == 0) return DADET_OK;
+  DADET_REQUIRE(x && y && aligned16(y), "nchw3_to_nhwc4: bad pointers");
+  const int64_t HW = (int64_t)H * W;
+  hipLaunchKernelGGL(nchw3_to_nhwc4_kernel, dim3(stream_blocks((int64_t)N * HW, 256)), dim3(256), 0,
+                     as_stream(stream), x, reinterpret_cast<float4*>(y), N, HW);
+  return check_launch("nchw3_to_nhwc4");
+}
+
+extern "C" int dadet_rpn_decode_clip(const float* deltas, const float* anchors, const int64_t* topk_idx,
+                                     int K, float wx, float wy, float ww, float wh, float xform_clip,
+                                     float im_w, float im_h, float* boxes_out, void* stream) {
+  DADET_REQUIRE(K >= 0, "rpn_decode_clip: K < 0");
+  if (K == 0) return DADET_OK;
+  DADET_REQUIRE(deltas && anchors && topk_idx && boxes_out, "rpn_decode_clip: null pointer");
+  DADET_REQUIRE(aligned16(deltas) && aligned16(anchors) && aligned16(boxes_out),
+                "rpn_decode_clip: pointers must be 16-byte aligned");
+  hipLaunchKernelGGL(rpn_decode_clip_kernel, dim3(ceil_div(K, 256)), dim3(256), 0, as_stream(stream),
+                     reinterpret_cast<const float4*>(deltas), reinterpret_cast<const float4*>(anchors),
+                     topk_idx, K, wx, wy, ww, wh, xform_clip, im_w, im_h,
+                     reinterpret_cast<float4*>(boxes_out));
+  return check_launch("rpn_decode_clip");
+}
+
+extern "C" int dadet_sigmoid_focal_loss_forward(const float* logits, const int32_t* targets, float* losses,
+                                                int N, int C, float gamma, float alpha, void* stream) {
+  DADET_REQUIRE(N >= 0 && C > 0, "focal_forward: bad dims");
+  if (N == 0) return DADET_OK;
+  DADET_REQUIRE(logits && targets && losses, "focal_forward: null pointer");
+  const int64_t total = (int64_t)N * C;
+  hipLaunchKernelGGL(focal_fwd_kernel, dim3(stream_blocks(total, 256)), dim3(256), 0, as_stream(stream),
+                     logits, targets, losses, total, C, gamma, alpha);
+  return check_launch("sigmoid_focal_loss_forward");
+}
+extern "C" int dadet_sigmoid_focal_loss_backward(const float* logits, const int32_t* targets,
+                                                 const float* d_losses, float* d_logits, int N, int C,
+                                                 float gamma, float alpha, void* stream) {
+  DADET_REQUIRE(N >= 0 && C > 0, "focal_backward: bad dims");
+  if (N == 0) return DADET_OK;
+  DADET_REQUIRE(logits && targets && d_losses && d_logits, "focal_backward: null pointer");
+  const int64_t total = (int64_t)N * C;
+  hipLaunchKernelGGL(focal_bwd_kernel, dim3(stream_blocks(total, 256)), dim3(256), 0, as_stream(stream),
+                     logits, targets, d_losses, d_logits, total, C, gamma, alpha);
+  return check_launch("sigmoid_focal_loss_backward");
+}
+
+extern "C" int dadet_sgd_step(const dadet_sgd_entry* table_dev, int num_tensors, int64_t max_numel,
+                              float momentum, int first_step, float grad_scale, void* stream) {
+  DADET_REQUIRE(num_tensors >= 0 && max_numel >= 0, "sgd_step: bad args");
+  if (num_tensors == 0 || max_numel == 0) return DADET_OK;
+  DADET_REQUIRE(table_dev, "sgd_step: null table");
+  DADET_REQUIRE(num_tensors <= 65535, "sgd_step: too many tensors for one launch");
+  int bx = (int)ceil_div64(ceil_div64(max_numel, 4), 256);
+  if (bx > 64) bx = 64;  // <= 64 x num_tensors workgroups, grid-stride inside
+  hipLaunchKernelGGL(sgd_kernel, dim3(bx, num_tensors), dim3(256), 0, as_stream(stream), table_dev,
+                     momentum, first_step, grad_scale);
+  return check_launch("sgd_step");
+}

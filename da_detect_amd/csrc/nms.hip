@@ -1,0 +1,359 @@
+// Greedy NMS entirely on the device (gfx950).
+//
+// Replaces _C.nms of the reference (maskrcnn_benchmark/csrc/nms.h:10-28; CPU kernel
+// csrc/cpu/nms_cpu.cpp:6-75; CUDA kernel + host sweep csrc/cuda/nms.cu:23-131).
+//
+// Differences in HOW (results are the reference's):
+//   * ranking: one workgroup bitonic-sorts (score desc, index asc) keys in LDS (n <= 16384 fits the
+//     160 KB LDS; larger n falls back to a global-memory bitonic network), instead of ATen sort;
+//   * IoU bitmask: only the upper triangle of 64x64 tiles is computed (the reference computes all
+//     tiles and ignores half, nms.cu:27);
+//   * greedy sweep: done by one workgroup on the device, 64 boxes per step — a wavefront resolves the
+//     64x64 diagonal tile with cross-lane reads, then every lane ORs the kept rows into its own 64-bit
+//     word of the removed-set.  The reference copies the whole mask (18 MB at n=12000) to the host
+//     with a blocking cudaMemcpy and sweeps there (nms.cu:99-123);
+//   * output compaction to ascending ORIGINAL indices (nms_cpu.cpp:64 / nms.cu:127-130) by a
+//     workgroup scan, written as int64.
+// Built with -ffp-contract=off so the IoU arithmetic is the reference's (nms_cpu.cpp:50-60).
+#include "common.h"
+
+namespace dadet {
+
+constexpr int kSortLdsMax = 16384;  // keys that fit one workgroup's LDS (8 B each = 128 KB)
+
+struct Key {
+  float score;
+  int idx;
+};
+
+// true when a must come before b: score descending, index ascending (stable-sort order)
+__device__ inline bool key_before(const Key& a, const Key& b) {
+  return (a.score > b.score) || (a.score == b.score && a.idx < b.idx);
+}
+
+// ---- ranking ------------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void nms_sort_lds_kernel(const float* __restrict__ scores, int n,
+                                                            int npow2, int* __restrict__ order) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  Key* keys = reinterpret_cast<Key*>(smem);
+  for (int i = threadIdx.x; i < npow2; i += blockDim.x) {
+    Key k;
+    if (i < n) {
+      k.score = scores[i];
+      k.idx = i;
+    } else {
+      k.score = -INFINITY;
+      k.idx = 0x7fffffff;  // padding sorts last
+    }
+    keys[i] = k;
+  }
+  __syncthreads();
+  for (int size = 2; size <= npow2; size <<= 1) {
+    for (int stride = size >> 1; stride > 0; stride >>= 1) {
+      for (int t = threadIdx.x; t < (npow2 >> 1); t += blockDim.x) {
+        const int lo = 2 * t - (t & (stride - 1));
+        const int hi = lo + stride;
+        const bool ascending_block = ((lo & size) == 0);  // "before"-ordered block
+        Key a = keys[lo], b = keys[hi];
+        const bool swap = ascending_block ? key_before(b, a) : key_before(a, b);
+        if (swap) {
+          keys[lo] = b;
+          keys[hi] = a;
+        }
+      }
+      __syncthreads();
+    }
+  }
+  for (int i = threadIdx.x; i < n; i += blockDim.x) order[i] = keys[i].idx;
+}
+
+// global-memory fallback (n > 16384): one launch per (size, stride) step
+__global__ void nms_sort_init_kernel(const float* __restrict__ scores, int n, int npow2,
+                                     Key* __restrict__ keys) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= npow2) return;
+  Key k;
+  if (i < n) {
+    k.score = scores[i];
+    k.idx = i;
+  } else {
+    k.score = -INFINITY;
+    k.idx = 0x7fffffff;
+  }
+  keys[i] = k;
+}
+__global__ void nms_sort_step_kernel(Key* __restrict__ keys, int npow2, int size, int stride) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= (npow2 >> 1)) return;
+  const int lo = 2 * t - (t & (stride - 1));
+  const int hi = lo + stride;
+  const bool ascending_block = ((lo & size) == 0);
+  Key a = keys[lo], b = keys[hi];
+  const bool swap = ascending_block ? key_before(b, a) : key_before(a, b);
+  if (swap) {
+    keys[lo] = b;
+    keys[hi] = a;
+  }
+}
+__global__ void nms_sort_finish_kernel(const Key* __restrict__ keys, int n, int* __restrict__ order) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) order[i] = keys[i].idx;
+}
+
+__global__ void nms_gather_boxes_kernel(const float4* __restrict__ boxes, const int* __restrict__ order,
+                                        int n, float4* __restrict__ sorted) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) sorted[i] = boxes[order[i]];
+}
+
+// ---- IoU bitmask, upper triangle of 64x64 tiles ----------------------------------------------
+// IoU exactly as nms_cpu.cpp:23,50-59: area = (x2-x1+1)*(y2-y1+1); inter = max(0,xx2-xx1+1)*max(0,yy2-yy1+1);
+// ovr = inter / (area_i + area_j - inter).
+template <int TIE_RULE>
+__global__ __launch_bounds__(64) void nms_mask_kernel(const float4* __restrict__ sorted, int n,
+                                                      float thresh, int col_blocks,
+                                                      unsigned long long* __restrict__ mask) {
+  // linear block id -> (row_block <= col_block) pair
+  const int row_start = blockIdx.y, col_start = blockIdx.x;
+  if (col_start < row_start) return;
+  const int row_size = min(n - row_start * 64, 64);
+  const int col_size = min(n - col_start * 64, 64);
+  __shared__ float4 cb[64];
+  __shared__ float carea[64];
+  if ((int)threadIdx.x < col_size) {
+    const float4 b = sorted[col_start * 64 + threadIdx.x];
+    cb[threadIdx.x] = b;
+    carea[threadIdx.x] = (b.z - b.x + 1.f) * (b.w - b.y + 1.f);
+  }
+  __syncthreads();
+  if ((int)threadIdx.x < row_size) {
+    const int cur = row_start * 64 + threadIdx.x;
+    const float4 a = sorted[cur];
+    const float iarea = (a.z - a.x + 1.f) * (a.w - a.y + 1.f);
+    unsigned long long t = 0;
+    const int start = (row_start == col_start) ? (int)threadIdx.x + 1 : 0;
+    for (int i = start; i < col_size; ++i) {
+      const float4 b = cb[i];
+      const float xx1 = fmaxf(a.x, b.x), yy1 = fmaxf(a.y, b.y);
+      const float xx2 = fminf(a.z, b.z), yy2 = fminf(a.w, b.w);
+      const float w = fmaxf(0.f, xx2 - xx1 + 1.f), h = fmaxf(0.f, yy2 - yy1 + 1.f);
+      const float inter = w * h;
+      const float ovr = inter / (iarea + carea[i] - inter);
+      const bool sup = (TIE_RULE == 0) ? (ovr >= thresh) : (ovr > thresh);
+      if (sup) t |= 1ULL << i;
+    }
+    mask[(size_t)cur * col_blocks + col_start] = t;
+  }
+}
+
+// ---- greedy sweep, one workgroup ------------------------------------------------------------
+// thread w owns word w of the removed-set.  Per 64-box chunk c: wave 0 resolves the diagonal tile
+// serially in registers (cross-lane reads), publishes the chunk's keep bits through LDS, then every
+// thread w > c ORs the kept rows' word w.
+__global__ __launch_bounds__(1024) void nms_sweep_kernel(const unsigned long long* __restrict__ mask,
+                                                         int n, int col_blocks, int max_keep,
+                                                         unsigned long long* __restrict__ keep_bits) {
+  __shared__ unsigned long long s_removed_c;  // removed word of the current chunk
+  __shared__ unsigned long long s_keep;       // keep bits of the current chunk
+  __shared__ int s_kept_total;
+  const int w = threadIdx.x;
+  unsigned long long removed = 0;  // word w of the removed set (valid for w < col_blocks)
+  if (threadIdx.x == 0) s_kept_total = 0;
+  __syncthreads();
+  for (int c = 0; c < col_blocks; ++c) {
+    if (w == c) s_removed_c = removed;
+    __syncthreads();
+    if (threadIdx.x < 64) {
+      const int lane = threadIdx.x;
+      const int box = c * 64 + lane;
+      unsigned long long diag = 0;
+      if (box < n) diag = mask[(size_t)box * col_blocks + c];
+      const unsigned lo = (unsigned)diag, hi = (unsigned)(diag >> 32);
+      unsigned long long rem = s_removed_c;
+      unsigned long long keep = 0;
+      const int limit = min(64, n - c * 64);
+      int kept_total = s_kept_total;
+      for (int j = 0; j < limit; ++j) {
+        if (!((rem >> j) & 1ULL)) {
+          if (max_keep > 0 && kept_total >= max_keep) break;
+          keep |= 1ULL << j;
+          ++kept_total;
+          const unsigned dlo = __shfl(lo, j, 64), dhi = __shfl(hi, j, 64);
+          rem |= ((unsigned long long)dhi << 32) | dlo;
+        }
+      }
+      if (lane == 0) {
+        s_keep = keep;
+        s_kept_total = kept_total;
+        keep_bits[c] = keep;
+      }
+    }
+    __syncthreads();
+    const unsigned long long keep = s_keep;
+    if (w > c && w < col_blocks) {
+      // the keep word is wavefront-uniform: peel four kept rows per step so four independent
+      // loads are in flight instead of one dependent round trip per kept box
+      unsigned long long k = keep;
+      const unsigned long long* mrow = mask + (size_t)c * 64 * col_blocks + w;
+      while (k) {
+        int j[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          j[u] = k ? (__ffsll((long long)k) - 1) : -1;
+          k &= (k - 1);
+        }
+        unsigned long long v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) v[u] = (j[u] >= 0) ? mrow[(size_t)j[u] * col_blocks] : 0ULL;
+        removed |= (v[0] | v[1]) | (v[2] | v[3]);
+      }
+    }
+    // early out once the quota is filled: later chunks keep nothing
+    if (max_keep > 0 && s_kept_total >= max_keep) {
+      for (int cc = c + 1 + (int)threadIdx.x; cc < col_blocks; cc += blockDim.x) keep_bits[cc] = 0;
+      break;
+    }
+    __syncthreads();
+  }
+}
+
+// ---- compaction to ascending original indices ----------------------------------------------
+__global__ void nms_flag_kernel(const unsigned long long* __restrict__ keep_bits,
+                                const int* __restrict__ order, int n, unsigned char* __restrict__ flag) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;  // sorted position
+  if (i >= n) return;
+  const bool kept = (keep_bits[i >> 6] >> (i & 63)) & 1ULL;
+  flag[order[i]] = kept ? 1 : 0;
+}
+
+__global__ __launch_bounds__(1024) void nms_compact_kernel(const unsigned char* __restrict__ flag, int n,
+                                                           int64_t* __restrict__ keep_out,
+                                                           int* __restrict__ num_out) {
+  __shared__ int wave_sums[16];
+  __shared__ int s_base;
+  if (threadIdx.x == 0) s_base = 0;
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int start = 0; start < n; start += blockDim.x) {
+    const int i = start + threadIdx.x;
+    const int f = (i < n) ? (int)flag[i] : 0;
+    const unsigned long long ballot = __ballot(f);
+    const int prefix = __popcll(ballot & ((1ULL << lane) - 1ULL));
+    if (lane == 0) wave_sums[wave] = __popcll(ballot);
+    __syncthreads();
+    int wave_off = 0, total = 0;
+    for (int k = 0; k < (int)(blockDim.x >> 6); ++k) {
+      const int s = wave_sums[k];
+      if (k < wave) wave_off += s;
+      total += s;
+    }
+    const int base = s_base;
+    if (f) keep_out[base + wave_off + prefix] = (int64_t)i;
+    __syncthreads();
+    if (threadIdx.x == 0) s_base = base + total;
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) *num_out = s_base;
+}
+
+static int next_pow2(int n) {
+  int p = 1;
+  while (p < n) p <<= 1;
+  return p;
+}
+
+struct NmsWorkspace {
+  size_t order_off, sorted_off, mask_off, keepbits_off, flag_off, keys_off, total;
+};
+
+static NmsWorkspace nms_layout(int n) {
+  NmsWorkspace ws;
+  auto align = [](size_t x) { return (x + 255) & ~(size_t)255; };
+  const int col_blocks = ceil_div(n, 64);
+  size_t off = 0;
+  ws.order_off = off;    off = align(off + sizeof(int) * (size_t)n);
+  ws.sorted_off = off;   off = align(off + sizeof(float4) * (size_t)n);
+  ws.mask_off = off;     off = align(off + sizeof(unsigned long long) * (size_t)n * col_blocks);
+  ws.keepbits_off = off; off = align(off + sizeof(unsigned long long) * (size_t)col_blocks);
+  ws.flag_off = off;     off = align(off + (size_t)n);
+  ws.keys_off = off;
+  const int p2 = next_pow2(n);
+  if (p2 > kSortLdsMax) off = align(off + sizeof(Key) * (size_t)p2);
+  ws.total = off;
+  return ws;
+}
+
+}  // namespace dadet
+
+using namespace dadet;
+
+extern "C" int dadet_nms_workspace_bytes(int n, size_t* bytes_out) {
+  DADET_REQUIRE(n >= 0 && bytes_out, "nms_workspace_bytes: bad args");
+  *bytes_out = n == 0 ? 0 : nms_layout(n).total;
+  return DADET_OK;
+}
+
+extern "C" int dadet_nms(const float* boxes_xyxy, const float* scores, int n, float thresh, int tie_rule,
+                         int max_keep, void* workspace, size_t workspace_bytes, int64_t* keep_out,
+                         int* num_keep_out, void* stream) {
+  DADET_REQUIRE(n >= 0, "nms: n < 0");
+  DADET_REQUIRE(num_keep_out, "nms: num_keep_out is null");
+  hipStream_t st = as_stream(stream);
+  if (n == 0) {
+    (void)hipMemsetAsync(num_keep_out, 0, sizeof(int), st);
+    return check_launch("nms(empty)");
+  }
+  DADET_REQUIRE(boxes_xyxy && scores && keep_out && workspace, "nms: null pointer");
+  DADET_REQUIRE(tie_rule == 0 || tie_rule == 1, "nms: tie_rule must be 0 (>=) or 1 (>)");
+  DADET_REQUIRE((reinterpret_cast<uintptr_t>(boxes_xyxy) & 15) == 0, "nms: boxes must be 16-byte aligned");
+  const int col_blocks = ceil_div(n, 64);
+  DADET_REQUIRE(col_blocks <= 1024, "nms: n=%d exceeds the single-workgroup sweep limit (65536)", n);
+  const NmsWorkspace ws = nms_layout(n);
+  if (workspace_bytes < ws.total) {
+    set_error("nms: workspace %zu < required %zu", workspace_bytes, ws.total);
+    return DADET_EWORKSPACE;
+  }
+  char* base = static_cast<char*>(workspace);
+  int* order = reinterpret_cast<int*>(base + ws.order_off);
+  float4* sorted = reinterpret_cast<float4*>(base + ws.sorted_off);
+  unsigned long long* mask = reinterpret_cast<unsigned long long*>(base + ws.mask_off);
+  unsigned long long* keep_bits = reinterpret_cast<unsigned long long*>(base + ws.keepbits_off);
+  unsigned char* flag = reinterpret_cast<unsigned char*>(base + ws.flag_off);
+
+  const int p2 = next_pow2(n);
+  if (p2 <= kSortLdsMax) {
+    const int threads = p2 / 2 >= 1024 ? 1024 : (p2 / 2 < 64 ? 64 : p2 / 2);
+    const size_t lds = sizeof(Key) * (size_t)p2;
+    if (lds > 48 * 1024) {
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(nms_sort_lds_kernel),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      if (e != hipSuccess) {
+        set_error("nms: hipFuncSetAttribute(%zu B LDS): %s", lds, hipGetErrorString(e));
+        return DADET_ELAUNCH;
+      }
+    }
+    hipLaunchKernelGGL(nms_sort_lds_kernel, dim3(1), dim3(threads), lds, st, scores, n, p2, order);
+  } else {
+    Key* keys = reinterpret_cast<Key*>(base + ws.keys_off);
+    hipLaunchKernelGGL(nms_sort_init_kernel, dim3(ceil_div(p2, 256)), dim3(256), 0, st, scores, n, p2,
+                       keys);
+    for (int size = 2; size <= p2; size <<= 1)
+      for (int stride = size >> 1; stride > 0; stride >>= 1)
+        hipLaunchKernelGGL(nms_sort_step_kernel, dim3(ceil_div(p2 / 2, 256)), dim3(256), 0, st, keys, p2,
+                           size, stride);
+    hipLaunchKernelGGL(nms_sort_finish_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, st, keys, n, order);
+  }
+  hipLaunchKernelGGL(nms_gather_boxes_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, st,
+                     reinterpret_cast<const float4*>(boxes_xyxy), order, n, sorted);
+  const dim3 mgrid(col_blocks, col_blocks);
+  if (tie_rule == 0)
+    hipLaunchKernelGGL(nms_mask_kernel<0>, mgrid, dim3(64), 0, st, sorted, n, thresh, col_blocks, mask);
+  else
+    hipLaunchKernelGGL(nms_mask_kernel<1>, mgrid, dim3(64), 0, st, sorted, n, thresh, col_blocks, mask);
+  const int sweep_threads = col_blocks <= 64 ? 64 : ((col_blocks + 63) / 64) * 64;
+  hipLaunchKernelGGL(nms_sweep_kernel, dim3(1), dim3(sweep_threads), 0, st, mask, n, col_blocks, max_keep,
+                     keep_bits);
+  hipLaunchKernelGGL(nms_flag_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, st, keep_bits, order, n, flag);
+  hipLaunchKernelGGL(nms_compact_kernel, dim3(1), dim3(1024), 0, st, flag, n, keep_out, num_keep_out);
+  return check_launch("nms");
+}

@@ -1,0 +1,242 @@
+// ROIAlign forward / backward for NHWC fp32 feature maps on gfx950.
+//
+// Replaces _C.roi_align_forward / _C.roi_align_backward of the reference
+// (maskrcnn_benchmark/csrc/ROIAlign.h:11-45; kernels csrc/cpu/ROIAlign_cpu.cpp:18-219 and
+// csrc/cuda/ROIAlign_cuda.cu:16-254).  The reference maps one thread to one (n,c,ph,pw) output element
+// of an NCHW tensor, so the four bilinear taps of a wavefront are scattered 4-byte reads.  Here the map
+// is NHWC: one workgroup owns one (roi, ph) row of bins, its lanes run along the CHANNEL axis with
+// 16-byte accesses, so every bilinear tap is one fully coalesced C*4-byte row and the per-sample
+// coordinate/weight math is computed once per sample instead of once per output element.
+//
+// Numerics: the sample coordinates, weights and the accumulation are evaluated in exactly the
+// reference's operation order (ROIAlign_cpu.cpp:34-104,198-209) and this translation unit is built with
+// -ffp-contract=off, so the forward is bit-comparable with the reference CPU kernel.
+#include "common.h"
+
+namespace dadet {
+
+struct RoiGeom {
+  int batch;
+  float start_w, start_h, bin_w, bin_h;
+  int grid_h, grid_w;
+  float count;
+};
+
+// reference: ROIAlign_cpu.cpp:140-172 / ROIAlign_cuda.cu:78-104
+__device__ inline RoiGeom roi_geometry(const float* __restrict__ roi, float scale, int pooled_h,
+                                       int pooled_w, int sampling_ratio) {
+  RoiGeom g;
+  g.batch = (int)roi[0];
+  g.start_w = roi[1] * scale;
+  g.start_h = roi[2] * scale;
+  const float end_w = roi[3] * scale;
+  const float end_h = roi[4] * scale;
+  const float roi_w = fmaxf(end_w - g.start_w, 1.f);
+  const float roi_h = fmaxf(end_h - g.start_h, 1.f);
+  g.bin_h = roi_h / (float)pooled_h;
+  g.bin_w = roi_w / (float)pooled_w;
+  g.grid_h = (sampling_ratio > 0) ? sampling_ratio : (int)ceilf(roi_h / (float)pooled_h);
+  g.grid_w = (sampling_ratio > 0) ? sampling_ratio : (int)ceilf(roi_w / (float)pooled_w);
+  g.count = (float)(g.grid_h * g.grid_w);
+  return g;
+}
+
+struct Tap {
+  int p1, p2, p3, p4;  // pixel indices y*W+x of the four neighbours, -1 when the sample is skipped
+  float w1, w2, w3, w4;
+};
+
+// reference: ROIAlign_cpu.cpp:46-104 (pre_calc_for_bilinear_interpolate) / ROIAlign_cuda.cu:16-62
+__device__ inline Tap bilinear_tap(float y, float x, int H, int W) {
+  Tap t;
+  if (y < -1.0f || y > (float)H || x < -1.0f || x > (float)W) {
+    t.p1 = t.p2 = t.p3 = t.p4 = -1;
+    t.w1 = t.w2 = t.w3 = t.w4 = 0.f;
+    return t;
+  }
+  if (y <= 0.f) y = 0.f;
+  if (x <= 0.f) x = 0.f;
+  int y_low = (int)y, x_low = (int)x, y_high, x_high;
+  if (y_low >= H - 1) {
+    y_high = y_low = H - 1;
+    y = (float)y_low;
+  } else {
+    y_high = y_low + 1;
+  }
+  if (x_low >= W - 1) {
+    x_high = x_low = W - 1;
+    x = (float)x_low;
+  } else {
+    x_high = x_low + 1;
+  }
+  const float ly = y - (float)y_low, lx = x - (float)x_low;
+  const float hy = 1.f - ly, hx = 1.f - lx;
+  t.w1 = hy * hx;
+  t.w2 = hy * lx;
+  t.w3 = ly * hx;
+  t.w4 = ly * lx;
+  t.p1 = y_low * W + x_low;
+  t.p2 = y_low * W + x_high;
+  t.p3 = y_high * W + x_low;
+  t.p4 = y_high * W + x_high;
+  return t;
+}
+
+__device__ inline float sample_coord(float start, int p, float bin, int i, int grid) {
+  // roi_start + p*bin + (i + .5f) * bin / grid        (ROIAlign_cpu.cpp:34-41)
+  return start + (float)p * bin + ((float)i + .5f) * bin / (float)grid;
+}
+
+// one workgroup per (roi, ph); lanes stride over channel quads; loop over pw.
+template <int VEC>
+__global__ __launch_bounds__(256) void roi_align_fwd_kernel(
+    const float* __restrict__ input, const float* __restrict__ rois, float* __restrict__ output, int C,
+    int H, int W, int pooled_h, int pooled_w, float scale, int sampling_ratio) {
+  const int r = blockIdx.x / pooled_h;
+  const int ph = blockIdx.x % pooled_h;
+  const RoiGeom g = roi_geometry(rois + (size_t)r * 5, scale, pooled_h, pooled_w, sampling_ratio);
+  const float* __restrict__ img = input + (size_t)g.batch * H * W * C;
+  float* __restrict__ out_row = output + ((size_t)r * pooled_h + ph) * pooled_w * C;
+
+  for (int c = threadIdx.x * VEC; c < C; c += blockDim.x * VEC) {
+    for (int pw = 0; pw < pooled_w; ++pw) {
+      float acc[VEC];
+#pragma unroll
+      for (int v = 0; v < VEC; ++v) acc[v] = 0.f;
+      for (int iy = 0; iy < g.grid_h; ++iy) {
+        const float y = sample_coord(g.start_h, ph, g.bin_h, iy, g.grid_h);
+        for (int ix = 0; ix < g.grid_w; ++ix) {
+          const float x = sample_coord(g.start_w, pw, g.bin_w, ix, g.grid_w);
+          const Tap t = bilinear_tap(y, x, H, W);
+          if (t.p1 < 0) continue;  // contributes exactly +0 in the reference
+          float v1[VEC], v2[VEC], v3[VEC], v4[VEC];
+          if constexpr (VEC == 4) {
+            const float4 a = *reinterpret_cast<const float4*>(img + (size_t)t.p1 * C + c);
+            const float4 b = *reinterpret_cast<const float4*>(img + (size_t)t.p2 * C + c);
+            const float4 d = *reinterpret_cast<const float4*>(img + (size_t)t.p3 * C + c);
+            const float4 e = *reinterpret_cast<const float4*>(img + (size_t)t.p4 * C + c);
+            v1[0] = a.x; v1[1] = a.y; v1[2] = a.z; v1[3] = a.w;
+            v2[0] = b.x; v2[1] = b.y; v2[2] = b.z; v2[3] = b.w;
+            v3[0] = d.x; v3[1] = d.y; v3[2] = d.z; v3[3] = d.w;
+            v4[0] = e.x; v4[1] = e.y; v4[2] = e.z; v4[3] = e.w;
+          } else {
+            v1[0] = img[(size_t)t.p1 * C + c];
+            v2[0] = img[(size_t)t.p2 * C + c];
+            v3[0] = img[(size_t)t.p3 * C + c];
+            v4[0] = img[(size_t)t.p4 * C + c];
+          }
+#pragma unroll
+          for (int v = 0; v < VEC; ++v) {
+            // output_val += w1*d1 + w2*d2 + w3*d3 + w4*d4   (ROIAlign_cpu.cpp:201-204)
+            const float s = ((t.w1 * v1[v] + t.w2 * v2[v]) + t.w3 * v3[v]) + t.w4 * v4[v];
+            acc[v] = acc[v] + s;
+          }
+        }
+      }
+      if constexpr (VEC == 4) {
+        float4 o;
+        o.x = acc[0] / g.count; o.y = acc[1] / g.count; o.z = acc[2] / g.count; o.w = acc[3] / g.count;
+        *reinterpret_cast<float4*>(out_row + (size_t)pw * C + c) = o;
+      } else {
+        out_row[(size_t)pw * C + c] = acc[0] / g.count;
+      }
+    }
+  }
+}
+
+// backward: scatter g * w / count to the four neighbours with hardware fp32 atomics
+// (reference: ROIAlign_cuda.cu:178-254; g1 = top_diff * w1 / count at :236-239).
+template <int VEC>
+__global__ __launch_bounds__(256) void roi_align_bwd_kernel(
+    const float* __restrict__ grad_out, const float* __restrict__ rois, float* __restrict__ grad_in,
+    int C, int H, int W, int pooled_h, int pooled_w, float scale, int sampling_ratio) {
+  const int r = blockIdx.x / pooled_h;
+  const int ph = blockIdx.x % pooled_h;
+  const RoiGeom g = roi_geometry(rois + (size_t)r * 5, scale, pooled_h, pooled_w, sampling_ratio);
+  float* __restrict__ img = grad_in + (size_t)g.batch * H * W * C;
+  const float* __restrict__ go_row = grad_out + ((size_t)r * pooled_h + ph) * pooled_w * C;
+
+  for (int c = threadIdx.x * VEC; c < C; c += blockDim.x * VEC) {
+    for (int pw = 0; pw < pooled_w; ++pw) {
+      float go[VEC];
+      if constexpr (VEC == 4) {
+        const float4 q = *reinterpret_cast<const float4*>(go_row + (size_t)pw * C + c);
+        go[0] = q.x; go[1] = q.y; go[2] = q.z; go[3] = q.w;
+      } else {
+        go[0] = go_row[(size_t)pw * C + c];
+      }
+      for (int iy = 0; iy < g.grid_h; ++iy) {
+        const float y = sample_coord(g.start_h, ph, g.bin_h, iy, g.grid_h);
+        for (int ix = 0; ix < g.grid_w; ++ix) {
+          const float x = sample_coord(g.start_w, pw, g.bin_w, ix, g.grid_w);
+          const Tap t = bilinear_tap(y, x, H, W);
+          if (t.p1 < 0) continue;
+          float* q1 = img + (size_t)t.p1 * C + c;
+          float* q2 = img + (size_t)t.p2 * C + c;
+          float* q3 = img + (size_t)t.p3 * C + c;
+          float* q4 = img + (size_t)t.p4 * C + c;
+#pragma unroll
+          for (int v = 0; v < VEC; ++v) {
+            unsafeAtomicAdd(q1 + v, go[v] * t.w1 / g.count);
+            unsafeAtomicAdd(q2 + v, go[v] * t.w2 / g.count);
+            unsafeAtomicAdd(q3 + v, go[v] * t.w3 / g.count);
+            unsafeAtomicAdd(q4 + v, go[v] * t.w4 / g.count);
+          }
+        }
+      }
+    }
+  }
+}
+
+}  // namespace dadet
+
+using namespace dadet;
+
+static int roi_args_ok(const void* a, const void* b, const void* c, int B, int C, int H, int W, int R,
+                       int ph, int pw) {
+  DADET_REQUIRE(B > 0 && C > 0 && H > 0 && W > 0 && R >= 0 && ph > 0 && pw > 0,
+                "roi_align: bad dims B=%d C=%d H=%d W=%d R=%d ph=%d pw=%d", B, C, H, W, R, ph, pw);
+  if (R > 0) DADET_REQUIRE(a && b && c, "roi_align: null pointer");
+  return DADET_OK;
+}
+
+extern "C" int dadet_roi_align_forward(const float* input, const float* rois, float* output, int B,
+                                       int C, int H, int W, int R, int pooled_h, int pooled_w,
+                                       float spatial_scale, int sampling_ratio, void* stream) {
+  int rc = roi_args_ok(input, rois, output, B, C, H, W, R, pooled_h, pooled_w);
+  if (rc) return rc;
+  if (R == 0) return DADET_OK;
+  const dim3 grid((unsigned)(R * pooled_h));
+  const bool vec = (C % 4 == 0) && ((reinterpret_cast<uintptr_t>(input) & 15) == 0) &&
+                   ((reinterpret_cast<uintptr_t>(output) & 15) == 0);
+  if (vec) {
+    const int threads = (C / 4 >= 256) ? 256 : ((C / 4 + 63) / 64) * 64;
+    hipLaunchKernelGGL(roi_align_fwd_kernel<4>, grid, dim3(threads), 0, as_stream(stream), input, rois,
+                       output, C, H, W, pooled_h, pooled_w, spatial_scale, sampling_ratio);
+  } else {
+    const int threads = (C >= 256) ? 256 : ((C + 63) / 64) * 64;
+    hipLaunchKernelGGL(roi_align_fwd_kernel<1>, grid, dim3(threads), 0, as_stream(stream), input, rois,
+                       output, C, H, W, pooled_h, pooled_w, spatial_scale, sampling_ratio);
+  }
+  return check_launch("roi_align_forward");
+}
+
+extern "C" int dadet_roi_align_backward(const float* grad_output, const float* rois, float* grad_input,
+                                        int B, int C, int H, int W, int R, int pooled_h, int pooled_w,
+                                        float spatial_scale, int sampling_ratio, void* stream) {
+  int rc = roi_args_ok(grad_output, rois, grad_input, B, C, H, W, R, pooled_h, pooled_w);
+  if (rc) return rc;
+  if (R == 0) return DADET_OK;
+  const dim3 grid((unsigned)(R * pooled_h));
+  const bool vec = (C % 4 == 0) && ((reinterpret_cast<uintptr_t>(grad_output) & 15) == 0);
+  if (vec) {
+    const int threads = (C / 4 >= 256) ? 256 : ((C / 4 + 63) / 64) * 64;
+    hipLaunchKernelGGL(roi_align_bwd_kernel<4>, grid, dim3(threads), 0, as_stream(stream), grad_output,
+                       rois, grad_input, C, H, W, pooled_h, pooled_w, spatial_scale, sampling_ratio);
+  } else {
+    const int threads = (C >= 256) ? 256 : ((C + 63) / 64) * 64;
+    hipLaunchKernelGGL(roi_align_bwd_kernel<1>, grid, dim3(threads), 0, as_stream(stream), grad_output,
+                       rois, grad_input, C, H, W, pooled_h, pooled_w, spatial_scale, sampling_ratio);
+  }
+  return check_launch("roi_align_backward");
+}

@@ -1,0 +1,219 @@
+/*
+ * dadet.h — C-ABI of libdadet_hip.so, the MI355X (gfx950) native operator library behind the
+ * domain-adaptive Faster R-CNN training hot path.
+ *
+ * This header is the drop-in boundary.  Every entry point replaces one function of the
+ * reference's native extension `maskrcnn_benchmark._C` (reference: maskrcnn_benchmark/csrc/vision.cpp:7-15,
+ * vendored tree tools/cityscapes/maskrcnn_benchmark/csrc/vision.cpp:17-24) or one ATen operator the
+ * reference's Python hot path calls (conv / linear / pooling / SGD), as cited per function.
+ *
+ * Conventions
+ *   - plain pointers + sizes, no framework types; all pointers are DEVICE pointers unless the
+ *     argument name ends in `_host`;
+ *   - the caller owns and allocates every buffer (outputs, scratch); scratch sizes come from the
+ *     matching `*_workspace_bytes` query;
+ *   - `stream` is a hipStream_t passed as void*; every kernel is launched on it, nothing
+ *     synchronises the device (the reference's nms does a blocking D2H copy, csrc/cuda/nms.cu:99-103;
+ *     this one does not);
+ *   - activations are fp32 NHWC ("channels_last" physical order: [N][H][W][C]); convolution
+ *     weights are fp32 [Cout][KH][KW][Cin] (K contiguous).  The Python shim presents them with the
+ *     reference's logical NCHW / OIHW shapes via torch.channels_last strides;
+ *   - every function returns 0 on success or a negative DADET_E* code; dadet_last_error() gives a
+ *     thread-local message.  Empty inputs (n == 0 / R == 0) return 0 without launching
+ *     (reference: ROIAlign_cuda.cu:278-281, nms.h:17-18).
+ */
+#ifndef DADET_H_
+#define DADET_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DADET_OK 0
+#define DADET_EINVAL (-1)   /* bad argument (shape / alignment / null pointer) */
+#define DADET_ELAUNCH (-2)  /* hip launch / runtime error */
+#define DADET_EWORKSPACE (-3) /* workspace too small */
+#define DADET_EUNSUPPORTED (-4)
+
+const char* dadet_last_error(void);
+/* library / device probe: returns 0 and fills the fields when a gfx950 device is present. */
+int dadet_version(void);
+int dadet_device_info(int* cu_count, int* clock_khz, size_t* hbm_bytes, char* arch_name, int arch_name_len);
+
+/* ------------------------------------------------------------------------------------------------
+ * NMS — replaces `_C.nms(dets[N,4], scores[N], thr) -> int64[K]`
+ *   reference: csrc/nms.h:10-28, csrc/cpu/nms_cpu.cpp:6-75, csrc/cuda/nms.cu:23-131.
+ * Greedy NMS with the reference's "+1" pixel convention.  Boxes are ranked by (score desc, index asc)
+ * on the device, the 64x64-tiled IoU bitmask is built for the upper triangle only, and the greedy
+ * sweep runs ON THE DEVICE (no D2H of the mask).  Kept ORIGINAL indices are written ascending
+ * (reference nms_cpu.cpp:64, nms.cu:127-130).
+ *   tie_rule 0: suppress when IoU >= thr (reference CPU rule, nms_cpu.cpp:60)
+ *   tie_rule 1: suppress when IoU >  thr (reference CUDA rule, nms.cu:60)
+ *   max_keep  : <=0 = unlimited; >0 stops the sweep after that many boxes are kept (the first
+ *               max_keep in score order; equals the reference's keep[:max_proposals],
+ *               structures/boxlist_ops.py:30-31, when the input is already score-sorted as in the RPN).
+ *   keep_out  : int64[n] device; num_keep_out: int32[1] device.
+ * ----------------------------------------------------------------------------------------------*/
+int dadet_nms_workspace_bytes(int n, size_t* bytes_out);
+int dadet_nms(const float* boxes_xyxy, const float* scores, int n, float thresh, int tie_rule,
+              int max_keep, void* workspace, size_t workspace_bytes, int64_t* keep_out,
+              int* num_keep_out, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * ROIAlign — replaces `_C.roi_align_forward` / `_C.roi_align_backward`
+ *   reference: csrc/ROIAlign.h:11-45, csrc/cpu/ROIAlign_cpu.cpp:114-257, csrc/cuda/ROIAlign_cuda.cu:65-254.
+ * input  [B][H][W][C] NHWC, rois [R][5] = (batch_idx, x1, y1, x2, y2), output [R][PH][PW][C] NHWC.
+ * No coordinate rounding, ROI min size 1, adaptive grid ceil(roi/pooled) when sampling_ratio == 0,
+ * sample skipped when y < -1 || y > H || x < -1 || x > W.  Forward is evaluated in the reference's
+ * operation order with FMA contraction disabled, so it is bit-comparable with ROIAlign_cpu.cpp.
+ * Backward accumulates with hardware fp32 atomics into grad_input, which the CALLER must zero
+ * (reference zero-fills at ROIAlign_cuda.cu:316).
+ * ----------------------------------------------------------------------------------------------*/
+int dadet_roi_align_forward(const float* input, const float* rois, float* output, int B, int C, int H,
+                            int W, int R, int pooled_h, int pooled_w, float spatial_scale,
+                            int sampling_ratio, void* stream);
+int dadet_roi_align_backward(const float* grad_output, const float* rois, float* grad_input, int B,
+                             int C, int H, int W, int R, int pooled_h, int pooled_w,
+                             float spatial_scale, int sampling_ratio, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * SigmoidFocalLoss — replaces `_C.sigmoid_focalloss_forward/backward`
+ *   reference: csrc/SigmoidFocalLoss.h:10-40, csrc/cuda/SigmoidFocalLoss_cuda.cu:21-101.
+ * logits [N][C] fp32, targets [N] int32 in [0..C] (t == d+1 positive, t >= 0 && t != d+1 negative).
+ * ----------------------------------------------------------------------------------------------*/
+int dadet_sigmoid_focal_loss_forward(const float* logits, const int32_t* targets, float* losses, int N,
+                                     int C, float gamma, float alpha, void* stream);
+int dadet_sigmoid_focal_loss_backward(const float* logits, const int32_t* targets,
+                                      const float* d_losses, float* d_logits, int N, int C,
+                                      float gamma, float alpha, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Implicit-GEMM convolution on fp32 MFMA (v_mfma_f32_32x32x2_f32) with fused epilogue.
+ * Replaces the ATen conv2d + FrozenBatchNorm2d + relu_ (+ residual add) chains of
+ *   reference: modeling/backbone/resnet.py:294-336 (Bottleneck / BaseStem), layers/batch_norm.py:19-24,
+ *   modeling/rpn/rpn.py:39-46 (RPNHead), modeling/da_heads/da_heads.py:32-37 (DAImgHead) and the
+ *   nn.Linear layers of da_heads.py:61-68 / roi_box_predictors.py:28-33 (as 1x1 convs on [R,1,1,C]).
+ *
+ *   y[n, ho*os, wo*os, co] = act( (sum_{r,s,ci} x[n, ho*stride-pad+r, wo*stride-pad+s, ci] * w[co,r,s,ci])
+ *                                  * scale[co] + bias[co] + addend[...] )
+ *   act: relu_mode 0 none | 1 max(v,0) | 2 (mask_ref[...] > 0 ? v : 0)  (backward ReLU gating)
+ * `os` (out_spatial_stride) > 1 scatters rows into a larger, caller-zeroed output [N][OutH][OutW][Cout]
+ * (dgrad of a strided 1x1 conv).  scale / bias / addend / mask_ref may be NULL.  addend may alias y.
+ * Requirements: Cin % 4 == 0, (KH*KW*Cin) % 4 == 0, 16-byte aligned x / w.
+ * ----------------------------------------------------------------------------------------------*/
+typedef struct dadet_conv_desc {
+  int N, H, W, Cin;        /* input  [N][H][W][Cin] */
+  int Cout, KH, KW;        /* weight [Cout][KH][KW][Cin] */
+  int stride, pad;         /* same in both spatial dims; dilation 1 */
+  int Ho, Wo;              /* GEMM rows: M = N*Ho*Wo */
+  int OutH, OutW;          /* physical output spatial dims (== Ho,Wo unless out_spatial_stride > 1) */
+  int out_spatial_stride;  /* 1, or s for scatter */
+  int relu_mode;           /* 0 | 1 | 2 */
+} dadet_conv_desc;
+
+int dadet_conv_forward(const dadet_conv_desc* d, const float* x, const float* w, const float* scale,
+                       const float* bias, const float* addend, const float* mask_ref, float* y,
+                       void* stream);
+
+/* weight gradient: dw[co][r][s][ci] = out_scale[co] * sum_m gy[m][co] * x[gather(m, r, s)][ci]
+ * (+ dw_prev when accumulate != 0).  Deterministic split-K over m through `workspace`
+ * (query with dadet_conv_wgrad_workspace_bytes).  gy is [N][Ho][Wo][Cout] dense. */
+int dadet_conv_wgrad_workspace_bytes(const dadet_conv_desc* d, size_t* bytes_out);
+int dadet_conv_wgrad(const dadet_conv_desc* d, const float* x, const float* gy, const float* out_scale,
+                     float* dw, int accumulate, void* workspace, size_t workspace_bytes, void* stream);
+
+/* weight re-layout for the data gradient: wt[ci][KH-1-r][KW-1-s][co] = w[co][r][s][ci] * scale[co].
+ * dgrad of a stride-1 conv is then dadet_conv_forward(gy, wt) with pad' = K-1-pad. */
+int dadet_conv_weight_transpose(const float* w, const float* scale, float* wt, int Cout, int KH, int KW,
+                                int Cin, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Elementwise / reduction helpers of the same path (all NHWC fp32).
+ * ----------------------------------------------------------------------------------------------*/
+/* g_out[m][c] = (y[m][c] > 0 ? g[m][c] : 0) ; g_scaled[m][c] = g_out * scale[c].  Either output may be
+ * NULL; scale may be NULL (=1).  Outputs may alias g.   (ReLU + FrozenBN backward, batch_norm.py:19-24) */
+int dadet_relu_bn_backward(const float* g, const float* y, const float* scale, float* g_out,
+                           float* g_scaled, int64_t rows, int C, void* stream);
+/* out[c] = sum_m g[m][c]  (bias gradient); workspace >= dadet_colsum_workspace_bytes */
+int dadet_colsum_workspace_bytes(int64_t rows, int C, size_t* bytes_out);
+int dadet_colsum(const float* g, float* out, int64_t rows, int C, void* workspace, size_t workspace_bytes,
+                 void* stream);
+/* y = x * scale[c] + bias[c]  (standalone FrozenBatchNorm2d, layers/batch_norm.py:19-24) */
+int dadet_channel_affine(const float* x, const float* scale, const float* bias, float* y, int64_t rows,
+                         int C, int relu, void* stream);
+/* 3x3 stride-2 pad-1 max pool, NHWC (BaseStem, resnet.py:335); forward only (stem is frozen). */
+int dadet_maxpool3x3s2_forward(const float* x, float* y, int N, int H, int W, int C, int Ho, int Wo,
+                               void* stream);
+/* global average pool over HW (nn.AvgPool2d(7) on 7x7 maps: roi_box_predictors.py:17,29; da_heads.py:89,403) */
+int dadet_avgpool_forward(const float* x, float* y, int R, int HW, int C, void* stream);
+int dadet_avgpool_backward(const float* gy, float* gx, int R, int HW, int C, void* stream);
+/* NCHW 3-channel image -> NHWC4 zero-padded channel (stem input staging) */
+int dadet_nchw3_to_nhwc4(const float* x, float* y, int N, int H, int W, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * RPN proposal decode — replaces BoxCoder.decode + clip_to_image on the top-k anchors
+ *   reference: modeling/box_coder.py:52-95, structures/bounding_box.py:214-224,
+ *   modeling/rpn/inference.py:96-113.
+ * For k in [0,K): a = topk_idx[k]; box = decode(deltas[a], anchors[a]) clipped to [0,im_w-1]x[0,im_h-1].
+ * deltas is the RPN bbox_pred map in NHWC: [H][W][A*4] for one image => delta of anchor index
+ * a = (h*W + w)*A + aa is at deltas[a*4 .. a*4+3] (same flattening as permute_and_flatten, rpn/utils.py:10-14).
+ * ----------------------------------------------------------------------------------------------*/
+int dadet_rpn_decode_clip(const float* deltas, const float* anchors, const int64_t* topk_idx, int K,
+                          float wx, float wy, float ww, float wh, float xform_clip, float im_w,
+                          float im_h, float* boxes_out, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Fused DA heads (reference: modeling/da_heads/da_heads.py:12-68,354-440, da_heads/loss.py:55-104,140-200,
+ * layers/gradient_scalar_layer.py:4-13, layers/consistency_loss.py:3-27).
+ *
+ * Image-level domain classifier tail.  Given the hidden map t = relu(conv1_da(x)) [M][C1]
+ * (M = num_images * rows_per_image, produced by dadet_conv_forward with its bias+ReLU epilogue):
+ *   logit[m]          = sum_c t[m][c] * w2[c] + b2[0]                    (conv2_da, 1x1 -> 1 channel)
+ *   sums[img][0]     += BCE-with-logits(logit[m], labels[img])           (da_heads/loss.py:95-97)
+ *   sums[img][1]     += sigmoid(logit[m])                                (consistency_loss.py:12-14)
+ * one wavefront per row, wave-reduced, one atomic per wavefront; the caller zeroes `sums` [num_images][2].
+ * ----------------------------------------------------------------------------------------------*/
+int dadet_da_img_head_loss_forward(const float* t, const float* w2, const float* b2, const float* labels,
+                                   float* logits_out, float* sums_out, int num_images,
+                                   int rows_per_image, int C1, void* stream);
+/* backward.  coef [num_images][4] (device) = (a_bce_w, a_sig_w, a_bce_x, a_sig_x):
+ *   g_logit_w = a_bce_w*(s-y) + a_sig_w*s*(1-s)  -> parameter gradients (g_w2, g_b2, and g_t_w for conv1_da's wgrad)
+ *   g_logit_x = a_bce_x*(s-y) + a_sig_x*s*(1-s)  -> g_t_x for conv1_da's dgrad: the gradient-reversal
+ *                                                 weights (GRL -w for the BCE path, +w for the consistency
+ *                                                 path, da_heads.py:377-380) are folded into a_*_x.
+ * g_w2 [C1] and g_b2 [1] are accumulated with atomics: the caller zeroes them.  g_t_x may be NULL. */
+int dadet_da_img_head_loss_backward(const float* t, const float* w2, const float* logits,
+                                    const float* labels, const float* coef, float* g_t_w, float* g_t_x,
+                                    float* g_w2, float* g_b2, int num_images, int rows_per_image, int C1,
+                                    void* stream);
+/* Domain-level triplet loss on NHWC maps [H][W][C] (one image each): L2 distance over the W axis with
+ * eps, hinge with margin, loss_sum[0] += sum over (h,c) (the caller zeroes it and divides by H*C).
+ * dist_out [H*C][2] keeps (d_ap, d_an) for the backward; g_scale[0] = upstream grad / (H*C).
+ * reference: da_heads/loss.py:180-200 (nn.TripletMarginLoss(margin, p=2) on [1,C,H,W]). */
+int dadet_triplet_w_forward(const float* anchor, const float* positive, const float* negative, int H,
+                            int W, int C, float margin, float eps, float* dist_out, float* loss_sum,
+                            void* stream);
+int dadet_triplet_w_backward(const float* anchor, const float* positive, const float* negative,
+                             const float* dist, const float* g_scale, int H, int W, int C, float margin,
+                             float eps, float* g_anchor, float* g_positive, float* g_negative,
+                             void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Fused multi-tensor SGD with momentum — replaces torch.optim.SGD.step over one param group per tensor
+ *   reference: solver/build.py:7-20, engine/trainer.py:237-239.
+ *   d = g + wd*p ; buf = first ? d : mom*buf + d ; p -= lr*buf      (torch.optim.SGD, dampening 0)
+ * Table entries are device pointers + per-tensor scalars, packed on the device by the caller.
+ * ----------------------------------------------------------------------------------------------*/
+typedef struct dadet_sgd_entry {
+  float* p; const float* g; float* buf; int64_t numel; float lr; float weight_decay;
+} dadet_sgd_entry;
+int dadet_sgd_step(const dadet_sgd_entry* table_dev, int num_tensors, int64_t max_numel, float momentum,
+                   int first_step, float grad_scale, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DADET_H_ */

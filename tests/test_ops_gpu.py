@@ -1,0 +1,339 @@
+"""Parity of the HIP operators (through the C-ABI) against the CPU oracle / a torch fp32 reference.
+
+Bars: integer / index results bit-exact; ROIAlign forward bit-exact (same operation order, contraction off);
+atomically-accumulated and MFMA results within the fp32 tolerances stated per test.
+"""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+CL = torch.channels_last
+
+
+def _rand_boxes(rng, n, W=2048, H=1024, max_side=400):
+    xy = np.stack([rng.uniform(0, W - 2, n), rng.uniform(0, H - 2, n)], 1)
+    wh = np.stack([rng.uniform(1, max_side, n), rng.uniform(1, max_side, n)], 1)
+    b = np.concatenate([xy, np.minimum(xy + wh, [W - 1, H - 1])], 1).astype(np.float32)
+    return b
+
+
+# ------------------------------------------------------------------------------------------- NMS
+@pytest.mark.parametrize("n,thr", [(1, 0.5), (5, 0.5), (63, 0.3), (64, 0.7), (65, 0.7), (1000, 0.3),
+                                   (6000, 0.7), (12000, 0.7), (20000, 0.5)])
+@pytest.mark.parametrize("tie_rule", [0, 1])
+def test_nms_matches_oracle(device, n, thr, tie_rule):
+    from da_detect_amd import _C
+    from oracle import ops as O
+
+    rng = np.random.default_rng(n * 7 + tie_rule)
+    boxes = _rand_boxes(rng, n)
+    scores = rng.uniform(0, 1, n).astype(np.float32)
+    # duplicate scores to exercise the (score desc, index asc) tie order
+    if n > 10:
+        scores[rng.integers(0, n, n // 10)] = scores[0]
+    want = O.nms(boxes, scores, thr, tie_rule)
+    keep, count = _C.nms_with_count(torch.from_numpy(boxes).to(device), torch.from_numpy(scores).to(device),
+                                    thr, tie_rule=tie_rule)
+    got = keep[: int(count.item())].cpu().numpy()
+    assert got.dtype == np.int64
+    assert np.array_equal(got, want)
+
+
+def test_nms_exact_threshold_tie_rules(device):
+    """IoU exactly 0.5: suppressed under the CPU rule (>=), kept under the CUDA rule (>)."""
+    from da_detect_amd import _C
+
+    boxes = torch.tensor([[0, 0, 9, 9], [0, 0, 9, 19]], dtype=torch.float32, device=device)  # 100 / 200
+    scores = torch.tensor([0.9, 0.8], device=device)
+    k0, c0 = _C.nms_with_count(boxes, scores, 0.5, tie_rule=0)
+    k1, c1 = _C.nms_with_count(boxes, scores, 0.5, tie_rule=1)
+    assert k0[: int(c0)].tolist() == [0]
+    assert k1[: int(c1)].tolist() == [0, 1]
+
+
+def test_nms_max_keep_on_sorted_input(device):
+    from da_detect_amd import _C
+    from oracle import ops as O
+
+    rng = np.random.default_rng(3)
+    n = 12000
+    boxes = _rand_boxes(rng, n, max_side=150)
+    scores = np.sort(rng.uniform(0, 1, n).astype(np.float32))[::-1].copy()
+    want = O.nms(boxes, scores, 0.7, 0)[:2000]
+    keep, count = _C.nms_with_count(torch.from_numpy(boxes).to(device), torch.from_numpy(scores).to(device),
+                                    0.7, max_keep=2000, tie_rule=0)
+    got = keep[: int(count.item())].cpu().numpy()
+    assert np.array_equal(got, want)
+
+
+def test_nms_empty(device):
+    from da_detect_amd import _C
+
+    out = _C.nms(torch.zeros((0, 4), device=device), torch.zeros((0,), device=device), 0.5)
+    assert out.numel() == 0 and out.dtype == torch.int64
+
+
+# -------------------------------------------------------------------------------------- ROIAlign
+def _rois(rng, R, B, W=2048, H=1024):
+    b = _rand_boxes(rng, R, W, H, max_side=900)
+    # edge cases: degenerate, out-of-image, whole image
+    b[0] = [10, 10, 10, 10]
+    if R > 3:
+        b[1] = [-50, -30, 40, 60]
+        b[2] = [0, 0, W - 1, H - 1]
+        b[3] = [W - 5, H - 5, W + 40, H + 40]
+    idx = rng.integers(0, B, (R, 1)).astype(np.float32)
+    return np.concatenate([idx, b], 1).astype(np.float32)
+
+
+@pytest.mark.parametrize("C,H,W,R,ph,sr", [(8, 20, 32, 16, 7, 0), (64, 38, 76, 40, 14, 0),
+                                            (256, 64, 128, 64, 14, 0), (12, 25, 31, 9, 7, 2), (3, 16, 16, 5, 2, 0)])
+def test_roi_align_forward_bit_exact(device, C, H, W, R, ph, sr):
+    from da_detect_amd import _C
+    from oracle import ops as O
+
+    rng = np.random.default_rng(C + R)
+    x = rng.standard_normal((2, C, H, W)).astype(np.float32)
+    rois = _rois(rng, R, 2, W * 16, H * 16)
+    want = O.roi_align_forward(x, rois, 1 / 16.0, ph, ph, sr)
+    got = _C.roi_align_forward(torch.from_numpy(x).to(device), torch.from_numpy(rois).to(device), 1 / 16.0,
+                               ph, ph, sr)
+    assert got.shape == (R, C, ph, ph)
+    assert np.array_equal(got.cpu().numpy(), want)
+
+
+@pytest.mark.parametrize("C,H,W,R,ph,sr", [(8, 20, 32, 16, 7, 0), (64, 38, 76, 40, 14, 0), (12, 25, 31, 9, 7, 2)])
+def test_roi_align_backward(device, C, H, W, R, ph, sr):
+    from da_detect_amd import _C
+    from oracle import ops as O
+
+    rng = np.random.default_rng(C * 3 + R)
+    g = rng.standard_normal((R, C, ph, ph)).astype(np.float32)
+    rois = _rois(rng, R, 2, W * 16, H * 16)
+    want = O.roi_align_backward(g, rois, 1 / 16.0, ph, ph, 2, C, H, W, sr)
+    got = _C.roi_align_backward(torch.from_numpy(g).to(device), torch.from_numpy(rois).to(device), 1 / 16.0,
+                                ph, ph, 2, C, H, W, sr).cpu().numpy()
+    # atomics: summation order differs -> fp32 tolerance
+    np.testing.assert_allclose(got, want, rtol=1e-5, atol=1e-5)
+
+
+def test_roi_align_empty(device):
+    from da_detect_amd import _C
+
+    x = torch.zeros((1, 8, 4, 4), device=device)
+    out = _C.roi_align_forward(x, torch.zeros((0, 5), device=device), 0.25, 7, 7, 2)
+    assert out.shape == (0, 8, 7, 7)
+
+
+# --------------------------------------------------------------------------------- convolution
+def _conv_case(rng, N, Cin, H, W, Cout, k, stride, pad):
+    x = rng.standard_normal((N, Cin, H, W)).astype(np.float32)
+    w = (rng.standard_normal((Cout, Cin, k, k)) / np.sqrt(Cin * k * k)).astype(np.float32)
+    return torch.from_numpy(x), torch.from_numpy(w)
+
+
+CONV_CASES = [
+    # N, Cin, H, W, Cout, k, stride, pad
+    (2, 64, 24, 40, 64, 1, 1, 0),
+    (2, 64, 24, 40, 256, 1, 1, 0),
+    (1, 256, 30, 34, 128, 1, 2, 0),
+    (2, 128, 19, 23, 128, 3, 1, 1),
+    (1, 1024, 16, 24, 1024, 3, 1, 1),
+    (3, 512, 7, 7, 2048, 1, 1, 0),
+    (5, 1024, 14, 14, 512, 1, 2, 0),
+    (1, 1024, 9, 13, 76, 1, 1, 0),   # fused RPN cls(15)+bbox(60) padded to 76
+    (300, 2048, 1, 1, 48, 1, 1, 0),  # predictor as 1x1 conv on [R,C,1,1]
+    (2, 32, 11, 9, 40, 3, 1, 1),
+]
+
+
+@pytest.mark.parametrize("case", CONV_CASES)
+def test_conv_forward_epilogues(device, case):
+    from da_detect_amd import _C
+
+    N, Cin, H, W, Cout, k, stride, pad = case
+    rng = np.random.default_rng(sum(case))
+    x, w = _conv_case(rng, *case)
+    scale = torch.from_numpy(rng.uniform(0.5, 1.5, Cout).astype(np.float32))
+    bias = torch.from_numpy(rng.standard_normal(Cout).astype(np.float32))
+    ref = F.conv2d(x, w, None, stride, pad)
+    res = torch.from_numpy(rng.standard_normal(tuple(ref.shape)).astype(np.float32))
+    xd, wd = x.to(device).contiguous(memory_format=CL), w.to(device).contiguous(memory_format=CL)
+    tol = dict(rtol=2e-5, atol=2e-5)
+    got = _C.conv_forward(xd, wd, stride=stride, pad=pad).cpu()
+    torch.testing.assert_close(got, ref, **tol)
+    got = _C.conv_forward(xd, wd, scale.to(device), bias.to(device), stride=stride, pad=pad, relu_mode=1).cpu()
+    torch.testing.assert_close(got, F.relu(ref * scale.view(1, -1, 1, 1) + bias.view(1, -1, 1, 1)), **tol)
+    got = _C.conv_forward(xd, wd, scale.to(device), bias.to(device), addend=res.to(device), stride=stride,
+                          pad=pad, relu_mode=1).cpu()
+    torch.testing.assert_close(got, F.relu(ref * scale.view(1, -1, 1, 1) + bias.view(1, -1, 1, 1) + res), **tol)
+    got = _C.conv_forward(xd, wd, addend=res.to(device), mask_ref=res.to(device), stride=stride, pad=pad,
+                          relu_mode=2).cpu()
+    torch.testing.assert_close(got, (ref + res) * (res > 0), **tol)
+
+
+@pytest.mark.parametrize("case", CONV_CASES)
+def test_conv_dgrad_wgrad(device, case):
+    """data / weight gradients against torch autograd on the CPU (fp32)."""
+    from da_detect_amd import _C
+
+    N, Cin, H, W, Cout, k, stride, pad = case
+    rng = np.random.default_rng(sum(case) + 1)
+    x, w = _conv_case(rng, *case)
+    x.requires_grad_(True)
+    w.requires_grad_(True)
+    y = F.conv2d(x, w, None, stride, pad)
+    gy = torch.from_numpy(rng.standard_normal(tuple(y.shape)).astype(np.float32))
+    y.backward(gy)
+    scale = torch.from_numpy(rng.uniform(0.5, 1.5, Cout).astype(np.float32))
+    xd = x.detach().to(device).contiguous(memory_format=CL)
+    wd = w.detach().to(device).contiguous(memory_format=CL)
+    gyd = gy.to(device).contiguous(memory_format=CL)
+    # wgrad (with the FrozenBN scale folded in as out_scale)
+    dw = _C.conv_wgrad(xd, gyd, tuple(w.shape), stride, pad, out_scale=scale.to(device)).cpu()
+    torch.testing.assert_close(dw, w.grad * scale.view(-1, 1, 1, 1), rtol=1e-4, atol=1e-4)
+    dw2 = _C.conv_wgrad(xd, gyd, tuple(w.shape), stride, pad, dw=dw.to(device).contiguous(memory_format=CL),
+                        accumulate=True).cpu()
+    torch.testing.assert_close(dw2, dw + w.grad, rtol=1e-4, atol=1e-4)
+    # dgrad = forward kernel on gy with transposed / flipped weights
+    wt = _C.conv_weight_transpose(wd)
+    if stride == 1:
+        dx = _C.conv_forward(gyd, wt, stride=1, pad=k - 1 - pad).cpu()
+    else:
+        assert k == 1
+        dx = _C.conv_forward(gyd, wt, stride=1, pad=0, out_spatial_stride=stride, out_hw=(H, W)).cpu()
+    torch.testing.assert_close(dx, x.grad, rtol=1e-4, atol=1e-4)
+
+
+def test_stem_conv7x7_as_padded_7x8(device):
+    """BaseStem conv (3->64, 7x7, s2, p3) through NHWC4 staging and a 7x8 zero-padded kernel."""
+    from da_detect_amd import _C
+
+    rng = np.random.default_rng(11)
+    x = torch.from_numpy(rng.standard_normal((2, 3, 45, 67)).astype(np.float32))
+    w = torch.from_numpy((rng.standard_normal((64, 3, 7, 7)) / 12).astype(np.float32))
+    ref = F.max_pool2d(F.relu(F.conv2d(x, w, None, 2, 3)), 3, 2, 1)
+    x4 = _C.nchw3_to_nhwc4(x.to(device))
+    w4 = torch.zeros((64, 4, 7, 8), dtype=torch.float32)
+    w4[:, :3, :, :7] = w
+    Ho, Wo = (45 + 6 - 7) // 2 + 1, (67 + 6 - 7) // 2 + 1
+    y = _C.conv_forward(x4, w4.to(device).contiguous(memory_format=CL), stride=2, pad=3, relu_mode=1,
+                        out_size=(Ho, Wo))
+    got = _C.maxpool3x3s2(y).cpu()
+    torch.testing.assert_close(got, ref, rtol=2e-5, atol=2e-5)
+
+
+# --------------------------------------------------------------------------- elementwise helpers
+def test_relu_bn_backward_colsum_avgpool(device):
+    from da_detect_amd import _C
+
+    rng = np.random.default_rng(5)
+    g = torch.from_numpy(rng.standard_normal((3, 64, 9, 11)).astype(np.float32))
+    y = torch.from_numpy(rng.standard_normal((3, 64, 9, 11)).astype(np.float32))
+    scale = torch.from_numpy(rng.uniform(0.5, 2, 64).astype(np.float32))
+    gm, gs = _C.relu_bn_backward(g.to(device), y.to(device), scale.to(device), want_unscaled=True)
+    torch.testing.assert_close(gm.cpu(), g * (y > 0))
+    torch.testing.assert_close(gs.cpu(), g * (y > 0) * scale.view(1, -1, 1, 1))
+    cs = _C.colsum(g.to(device).contiguous(memory_format=CL)).cpu()
+    torch.testing.assert_close(cs, g.sum((0, 2, 3)), rtol=1e-4, atol=1e-4)
+    x = torch.from_numpy(rng.standard_normal((10, 128, 7, 7)).astype(np.float32))
+    ap = _C.avgpool_forward(x.to(device)).cpu()
+    torch.testing.assert_close(ap, F.avg_pool2d(x, 7).flatten(1), rtol=1e-5, atol=1e-6)
+    gx = _C.avgpool_backward(ap.to(device), 7, 7).cpu()
+    torch.testing.assert_close(gx, (ap / 49).view(10, 128, 1, 1).expand(10, 128, 7, 7))
+    ca = _C.channel_affine(g.to(device), scale.to(device), scale.to(device), relu=True).cpu()
+    torch.testing.assert_close(ca, F.relu(g * scale.view(1, -1, 1, 1) + scale.view(1, -1, 1, 1)))
+
+
+def test_sigmoid_focal_loss(device):
+    from da_detect_amd import _C
+    from oracle import ops as O
+
+    rng = np.random.default_rng(9)
+    logits = (rng.standard_normal((500, 80)) * 4).astype(np.float32)
+    targets = rng.integers(-1, 81, 500).astype(np.int32)
+    dl = rng.standard_normal((500, 80)).astype(np.float32)
+    want = O.sigmoid_focal_loss_forward(logits, targets, 2.0, 0.25)
+    got = _C.sigmoid_focalloss_forward(torch.from_numpy(logits).to(device), torch.from_numpy(targets).to(device),
+                                       80, 2.0, 0.25).cpu().numpy()
+    np.testing.assert_allclose(got, want, rtol=2e-5, atol=1e-6)
+    wantb = O.sigmoid_focal_loss_backward(logits, targets, dl, 2.0, 0.25)
+    gotb = _C.sigmoid_focalloss_backward(torch.from_numpy(logits).to(device), torch.from_numpy(targets).to(device),
+                                         torch.from_numpy(dl).to(device), 80, 2.0, 0.25).cpu().numpy()
+    np.testing.assert_allclose(gotb, wantb, rtol=2e-5, atol=1e-6)
+
+
+def test_rpn_decode_clip(device):
+    from da_detect_amd import _C
+    from oracle import ops as O
+
+    rng = np.random.default_rng(21)
+    A = 4000
+    anchors = _rand_boxes(rng, A, 1200, 600, 500)
+    deltas = (rng.standard_normal((A, 4)) * 0.5).astype(np.float32)
+    deltas[:5, 2:] = 9.0  # exercises the log(1000/16) clamp
+    idx = rng.permutation(A)[:1500].astype(np.int64)
+    clip = float(np.log(1000.0 / 16))
+    want = O.decode_clip(deltas[idx], anchors[idx], (1.0, 1.0, 1.0, 1.0), clip, 1200, 600)
+    got = _C.rpn_decode_clip(torch.from_numpy(deltas).to(device), torch.from_numpy(anchors).to(device),
+                             torch.from_numpy(idx).to(device), (1.0, 1.0, 1.0, 1.0), clip, 1200, 600).cpu().numpy()
+    # expf may differ by an ulp between libm and the device
+    np.testing.assert_allclose(got, want, rtol=1e-6, atol=1e-3)
+
+
+# ------------------------------------------------------------------------------------- DA heads
+def test_da_img_head_loss_forward_backward(device):
+    from da_detect_amd import _C
+
+    rng = np.random.default_rng(33)
+    B, HW, C1 = 2, 37 * 5, 512
+    t = torch.from_numpy(np.maximum(rng.standard_normal((B * HW, C1)), 0).astype(np.float32)).requires_grad_(True)
+    w2 = torch.from_numpy((rng.standard_normal(C1) * 0.05).astype(np.float32)).requires_grad_(True)
+    b2 = torch.tensor([0.1], requires_grad=True)
+    labels = torch.tensor([1.0, 0.0])
+    logits = t @ w2 + b2
+    lab_rows = labels.repeat_interleave(HW)
+    bce = F.binary_cross_entropy_with_logits(logits, lab_rows)
+    mean_sig = torch.sigmoid(logits).view(B, HW).mean(1)
+    got_logits, sums = _C.da_img_head_loss_forward(t.detach().to(device), w2.detach().to(device),
+                                                   b2.detach().to(device), labels.to(device), B, HW)
+    torch.testing.assert_close(got_logits.cpu(), logits.detach(), rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(sums[:, 0].sum().cpu() / (B * HW), bce.detach(), rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(sums[:, 1].cpu() / HW, mean_sig.detach(), rtol=1e-5, atol=1e-6)
+    # backward: loss = 1.0*bce + sum_i k_i * mean_sig_i ; feature path uses reversal weights -0.1 / +0.1
+    k = torch.tensor([0.3, -0.7])
+    (bce + (k * mean_sig).sum()).backward()
+    coef = torch.stack([torch.full((B,), 1.0 / (B * HW)), k / HW, torch.full((B,), -0.1 / (B * HW)),
+                        0.1 * k / HW], 1).contiguous()
+    g_t_w, g_t_x, g_w2, g_b2 = _C.da_img_head_loss_backward(t.detach().to(device), w2.detach().to(device),
+                                                            got_logits, labels.to(device), coef.to(device), B, HW)
+    mask = (t.detach() > 0).float()
+    torch.testing.assert_close(g_t_w.cpu(), t.grad * mask, rtol=1e-4, atol=1e-7)
+    torch.testing.assert_close(g_w2.cpu(), w2.grad, rtol=1e-4, atol=1e-6)
+    torch.testing.assert_close(g_b2.cpu(), b2.grad, rtol=1e-4, atol=1e-6)
+    # g_t_x: same with the two paths reweighted
+    t2 = t.detach().clone().requires_grad_(True)
+    lg = t2 @ w2.detach() + b2.detach()
+    (-0.1 * F.binary_cross_entropy_with_logits(lg, lab_rows) + 0.1 * (k * torch.sigmoid(lg).view(B, HW).mean(1)).sum()).backward()
+    torch.testing.assert_close(g_t_x.cpu(), t2.grad * mask, rtol=1e-4, atol=1e-7)
+
+
+def test_triplet_w_loss(device):
+    from da_detect_amd import _C
+
+    rng = np.random.default_rng(41)
+    a, p, n = [torch.from_numpy(rng.standard_normal((1, 64, 9, 13)).astype(np.float32)).requires_grad_(True)
+               for _ in range(3)]
+    ref = torch.nn.TripletMarginLoss(margin=1.0, p=2)(a, p, n)
+    ref.backward()
+    loss, dist = _C.triplet_w_forward(a.detach().to(device), p.detach().to(device), n.detach().to(device), 1.0)
+    torch.testing.assert_close(loss.cpu()[0], ref.detach(), rtol=1e-5, atol=1e-6)
+    g = torch.tensor([1.0 / (64 * 9)], device=device)
+    ga, gp, gn = _C.triplet_w_backward(a.detach().to(device), p.detach().to(device), n.detach().to(device), dist,
+                                       g, 1.0)
+    torch.testing.assert_close(ga.cpu(), a.grad, rtol=1e-4, atol=1e-7)
+    torch.testing.assert_close(gp.cpu(), p.grad, rtol=1e-4, atol=1e-7)
+    torch.testing.assert_close(gn.cpu(), n.grad, rtol=1e-4, atol=1e-7)
