@@ -99,8 +99,8 @@ def roi_align_backward(grad, rois, spatial_scale, pooled_height, pooled_width, b
     _dev(grad, "grad"), _dev(rois, "rois")
     g = _nhwc(grad)
     rois = rois.contiguous()
-    gin = torch.zeros((batch_size, channels, height, width), dtype=torch.float32, device=grad.device,
-                      memory_format=CL)
+    gin = torch.empty((batch_size, channels, height, width), dtype=torch.float32, device=grad.device,
+                      memory_format=CL).zero_()
     _lib.call("dadet_roi_align_backward", _p(g), _p(rois), _p(gin), batch_size, channels, height, width,
               rois.shape[0], pooled_height, pooled_width, float(spatial_scale), int(sampling_ratio),
               _stream())
@@ -159,13 +159,12 @@ def conv_forward(x, w, scale=None, bias=None, addend=None, mask_ref=None, stride
     if out_spatial_stride > 1:
         OutH, OutW = out_hw
         if out is None:
-            out = torch.zeros((N, Cout, OutH, OutW), dtype=torch.float32, device=x.device, memory_format=CL)
+            out = torch.empty((N, Cout, OutH, OutW), dtype=torch.float32, device=x.device,
+                              memory_format=CL).zero_()
     else:
         OutH, OutW = Ho, Wo
         if out is None:
             out = torch.empty((N, Cout, Ho, Wo), dtype=torch.float32, device=x.device, memory_format=CL)
-    assert out.is_contiguous(memory_format=CL) or out.dim() != 4 or min(out.shape[1:]) == 1 or \
-        out.is_contiguous(), "conv_forward: out must be channels_last"
     if addend is not None:
         addend = _nhwc(addend) if addend is not out else addend
     if mask_ref is not None:

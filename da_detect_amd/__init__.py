@@ -1,0 +1,8 @@
+"""da_detect_amd — MI355X-native training hot path of DA-Detect (domain-adaptive Faster R-CNN).
+
+Layout: csrc/ (HIP kernels + C-ABI, include/dadet.h) -> _lib.py (ctypes) -> _C.py (tensor-level ops, the
+stand-in for maskrcnn_benchmark._C) -> layers / structures / modeling / solver / engine mirroring the
+reference's package so `build_detection_model(cfg)` and the DA YAMLs are drop-in.
+`compat.install()` additionally registers the modules under the `maskrcnn_benchmark.*` names.
+"""
+__version__ = "0.1.0"

@@ -1,0 +1,178 @@
+"""Small layers of the reference's operator API (reference: maskrcnn_benchmark/layers/{batch_norm,misc,
+gradient_scalar_layer,smooth_l1_loss,consistency_loss,sigmoid_focal_loss}.py), backed by the HIP library."""
+import math
+
+import torch
+from torch import nn
+from torch.autograd import Function
+from torch.autograd.function import once_differentiable
+
+from .. import _C
+from .conv import conv2d_affine_act
+
+CL = torch.channels_last
+
+
+class FrozenBatchNorm2d(nn.Module):
+    """BatchNorm2d with fixed statistics and affine parameters (layers/batch_norm.py:6-24): buffers
+    weight / bias / running_mean / running_var, y = x * scale + shift with scale = weight * rsqrt(var)
+    (no epsilon, like the reference).  Inside the backbone the affine is folded into the conv epilogue
+    through `folded()`; called standalone it runs the channel_affine kernel."""
+
+    def __init__(self, n):
+        super(FrozenBatchNorm2d, self).__init__()
+        self.register_buffer("weight", torch.ones(n))
+        self.register_buffer("bias", torch.zeros(n))
+        self.register_buffer("running_mean", torch.zeros(n))
+        self.register_buffer("running_var", torch.ones(n))
+        self._cache = None
+
+    def folded(self):
+        """(scale, shift) fp32 vectors, cached until a buffer is modified (e.g. by load_state_dict)"""
+        key = (self.weight._version, self.bias._version, self.running_mean._version,
+               self.running_var._version, self.weight.device)
+        if self._cache is None or self._cache[0] != key:
+            scale = self.weight * self.running_var.rsqrt()
+            shift = self.bias - self.running_mean * scale
+            self._cache = (key, scale.contiguous(), shift.contiguous())
+        return self._cache[1], self._cache[2]
+
+    def forward(self, x):
+        scale, shift = self.folded()
+        return _ChannelAffine.apply(x, scale, shift)
+
+
+class _ChannelAffine(Function):
+    @staticmethod
+    def forward(ctx, x, scale, shift):
+        ctx.save_for_backward(scale)
+        return _C.channel_affine(x, scale, shift)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g):
+        (scale,) = ctx.saved_tensors
+        return _C.relu_bn_backward(g, None, scale)[1], None, None
+
+
+class Conv2d(nn.Conv2d):
+    """nn.Conv2d whose forward runs the implicit-GEMM kernel; keeps the reference wrapper's behaviour of
+    returning a correctly-shaped empty tensor for empty inputs (layers/misc.py:30-43).  Parameters are kept
+    in channels_last memory format ([Cout][KH][KW][Cin], the kernel's native weight layout)."""
+
+    def __init__(self, *args, **kwargs):
+        super(Conv2d, self).__init__(*args, **kwargs)
+        if self.groups != 1 or self.dilation != (1, 1) or self.kernel_size[0] != self.kernel_size[1] or \
+                self.stride[0] != self.stride[1] or self.padding[0] != self.padding[1]:
+            raise NotImplementedError("Conv2d: only square, undilated, ungrouped convolutions are on the HIP path")
+        self.weight.data = self.weight.data.contiguous(memory_format=CL)
+
+    def forward(self, x, scale=None, shift=None, residual=None, relu=False):
+        if scale is None:
+            return conv2d_affine_act(x, self.weight, None, self.bias, residual, self.stride[0],
+                                     self.padding[0], relu)
+        assert self.bias is None
+        return conv2d_affine_act(x, self.weight, scale, shift, residual, self.stride[0], self.padding[0], relu)
+
+
+class _GradientScalarLayer(Function):
+    """identity forward, weight * grad backward (layers/gradient_scalar_layer.py:4-13)"""
+
+    @staticmethod
+    def forward(ctx, input, weight):
+        ctx.weight = weight
+        return input.view_as(input)
+
+    @staticmethod
+    def backward(ctx, grad_output):
+        return ctx.weight * grad_output, None
+
+
+gradient_scalar = _GradientScalarLayer.apply
+
+
+class GradientScalarLayer(nn.Module):
+    def __init__(self, weight):
+        super(GradientScalarLayer, self).__init__()
+        self.weight = weight
+
+    def forward(self, input):
+        return gradient_scalar(input, self.weight)
+
+    def __repr__(self):
+        return "{}(weight={})".format(self.__class__.__name__, self.weight)
+
+
+def smooth_l1_loss(input, target, beta=1.0 / 9, size_average=True):
+    """smooth-L1 with the extra beta (layers/smooth_l1_loss.py:6-16)"""
+    n = torch.abs(input - target)
+    loss = torch.where(n < beta, 0.5 * n ** 2 / beta, n - 0.5 * beta)
+    return loss.mean() if size_average else loss.sum()
+
+
+def consistency_loss(img_feas, ins_fea, ins_labels, size_average=True):
+    """|mean_hw(p_img_i) - p_ins_ij| (layers/consistency_loss.py:3-27).  `img_feas` is a list of per-level
+    [N,1,H,W] probability maps, or (fused path) of per-level [N] tensors that already hold the spatial mean."""
+    loss = []
+    n_src = int(torch.nonzero(ins_labels).size(0))
+    intervals = [n_src, ins_fea.size(0) - n_src]
+    for lvl in img_feas:
+        means = lvl if lvl.dim() == 1 else torch.mean(lvl.reshape(lvl.shape[0], -1), 1)
+        assert means.shape[0] == 2, \
+            "only batch size=2 is supported for consistency loss now, received batch size: {}".format(means.shape[0])
+        rows = torch.cat([means[i].view(1, 1).repeat(intervals[i], 1) for i in range(2)], dim=0)
+        loss.append(torch.abs(rows - ins_fea))
+    loss = torch.cat(loss, dim=1)
+    return loss.mean() if size_average else loss.sum()
+
+
+class _SigmoidFocalLoss(Function):
+    @staticmethod
+    def forward(ctx, logits, targets, gamma, alpha):
+        ctx.save_for_backward(logits, targets)
+        ctx.num_classes, ctx.gamma, ctx.alpha = logits.shape[1], gamma, alpha
+        return _C.sigmoid_focalloss_forward(logits, targets, ctx.num_classes, gamma, alpha)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, d_loss):
+        logits, targets = ctx.saved_tensors
+        return _C.sigmoid_focalloss_backward(logits, targets, d_loss.contiguous(), ctx.num_classes, ctx.gamma,
+                                             ctx.alpha), None, None, None
+
+
+sigmoid_focal_loss = _SigmoidFocalLoss.apply
+
+
+class SigmoidFocalLoss(nn.Module):
+    """sum of the per-element focal loss (layers/sigmoid_focal_loss.py:55-76)"""
+
+    def __init__(self, gamma, alpha):
+        super(SigmoidFocalLoss, self).__init__()
+        self.gamma, self.alpha = gamma, alpha
+
+    def forward(self, logits, targets):
+        return sigmoid_focal_loss(logits, targets, self.gamma, self.alpha).sum()
+
+    def __repr__(self):
+        return "{}(gamma={}, alpha={})".format(self.__class__.__name__, self.gamma, self.alpha)
+
+
+class _AvgPoolHW(Function):
+    """nn.AvgPool2d(k) on a k x k map == mean over H*W -> [R, C]"""
+
+    @staticmethod
+    def forward(ctx, x):
+        ctx.hw = (x.shape[2], x.shape[3])
+        return _C.avgpool_forward(x)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g):
+        return _C.avgpool_backward(g, *ctx.hw)
+
+
+def global_avg_pool(x):
+    if x.shape[0] == 0:
+        return x.new_empty((0, x.shape[1]))
+    return _AvgPoolHW.apply(x)

@@ -1,0 +1,208 @@
+"""ResNet C4 / C5 / FPN bodies and the res5 ROI head, running on the fused implicit-GEMM kernels.
+
+Module tree and parameter / buffer names are the reference's (reference:
+maskrcnn_benchmark/modeling/backbone/resnet.py:80-314) so released checkpoints load by key:
+  stem.conv1, stem.bn1, layer{1..4}.{i}.{conv1,bn1,conv2,bn2,conv3,bn3,downsample.0,downsample.1}.
+What differs is the execution: every conv -> FrozenBN -> (+identity) -> ReLU group is ONE kernel launch
+(the affine, the residual add and the ReLU live in the GEMM epilogue), activations stay NHWC end to end, and
+the 3-channel stem input is staged as NHWC4 so the 7x7 conv is an implicit GEMM over a 7x8x4 window.
+"""
+from collections import namedtuple
+
+import torch
+import torch.nn.functional as F
+from torch import nn
+
+from ... import _C
+from ...layers import Conv2d, FrozenBatchNorm2d, conv2d_affine_act
+from ...utils.registry import Registry
+
+StageSpec = namedtuple("StageSpec", ["index", "block_count", "return_features"])
+
+
+def _specs(*rows):
+    return tuple(StageSpec(index=i, block_count=c, return_features=r) for (i, c, r) in rows)
+
+
+# (stage index, number of bottlenecks, returned?)  — resnet.py:42-74 of the reference
+ResNet50StagesTo5 = _specs((1, 3, False), (2, 4, False), (3, 6, False), (4, 3, True))
+ResNet50StagesTo4 = _specs((1, 3, False), (2, 4, False), (3, 6, True))
+ResNet101StagesTo5 = _specs((1, 3, False), (2, 4, False), (3, 23, False), (4, 3, True))
+ResNet101StagesTo4 = _specs((1, 3, False), (2, 4, False), (3, 23, True))
+ResNet50FPNStagesTo5 = _specs((1, 3, True), (2, 4, True), (3, 6, True), (4, 3, True))
+ResNet101FPNStagesTo5 = _specs((1, 3, True), (2, 4, True), (3, 23, True), (4, 3, True))
+ResNet152FPNStagesTo5 = _specs((1, 3, True), (2, 8, True), (3, 36, True), (4, 3, True))
+
+
+class Bottleneck(nn.Module):
+    """1x1 (carries the stride when stride_in_1x1) -> 3x3 -> 1x1, FrozenBN after each, projection shortcut
+    when the channel count changes (resnet.py:227-314)."""
+
+    def __init__(self, in_channels, bottleneck_channels, out_channels, num_groups, stride_in_1x1, stride,
+                 dilation, norm_func):
+        super(Bottleneck, self).__init__()
+        if num_groups != 1 or dilation != 1:
+            raise NotImplementedError("grouped / dilated bottlenecks are outside the DA Faster R-CNN path")
+        self.downsample = None
+        if in_channels != out_channels:
+            self.downsample = nn.Sequential(
+                Conv2d(in_channels, out_channels, kernel_size=1, stride=stride, bias=False),
+                norm_func(out_channels))
+            nn.init.kaiming_uniform_(self.downsample[0].weight, a=1)
+        stride_1x1, stride_3x3 = (stride, 1) if stride_in_1x1 else (1, stride)
+        self.conv1 = Conv2d(in_channels, bottleneck_channels, kernel_size=1, stride=stride_1x1, bias=False)
+        self.bn1 = norm_func(bottleneck_channels)
+        self.conv2 = Conv2d(bottleneck_channels, bottleneck_channels, kernel_size=3, stride=stride_3x3,
+                            padding=1, bias=False)
+        self.bn2 = norm_func(bottleneck_channels)
+        self.conv3 = Conv2d(bottleneck_channels, out_channels, kernel_size=1, bias=False)
+        self.bn3 = norm_func(out_channels)
+        for l in (self.conv1, self.conv2, self.conv3):
+            nn.init.kaiming_uniform_(l.weight, a=1)
+
+    def forward(self, x):
+        out = self.conv1(x, *self.bn1.folded(), relu=True)
+        out = self.conv2(out, *self.bn2.folded(), relu=True)
+        identity = x if self.downsample is None else self.downsample[0](x, *self.downsample[1].folded())
+        # relu(bn3(conv3(out)) + identity) in one epilogue
+        return self.conv3(out, *self.bn3.folded(), residual=identity, relu=True)
+
+
+class BottleneckWithFixedBatchNorm(Bottleneck):
+    def __init__(self, in_channels, bottleneck_channels, out_channels, num_groups=1, stride_in_1x1=True,
+                 stride=1, dilation=1):
+        super(BottleneckWithFixedBatchNorm, self).__init__(
+            in_channels, bottleneck_channels, out_channels, num_groups, stride_in_1x1, stride, dilation,
+            norm_func=FrozenBatchNorm2d)
+
+
+class BaseStem(nn.Module):
+    """conv 7x7/2 (3 -> 64) + FrozenBN + ReLU + maxpool 3x3/2 (resnet.py:317-336)"""
+
+    def __init__(self, cfg, norm_func):
+        super(BaseStem, self).__init__()
+        out_channels = cfg.MODEL.RESNETS.STEM_OUT_CHANNELS
+        self.conv1 = Conv2d(3, out_channels, kernel_size=7, stride=2, padding=3, bias=False)
+        self.bn1 = norm_func(out_channels)
+        nn.init.kaiming_uniform_(self.conv1.weight, a=1)
+        self._w4 = None
+
+    def _padded_weight(self):
+        """[64,3,7,7] -> [64,4,7,8] (zero 4th channel and 8th column) in channels_last"""
+        w = self.conv1.weight
+        if w.requires_grad and torch.is_grad_enabled():
+            return F.pad(w, (0, 1, 0, 0, 0, 1)).contiguous(memory_format=torch.channels_last)
+        key = (w._version, w.device)
+        if self._w4 is None or self._w4[0] != key:
+            with torch.no_grad():
+                self._w4 = (key, F.pad(w, (0, 1, 0, 0, 0, 1)).contiguous(memory_format=torch.channels_last))
+        return self._w4[1]
+
+    def forward(self, x):
+        N, C, H, W = x.shape
+        assert C == 3, "the stem expects BGR images [N,3,H,W]"
+        x4 = _C.nchw3_to_nhwc4(x)
+        out_size = _C.conv_out_size(H, W, 7, 7, 2, 3)
+        scale, shift = self.bn1.folded()
+        y = conv2d_affine_act(x4, self._padded_weight(), scale, shift, None, 2, 3, True, out_size)
+        if y.requires_grad:
+            raise NotImplementedError("max-pool backward: the stem is frozen in every DA configuration "
+                                      "(MODEL.BACKBONE.FREEZE_CONV_BODY_AT >= 1)")
+        return _C.maxpool3x3s2(y)
+
+
+class StemWithFixedBatchNorm(BaseStem):
+    def __init__(self, cfg):
+        super(StemWithFixedBatchNorm, self).__init__(cfg, norm_func=FrozenBatchNorm2d)
+
+
+def _make_stage(block, in_channels, bottleneck_channels, out_channels, block_count, num_groups,
+                stride_in_1x1, first_stride, dilation=1):
+    blocks, stride = [], first_stride
+    for _ in range(block_count):
+        blocks.append(block(in_channels, bottleneck_channels, out_channels, num_groups, stride_in_1x1, stride,
+                            dilation=dilation))
+        stride = 1
+        in_channels = out_channels
+    return nn.Sequential(*blocks)
+
+
+class ResNet(nn.Module):
+    def __init__(self, cfg):
+        super(ResNet, self).__init__()
+        stem_module = _STEM_MODULES[cfg.MODEL.RESNETS.STEM_FUNC]
+        stage_specs = _STAGE_SPECS[cfg.MODEL.BACKBONE.CONV_BODY]
+        block = _TRANSFORMATION_MODULES[cfg.MODEL.RESNETS.TRANS_FUNC]
+        self.stem = stem_module(cfg)
+        num_groups = cfg.MODEL.RESNETS.NUM_GROUPS
+        in_channels = cfg.MODEL.RESNETS.STEM_OUT_CHANNELS
+        stage2_bottleneck = num_groups * cfg.MODEL.RESNETS.WIDTH_PER_GROUP
+        stage2_out = cfg.MODEL.RESNETS.RES2_OUT_CHANNELS
+        self.stages, self.return_features = [], {}
+        for spec in stage_specs:
+            name = "layer" + str(spec.index)
+            factor = 2 ** (spec.index - 1)
+            out_channels = stage2_out * factor
+            self.add_module(name, _make_stage(block, in_channels, stage2_bottleneck * factor, out_channels,
+                                              spec.block_count, num_groups, cfg.MODEL.RESNETS.STRIDE_IN_1X1,
+                                              first_stride=int(spec.index > 1) + 1))
+            in_channels = out_channels
+            self.stages.append(name)
+            self.return_features[name] = spec.return_features
+        self._freeze_backbone(cfg.MODEL.BACKBONE.FREEZE_CONV_BODY_AT)
+
+    def _freeze_backbone(self, freeze_at):
+        """stage 0 = stem, stage i = layer{i} (resnet.py:127-136)"""
+        for stage_index in range(max(freeze_at, 0)):
+            m = self.stem if stage_index == 0 else getattr(self, "layer" + str(stage_index))
+            for p in m.parameters():
+                p.requires_grad = False
+
+    def forward(self, x):
+        outputs = []
+        x = self.stem(x)
+        for name in self.stages:
+            x = getattr(self, name)(x)
+            if self.return_features[name]:
+                outputs.append(x)
+        return outputs
+
+
+class ResNetHead(nn.Module):
+    """res5 as an ROI head: stages of bottlenecks applied to pooled ROI features (resnet.py:148-194)"""
+
+    def __init__(self, block_module, stages, num_groups=1, width_per_group=64, stride_in_1x1=True,
+                 stride_init=None, res2_out_channels=256, dilation=1):
+        super(ResNetHead, self).__init__()
+        factor = 2 ** (stages[0].index - 1)
+        out_channels = res2_out_channels * factor
+        in_channels = out_channels // 2
+        bottleneck_channels = num_groups * width_per_group * factor
+        block = _TRANSFORMATION_MODULES[block_module]
+        self.stages = []
+        stride = stride_init
+        for stage in stages:
+            name = "layer" + str(stage.index)
+            if not stride:
+                stride = int(stage.index > 1) + 1
+            self.add_module(name, _make_stage(block, in_channels, bottleneck_channels, out_channels,
+                                              stage.block_count, num_groups, stride_in_1x1, first_stride=stride,
+                                              dilation=dilation))
+            stride = None
+            self.stages.append(name)
+
+    def forward(self, x):
+        for stage in self.stages:
+            x = getattr(self, stage)(x)
+        return x
+
+
+_TRANSFORMATION_MODULES = Registry({"BottleneckWithFixedBatchNorm": BottleneckWithFixedBatchNorm})
+_STEM_MODULES = Registry({"StemWithFixedBatchNorm": StemWithFixedBatchNorm})
+_STAGE_SPECS = Registry({
+    "R-50-C4": ResNet50StagesTo4, "R-50-C5": ResNet50StagesTo5,
+    "R-101-C4": ResNet101StagesTo4, "R-101-C5": ResNet101StagesTo5,
+    "R-50-FPN": ResNet50FPNStagesTo5, "R-50-FPN-RETINANET": ResNet50FPNStagesTo5,
+    "R-101-FPN": ResNet101FPNStagesTo5, "R-101-FPN-RETINANET": ResNet101FPNStagesTo5,
+    "R-152-FPN": ResNet152FPNStagesTo5,
+})

@@ -1,0 +1,223 @@
+"""Domain-adaptation heads (reference: maskrcnn_benchmark/modeling/da_heads/da_heads.py:12-440).
+
+Module / parameter names follow the reference (`imghead.conv1_da`, `imghead.conv2_da`, `inshead.fc{1,2,3}_da`).
+Execution differs: the image-level classifier is evaluated once by the fused kernels (fused.py) instead of
+two (three with AdvGRL) full passes; the instance-level classifier keeps the reference's separate passes
+because each pass draws its own dropout masks (da_heads.py:61-68).
+"""
+import torch
+import torch.nn.functional as F
+from torch import nn
+
+from ...layers import Conv2d, GradientScalarLayer, global_avg_pool, linear
+from ...layers.misc import gradient_scalar
+from ...utils import rng
+from .fused import da_image_head
+from .loss import TripletMargins, da_consist_loss, da_ins_loss, image_domain_labels
+
+
+class DAImgHead(nn.Module):
+    """1x1 conv C->512, ReLU, 1x1 conv 512->1 (da_heads.py:12-37)"""
+
+    def __init__(self, in_channels):
+        super(DAImgHead, self).__init__()
+        self.conv1_da = Conv2d(in_channels, 512, kernel_size=1, stride=1)
+        self.conv2_da = Conv2d(512, 1, kernel_size=1, stride=1)
+        for l in (self.conv1_da, self.conv2_da):
+            torch.nn.init.normal_(l.weight, std=0.001)
+            torch.nn.init.constant_(l.bias, 0)
+
+    def fused(self, feature, labels, w_adv, w_cst):
+        """-> (mean BCE, per-image mean sigmoid, logits [N,1,H,W]) for one feature level"""
+        return da_image_head(feature, self.conv1_da, self.conv2_da, labels, w_adv, w_cst)
+
+    def forward(self, x):
+        """plain logits per level (reference signature); no loss fusion"""
+        out = []
+        for feature in x:
+            t = self.conv1_da(feature, relu=True)
+            out.append(linear_map(t, self.conv2_da))
+        return out
+
+
+def linear_map(t, conv):
+    """1x1 conv with a single output channel through the padded-linear path"""
+    N, C, H, W = t.shape
+    flat = t.permute(0, 2, 3, 1).reshape(-1, C)
+    y = linear(flat, conv.weight.reshape(conv.weight.shape[0], C), conv.bias)
+    return y.reshape(N, H, W, -1).permute(0, 3, 1, 2)
+
+
+class DAInsHead(nn.Module):
+    """fc 2048->1024, ReLU, dropout, fc 1024->1024, ReLU, dropout, fc 1024->1 (da_heads.py:40-68)"""
+
+    def __init__(self, in_channels):
+        super(DAInsHead, self).__init__()
+        self.fc1_da = nn.Linear(in_channels, 1024)
+        self.fc2_da = nn.Linear(1024, 1024)
+        self.fc3_da = nn.Linear(1024, 1)
+        for l in (self.fc1_da, self.fc2_da):
+            nn.init.normal_(l.weight, std=0.01)
+            nn.init.constant_(l.bias, 0)
+        nn.init.normal_(self.fc3_da.weight, std=0.05)
+        nn.init.constant_(self.fc3_da.bias, 0)
+        self.in_channels = in_channels
+
+    def forward(self, x):
+        x = linear(x, self.fc1_da.weight, self.fc1_da.bias, relu=True)
+        if self.training:
+            x = x * rng.dropout_mask(tuple(x.shape), 0.5, x.device)
+        x = linear(x, self.fc2_da.weight, self.fc2_da.bias, relu=True)
+        if self.training:
+            x = x * rng.dropout_mask(tuple(x.shape), 0.5, x.device)
+        return linear(x, self.fc3_da.weight, self.fc3_da.bias)
+
+
+def _ins_input_dim(cfg):
+    if cfg.MODEL.BACKBONE.CONV_BODY.startswith("V"):
+        return cfg.MODEL.ROI_BOX_HEAD.MLP_HEAD_DIM
+    return cfg.MODEL.RESNETS.RES2_OUT_CHANNELS * 8
+
+
+def _pool_ins(feat, resnet_backbone):
+    """AvgPool2d(7) + flatten of the [R,2048,7,7] ROI features (da_heads.py:402-407)"""
+    if resnet_backbone:
+        return global_avg_pool(feat)
+    return feat.reshape(feat.size(0), -1)
+
+
+class DomainAdaptationModule(torch.nn.Module):
+    """image-level + instance-level adversarial losses and their consistency regulariser
+    (da_heads.py:354-440, losses da_heads/loss.py:55-104)"""
+
+    def __init__(self, cfg):
+        super(DomainAdaptationModule, self).__init__()
+        self.cfg = cfg.clone()
+        da = cfg.MODEL.DA_HEADS
+        self.resnet_backbone = cfg.MODEL.BACKBONE.CONV_BODY.startswith("R")
+        self.avgpool = nn.AvgPool2d(kernel_size=7, stride=7)
+        self.img_weight, self.ins_weight, self.cst_weight = (da.DA_IMG_LOSS_WEIGHT, da.DA_INS_LOSS_WEIGHT,
+                                                             da.DA_CST_LOSS_WEIGHT)
+        self.grl_img = GradientScalarLayer(-1.0 * da.DA_IMG_GRL_WEIGHT)
+        self.grl_ins = GradientScalarLayer(-1.0 * da.DA_INS_GRL_WEIGHT)
+        self.grl_img_consist = GradientScalarLayer(1.0 * da.DA_IMG_GRL_WEIGHT)
+        self.grl_ins_consist = GradientScalarLayer(1.0 * da.DA_INS_GRL_WEIGHT)
+        self.imghead = DAImgHead(cfg.MODEL.BACKBONE.OUT_CHANNELS)
+        self.inshead = DAInsHead(_ins_input_dim(cfg))
+
+    def forward(self, img_features, da_ins_feature, da_ins_labels, targets=None):
+        if not self.training:
+            return {}
+        assert len(img_features) == 1, "the DA heads operate on a single feature level (C4), like the reference"
+        da_ins_feature = _pool_ins(da_ins_feature, self.resnet_backbone)
+        # instance head: adversarial pass then consistency pass, each with its own dropout masks
+        da_ins_features = self.inshead(self.grl_ins(da_ins_feature))
+        da_ins_consist = self.inshead(self.grl_ins_consist(da_ins_feature)).sigmoid()
+        # image head: one fused evaluation serves both the BCE (GRL -w) and the consistency (GRL +w) paths
+        labels = image_domain_labels(targets)
+        da_img_loss, img_mean_sig, _ = self.imghead.fused(img_features[0], labels, self.grl_img.weight,
+                                                         self.grl_img_consist.weight)
+        losses = {}
+        if self.img_weight > 0:
+            losses["loss_da_image"] = self.img_weight * da_img_loss
+        if self.ins_weight > 0:
+            losses["loss_da_instance"] = self.ins_weight * da_ins_loss(da_ins_features, da_ins_labels)
+        if self.cst_weight > 0:
+            losses["loss_da_consistency"] = self.cst_weight * da_consist_loss(img_mean_sig, da_ins_consist,
+                                                                              da_ins_labels)
+        return losses
+
+
+class DomainAdaptationModule_triplet(torch.nn.Module):
+    """component-wise DA losses with AdvGRL and domain-level triplet regularisation (da_heads.py:72-344)"""
+
+    def __init__(self, cfg):
+        super(DomainAdaptationModule_triplet, self).__init__()
+        self.cfg = cfg.clone()
+        da = cfg.MODEL.DA_HEADS
+        self.resnet_backbone = cfg.MODEL.BACKBONE.CONV_BODY.startswith("R")
+        self.avgpool = nn.AvgPool2d(kernel_size=7, stride=7)
+        self.img_weight, self.ins_weight, self.cst_weight = (da.DA_IMG_LOSS_WEIGHT, da.DA_INS_LOSS_WEIGHT,
+                                                             da.DA_CST_LOSS_WEIGHT)
+        self.triplet_img_weight, self.triplet_ins_weight = da.DA_TRIPLET_IMG_WEIGHT, da.DA_TRIPLET_INS_WEIGHT
+        self.grl_img = GradientScalarLayer(-1.0 * da.DA_IMG_GRL_WEIGHT)
+        self.grl_ins = GradientScalarLayer(-1.0 * da.DA_INS_GRL_WEIGHT)
+        self.grl_img_consist = GradientScalarLayer(1.0 * da.DA_IMG_GRL_WEIGHT)
+        self.grl_ins_consist = GradientScalarLayer(1.0 * da.DA_INS_GRL_WEIGHT)
+        self.imghead = DAImgHead(cfg.MODEL.BACKBONE.OUT_CHANNELS)
+        self.inshead = DAInsHead(_ins_input_dim(cfg))
+        self.loss_evaluator = TripletMargins()
+        self.triplet_ins = [1]
+        self.triplet_img = [1]
+        self.advGRL = da.DA_ADV_GRL
+        self.advGRL_threshold = da.DA_ADV_GRL_THRESHOLD
+        self.adv_img_weight, self.adv_ins_weight = da.DA_IMG_advGRL_WEIGHT, da.DA_INS_advGRL_WEIGHT
+        self.triplet_metric_img, self.triplet_metric_ins = da.TRIPLET_MARGIN_IMG, da.TRIPLET_MARGIN_INS
+        self.triplet_max_margin = da.TRIPLET_MAX_MARGIN
+        # the AdvGRL gate: BCE-with-logits of logits (0.7, 0.3) against labels (1, 0) (da_heads.py:175)
+        self.adv_gate = float(F.binary_cross_entropy_with_logits(torch.tensor([[0.7, 0.3]]),
+                                                                 torch.tensor([[1.0, 0.0]])))
+
+    def adv_grl_weight(self, current_loss, base_weight, adv_weight):
+        """adaptive reversal weight (da_heads.py:173-195) as a 0-d device tensor, no host sync:
+        loss <= gate -> -adv_weight * min(threshold, 1 / loss), else the fixed -base_weight.
+        (The reference calls .numpy() on the loss here, which fails on device tensors — SURVEY.md fact 10;
+        this is the intended rule with the loss detached.)"""
+        loss = current_loss.detach()
+        adaptive = -adv_weight * torch.clamp(1.0 / loss, max=float(self.advGRL_threshold))
+        return torch.where(loss <= self.adv_gate, adaptive, torch.full_like(loss, -base_weight))
+
+    def forward(self, img_features, da_ins_feature, da_ins_labels, da_ins_feas_set, img_fea_set, targets=None):
+        if not self.training:
+            return {}
+        assert len(img_features) == 1
+        losses = {}
+        if self.triplet_ins_weight > 0:
+            s, p, n = [_pool_ins(f, self.resnet_backbone) for f in da_ins_feas_set]
+            loss = self.loss_evaluator.triplet_ins_loss(
+                s, p, n, self.triplet_ins[-1], adaptive=False, lr=0.001, max_margin=self.triplet_max_margin,
+                margin=self.triplet_metric_ins)
+            losses["triplet_loss_instance"] = self.triplet_ins_weight * loss
+            self.triplet_ins = [loss.detach().cpu()]  # only [-1] is ever read
+        if self.triplet_img_weight > 0:
+            loss = self.loss_evaluator.triplet_img_loss(
+                img_fea_set[0][0], img_fea_set[1][0], img_fea_set[2][0], self.triplet_img[-1], adaptive=True,
+                lr=0.001, max_margin=self.triplet_max_margin, margin=self.triplet_metric_img)
+            losses["triplet_loss_image"] = self.triplet_img_weight * loss
+            self.triplet_img = [loss.detach().cpu()]
+
+        need_img = self.img_weight > 0 or self.cst_weight > 0
+        if need_img:
+            labels = image_domain_labels(targets)
+            w_adv = self.grl_img.weight
+            if self.advGRL and self.img_weight > 0:
+                # the head's own forward value IS the reference's detached "current loss" (da_heads.py:128-130):
+                # the adaptive weight is resolved from it inside the fused op, no second pass
+                w_adv = lambda cur: self.adv_grl_weight(cur, -self.grl_img.weight, self.adv_img_weight)  # noqa: E731
+            da_img_loss, img_mean_sig, _ = self.imghead.fused(img_features[0], labels, w_adv,
+                                                             self.grl_img_consist.weight)
+            if self.img_weight > 0:
+                losses["loss_da_image"] = self.img_weight * da_img_loss
+        if self.ins_weight > 0:
+            feat = _pool_ins(da_ins_feature, self.resnet_backbone)
+            cur = da_ins_loss(self.inshead(feat.detach()), da_ins_labels)  # own dropout draws, as the reference
+            if self.advGRL:
+                w = self.adv_grl_weight(cur, -self.grl_ins.weight, self.adv_ins_weight)
+                grl_fea = gradient_scalar(feat, w)
+            else:
+                grl_fea = self.grl_ins(feat)
+            losses["loss_da_instance"] = self.ins_weight * da_ins_loss(self.inshead(grl_fea), da_ins_labels)
+        if self.cst_weight > 0:
+            feat = _pool_ins(da_ins_feature, self.resnet_backbone)
+            ins_consist = self.inshead(self.grl_ins_consist(feat)).sigmoid()
+            losses["loss_da_consistency"] = self.cst_weight * da_consist_loss(img_mean_sig, ins_consist,
+                                                                              da_ins_labels)
+        return losses
+
+
+def build_da_heads(cfg):
+    return DomainAdaptationModule(cfg) if cfg.MODEL.DOMAIN_ADAPTATION_ON else []
+
+
+def build_da_heads_triplet(cfg):
+    return DomainAdaptationModule_triplet(cfg) if cfg.MODEL.DOMAIN_ADAPTATION_ON else []

@@ -1,0 +1,69 @@
+"""Generalized R-CNN with domain-adaptation heads
+(reference: maskrcnn_benchmark/modeling/detector/generalized_rcnn.py:37-156).
+
+forward(images, targets) -> dict of scalar losses (training) | list[BoxList] detections (eval).
+Batch layout contracts inherited from the reference trainer (engine/trainer.py:215-224): source images first;
+plain DA = [source, target]; triplet DA = [source, target(positive), auxiliary(negative)].
+"""
+import torch
+from torch import nn
+
+from ...structures.image_list import to_image_list
+from ..backbone import build_backbone
+from ..da_heads.da_heads import build_da_heads, build_da_heads_triplet
+from ..roi_heads.roi_heads import build_roi_heads
+from ..rpn.rpn import build_rpn
+
+
+class GeneralizedRCNN(nn.Module):
+    def __init__(self, cfg):
+        super(GeneralizedRCNN, self).__init__()
+        self.backbone = build_backbone(cfg)
+        self.rpn = build_rpn(cfg)
+        self.roi_heads = build_roi_heads(cfg)
+        self.da_heads = build_da_heads(cfg)
+        self.triplet_use = cfg.MODEL.DA_HEADS.TRIPLET_USE
+        self.da_heads_triplet = build_da_heads_triplet(cfg) if self.triplet_use else False
+        self.Aligned = cfg.MODEL.DA_HEADS.ALIGNMENT
+
+    def forward(self, images, targets=None):
+        if self.training and targets is None:
+            raise ValueError("In training mode, targets should be passed")
+        images = to_image_list(images)
+        features = self.backbone(images.tensors)
+        proposals, proposal_losses = self.rpn(images, features, targets)
+        da_losses, detector_losses = {}, {}
+        if self.roi_heads:
+            if self.training and self.da_heads_triplet:
+                f = features[0]
+                assert f.shape[0] == 3, "triplet training expects [source, target, auxiliary] batches"
+                da_img_fea_set = [[f[0:1]], [f[1:2]], [f[2:3]]]
+                ori_features, ori_targets = [f[0:2]], targets[0:2]
+                x, result, detector_losses, da_ins_feas, da_ins_labels = self.roi_heads(
+                    ori_features, proposals[0:2], ori_targets)
+                if self.Aligned:
+                    # all three domains are pooled with the TARGET image's proposals (generalized_rcnn.py:110-112)
+                    ins_set = []
+                    for fea, tgt in zip(da_img_fea_set, (targets[0], targets[1], targets[2])):
+                        _, _, _, feas, _ = self.roi_heads(fea, [proposals[1]], [tgt])
+                        ins_set.append(feas)
+                else:
+                    ins_set = [0, 0, 0]
+                da_losses = self.da_heads_triplet(ori_features, da_ins_feas, da_ins_labels, ins_set,
+                                                  da_img_fea_set, ori_targets)
+            elif self.training and self.da_heads:
+                x, result, detector_losses, da_ins_feas, da_ins_labels = self.roi_heads(features, proposals, targets)
+                da_losses = self.da_heads(features, da_ins_feas, da_ins_labels, targets)
+            else:
+                # evaluation, and plain (non-DA) training — the latter raises UnboundLocalError in the
+                # reference (generalized_rcnn.py:150); upstream behaviour is used instead
+                x, result, detector_losses, _, _ = self.roi_heads(features, proposals, targets)
+        else:
+            result = proposals
+        if self.training:
+            losses = {}
+            losses.update(detector_losses)
+            losses.update(proposal_losses)
+            losses.update(da_losses)
+            return losses
+        return result

@@ -1,0 +1,50 @@
+"""ROI feature pooler (reference: maskrcnn_benchmark/modeling/poolers.py:11-121)."""
+import torch
+from torch import nn
+
+from ..layers import ROIAlign
+from .utils import cat
+
+
+class LevelMapper(object):
+    """FPN level assignment k = floor(k0 + log2(sqrt(area) / 224)) (poolers.py:11-42)"""
+
+    def __init__(self, k_min, k_max, canonical_scale=224, canonical_level=4, eps=1e-6):
+        self.k_min, self.k_max = k_min, k_max
+        self.s0, self.lvl0, self.eps = canonical_scale, canonical_level, eps
+
+    def __call__(self, boxlists):
+        s = torch.sqrt(cat([b.area() for b in boxlists]))
+        lvls = torch.floor(self.lvl0 + torch.log2(s / self.s0 + self.eps))
+        return torch.clamp(lvls, min=self.k_min, max=self.k_max).to(torch.int64) - self.k_min
+
+
+class Pooler(nn.Module):
+    def __init__(self, output_size, scales, sampling_ratio):
+        super(Pooler, self).__init__()
+        self.poolers = nn.ModuleList(
+            [ROIAlign(output_size, spatial_scale=s, sampling_ratio=sampling_ratio) for s in scales])
+        self.output_size = output_size
+        lvl_min = -torch.log2(torch.tensor(scales[0], dtype=torch.float32)).item()
+        lvl_max = -torch.log2(torch.tensor(scales[-1], dtype=torch.float32)).item()
+        self.map_levels = LevelMapper(lvl_min, lvl_max)
+
+    def convert_to_roi_format(self, boxes):
+        """list[BoxList] -> [R,5] (batch index, x1, y1, x2, y2) (poolers.py:78-89)"""
+        concat = cat([b.bbox for b in boxes], dim=0)
+        ids = cat([torch.full((len(b), 1), i, dtype=concat.dtype, device=concat.device)
+                   for i, b in enumerate(boxes)], dim=0)
+        return torch.cat([ids, concat], dim=1)
+
+    def forward(self, x, boxes):
+        rois = self.convert_to_roi_format(boxes)
+        if len(self.poolers) == 1:
+            return self.poolers[0](x[0], rois)
+        levels = self.map_levels(boxes)
+        out_size = self.output_size[0]
+        result = torch.zeros((len(rois), x[0].shape[1], out_size, out_size), dtype=x[0].dtype,
+                             device=x[0].device).contiguous(memory_format=torch.channels_last)
+        for level, (feat, pooler) in enumerate(zip(x, self.poolers)):
+            idx = torch.nonzero(levels == level).squeeze(1)
+            result[idx] = pooler(feat, rois[idx])
+        return result

@@ -1,0 +1,110 @@
+"""Fast R-CNN losses with the domain-adaptation sampling rules
+(reference: maskrcnn_benchmark/modeling/roi_heads/box_head/loss.py:16-251)."""
+import torch
+from torch.nn import functional as F
+
+from ....layers import smooth_l1_loss
+from ....structures.boxlist_ops import boxlist_iou
+from ...balanced_positive_negative_sampler import BalancedPositiveNegativeSampler
+from ...box_coder import BoxCoder
+from ...matcher import Matcher
+from ...utils import cat
+
+
+class FastRCNNLossComputation(object):
+    def __init__(self, proposal_matcher, fg_bg_sampler, box_coder, cls_agnostic_bbox_reg=False):
+        self.proposal_matcher = proposal_matcher
+        self.fg_bg_sampler = fg_bg_sampler
+        self.box_coder = box_coder
+        self.cls_agnostic_bbox_reg = cls_agnostic_bbox_reg
+
+    def match_targets_to_proposals(self, proposal, target, is_source=True):
+        matched_idxs = self.proposal_matcher(boxlist_iou(target, proposal))
+        target = target.copy_with_fields("labels")
+        # source: negatives (-1/-2) are clamped to gt 0; target domain: raw (negative = from the end) indexing,
+        # its labels are overwritten with 0 below anyway (loss.py:55-66)
+        matched = target[matched_idxs.clamp(min=0)] if is_source else target[matched_idxs]
+        matched.add_field("matched_idxs", matched_idxs)
+        return matched
+
+    def prepare_targets(self, proposals, targets, sample_for_da=False):
+        labels, regression_targets, domain_labels = [], [], []
+        for proposals_per_image, targets_per_image in zip(proposals, targets):
+            is_source = bool(targets_per_image.get_field("is_source").any())
+            matched = self.match_targets_to_proposals(proposals_per_image, targets_per_image, is_source)
+            matched_idxs = matched.get_field("matched_idxs")
+            lab = matched.get_field("labels").to(dtype=torch.int64)
+            lab[matched_idxs == Matcher.BELOW_LOW_THRESHOLD] = 0
+            lab[matched_idxs == Matcher.BETWEEN_THRESHOLDS] = -1  # ignored by the sampler
+            regression_targets.append(self.box_coder.encode(matched.bbox, proposals_per_image.bbox))
+            dom = torch.ones_like(lab, dtype=torch.bool) if is_source else torch.zeros_like(lab, dtype=torch.bool)
+            domain_labels.append(dom)
+            if not is_source or sample_for_da:
+                lab[:] = 0  # everything is a "negative": uniform random sampling (loss.py:85-88)
+            labels.append(lab)
+        return labels, regression_targets, domain_labels
+
+    def _take_sampled(self, proposals, pos_masks, neg_masks):
+        for i, (pm, nm) in enumerate(zip(pos_masks, neg_masks)):
+            proposals[i] = proposals[i][torch.nonzero(pm | nm).squeeze(1)]
+        return proposals
+
+    def subsample(self, proposals, targets):
+        """sample BATCH_SIZE_PER_IMAGE proposals per image for the detection loss; keeps them in
+        self._proposals for the following __call__ (loss.py:95-130)"""
+        labels, regression_targets, domain_labels = self.prepare_targets(proposals, targets)
+        pos_masks, neg_masks = self.fg_bg_sampler(labels)
+        proposals = list(proposals)
+        for lab, reg, prop, dom in zip(labels, regression_targets, proposals, domain_labels):
+            prop.add_field("labels", lab)
+            prop.add_field("regression_targets", reg)
+            prop.add_field("domain_labels", dom)
+        self._proposals = self._take_sampled(proposals, pos_masks, neg_masks)
+        return self._proposals
+
+    def subsample_for_da(self, proposals, targets):
+        """uniformly sampled proposals (all labels forced to 0) for the instance-level domain classifier
+        (loss.py:132-163); does NOT replace self._proposals"""
+        labels, _, domain_labels = self.prepare_targets(proposals, targets, sample_for_da=True)
+        pos_masks, neg_masks = self.fg_bg_sampler(labels)
+        proposals = list(proposals)
+        for prop, dom in zip(proposals, domain_labels):
+            prop.add_field("domain_labels", dom)
+        return self._take_sampled(proposals, pos_masks, neg_masks)
+
+    def __call__(self, class_logits, box_regression):
+        """-> (classification_loss, box_loss, domain_masks); only source-domain rows enter the detection
+        losses (loss.py:165-221)"""
+        class_logits = cat(class_logits, dim=0)
+        box_regression = cat(box_regression, dim=0)
+        device = class_logits.device
+        if not hasattr(self, "_proposals"):
+            raise RuntimeError("subsample needs to be called before")
+        proposals = self._proposals
+        labels = cat([p.get_field("labels") for p in proposals], dim=0)
+        regression_targets = cat([p.get_field("regression_targets") for p in proposals], dim=0)
+        domain_masks = cat([p.get_field("domain_labels") for p in proposals], dim=0)
+        class_logits = class_logits[domain_masks, :]
+        box_regression = box_regression[domain_masks, :]
+        labels = labels[domain_masks]
+        regression_targets = regression_targets[domain_masks, :]
+        classification_loss = F.cross_entropy(class_logits, labels)
+        pos = torch.nonzero(labels > 0).squeeze(1)
+        labels_pos = labels[pos]
+        if self.cls_agnostic_bbox_reg:
+            map_inds = torch.tensor([4, 5, 6, 7], device=device)
+        else:
+            map_inds = 4 * labels_pos[:, None] + torch.tensor([0, 1, 2, 3], device=device)
+        box_loss = smooth_l1_loss(box_regression[pos[:, None], map_inds], regression_targets[pos],
+                                  size_average=False, beta=1)
+        box_loss = box_loss / labels.numel()
+        return classification_loss, box_loss, domain_masks
+
+
+def make_roi_box_loss_evaluator(cfg):
+    matcher = Matcher(cfg.MODEL.ROI_HEADS.FG_IOU_THRESHOLD, cfg.MODEL.ROI_HEADS.BG_IOU_THRESHOLD,
+                      allow_low_quality_matches=False)
+    box_coder = BoxCoder(weights=cfg.MODEL.ROI_HEADS.BBOX_REG_WEIGHTS)
+    sampler = BalancedPositiveNegativeSampler(cfg.MODEL.ROI_HEADS.BATCH_SIZE_PER_IMAGE,
+                                              cfg.MODEL.ROI_HEADS.POSITIVE_FRACTION)
+    return FastRCNNLossComputation(matcher, sampler, box_coder, cfg.MODEL.CLS_AGNOSTIC_BBOX_REG)

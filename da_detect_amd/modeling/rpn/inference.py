@@ -1,0 +1,114 @@
+"""RPN proposal selection (reference: maskrcnn_benchmark/modeling/rpn/inference.py:13-181).
+
+Same chain as the reference — sigmoid, per-image top-k, decode, clip, small-box filter, NMS, first
+post_nms_top_n, (training) append ground truth of source images — with the gather + BoxCoder.decode +
+clip_to_image done by one HIP kernel on the top-k anchors and NMS (rank, IoU bitmask, greedy sweep,
+compaction) fully on the device.
+
+Ranking rule: the reference uses `topk(sorted=True)`, whose order among EQUAL scores is unspecified (and
+differs between its CPU and CUDA builds).  Here equal scores are ordered by ascending anchor index (a
+stable descending sort), which makes proposal indices reproducible; with distinct scores the result is the
+reference's.
+"""
+import torch
+
+from ... import _C
+from ...structures.bounding_box import BoxList
+from ...structures.boxlist_ops import cat_boxlist
+from ..box_coder import BoxCoder
+from .utils import permute_and_flatten
+
+
+class RPNPostProcessor(torch.nn.Module):
+    def __init__(self, pre_nms_top_n, post_nms_top_n, nms_thresh, min_size, box_coder=None,
+                 fpn_post_nms_top_n=None):
+        super(RPNPostProcessor, self).__init__()
+        self.pre_nms_top_n = pre_nms_top_n
+        self.post_nms_top_n = post_nms_top_n
+        self.nms_thresh = nms_thresh
+        self.min_size = min_size
+        self.box_coder = box_coder if box_coder is not None else BoxCoder(weights=(1.0, 1.0, 1.0, 1.0))
+        self.fpn_post_nms_top_n = post_nms_top_n if fpn_post_nms_top_n is None else fpn_post_nms_top_n
+
+    def add_gt_proposals(self, proposals, targets):
+        """append the ground-truth boxes of SOURCE images with objectness 1 (inference.py:51-74)"""
+        device = proposals[0].bbox.device
+        out = []
+        for proposal, target in zip(proposals, targets):
+            if target.get_field("is_source").any():
+                gt = target.copy_with_fields([])
+                gt.add_field("objectness", torch.ones(len(gt), device=device))
+                out.append(cat_boxlist((proposal, gt)))
+            else:
+                out.append(proposal)
+        return out
+
+    def forward_for_single_feature_map(self, anchors, objectness, box_regression):
+        """anchors: list[BoxList] (one per image); objectness [N,A,H,W]; box_regression [N,4A,H,W]"""
+        N, A, H, W = objectness.shape
+        scores_all = permute_and_flatten(objectness, N, A, 1, H, W).reshape(N, -1).sigmoid()
+        deltas_all = permute_and_flatten(box_regression, N, A, 4, H, W).contiguous()  # [N, HWA, 4]
+        num_anchors = A * H * W
+        pre_nms_top_n = min(self.pre_nms_top_n, num_anchors)
+        sorted_scores, order = torch.sort(scores_all, dim=1, descending=True, stable=True)
+        sorted_scores = sorted_scores[:, :pre_nms_top_n].contiguous()
+        topk_idx = order[:, :pre_nms_top_n].contiguous()
+
+        result = []
+        for i in range(N):
+            im_w, im_h = anchors[i].size
+            boxes = _C.rpn_decode_clip(deltas_all[i], anchors[i].bbox.contiguous(), topk_idx[i],
+                                       self.box_coder.weights, self.box_coder.bbox_xform_clip, im_w, im_h)
+            scores = sorted_scores[i]
+            if self.min_size > 0:  # with min_size == 0 every clipped box passes (w, h >= 1)
+                keep = ((boxes[:, 2] - boxes[:, 0] + 1 >= self.min_size) &
+                        (boxes[:, 3] - boxes[:, 1] + 1 >= self.min_size)).nonzero().squeeze(1)
+                boxes, scores = boxes[keep].contiguous(), scores[keep].contiguous()
+            if self.nms_thresh > 0:
+                keep, count = _C.nms_with_count(boxes, scores, self.nms_thresh, max_keep=self.post_nms_top_n)
+                keep = keep[: int(count.item())]
+                boxes, scores = boxes[keep], scores[keep]
+            boxlist = BoxList(boxes, (im_w, im_h), mode="xyxy")
+            boxlist.add_field("objectness", scores)
+            result.append(boxlist)
+        return result
+
+    def forward(self, anchors, objectness, box_regression, targets=None):
+        sampled = []
+        num_levels = len(objectness)
+        for a, o, b in zip(list(zip(*anchors)), objectness, box_regression):
+            sampled.append(self.forward_for_single_feature_map(a, o, b))
+        boxlists = [cat_boxlist(per_image) for per_image in zip(*sampled)]
+        if num_levels > 1:
+            boxlists = self.select_over_all_levels(boxlists)
+        if self.training and targets is not None:
+            boxlists = self.add_gt_proposals(boxlists, targets)
+        return boxlists
+
+    def select_over_all_levels(self, boxlists):
+        """FPN: keep fpn_post_nms_top_n over the whole batch (train) / per image (test) (inference.py:154-181)"""
+        if self.training:
+            objectness = torch.cat([b.get_field("objectness") for b in boxlists], dim=0)
+            sizes = [len(b) for b in boxlists]
+            k = min(self.fpn_post_nms_top_n, len(objectness))
+            _, inds = torch.topk(objectness, k, dim=0, sorted=True)
+            mask = torch.zeros_like(objectness, dtype=torch.bool)
+            mask[inds] = 1
+            for i, m in enumerate(mask.split(sizes)):
+                boxlists[i] = boxlists[i][m]
+        else:
+            for i in range(len(boxlists)):
+                objectness = boxlists[i].get_field("objectness")
+                k = min(self.fpn_post_nms_top_n, len(objectness))
+                _, inds = torch.topk(objectness, k, dim=0, sorted=True)
+                boxlists[i] = boxlists[i][inds]
+        return boxlists
+
+
+def make_rpn_postprocessor(config, rpn_box_coder, is_train):
+    rpn = config.MODEL.RPN
+    return RPNPostProcessor(
+        pre_nms_top_n=rpn.PRE_NMS_TOP_N_TRAIN if is_train else rpn.PRE_NMS_TOP_N_TEST,
+        post_nms_top_n=rpn.POST_NMS_TOP_N_TRAIN if is_train else rpn.POST_NMS_TOP_N_TEST,
+        nms_thresh=rpn.NMS_THRESH, min_size=rpn.MIN_SIZE, box_coder=rpn_box_coder,
+        fpn_post_nms_top_n=rpn.FPN_POST_NMS_TOP_N_TRAIN if is_train else rpn.FPN_POST_NMS_TOP_N_TEST)

@@ -1,0 +1,79 @@
+"""RPN losses (reference: maskrcnn_benchmark/modeling/rpn/loss.py:22-178).
+
+Target-domain images carry no labels: they are skipped when targets are built, and — exactly as in the
+reference — the sampled indices computed from the source images index the flattened predictions of the whole
+batch, which is only meaningful because source images come first (asserted here)."""
+import torch
+from torch.nn import functional as F
+
+from ...layers import smooth_l1_loss
+from ...structures.boxlist_ops import boxlist_iou, cat_boxlist
+from ..balanced_positive_negative_sampler import BalancedPositiveNegativeSampler
+from ..matcher import Matcher
+from .utils import concat_box_prediction_layers
+
+
+class RPNLossComputation(object):
+    def __init__(self, proposal_matcher, fg_bg_sampler, box_coder, generate_labels_func):
+        self.proposal_matcher = proposal_matcher
+        self.fg_bg_sampler = fg_bg_sampler
+        self.box_coder = box_coder
+        self.copied_fields = []
+        self.generate_labels_func = generate_labels_func
+        self.discard_cases = ["not_visibility", "between_thresholds"]
+
+    def match_targets_to_anchors(self, anchor, target, copied_fields=[]):
+        matched_idxs = self.proposal_matcher(boxlist_iou(target, anchor))
+        target = target.copy_with_fields(copied_fields)
+        matched = target[matched_idxs.clamp(min=0)]
+        matched.add_field("matched_idxs", matched_idxs)
+        return matched
+
+    def prepare_targets(self, anchors, targets):
+        labels, regression_targets, masks = [], [], []
+        seen_target_domain = False
+        for anchors_per_image, targets_per_image in zip(anchors, targets):
+            is_source = bool(targets_per_image.get_field("is_source").any())
+            masks.append(is_source)
+            if not is_source:
+                seen_target_domain = True
+                continue
+            assert not seen_target_domain, "source-domain images must precede target-domain images in a batch"
+            matched = self.match_targets_to_anchors(anchors_per_image, targets_per_image, self.copied_fields)
+            matched_idxs = matched.get_field("matched_idxs")
+            lab = self.generate_labels_func(matched).to(dtype=torch.float32)
+            lab[matched_idxs == Matcher.BELOW_LOW_THRESHOLD] = 0
+            if "not_visibility" in self.discard_cases:
+                lab[~anchors_per_image.get_field("visibility")] = -1
+            if "between_thresholds" in self.discard_cases:
+                lab[matched_idxs == Matcher.BETWEEN_THRESHOLDS] = -1
+            labels.append(lab)
+            regression_targets.append(self.box_coder.encode(matched.bbox, anchors_per_image.bbox))
+        return labels, regression_targets, masks
+
+    def __call__(self, anchors, objectness, box_regression, targets):
+        anchors = [cat_boxlist(a) for a in anchors]
+        labels, regression_targets, _ = self.prepare_targets(anchors, targets)
+        pos_masks, neg_masks = self.fg_bg_sampler(labels)
+        pos_inds = torch.nonzero(torch.cat(pos_masks, dim=0)).squeeze(1)
+        neg_inds = torch.nonzero(torch.cat(neg_masks, dim=0)).squeeze(1)
+        sampled_inds = torch.cat([pos_inds, neg_inds], dim=0)
+        objectness, box_regression = concat_box_prediction_layers(objectness, box_regression)
+        objectness = objectness.squeeze()
+        labels = torch.cat(labels, dim=0)
+        regression_targets = torch.cat(regression_targets, dim=0)
+        box_loss = smooth_l1_loss(box_regression[pos_inds], regression_targets[pos_inds], beta=1.0 / 9,
+                                  size_average=False) / (sampled_inds.numel())
+        objectness_loss = F.binary_cross_entropy_with_logits(objectness[sampled_inds], labels[sampled_inds])
+        return objectness_loss, box_loss
+
+
+def generate_rpn_labels(matched_targets):
+    return matched_targets.get_field("matched_idxs") >= 0
+
+
+def make_rpn_loss_evaluator(cfg, box_coder):
+    matcher = Matcher(cfg.MODEL.RPN.FG_IOU_THRESHOLD, cfg.MODEL.RPN.BG_IOU_THRESHOLD,
+                      allow_low_quality_matches=True)
+    sampler = BalancedPositiveNegativeSampler(cfg.MODEL.RPN.BATCH_SIZE_PER_IMAGE, cfg.MODEL.RPN.POSITIVE_FRACTION)
+    return RPNLossComputation(matcher, sampler, box_coder, generate_rpn_labels)

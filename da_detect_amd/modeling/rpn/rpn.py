@@ -1,0 +1,80 @@
+"""Region proposal network (reference: maskrcnn_benchmark/modeling/rpn/rpn.py:13-138)."""
+import torch
+from torch import nn
+
+from ...layers import Conv2d, conv1x1_multi
+from .. import registry
+from ..box_coder import BoxCoder
+from .anchor_generator import make_anchor_generator
+from .inference import make_rpn_postprocessor
+from .loss import make_rpn_loss_evaluator
+
+
+@registry.RPN_HEADS.register("SingleConvRPNHead")
+class RPNHead(nn.Module):
+    """3x3 conv + ReLU, then 1x1 objectness (A) and 1x1 box deltas (4A) (rpn.py:13-46).  The bias + ReLU is
+    in the 3x3 GEMM's epilogue and the two 1x1 convs run as ONE GEMM of width 5A (padded to a multiple of 4)."""
+
+    def __init__(self, cfg, in_channels, num_anchors):
+        super(RPNHead, self).__init__()
+        self.conv = Conv2d(in_channels, in_channels, kernel_size=3, stride=1, padding=1)
+        self.cls_logits = Conv2d(in_channels, num_anchors, kernel_size=1, stride=1)
+        self.bbox_pred = Conv2d(in_channels, num_anchors * 4, kernel_size=1, stride=1)
+        for l in (self.conv, self.cls_logits, self.bbox_pred):
+            torch.nn.init.normal_(l.weight, std=0.01)
+            torch.nn.init.constant_(l.bias, 0)
+
+    def forward(self, x):
+        logits, bbox_reg = [], []
+        for feature in x:
+            t = self.conv(feature, relu=True)
+            cls, box = conv1x1_multi(t, [self.cls_logits.weight, self.bbox_pred.weight],
+                                     [self.cls_logits.bias, self.bbox_pred.bias])
+            logits.append(cls)
+            bbox_reg.append(box)
+        return logits, bbox_reg
+
+
+class RPNModule(torch.nn.Module):
+    def __init__(self, cfg):
+        super(RPNModule, self).__init__()
+        self.cfg = cfg.clone()
+        anchor_generator = make_anchor_generator(cfg)
+        in_channels = cfg.MODEL.BACKBONE.OUT_CHANNELS
+        head = registry.RPN_HEADS[cfg.MODEL.RPN.RPN_HEAD](cfg, in_channels,
+                                                         anchor_generator.num_anchors_per_location()[0])
+        rpn_box_coder = BoxCoder(weights=(1.0, 1.0, 1.0, 1.0))
+        self.anchor_generator = anchor_generator
+        self.head = head
+        self.box_selector_train = make_rpn_postprocessor(cfg, rpn_box_coder, is_train=True)
+        self.box_selector_test = make_rpn_postprocessor(cfg, rpn_box_coder, is_train=False)
+        self.loss_evaluator = make_rpn_loss_evaluator(cfg, rpn_box_coder)
+
+    def forward(self, images, features, targets=None):
+        objectness, rpn_box_regression = self.head(features)
+        anchors = self.anchor_generator(images, features)
+        if self.training:
+            return self._forward_train(anchors, objectness, rpn_box_regression, targets)
+        return self._forward_test(anchors, objectness, rpn_box_regression)
+
+    def _forward_train(self, anchors, objectness, rpn_box_regression, targets):
+        if self.cfg.MODEL.RPN_ONLY:
+            boxes = anchors
+        else:
+            with torch.no_grad():
+                boxes = self.box_selector_train(anchors, objectness, rpn_box_regression, targets)
+        loss_objectness, loss_rpn_box_reg = self.loss_evaluator(anchors, objectness, rpn_box_regression, targets)
+        return boxes, {"loss_objectness": loss_objectness, "loss_rpn_box_reg": loss_rpn_box_reg}
+
+    def _forward_test(self, anchors, objectness, rpn_box_regression):
+        boxes = self.box_selector_test(anchors, objectness, rpn_box_regression)
+        if self.cfg.MODEL.RPN_ONLY:
+            inds = [b.get_field("objectness").sort(descending=True)[1] for b in boxes]
+            boxes = [b[ind] for b, ind in zip(boxes, inds)]
+        return boxes, {}
+
+
+def build_rpn(cfg):
+    if cfg.MODEL.RETINANET_ON:
+        raise NotImplementedError("RetinaNet is outside the DA Faster R-CNN path (SURVEY.md section 2.1 row 8)")
+    return RPNModule(cfg)

@@ -1,0 +1,100 @@
+"""SGD with momentum as ONE multi-tensor HIP launch per step.
+
+Numerically torch.optim.SGD (dampening 0, no nesterov): d = g + wd * p; buf = d (first step) or
+momentum * buf + d; p -= lr * buf — applied to the reference's one-param-group-per-tensor layout
+(reference: maskrcnn_benchmark/solver/build.py:7-20, engine/trainer.py:237-239) by dadet_sgd_step, which reads a
+device-resident table of (p, g, buf, numel, lr, weight_decay) entries.  It subclasses torch.optim.Optimizer so
+LR schedulers and checkpoint code that walk `param_groups` / `state_dict()` keep working.
+"""
+import ctypes
+
+import torch
+
+from .. import _lib
+from .._lib import SgdEntry
+
+
+class FusedSGD(torch.optim.Optimizer):
+    def __init__(self, params, lr, momentum=0.0, weight_decay=0.0):
+        defaults = dict(lr=lr, momentum=momentum, weight_decay=weight_decay)
+        super(FusedSGD, self).__init__(params, defaults)
+        self._table = None       # (key, device tensor, max_numel, n)
+        self._steps = 0
+        self.reducer = None      # optional parallel.reducer.BucketedGradReducer owning the .grad storage
+
+    def attach_reducer(self, reducer):
+        """gradients live in the reducer's flat buckets: zero_grad() clears them in place (stable pointers)
+        and step() first completes the outstanding all-reduces"""
+        self.reducer = reducer
+
+    def zero_grad(self, set_to_none=True):
+        if self.reducer is not None:
+            self.reducer.zero_grad()
+        else:
+            super(FusedSGD, self).zero_grad(set_to_none=set_to_none)
+
+    def _entries(self):
+        out = []
+        for group in self.param_groups:
+            for p in group["params"]:
+                if p.grad is None:
+                    continue
+                out.append((p, group["lr"], group["weight_decay"], group["momentum"]))
+        return out
+
+    @torch.no_grad()
+    def step(self, closure=None, grad_scale=1.0):
+        loss = None
+        if closure is not None:
+            with torch.enable_grad():
+                loss = closure()
+        if self.reducer is not None:
+            self.reducer.finalize()
+        entries = self._entries()
+        if not entries:
+            return loss
+        momentum = entries[0][3]
+        assert all(e[3] == momentum for e in entries), "FusedSGD: one momentum for all groups"
+        first = []
+        rows = []
+        for p, lr, wd, _ in entries:
+            if not p.is_cuda:
+                raise _lib.DadetError("FusedSGD runs on the HIP device only")
+            g = p.grad
+            if g.stride() != p.stride() or not _dense(p):
+                # the kernel walks raw storage: gradient must share the parameter's physical layout
+                g = _like_layout(g, p)
+                p.grad = g
+            st = self.state[p]
+            if "momentum_buffer" not in st:
+                st["momentum_buffer"] = torch.empty_strided(p.size(), p.stride(), dtype=p.dtype, device=p.device)
+                first.append(True)
+            else:
+                first.append(False)
+            rows.append((p.data_ptr(), g.data_ptr(), st["momentum_buffer"].data_ptr(), p.numel(), lr, wd))
+        assert all(first) or not any(first), "FusedSGD: parameters joined after the first step are not supported"
+        key = tuple(rows)
+        if self._table is None or self._table[0] != key:
+            arr = (SgdEntry * len(rows))()
+            for i, r in enumerate(rows):
+                arr[i].p, arr[i].g, arr[i].buf, arr[i].numel, arr[i].lr, arr[i].weight_decay = r
+            raw = bytes(arr)
+            host = torch.frombuffer(bytearray(raw), dtype=torch.uint8)
+            dev = host.to(entries[0][0].device)
+            self._table = (key, dev, max(r[3] for r in rows), len(rows))
+        _, dev, max_numel, n = self._table
+        _lib.call("dadet_sgd_step", ctypes.c_void_p(dev.data_ptr()), n, ctypes.c_int64(max_numel),
+                  float(momentum), 1 if all(first) else 0, float(grad_scale),
+                  ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+        self._steps += 1
+        return loss
+
+
+def _dense(t):
+    return t.is_contiguous() or t.is_contiguous(memory_format=torch.channels_last)
+
+
+def _like_layout(g, p):
+    out = torch.empty_strided(p.size(), p.stride(), dtype=g.dtype, device=g.device)
+    out.copy_(g)
+    return out
