@@ -1,0 +1,183 @@
+#!/usr/bin/env python
+"""bench.py — train images/sec of DA Faster R-CNN R-50-C4 on synthetic Cityscapes-shaped batches.
+
+Workload (BASELINE.json configs[1]): configs/da_faster_rcnn/e2e_da_faster_rcnn_R_50_C4_img_only.yaml — image-level
+DA head only, 1 source + 1 target image of 1024 x 2048 per GPU per step (SOLVER.IMS_PER_BATCH = 2 * n_gpus),
+256 ROIs per image and per box-head pass, SGD(momentum) step included.  One "step" = forward + backward
+(+ bucketed gradient all-reduce when n_gpus > 1) + fused SGD over one such batch; inputs are resident in HBM
+before the timed region.  Weak scaling: every rank processes its own (source, target) pair.
+
+Launch:  python bench.py --gpus 1 --steps K --warmup W
+         python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+                bench.py --gpus N --steps K --warmup W
+Rank 0 prints ONE JSON line (metric / value / roofline / cpu_baseline ...).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+YAML = "configs/da_faster_rcnn/e2e_da_faster_rcnn_R_50_C4_img_only.yaml"
+HEIGHT, WIDTH, IMAGES_PER_GPU = 1024, 2048, 2
+FP32_MFMA_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 64 FLOP/clk/SIMD x 1024 SIMDs x 2.4 GHz
+
+
+def benchmark_init(model, seed):
+    """seeded variance-preserving random init (no network for the MSRA R-50 pickle): He-normal conv weights,
+    identity FrozenBN statistics, the last BN of every bottleneck scaled by 0.25 so that 16 un-normalised
+    residual blocks keep O(1) activations.  Head initialisers are the reference's own (normal 0.01 / 0.001)."""
+    from da_detect_amd.layers import FrozenBatchNorm2d
+    from da_detect_amd.modeling.backbone.resnet import Bottleneck
+
+    g = torch.Generator().manual_seed(seed)
+    for mod in model.modules():
+        if isinstance(mod, Bottleneck):
+            convs = [mod.conv1, mod.conv2, mod.conv3] + ([mod.downsample[0]] if mod.downsample is not None else [])
+            for conv in convs:
+                fan_in = conv.weight.shape[1] * conv.weight.shape[2] * conv.weight.shape[3]
+                w = torch.randn(conv.weight.shape, generator=g) * (2.0 / fan_in) ** 0.5
+                conv.weight.data.copy_(w)
+            mod.bn3.weight.fill_(0.25)
+    stem = model.backbone.body.stem
+    stem.conv1.weight.data.copy_(torch.randn(stem.conv1.weight.shape, generator=g) * (2.0 / 147) ** 0.5 / 60.0)
+    for mod in model.modules():
+        if isinstance(mod, FrozenBatchNorm2d):
+            mod._cache = None
+
+
+def build(cfg_path, device, seed):
+    from da_detect_amd.config import cfg
+    from da_detect_amd.modeling.detector import build_detection_model
+    from da_detect_amd.parallel.reducer import BucketedGradReducer
+    from da_detect_amd.solver import make_optimizer
+
+    c = cfg.clone()
+    c.merge_from_file(os.path.join(ROOT, cfg_path))
+    torch.manual_seed(seed)
+    model = build_detection_model(c)
+    benchmark_init(model, seed)
+    model = model.to(device)
+    model.train()
+    opt = make_optimizer(c, model)
+    reducer = BucketedGradReducer([p for p in model.parameters() if p.requires_grad])
+    reducer.broadcast_parameters(0)
+    opt.attach_reducer(reducer)
+    return c, model, opt, reducer
+
+
+def cpu_baseline(cfg_path, seed, budget_s=25.0):
+    """the CPU oracle (oracle/model_ref.py: a torch-CPU fp32 restatement of the same training step, with the
+    C restatements of NMS / ROIAlign) timed on the host cores on a bounded sample of the same workload."""
+    from oracle import model_ref
+
+    return model_ref.timed_training_sample(os.path.join(ROOT, cfg_path), seed, HEIGHT, WIDTH, IMAGES_PER_GPU,
+                                           benchmark_init, budget_s)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-timing", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device: the product path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", init_method="env://")  # "nccl" is RCCL on ROCm
+    assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
+
+    from da_detect_amd import _C
+    from da_detect_amd.data.synthetic import make_batch
+    from da_detect_amd.engine.trainer import train_step
+
+    c, model, opt, reducer = build(YAML, device, seed=100)
+    images, targets = make_batch(c, IMAGES_PER_GPU, HEIGHT, WIDTH, seed=100 + rank, device=device)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        loss_dict = train_step(model, opt, images, targets)
+    profiler = None
+    if not args.no_kernel_timing and rank == 0:
+        profiler = _C.KernelProfiler()
+        _C.PROFILER = profiler
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss_dict = train_step(model, opt, images, targets)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    _C.PROFILER = None
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    losses = {k: float(v.detach()) for k, v in loss_dict.items()}
+
+    if rank == 0:
+        value = world * IMAGES_PER_GPU * args.steps / elapsed
+        roofline = None
+        kernels = {}
+        if profiler is not None:
+            kernels = profiler.summary()
+            name = max(kernels, key=lambda k: kernels[k]["total_ms"])
+            k = kernels[name]
+            achieved = k["achieved"] / 1e12
+            roofline = {"bound": "mfma", "kernel": name, "achieved": round(achieved, 2),
+                        "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                        "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
+                        "launches_per_step": k["launches"] / args.steps,
+                        "avg_launch_ms": round(k["avg_ms"], 4),
+                        "gflop_per_launch": round(k["work_per_launch"] / 1e9, 3),
+                        "share_of_step": round(k["total_ms"] / (elapsed * 1e3), 4)}
+        cpu = None
+        if not args.no_cpu_baseline and world == 1:
+            try:
+                cpu = cpu_baseline(YAML, seed=100)
+            except Exception as e:  # the baseline is reported, never required for the GPU number
+                cpu = {"value": None, "unit": "images/s", "cores": os.cpu_count(), "kind": "port",
+                       "sample": "failed: %r" % (e,)}
+        line = {
+            "metric": "train images/sec, DA-Faster-RCNN R-50 Cityscapes->Foggy",
+            "value": round(value, 3), "unit": "images/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+            "data": "synthetic (seeded rand*255 - PIXEL_MEAN images, 8-20 seeded boxes/image, seeded random-init weights)",
+            "config": {"workload": "configs/da_faster_rcnn R-50-C4, image-level DA head only, 1 source + 1 target "
+                                   "1024x2048 image per GPU per step, 2x256 ROIs x 2 box-head passes, fwd+bwd+SGD",
+                       "yaml": YAML, "global_batch": world * IMAGES_PER_GPU, "image_hw": [HEIGHT, WIDTH],
+                       "parallelism": "dp%d" % world},
+            "roofline": roofline, "cpu_baseline": cpu,
+            "kernel_timing": {k: {"launches": v["launches"], "total_ms": round(v["total_ms"], 3),
+                                  "tflops": round(v["achieved"] / 1e12, 2)} for k, v in kernels.items()},
+            "final_losses": {k: round(v, 5) for k, v in losses.items()},
+        }
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -24,6 +24,44 @@ CL = torch.channels_last
 # rule, so that is the default; set to 1 to reproduce the CUDA build.
 NMS_TIE_RULE = 0
 
+# optional per-launch timing of the GEMM kernels (bench.py sets this to a KernelProfiler; None = off)
+PROFILER = None
+
+
+class KernelProfiler(object):
+    """HIP-event bracket around kernel launches on the CURRENT stream (the stream the kernels are launched
+    on); elapsed times are read after a device synchronise, never inside the timed region."""
+
+    def __init__(self):
+        self.records = {}   # name -> list of (start_event, end_event, algorithmic_flops)
+
+    class _Span(object):
+        def __init__(self, prof, name, work):
+            self.prof, self.name, self.work = prof, name, work
+
+        def __enter__(self):
+            self.s = torch.cuda.Event(enable_timing=True)
+            self.e = torch.cuda.Event(enable_timing=True)
+            self.s.record()
+
+        def __exit__(self, *exc):
+            self.e.record()
+            self.prof.records.setdefault(self.name, []).append((self.s, self.e, self.work))
+
+    def span(self, name, work):
+        return KernelProfiler._Span(self, name, work)
+
+    def summary(self):
+        """name -> dict(launches, total_ms, avg_ms, work_per_launch, achieved = work / time per second)"""
+        torch.cuda.synchronize()
+        out = {}
+        for name, recs in self.records.items():
+            ms = sum(s.elapsed_time(e) for s, e, _ in recs)
+            work = sum(w for _, _, w in recs)
+            out[name] = dict(launches=len(recs), total_ms=ms, avg_ms=ms / len(recs),
+                             work_per_launch=work / len(recs), achieved=work / (ms * 1e-3) if ms > 0 else 0.0)
+        return out
+
 
 def _stream():
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
@@ -170,6 +208,13 @@ def conv_forward(x, w, scale=None, bias=None, addend=None, mask_ref=None, stride
     if mask_ref is not None:
         mask_ref = _nhwc(mask_ref)
     d = _desc(N, H, W, Cin, Cout, KH, KW, stride, pad, Ho, Wo, OutH, OutW, out_spatial_stride, relu_mode)
+    if PROFILER is not None:
+        variant = _lib.load().dadet_conv_forward_variant(ctypes.byref(d))
+        with PROFILER.span("conv_fwd_kernel<%s>" % ("2,2", "2,1", "1,1")[variant],
+                           2.0 * N * Ho * Wo * Cout * Cin * KH * KW):
+            _lib.call("dadet_conv_forward", ctypes.byref(d), _p(x), _p(w), _p(scale), _p(bias), _p(addend),
+                      _p(mask_ref), _p(out), _stream())
+        return out
     _lib.call("dadet_conv_forward", ctypes.byref(d), _p(x), _p(w), _p(scale), _p(bias), _p(addend),
               _p(mask_ref), _p(out), _stream())
     return out
@@ -201,6 +246,11 @@ def conv_wgrad(x, gy, weight_shape, stride=1, pad=0, out_scale=None, dw=None, ac
     nbytes = ctypes.c_size_t(0)
     _lib.call("dadet_conv_wgrad_workspace_bytes", ctypes.byref(d), ctypes.byref(nbytes))
     ws = _workspace(nbytes.value, x.device)
+    if PROFILER is not None:
+        with PROFILER.span("conv_wgrad_kernel", 2.0 * N * Ho * Wo * Cout * Cin * KH * KW):
+            _lib.call("dadet_conv_wgrad", ctypes.byref(d), _p(x), _p(gy), _p(out_scale), _p(dw),
+                      1 if accumulate else 0, _p(ws), ctypes.c_size_t(ws.numel()), _stream())
+        return dw
     _lib.call("dadet_conv_wgrad", ctypes.byref(d), _p(x), _p(gy), _p(out_scale), _p(dw),
               1 if accumulate else 0, _p(ws), ctypes.c_size_t(ws.numel()), _stream())
     return dw

@@ -429,6 +429,19 @@ static int launch_fwd(ConvArgs& a, hipStream_t st) {
   return check_launch("conv_forward");
 }
 
+// tile choice: widest tile whose grid still gives every CU about two workgroups
+//   0: 128x128 (conv_fwd_kernel<2,2>)   1: 128x64 (<2,1>)   2: 64x64 (<1,1>)
+static int fwd_variant(int M, int Cout) {
+  const int64_t t128 = (int64_t)ceil_div(M, 128) * ceil_div(Cout, 128);
+  if (Cout > 64 && t128 >= 2 * kNumCU) return 0;
+  if (Cout > 32) {
+    const int64_t t64 = (int64_t)ceil_div(M, 128) * ceil_div(Cout, 64);
+    if (t64 >= kNumCU || M <= 64 * 64) return 1;
+    return 2;
+  }
+  return 1;
+}
+
 extern "C" int dadet_conv_forward(const dadet_conv_desc* d, const float* x, const float* w,
                                   const float* scale, const float* bias, const float* addend,
                                   const float* mask_ref, float* y, void* stream) {
@@ -450,15 +463,16 @@ extern "C" int dadet_conv_forward(const dadet_conv_desc* d, const float* x, cons
   a.M = d->N * d->Ho * d->Wo;
   a.K = d->KH * d->KW * d->Cin;
   hipStream_t st = as_stream(stream);
-  // tile choice: widest tile whose grid still gives every CU about two workgroups
-  const int64_t t128 = (int64_t)ceil_div(a.M, 128) * ceil_div(a.Cout, 128);
-  if (a.Cout > 64 && t128 >= 2 * kNumCU) return launch_fwd<2, 2>(a, st);
-  if (a.Cout > 32) {
-    const int64_t t64 = (int64_t)ceil_div(a.M, 128) * ceil_div(a.Cout, 64);
-    if (t64 >= kNumCU || a.M <= 64 * 64) return launch_fwd<2, 1>(a, st);
-    return launch_fwd<1, 1>(a, st);
+  switch (fwd_variant(a.M, a.Cout)) {
+    case 0: return launch_fwd<2, 2>(a, st);
+    case 1: return launch_fwd<2, 1>(a, st);
+    default: return launch_fwd<1, 1>(a, st);
   }
-  return launch_fwd<2, 1>(a, st);
+}
+
+extern "C" int dadet_conv_forward_variant(const dadet_conv_desc* d) {
+  if (!d) return -1;
+  return fwd_variant(d->N * d->Ho * d->Wo, d->Cout);
 }
 
 static void wgrad_plan(const dadet_conv_desc* d, int* tiles_co, int* tiles_kc, int* splits, int* rps) {

@@ -31,6 +31,7 @@ class BucketedGradReducer(object):
         self._bucket_of = {}
         self._build(bucket_bytes)
         self._hooks = [p.register_post_accumulate_grad_hook(self._on_grad) for p in self.params]
+        self._next = 0
         self._finalized = True
 
     def _build(self, bucket_bytes):
@@ -64,25 +65,31 @@ class BucketedGradReducer(object):
             b["flat"].zero_()
             b["pending"] = len(b["params"])
             b["work"] = None
+        self._next = 0
         self._finalized = False
 
-    def _launch(self, b):
-        if self.world_size > 1:
-            b["work"] = dist.all_reduce(b["flat"], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+    def _launch_ready(self, force=False):
+        """collectives must be issued in the same order on every rank: buckets are launched strictly by index,
+        a ready bucket waits for its predecessors (which may only complete in finalize() on some ranks)"""
+        while self._next < len(self.buckets):
+            b = self.buckets[self._next]
+            if b["pending"] > 0 and not force:
+                return
+            if self.world_size > 1:
+                b["work"] = dist.all_reduce(b["flat"], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+            self._next += 1
 
     def _on_grad(self, p):
         b = self._bucket_of[id(p)]
         b["pending"] -= 1
-        if b["pending"] == 0:
-            self._launch(b)
+        if b["pending"] == 0 and not self._finalized:
+            self._launch_ready()
 
     def finalize(self):
         """reduce buckets that never completed, wait for every collective, turn sums into means"""
         if self._finalized:
             return
-        for b in self.buckets:
-            if b["pending"] > 0 and b["work"] is None:
-                self._launch(b)
+        self._launch_ready(force=True)
         if self.world_size > 1:
             for b in self.buckets:
                 if b["work"] is not None:

@@ -118,6 +118,10 @@ int dadet_conv_forward(const dadet_conv_desc* d, const float* x, const float* w,
                        const float* bias, const float* addend, const float* mask_ref, float* y,
                        void* stream);
 
+/* which tile variant dadet_conv_forward launches for this shape: 0 = 128x128 (conv_fwd_kernel<2,2>),
+ * 1 = 128x64 (<2,1>), 2 = 64x64 (<1,1>).  Used by bench.py to attribute per-launch timings. */
+int dadet_conv_forward_variant(const dadet_conv_desc* d);
+
 /* weight gradient: dw[co][r][s][ci] = out_scale[co] * sum_m gy[m][co] * x[gather(m, r, s)][ci]
  * (+ dw_prev when accumulate != 0).  Deterministic split-K over m through `workspace`
  * (query with dadet_conv_wgrad_workspace_bytes).  gy is [N][Ho][Wo][Cout] dense. */

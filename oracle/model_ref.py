@@ -1,0 +1,539 @@
+"""CPU restatement of the DA Faster R-CNN training step (torch fp32 on the CPU + oracle/dadet_oracle.c).
+
+TEST INFRASTRUCTURE ONLY (see oracle/dadet_oracle.c): imported by tests/, __graft_entry__.smoke() and bench.py's
+cpu_baseline leg; never by da_detect_amd/.  It is a flat, functional re-statement — plain tensors and dicts, no
+BoxList / nn.Module — of what the reference executes for one training iteration, written against the reference
+source, each function citing the lines it follows.  Floating-point contractions are torch's own CPU kernels (the
+"plain PyTorch fp32 reference" for the GEMM-shaped kernels); NMS and ROIAlign go through the C oracle.
+
+Parity status: PINNED against the imported Python reference (tests/golden/make_golden.py runs the reference from
+/root/reference on the CPU with identical weights / inputs / RNG seed and stores its loss dictionaries and
+intermediate tensors under tests/golden/; tests/test_oracle_golden.py replays them through this file).
+
+Random draws follow the reference's call order on the global CPU generator (sampler randperm:
+modeling/balanced_positive_negative_sampler.py:57-58; F.dropout in da_heads.py:63,65), so one torch.manual_seed
+reproduces the reference's sampled indices and dropout masks.
+"""
+import math
+import os
+import time
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+from . import ops as O
+
+BELOW_LOW, BETWEEN = -1, -2
+
+
+# ------------------------------------------------------------------------------------------------- layers
+def frozen_bn(x, sd, prefix):
+    """x * scale + bias with scale = weight * rsqrt(running_var) (layers/batch_norm.py:19-24)"""
+    scale = sd[prefix + ".weight"] * sd[prefix + ".running_var"].rsqrt()
+    bias = sd[prefix + ".bias"] - sd[prefix + ".running_mean"] * scale
+    return x * scale.reshape(1, -1, 1, 1) + bias.reshape(1, -1, 1, 1)
+
+
+def bottleneck(x, sd, p, stride):
+    """modeling/backbone/resnet.py:294-314 with STRIDE_IN_1X1 (the stride sits in conv1 and the shortcut)"""
+    out = F.relu(frozen_bn(F.conv2d(x, sd[p + ".conv1.weight"], None, stride), sd, p + ".bn1"))
+    out = F.relu(frozen_bn(F.conv2d(out, sd[p + ".conv2.weight"], None, 1, 1), sd, p + ".bn2"))
+    out = frozen_bn(F.conv2d(out, sd[p + ".conv3.weight"], None), sd, p + ".bn3")
+    if (p + ".downsample.0.weight") in sd:
+        x = frozen_bn(F.conv2d(x, sd[p + ".downsample.0.weight"], None, stride), sd, p + ".downsample.1")
+    return F.relu(out + x)
+
+
+def stage(x, sd, prefix, blocks, first_stride):
+    for b in range(blocks):
+        x = bottleneck(x, sd, "%s.%d" % (prefix, b), first_stride if b == 0 else 1)
+    return x
+
+
+def backbone_c4(images, sd, blocks=(3, 4, 6)):
+    """stem + layer1..3 (resnet.py:138-145, 331-336)"""
+    p = "backbone.body"
+    x = F.relu(frozen_bn(F.conv2d(images, sd[p + ".stem.conv1.weight"], None, 2, 3), sd, p + ".stem.bn1"))
+    x = F.max_pool2d(x, kernel_size=3, stride=2, padding=1)
+    x = stage(x, sd, p + ".layer1", blocks[0], 1)
+    x = stage(x, sd, p + ".layer2", blocks[1], 2)
+    return stage(x, sd, p + ".layer3", blocks[2], 2)
+
+
+# ------------------------------------------------------------------------------------------------ anchors
+def cell_anchors(stride, sizes, ratios):
+    """modeling/rpn/anchor_generator.py:222-291"""
+    def whc(a):
+        w, h = a[2] - a[0] + 1, a[3] - a[1] + 1
+        return w, h, a[0] + 0.5 * (w - 1), a[1] + 0.5 * (h - 1)
+
+    def mk(ws, hs, cx, cy):
+        ws, hs = ws[:, None], hs[:, None]
+        return np.hstack((cx - 0.5 * (ws - 1), cy - 0.5 * (hs - 1), cx + 0.5 * (ws - 1), cy + 0.5 * (hs - 1)))
+
+    base = np.array([1, 1, stride, stride], dtype=np.float64) - 1
+    w, h, cx, cy = whc(base)
+    ws = np.round(np.sqrt(w * h / np.array(ratios, dtype=np.float64)))
+    hs = np.round(ws * np.array(ratios, dtype=np.float64))
+    out = []
+    for a in mk(ws, hs, cx, cy):
+        w, h, cx, cy = whc(a)
+        sc = np.array(sizes, dtype=np.float64) / stride
+        out.append(mk(w * sc, h * sc, cx, cy))
+    return torch.from_numpy(np.vstack(out)).float()
+
+
+def grid_anchors(fh, fw, stride, cell):
+    """anchor index = (y*fw + x)*A + a (anchor_generator.py:73-97)"""
+    sx = torch.arange(0, fw * stride, step=stride, dtype=torch.float32)
+    sy = torch.arange(0, fh * stride, step=stride, dtype=torch.float32)
+    yy, xx = torch.meshgrid(sy, sx, indexing="ij")
+    shifts = torch.stack((xx.reshape(-1), yy.reshape(-1), xx.reshape(-1), yy.reshape(-1)), dim=1)
+    return (shifts.view(-1, 1, 4) + cell.view(1, -1, 4)).reshape(-1, 4)
+
+
+# ----------------------------------------------------------------------------------------- box arithmetic
+def box_area(b):
+    return (b[:, 2] - b[:, 0] + 1) * (b[:, 3] - b[:, 1] + 1)
+
+
+def box_iou(a, b):
+    """structures/boxlist_ops.py:56-91"""
+    lt = torch.max(a[:, None, :2], b[:, :2])
+    rb = torch.min(a[:, None, 2:], b[:, 2:])
+    wh = (rb - lt + 1).clamp(min=0)
+    inter = wh[:, :, 0] * wh[:, :, 1]
+    return inter / (box_area(a)[:, None] + box_area(b) - inter)
+
+
+def encode(ref, prop, weights):
+    """modeling/box_coder.py:22-50"""
+    ew, eh = prop[:, 2] - prop[:, 0] + 1, prop[:, 3] - prop[:, 1] + 1
+    ecx, ecy = prop[:, 0] + 0.5 * ew, prop[:, 1] + 0.5 * eh
+    gw, gh = ref[:, 2] - ref[:, 0] + 1, ref[:, 3] - ref[:, 1] + 1
+    gcx, gcy = ref[:, 0] + 0.5 * gw, ref[:, 1] + 0.5 * gh
+    wx, wy, ww, wh = weights
+    return torch.stack((wx * (gcx - ecx) / ew, wy * (gcy - ecy) / eh, ww * torch.log(gw / ew),
+                        wh * torch.log(gh / eh)), dim=1)
+
+
+def decode(codes, boxes, weights, clip=math.log(1000.0 / 16)):
+    """modeling/box_coder.py:52-95 for [N,4] codes"""
+    w, h = boxes[:, 2] - boxes[:, 0] + 1, boxes[:, 3] - boxes[:, 1] + 1
+    cx, cy = boxes[:, 0] + 0.5 * w, boxes[:, 1] + 0.5 * h
+    wx, wy, ww, wh = weights
+    dx, dy = codes[:, 0] / wx, codes[:, 1] / wy
+    dw = torch.clamp(codes[:, 2] / ww, max=clip)
+    dh = torch.clamp(codes[:, 3] / wh, max=clip)
+    pcx, pcy = dx * w + cx, dy * h + cy
+    pw, ph = torch.exp(dw) * w, torch.exp(dh) * h
+    return torch.stack((pcx - 0.5 * pw, pcy - 0.5 * ph, pcx + 0.5 * pw - 1, pcy + 0.5 * ph - 1), dim=1)
+
+
+def matcher(iou, high, low, allow_low_quality):
+    """modeling/matcher.py:42-112"""
+    vals, matches = iou.max(dim=0)
+    all_matches = matches.clone()
+    matches[vals < low] = BELOW_LOW
+    matches[(vals >= low) & (vals < high)] = BETWEEN
+    if allow_low_quality:
+        best, _ = iou.max(dim=1)
+        upd = torch.nonzero(iou == best[:, None])[:, 1]
+        matches[upd] = all_matches[upd]
+    return matches
+
+
+def sample_pos_neg(labels, batch_size, positive_fraction):
+    """modeling/balanced_positive_negative_sampler.py:27-76 for one image -> (pos mask, neg mask)"""
+    positive = torch.nonzero(labels >= 1).squeeze(1)
+    negative = torch.nonzero(labels == 0).squeeze(1)
+    num_pos = min(positive.numel(), int(batch_size * positive_fraction))
+    num_neg = min(negative.numel(), batch_size - num_pos)
+    perm1 = torch.randperm(positive.numel())[:num_pos]
+    perm2 = torch.randperm(negative.numel())[:num_neg]
+    pm = torch.zeros_like(labels, dtype=torch.bool)
+    nm = torch.zeros_like(labels, dtype=torch.bool)
+    pm[positive[perm1]] = 1
+    nm[negative[perm2]] = 1
+    return pm, nm
+
+
+def smooth_l1(x, t, beta):
+    """layers/smooth_l1_loss.py:6-16, summed"""
+    n = torch.abs(x - t)
+    return torch.where(n < beta, 0.5 * n ** 2 / beta, n - 0.5 * beta).sum()
+
+
+# ---------------------------------------------------------------------------------------------- ROIAlign
+class _RoiAlign(torch.autograd.Function):
+    """forward: csrc/cpu/ROIAlign_cpu.cpp; backward: csrc/cuda/ROIAlign_cuda.cu:178-254 (C oracle)"""
+
+    @staticmethod
+    def forward(ctx, x, rois, scale, ph, pw, sr):
+        ctx.save_for_backward(rois)
+        ctx.args = (scale, ph, pw, sr, tuple(x.shape))
+        return torch.from_numpy(O.roi_align_forward(x.detach().numpy(), rois.numpy(), scale, ph, pw, sr))
+
+    @staticmethod
+    def backward(ctx, g):
+        (rois,) = ctx.saved_tensors
+        scale, ph, pw, sr, (B, C, H, W) = ctx.args
+        gin = O.roi_align_backward(g.contiguous().numpy(), rois.numpy(), scale, ph, pw, B, C, H, W, sr)
+        return torch.from_numpy(gin), None, None, None, None, None
+
+
+def roi_align(x, rois, scale, ph, pw, sr):
+    return _RoiAlign.apply(x, rois, scale, ph, pw, sr)
+
+
+# --------------------------------------------------------------------------------------------------- RPN
+def rpn_head(feat, sd):
+    """modeling/rpn/rpn.py:39-46"""
+    t = F.relu(F.conv2d(feat, sd["rpn.head.conv.weight"], sd["rpn.head.conv.bias"], 1, 1))
+    return (F.conv2d(t, sd["rpn.head.cls_logits.weight"], sd["rpn.head.cls_logits.bias"]),
+            F.conv2d(t, sd["rpn.head.bbox_pred.weight"], sd["rpn.head.bbox_pred.bias"]))
+
+
+def flatten_hwa(layer, C):
+    """rpn/utils.py:10-14: [N, A*C, H, W] -> [N, H*W*A, C]"""
+    N, _, H, W = layer.shape
+    return layer.view(N, -1, C, H, W).permute(0, 3, 4, 1, 2).reshape(N, -1, C)
+
+
+def rpn_proposals(objectness, deltas, anchors, image_sizes, gts, cfg, training):
+    """rpn/inference.py:76-152: per image (boxes [P,4], objectness [P]).  Equal scores are ranked by ascending
+    anchor index (stable sort); the reference's topk leaves that order unspecified."""
+    rpn = cfg.MODEL.RPN
+    pre = rpn.PRE_NMS_TOP_N_TRAIN if training else rpn.PRE_NMS_TOP_N_TEST
+    post = rpn.POST_NMS_TOP_N_TRAIN if training else rpn.POST_NMS_TOP_N_TEST
+    N = objectness.shape[0]
+    scores = flatten_hwa(objectness, 1).reshape(N, -1).sigmoid()
+    d = flatten_hwa(deltas, 4)
+    pre = min(pre, scores.shape[1])
+    out = []
+    for i in range(N):
+        s, order = torch.sort(scores[i], descending=True, stable=True)
+        s, order = s[:pre], order[:pre]
+        h, w = image_sizes[i]
+        boxes = torch.from_numpy(O.decode_clip(d[i][order].numpy(), anchors[order].numpy(), (1.0, 1.0, 1.0, 1.0),
+                                               math.log(1000.0 / 16), w, h))
+        if rpn.MIN_SIZE > 0:
+            keep = ((boxes[:, 2] - boxes[:, 0] + 1 >= rpn.MIN_SIZE) & (boxes[:, 3] - boxes[:, 1] + 1 >= rpn.MIN_SIZE))
+            boxes, s = boxes[keep], s[keep]
+        keep = torch.from_numpy(O.nms(boxes.numpy(), s.numpy(), rpn.NMS_THRESH, 0))[:post]
+        boxes, s = boxes[keep], s[keep]
+        if training and gts[i]["is_source"].any():  # add_gt_proposals, source images only
+            boxes = torch.cat([boxes, gts[i]["boxes"]], 0)
+            s = torch.cat([s, torch.ones(len(gts[i]["boxes"]))], 0)
+        out.append((boxes, s))
+    return out
+
+
+def rpn_losses(objectness, deltas, anchors, image_sizes, gts, cfg):
+    """rpn/loss.py:57-143"""
+    rpn = cfg.MODEL.RPN
+    labels, reg_targets = [], []
+    for i, gt in enumerate(gts):
+        if not gt["is_source"].any():
+            continue
+        h, w = image_sizes[i]
+        m = matcher(box_iou(gt["boxes"], anchors), rpn.FG_IOU_THRESHOLD, rpn.BG_IOU_THRESHOLD, True)
+        matched = gt["boxes"][m.clamp(min=0)]
+        lab = (m >= 0).to(torch.float32)
+        lab[m == BELOW_LOW] = 0
+        t = rpn.STRADDLE_THRESH
+        visible = (anchors[:, 0] >= -t) & (anchors[:, 1] >= -t) & (anchors[:, 2] < w + t) & (anchors[:, 3] < h + t)
+        lab[~visible] = -1
+        lab[m == BETWEEN] = -1
+        labels.append(lab)
+        reg_targets.append(encode(matched, anchors, (1.0, 1.0, 1.0, 1.0)))
+    pos, neg = [], []
+    for lab in labels:
+        pm, nm = sample_pos_neg(lab, rpn.BATCH_SIZE_PER_IMAGE, rpn.POSITIVE_FRACTION)
+        pos.append(pm)
+        neg.append(nm)
+    pos_inds = torch.nonzero(torch.cat(pos)).squeeze(1)
+    neg_inds = torch.nonzero(torch.cat(neg)).squeeze(1)
+    sampled = torch.cat([pos_inds, neg_inds])
+    obj = flatten_hwa(objectness, 1).reshape(-1)
+    reg = flatten_hwa(deltas, 4).reshape(-1, 4)
+    labels, reg_targets = torch.cat(labels), torch.cat(reg_targets)
+    box_loss = smooth_l1(reg[pos_inds], reg_targets[pos_inds], 1.0 / 9) / sampled.numel()
+    obj_loss = F.binary_cross_entropy_with_logits(obj[sampled], labels[sampled])
+    return obj_loss, box_loss
+
+
+# ---------------------------------------------------------------------------------------------- box head
+def box_head_targets(proposals, gts, cfg, sample_for_da):
+    """roi_heads/box_head/loss.py:68-93 -> per image (labels, regression targets, domain flag)"""
+    rh = cfg.MODEL.ROI_HEADS
+    out = []
+    for (boxes, _), gt in zip(proposals, gts):
+        is_source = bool(gt["is_source"].any())
+        m = matcher(box_iou(gt["boxes"], boxes), rh.FG_IOU_THRESHOLD, rh.BG_IOU_THRESHOLD, False)
+        idx = m.clamp(min=0) if is_source else m
+        lab = gt["labels"][idx].to(torch.int64).clone()
+        lab[m == BELOW_LOW] = 0
+        lab[m == BETWEEN] = -1
+        reg = encode(gt["boxes"][idx], boxes, rh.BBOX_REG_WEIGHTS)
+        if (not is_source) or sample_for_da:
+            lab[:] = 0
+        out.append((lab, reg, is_source))
+    return out
+
+
+def subsample(proposals, gts, cfg, sample_for_da=False):
+    """loss.py:95-163 -> per image dict(boxes, labels, reg, domain)"""
+    rh = cfg.MODEL.ROI_HEADS
+    tg = box_head_targets(proposals, gts, cfg, sample_for_da)
+    masks = [sample_pos_neg(lab, rh.BATCH_SIZE_PER_IMAGE, rh.POSITIVE_FRACTION) for lab, _, _ in tg]
+    out = []
+    for (boxes, _), (lab, reg, src), (pm, nm) in zip(proposals, tg, masks):
+        idx = torch.nonzero(pm | nm).squeeze(1)
+        out.append(dict(boxes=boxes[idx], labels=lab[idx], reg=reg[idx],
+                        domain=torch.full((idx.numel(),), src, dtype=torch.bool), idx=idx))
+    return out
+
+
+def roi_feature(feat, samples, sd, cfg):
+    """poolers.py:78-121 + ResNetHead (roi_box_feature_extractors.py:42-45)"""
+    bh = cfg.MODEL.ROI_BOX_HEAD
+    rois = torch.cat([torch.cat([torch.full((len(s["boxes"]), 1), float(i)), s["boxes"]], 1)
+                      for i, s in enumerate(samples)], 0)
+    x = roi_align(feat, rois, bh.POOLER_SCALES[0], bh.POOLER_RESOLUTION, bh.POOLER_RESOLUTION,
+                  bh.POOLER_SAMPLING_RATIO)
+    return stage(x, sd, "roi_heads.box.feature_extractor.head.layer4", 3, 2)
+
+
+def box_losses(x, samples, sd, cfg):
+    """roi_box_predictors.py:28-33 + loss.py:165-221"""
+    v = F.avg_pool2d(x, 7).flatten(1)
+    logits = F.linear(v, sd["roi_heads.box.predictor.cls_score.weight"], sd["roi_heads.box.predictor.cls_score.bias"])
+    reg = F.linear(v, sd["roi_heads.box.predictor.bbox_pred.weight"], sd["roi_heads.box.predictor.bbox_pred.bias"])
+    labels = torch.cat([s["labels"] for s in samples])
+    targets = torch.cat([s["reg"] for s in samples])
+    dom = torch.cat([s["domain"] for s in samples])
+    logits, reg, labels, targets = logits[dom], reg[dom], labels[dom], targets[dom]
+    cls_loss = F.cross_entropy(logits, labels)
+    pos = torch.nonzero(labels > 0).squeeze(1)
+    cols = 4 * labels[pos][:, None] + torch.tensor([0, 1, 2, 3])
+    box_loss = smooth_l1(reg[pos[:, None], cols], targets[pos], 1.0) / labels.numel()
+    return cls_loss, box_loss, dom
+
+
+# ---------------------------------------------------------------------------------------------- DA heads
+def img_head(x, sd, p):
+    """da_heads.py:32-37"""
+    t = F.relu(F.conv2d(x, sd[p + ".imghead.conv1_da.weight"], sd[p + ".imghead.conv1_da.bias"]))
+    return F.conv2d(t, sd[p + ".imghead.conv2_da.weight"], sd[p + ".imghead.conv2_da.bias"])
+
+
+def ins_head(x, sd, p, training=True):
+    """da_heads.py:61-68 (dropout masks drawn exactly like F.dropout on the CPU)"""
+    x = F.relu(F.linear(x, sd[p + ".inshead.fc1_da.weight"], sd[p + ".inshead.fc1_da.bias"]))
+    x = F.dropout(x, p=0.5, training=training)
+    x = F.relu(F.linear(x, sd[p + ".inshead.fc2_da.weight"], sd[p + ".inshead.fc2_da.bias"]))
+    x = F.dropout(x, p=0.5, training=training)
+    return F.linear(x, sd[p + ".inshead.fc3_da.weight"], sd[p + ".inshead.fc3_da.bias"])
+
+
+class _GRL(torch.autograd.Function):
+    """layers/gradient_scalar_layer.py:4-13"""
+
+    @staticmethod
+    def forward(ctx, x, w):
+        ctx.w = w
+        return x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        return ctx.w * g, None
+
+
+def img_bce(logits, img_labels):
+    """da_heads/loss.py:80-98: per-pixel label = is_source of the image, mean over N*H*W"""
+    lab = img_labels.view(-1, 1, 1, 1).expand_as(logits)
+    return F.binary_cross_entropy_with_logits(logits.permute(0, 2, 3, 1).reshape(logits.shape[0], -1),
+                                              lab.permute(0, 2, 3, 1).reshape(logits.shape[0], -1))
+
+
+def consistency(img_sig, ins_sig, ins_labels):
+    """layers/consistency_loss.py:3-27 (N == 2, source ROIs first)"""
+    n_src = int(torch.nonzero(ins_labels).size(0))
+    means = img_sig.reshape(img_sig.shape[0], -1).mean(1)
+    rows = torch.cat([means[0].view(1, 1).repeat(n_src, 1), means[1].view(1, 1).repeat(ins_sig.size(0) - n_src, 1)], 0)
+    return torch.abs(rows - ins_sig).mean()
+
+
+def da_losses_plain(feat, ins_feat, ins_labels, img_labels, sd, cfg):
+    """DomainAdaptationModule.forward (da_heads.py:388-440)"""
+    da = cfg.MODEL.DA_HEADS
+    p = "da_heads"
+    v = F.avg_pool2d(ins_feat, 7).flatten(1)
+    img_logits = img_head(_GRL.apply(feat, -da.DA_IMG_GRL_WEIGHT), sd, p)
+    ins_logits = ins_head(_GRL.apply(v, -da.DA_INS_GRL_WEIGHT), sd, p)
+    img_cst = img_head(_GRL.apply(feat, da.DA_IMG_GRL_WEIGHT), sd, p).sigmoid()
+    ins_cst = ins_head(_GRL.apply(v, da.DA_INS_GRL_WEIGHT), sd, p).sigmoid()
+    out = {}
+    if da.DA_IMG_LOSS_WEIGHT > 0:
+        out["loss_da_image"] = da.DA_IMG_LOSS_WEIGHT * img_bce(img_logits, img_labels)
+    if da.DA_INS_LOSS_WEIGHT > 0:
+        out["loss_da_instance"] = da.DA_INS_LOSS_WEIGHT * F.binary_cross_entropy_with_logits(
+            ins_logits.squeeze(), ins_labels.float())
+    if da.DA_CST_LOSS_WEIGHT > 0:
+        out["loss_da_consistency"] = da.DA_CST_LOSS_WEIGHT * consistency(img_cst, ins_cst, ins_labels)
+    return out
+
+
+def adv_weight(cur_loss, base, adv, threshold):
+    """intended AdvGRL rule (da_heads.py:173-195)"""
+    gate = float(F.binary_cross_entropy_with_logits(torch.tensor([[0.7, 0.3]]), torch.tensor([[1.0, 0.0]])))
+    cur = float(cur_loss.detach())
+    return -adv * min(float(threshold), 1.0 / cur) if cur <= gate else -base
+
+
+def da_losses_triplet(feat2, ins_feat, ins_labels, img_labels, feat3, ins_set, state, sd, cfg):
+    """DomainAdaptationModule_triplet.forward (da_heads.py:293-344); `state` carries the adaptive margins and
+    the previous triplet losses"""
+    da = cfg.MODEL.DA_HEADS
+    p = "da_heads_triplet"
+    out = {}
+    if da.DA_TRIPLET_INS_WEIGHT > 0:
+        s, q, n = [F.avg_pool2d(f, 7).flatten(1) for f in ins_set]
+        state["margin_ins"] = da.TRIPLET_MARGIN_INS
+        loss = F.triplet_margin_loss(s, q, n, margin=state["margin_ins"], p=2)
+        out["triplet_loss_instance"] = da.DA_TRIPLET_INS_WEIGHT * loss
+    if da.DA_TRIPLET_IMG_WEIGHT > 0:
+        if state.get("margin_img", 0.0) == 0.0:
+            state["margin_img"] = da.TRIPLET_MARGIN_IMG
+        if state.get("prev_img", 1) == 0.0 and int(state["margin_img"]) != int(da.TRIPLET_MAX_MARGIN):
+            state["margin_img"] += 0.001
+        loss = F.triplet_margin_loss(feat3[0:1], feat3[1:2], feat3[2:3], margin=state["margin_img"], p=2)
+        out["triplet_loss_image"] = da.DA_TRIPLET_IMG_WEIGHT * loss
+        state["prev_img"] = float(loss.detach())
+    if da.DA_IMG_LOSS_WEIGHT > 0:
+        cur = img_bce(img_head(feat2, sd, p).detach(), img_labels)
+        w = adv_weight(cur, da.DA_IMG_GRL_WEIGHT, da.DA_IMG_advGRL_WEIGHT, da.DA_ADV_GRL_THRESHOLD) \
+            if da.DA_ADV_GRL else -da.DA_IMG_GRL_WEIGHT
+        out["loss_da_image"] = da.DA_IMG_LOSS_WEIGHT * img_bce(img_head(_GRL.apply(feat2, w), sd, p), img_labels)
+    v = F.avg_pool2d(ins_feat, 7).flatten(1)
+    if da.DA_INS_LOSS_WEIGHT > 0:
+        cur = F.binary_cross_entropy_with_logits(ins_head(v.detach(), sd, p).squeeze(), ins_labels.float())
+        w = adv_weight(cur, da.DA_INS_GRL_WEIGHT, da.DA_INS_advGRL_WEIGHT, da.DA_ADV_GRL_THRESHOLD) \
+            if da.DA_ADV_GRL else -da.DA_INS_GRL_WEIGHT
+        out["loss_da_instance"] = da.DA_INS_LOSS_WEIGHT * F.binary_cross_entropy_with_logits(
+            ins_head(_GRL.apply(v, w), sd, p).squeeze(), ins_labels.float())
+    if da.DA_CST_LOSS_WEIGHT > 0:
+        img_cst = img_head(_GRL.apply(feat2, da.DA_IMG_GRL_WEIGHT), sd, p).sigmoid()
+        ins_cst = ins_head(_GRL.apply(v, da.DA_INS_GRL_WEIGHT), sd, p).sigmoid()
+        out["loss_da_consistency"] = da.DA_CST_LOSS_WEIGHT * consistency(img_cst, ins_cst, ins_labels)
+    return out
+
+
+# -------------------------------------------------------------------------------------------- full model
+def box_head_pass(feat, proposals, gts, sd, cfg, with_losses=True):
+    """ROIBoxHead.forward in training (box_head.py:36-118)"""
+    with torch.no_grad():
+        samples = subsample(proposals, gts, cfg)
+    x = roi_feature(feat, samples, sd, cfg)
+    cls_loss, box_loss, dom = box_losses(x, samples, sd, cfg)
+    with torch.no_grad():
+        # the reference samples the DA ROIs from the ALREADY SUBSAMPLED proposals (box_head.py:102-104)
+        sub = [(s["boxes"], None) for s in samples]
+        da_samples = subsample(sub, gts, cfg, sample_for_da=True)
+    da_feat = roi_feature(feat, da_samples, sd, cfg)
+    return dict(loss_classifier=cls_loss, loss_box_reg=box_loss), da_feat, dom, samples, da_samples
+
+
+def training_losses(sd, cfg, images, gts, state=None, intermediates=None):
+    """GeneralizedRCNN.forward in training mode (modeling/detector/generalized_rcnn.py:61-153).
+    images [N,3,H,W] (already padded), gts: list of dict(boxes [G,4], labels [G], is_source [G] bool)."""
+    N, _, H, W = images.shape
+    image_sizes = [(H, W)] * N
+    feat = backbone_c4(images, sd)
+    objectness, deltas = rpn_head(feat, sd)
+    rpn = cfg.MODEL.RPN
+    anchors = grid_anchors(feat.shape[2], feat.shape[3], rpn.ANCHOR_STRIDE[0],
+                           cell_anchors(rpn.ANCHOR_STRIDE[0], rpn.ANCHOR_SIZES, rpn.ASPECT_RATIOS))
+    with torch.no_grad():
+        proposals = rpn_proposals(objectness, deltas, anchors, image_sizes, gts, cfg, True)
+    obj_loss, rpn_box_loss = rpn_losses(objectness, deltas, anchors, image_sizes, gts, cfg)
+    img_labels = torch.tensor([1.0 if g["is_source"].any() else 0.0 for g in gts])
+    losses = {}
+    if cfg.MODEL.DA_HEADS.TRIPLET_USE:
+        det, da_feat, dom, samples, da_samples = box_head_pass(feat[0:2], proposals[0:2], gts[0:2], sd, cfg)
+        ins_set = None
+        if cfg.MODEL.DA_HEADS.ALIGNMENT:
+            ins_set = []
+            for k in range(3):
+                _, f_k, _, _, _ = box_head_pass(feat[k:k + 1], [proposals[1]], [gts[k]], sd, cfg)
+                ins_set.append(f_k)
+        da = da_losses_triplet(feat[0:2], da_feat, dom, img_labels[0:2], feat, ins_set,
+                               state if state is not None else {}, sd, cfg)
+    else:
+        det, da_feat, dom, samples, da_samples = box_head_pass(feat, proposals, gts, sd, cfg)
+        da = da_losses_plain(feat, da_feat, dom, img_labels, sd, cfg)
+    losses.update(det)
+    losses.update({"loss_objectness": obj_loss, "loss_rpn_box_reg": rpn_box_loss})
+    losses.update(da)
+    if intermediates is not None:
+        intermediates.update(feat=feat.detach(), objectness=objectness.detach(), deltas=deltas.detach(),
+                             proposals=[(b.clone(), s.clone()) for b, s in proposals],
+                             sampled_idx=[s["idx"] for s in samples], da_sampled_idx=[s["idx"] for s in da_samples],
+                             da_feat=da_feat.detach())
+    return losses
+
+
+# ------------------------------------------------------------------------------------------ CPU baseline
+def targets_to_dicts(targets):
+    return [dict(boxes=t.bbox.cpu(), labels=t.get_field("labels").cpu(), is_source=t.get_field("is_source").cpu())
+            for t in targets]
+
+
+def timed_training_sample(cfg_path, seed, height, width, images_per_step, init_fn, budget_s=25.0):
+    """cpu_baseline leg of bench.py: one full training step (forward + backward + SGD) of this restatement on
+    the host cores, on a bounded sample of the GPU workload."""
+    from da_detect_amd.config import cfg as base_cfg
+    from da_detect_amd.data.synthetic import make_batch
+    from da_detect_amd.modeling.detector import build_detection_model
+
+    cfg = base_cfg.clone()
+    cfg.merge_from_file(cfg_path)
+    torch.manual_seed(seed)
+    model = build_detection_model(cfg)  # parameter container only (names / shapes / trainable flags)
+    init_fn(model, seed)
+    trainable = {k for k, p in model.named_parameters() if p.requires_grad}
+    sd = {k: v.detach().clone().contiguous() for k, v in model.state_dict().items()}
+    params = []
+    for k in trainable:
+        sd[k].requires_grad_(True)
+        params.append(sd[k])
+    opt = torch.optim.SGD(params, lr=cfg.SOLVER.BASE_LR, momentum=cfg.SOLVER.MOMENTUM,
+                          weight_decay=cfg.SOLVER.WEIGHT_DECAY)
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+
+    def one_step(h, w):
+        images, targets = make_batch(cfg, images_per_step, h, w, seed=seed, device=torch.device("cpu"))
+        gts = targets_to_dicts(targets)
+        t0 = time.perf_counter()
+        losses = training_losses(sd, cfg, images.tensors, gts)
+        total = sum(losses.values())
+        opt.zero_grad()
+        total.backward()
+        opt.step()
+        return time.perf_counter() - t0
+
+    h, w = height // 2, width // 2
+    dt = one_step(h, w)
+    sample = "1 training step (fwd+bwd+SGD) on %d images of %dx%d (1/4 of the GPU workload's pixels, same ROI counts)" % (
+        images_per_step, h, w)
+    if dt * 4.5 < budget_s:  # the full-size step fits the budget: report that instead
+        dt = one_step(height, width)
+        h, w = height, width
+        sample = "1 training step (fwd+bwd+SGD) on %d images of %dx%d (the GPU workload's batch)" % (
+            images_per_step, h, w)
+    return {"value": round(images_per_step / dt, 4), "unit": "images/s", "cores": cores, "kind": "port",
+            "sample": sample + "; torch CPU fp32 convs on all host threads, single-thread C NMS/ROIAlign like the "
+                               "reference's CPU operators", "seconds": round(dt, 2)}

@@ -1,0 +1,137 @@
+"""Golden-vector generator — runs ONLY in the authoring container, where /root/reference exists.
+
+For each case it imports the REFERENCE model (maskrcnn_benchmark from /root/reference, CPU, via ref_shims),
+fills its parameters with tests/golden/fill.py, seeds torch's CPU generator and runs one training-mode forward
+on the seeded synthetic batch; the loss dictionary and intermediate tensors go to tests/golden/<case>.npz.
+The same inputs are then pushed through oracle/model_ref.py and must agree — that is what pins the oracle.
+Nothing of the reference is stored: fixtures hold seeds, shapes and OUTPUT tensors only.
+
+    python tests/golden/make_golden.py            # regenerate every fixture
+"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, HERE)
+sys.path.insert(0, ROOT)
+
+import ref_shims  # noqa: E402
+
+ref_shims.install()
+from fill import fill_state_dict  # noqa: E402
+from maskrcnn_benchmark.config import cfg as ref_cfg  # noqa: E402
+from maskrcnn_benchmark.modeling.detector import build_detection_model as ref_build  # noqa: E402
+from maskrcnn_benchmark.structures.bounding_box import BoxList as RefBoxList  # noqa: E402
+from maskrcnn_benchmark.structures.image_list import to_image_list as ref_to_image_list  # noqa: E402
+
+from da_detect_amd.config import cfg as my_cfg  # noqa: E402
+from da_detect_amd.data.synthetic import make_batch  # noqa: E402
+from oracle import model_ref  # noqa: E402
+
+REF_CFG_DIR = "/root/reference/configs/da_faster_rcnn"
+CASES = {
+    # name: (reference yaml, overrides, images, H, W)
+    "da_plain": ("e2e_da_faster_rcnn_R_50_C4_cityscapes_to_foggy_cityscapes.yaml", [], 2, 192, 320),
+    "da_img_only": ("e2e_da_faster_rcnn_R_50_C4_cityscapes_to_foggy_cityscapes.yaml",
+                    ["MODEL.DA_HEADS.DA_INS_LOSS_WEIGHT", 0.0, "MODEL.DA_HEADS.DA_CST_LOSS_WEIGHT", 0.0], 2, 192, 320),
+    "da_triplet": ("e2e_triplet_da_faster_rcnn_R_50_C4_cityscapes_to_foggy_cityscapes.yaml", [], 3, 160, 288),
+    "da_triplet_aligned": ("e2e_triplet_da_faster_rcnn_R_50_C4_cityscapes_to_foggy_cityscapes.yaml",
+                           ["MODEL.DA_HEADS.ALIGNMENT", True, "MODEL.DA_HEADS.DA_TRIPLET_INS_WEIGHT", 1.0,
+                            "MODEL.DA_HEADS.DA_CST_LOSS_WEIGHT", 0.1], 3, 160, 288),
+}
+
+
+def run_reference(yaml, overrides, nimg, H, W, seed):
+    c = ref_cfg.clone()
+    c.merge_from_file(os.path.join(REF_CFG_DIR, yaml))
+    c.merge_from_list(["MODEL.DEVICE", "cpu"] + list(overrides))
+    model = ref_build(c)
+    weights = fill_state_dict(model.state_dict(), seed)
+    model.load_state_dict(weights)
+    model.train()
+    mc = my_cfg.clone()
+    mc.merge_from_file(os.path.join(REF_CFG_DIR, yaml))
+    mc.merge_from_list(list(overrides))
+    images, targets = make_batch(mc, nimg, H, W, seed=seed, device=torch.device("cpu"))
+    ref_targets = []
+    for t in targets:
+        b = RefBoxList(t.bbox.clone(), t.size, mode="xyxy")
+        b.add_field("labels", t.get_field("labels").clone())
+        b.add_field("is_source", t.get_field("is_source").clone())
+        ref_targets.append(b)
+    inter = {}
+    model.backbone.register_forward_hook(lambda m, i, o: inter.__setitem__("feat", o[0].detach().clone()))
+    model.rpn.head.register_forward_hook(
+        lambda m, i, o: inter.update(objectness=o[0][0].detach().clone(), deltas=o[1][0].detach().clone()))
+    box = model.roi_heads.box
+    orig_sub = box.loss_evaluator.subsample
+
+    def sub_hook(proposals, tg):
+        inter.setdefault("proposals", [(p.bbox.clone(), p.get_field("objectness").clone()) for p in proposals])
+        out = orig_sub(proposals, tg)
+        inter.setdefault("sampled_boxes", [p.bbox.clone() for p in out])
+        return out
+
+    box.loss_evaluator.subsample = sub_hook
+    torch.manual_seed(seed)
+    losses = model(ref_to_image_list(images.tensors), ref_targets)
+    return mc, weights, images, targets, {k: v.detach() for k, v in losses.items()}, inter
+
+
+def scores_unique(inter):
+    for _, s in inter["proposals"]:
+        pass
+    obj = inter["objectness"]
+    N = obj.shape[0]
+    flat = obj.permute(0, 2, 3, 1).reshape(N, -1).sigmoid()
+    return all(torch.unique(flat[i]).numel() == flat[i].numel() for i in range(N))
+
+
+def main():
+    for name, (yaml, overrides, nimg, H, W) in CASES.items():
+        seed = 0
+        while True:
+            mc, weights, images, targets, losses, inter = run_reference(yaml, overrides, nimg, H, W, seed)
+            if scores_unique(inter):
+                break
+            print("%s: seed %d has tied objectness scores (reference order unspecified) -> next seed" % (name, seed))
+            seed += 1
+        # pin the oracle: same weights / inputs / seed through oracle/model_ref.py
+        sd = {k: v.clone() for k, v in weights.items()}
+        o_inter = {}
+        torch.manual_seed(seed)
+        o_losses = model_ref.training_losses(sd, mc, images.tensors, model_ref.targets_to_dicts(targets), state={},
+                                             intermediates=o_inter)
+        print(name, "seed", seed)
+        for k in losses:
+            r, o = float(losses[k]), float(o_losses[k])
+            print("   %-24s ref %.7f oracle %.7f  rel %.2e" % (k, r, o, abs(r - o) / max(abs(r), 1e-12)))
+            assert abs(r - o) <= 1e-5 * max(abs(r), 1.0), (name, k, r, o)
+        assert set(losses) == set(o_losses), (set(losses), set(o_losses))
+        for i, (rb, rs) in enumerate(inter["proposals"]):
+            ob, os_ = o_inter["proposals"][i]
+            assert rb.shape == ob.shape, (name, i, rb.shape, ob.shape)
+            assert torch.allclose(rb, ob, atol=1e-3), (name, "proposal boxes", i)
+        out = {"seed": np.int64(seed), "H": np.int64(H), "W": np.int64(W), "nimg": np.int64(nimg)}
+        for k, v in losses.items():
+            out["loss/" + k] = v.numpy()
+        out["feat_sample"] = inter["feat"][:, ::64, ::3, ::3].numpy()
+        out["feat_absmean"] = inter["feat"].abs().mean().numpy()
+        out["objectness"] = inter["objectness"].numpy()
+        out["deltas_sample"] = inter["deltas"][:, :, ::2, ::2].numpy()
+        for i, (b, s) in enumerate(inter["proposals"]):
+            out["proposals/%d/boxes" % i] = b.numpy()
+            out["proposals/%d/objectness" % i] = s.numpy()
+        for i, b in enumerate(inter["sampled_boxes"]):
+            out["sampled_boxes/%d" % i] = b.numpy()
+        path = os.path.join(HERE, name + ".npz")
+        np.savez_compressed(path, **out)
+        print("   wrote %s (%.1f KB)" % (path, os.path.getsize(path) / 1024.0))
+
+
+if __name__ == "__main__":
+    main()

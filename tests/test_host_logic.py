@@ -1,0 +1,176 @@
+"""CPU tests of the host-side logic and of the C-ABI surface (no kernels are launched)."""
+import ctypes
+import json
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+
+
+def test_library_exports_every_declared_symbol():
+    from da_detect_amd import _lib
+
+    header = open(os.path.join(ROOT, "include", "dadet.h")).read()
+    declared = set(re.findall(r"\b(dadet_[a-z0-9_]+)\s*\(", header))
+    declared -= {"dadet_conv_desc", "dadet_sgd_entry"}
+    assert len(declared) >= 25
+    lib = ctypes.CDLL(_lib.LIB_PATH)
+    for name in sorted(declared):
+        assert hasattr(lib, name), "libdadet_hip.so does not export %s" % name
+    assert declared == set(_lib.EXPORTED_SYMBOLS), declared ^ set(_lib.EXPORTED_SYMBOLS)
+    assert lib.dadet_version() >= 100
+
+
+def test_product_path_has_no_cpu_fallback():
+    from da_detect_amd import _C, _lib
+
+    with pytest.raises(_lib.DadetError):
+        _C.roi_align_forward(torch.zeros(1, 4, 8, 8), torch.zeros(1, 5), 0.25, 7, 7, 2)
+    with pytest.raises(_lib.DadetError):
+        _C.conv_forward(torch.zeros(1, 4, 8, 8), torch.zeros(4, 4, 1, 1))
+    with pytest.raises(_lib.DadetError):
+        _C.nms(torch.zeros(3, 4), torch.zeros(3), 0.5)
+
+
+def test_cfgnode_yacs_semantics(tmp_path):
+    from da_detect_amd.config import cfg
+
+    c = cfg.clone()
+    p = tmp_path / "a.yaml"
+    p.write_text("MODEL:\n  ROI_BOX_HEAD:\n    NUM_CLASSES: 9\nINPUT:\n  MIN_SIZE_TRAIN: (600,)\nSOLVER:\n  BASE_LR: 1\n")
+    c.merge_from_file(str(p))
+    assert c.MODEL.ROI_BOX_HEAD.NUM_CLASSES == 9 and c.INPUT.MIN_SIZE_TRAIN == (600,) and c.SOLVER.BASE_LR == 1.0
+    c.merge_from_list(["MODEL.DEVICE", "cpu", "SOLVER.STEPS", "(1, 2)"])
+    assert c.MODEL.DEVICE == "cpu" and c.SOLVER.STEPS == (1, 2)
+    with pytest.raises(KeyError):
+        c.merge_from_list(["MODEL.NOPE", 1])
+    with pytest.raises(ValueError):
+        c.merge_from_list(["MODEL.RPN.NMS_THRESH", "high"])
+    assert cfg.MODEL.ROI_BOX_HEAD.NUM_CLASSES == 81  # clone is deep
+    c.freeze()
+    with pytest.raises(AttributeError):
+        c.MODEL.DEVICE = "cuda"
+
+
+def test_every_shipped_yaml_merges():
+    import glob
+
+    from da_detect_amd.config import cfg
+
+    files = glob.glob(os.path.join(ROOT, "configs", "**", "*.yaml"), recursive=True)
+    assert len(files) >= 4
+    for f in files:
+        cfg.clone().merge_from_file(f)
+
+
+def test_box_coder_reference_known_answer_and_roundtrip():
+    from da_detect_amd.modeling.box_coder import BoxCoder
+
+    ka = json.load(open(os.path.join(HERE, "golden", "reference_known_answers.json")))
+    for case in ka["box_decode"]:
+        got = BoxCoder(tuple(case["weights"])).decode(torch.tensor(case["deltas"]), torch.tensor(case["boxes"]))
+        np.testing.assert_allclose(got.numpy(), np.array(case["expected"], np.float32), atol=1e-4)
+    g = torch.Generator().manual_seed(0)
+    a = torch.rand(50, 2, generator=g) * 300
+    boxes = torch.cat([a, a + 10 + torch.rand(50, 2, generator=g) * 200], 1)
+    b = torch.rand(50, 2, generator=g) * 300
+    gts = torch.cat([b, b + 10 + torch.rand(50, 2, generator=g) * 200], 1)
+    coder = BoxCoder((10.0, 10.0, 5.0, 5.0))
+    torch.testing.assert_close(coder.decode(coder.encode(gts, boxes), boxes), gts, rtol=1e-4, atol=1e-3)
+
+
+def test_boxlist_semantics():
+    from da_detect_amd.structures import BoxList, boxlist_iou, cat_boxlist, remove_small_boxes
+
+    b = BoxList(torch.tensor([[0.0, 0, 9, 9], [5, 5, 14, 24], [3, 3, 3, 3]]), (20, 30))
+    b.add_field("labels", torch.tensor([1, 2, 3]))
+    assert b.area().tolist() == [100.0, 200.0, 1.0]
+    assert b.convert("xywh").bbox[1].tolist() == [5, 5, 10, 20]
+    assert b.convert("xywh").convert("xyxy").bbox.tolist() == b.bbox.tolist()
+    assert b.transpose(0).bbox[0].tolist() == [10, 0, 19, 9]
+    assert b.resize((40, 60)).bbox[0].tolist() == [0, 0, 18, 18]
+    assert b[torch.tensor([2, 0])].get_field("labels").tolist() == [3, 1]
+    assert len(remove_small_boxes(b, 2)) == 2
+    iou = boxlist_iou(b, b)
+    assert torch.allclose(torch.diag(iou), torch.ones(3))
+    assert abs(float(iou[0, 1]) - 25.0 / 275.0) < 1e-6
+    c = cat_boxlist([b, b])
+    assert len(c) == 6 and c.get_field("labels").tolist() == [1, 2, 3, 1, 2, 3]
+    clipped = BoxList(torch.tensor([[-5.0, -5, 50, 50]]), (20, 30)).clip_to_image(remove_empty=False)
+    assert clipped.bbox[0].tolist() == [0, 0, 19, 29]
+
+
+def test_matcher_and_sampler():
+    from da_detect_amd.modeling.balanced_positive_negative_sampler import BalancedPositiveNegativeSampler
+    from da_detect_amd.modeling.matcher import Matcher
+
+    q = torch.tensor([[0.9, 0.2, 0.45, 0.1], [0.1, 0.6, 0.45, 0.05]])
+    assert Matcher(0.7, 0.3, False)(q.clone()).tolist() == [0, -2, -2, -1]
+    # low-quality matches: every gt keeps its best prediction (ties included)
+    assert Matcher(0.7, 0.3, True)(q.clone()).tolist() == [0, 1, -2, -1]
+    with pytest.raises(ValueError):
+        Matcher(0.5, 0.5)(torch.zeros(0, 3))
+    torch.manual_seed(0)
+    labels = torch.tensor([1] * 10 + [0] * 100 + [-1] * 5)
+    pos, neg = BalancedPositiveNegativeSampler(16, 0.25)([labels])
+    assert int(pos[0].sum()) == 4 and int(neg[0].sum()) == 12
+    assert not bool((pos[0] & (labels != 1)).any()) and not bool((neg[0] & (labels != 0)).any())
+
+
+def test_anchor_generator_matches_detectron_values():
+    from da_detect_amd.modeling.rpn.anchor_generator import AnchorGenerator, generate_anchors
+    from da_detect_amd.structures import ImageList
+
+    cell = generate_anchors(16, (32, 64, 128, 256, 512), (0.5, 1.0, 2.0))
+    assert cell.shape == (15, 4)
+    # Detectron's stride-16 anchors: ratio 0.5 / scale 32 and ratio 1 / scale 512
+    assert cell[0].tolist() == [-15.0, -4.0, 30.0, 19.0]
+    assert cell[9].tolist() == [-248.0, -248.0, 263.0, 263.0]
+    ag = AnchorGenerator((32, 64, 128, 256, 512), (0.5, 1.0, 2.0), (16,), 0)
+    out = ag(ImageList(torch.zeros(1, 3, 64, 96), [(64, 96)]), [torch.zeros(1, 8, 4, 6)])
+    a = out[0][0]
+    assert a.bbox.shape == (4 * 6 * 15, 4)
+    assert a.bbox[15].tolist() == [1.0, -4.0, 46.0, 19.0]  # next cell along x
+    vis = a.get_field("visibility")
+    assert bool(vis.any()) and not bool(vis.all())
+
+
+def test_model_structure_matches_reference_state_dict_layout():
+    from da_detect_amd.config import cfg
+    from da_detect_amd.modeling.detector import build_detection_model
+
+    c = cfg.clone()
+    c.merge_from_file(os.path.join(ROOT, "configs/da_faster_rcnn/e2e_da_faster_rcnn_R_50_C4_cityscapes_to_foggy_cityscapes.yaml"))
+    m = build_detection_model(c)
+    sd = m.state_dict()
+    assert len(sd) == 286
+    total = sum(p.numel() for p in m.parameters())
+    trainable = sum(p.numel() for p in m.parameters() if p.requires_grad)
+    assert (total, trainable) == (36736314, 36513914)  # SURVEY.md section 2.3 [probe]
+    for k in ["backbone.body.stem.conv1.weight", "backbone.body.layer3.5.bn3.running_var",
+              "rpn.anchor_generator.cell_anchors.0", "rpn.head.bbox_pred.bias",
+              "roi_heads.box.feature_extractor.head.layer4.0.downsample.0.weight",
+              "roi_heads.box.predictor.cls_score.weight", "da_heads.imghead.conv2_da.weight",
+              "da_heads.inshead.fc3_da.bias"]:
+        assert k in sd, k
+    assert tuple(sd["backbone.body.stem.conv1.weight"].shape) == (64, 3, 7, 7)
+
+
+def test_cosine_scheduler_restated_from_call_site():
+    from da_detect_amd.solver import CosineLRScheduler
+
+    p = torch.nn.Parameter(torch.zeros(1))
+    opt = torch.optim.SGD([{"params": [p], "lr": 1e-3}], lr=1e-3)
+    s = CosineLRScheduler(opt, t_initial=1000, lr_min=1e-6, warmup_lr_init=1e-4, warmup_t=100, t_in_epochs=False)
+    assert abs(opt.param_groups[0]["lr"] - 1e-4) < 1e-12
+    s.step_update(50)
+    assert abs(opt.param_groups[0]["lr"] - (1e-4 + 50 * (1e-3 - 1e-4) / 100)) < 1e-12
+    s.step_update(500)
+    assert abs(opt.param_groups[0]["lr"] - (1e-6 + 0.5 * (1e-3 - 1e-6))) < 1e-9
+    s.step_update(5000)
+    assert abs(opt.param_groups[0]["lr"] - 1e-6) < 1e-12
