@@ -3,9 +3,11 @@ import sys
 
 import pytest
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-if ROOT not in sys.path:
-    sys.path.insert(0, ROOT)
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+for p in (ROOT, HERE):  # repo root (da_detect_amd, oracle) and tests/ (golden.*)
+    if p not in sys.path:
+        sys.path.insert(0, p)
 
 
 def pytest_configure(config):
