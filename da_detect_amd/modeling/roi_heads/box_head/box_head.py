@@ -1,11 +1,16 @@
 """Box head with the extra domain-adaptation ROI pass
 (reference: maskrcnn_benchmark/modeling/roi_heads/box_head/box_head.py:22-118)."""
+import os
+
 import torch
 
 from .inference import make_roi_box_post_processor
 from .loss import make_roi_box_loss_evaluator
 from .roi_box_feature_extractors import make_roi_box_feature_extractor
 from .roi_box_predictors import make_roi_box_predictor
+
+
+_NO_DEDUP = os.environ.get("DADET_NO_ROI_DEDUP", "0") == "1"
 
 
 class ROIBoxHead(torch.nn.Module):
@@ -30,7 +35,20 @@ class ROIBoxHead(torch.nn.Module):
         loss_classifier, loss_box_reg, _ = self.loss_evaluator([class_logits], [box_regression])
         with torch.no_grad():
             da_proposals = self.loss_evaluator.subsample_for_da(proposals, targets)
-        da_ins_feas = self.feature_extractor(features, da_proposals)
+        # The reference samples the DA ROIs FROM THE ALREADY SUBSAMPLED `proposals` (box_head.py:50-104: the name
+        # is rebound by subsample()).  With every label forced to 0 the sampler takes min(n, BATCH_SIZE_PER_IMAGE)
+        # "negatives"; n <= BATCH_SIZE_PER_IMAGE here, so it takes ALL of them, in ascending index order: the DA
+        # ROI set is the detection ROI set, and the reference's second pooler + res5 pass recomputes `x` bit for
+        # bit.  The identical sub-expression is evaluated once; its two consumers' gradients add up in autograd
+        # exactly as the two passes' parameter gradients would.  (subsample_for_da still runs: it draws from the
+        # random stream.)  Set DADET_NO_ROI_DEDUP=1 to execute the redundant pass.
+        limit = self.loss_evaluator.fg_bg_sampler.batch_size_per_image
+        same_set = all(len(p) <= limit for p in proposals) and not _NO_DEDUP
+        if same_set:
+            assert all(len(a) == len(b) for a, b in zip(da_proposals, proposals))
+            da_ins_feas = x
+        else:
+            da_ins_feas = self.feature_extractor(features, da_proposals)
         # the reference runs the predictor on the DA features too and only keeps the domain mask, which
         # depends on self._proposals alone (box_head.py:107-110); the dead predictor call is skipped
         da_ins_labels = torch.cat([p.get_field("domain_labels") for p in self.loss_evaluator._proposals], dim=0)

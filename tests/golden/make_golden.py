@@ -122,7 +122,7 @@ def main():
         out["feat_sample"] = inter["feat"][:, ::64, ::3, ::3].numpy()
         out["feat_absmean"] = inter["feat"].abs().mean().numpy()
         out["objectness"] = inter["objectness"].numpy()
-        out["deltas_sample"] = inter["deltas"][:, :, ::2, ::2].numpy()
+        out["deltas"] = inter["deltas"].numpy()
         for i, (b, s) in enumerate(inter["proposals"]):
             out["proposals/%d/boxes" % i] = b.numpy()
             out["proposals/%d/objectness" % i] = s.numpy()

@@ -28,68 +28,102 @@ def _build(case, device):
     return z, c, model.to(device).train(), sd
 
 
-@pytest.mark.parametrize("case", ["da_plain", "da_img_only", "da_triplet", "da_triplet_aligned"])
-def test_losses_match_reference_golden(device, case):
-    from da_detect_amd.data.synthetic import make_batch
+def _run_with_golden_rpn_selection(model, z, images, targets, seed, device, inject=True):
+    """training-mode forward with the CPU random stream; optionally the proposal SELECTION (sort / decode / NMS —
+    the discontinuous part of the path) is fed the reference's RPN maps from the fixture, so that index-valued
+    results can be compared exactly instead of through fp32 noise on near-tied scores.  Everything continuous
+    (backbone, RPN head, RPN losses, box head, DA heads) still runs on this model's own tensors."""
     from da_detect_amd.utils import rng
 
-    z, c, model, _ = _build(case, device)
-    seed, H, W, nimg = int(z["seed"]), int(z["H"]), int(z["W"]), int(z["nimg"])
-    images, targets = make_batch(c, nimg, H, W, seed=seed, device=device)
     captured = {}
     model.backbone.register_forward_hook(lambda m, i, o: captured.__setitem__("feat", o[0].detach()))
     model.rpn.head.register_forward_hook(
         lambda m, i, o: captured.update(objectness=o[0][0].detach(), deltas=o[1][0].detach()))
-    orig = model.roi_heads.box.loss_evaluator.subsample
+    selector = model.rpn.box_selector_train
+    orig_sel = selector.forward
+    if inject:
+        gold_obj = [torch.from_numpy(z["objectness"]).to(device)]
+        gold_del = [torch.from_numpy(z["deltas"]).to(device)]
+        selector.forward = lambda anchors, objectness, box_regression, tg=None: orig_sel(anchors, gold_obj, gold_del, tg)
+    evaluator = model.roi_heads.box.loss_evaluator
+    orig_sub = evaluator.subsample
 
     def spy(proposals, tg):
         captured.setdefault("proposals", [(p.bbox.clone(), p.get_field("objectness").clone()) for p in proposals])
-        out = orig(proposals, tg)
+        out = orig_sub(proposals, tg)
         captured.setdefault("sampled", [p.bbox.clone() for p in out])
         return out
 
-    model.roi_heads.box.loss_evaluator.subsample = spy
+    evaluator.subsample = spy
     rng.use_cpu_stream(True)
     try:
         torch.manual_seed(seed)
         losses = model(images, targets)
     finally:
         rng.use_cpu_stream(False)
+        selector.forward = orig_sel
+        evaluator.subsample = orig_sub
+    return losses, captured
+
+
+@pytest.mark.parametrize("case", ["da_plain", "da_img_only", "da_triplet", "da_triplet_aligned"])
+def test_losses_match_reference_golden(device, case):
+    from da_detect_amd.data.synthetic import make_batch
+
+    z, c, model, _ = _build(case, device)
+    seed, H, W, nimg = int(z["seed"]), int(z["H"]), int(z["W"]), int(z["nimg"])
+    images, targets = make_batch(c, nimg, H, W, seed=seed, device=device)
+    losses, captured = _run_with_golden_rpn_selection(model, z, images, targets, seed, device, inject=True)
     want = {k[5:]: float(z[k]) for k in z.files if k.startswith("loss/")}
     assert set(losses) == set(want), (sorted(losses), sorted(want))
+    # continuous stages: backbone and RPN head against the reference's tensors
     feat = captured["feat"].cpu()
     np.testing.assert_allclose(feat[:, ::64, ::3, ::3].numpy(), z["feat_sample"], rtol=1e-4,
                                atol=1e-4 * float(z["feat_absmean"]))
     np.testing.assert_allclose(captured["objectness"].cpu().numpy(), z["objectness"], rtol=1e-4, atol=1e-4)
-    np.testing.assert_allclose(captured["deltas"].cpu()[:, :, ::2, ::2].numpy(), z["deltas_sample"], rtol=1e-4, atol=1e-4)
+    np.testing.assert_allclose(captured["deltas"].cpu().numpy(), z["deltas"], rtol=1e-4, atol=1e-4)
+    # index-valued stages given identical RPN maps: same proposals in the same order, same sampled ROIs
     for i, (b, s) in enumerate(captured["proposals"]):
         assert tuple(b.shape) == z["proposals/%d/boxes" % i].shape, "proposal count differs for image %d" % i
-        np.testing.assert_allclose(b.cpu().numpy(), z["proposals/%d/boxes" % i], atol=1e-3)
-        np.testing.assert_allclose(s.cpu().numpy(), z["proposals/%d/objectness" % i], rtol=1e-5, atol=1e-6)
+        assert np.array_equal(s.cpu().numpy(), z["proposals/%d/objectness" % i]), "proposal ranking differs"
+        np.testing.assert_allclose(b.cpu().numpy(), z["proposals/%d/boxes" % i], atol=2e-4)  # device expf ulp
     for i, b in enumerate(captured["sampled"]):
-        np.testing.assert_allclose(b.cpu().numpy(), z["sampled_boxes/%d" % i], atol=1e-3)  # same sampled ROIs
+        np.testing.assert_allclose(b.cpu().numpy(), z["sampled_boxes/%d" % i], atol=2e-4)
     for k, v in want.items():
         got = float(losses[k])
         assert abs(got - v) <= 1e-4 * max(abs(v), 1.0), (case, k, got, v)
+
+
+def test_end_to_end_without_injection_is_statistically_close(device):
+    """no injection: proposal ranking may flip between near-tied scores (fp32 noise), so only aggregate
+    agreement is asserted"""
+    from da_detect_amd.data.synthetic import make_batch
+
+    z, c, model, _ = _build("da_plain", device)
+    seed, H, W, nimg = int(z["seed"]), int(z["H"]), int(z["W"]), int(z["nimg"])
+    images, targets = make_batch(c, nimg, H, W, seed=seed, device=device)
+    losses, captured = _run_with_golden_rpn_selection(model, z, images, targets, seed, device, inject=False)
+    for i, (b, _) in enumerate(captured["proposals"]):
+        assert abs(b.shape[0] - z["proposals/%d/boxes" % i].shape[0]) <= 0.02 * z["proposals/%d/boxes" % i].shape[0] + 2
+    for k in ("loss_objectness", "loss_rpn_box_reg", "loss_da_image"):  # independent of the proposal set
+        v = float(z["loss/" + k])
+        assert abs(float(losses[k]) - v) <= 1e-4 * max(abs(v), 1.0), (k, float(losses[k]), v)
+    for k in ("loss_classifier", "loss_box_reg", "loss_da_instance"):
+        v = float(z["loss/" + k])
+        assert abs(float(losses[k]) - v) <= 0.1 * max(abs(v), 1.0), (k, float(losses[k]), v)
 
 
 def test_gradients_match_cpu_oracle(device):
     """backward through every HIP kernel (conv dgrad / wgrad, ROIAlign backward, fused DA heads) against torch
     autograd on the oracle (oracle/model_ref.py), same weights / inputs / random stream."""
     from da_detect_amd.data.synthetic import make_batch
-    from da_detect_amd.utils import rng
     from oracle import model_ref
 
     z, c, model, sd = _build("da_plain", device)
     seed, H, W, nimg = int(z["seed"]), int(z["H"]), int(z["W"]), int(z["nimg"])
     images, targets = make_batch(c, nimg, H, W, seed=seed, device=device)
-    rng.use_cpu_stream(True)
-    try:
-        torch.manual_seed(seed)
-        losses = model(images, targets)
-        sum(losses.values()).backward()
-    finally:
-        rng.use_cpu_stream(False)
+    losses, _ = _run_with_golden_rpn_selection(model, z, images, targets, seed, device, inject=True)
+    sum(losses.values()).backward()
     names = [n for n, p in model.named_parameters() if p.requires_grad]
     osd = {k: v.clone() for k, v in sd.items()}
     for n in names:
@@ -97,6 +131,8 @@ def test_gradients_match_cpu_oracle(device):
     cpu_images, cpu_targets = make_batch(c, nimg, H, W, seed=seed, device=torch.device("cpu"))
     torch.manual_seed(seed)
     olosses = model_ref.training_losses(osd, c, cpu_images.tensors, model_ref.targets_to_dicts(cpu_targets))
+    for k in olosses:  # same sampled ROIs on both sides -> same losses
+        assert abs(float(olosses[k]) - float(losses[k])) <= 1e-4 * max(abs(float(olosses[k])), 1.0), k
     sum(olosses.values()).backward()
     params = dict(model.named_parameters())
     worst = 0.0
