@@ -132,16 +132,18 @@ def roi_align_forward(input, rois, spatial_scale, pooled_height, pooled_width, s
 
 
 def roi_align_backward(grad, rois, spatial_scale, pooled_height, pooled_width, batch_size, channels,
-                       height, width, sampling_ratio):
+                       height, width, sampling_ratio, atomic=False):
     """_C.roi_align_backward -> [B,C,H,W] (ROIAlign.h:27-45)."""
     _dev(grad, "grad"), _dev(rois, "rois")
     g = _nhwc(grad)
     rois = rois.contiguous()
     gin = torch.empty((batch_size, channels, height, width), dtype=torch.float32, device=grad.device,
-                      memory_format=CL).zero_()
-    _lib.call("dadet_roi_align_backward", _p(g), _p(rois), _p(gin), batch_size, channels, height, width,
-              rois.shape[0], pooled_height, pooled_width, float(spatial_scale), int(sampling_ratio),
-              _stream())
+                      memory_format=CL)
+    if atomic:
+        gin.zero_()
+    _lib.call("dadet_roi_align_backward_atomic" if atomic else "dadet_roi_align_backward", _p(g), _p(rois),
+              _p(gin), batch_size, channels, height, width, rois.shape[0], pooled_height, pooled_width,
+              float(spatial_scale), int(sampling_ratio), _stream())
     return gin
 
 

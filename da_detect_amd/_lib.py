@@ -37,6 +37,7 @@ _SIGNATURES = {
     "dadet_nms": [_P, _P, c_int, c_float, c_int, c_int, _P, c_size_t, _P, _P, _P],
     "dadet_roi_align_forward": [_P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_float, c_int, _P],
     "dadet_roi_align_backward": [_P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_float, c_int, _P],
+    "dadet_roi_align_backward_atomic": [_P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_float, c_int, _P],
     "dadet_sigmoid_focal_loss_forward": [_P, _P, _P, c_int, c_int, c_float, c_float, _P],
     "dadet_sigmoid_focal_loss_backward": [_P, _P, _P, _P, c_int, c_int, c_float, c_float, _P],
     "dadet_conv_forward": [POINTER(ConvDesc), _P, _P, _P, _P, _P, _P, _P, _P],

@@ -188,6 +188,100 @@ __global__ __launch_bounds__(256) void roi_align_bwd_kernel(
   }
 }
 
+
+// ---- backward, gather form (no atomics, deterministic) -------------------------------------------------
+// One workgroup per input-gradient pixel (b, y, x), lanes along channels.  The pixel receives
+// g[r,ph,pw,c] * wy * wx / count from every sample of every ROI of image b whose bilinear footprint touches
+// it; ROIAlign weights are separable (w1..w4 = {hy,ly} x {hx,lx}), so per ROI the kernel walks the few
+// sample rows / columns that can reach (y, x) and accumulates in a fixed order.  Cost is reads of the
+// (L2-resident) output gradient rows instead of ~R*PH*PW*samples*4*C global atomics.
+__device__ inline float axis_weight(float coord, int limit, int pixel) {
+  // 1-D version of bilinear_tap(): weight with which a sample at `coord` lands on `pixel` (0 = not at all)
+  if (coord < -1.0f || coord > (float)limit) return 0.f;
+  if (coord <= 0.f) coord = 0.f;
+  int lo = (int)coord, hi;
+  if (lo >= limit - 1) {
+    hi = lo = limit - 1;
+    coord = (float)lo;
+  } else {
+    hi = lo + 1;
+  }
+  const float l = coord - (float)lo, h = 1.f - l;
+  float w = 0.f;
+  if (lo == pixel) w += h;
+  if (hi == pixel) w += l;
+  return w;
+}
+
+__device__ inline void candidate_range(float start, float bin, int grid, int pooled, int pixel, int* lo,
+                                       int* hi) {
+  // sample s (0 <= s < pooled*grid) sits near start + (s + .5) * bin / grid; keep those within (pixel-1, pixel+1)
+  // with one sample of slack either side — axis_weight() decides exactly.
+  const float step = bin / (float)grid;
+  int a = (int)floorf(((float)pixel - 1.f - start) / step - 0.5f) - 1;
+  int b = (int)ceilf(((float)pixel + 1.f - start) / step - 0.5f) + 1;
+  *lo = a < 0 ? 0 : a;
+  *hi = b > pooled * grid - 1 ? pooled * grid - 1 : b;
+}
+
+template <int VEC>
+__global__ __launch_bounds__(256) void roi_align_bwd_gather_kernel(
+    const float* __restrict__ grad_out, const float* __restrict__ rois, float* __restrict__ grad_in, int C,
+    int H, int W, int R, int pooled_h, int pooled_w, float scale, int sampling_ratio) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  unsigned char* touches = reinterpret_cast<unsigned char*>(smem);  // [R]
+  const int pix = blockIdx.x;
+  const int b = pix / (H * W);
+  const int y = (pix / W) % H;
+  const int x = pix % W;
+  for (int r = threadIdx.x; r < R; r += blockDim.x) {
+    const RoiGeom g = roi_geometry(rois + (size_t)r * 5, scale, pooled_h, pooled_w, sampling_ratio);
+    const float roi_h = g.bin_h * (float)pooled_h, roi_w = g.bin_w * (float)pooled_w;
+    const bool hit = g.batch == b && g.start_h <= (float)y + 1.f && g.start_h + roi_h >= (float)y - 1.f &&
+                     g.start_w <= (float)x + 1.f && g.start_w + roi_w >= (float)x - 1.f;
+    touches[r] = hit ? 1 : 0;
+  }
+  __syncthreads();
+  for (int c = threadIdx.x * VEC; c < C; c += blockDim.x * VEC) {
+    float acc[VEC];
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) acc[v] = 0.f;
+    for (int r = 0; r < R; ++r) {
+      if (!touches[r]) continue;  // uniform
+      const RoiGeom g = roi_geometry(rois + (size_t)r * 5, scale, pooled_h, pooled_w, sampling_ratio);
+      int sy0, sy1, sx0, sx1;
+      candidate_range(g.start_h, g.bin_h, g.grid_h, pooled_h, y, &sy0, &sy1);
+      candidate_range(g.start_w, g.bin_w, g.grid_w, pooled_w, x, &sx0, &sx1);
+      const float* __restrict__ go_roi = grad_out + (size_t)r * pooled_h * pooled_w * C + c;
+      for (int sy = sy0; sy <= sy1; ++sy) {
+        const int ph = sy / g.grid_h, iy = sy - ph * g.grid_h;
+        const float wy = axis_weight(sample_coord(g.start_h, ph, g.bin_h, iy, g.grid_h), H, y);
+        if (wy == 0.f) continue;
+        for (int sx = sx0; sx <= sx1; ++sx) {
+          const int pw = sx / g.grid_w, ix = sx - pw * g.grid_w;
+          const float wx = axis_weight(sample_coord(g.start_w, pw, g.bin_w, ix, g.grid_w), W, x);
+          if (wx == 0.f) continue;
+          const float w = wy * wx;
+          const float* q = go_roi + (size_t)(ph * pooled_w + pw) * C;
+          if constexpr (VEC == 4) {
+            const float4 gq = *reinterpret_cast<const float4*>(q);
+            acc[0] += gq.x * w / g.count; acc[1] += gq.y * w / g.count;
+            acc[2] += gq.z * w / g.count; acc[3] += gq.w * w / g.count;
+          } else {
+            acc[0] += q[0] * w / g.count;
+          }
+        }
+      }
+    }
+    float* dst = grad_in + (size_t)pix * C + c;
+    if constexpr (VEC == 4) {
+      *reinterpret_cast<float4*>(dst) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+    } else {
+      dst[0] = acc[0];
+    }
+  }
+}
+
 }  // namespace dadet
 
 using namespace dadet;
@@ -221,7 +315,7 @@ extern "C" int dadet_roi_align_forward(const float* input, const float* rois, fl
   return check_launch("roi_align_forward");
 }
 
-extern "C" int dadet_roi_align_backward(const float* grad_output, const float* rois, float* grad_input,
+extern "C" int dadet_roi_align_backward_atomic(const float* grad_output, const float* rois, float* grad_input,
                                         int B, int C, int H, int W, int R, int pooled_h, int pooled_w,
                                         float spatial_scale, int sampling_ratio, void* stream) {
   int rc = roi_args_ok(grad_output, rois, grad_input, B, C, H, W, R, pooled_h, pooled_w);
@@ -237,6 +331,33 @@ extern "C" int dadet_roi_align_backward(const float* grad_output, const float* r
     const int threads = (C >= 256) ? 256 : ((C + 63) / 64) * 64;
     hipLaunchKernelGGL(roi_align_bwd_kernel<1>, grid, dim3(threads), 0, as_stream(stream), grad_output,
                        rois, grad_input, C, H, W, pooled_h, pooled_w, spatial_scale, sampling_ratio);
+  }
+  return check_launch("roi_align_backward_atomic");
+}
+
+extern "C" int dadet_roi_align_backward(const float* grad_output, const float* rois, float* grad_input,
+                                        int B, int C, int H, int W, int R, int pooled_h, int pooled_w,
+                                        float spatial_scale, int sampling_ratio, void* stream) {
+  int rc = roi_args_ok(grad_output, rois, grad_input, B, C, H, W, R, pooled_h, pooled_w);
+  if (rc) return rc;
+  hipStream_t st = as_stream(stream);
+  if (R == 0) {
+    (void)hipMemsetAsync(grad_input, 0, sizeof(float) * (size_t)B * C * H * W, st);
+    return check_launch("roi_align_backward(empty)");
+  }
+  DADET_REQUIRE(R <= 60000, "roi_align_backward: R=%d exceeds the per-workgroup ROI table", R);
+  const dim3 grid((unsigned)(B * H * W));
+  const size_t lds = ((size_t)R + 15) & ~(size_t)15;
+  const bool vec = (C % 4 == 0) && ((reinterpret_cast<uintptr_t>(grad_output) & 15) == 0) &&
+                   ((reinterpret_cast<uintptr_t>(grad_input) & 15) == 0);
+  if (vec) {
+    const int threads = (C / 4 >= 256) ? 256 : ((C / 4 + 63) / 64) * 64;
+    hipLaunchKernelGGL(roi_align_bwd_gather_kernel<4>, grid, dim3(threads), lds, st, grad_output, rois,
+                       grad_input, C, H, W, R, pooled_h, pooled_w, spatial_scale, sampling_ratio);
+  } else {
+    const int threads = (C >= 256) ? 256 : ((C + 63) / 64) * 64;
+    hipLaunchKernelGGL(roi_align_bwd_gather_kernel<1>, grid, dim3(threads), lds, st, grad_output, rois,
+                       grad_input, C, H, W, R, pooled_h, pooled_w, spatial_scale, sampling_ratio);
   }
   return check_launch("roi_align_backward");
 }

@@ -69,8 +69,11 @@ int dadet_nms(const float* boxes_xyxy, const float* scores, int n, float thresh,
  * No coordinate rounding, ROI min size 1, adaptive grid ceil(roi/pooled) when sampling_ratio == 0,
  * sample skipped when y < -1 || y > H || x < -1 || x > W.  Forward is evaluated in the reference's
  * operation order with FMA contraction disabled, so it is bit-comparable with ROIAlign_cpu.cpp.
- * Backward accumulates with hardware fp32 atomics into grad_input, which the CALLER must zero
- * (reference zero-fills at ROIAlign_cuda.cu:316).
+ * Backward is a deterministic GATHER: one workgroup per grad_input pixel sums, in a fixed order, the
+ * contributions of every ROI sample whose bilinear footprint touches it (the weights are separable), and
+ * overwrites grad_input completely — no atomics, no pre-zeroing.  The reference's scatter form
+ * (ROIAlign_cuda.cu:178-254, atomicAdd into a zero-filled tensor at :316) is kept as
+ * dadet_roi_align_backward_atomic (the caller zero-fills) for A/B measurements.
  * ----------------------------------------------------------------------------------------------*/
 int dadet_roi_align_forward(const float* input, const float* rois, float* output, int B, int C, int H,
                             int W, int R, int pooled_h, int pooled_w, float spatial_scale,
@@ -78,6 +81,9 @@ int dadet_roi_align_forward(const float* input, const float* rois, float* output
 int dadet_roi_align_backward(const float* grad_output, const float* rois, float* grad_input, int B,
                              int C, int H, int W, int R, int pooled_h, int pooled_w,
                              float spatial_scale, int sampling_ratio, void* stream);
+int dadet_roi_align_backward_atomic(const float* grad_output, const float* rois, float* grad_input, int B,
+                                    int C, int H, int W, int R, int pooled_h, int pooled_w,
+                                    float spatial_scale, int sampling_ratio, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * SigmoidFocalLoss — replaces `_C.sigmoid_focalloss_forward/backward`

@@ -105,8 +105,10 @@ def test_roi_align_forward_bit_exact(device, C, H, W, R, ph, sr):
     assert np.array_equal(got.cpu().numpy(), want)
 
 
-@pytest.mark.parametrize("C,H,W,R,ph,sr", [(8, 20, 32, 16, 7, 0), (64, 38, 76, 40, 14, 0), (12, 25, 31, 9, 7, 2)])
-def test_roi_align_backward(device, C, H, W, R, ph, sr):
+@pytest.mark.parametrize("atomic", [False, True])
+@pytest.mark.parametrize("C,H,W,R,ph,sr", [(8, 20, 32, 16, 7, 0), (64, 38, 76, 40, 14, 0), (12, 25, 31, 9, 7, 2),
+                                            (3, 9, 7, 300, 7, 0)])
+def test_roi_align_backward(device, C, H, W, R, ph, sr, atomic):
     from da_detect_amd import _C
     from oracle import ops as O
 
@@ -115,8 +117,8 @@ def test_roi_align_backward(device, C, H, W, R, ph, sr):
     rois = _rois(rng, R, 2, W * 16, H * 16)
     want = O.roi_align_backward(g, rois, 1 / 16.0, ph, ph, 2, C, H, W, sr)
     got = _C.roi_align_backward(torch.from_numpy(g).to(device), torch.from_numpy(rois).to(device), 1 / 16.0,
-                                ph, ph, 2, C, H, W, sr).cpu().numpy()
-    # atomics: summation order differs -> fp32 tolerance
+                                ph, ph, 2, C, H, W, sr, atomic=atomic).cpu().numpy()
+    # gather form (default) / atomic scatter form: summation order differs from the oracle -> fp32 tolerance
     np.testing.assert_allclose(got, want, rtol=1e-5, atol=1e-5)
 
 

@@ -80,7 +80,9 @@ def main():
     print("roi_align fwd: %.3f ms  %.0f GB/s (algorithmic %.0f MB)" % (ms, (out_bytes + feat.numel() * 4) / ms / 1e6, (out_bytes + feat.numel() * 4) / 1e6))
     go = torch.randn((512, 1024, 14, 14), device=dev).contiguous(memory_format=CL)
     ms = timeit(lambda: _C.roi_align_backward(go, rois, 1 / 16.0, 14, 14, 2, 1024, 64, 128, 0))
-    print("roi_align bwd: %.3f ms  %.0f GB/s" % (ms, (out_bytes + 2 * feat.numel() * 4) / ms / 1e6))
+    print("roi_align bwd (gather): %.3f ms  %.0f GB/s" % (ms, (out_bytes + feat.numel() * 4) / ms / 1e6))
+    ms = timeit(lambda: _C.roi_align_backward(go, rois, 1 / 16.0, 14, 14, 2, 1024, 64, 128, 0, atomic=True))
+    print("roi_align bwd (atomic): %.3f ms  %.0f GB/s" % (ms, (out_bytes + 2 * feat.numel() * 4) / ms / 1e6))
     # NMS
     n = 12000
     xy = torch.rand((n, 2), generator=g) * torch.tensor([1900.0, 950.0])
