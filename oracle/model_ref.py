@@ -446,9 +446,11 @@ def box_head_pass(feat, proposals, gts, sd, cfg, with_losses=True):
     return dict(loss_classifier=cls_loss, loss_box_reg=box_loss), da_feat, dom, samples, da_samples
 
 
-def training_losses(sd, cfg, images, gts, state=None, intermediates=None):
+def training_losses(sd, cfg, images, gts, state=None, intermediates=None, selection_maps=None):
     """GeneralizedRCNN.forward in training mode (modeling/detector/generalized_rcnn.py:61-153).
-    images [N,3,H,W] (already padded), gts: list of dict(boxes [G,4], labels [G], is_source [G] bool)."""
+    images [N,3,H,W] (already padded), gts: list of dict(boxes [G,4], labels [G], is_source [G] bool).
+    selection_maps=(objectness, deltas): tests may feed the proposal SELECTION fixed RPN maps (e.g. the golden
+    reference ones) so index-valued results do not depend on this machine's fp32 GEMM rounding."""
     N, _, H, W = images.shape
     image_sizes = [(H, W)] * N
     feat = backbone_c4(images, sd)
@@ -457,7 +459,8 @@ def training_losses(sd, cfg, images, gts, state=None, intermediates=None):
     anchors = grid_anchors(feat.shape[2], feat.shape[3], rpn.ANCHOR_STRIDE[0],
                            cell_anchors(rpn.ANCHOR_STRIDE[0], rpn.ANCHOR_SIZES, rpn.ASPECT_RATIOS))
     with torch.no_grad():
-        proposals = rpn_proposals(objectness, deltas, anchors, image_sizes, gts, cfg, True)
+        sel_obj, sel_del = selection_maps if selection_maps is not None else (objectness, deltas)
+        proposals = rpn_proposals(sel_obj, sel_del, anchors, image_sizes, gts, cfg, True)
     obj_loss, rpn_box_loss = rpn_losses(objectness, deltas, anchors, image_sizes, gts, cfg)
     img_labels = torch.tensor([1.0 if g["is_source"].any() else 0.0 for g in gts])
     losses = {}

@@ -131,7 +131,8 @@ def test_gradients_match_cpu_oracle(device):
         osd[n].requires_grad_(True)
     cpu_images, cpu_targets = make_batch(c, nimg, H, W, seed=seed, device=torch.device("cpu"))
     torch.manual_seed(seed)
-    olosses = model_ref.training_losses(osd, c, cpu_images.tensors, model_ref.targets_to_dicts(cpu_targets))
+    olosses = model_ref.training_losses(osd, c, cpu_images.tensors, model_ref.targets_to_dicts(cpu_targets),
+                                        selection_maps=(torch.from_numpy(z["objectness"]), torch.from_numpy(z["deltas"])))
     for k in olosses:  # same sampled ROIs on both sides -> same losses
         assert abs(float(olosses[k]) - float(losses[k])) <= 1e-4 * max(abs(float(olosses[k])), 1.0), k
     sum(olosses.values()).backward()
