@@ -19,8 +19,11 @@
 // bank-conflict free for the 16-lane service groups of ds_read_b128 (36*i mod 64 is a permutation of the
 // 16 quad-slots); the staging writes are ds_write_b128 of 8 contiguous lanes per row.
 // A 256-thread workgroup = 4 wavefronts as 2x2, each wavefront owns a (TM*32)x(TN*32) block of the
-// output tile, accumulators live in registers (16 fp32 per 32x32 block).  K loop: register prefetch of
-// tile t+1 is issued before the MFMAs of tile t, LDS is double buffered, one barrier per K-tile.
+// output tile, accumulators live in registers (16 fp32 per 32x32 block).  K loop: the global loads of
+// tile t+1 are issued into registers before the MFMAs of tile t and written to the (single) LDS buffer
+// after them; at ~36 KB of LDS and 144 registers three workgroups are resident per CU (12 waves), and it is
+// this cross-workgroup overlap that keeps the matrix pipe fed across the two barriers of a K-tile (PMC on
+// the double-buffered / 2-workgroup variant: 38% of wave cycles parked in s_waitcnt/s_barrier).
 // Workgroup ids are remapped so that each XCD (private L2) walks a contiguous range of m-tiles.
 #include "common.h"
 
@@ -49,8 +52,8 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(const ConvArgs a) {
   constexpr int BM = 2 * TM * 32, BN = 2 * TN * 32;
   constexpr int A_LOADS = BM / 32, B_LOADS = BN / 32;  // float4 loads per thread per K-tile
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  float* As = reinterpret_cast<float*>(smem);                 // [2][BM][LDS_STRIDE]
-  float* Bs = As + 2 * BM * LDS_STRIDE;                       // [2][BN][LDS_STRIDE]
+  float* As = reinterpret_cast<float*>(smem);                 // [BM][LDS_STRIDE]
+  float* Bs = As + BM * LDS_STRIDE;                           // [BN][LDS_STRIDE]
 
   const int nwg = a.tiles_m * a.tiles_n;
   const int tile = xcd_remap(blockIdx.x, nwg);
@@ -108,15 +111,13 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(const ConvArgs a) {
       rb[i] = ok ? *reinterpret_cast<const float4*>(a.w + (int64_t)n * a.K + kk) : zero4;
     }
   };
-  auto store_tile = [&](int buf) {
-    float* Ab = As + buf * BM * LDS_STRIDE;
-    float* Bb = Bs + buf * BN * LDS_STRIDE;
+  auto store_tile = [&]() {
 #pragma unroll
     for (int i = 0; i < A_LOADS; ++i)
-      *reinterpret_cast<float4*>(Ab + (lrow + 32 * i) * LDS_STRIDE + lcol * 4) = ra[i];
+      *reinterpret_cast<float4*>(As + (lrow + 32 * i) * LDS_STRIDE + lcol * 4) = ra[i];
 #pragma unroll
     for (int i = 0; i < B_LOADS; ++i)
-      *reinterpret_cast<float4*>(Bb + (lrow + 32 * i) * LDS_STRIDE + lcol * 4) = rb[i];
+      *reinterpret_cast<float4*>(Bs + (lrow + 32 * i) * LDS_STRIDE + lcol * 4) = rb[i];
   };
 
   f32x16 acc[TM][TN];
@@ -129,16 +130,15 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(const ConvArgs a) {
 
   const int nk = (a.K + BK - 1) / BK;
   load_tile(0);
-  store_tile(0);
+  store_tile();
   __syncthreads();
 
   const int frag_row = lane & 31;        // row of the 32-row fragment this lane feeds
   const int frag_k = (lane >> 5) * 4;    // which 4-float half of each 8-float k-group
-  int buf = 0;
+  const float* Ab = As + (wm * TM * 32 + frag_row) * LDS_STRIDE + frag_k;
+  const float* Bb = Bs + (wn * TN * 32 + frag_row) * LDS_STRIDE + frag_k;
   for (int kt = 0; kt < nk; ++kt) {
     if (kt + 1 < nk) load_tile(kt + 1);  // global loads in flight during the MFMAs below
-    const float* Ab = As + buf * BM * LDS_STRIDE + (wm * TM * 32 + frag_row) * LDS_STRIDE + frag_k;
-    const float* Bb = Bs + buf * BN * LDS_STRIDE + (wn * TN * 32 + frag_row) * LDS_STRIDE + frag_k;
 #pragma unroll
     for (int j = 0; j < BK / 8; ++j) {
       float4 fa[TM], fb[TN];
@@ -160,9 +160,13 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(const ConvArgs a) {
           }
       }
     }
-    if (kt + 1 < nk) store_tile(buf ^ 1);
-    __syncthreads();
-    buf ^= 1;
+    // one LDS buffer (36 KB for the 128x128 tile): three workgroups share a CU, so another workgroup's MFMAs
+    // cover this one's staging; the price is a second barrier per K-tile
+    if (kt + 1 < nk) {
+      __syncthreads();
+      store_tile();
+      __syncthreads();
+    }
   }
 
   // epilogue: D layout of the 32x32 MFMA — col = lane & 31, row = (reg & 3) + 8*(reg >> 2) + 4*(lane >> 5)
@@ -221,8 +225,8 @@ struct WgradArgs {
 __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs a) {
   constexpr int TILE = 128, RK = 32;  // output tile 128x128, 32 m-rows per step
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  float* Gs = reinterpret_cast<float*>(smem);   // [2][RK][TILE]  gY rows
-  float* Xs = Gs + 2 * RK * TILE;               // [2][RK][TILE]  gathered X rows
+  float* Gs = reinterpret_cast<float*>(smem);   // [RK][TILE]  gY rows
+  float* Xs = Gs + RK * TILE;                   // [RK][TILE]  gathered X rows
 
   const int tile = xcd_remap(blockIdx.x, a.tiles_co * a.tiles_kc);
   const int co0 = (tile / a.tiles_kc) * TILE;
@@ -272,13 +276,11 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs a) {
       rx[i] = ok ? *reinterpret_cast<const float4*>(a.x + off) : zero4;
     }
   };
-  auto store_tile = [&](int buf) {
-    float* Gb = Gs + buf * RK * TILE;
-    float* Xb = Xs + buf * RK * TILE;
+  auto store_tile = [&]() {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      *reinterpret_cast<float4*>(Gb + (lrow + 8 * i) * TILE + lcol * 4) = rg[i];
-      *reinterpret_cast<float4*>(Xb + (lrow + 8 * i) * TILE + lcol * 4) = rx[i];
+      *reinterpret_cast<float4*>(Gs + (lrow + 8 * i) * TILE + lcol * 4) = rg[i];
+      *reinterpret_cast<float4*>(Xs + (lrow + 8 * i) * TILE + lcol * 4) = rx[i];
     }
   };
 
@@ -293,15 +295,14 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs a) {
   const int nsteps = (m_end - m_begin + RK - 1) / RK;
   if (nsteps > 0) {
     load_tile(m_begin);
-    store_tile(0);
+    store_tile();
   }
   __syncthreads();
   const int fcol = lane & 31, fk = lane >> 5;
-  int buf = 0;
+  const float* Gb = Gs + wm * 64 + fcol;
+  const float* Xb = Xs + wn * 64 + fcol;
   for (int st = 0; st < nsteps; ++st) {
     if (st + 1 < nsteps) load_tile(m_begin + (st + 1) * RK);
-    const float* Gb = Gs + buf * RK * TILE + wm * 64 + fcol;
-    const float* Xb = Xs + buf * RK * TILE + wn * 64 + fcol;
 #pragma unroll
     for (int k2 = 0; k2 < RK / 2; ++k2) {
       const int row = 2 * k2 + fk;
@@ -312,9 +313,11 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs a) {
       acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(g1, x0, acc[1][0], 0, 0, 0);
       acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(g1, x1, acc[1][1], 0, 0, 0);
     }
-    if (st + 1 < nsteps) store_tile(buf ^ 1);
-    __syncthreads();
-    buf ^= 1;
+    if (st + 1 < nsteps) {
+      __syncthreads();
+      store_tile();
+      __syncthreads();
+    }
   }
 
   float* out = a.direct ? a.out : a.out + (size_t)split * a.Cout * a.K;
@@ -414,7 +417,7 @@ static int launch_fwd(ConvArgs& a, hipStream_t st) {
   constexpr int BM = 2 * TM * 32, BN = 2 * TN * 32;
   a.tiles_m = ceil_div(a.M, BM);
   a.tiles_n = ceil_div(a.Cout, BN);
-  const size_t lds = sizeof(float) * 2 * (BM + BN) * LDS_STRIDE;
+  const size_t lds = sizeof(float) * (BM + BN) * LDS_STRIDE;
   static bool attr_set = false;
   if (!attr_set && lds > 48 * 1024) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_fwd_kernel<TM, TN>),
@@ -534,7 +537,7 @@ extern "C" int dadet_conv_wgrad(const dadet_conv_desc* d, const float* x, const 
     a.direct = 0;
     a.out = static_cast<float*>(workspace);
   }
-  const size_t lds = sizeof(float) * 2 * 2 * 32 * 128;  // 64 KB
+  const size_t lds = sizeof(float) * 2 * 32 * 128;  // 32 KB: three workgroups per CU
   static bool attr_set = false;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad_kernel),
