@@ -30,6 +30,26 @@
 namespace dadet {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+// Buffer-descriptor access (guide T8): a raw buffer load whose byte offset is >= num_records returns 0 and
+// a raw buffer store there is dropped, so padding taps, ragged tile edges and the K tail need NO branches
+// and NO selects — every load of a K-tile is issued back to back and waited for once, right before the LDS
+// write.  (The first version used `ok ? *p : 0`: hipcc lowered it to exec-masked flat_loads each followed by
+// s_waitcnt vmcnt(0), i.e. eight serialised memory round trips per K-tile in front of the MFMAs.)
+constexpr unsigned kOOB = 0xFFFFFFF0u;  // 16-byte aligned, beyond any supported buffer
+__device__ inline __amdgpu_buffer_rsrc_t make_rsrc(const void* p, unsigned bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, (int)bytes, 0x00020000);
+}
+__device__ inline float4 buf_load4(__amdgpu_buffer_rsrc_t r, unsigned byte_off) {
+  return __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)byte_off, 0, 0));
+}
+__device__ inline float buf_load1(__amdgpu_buffer_rsrc_t r, unsigned byte_off) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, (int)byte_off, 0, 0));
+}
+__device__ inline void buf_store1(__amdgpu_buffer_rsrc_t r, unsigned byte_off, float v) {
+  __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), r, (int)byte_off, 0, 0);
+}
 
 constexpr int BK = 32;          // K-tile
 constexpr int LDS_STRIDE = 36;  // floats per staged row (32 + 4 pad, keeps 16-byte alignment)
@@ -45,10 +65,11 @@ struct ConvArgs {
   int N, H, W, Cin, Cout, KH, KW, stride, pad, Ho, Wo, OutH, OutW, os, relu_mode;
   int M, K;        // GEMM rows, reduction length
   int tiles_m, tiles_n;
+  unsigned x_bytes, w_bytes, y_bytes;  // buffer extents (< 4 GB each)
 };
 
 template <int TM, int TN>
-__global__ __launch_bounds__(256) void conv_fwd_kernel(const ConvArgs a) {
+__global__ __launch_bounds__(256, 3) void conv_fwd_kernel(const ConvArgs a) {
   constexpr int BM = 2 * TM * 32, BN = 2 * TN * 32;
   constexpr int A_LOADS = BM / 32, B_LOADS = BN / 32;  // float4 loads per thread per K-tile
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -65,6 +86,9 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(const ConvArgs a) {
   const int wm = wave >> 1, wn = wave & 1;
   const int lcol = t & 7;    // float4 column of the K-tile this thread stages
   const int lrow = t >> 3;   // first staged row (0..31)
+
+  const __amdgpu_buffer_rsrc_t xr = make_rsrc(a.x, a.x_bytes);
+  const __amdgpu_buffer_rsrc_t wr = make_rsrc(a.w, a.w_bytes);
 
   // per staged A row: image pixel base and top-left input coordinate
   int pixbase[A_LOADS], hi0[A_LOADS], wi0[A_LOADS];
@@ -86,29 +110,44 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(const ConvArgs a) {
       wi0[i] = 0;
     }
   }
+  // weight rows of this thread (byte offsets of column 0), out-of-range rows read as zero
+  unsigned wrow[B_LOADS];
+#pragma unroll
+  for (int i = 0; i < B_LOADS; ++i) {
+    const int n = bn0 + lrow + 32 * i;
+    wrow[i] = n < a.Cout ? (unsigned)n * (unsigned)a.K * 4u : kOOB;
+  }
 
   float4 ra[A_LOADS], rb[B_LOADS];
-  const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
 
-  auto load_tile = [&](int kt) {
-    const int kk = kt * BK + lcol * 4;
+  // (r, s, c) of this thread's float4 column, advanced incrementally from K-tile to K-tile
+  int kk = lcol * 4;
+  int tap = kk / a.Cin;
+  int kc = kk - tap * a.Cin;
+  int kr = tap / a.KW;
+  int ks = tap - kr * a.KW;
+
+  auto load_tile = [&]() {
     const bool kvalid = kk < a.K;
-    const int tap = kk / a.Cin;
-    const int c = kk - tap * a.Cin;
-    const int r = tap / a.KW;
-    const int s = tap - r * a.KW;
 #pragma unroll
     for (int i = 0; i < A_LOADS; ++i) {
-      const int hi = hi0[i] + r, wi = wi0[i] + s;
+      const int hi = hi0[i] + kr, wi = wi0[i] + ks;
       const bool ok = kvalid && (unsigned)hi < (unsigned)a.H && (unsigned)wi < (unsigned)a.W;
-      const int64_t off = ((int64_t)(pixbase[i] + hi * a.W + wi)) * a.Cin + c;
-      ra[i] = ok ? *reinterpret_cast<const float4*>(a.x + off) : zero4;
+      const unsigned off = ((unsigned)(pixbase[i] + hi * a.W + wi) * (unsigned)a.Cin + (unsigned)kc) * 4u;
+      ra[i] = buf_load4(xr, ok ? off : kOOB);
     }
 #pragma unroll
-    for (int i = 0; i < B_LOADS; ++i) {
-      const int n = bn0 + lrow + 32 * i;
-      const bool ok = kvalid && n < a.Cout;
-      rb[i] = ok ? *reinterpret_cast<const float4*>(a.w + (int64_t)n * a.K + kk) : zero4;
+    for (int i = 0; i < B_LOADS; ++i)
+      rb[i] = buf_load4(wr, (kvalid && wrow[i] != kOOB) ? wrow[i] + (unsigned)kk * 4u : kOOB);
+    // advance to the next K-tile
+    kk += BK;
+    kc += BK;
+    while (kc >= a.Cin) {
+      kc -= a.Cin;
+      if (++ks == a.KW) {
+        ks = 0;
+        ++kr;
+      }
     }
   };
   auto store_tile = [&]() {
@@ -129,7 +168,7 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(const ConvArgs a) {
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
   const int nk = (a.K + BK - 1) / BK;
-  load_tile(0);
+  load_tile();
   store_tile();
   __syncthreads();
 
@@ -138,7 +177,7 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(const ConvArgs a) {
   const float* Ab = As + (wm * TM * 32 + frag_row) * LDS_STRIDE + frag_k;
   const float* Bb = Bs + (wn * TN * 32 + frag_row) * LDS_STRIDE + frag_k;
   for (int kt = 0; kt < nk; ++kt) {
-    if (kt + 1 < nk) load_tile(kt + 1);  // global loads in flight during the MFMAs below
+    if (kt + 1 < nk) load_tile();  // buffer loads in flight during the MFMAs below
 #pragma unroll
     for (int j = 0; j < BK / 8; ++j) {
       float4 fa[TM], fb[TN];
@@ -169,37 +208,59 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(const ConvArgs a) {
     }
   }
 
-  // epilogue: D layout of the 32x32 MFMA — col = lane & 31, row = (reg & 3) + 8*(reg >> 2) + 4*(lane >> 5)
+  // epilogue: D layout of the 32x32 MFMA — col = lane & 31, row = (reg & 3) + 8*(reg >> 2) + 4*(lane >> 5).
+  // Ragged edges are handled by out-of-range buffer offsets (loads give 0, stores are dropped).
+  const __amdgpu_buffer_rsrc_t yr = make_rsrc(a.y, a.y_bytes);
+  const __amdgpu_buffer_rsrc_t ar = make_rsrc(a.addend ? a.addend : a.y, a.addend ? a.y_bytes : 0u);
+  const __amdgpu_buffer_rsrc_t mr = make_rsrc(a.mask_ref ? a.mask_ref : a.y, a.mask_ref ? a.y_bytes : 0u);
   const int col_in = lane & 31;
   const int row_hi = 4 * (lane >> 5);
 #pragma unroll
   for (int in = 0; in < TN; ++in) {
     const int n = bn0 + wn * TN * 32 + in * 32 + col_in;
-    if (n >= a.Cout) continue;
-    const float sc = a.scale ? a.scale[n] : 1.f;
-    const float bi = a.bias ? a.bias[n] : 0.f;
+    const bool nvalid = n < a.Cout;
+    const float sc = (a.scale && nvalid) ? a.scale[n] : 1.f;
+    const float bi = (a.bias && nvalid) ? a.bias[n] : 0.f;
 #pragma unroll
     for (int im = 0; im < TM; ++im) {
+      // four rows (one accumulator row-group) at a time keeps the epilogue's live registers small; the
+      // scheduling barrier stops hipcc from interleaving all 16 groups (which cost 200+ VGPRs and occupancy)
 #pragma unroll
-      for (int reg = 0; reg < 16; ++reg) {
-        const int m = bm0 + wm * TM * 32 + im * 32 + (reg & 3) + 8 * (reg >> 2) + row_hi;
-        if (m >= a.M) continue;
-        int64_t orow = m;
-        if (a.os != 1) {
-          const int img = m / HoWo;
-          const int rem = m - img * HoWo;
-          const int ho = rem / a.Wo;
-          const int wo = rem - ho * a.Wo;
-          orow = ((int64_t)img * a.OutH + (int64_t)ho * a.os) * a.OutW + (int64_t)wo * a.os;
+      for (int g = 0; g < 4; ++g) {
+        unsigned offs[4];
+        float add[4], msk[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int m = bm0 + wm * TM * 32 + im * 32 + q + 8 * g + row_hi;
+          unsigned orow = (unsigned)m;
+          if (a.os != 1) {
+            const int img = m / HoWo;
+            const int rem = m - img * HoWo;
+            const int ho = rem / a.Wo;
+            const int wo = rem - ho * a.Wo;
+            orow = (unsigned)((img * a.OutH + ho * a.os) * a.OutW + wo * a.os);
+          }
+          offs[q] = (nvalid && m < a.M) ? (orow * (unsigned)a.Cout + (unsigned)n) * 4u : kOOB;
         }
-        const int64_t off = orow * a.Cout + n;
-        float v = acc[im][in][reg];
-        if (a.scale) v = v * sc;
-        if (a.bias) v = v + bi;
-        if (a.addend) v = v + a.addend[off];
-        if (a.relu_mode == 1) v = fmaxf(v, 0.f);
-        else if (a.relu_mode == 2) v = (a.mask_ref[off] > 0.f) ? v : 0.f;
-        a.y[off] = v;
+        if (a.addend) {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) add[q] = buf_load1(ar, offs[q]);
+        }
+        if (a.relu_mode == 2) {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) msk[q] = buf_load1(mr, offs[q]);
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          float v = acc[im][in][g * 4 + q];
+          if (a.scale) v = v * sc;
+          if (a.bias) v = v + bi;
+          if (a.addend) v = v + add[q];
+          if (a.relu_mode == 1) v = fmaxf(v, 0.f);
+          else if (a.relu_mode == 2) v = (msk[q] > 0.f) ? v : 0.f;
+          buf_store1(yr, offs[q], v);
+        }
+        __builtin_amdgcn_sched_barrier(0);
       }
     }
   }
@@ -220,9 +281,10 @@ struct WgradArgs {
   int tiles_co, tiles_kc, splits, rows_per_split;  // rows_per_split is a multiple of 32
   int direct;       // 1: write dw with scale / accumulate applied here
   int accumulate;
+  unsigned x_bytes, gy_bytes;
 };
 
-__global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs a) {
+__global__ __launch_bounds__(256, 3) void conv_wgrad_kernel(const WgradArgs a) {
   constexpr int TILE = 128, RK = 32;  // output tile 128x128, 32 m-rows per step
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float* Gs = reinterpret_cast<float*>(smem);   // [RK][TILE]  gY rows
@@ -253,28 +315,43 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs a) {
   const bool covalid = co < a.Cout;  // Cout % 4 == 0 is required by the host wrapper
   const int HoWo = a.Ho * a.Wo;
 
+  const __amdgpu_buffer_rsrc_t xr = make_rsrc(a.x, a.x_bytes);
+  const __amdgpu_buffer_rsrc_t gr = make_rsrc(a.gy, a.gy_bytes);
   float4 rg[4], rx[4];
-  const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
-  auto load_tile = [&](int m0) {
+  const unsigned co_off = covalid ? (unsigned)co * 4u : kOOB;
+  // (img, ho, wo) of this thread's four rows, advanced by RK rows per step
+  int r_img[4], r_ho[4], r_wo[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int m = m_begin + lrow + 8 * i;
+    r_img[i] = m / HoWo;
+    const int rem = m - r_img[i] * HoWo;
+    r_ho[i] = rem / a.Wo;
+    r_wo[i] = rem - r_ho[i] * a.Wo;
+  }
+  int m_cur = m_begin;
+  auto load_tile = [&]() {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      const int m = m0 + lrow + 8 * i;
+      const int m = m_cur + lrow + 8 * i;
       const bool mv = m < m_end;
-      rg[i] = (mv && covalid) ? *reinterpret_cast<const float4*>(a.gy + (int64_t)m * a.Cout + co) : zero4;
-      bool ok = mv && kvalid;
-      int64_t off = 0;
-      if (ok) {
-        const int img = m / HoWo;
-        const int rem = m - img * HoWo;
-        const int ho = rem / a.Wo;
-        const int wo = rem - ho * a.Wo;
-        const int hi = ho * a.stride - a.pad + r;
-        const int wi = wo * a.stride - a.pad + s;
-        ok = (unsigned)hi < (unsigned)a.H && (unsigned)wi < (unsigned)a.W;
-        off = ((int64_t)(img * a.H + hi) * a.W + wi) * a.Cin + ci;
+      rg[i] = buf_load4(gr, (mv && covalid) ? (unsigned)m * (unsigned)a.Cout * 4u + co_off : kOOB);
+      const int hi = r_ho[i] * a.stride - a.pad + r;
+      const int wi = r_wo[i] * a.stride - a.pad + s;
+      const bool ok = mv && kvalid && (unsigned)hi < (unsigned)a.H && (unsigned)wi < (unsigned)a.W;
+      const unsigned off = ((unsigned)((r_img[i] * a.H + hi) * a.W + wi) * (unsigned)a.Cin + (unsigned)ci) * 4u;
+      rx[i] = buf_load4(xr, ok ? off : kOOB);
+      // advance this row by RK output pixels
+      r_wo[i] += RK;
+      while (r_wo[i] >= a.Wo) {
+        r_wo[i] -= a.Wo;
+        if (++r_ho[i] == a.Ho) {
+          r_ho[i] = 0;
+          ++r_img[i];
+        }
       }
-      rx[i] = ok ? *reinterpret_cast<const float4*>(a.x + off) : zero4;
     }
+    m_cur += RK;
   };
   auto store_tile = [&]() {
 #pragma unroll
@@ -294,7 +371,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs a) {
 
   const int nsteps = (m_end - m_begin + RK - 1) / RK;
   if (nsteps > 0) {
-    load_tile(m_begin);
+    load_tile();
     store_tile();
   }
   __syncthreads();
@@ -302,7 +379,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs a) {
   const float* Gb = Gs + wm * 64 + fcol;
   const float* Xb = Xs + wn * 64 + fcol;
   for (int st = 0; st < nsteps; ++st) {
-    if (st + 1 < nsteps) load_tile(m_begin + (st + 1) * RK);
+    if (st + 1 < nsteps) load_tile();
 #pragma unroll
     for (int k2 = 0; k2 < RK / 2; ++k2) {
       const int row = 2 * k2 + fk;
@@ -465,6 +542,11 @@ extern "C" int dadet_conv_forward(const dadet_conv_desc* d, const float* x, cons
   a.os = os; a.relu_mode = d->relu_mode;
   a.M = d->N * d->Ho * d->Wo;
   a.K = d->KH * d->KW * d->Cin;
+  const uint64_t xb = (uint64_t)d->N * d->H * d->W * d->Cin * 4, wb = (uint64_t)d->Cout * a.K * 4,
+                 yb = (uint64_t)d->N * d->OutH * d->OutW * d->Cout * 4;
+  DADET_REQUIRE(xb < 0xFFFFFFF0ull && wb < 0xFFFFFFF0ull && yb < 0xFFFFFFF0ull,
+                "conv_forward: tensors of 4 GB or more are not addressable through one buffer descriptor");
+  a.x_bytes = (unsigned)xb; a.w_bytes = (unsigned)wb; a.y_bytes = (unsigned)yb;
   hipStream_t st = as_stream(stream);
   switch (fwd_variant(a.M, a.Cout)) {
     case 0: return launch_fwd<2, 2>(a, st);
@@ -523,6 +605,10 @@ extern "C" int dadet_conv_wgrad(const dadet_conv_desc* d, const float* x, const 
   a.N = d->N; a.H = d->H; a.W = d->W; a.Cin = d->Cin; a.Cout = d->Cout; a.KH = d->KH; a.KW = d->KW;
   a.stride = d->stride; a.pad = d->pad; a.Ho = d->Ho; a.Wo = d->Wo;
   a.M = d->N * d->Ho * d->Wo; a.K = K;
+  const uint64_t xb = (uint64_t)d->N * d->H * d->W * d->Cin * 4, gb = (uint64_t)a.M * d->Cout * 4;
+  DADET_REQUIRE(xb < 0xFFFFFFF0ull && gb < 0xFFFFFFF0ull,
+                "conv_wgrad: tensors of 4 GB or more are not addressable through one buffer descriptor");
+  a.x_bytes = (unsigned)xb; a.gy_bytes = (unsigned)gb;
   wgrad_plan(d, &a.tiles_co, &a.tiles_kc, &a.splits, &a.rows_per_split);
   a.accumulate = accumulate;
   if (a.splits == 1) {
