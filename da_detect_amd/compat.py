@@ -1,0 +1,37 @@
+"""Drop-in aliasing: after `compat.install()`, `import maskrcnn_benchmark.<x>` resolves to `da_detect_amd.<x>`.
+
+The reference's entry points import e.g. `maskrcnn_benchmark.config.cfg`, `maskrcnn_benchmark.modeling.detector.
+build_detection_model`, `maskrcnn_benchmark.solver.make_optimizer`, `maskrcnn_benchmark.structures.image_list.
+to_image_list`, `maskrcnn_benchmark.layers.*`, `maskrcnn_benchmark._C` (reference: tools/train_net_triplet.py:16-36,
+maskrcnn_benchmark/layers/nms.py:2).  This package mirrors those module paths one to one, so aliasing the package
+prefix is enough; data loading / checkpoint / evaluation modules of the reference are outside the hot path and are
+not provided (INTEGRATION.md lists them)."""
+import importlib
+import sys
+
+_SUBMODULES = [
+    "_C", "config", "config.defaults", "layers", "layers.roi_align", "layers.misc", "structures",
+    "structures.bounding_box", "structures.boxlist_ops", "structures.image_list", "modeling", "modeling.registry",
+    "modeling.box_coder", "modeling.matcher", "modeling.balanced_positive_negative_sampler", "modeling.poolers",
+    "modeling.utils", "modeling.backbone", "modeling.backbone.resnet", "modeling.backbone.backbone", "modeling.rpn",
+    "modeling.rpn.rpn", "modeling.rpn.anchor_generator", "modeling.rpn.inference", "modeling.rpn.loss",
+    "modeling.rpn.utils", "modeling.roi_heads", "modeling.roi_heads.roi_heads", "modeling.roi_heads.box_head",
+    "modeling.roi_heads.box_head.box_head", "modeling.roi_heads.box_head.loss",
+    "modeling.roi_heads.box_head.inference", "modeling.roi_heads.box_head.roi_box_feature_extractors",
+    "modeling.roi_heads.box_head.roi_box_predictors", "modeling.da_heads", "modeling.da_heads.da_heads",
+    "modeling.da_heads.loss", "modeling.detector", "modeling.detector.detectors",
+    "modeling.detector.generalized_rcnn", "solver", "solver.build", "solver.lr_scheduler", "engine",
+    "engine.trainer", "utils", "utils.comm", "utils.registry",
+]
+
+
+def install(prefix="maskrcnn_benchmark"):
+    if prefix in sys.modules and not getattr(sys.modules[prefix], "__dadet_alias__", False):
+        raise RuntimeError("%s is already imported from elsewhere; install the alias before importing it" % prefix)
+    root = importlib.import_module("da_detect_amd")
+    root.__dadet_alias__ = True
+    sys.modules[prefix] = root
+    for sub in _SUBMODULES:
+        mod = importlib.import_module("da_detect_amd." + sub)
+        sys.modules[prefix + "." + sub] = mod
+    return root
