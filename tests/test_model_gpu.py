@@ -208,12 +208,12 @@ def test_roi_align_constant_and_linearity_at_full_size(device):
 
     g = torch.Generator().manual_seed(6)
     R = 512
-    xy = torch.rand((R, 2), generator=g) * torch.tensor([1700.0, 800.0])
+    xy = torch.rand((R, 2), generator=g) * torch.tensor([1700.0, 680.0])  # ROIs stay inside the 2048x1024 image
     rois = torch.cat([(torch.arange(R) % 2).float().view(-1, 1), xy, xy + torch.rand((R, 2), generator=g) * 300 + 20], 1).to(device)
     const = torch.full((2, 1024, 64, 128), 3.25, device=device)
     out = _C.roi_align_forward(const, rois, 1 / 16.0, 14, 14, 0)
     assert out.shape == (R, 1024, 14, 14)
-    torch.testing.assert_close(out, torch.full_like(out, 3.25), rtol=1e-6, atol=1e-6)
+    torch.testing.assert_close(out, torch.full_like(out, 3.25), rtol=2e-6, atol=2e-6)
     a = torch.randn((2, 256, 64, 128), device=device)
     b = torch.randn((2, 256, 64, 128), device=device)
     ya, yb, yab = [_C.roi_align_forward(t, rois, 1 / 16.0, 14, 14, 0) for t in (a, b, a + b)]

@@ -119,7 +119,8 @@ def test_roi_align_backward(device, C, H, W, R, ph, sr, atomic):
     got = _C.roi_align_backward(torch.from_numpy(g).to(device), torch.from_numpy(rois).to(device), 1 / 16.0,
                                 ph, ph, 2, C, H, W, sr, atomic=atomic).cpu().numpy()
     # gather form (default) / atomic scatter form: summation order differs from the oracle -> fp32 tolerance
-    np.testing.assert_allclose(got, want, rtol=1e-5, atol=1e-5)
+    tol = 1e-4 if atomic else 1e-5  # the atomic form sums hundreds of contributions per pixel in arrival order
+    np.testing.assert_allclose(got, want, rtol=tol, atol=tol)
 
 
 def test_roi_align_empty(device):
