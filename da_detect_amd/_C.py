@@ -212,7 +212,9 @@ def conv_forward(x, w, scale=None, bias=None, addend=None, mask_ref=None, stride
     d = _desc(N, H, W, Cin, Cout, KH, KW, stride, pad, Ho, Wo, OutH, OutW, out_spatial_stride, relu_mode)
     if PROFILER is not None:
         variant = _lib.load().dadet_conv_forward_variant(ctypes.byref(d))
-        with PROFILER.span("conv_fwd_kernel<%s>" % ("2,2", "2,1", "1,1")[variant],
+        mode = get_gemm_mode()
+        kname = "conv_fwd_kernel<%s>" if mode == 0 else ("conv_fwd_split_kernel<%%s,%d>" % mode)
+        with PROFILER.span(kname % ("2,2", "2,1", "1,1")[variant],
                            2.0 * N * Ho * Wo * Cout * Cin * KH * KW):
             _lib.call("dadet_conv_forward", ctypes.byref(d), _p(x), _p(w), _p(scale), _p(bias), _p(addend),
                       _p(mask_ref), _p(out), _stream())
@@ -391,6 +393,15 @@ def triplet_w_backward(a, p, n, dist, g_scale, margin, eps=1e-6, need=(True, Tru
     _lib.call("dadet_triplet_w_backward", _p(a), _p(p), _p(n), _p(dist), _p(g_scale), H, W, C, float(margin),
               float(eps), _p(ga), _p(gp), _p(gn), _stream())
     return ga, gp, gn
+
+
+def set_gemm_mode(mode):
+    """0 exact fp32 MFMA | 3 three-term bf16 split (fp32-class accuracy) | 2 two-term split; see include/dadet.h"""
+    _lib.call("dadet_set_gemm_mode", int(mode))
+
+
+def get_gemm_mode():
+    return _lib.load().dadet_get_gemm_mode()
 
 
 def device_info():

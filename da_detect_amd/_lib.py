@@ -42,6 +42,8 @@ _SIGNATURES = {
     "dadet_sigmoid_focal_loss_backward": [_P, _P, _P, _P, c_int, c_int, c_float, c_float, _P],
     "dadet_conv_forward": [POINTER(ConvDesc), _P, _P, _P, _P, _P, _P, _P, _P],
     "dadet_conv_forward_variant": [POINTER(ConvDesc)],
+    "dadet_set_gemm_mode": [c_int],
+    "dadet_get_gemm_mode": [],
     "dadet_conv_wgrad_workspace_bytes": [POINTER(ConvDesc), POINTER(c_size_t)],
     "dadet_conv_wgrad": [POINTER(ConvDesc), _P, _P, _P, _P, c_int, _P, c_size_t, _P],
     "dadet_conv_weight_transpose": [_P, _P, _P, c_int, c_int, c_int, c_int, _P],

@@ -1,0 +1,78 @@
+// Shared declarations of the implicit-GEMM convolution kernels (conv_igemm.hip: exact fp32 MFMA;
+// conv_split.hip: split-bf16 MFMA).
+#pragma once
+#include "common.h"
+
+namespace dadet {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+// Buffer-descriptor access (guide T8): a raw buffer load whose byte offset is >= num_records returns 0 and
+// a raw buffer store there is dropped, so padding taps, ragged tile edges and the K tail need NO branches
+// and NO selects — every load of a K-tile is issued back to back and waited for once, right before the LDS
+// write.  (The first version used `ok ? *p : 0`: hipcc lowered it to exec-masked flat_loads each followed by
+// s_waitcnt vmcnt(0), i.e. eight serialised memory round trips per K-tile in front of the MFMAs.)
+constexpr unsigned kOOB = 0xFFFFFFF0u;  // 16-byte aligned, beyond any supported buffer
+__device__ inline __amdgpu_buffer_rsrc_t make_rsrc(const void* p, unsigned bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, (int)bytes, 0x00020000);
+}
+__device__ inline float4 buf_load4(__amdgpu_buffer_rsrc_t r, unsigned byte_off) {
+  return __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)byte_off, 0, 0));
+}
+__device__ inline float buf_load1(__amdgpu_buffer_rsrc_t r, unsigned byte_off) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, (int)byte_off, 0, 0));
+}
+__device__ inline void buf_store1(__amdgpu_buffer_rsrc_t r, unsigned byte_off, float v) {
+  __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), r, (int)byte_off, 0, 0);
+}
+
+constexpr int BK = 32;          // K-tile
+constexpr int LDS_STRIDE = 36;  // floats per staged row (32 + 4 pad, keeps 16-byte alignment)
+
+struct ConvArgs {
+  const float* x;
+  const float* w;
+  const float* scale;
+  const float* bias;
+  const float* addend;
+  const float* mask_ref;
+  float* y;
+  int N, H, W, Cin, Cout, KH, KW, stride, pad, Ho, Wo, OutH, OutW, os, relu_mode;
+  int M, K;        // GEMM rows, reduction length
+  int tiles_m, tiles_n;
+  unsigned x_bytes, w_bytes, y_bytes;  // buffer extents (< 4 GB each)
+};
+
+struct WgradArgs {
+  const float* x;
+  const float* gy;
+  const float* out_scale;
+  float* out;       // dw (splits == 1) or workspace [splits][Cout][K]
+  int N, H, W, Cin, Cout, KH, KW, stride, pad, Ho, Wo;
+  int M, K;
+  int tiles_co, tiles_kc, splits, rows_per_split;  // rows_per_split is a multiple of 32
+  int direct;       // 1: write dw with scale / accumulate applied here
+  int accumulate;
+  unsigned x_bytes, gy_bytes;
+};
+
+// tile variant chosen for a forward / dgrad GEMM of M rows and Cout columns
+//   0: 128x128 (TM=2,TN=2)   1: 128x64 (TM=2,TN=1)   2: 64x64 (TM=1,TN=1)
+inline int fwd_variant(int M, int Cout) {
+  const int64_t t128 = (int64_t)ceil_div(M, 128) * ceil_div(Cout, 128);
+  if (Cout > 64 && t128 >= 2 * kNumCU) return 0;
+  if (Cout > 32) {
+    const int64_t t64 = (int64_t)ceil_div(M, 128) * ceil_div(Cout, 64);
+    if (t64 >= kNumCU || M <= 64 * 64) return 1;
+    return 2;
+  }
+  return 1;
+}
+
+// 0 = exact fp32 MFMA (default); 2 / 3 = products from a 2- / 3-term bf16 split of both operands
+int gemm_mode();
+int launch_fwd_split(ConvArgs& a, int variant, int terms, hipStream_t st);
+int launch_wgrad_split(WgradArgs& a, int terms, hipStream_t st);
+
+}  // namespace dadet

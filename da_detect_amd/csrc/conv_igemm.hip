@@ -25,48 +25,9 @@
 // this cross-workgroup overlap that keeps the matrix pipe fed across the two barriers of a K-tile (PMC on
 // the double-buffered / 2-workgroup variant: 38% of wave cycles parked in s_waitcnt/s_barrier).
 // Workgroup ids are remapped so that each XCD (private L2) walks a contiguous range of m-tiles.
-#include "common.h"
+#include "conv_common.h"
 
 namespace dadet {
-
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-
-// Buffer-descriptor access (guide T8): a raw buffer load whose byte offset is >= num_records returns 0 and
-// a raw buffer store there is dropped, so padding taps, ragged tile edges and the K tail need NO branches
-// and NO selects — every load of a K-tile is issued back to back and waited for once, right before the LDS
-// write.  (The first version used `ok ? *p : 0`: hipcc lowered it to exec-masked flat_loads each followed by
-// s_waitcnt vmcnt(0), i.e. eight serialised memory round trips per K-tile in front of the MFMAs.)
-constexpr unsigned kOOB = 0xFFFFFFF0u;  // 16-byte aligned, beyond any supported buffer
-__device__ inline __amdgpu_buffer_rsrc_t make_rsrc(const void* p, unsigned bytes) {
-  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, (int)bytes, 0x00020000);
-}
-__device__ inline float4 buf_load4(__amdgpu_buffer_rsrc_t r, unsigned byte_off) {
-  return __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)byte_off, 0, 0));
-}
-__device__ inline float buf_load1(__amdgpu_buffer_rsrc_t r, unsigned byte_off) {
-  return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, (int)byte_off, 0, 0));
-}
-__device__ inline void buf_store1(__amdgpu_buffer_rsrc_t r, unsigned byte_off, float v) {
-  __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), r, (int)byte_off, 0, 0);
-}
-
-constexpr int BK = 32;          // K-tile
-constexpr int LDS_STRIDE = 36;  // floats per staged row (32 + 4 pad, keeps 16-byte alignment)
-
-struct ConvArgs {
-  const float* x;
-  const float* w;
-  const float* scale;
-  const float* bias;
-  const float* addend;
-  const float* mask_ref;
-  float* y;
-  int N, H, W, Cin, Cout, KH, KW, stride, pad, Ho, Wo, OutH, OutW, os, relu_mode;
-  int M, K;        // GEMM rows, reduction length
-  int tiles_m, tiles_n;
-  unsigned x_bytes, w_bytes, y_bytes;  // buffer extents (< 4 GB each)
-};
 
 template <int TM, int TN>
 __global__ __launch_bounds__(256, 3) void conv_fwd_kernel(const ConvArgs a) {
@@ -271,18 +232,6 @@ __global__ __launch_bounds__(256, 3) void conv_fwd_kernel(const ConvArgs a) {
 // Both operands are staged as [32 m-rows][128 columns] (their natural HBM orientation, 16 B per lane
 // along the channel axis); MFMA fragments are ds_read_b32 down the columns — consecutive lanes hit
 // consecutive banks, so no padding is needed.  grid = (co tiles * kc tiles, m splits).
-struct WgradArgs {
-  const float* x;
-  const float* gy;
-  const float* out_scale;
-  float* out;       // dw (splits == 1) or workspace [splits][Cout][K]
-  int N, H, W, Cin, Cout, KH, KW, stride, pad, Ho, Wo;
-  int M, K;
-  int tiles_co, tiles_kc, splits, rows_per_split;  // rows_per_split is a multiple of 32
-  int direct;       // 1: write dw with scale / accumulate applied here
-  int accumulate;
-  unsigned x_bytes, gy_bytes;
-};
 
 __global__ __launch_bounds__(256, 3) void conv_wgrad_kernel(const WgradArgs a) {
   constexpr int TILE = 128, RK = 32;  // output tile 128x128, 32 m-rows per step
@@ -509,19 +458,6 @@ static int launch_fwd(ConvArgs& a, hipStream_t st) {
   return check_launch("conv_forward");
 }
 
-// tile choice: widest tile whose grid still gives every CU about two workgroups
-//   0: 128x128 (conv_fwd_kernel<2,2>)   1: 128x64 (<2,1>)   2: 64x64 (<1,1>)
-static int fwd_variant(int M, int Cout) {
-  const int64_t t128 = (int64_t)ceil_div(M, 128) * ceil_div(Cout, 128);
-  if (Cout > 64 && t128 >= 2 * kNumCU) return 0;
-  if (Cout > 32) {
-    const int64_t t64 = (int64_t)ceil_div(M, 128) * ceil_div(Cout, 64);
-    if (t64 >= kNumCU || M <= 64 * 64) return 1;
-    return 2;
-  }
-  return 1;
-}
-
 extern "C" int dadet_conv_forward(const dadet_conv_desc* d, const float* x, const float* w,
                                   const float* scale, const float* bias, const float* addend,
                                   const float* mask_ref, float* y, void* stream) {
@@ -548,6 +484,7 @@ extern "C" int dadet_conv_forward(const dadet_conv_desc* d, const float* x, cons
                 "conv_forward: tensors of 4 GB or more are not addressable through one buffer descriptor");
   a.x_bytes = (unsigned)xb; a.w_bytes = (unsigned)wb; a.y_bytes = (unsigned)yb;
   hipStream_t st = as_stream(stream);
+  if (gemm_mode() != 0) return launch_fwd_split(a, fwd_variant(a.M, a.Cout), gemm_mode(), st);
   switch (fwd_variant(a.M, a.Cout)) {
     case 0: return launch_fwd<2, 2>(a, st);
     case 1: return launch_fwd<2, 1>(a, st);

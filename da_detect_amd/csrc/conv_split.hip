@@ -1,0 +1,304 @@
+// Implicit-GEMM convolution with fp32 operands contracted on the bf16 matrix pipe through an exact
+// operand split (gfx950: v_mfma_f32_32x32x16_bf16 is 16x the rate of v_mfma_f32_32x32x2_f32).
+//
+//   x = x0 + x1 (+ x2) + eps,   x0 = bf16(x), x1 = bf16(x - x0), x2 = bf16(x - x0 - x1)      (round to nearest even)
+// Each term carries 8 significand bits and the residuals are formed exactly in fp32, so the 2-term split
+// represents x to 2^-17 relative and the 3-term split to 2^-25 — below one fp32 ulp.  Products of bf16 values are
+// exact in the MFMA's fp32 accumulator, so
+//   TERMS = 3:  a*b ~= a0b0 + a0b1 + a1b0 + a0b2 + a1b1 + a2b0      6 MFMAs per K=16, error ~2^-24 |ab|  (fp32 class)
+//   TERMS = 2:  a*b ~= a0b0 + a0b1 + a1b0                           3 MFMAs per K=16, error ~2^-16 |ab|
+// against 8 fp32 MFMAs (512 cycles) for the same K=16 on the fp32 pipe: 192 resp. 96 cycles of matrix time.
+// The split is done once per staged element (when the K-tile goes from registers to LDS), i.e. it is amortised
+// over the 128-wide reuse of the tile; the LDS image is one [rows][32 + 8 pad] bf16 plane per term (80-byte
+// rows: ds_read_b128 fragment reads and ds_write_b64 staging writes are both bank-conflict free).
+// Everything else — buffer-descriptor loads, tap/channel indexing, XCD-aware tile order, fused epilogue — is the
+// fp32 kernel's (conv_igemm.hip).  Selected with dadet_set_gemm_mode(); the default stays exact fp32.
+#include "conv_common.h"
+
+namespace dadet {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+constexpr int PLANE_STRIDE = 40;  // bf16 per staged row: 32 + 8 pad = 80 bytes
+
+static int g_gemm_mode = 0;
+int gemm_mode() { return g_gemm_mode; }
+
+__device__ inline unsigned pack_bf16(float lo, float hi) {
+  unsigned r;
+  asm volatile("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
+  return r;
+}
+__device__ inline float lo_as_float(unsigned p) { return __builtin_bit_cast(float, p << 16); }
+__device__ inline float hi_as_float(unsigned p) { return __builtin_bit_cast(float, p & 0xFFFF0000u); }
+
+// split four consecutive-k floats into TERMS planes of 4 bf16 (8 bytes each)
+template <int TERMS>
+__device__ inline void split4(const float4 v, uint2 (&out)[TERMS]) {
+  float a = v.x, b = v.y, c = v.z, d = v.w;
+#pragma unroll
+  for (int t = 0; t < TERMS; ++t) {
+    const unsigned p0 = pack_bf16(a, b), p1 = pack_bf16(c, d);
+    out[t] = make_uint2(p0, p1);
+    if (t + 1 < TERMS) {
+      a -= lo_as_float(p0); b -= hi_as_float(p0);
+      c -= lo_as_float(p1); d -= hi_as_float(p1);
+    }
+  }
+}
+
+template <int TM, int TN, int TERMS>
+__global__ __launch_bounds__(256, 2) void conv_fwd_split_kernel(const ConvArgs a) {
+  constexpr int BM = 2 * TM * 32, BN = 2 * TN * 32;
+  constexpr int A_LOADS = BM / 32, B_LOADS = BN / 32;
+  constexpr int A_PLANE = BM * PLANE_STRIDE, B_PLANE = BN * PLANE_STRIDE;  // bf16 elements
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  __bf16* As = reinterpret_cast<__bf16*>(smem);   // [TERMS][BM][PLANE_STRIDE]
+  __bf16* Bs = As + TERMS * A_PLANE;              // [TERMS][BN][PLANE_STRIDE]
+
+  const int nwg = a.tiles_m * a.tiles_n;
+  const int tile = xcd_remap(blockIdx.x, nwg);
+  const int bm0 = (tile / a.tiles_n) * BM;
+  const int bn0 = (tile % a.tiles_n) * BN;
+  const int t = threadIdx.x;
+  const int lane = t & 63, wave = t >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int lcol = t & 7, lrow = t >> 3;
+
+  const __amdgpu_buffer_rsrc_t xr = make_rsrc(a.x, a.x_bytes);
+  const __amdgpu_buffer_rsrc_t wr = make_rsrc(a.w, a.w_bytes);
+  int pixbase[A_LOADS], hi0[A_LOADS], wi0[A_LOADS];
+  const int HoWo = a.Ho * a.Wo;
+#pragma unroll
+  for (int i = 0; i < A_LOADS; ++i) {
+    const int m = bm0 + lrow + 32 * i;
+    if (m < a.M) {
+      const int img = m / HoWo;
+      const int rem = m - img * HoWo;
+      const int ho = rem / a.Wo;
+      const int wo = rem - ho * a.Wo;
+      pixbase[i] = img * a.H * a.W;
+      hi0[i] = ho * a.stride - a.pad;
+      wi0[i] = wo * a.stride - a.pad;
+    } else {
+      pixbase[i] = 0;
+      hi0[i] = -(1 << 28);
+      wi0[i] = 0;
+    }
+  }
+  unsigned wrow[B_LOADS];
+#pragma unroll
+  for (int i = 0; i < B_LOADS; ++i) {
+    const int n = bn0 + lrow + 32 * i;
+    wrow[i] = n < a.Cout ? (unsigned)n * (unsigned)a.K * 4u : kOOB;
+  }
+  float4 ra[A_LOADS], rb[B_LOADS];
+  int kk = lcol * 4;
+  int tap = kk / a.Cin;
+  int kc = kk - tap * a.Cin;
+  int kr = tap / a.KW;
+  int ks = tap - kr * a.KW;
+
+  auto load_tile = [&]() {
+    const bool kvalid = kk < a.K;
+#pragma unroll
+    for (int i = 0; i < A_LOADS; ++i) {
+      const int hi = hi0[i] + kr, wi = wi0[i] + ks;
+      const bool ok = kvalid && (unsigned)hi < (unsigned)a.H && (unsigned)wi < (unsigned)a.W;
+      const unsigned off = ((unsigned)(pixbase[i] + hi * a.W + wi) * (unsigned)a.Cin + (unsigned)kc) * 4u;
+      ra[i] = buf_load4(xr, ok ? off : kOOB);
+    }
+#pragma unroll
+    for (int i = 0; i < B_LOADS; ++i)
+      rb[i] = buf_load4(wr, (kvalid && wrow[i] != kOOB) ? wrow[i] + (unsigned)kk * 4u : kOOB);
+    kk += BK;
+    kc += BK;
+    while (kc >= a.Cin) {
+      kc -= a.Cin;
+      if (++ks == a.KW) {
+        ks = 0;
+        ++kr;
+      }
+    }
+  };
+  auto store_tile = [&]() {
+#pragma unroll
+    for (int i = 0; i < A_LOADS; ++i) {
+      uint2 parts[TERMS];
+      split4<TERMS>(ra[i], parts);
+#pragma unroll
+      for (int p = 0; p < TERMS; ++p)
+        *reinterpret_cast<uint2*>(As + p * A_PLANE + (lrow + 32 * i) * PLANE_STRIDE + lcol * 4) = parts[p];
+    }
+#pragma unroll
+    for (int i = 0; i < B_LOADS; ++i) {
+      uint2 parts[TERMS];
+      split4<TERMS>(rb[i], parts);
+#pragma unroll
+      for (int p = 0; p < TERMS; ++p)
+        *reinterpret_cast<uint2*>(Bs + p * B_PLANE + (lrow + 32 * i) * PLANE_STRIDE + lcol * 4) = parts[p];
+    }
+  };
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  const int nk = (a.K + BK - 1) / BK;
+  load_tile();
+  store_tile();
+  __syncthreads();
+
+  // MFMA 32x32x16 bf16 fragments: lane l feeds row (l & 31), k = 8*(l >> 5) .. +7 of each 16-wide k step
+  const int frag_row = lane & 31;
+  const int frag_k = (lane >> 5) * 8;
+  const __bf16* Ab = As + (wm * TM * 32 + frag_row) * PLANE_STRIDE + frag_k;
+  const __bf16* Bb = Bs + (wn * TN * 32 + frag_row) * PLANE_STRIDE + frag_k;
+  for (int kt = 0; kt < nk; ++kt) {
+    if (kt + 1 < nk) load_tile();
+#pragma unroll
+    for (int step = 0; step < BK / 16; ++step) {
+      bf16x8 fa[TERMS][TM], fb[TERMS][TN];
+#pragma unroll
+      for (int p = 0; p < TERMS; ++p) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+          fa[p][i] = *reinterpret_cast<const bf16x8*>(Ab + p * A_PLANE + i * 32 * PLANE_STRIDE + step * 16);
+#pragma unroll
+        for (int i = 0; i < TN; ++i)
+          fb[p][i] = *reinterpret_cast<const bf16x8*>(Bb + p * B_PLANE + i * 32 * PLANE_STRIDE + step * 16);
+      }
+      // smallest cross terms first, the leading a0*b0 last
+#pragma unroll
+      for (int order = 2 * (TERMS - 1); order >= 0; --order) {
+#pragma unroll
+        for (int pa = 0; pa < TERMS; ++pa) {
+          const int pb = order - pa;
+          if (pb < 0 || pb >= TERMS) continue;
+          if (pa + pb > TERMS - 1) continue;  // dropped: below the split's own residual
+#pragma unroll
+          for (int im = 0; im < TM; ++im)
+#pragma unroll
+            for (int in = 0; in < TN; ++in)
+              acc[im][in] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[pa][im], fb[pb][in], acc[im][in], 0, 0, 0);
+        }
+      }
+    }
+    if (kt + 1 < nk) {
+      __syncthreads();
+      store_tile();
+      __syncthreads();
+    }
+  }
+
+  // epilogue (same as conv_igemm.hip)
+  const __amdgpu_buffer_rsrc_t yr = make_rsrc(a.y, a.y_bytes);
+  const __amdgpu_buffer_rsrc_t ar = make_rsrc(a.addend ? a.addend : a.y, a.addend ? a.y_bytes : 0u);
+  const __amdgpu_buffer_rsrc_t mr = make_rsrc(a.mask_ref ? a.mask_ref : a.y, a.mask_ref ? a.y_bytes : 0u);
+  const int col_in = lane & 31;
+  const int row_hi = 4 * (lane >> 5);
+#pragma unroll
+  for (int in = 0; in < TN; ++in) {
+    const int n = bn0 + wn * TN * 32 + in * 32 + col_in;
+    const bool nvalid = n < a.Cout;
+    const float sc = (a.scale && nvalid) ? a.scale[n] : 1.f;
+    const float bi = (a.bias && nvalid) ? a.bias[n] : 0.f;
+#pragma unroll
+    for (int im = 0; im < TM; ++im) {
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        unsigned offs[4];
+        float add[4], msk[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int m = bm0 + wm * TM * 32 + im * 32 + q + 8 * g + row_hi;
+          unsigned orow = (unsigned)m;
+          if (a.os != 1) {
+            const int img = m / HoWo;
+            const int rem = m - img * HoWo;
+            const int ho = rem / a.Wo;
+            const int wo = rem - ho * a.Wo;
+            orow = (unsigned)((img * a.OutH + ho * a.os) * a.OutW + wo * a.os);
+          }
+          offs[q] = (nvalid && m < a.M) ? (orow * (unsigned)a.Cout + (unsigned)n) * 4u : kOOB;
+        }
+        if (a.addend) {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) add[q] = buf_load1(ar, offs[q]);
+        }
+        if (a.relu_mode == 2) {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) msk[q] = buf_load1(mr, offs[q]);
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          float v = acc[im][in][g * 4 + q];
+          if (a.scale) v = v * sc;
+          if (a.bias) v = v + bi;
+          if (a.addend) v = v + add[q];
+          if (a.relu_mode == 1) v = fmaxf(v, 0.f);
+          else if (a.relu_mode == 2) v = (msk[q] > 0.f) ? v : 0.f;
+          buf_store1(yr, offs[q], v);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+  }
+}
+
+template <int TM, int TN, int TERMS>
+static int launch_split(ConvArgs& a, hipStream_t st) {
+  constexpr int BM = 2 * TM * 32, BN = 2 * TN * 32;
+  a.tiles_m = ceil_div(a.M, BM);
+  a.tiles_n = ceil_div(a.Cout, BN);
+  const size_t lds = sizeof(__bf16) * TERMS * (BM + BN) * PLANE_STRIDE;
+  static bool attr_set = false;
+  if (!attr_set && lds > 48 * 1024) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_fwd_split_kernel<TM, TN, TERMS>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) {
+      set_error("conv_forward(split): hipFuncSetAttribute: %s", hipGetErrorString(e));
+      return DADET_ELAUNCH;
+    }
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((conv_fwd_split_kernel<TM, TN, TERMS>), dim3(a.tiles_m * a.tiles_n), dim3(256), lds, st, a);
+  return check_launch("conv_forward(split)");
+}
+
+int launch_fwd_split(ConvArgs& a, int variant, int terms, hipStream_t st) {
+  if (terms == 2) {
+    switch (variant) {
+      case 0: return launch_split<2, 2, 2>(a, st);
+      case 1: return launch_split<2, 1, 2>(a, st);
+      default: return launch_split<1, 1, 2>(a, st);
+    }
+  }
+  switch (variant) {
+    case 0: return launch_split<2, 2, 3>(a, st);
+    case 1: return launch_split<2, 1, 3>(a, st);
+    default: return launch_split<1, 1, 3>(a, st);
+  }
+}
+
+int launch_wgrad_split(WgradArgs&, int, hipStream_t) {
+  set_error("conv_wgrad(split): not built yet");
+  return DADET_EUNSUPPORTED;
+}
+
+}  // namespace dadet
+
+// 0 = exact fp32 MFMA (default); 2 = 2-term bf16 split (3 MFMAs / K=16); 3 = 3-term split (6 MFMAs / K=16)
+extern "C" int dadet_set_gemm_mode(int mode) {
+  if (mode != 0 && mode != 2 && mode != 3) {
+    dadet::set_error("set_gemm_mode: mode must be 0, 2 or 3");
+    return DADET_EINVAL;
+  }
+  dadet::g_gemm_mode = mode;
+  return DADET_OK;
+}
+extern "C" int dadet_get_gemm_mode(void) { return dadet::g_gemm_mode; }

@@ -124,6 +124,13 @@ int dadet_conv_forward(const dadet_conv_desc* d, const float* x, const float* w,
                        const float* bias, const float* addend, const float* mask_ref, float* y,
                        void* stream);
 
+/* Contraction mode of dadet_conv_forward (process-wide): 0 = exact fp32 MFMA (v_mfma_f32_32x32x2_f32, default);
+ * 3 = fp32 operands split into three bf16 terms, six v_mfma_f32_32x32x16_bf16 per K=16 (error ~2^-24 |ab|, fp32
+ * class); 2 = two-term split, three MFMAs per K=16 (error ~2^-16 |ab|).  Inputs, outputs and accumulation are
+ * fp32 in every mode. */
+int dadet_set_gemm_mode(int mode);
+int dadet_get_gemm_mode(void);
+
 /* which tile variant dadet_conv_forward launches for this shape: 0 = 128x128 (conv_fwd_kernel<2,2>),
  * 1 = 128x64 (<2,1>), 2 = 64x64 (<1,1>).  Used by bench.py to attribute per-launch timings. */
 int dadet_conv_forward_variant(const dadet_conv_desc* d);

@@ -211,6 +211,32 @@ def test_conv_dgrad_wgrad(device, case):
     torch.testing.assert_close(dx, x.grad, rtol=1e-4, atol=1e-4)
 
 
+@pytest.mark.parametrize("mode,tol", [(3, 2e-5), (2, 2e-3)])
+@pytest.mark.parametrize("case", [CONV_CASES[1], CONV_CASES[3], CONV_CASES[4], CONV_CASES[6], CONV_CASES[9]])
+def test_conv_forward_split_bf16_modes(device, case, mode, tol):
+    """split-bf16 contraction: mode 3 (6 MFMAs / K=16) must hold the exact-fp32 tolerance, mode 2 is ~2^-16"""
+    from da_detect_amd import _C
+
+    N, Cin, H, W, Cout, k, stride, pad = case
+    rng = np.random.default_rng(sum(case) + 5)
+    x, w = _conv_case(rng, *case)
+    ref64 = F.conv2d(x.double(), w.double(), None, stride, pad)
+    xd, wd = x.to(device).contiguous(memory_format=CL), w.to(device).contiguous(memory_format=CL)
+    exact = _C.conv_forward(xd, wd, stride=stride, pad=pad).cpu()
+    _C.set_gemm_mode(mode)
+    try:
+        got = _C.conv_forward(xd, wd, stride=stride, pad=pad).cpu()
+    finally:
+        _C.set_gemm_mode(0)
+    scale = float(ref64.abs().mean())
+    err_exact = float((exact.double() - ref64).abs().max()) / scale
+    err_split = float((got.double() - ref64).abs().max()) / scale
+    print("case %s mode %d: max err / mean|y|  exact-fp32 %.2e  split %.2e" % (case, mode, err_exact, err_split))
+    assert err_split < tol * 10
+    if mode == 3:  # fp32 class: no worse than a few times the exact-fp32 kernel's own rounding
+        assert err_split < max(4 * err_exact, 1e-6)
+
+
 def test_stem_conv7x7_as_padded_7x8(device):
     """BaseStem conv (3->64, 7x7, s2, p3) through NHWC4 staging and a 7x8 zero-padded kernel."""
     from da_detect_amd import _C

@@ -43,6 +43,9 @@ def conv_case(name, N, Cin, H, W, Cout, k, stride, pad):
 
 def main():
     print(_C.device_info())
+    if len(sys.argv) > 1:
+        _C.set_gemm_mode(int(sys.argv[1]))
+        print("gemm mode", _C.get_gemm_mode())
     conv_case("layer1 1x1 64->256", 2, 64, 256, 512, 256, 1, 1, 0)
     conv_case("layer1 3x3 64->64", 2, 64, 256, 512, 64, 3, 1, 1)
     conv_case("layer2 1x1 256->128 s2", 2, 256, 256, 512, 128, 1, 2, 0)
