@@ -251,7 +251,9 @@ def conv_wgrad(x, gy, weight_shape, stride=1, pad=0, out_scale=None, dw=None, ac
     _lib.call("dadet_conv_wgrad_workspace_bytes", ctypes.byref(d), ctypes.byref(nbytes))
     ws = _workspace(nbytes.value, x.device)
     if PROFILER is not None:
-        with PROFILER.span("conv_wgrad_kernel", 2.0 * N * Ho * Wo * Cout * Cin * KH * KW):
+        mode = get_gemm_mode()
+        with PROFILER.span("conv_wgrad_kernel" if mode == 0 else "conv_wgrad_split_kernel<%d>" % mode,
+                           2.0 * N * Ho * Wo * Cout * Cin * KH * KW):
             _lib.call("dadet_conv_wgrad", ctypes.byref(d), _p(x), _p(gy), _p(out_scale), _p(dw),
                       1 if accumulate else 0, _p(ws), ctypes.c_size_t(ws.numel()), _stream())
         return dw

@@ -571,8 +571,12 @@ extern "C" int dadet_conv_wgrad(const dadet_conv_desc* d, const float* x, const 
     }
     attr_set = true;
   }
-  hipLaunchKernelGGL(conv_wgrad_kernel, dim3(a.tiles_co * a.tiles_kc, a.splits), dim3(256), lds, st, a);
-  rc = check_launch("conv_wgrad");
+  if (gemm_mode() != 0) {
+    rc = launch_wgrad_split(a, gemm_mode(), st);
+  } else {
+    hipLaunchKernelGGL(conv_wgrad_kernel, dim3(a.tiles_co * a.tiles_kc, a.splits), dim3(256), lds, st, a);
+    rc = check_launch("conv_wgrad");
+  }
   if (rc) return rc;
   if (a.splits > 1) {
     const int64_t total4 = (int64_t)d->Cout * K / 4;

@@ -285,9 +285,191 @@ int launch_fwd_split(ConvArgs& a, int variant, int terms, hipStream_t st) {
   }
 }
 
-int launch_wgrad_split(WgradArgs&, int, hipStream_t) {
-  set_error("conv_wgrad(split): not built yet");
-  return DADET_EUNSUPPORTED;
+// ------------------------------------------------------------------------------------------------
+// weight gradient on the split-bf16 pipe.  D[co][kc] = sum_m gY[m][co] * Xg[m][kc].  The bf16 MFMA wants each
+// lane's 8 k-values (= 8 consecutive m) contiguous, but m is the slow axis of both operands in HBM, so the
+// staging transposes in registers: a thread loads a 4(m) x 4(channel) block (four 16-byte row loads), splits,
+// and writes for each channel the four m-values as one 8-byte ds_write into a [channel][m] plane
+// ([128][32 + 8 pad] bf16 per term).  Lane -> (m-group = t % 8, channel-quad = t / 8) keeps the global loads as
+// 128-byte row segments and the LDS writes bank-conflict free.
+template <int TERMS>
+__global__ __launch_bounds__(256, 2) void conv_wgrad_split_kernel(const WgradArgs a) {
+  constexpr int TILE = 128, RK = 32;
+  constexpr int PLANE = TILE * PLANE_STRIDE;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  __bf16* Gs = reinterpret_cast<__bf16*>(smem);  // [TERMS][128 co][PLANE_STRIDE]
+  __bf16* Xs = Gs + TERMS * PLANE;               // [TERMS][128 kc][PLANE_STRIDE]
+
+  const int tile = xcd_remap(blockIdx.x, a.tiles_co * a.tiles_kc);
+  const int co0 = (tile / a.tiles_kc) * TILE;
+  const int kc0 = (tile % a.tiles_kc) * TILE;
+  const int split = blockIdx.y;
+  const int m_begin = split * a.rows_per_split;
+  int m_end = m_begin + a.rows_per_split;
+  if (m_end > a.M) m_end = a.M;
+
+  const int t = threadIdx.x;
+  const int lane = t & 63, wave = t >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int mg = t & 7;    // rows mg*4 .. mg*4+3 of the 32-row step
+  const int cq = t >> 3;   // channels cq*4 .. cq*4+3 of the 128-wide tile
+
+  const int kk = kc0 + cq * 4;
+  const bool kvalid = kk < a.K;
+  const int tap = kk / a.Cin;
+  const int ci = kk - tap * a.Cin;
+  const int r = tap / a.KW;
+  const int s = tap - r * a.KW;
+  const int co = co0 + cq * 4;
+  const bool covalid = co < a.Cout;
+  const int HoWo = a.Ho * a.Wo;
+  const __amdgpu_buffer_rsrc_t xr = make_rsrc(a.x, a.x_bytes);
+  const __amdgpu_buffer_rsrc_t gr = make_rsrc(a.gy, a.gy_bytes);
+  const unsigned co_off = covalid ? (unsigned)co * 4u : kOOB;
+
+  float4 rg[4], rx[4];
+  int r_img[4], r_ho[4], r_wo[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int m = m_begin + mg * 4 + j;
+    r_img[j] = m / HoWo;
+    const int rem = m - r_img[j] * HoWo;
+    r_ho[j] = rem / a.Wo;
+    r_wo[j] = rem - r_ho[j] * a.Wo;
+  }
+  int m_cur = m_begin;
+  auto load_tile = [&]() {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int m = m_cur + mg * 4 + j;
+      const bool mv = m < m_end;
+      rg[j] = buf_load4(gr, (mv && covalid) ? (unsigned)m * (unsigned)a.Cout * 4u + co_off : kOOB);
+      const int hi = r_ho[j] * a.stride - a.pad + r;
+      const int wi = r_wo[j] * a.stride - a.pad + s;
+      const bool ok = mv && kvalid && (unsigned)hi < (unsigned)a.H && (unsigned)wi < (unsigned)a.W;
+      const unsigned off = ((unsigned)((r_img[j] * a.H + hi) * a.W + wi) * (unsigned)a.Cin + (unsigned)ci) * 4u;
+      rx[j] = buf_load4(xr, ok ? off : kOOB);
+      r_wo[j] += RK;
+      while (r_wo[j] >= a.Wo) {
+        r_wo[j] -= a.Wo;
+        if (++r_ho[j] == a.Ho) {
+          r_ho[j] = 0;
+          ++r_img[j];
+        }
+      }
+    }
+    m_cur += RK;
+  };
+  auto store_plane = [&](__bf16* base, const float4 (&v)[4]) {
+    // 4x4 register transpose: channel c of the quad gets (row0[c], row1[c], row2[c], row3[c])
+    const float4 cols[4] = {make_float4(v[0].x, v[1].x, v[2].x, v[3].x), make_float4(v[0].y, v[1].y, v[2].y, v[3].y),
+                            make_float4(v[0].z, v[1].z, v[2].z, v[3].z), make_float4(v[0].w, v[1].w, v[2].w, v[3].w)};
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      uint2 parts[TERMS];
+      split4<TERMS>(cols[c], parts);
+#pragma unroll
+      for (int p = 0; p < TERMS; ++p)
+        *reinterpret_cast<uint2*>(base + p * PLANE + (cq * 4 + c) * PLANE_STRIDE + mg * 4) = parts[p];
+    }
+  };
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  const int nsteps = (m_end - m_begin + RK - 1) / RK;
+  if (nsteps > 0) {
+    load_tile();
+    store_plane(Gs, rg);
+    store_plane(Xs, rx);
+  }
+  __syncthreads();
+  const int frag_row = lane & 31;
+  const int frag_k = (lane >> 5) * 8;
+  const __bf16* Gb = Gs + (wm * 64 + frag_row) * PLANE_STRIDE + frag_k;
+  const __bf16* Xb = Xs + (wn * 64 + frag_row) * PLANE_STRIDE + frag_k;
+  for (int st = 0; st < nsteps; ++st) {
+    if (st + 1 < nsteps) load_tile();
+#pragma unroll
+    for (int step = 0; step < RK / 16; ++step) {
+      bf16x8 fg[TERMS][2], fx[TERMS][2];
+#pragma unroll
+      for (int p = 0; p < TERMS; ++p)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          fg[p][i] = *reinterpret_cast<const bf16x8*>(Gb + p * PLANE + i * 32 * PLANE_STRIDE + step * 16);
+          fx[p][i] = *reinterpret_cast<const bf16x8*>(Xb + p * PLANE + i * 32 * PLANE_STRIDE + step * 16);
+        }
+#pragma unroll
+      for (int order = 2 * (TERMS - 1); order >= 0; --order) {
+#pragma unroll
+        for (int pa = 0; pa < TERMS; ++pa) {
+          const int pb = order - pa;
+          if (pb < 0 || pb >= TERMS) continue;
+          if (pa + pb > TERMS - 1) continue;
+#pragma unroll
+          for (int im = 0; im < 2; ++im)
+#pragma unroll
+            for (int in = 0; in < 2; ++in)
+              acc[im][in] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fg[pa][im], fx[pb][in], acc[im][in], 0, 0, 0);
+        }
+      }
+    }
+    if (st + 1 < nsteps) {
+      __syncthreads();
+      store_plane(Gs, rg);
+      store_plane(Xs, rx);
+      __syncthreads();
+    }
+  }
+
+  float* out = a.direct ? a.out : a.out + (size_t)split * a.Cout * a.K;
+  const int col_in = lane & 31, row_hi = 4 * (lane >> 5);
+#pragma unroll
+  for (int in = 0; in < 2; ++in) {
+    const int kc = kc0 + wn * 64 + in * 32 + col_in;
+    if (kc >= a.K) continue;
+#pragma unroll
+    for (int im = 0; im < 2; ++im)
+#pragma unroll
+      for (int reg = 0; reg < 16; ++reg) {
+        const int c = co0 + wm * 64 + im * 32 + (reg & 3) + 8 * (reg >> 2) + row_hi;
+        if (c >= a.Cout) continue;
+        const size_t off = (size_t)c * a.K + kc;
+        float v = acc[im][in][reg];
+        if (a.direct) {
+          if (a.out_scale) v = v * a.out_scale[c];
+          if (a.accumulate) v = v + out[off];
+        }
+        out[off] = v;
+      }
+  }
+}
+
+template <int TERMS>
+static int launch_wgrad_terms(WgradArgs& a, hipStream_t st) {
+  const size_t lds = sizeof(__bf16) * TERMS * 2 * 128 * PLANE_STRIDE;
+  static bool attr_set = false;
+  if (!attr_set && lds > 48 * 1024) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad_split_kernel<TERMS>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) {
+      set_error("conv_wgrad(split): hipFuncSetAttribute: %s", hipGetErrorString(e));
+      return DADET_ELAUNCH;
+    }
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(conv_wgrad_split_kernel<TERMS>, dim3(a.tiles_co * a.tiles_kc, a.splits), dim3(256), lds, st, a);
+  return check_launch("conv_wgrad(split)");
+}
+
+int launch_wgrad_split(WgradArgs& a, int terms, hipStream_t st) {
+  return terms == 2 ? launch_wgrad_terms<2>(a, st) : launch_wgrad_terms<3>(a, st);
 }
 
 }  // namespace dadet

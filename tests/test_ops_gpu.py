@@ -237,6 +237,34 @@ def test_conv_forward_split_bf16_modes(device, case, mode, tol):
         assert err_split < max(4 * err_exact, 1e-6)
 
 
+@pytest.mark.parametrize("mode,tol", [(3, 1e-4), (2, 2e-3)])
+@pytest.mark.parametrize("case", [CONV_CASES[1], CONV_CASES[2], CONV_CASES[3], CONV_CASES[6], CONV_CASES[7], CONV_CASES[9]])
+def test_conv_wgrad_split_bf16_modes(device, case, mode, tol):
+    from da_detect_amd import _C
+
+    N, Cin, H, W, Cout, k, stride, pad = case
+    rng = np.random.default_rng(sum(case) + 9)
+    x, w = _conv_case(rng, *case)
+    Ho, Wo = _C.conv_out_size(H, W, k, k, stride, pad)
+    gy = torch.from_numpy(rng.standard_normal((N, Cout, Ho, Wo)).astype(np.float32))
+    w64 = w.double().requires_grad_(True)
+    F.conv2d(x.double(), w64, None, stride, pad).backward(gy.double())
+    xd, gyd = x.to(device).contiguous(memory_format=CL), gy.to(device).contiguous(memory_format=CL)
+    exact = _C.conv_wgrad(xd, gyd, tuple(w.shape), stride, pad).cpu()
+    _C.set_gemm_mode(mode)
+    try:
+        got = _C.conv_wgrad(xd, gyd, tuple(w.shape), stride, pad).cpu()
+    finally:
+        _C.set_gemm_mode(0)
+    scale = float(w64.grad.abs().mean())
+    err_exact = float((exact.double() - w64.grad).abs().max()) / scale
+    err_split = float((got.double() - w64.grad).abs().max()) / scale
+    print("wgrad case %s mode %d: exact-fp32 %.2e  split %.2e" % (case, mode, err_exact, err_split))
+    assert err_split < tol
+    if mode == 3:
+        assert err_split < max(4 * err_exact, 1e-6)
+
+
 def test_stem_conv7x7_as_padded_7x8(device):
     """BaseStem conv (3->64, 7x7, s2, p3) through NHWC4 staging and a 7x8 zero-padded kernel."""
     from da_detect_amd import _C
