@@ -406,6 +406,14 @@ def get_gemm_mode():
     return _lib.load().dadet_get_gemm_mode()
 
 
+def apply_env_gemm_mode():
+    """DADET_GEMM_MODE = 0 | 2 | 3 selects the contraction mode at start-up (default: 3, the fp32-accurate
+    three-term split; 0 = exact fp32 MFMA)."""
+    import os
+
+    set_gemm_mode(int(os.environ.get("DADET_GEMM_MODE", "3")))
+
+
 def device_info():
     cu, khz, hbm = ctypes.c_int(0), ctypes.c_int(0), ctypes.c_size_t(0)
     name = ctypes.create_string_buffer(64)

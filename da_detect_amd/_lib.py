@@ -87,6 +87,11 @@ def load():
     lib.dadet_last_error.argtypes = []
     lib.dadet_last_error.restype = c_char_p
     _lib = lib
+    # contraction mode of the GEMM kernels: DADET_GEMM_MODE = 3 (default: fp32-accurate 3-term bf16 split),
+    # 0 (exact fp32 MFMA) or 2 (2-term split, ~2^-16 products); see include/dadet.h
+    mode = int(os.environ.get("DADET_GEMM_MODE", "3"))
+    if lib.dadet_set_gemm_mode(mode) != 0:
+        raise DadetError("DADET_GEMM_MODE=%d is not a valid contraction mode (0, 2 or 3)" % mode)
     return lib
 
 
