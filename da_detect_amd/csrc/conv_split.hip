@@ -63,7 +63,12 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_split_kernel(const ConvArgs a
   const int t = threadIdx.x;
   const int lane = t & 63, wave = t >> 6;
   const int wm = wave >> 1, wn = wave & 1;
-  const int lcol = t & 7, lrow = t >> 3;
+  const int lcol = t & 7;
+  // staged row of this thread.  Eight lanes write one row's 64 bytes; a ds_write_b64 is serviced in 16-lane
+  // groups over 32 banks, and with 80-byte rows two rows are bank-disjoint exactly when they are 4 (mod 8) apart,
+  // so consecutive 8-lane groups take rows r and r + 4 (PMC: 33% of LDS cycles were conflicts with r, r + 1).
+  const int lgrp = t >> 3;
+  const int lrow = (lgrp >> 3) * 8 + (lgrp & 1) * 4 + ((lgrp >> 1) & 3);
 
   const __amdgpu_buffer_rsrc_t xr = make_rsrc(a.x, a.x_bytes);
   const __amdgpu_buffer_rsrc_t wr = make_rsrc(a.w, a.w_bytes);
@@ -121,23 +126,29 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_split_kernel(const ConvArgs a
       }
     }
   };
+  // staged tile as packed bf16 terms: produced from ra / rb while the MFMAs of the current tile are in flight
+  // (plain VALU work that hipcc interleaves with the matrix instructions), so that between the two barriers of
+  // a K-tile only the ds_writes remain
+  uint2 pa_[A_LOADS][TERMS], pb_[B_LOADS][TERMS];
+  auto split_a = [&]() {
+#pragma unroll
+    for (int i = 0; i < A_LOADS; ++i) split4<TERMS>(ra[i], pa_[i]);
+  };
+  auto split_b = [&]() {
+#pragma unroll
+    for (int i = 0; i < B_LOADS; ++i) split4<TERMS>(rb[i], pb_[i]);
+  };
   auto store_tile = [&]() {
 #pragma unroll
-    for (int i = 0; i < A_LOADS; ++i) {
-      uint2 parts[TERMS];
-      split4<TERMS>(ra[i], parts);
+    for (int i = 0; i < A_LOADS; ++i)
 #pragma unroll
       for (int p = 0; p < TERMS; ++p)
-        *reinterpret_cast<uint2*>(As + p * A_PLANE + (lrow + 32 * i) * PLANE_STRIDE + lcol * 4) = parts[p];
-    }
+        *reinterpret_cast<uint2*>(As + p * A_PLANE + (lrow + 32 * i) * PLANE_STRIDE + lcol * 4) = pa_[i][p];
 #pragma unroll
-    for (int i = 0; i < B_LOADS; ++i) {
-      uint2 parts[TERMS];
-      split4<TERMS>(rb[i], parts);
+    for (int i = 0; i < B_LOADS; ++i)
 #pragma unroll
       for (int p = 0; p < TERMS; ++p)
-        *reinterpret_cast<uint2*>(Bs + p * B_PLANE + (lrow + 32 * i) * PLANE_STRIDE + lcol * 4) = parts[p];
-    }
+        *reinterpret_cast<uint2*>(Bs + p * B_PLANE + (lrow + 32 * i) * PLANE_STRIDE + lcol * 4) = pb_[i][p];
   };
 
   f32x16 acc[TM][TN];
@@ -150,6 +161,8 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_split_kernel(const ConvArgs a
 
   const int nk = (a.K + BK - 1) / BK;
   load_tile();
+  split_a();
+  split_b();
   store_tile();
   __syncthreads();
 
@@ -159,7 +172,8 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_split_kernel(const ConvArgs a
   const __bf16* Ab = As + (wm * TM * 32 + frag_row) * PLANE_STRIDE + frag_k;
   const __bf16* Bb = Bs + (wn * TN * 32 + frag_row) * PLANE_STRIDE + frag_k;
   for (int kt = 0; kt < nk; ++kt) {
-    if (kt + 1 < nk) load_tile();
+    const bool more = kt + 1 < nk;
+    if (more) load_tile();
 #pragma unroll
     for (int step = 0; step < BK / 16; ++step) {
       bf16x8 fa[TERMS][TM], fb[TERMS][TN];
@@ -187,8 +201,13 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_split_kernel(const ConvArgs a
               acc[im][in] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[pa][im], fb[pb][in], acc[im][in], 0, 0, 0);
         }
       }
+      // the next tile's operands have landed by now: split one operand behind each k16 group of MFMAs
+      if (more) {
+        if (step == 0) split_a();
+        else split_b();
+      }
     }
-    if (kt + 1 < nk) {
+    if (more) {
       __syncthreads();
       store_tile();
       __syncthreads();
@@ -360,18 +379,20 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_split_kernel(const WgradArg
     }
     m_cur += RK;
   };
-  auto store_plane = [&](__bf16* base, const float4 (&v)[4]) {
+  uint2 pg_[4][TERMS], px_[4][TERMS];
+  auto split_block = [&](const float4 (&v)[4], uint2 (&out)[4][TERMS]) {
     // 4x4 register transpose: channel c of the quad gets (row0[c], row1[c], row2[c], row3[c])
     const float4 cols[4] = {make_float4(v[0].x, v[1].x, v[2].x, v[3].x), make_float4(v[0].y, v[1].y, v[2].y, v[3].y),
                             make_float4(v[0].z, v[1].z, v[2].z, v[3].z), make_float4(v[0].w, v[1].w, v[2].w, v[3].w)};
 #pragma unroll
-    for (int c = 0; c < 4; ++c) {
-      uint2 parts[TERMS];
-      split4<TERMS>(cols[c], parts);
+    for (int c = 0; c < 4; ++c) split4<TERMS>(cols[c], out[c]);
+  };
+  auto store_plane = [&](__bf16* base, const uint2 (&parts)[4][TERMS]) {
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
 #pragma unroll
       for (int p = 0; p < TERMS; ++p)
-        *reinterpret_cast<uint2*>(base + p * PLANE + (cq * 4 + c) * PLANE_STRIDE + mg * 4) = parts[p];
-    }
+        *reinterpret_cast<uint2*>(base + p * PLANE + (cq * 4 + c) * PLANE_STRIDE + mg * 4) = parts[c][p];
   };
 
   f32x16 acc[2][2];
@@ -385,8 +406,10 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_split_kernel(const WgradArg
   const int nsteps = (m_end - m_begin + RK - 1) / RK;
   if (nsteps > 0) {
     load_tile();
-    store_plane(Gs, rg);
-    store_plane(Xs, rx);
+    split_block(rg, pg_);
+    split_block(rx, px_);
+    store_plane(Gs, pg_);
+    store_plane(Xs, px_);
   }
   __syncthreads();
   const int frag_row = lane & 31;
@@ -394,7 +417,8 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_split_kernel(const WgradArg
   const __bf16* Gb = Gs + (wm * 64 + frag_row) * PLANE_STRIDE + frag_k;
   const __bf16* Xb = Xs + (wn * 64 + frag_row) * PLANE_STRIDE + frag_k;
   for (int st = 0; st < nsteps; ++st) {
-    if (st + 1 < nsteps) load_tile();
+    const bool more = st + 1 < nsteps;
+    if (more) load_tile();
 #pragma unroll
     for (int step = 0; step < RK / 16; ++step) {
       bf16x8 fg[TERMS][2], fx[TERMS][2];
@@ -419,11 +443,15 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_split_kernel(const WgradArg
               acc[im][in] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fg[pa][im], fx[pb][in], acc[im][in], 0, 0, 0);
         }
       }
+      if (more) {
+        if (step == 0) split_block(rg, pg_);
+        else split_block(rx, px_);
+      }
     }
-    if (st + 1 < nsteps) {
+    if (more) {
       __syncthreads();
-      store_plane(Gs, rg);
-      store_plane(Xs, rx);
+      store_plane(Gs, pg_);
+      store_plane(Xs, px_);
       __syncthreads();
     }
   }
