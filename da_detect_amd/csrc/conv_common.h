@@ -42,6 +42,7 @@ struct ConvArgs {
   int M, K;        // GEMM rows, reduction length
   int tiles_m, tiles_n;
   unsigned x_bytes, w_bytes, y_bytes;  // buffer extents (< 4 GB each)
+  int ablate;                          // profiling only (DADET_ABLATE): bit mask of pipeline stages to skip
 };
 
 struct WgradArgs {

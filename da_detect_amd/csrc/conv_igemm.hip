@@ -26,6 +26,7 @@
 // the double-buffered / 2-workgroup variant: 38% of wave cycles parked in s_waitcnt/s_barrier).
 // Workgroup ids are remapped so that each XCD (private L2) walks a contiguous range of m-tiles.
 #include "conv_common.h"
+#include <stdlib.h>
 
 namespace dadet {
 
@@ -483,6 +484,10 @@ extern "C" int dadet_conv_forward(const dadet_conv_desc* d, const float* x, cons
   DADET_REQUIRE(xb < 0xFFFFFFF0ull && wb < 0xFFFFFFF0ull && yb < 0xFFFFFFF0ull,
                 "conv_forward: tensors of 4 GB or more are not addressable through one buffer descriptor");
   a.x_bytes = (unsigned)xb; a.w_bytes = (unsigned)wb; a.y_bytes = (unsigned)yb;
+  {
+    static const int ablate = getenv("DADET_ABLATE") ? atoi(getenv("DADET_ABLATE")) : 0;
+    a.ablate = ablate;
+  }
   hipStream_t st = as_stream(stream);
   if (gemm_mode() != 0) return launch_fwd_split(a, fwd_variant(a.M, a.Cout), gemm_mode(), st);
   switch (fwd_variant(a.M, a.Cout)) {

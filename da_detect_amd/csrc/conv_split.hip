@@ -171,12 +171,14 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_split_kernel(const ConvArgs a
   const int frag_k = (lane >> 5) * 8;
   const __bf16* Ab = As + (wm * TM * 32 + frag_row) * PLANE_STRIDE + frag_k;
   const __bf16* Bb = Bs + (wn * TN * 32 + frag_row) * PLANE_STRIDE + frag_k;
+  const int ab = a.ablate;
   for (int kt = 0; kt < nk; ++kt) {
     const bool more = kt + 1 < nk;
-    if (more) load_tile();
+    if (more && !(ab & 4)) load_tile();
 #pragma unroll
     for (int step = 0; step < BK / 16; ++step) {
       bf16x8 fa[TERMS][TM], fb[TERMS][TN];
+      if (!(ab & 16) || kt == 0)
 #pragma unroll
       for (int p = 0; p < TERMS; ++p) {
 #pragma unroll
@@ -194,6 +196,7 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_split_kernel(const ConvArgs a
           const int pb = order - pa;
           if (pb < 0 || pb >= TERMS) continue;
           if (pa + pb > TERMS - 1) continue;  // dropped: below the split's own residual
+          if (!(ab & 8))
 #pragma unroll
           for (int im = 0; im < TM; ++im)
 #pragma unroll
@@ -202,14 +205,14 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_split_kernel(const ConvArgs a
         }
       }
       // the next tile's operands have landed by now: split one operand behind each k16 group of MFMAs
-      if (more) {
+      if (more && !(ab & 1)) {
         if (step == 0) split_a();
         else split_b();
       }
     }
     if (more) {
       __syncthreads();
-      store_tile();
+      if (!(ab & 2)) store_tile();
       __syncthreads();
     }
   }
