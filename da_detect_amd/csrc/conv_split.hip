@@ -14,6 +14,7 @@
 // Everything else — buffer-descriptor loads, tap/channel indexing, XCD-aware tile order, fused epilogue — is the
 // fp32 kernel's (conv_igemm.hip).  Selected with dadet_set_gemm_mode(); the default stays exact fp32.
 #include "conv_common.h"
+#include <stdlib.h>
 
 namespace dadet {
 
@@ -272,6 +273,249 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_split_kernel(const ConvArgs a
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Wave-specialised variant of the 128x128 split kernel (8 wavefronts): waves 0-3 are CONSUMERS (LDS fragment
+// reads + bf16 MFMAs on a 64x64 sub-tile each), waves 4-7 are PRODUCERS (buffer loads of tile t+2, operand
+// split of tile t+1, ds_writes into the other LDS buffer).  A SIMD hosts one consumer and one producer wave, so
+// the matrix pipe and the VALU / memory pipes run concurrently by construction instead of by luck
+// (stage ablation of the 4-wave kernel on the RPN conv: MFMAs alone 1.0 ms, everything else alone 1.0 ms,
+// together 1.74 ms — the two halves barely overlapped).  LDS is double buffered (2 x TERMS x 256 rows x 80 B =
+// 120 KB), one barrier per K-tile, one workgroup per CU.
+template <int TERMS>
+__global__ __launch_bounds__(512, 2) void conv_fwd_split_ws_kernel(const ConvArgs a) {
+  constexpr int BM = 128, BN = 128, TM = 2, TN = 2;
+  constexpr int A_LOADS = BM / 32, B_LOADS = BN / 32;
+  constexpr int A_PLANE = BM * PLANE_STRIDE, B_PLANE = BN * PLANE_STRIDE;
+  constexpr int BUF = TERMS * (A_PLANE + B_PLANE);  // bf16 elements per LDS buffer
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  __bf16* lds = reinterpret_cast<__bf16*>(smem);
+
+  const int nwg = a.tiles_m * a.tiles_n;
+  const int tile = xcd_remap(blockIdx.x, nwg);
+  const int bm0 = (tile / a.tiles_n) * BM;
+  const int bn0 = (tile % a.tiles_n) * BN;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  const int nk = (a.K + BK - 1) / BK;
+  const int HoWo = a.Ho * a.Wo;
+
+  if (wave >= 4) {
+    // ------------------------------------------------------------------ producers
+    const int t = threadIdx.x - 256;
+    const int lcol = t & 7;
+    const int lgrp = t >> 3;
+    const int lrow = (lgrp >> 3) * 8 + (lgrp & 1) * 4 + ((lgrp >> 1) & 3);  // conflict-free ds_write_b64 rows
+    const __amdgpu_buffer_rsrc_t xr = make_rsrc(a.x, a.x_bytes);
+    const __amdgpu_buffer_rsrc_t wr = make_rsrc(a.w, a.w_bytes);
+    int pixbase[A_LOADS], hi0[A_LOADS], wi0[A_LOADS];
+#pragma unroll
+    for (int i = 0; i < A_LOADS; ++i) {
+      const int m = bm0 + lrow + 32 * i;
+      if (m < a.M) {
+        const int img = m / HoWo;
+        const int rem = m - img * HoWo;
+        const int ho = rem / a.Wo;
+        const int wo = rem - ho * a.Wo;
+        pixbase[i] = img * a.H * a.W;
+        hi0[i] = ho * a.stride - a.pad;
+        wi0[i] = wo * a.stride - a.pad;
+      } else {
+        pixbase[i] = 0;
+        hi0[i] = -(1 << 28);
+        wi0[i] = 0;
+      }
+    }
+    unsigned wrow[B_LOADS];
+#pragma unroll
+    for (int i = 0; i < B_LOADS; ++i) {
+      const int n = bn0 + lrow + 32 * i;
+      wrow[i] = n < a.Cout ? (unsigned)n * (unsigned)a.K * 4u : kOOB;
+    }
+    float4 ra[A_LOADS], rb[B_LOADS];
+    int kk = lcol * 4;
+    int tap = kk / a.Cin;
+    int kc = kk - tap * a.Cin;
+    int kr = tap / a.KW;
+    int ks = tap - kr * a.KW;
+    auto load_tile = [&]() {
+      const bool kvalid = kk < a.K;
+#pragma unroll
+      for (int i = 0; i < A_LOADS; ++i) {
+        const int hi = hi0[i] + kr, wi = wi0[i] + ks;
+        const bool ok = kvalid && (unsigned)hi < (unsigned)a.H && (unsigned)wi < (unsigned)a.W;
+        const unsigned off = ((unsigned)(pixbase[i] + hi * a.W + wi) * (unsigned)a.Cin + (unsigned)kc) * 4u;
+        ra[i] = buf_load4(xr, ok ? off : kOOB);
+      }
+#pragma unroll
+      for (int i = 0; i < B_LOADS; ++i)
+        rb[i] = buf_load4(wr, (kvalid && wrow[i] != kOOB) ? wrow[i] + (unsigned)kk * 4u : kOOB);
+      kk += BK;
+      kc += BK;
+      while (kc >= a.Cin) {
+        kc -= a.Cin;
+        if (++ks == a.KW) {
+          ks = 0;
+          ++kr;
+        }
+      }
+    };
+    uint2 pa_[A_LOADS][TERMS], pb_[B_LOADS][TERMS];
+    auto split_tile = [&]() {
+#pragma unroll
+      for (int i = 0; i < A_LOADS; ++i) split4<TERMS>(ra[i], pa_[i]);
+#pragma unroll
+      for (int i = 0; i < B_LOADS; ++i) split4<TERMS>(rb[i], pb_[i]);
+    };
+    auto store_tile = [&](int buf) {
+      __bf16* As = lds + buf * BUF;
+      __bf16* Bs = As + TERMS * A_PLANE;
+#pragma unroll
+      for (int i = 0; i < A_LOADS; ++i)
+#pragma unroll
+        for (int p = 0; p < TERMS; ++p)
+          *reinterpret_cast<uint2*>(As + p * A_PLANE + (lrow + 32 * i) * PLANE_STRIDE + lcol * 4) = pa_[i][p];
+#pragma unroll
+      for (int i = 0; i < B_LOADS; ++i)
+#pragma unroll
+        for (int p = 0; p < TERMS; ++p)
+          *reinterpret_cast<uint2*>(Bs + p * B_PLANE + (lrow + 32 * i) * PLANE_STRIDE + lcol * 4) = pb_[i][p];
+    };
+    load_tile();                 // tile 0
+    split_tile();
+    if (nk > 1) load_tile();     // tile 1 in flight
+    store_tile(0);
+    __syncthreads();             // buffer 0 published
+    for (int kt = 0; kt < nk; ++kt) {
+      if (kt + 1 < nk) {
+        split_tile();                      // tile kt+1 (its loads were issued one iteration ago)
+        if (kt + 2 < nk) load_tile();      // tile kt+2 goes in flight, registers are free again
+        store_tile((kt + 1) & 1);
+      }
+      __syncthreads();
+    }
+    return;
+  }
+
+  // -------------------------------------------------------------------- consumers
+  const int wm = wave >> 1, wn = wave & 1;
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+  const int frag_row = lane & 31;
+  const int frag_k = (lane >> 5) * 8;
+  const int a_off = (wm * TM * 32 + frag_row) * PLANE_STRIDE + frag_k;
+  const int b_off = TERMS * A_PLANE + (wn * TN * 32 + frag_row) * PLANE_STRIDE + frag_k;
+  __syncthreads();  // buffer 0 published
+  for (int kt = 0; kt < nk; ++kt) {
+    const __bf16* Ab = lds + (kt & 1) * BUF + a_off;
+    const __bf16* Bb = lds + (kt & 1) * BUF + b_off;
+#pragma unroll
+    for (int step = 0; step < BK / 16; ++step) {
+      bf16x8 fa[TERMS][TM], fb[TERMS][TN];
+#pragma unroll
+      for (int p = 0; p < TERMS; ++p) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+          fa[p][i] = *reinterpret_cast<const bf16x8*>(Ab + p * A_PLANE + i * 32 * PLANE_STRIDE + step * 16);
+#pragma unroll
+        for (int i = 0; i < TN; ++i)
+          fb[p][i] = *reinterpret_cast<const bf16x8*>(Bb + p * B_PLANE + i * 32 * PLANE_STRIDE + step * 16);
+      }
+#pragma unroll
+      for (int order = 2 * (TERMS - 1); order >= 0; --order) {
+#pragma unroll
+        for (int pa = 0; pa < TERMS; ++pa) {
+          const int pb = order - pa;
+          if (pb < 0 || pb >= TERMS) continue;
+          if (pa + pb > TERMS - 1) continue;
+#pragma unroll
+          for (int im = 0; im < TM; ++im)
+#pragma unroll
+            for (int in = 0; in < TN; ++in)
+              acc[im][in] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[pa][im], fb[pb][in], acc[im][in], 0, 0, 0);
+        }
+      }
+    }
+    __syncthreads();
+  }
+
+  const __amdgpu_buffer_rsrc_t yr = make_rsrc(a.y, a.y_bytes);
+  const __amdgpu_buffer_rsrc_t ar = make_rsrc(a.addend ? a.addend : a.y, a.addend ? a.y_bytes : 0u);
+  const __amdgpu_buffer_rsrc_t mr = make_rsrc(a.mask_ref ? a.mask_ref : a.y, a.mask_ref ? a.y_bytes : 0u);
+  const int col_in = lane & 31;
+  const int row_hi = 4 * (lane >> 5);
+#pragma unroll
+  for (int in = 0; in < TN; ++in) {
+    const int n = bn0 + wn * TN * 32 + in * 32 + col_in;
+    const bool nvalid = n < a.Cout;
+    const float sc = (a.scale && nvalid) ? a.scale[n] : 1.f;
+    const float bi = (a.bias && nvalid) ? a.bias[n] : 0.f;
+#pragma unroll
+    for (int im = 0; im < TM; ++im) {
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        unsigned offs[4];
+        float add[4], msk[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int m = bm0 + wm * TM * 32 + im * 32 + q + 8 * g + row_hi;
+          unsigned orow = (unsigned)m;
+          if (a.os != 1) {
+            const int img = m / HoWo;
+            const int rem = m - img * HoWo;
+            const int ho = rem / a.Wo;
+            const int wo = rem - ho * a.Wo;
+            orow = (unsigned)((img * a.OutH + ho * a.os) * a.OutW + wo * a.os);
+          }
+          offs[q] = (nvalid && m < a.M) ? (orow * (unsigned)a.Cout + (unsigned)n) * 4u : kOOB;
+        }
+        if (a.addend) {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) add[q] = buf_load1(ar, offs[q]);
+        }
+        if (a.relu_mode == 2) {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) msk[q] = buf_load1(mr, offs[q]);
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          float v = acc[im][in][g * 4 + q];
+          if (a.scale) v = v * sc;
+          if (a.bias) v = v + bi;
+          if (a.addend) v = v + add[q];
+          if (a.relu_mode == 1) v = fmaxf(v, 0.f);
+          else if (a.relu_mode == 2) v = (msk[q] > 0.f) ? v : 0.f;
+          buf_store1(yr, offs[q], v);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+  }
+}
+
+template <int TERMS>
+static int launch_split_ws(ConvArgs& a, hipStream_t st) {
+  a.tiles_m = ceil_div(a.M, 128);
+  a.tiles_n = ceil_div(a.Cout, 128);
+  const size_t lds = sizeof(__bf16) * 2 * TERMS * 256 * PLANE_STRIDE;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_fwd_split_ws_kernel<TERMS>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) {
+      set_error("conv_forward(split, wave-specialised): hipFuncSetAttribute: %s", hipGetErrorString(e));
+      return DADET_ELAUNCH;
+    }
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((conv_fwd_split_ws_kernel<TERMS>), dim3(a.tiles_m * a.tiles_n), dim3(512), lds, st, a);
+  return check_launch("conv_forward(split, wave-specialised)");
+}
+
 template <int TM, int TN, int TERMS>
 static int launch_split(ConvArgs& a, hipStream_t st) {
   constexpr int BM = 2 * TM * 32, BN = 2 * TN * 32;
@@ -293,6 +537,8 @@ static int launch_split(ConvArgs& a, hipStream_t st) {
 }
 
 int launch_fwd_split(ConvArgs& a, int variant, int terms, hipStream_t st) {
+  static const bool use_ws = !(getenv("DADET_NO_WS") && atoi(getenv("DADET_NO_WS")));
+  if (variant == 0 && use_ws) return terms == 2 ? launch_split_ws<2>(a, st) : launch_split_ws<3>(a, st);
   if (terms == 2) {
     switch (variant) {
       case 0: return launch_split<2, 2, 2>(a, st);
