@@ -537,7 +537,9 @@ static int launch_split(ConvArgs& a, hipStream_t st) {
 }
 
 int launch_fwd_split(ConvArgs& a, int variant, int terms, hipStream_t st) {
-  static const bool use_ws = !(getenv("DADET_NO_WS") && atoi(getenv("DADET_NO_WS")));
+  // the producer/consumer variant measured the same as the 4-wave kernel on long-K layers and slower on short-K
+  // ones (one workgroup per CU): opt-in for experiments only
+  static const bool use_ws = getenv("DADET_WS") && atoi(getenv("DADET_WS"));
   if (variant == 0 && use_ws) return terms == 2 ? launch_split_ws<2>(a, st) : launch_split_ws<3>(a, st);
   if (terms == 2) {
     switch (variant) {
