@@ -397,6 +397,33 @@ def triplet_w_backward(a, p, n, dist, g_scale, margin, eps=1e-6, need=(True, Tru
     return ga, gp, gn
 
 
+def deform_sample_forward(x, offset, mask, kh, kw, stride, pad, dil, dg):
+    """x [N,C,H,W], offset [N,dg*2*kh*kw,Ho,Wo], mask [N,dg*kh*kw,Ho,Wo] | None (all channels_last)
+    -> cols [N, kh*kw*C, Ho, Wo] channels_last (channel = tap*C + c)"""
+    _dev(x, "x"), _dev(offset, "offset")
+    x, offset = _nhwc(x), _nhwc(offset)
+    mask = _nhwc(mask) if mask is not None else None
+    N, C, H, W = x.shape
+    Ho, Wo = offset.shape[2], offset.shape[3]
+    cols = torch.empty((N, kh * kw * C, Ho, Wo), dtype=torch.float32, device=x.device, memory_format=CL)
+    _lib.call("dadet_deform_sample_forward", _p(x), _p(offset), _p(mask), _p(cols), N, H, W, C, kh, kw, stride, pad,
+              dil, dg, Ho, Wo, _stream())
+    return cols
+
+
+def deform_sample_backward(x, offset, mask, gcols, kh, kw, stride, pad, dil, dg, need_x=True):
+    x, offset, gcols = _nhwc(x), _nhwc(offset), _nhwc(gcols)
+    mask = _nhwc(mask) if mask is not None else None
+    N, C, H, W = x.shape
+    Ho, Wo = offset.shape[2], offset.shape[3]
+    gx = torch.empty_like(x).zero_() if need_x else None
+    goffset = torch.empty_like(offset).zero_()
+    gmask = torch.empty_like(mask).zero_() if mask is not None else None
+    _lib.call("dadet_deform_sample_backward", _p(x), _p(offset), _p(mask), _p(gcols), _p(gx), _p(goffset), _p(gmask),
+              N, H, W, C, kh, kw, stride, pad, dil, dg, Ho, Wo, _stream())
+    return gx, goffset, gmask
+
+
 def set_gemm_mode(mode):
     """0 exact fp32 MFMA | 3 three-term bf16 split (fp32-class accuracy) | 2 two-term split; see include/dadet.h"""
     _lib.call("dadet_set_gemm_mode", int(mode))

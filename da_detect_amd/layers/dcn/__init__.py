@@ -1,0 +1,7 @@
+"""Deformable convolution layers (operator API of the reference's vendored tree:
+tools/cityscapes/maskrcnn_benchmark/layers/dcn/{deform_conv_func,deform_conv_module}.py, layers/misc.py:114-203)."""
+from .deform_conv import (DeformConv, DFConv2d, ModulatedDeformConv, ModulatedDeformConvPack, deform_conv,
+                          modulated_deform_conv)
+
+__all__ = ["deform_conv", "modulated_deform_conv", "DeformConv", "ModulatedDeformConv", "ModulatedDeformConvPack",
+           "DFConv2d"]

@@ -148,6 +148,27 @@ int dadet_conv_weight_transpose(const float* w, const float* scale, float* wt, i
                                 int Cin, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * Deformable convolution v1 / v2 — replaces the vendored tree's `_C.deform_conv_forward / _backward_input /
+ * _backward_parameters` and `_C.modulated_deform_conv_forward / _backward`
+ *   reference: tools/cityscapes/maskrcnn_benchmark/csrc/vision.cpp:17-24, csrc/cuda/deform_conv_cuda.cu:158-690,
+ *   csrc/cuda/deform_conv_kernel_cuda.cu:92-775 (not bound in the reference's main tree).
+ * The deformable sampling is one kernel that writes the sampled operand as an NHWC column tensor
+ *   cols[n][ho][wo][tap][c] = mask[n][ho][wo][g][tap] * bilinear(x[n], p0 + p_tap + offset[n][ho][wo][g][tap])
+ * (zero outside (-1,H)x(-1,W)); the contraction with the [Cout][KH][KW][Cin] weights, its data gradient and its
+ * weight gradient are dadet_conv_forward / dadet_conv_wgrad calls on `cols` viewed as a 1x1 convolution over
+ * K = KH*KW*Cin.  offset: [N][Ho][Wo][dg*2*KH*KW] (channel = g*2*T + 2*tap + {0: dy, 1: dx}, the reference's order);
+ * mask: [N][Ho][Wo][dg*KH*KW] or NULL (v1).  Backward: gx is accumulated with atomics (caller zero-fills, may be
+ * NULL), goffset / gmask are accumulated with atomics (caller zero-fills).
+ * ----------------------------------------------------------------------------------------------*/
+int dadet_deform_sample_forward(const float* x, const float* offset, const float* mask, float* cols, int N,
+                                int H, int W, int C, int KH, int KW, int stride, int pad, int dil,
+                                int deformable_groups, int Ho, int Wo, void* stream);
+int dadet_deform_sample_backward(const float* x, const float* offset, const float* mask, const float* gcols,
+                                 float* gx, float* goffset, float* gmask, int N, int H, int W, int C, int KH,
+                                 int KW, int stride, int pad, int dil, int deformable_groups, int Ho, int Wo,
+                                 void* stream);
+
+/* ------------------------------------------------------------------------------------------------
  * Elementwise / reduction helpers of the same path (all NHWC fp32).
  * ----------------------------------------------------------------------------------------------*/
 /* g_out[m][c] = (y[m][c] > 0 ? g[m][c] : 0) ; g_scaled[m][c] = g_out * scale[c].  Either output may be
