@@ -29,12 +29,18 @@ def _one(v, name):
     return int(v[0])
 
 
+def _as_1x1(weight):
+    """[Cout,Cin,kh,kw] (physically [Cout][kh][kw][Cin]) -> [Cout, kh*kw*Cin, 1, 1] with K = (tap, ci)"""
+    cout, cin, kh, kw = weight.shape
+    return weight.contiguous(memory_format=CL).permute(0, 2, 3, 1).reshape(cout, kh * kw * cin, 1, 1)
+
+
 class _DeformConv(Function):
     @staticmethod
     def forward(ctx, x, offset, mask, weight, bias, stride, padding, dilation, deformable_groups):
         cout, cin, kh, kw = weight.shape
         cols = _C.deform_sample_forward(x, offset, mask, kh, kw, stride, padding, dilation, deformable_groups)
-        w1x1 = weight.contiguous(memory_format=CL).view(cout, 1, 1, kh * kw * cin).permute(0, 3, 1, 2)
+        w1x1 = _as_1x1(weight)
         y = _C.conv_forward(cols, w1x1, None, bias)
         ctx.save_for_backward(x, offset, mask, weight, cols)
         ctx.conf = (kh, kw, stride, padding, dilation, deformable_groups, bias is not None)
@@ -47,14 +53,14 @@ class _DeformConv(Function):
         kh, kw, stride, padding, dilation, dg, has_bias = ctx.conf
         cout, cin = weight.shape[0], weight.shape[1]
         gy = gy.contiguous(memory_format=CL)
-        w1x1 = weight.contiguous(memory_format=CL).view(cout, 1, 1, kh * kw * cin).permute(0, 3, 1, 2)
+        w1x1 = _as_1x1(weight)
         gcols = _C.conv_forward(gy, _C.conv_weight_transpose(w1x1))
         gx, goffset, gmask = _C.deform_sample_backward(x, offset, mask, gcols, kh, kw, stride, padding, dilation, dg,
                                                        need_x=ctx.needs_input_grad[0])
         gw = None
         if ctx.needs_input_grad[3]:
             gw1 = _C.conv_wgrad(cols, gy, (cout, kh * kw * cin, 1, 1))          # [Cout, K, 1, 1], K = (tap, ci)
-            gw = gw1.view(cout, kh, kw, cin).permute(0, 3, 1, 2)                # channels_last [Cout,Cin,kh,kw]
+            gw = gw1.reshape(cout, kh, kw, cin).permute(0, 3, 1, 2)             # channels_last [Cout,Cin,kh,kw]
         gb = _C.colsum(gy) if (has_bias and ctx.needs_input_grad[4]) else None
         return gx, goffset, gmask, gw, gb, None, None, None, None
 
