@@ -424,6 +424,49 @@ def deform_sample_backward(x, offset, mask, gcols, kh, kw, stride, pad, dil, dg,
     return gx, goffset, gmask
 
 
+def _psroi_args(data, rois, offset, out_size, out_channels, no_trans, group_size, part_size, sample_per_part):
+    B, C, H, W = data.shape
+    R = rois.shape[0]
+    num_classes = 1 if no_trans else offset.shape[1] // 2
+    return B, H, W, C, R, num_classes
+
+
+def deform_psroi_pooling_forward(data, rois, offset, no_trans, spatial_scale, out_channels, group_size, out_size,
+                                 part_size, sample_per_part, trans_std):
+    """data [B, out_channels*group_size^2, H, W] (channels_last), rois [R,5], offset [R, 2*num_classes, part, part]
+    (ignored with no_trans) -> (output, output_count) [R, out_channels, out_size, out_size] channels_last.
+    Reference: tools/cityscapes/maskrcnn_benchmark/layers/dcn/deform_pool_func.py:30-35."""
+    _dev(data, "data"), _dev(rois, "rois")
+    data = _nhwc(data)
+    rois = rois.contiguous().float()
+    offset = None if no_trans else offset.contiguous().float()
+    B, H, W, C, R, ncls = _psroi_args(data, rois, offset, out_size, out_channels, no_trans, group_size, part_size,
+                                      sample_per_part)
+    out = torch.empty((R, out_channels, out_size, out_size), dtype=torch.float32, device=data.device,
+                      memory_format=CL)
+    cnt = torch.empty_like(out)
+    _lib.call("dadet_deform_psroi_pool_forward", _p(data), _p(rois), _p(offset), _p(out), _p(cnt), B, H, W, C, R,
+              int(bool(no_trans)), float(spatial_scale), out_channels, group_size, out_size, part_size,
+              sample_per_part, float(trans_std), ncls, _stream())
+    return out, cnt
+
+
+def deform_psroi_pooling_backward(grad_out, data, rois, offset, count, no_trans, spatial_scale, out_channels,
+                                  group_size, out_size, part_size, sample_per_part, trans_std):
+    """-> (grad_data channels_last, grad_offset | None); reference deform_pool_func.py:52-60"""
+    data, grad_out, count = _nhwc(data), _nhwc(grad_out), _nhwc(count)
+    rois = rois.contiguous().float()
+    offset = None if no_trans else offset.contiguous().float()
+    B, H, W, C, R, ncls = _psroi_args(data, rois, offset, out_size, out_channels, no_trans, group_size, part_size,
+                                      sample_per_part)
+    gdata = torch.empty_like(data).zero_()
+    goffset = None if no_trans else torch.zeros_like(offset)
+    _lib.call("dadet_deform_psroi_pool_backward", _p(grad_out), _p(count), _p(data), _p(rois), _p(offset), _p(gdata),
+              _p(goffset), B, H, W, C, R, int(bool(no_trans)), float(spatial_scale), out_channels, group_size,
+              out_size, part_size, sample_per_part, float(trans_std), ncls, _stream())
+    return gdata, goffset
+
+
 def set_gemm_mode(mode):
     """0 exact fp32 MFMA | 3 three-term bf16 split (fp32-class accuracy) | 2 two-term split; see include/dadet.h"""
     _lib.call("dadet_set_gemm_mode", int(mode))

@@ -49,6 +49,10 @@ _SIGNATURES = {
     "dadet_conv_weight_transpose": [_P, _P, _P, c_int, c_int, c_int, c_int, _P],
     "dadet_deform_sample_forward": [_P, _P, _P, _P] + [c_int] * 12 + [_P],
     "dadet_deform_sample_backward": [_P, _P, _P, _P, _P, _P, _P] + [c_int] * 12 + [_P],
+    "dadet_deform_psroi_pool_forward": [_P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_float,
+                                        c_int, c_int, c_int, c_int, c_int, c_float, c_int, _P],
+    "dadet_deform_psroi_pool_backward": [_P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int,
+                                         c_float, c_int, c_int, c_int, c_int, c_int, c_float, c_int, _P],
     "dadet_relu_bn_backward": [_P, _P, _P, _P, _P, c_int64, c_int, _P],
     "dadet_colsum_workspace_bytes": [c_int64, c_int, POINTER(c_size_t)],
     "dadet_colsum": [_P, _P, c_int64, c_int, _P, c_size_t, _P],

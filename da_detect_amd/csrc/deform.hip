@@ -225,3 +225,183 @@ extern "C" int dadet_deform_sample_backward(const float* x, const float* offset,
                      as_stream(stream), x, offset, mask, gcols, gx, goffset, gmask, g);
   return check_launch("deform_sample_backward");
 }
+
+// ------------------------------------------------------------------------------------------------
+// Deformable position-sensitive ROI pooling (reference: tools/cityscapes/maskrcnn_benchmark/csrc/cuda/
+// deform_pool_kernel_cuda.cu:30-141 forward, :143-264 backward).  NHWC data [B][H][W][C], C = output_dim * gs * gs;
+// output / count [R][PH][PW][output_dim]; trans [R][num_classes*2][part][part] (reference layout, tiny).
+// One thread per output element with the output channel fastest, so a wavefront covers consecutive channels of
+// one bin: all lanes share the bin's sample coordinates.
+namespace dadet {
+
+struct PsGeom {
+  int B, H, W, C, R, PH, PW, out_dim, gs, part, spp, no_trans, num_classes, ch_each_class;
+  float scale, trans_std;
+};
+
+struct PsBin {
+  int batch, part_h, part_w, class_id, gh, gw;
+  float wstart, hstart, sub_w, sub_h, roi_w, roi_h;
+};
+
+__device__ inline PsBin ps_bin(const PsGeom& g, const float* __restrict__ rois, const float* __restrict__ trans,
+                               int n, int ctop, int ph, int pw) {
+  PsBin b;
+  const float* r = rois + (size_t)n * 5;
+  b.batch = (int)r[0];
+  const float sw = roundf(r[1]) * g.scale - 0.5f, sh = roundf(r[2]) * g.scale - 0.5f;
+  const float ew = (roundf(r[3]) + 1.f) * g.scale - 0.5f, eh = (roundf(r[4]) + 1.f) * g.scale - 0.5f;
+  b.roi_w = fmaxf(ew - sw, 0.1f);
+  b.roi_h = fmaxf(eh - sh, 0.1f);
+  const float bin_h = b.roi_h / (float)g.PH, bin_w = b.roi_w / (float)g.PW;
+  b.sub_h = bin_h / (float)g.spp;
+  b.sub_w = bin_w / (float)g.spp;
+  b.part_h = (int)floorf((float)ph / (float)g.PH * (float)g.part);
+  b.part_w = (int)floorf((float)pw / (float)g.PW * (float)g.part);
+  b.class_id = ctop / g.ch_each_class;
+  float tx = 0.f, ty = 0.f;
+  if (!g.no_trans) {
+    const size_t base = ((size_t)n * g.num_classes + b.class_id) * 2;
+    tx = trans[((base)*g.part + b.part_h) * g.part + b.part_w] * g.trans_std;
+    ty = trans[((base + 1) * g.part + b.part_h) * g.part + b.part_w] * g.trans_std;
+  }
+  b.wstart = (float)pw * bin_w + sw + tx * b.roi_w;
+  b.hstart = (float)ph * bin_h + sh + ty * b.roi_h;
+  int gw = (int)floorf((float)pw * (float)g.gs / (float)g.PW);
+  int gh = (int)floorf((float)ph * (float)g.gs / (float)g.PH);
+  b.gw = min(max(gw, 0), g.gs - 1);
+  b.gh = min(max(gh, 0), g.gs - 1);
+  return b;
+}
+
+__global__ void deform_psroi_fwd_kernel(const float* __restrict__ data, const float* __restrict__ rois,
+                                        const float* __restrict__ trans, float* __restrict__ out,
+                                        float* __restrict__ cnt, PsGeom g) {
+  const int64_t total = (int64_t)g.R * g.PH * g.PW * g.out_dim;
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+       idx += (int64_t)gridDim.x * blockDim.x) {
+    const int ctop = (int)(idx % g.out_dim);
+    const int pw = (int)((idx / g.out_dim) % g.PW);
+    const int ph = (int)((idx / g.out_dim / g.PW) % g.PH);
+    const int n = (int)(idx / g.out_dim / g.PW / g.PH);
+    const PsBin b = ps_bin(g, rois, trans, n, ctop, ph, pw);
+    const float* img = data + (size_t)b.batch * g.H * g.W * g.C;
+    const int c = (ctop * g.gs + b.gh) * g.gs + b.gw;
+    float sum = 0.f;
+    int count = 0;
+    for (int ih = 0; ih < g.spp; ++ih)
+      for (int iw = 0; iw < g.spp; ++iw) {
+        float w = b.wstart + (float)iw * b.sub_w, h = b.hstart + (float)ih * b.sub_h;
+        if (w < -0.5f || w > (float)g.W - 0.5f || h < -0.5f || h > (float)g.H - 0.5f) continue;
+        w = fminf(fmaxf(w, 0.f), (float)g.W - 1.f);
+        h = fminf(fmaxf(h, 0.f), (float)g.H - 1.f);
+        const int x1 = (int)floorf(w), x2 = (int)ceilf(w), y1 = (int)floorf(h), y2 = (int)ceilf(h);
+        const float dx = w - (float)x1, dy = h - (float)y1;
+        const float v11 = img[((size_t)y1 * g.W + x1) * g.C + c], v12 = img[((size_t)y2 * g.W + x1) * g.C + c];
+        const float v21 = img[((size_t)y1 * g.W + x2) * g.C + c], v22 = img[((size_t)y2 * g.W + x2) * g.C + c];
+        sum += (1.f - dx) * (1.f - dy) * v11 + (1.f - dx) * dy * v12 + dx * (1.f - dy) * v21 + dx * dy * v22;
+        ++count;
+      }
+    out[idx] = count == 0 ? 0.f : sum / (float)count;
+    cnt[idx] = (float)count;
+  }
+}
+
+__global__ void deform_psroi_bwd_kernel(const float* __restrict__ gout, const float* __restrict__ cnt,
+                                        const float* __restrict__ data, const float* __restrict__ rois,
+                                        const float* __restrict__ trans, float* __restrict__ gdata,
+                                        float* __restrict__ gtrans, PsGeom g) {
+  const int64_t total = (int64_t)g.R * g.PH * g.PW * g.out_dim;
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+       idx += (int64_t)gridDim.x * blockDim.x) {
+    if (cnt[idx] <= 0.f) continue;
+    const int ctop = (int)(idx % g.out_dim);
+    const int pw = (int)((idx / g.out_dim) % g.PW);
+    const int ph = (int)((idx / g.out_dim / g.PW) % g.PH);
+    const int n = (int)(idx / g.out_dim / g.PW / g.PH);
+    const PsBin b = ps_bin(g, rois, trans, n, ctop, ph, pw);
+    const float diff = gout[idx] / cnt[idx];
+    const float* img = data + (size_t)b.batch * g.H * g.W * g.C;
+    float* gimg = gdata + (size_t)b.batch * g.H * g.W * g.C;
+    const int c = (ctop * g.gs + b.gh) * g.gs + b.gw;
+    for (int ih = 0; ih < g.spp; ++ih)
+      for (int iw = 0; iw < g.spp; ++iw) {
+        float w = b.wstart + (float)iw * b.sub_w, h = b.hstart + (float)ih * b.sub_h;
+        if (w < -0.5f || w > (float)g.W - 0.5f || h < -0.5f || h > (float)g.H - 0.5f) continue;
+        w = fminf(fmaxf(w, 0.f), (float)g.W - 1.f);
+        h = fminf(fmaxf(h, 0.f), (float)g.H - 1.f);
+        const int x0 = (int)floorf(w), x1 = (int)ceilf(w), y0 = (int)floorf(h), y1 = (int)ceilf(h);
+        const float dx = w - (float)x0, dy = h - (float)y0;
+        const size_t p00 = ((size_t)y0 * g.W + x0) * g.C + c, p01 = ((size_t)y1 * g.W + x0) * g.C + c;
+        const size_t p10 = ((size_t)y0 * g.W + x1) * g.C + c, p11 = ((size_t)y1 * g.W + x1) * g.C + c;
+        unsafeAtomicAdd(gimg + p00, (1.f - dx) * (1.f - dy) * diff);
+        unsafeAtomicAdd(gimg + p01, (1.f - dx) * dy * diff);
+        unsafeAtomicAdd(gimg + p10, dx * (1.f - dy) * diff);
+        unsafeAtomicAdd(gimg + p11, dx * dy * diff);
+        if (g.no_trans) continue;
+        const float U00 = img[p00], U01 = img[p01], U10 = img[p10], U11 = img[p11];
+        float gx = (U11 * dy + U10 * (1.f - dy) - U01 * dy - U00 * (1.f - dy)) * g.trans_std * diff;
+        gx *= b.roi_w;
+        float gy = (U11 * dx + U01 * (1.f - dx) - U10 * dx - U00 * (1.f - dx)) * g.trans_std * diff;
+        gy *= b.roi_h;
+        const size_t base = ((size_t)n * g.num_classes + b.class_id) * 2;
+        atomicAdd(gtrans + ((base)*g.part + b.part_h) * g.part + b.part_w, gx);
+        atomicAdd(gtrans + ((base + 1) * g.part + b.part_h) * g.part + b.part_w, gy);
+      }
+  }
+}
+
+static int ps_geom(PsGeom* g, const char* who, int B, int H, int W, int C, int R, int out_size, int out_dim,
+                   int group_size, int part_size, int sample_per_part, int no_trans, int num_classes,
+                   float scale, float trans_std) {
+  DADET_REQUIRE(B > 0 && H > 0 && W > 0 && C > 0 && R >= 0 && out_size > 0 && out_dim > 0 && group_size > 0 &&
+                    part_size > 0 && sample_per_part > 0 && num_classes > 0,
+                "%s: bad dims", who);
+  DADET_REQUIRE(C == out_dim * group_size * group_size, "%s: C must equal output_dim * group_size^2", who);
+  DADET_REQUIRE(out_dim % num_classes == 0, "%s: output_dim must be a multiple of num_classes", who);
+  *g = PsGeom{B, H, W, C, R, out_size, out_size, out_dim, group_size, part_size, sample_per_part, no_trans,
+              num_classes, out_dim / num_classes, scale, trans_std};
+  return DADET_OK;
+}
+
+}  // namespace dadet
+
+extern "C" int dadet_deform_psroi_pool_forward(const float* data, const float* rois, const float* trans,
+                                               float* out, float* top_count, int B, int H, int W, int C, int R,
+                                               int no_trans, float spatial_scale, int output_dim, int group_size,
+                                               int pooled_size, int part_size, int sample_per_part,
+                                               float trans_std, int num_classes, void* stream) {
+  dadet::PsGeom g;
+  int rc = dadet::ps_geom(&g, "deform_psroi_pool_forward", B, H, W, C, R, pooled_size, output_dim, group_size,
+                          part_size, sample_per_part, no_trans, no_trans ? 1 : num_classes, spatial_scale, trans_std);
+  if (rc) return rc;
+  if (R == 0) return DADET_OK;
+  DADET_REQUIRE(data && rois && out && top_count && (no_trans || trans), "deform_psroi_pool_forward: null pointer");
+  const int64_t total = (int64_t)R * pooled_size * pooled_size * output_dim;
+  int64_t blocks = dadet::ceil_div64(total, 256);
+  if (blocks > dadet::kMaxStreamBlocks) blocks = dadet::kMaxStreamBlocks;
+  hipLaunchKernelGGL(dadet::deform_psroi_fwd_kernel, dim3((int)blocks), dim3(256), 0, dadet::as_stream(stream), data,
+                     rois, trans, out, top_count, g);
+  return dadet::check_launch("deform_psroi_pool_forward");
+}
+
+extern "C" int dadet_deform_psroi_pool_backward(const float* grad_out, const float* top_count, const float* data,
+                                                const float* rois, const float* trans, float* grad_data,
+                                                float* grad_trans, int B, int H, int W, int C, int R, int no_trans,
+                                                float spatial_scale, int output_dim, int group_size,
+                                                int pooled_size, int part_size, int sample_per_part,
+                                                float trans_std, int num_classes, void* stream) {
+  dadet::PsGeom g;
+  int rc = dadet::ps_geom(&g, "deform_psroi_pool_backward", B, H, W, C, R, pooled_size, output_dim, group_size,
+                          part_size, sample_per_part, no_trans, no_trans ? 1 : num_classes, spatial_scale, trans_std);
+  if (rc) return rc;
+  if (R == 0) return DADET_OK;
+  DADET_REQUIRE(grad_out && top_count && data && rois && grad_data && (no_trans || (trans && grad_trans)),
+                "deform_psroi_pool_backward: null pointer");
+  const int64_t total = (int64_t)R * pooled_size * pooled_size * output_dim;
+  int64_t blocks = dadet::ceil_div64(total, 256);
+  if (blocks > dadet::kMaxStreamBlocks) blocks = dadet::kMaxStreamBlocks;
+  hipLaunchKernelGGL(dadet::deform_psroi_bwd_kernel, dim3((int)blocks), dim3(256), 0, dadet::as_stream(stream),
+                     grad_out, top_count, data, rois, trans, grad_data, grad_trans, g);
+  return dadet::check_launch("deform_psroi_pool_backward");
+}

@@ -168,6 +168,22 @@ int dadet_deform_sample_backward(const float* x, const float* offset, const floa
                                  int KW, int stride, int pad, int dil, int deformable_groups, int Ho, int Wo,
                                  void* stream);
 
+/* Deformable position-sensitive ROI pooling — replaces the vendored tree's `_C.deform_psroi_pooling_forward /
+ * _backward` (tools/cityscapes/maskrcnn_benchmark/csrc/vision.cpp:22-23, cuda/deform_pool_kernel_cuda.cu:30-264).
+ * data [B][H][W][C] NHWC with C = output_dim*group_size^2; rois [R][5]; trans [R][num_classes*2][part][part]
+ * (NULL with no_trans); out / top_count [R][P][P][output_dim] NHWC.  Backward accumulates grad_data and
+ * grad_trans with atomics (caller zero-fills). */
+int dadet_deform_psroi_pool_forward(const float* data, const float* rois, const float* trans, float* out,
+                                    float* top_count, int B, int H, int W, int C, int R, int no_trans,
+                                    float spatial_scale, int output_dim, int group_size, int pooled_size,
+                                    int part_size, int sample_per_part, float trans_std, int num_classes,
+                                    void* stream);
+int dadet_deform_psroi_pool_backward(const float* grad_out, const float* top_count, const float* data,
+                                     const float* rois, const float* trans, float* grad_data, float* grad_trans,
+                                     int B, int H, int W, int C, int R, int no_trans, float spatial_scale,
+                                     int output_dim, int group_size, int pooled_size, int part_size,
+                                     int sample_per_part, float trans_std, int num_classes, void* stream);
+
 /* ------------------------------------------------------------------------------------------------
  * Elementwise / reduction helpers of the same path (all NHWC fp32).
  * ----------------------------------------------------------------------------------------------*/

@@ -79,3 +79,73 @@ def test_dfconv2d_zero_offsets_equals_conv(device):
     x = torch.randn(2, 32, 10, 12)
     y = m(x.to(device).contiguous(memory_format=CL)).cpu()
     torch.testing.assert_close(y, F.conv2d(x, m.conv.weight.detach().cpu(), None, 1, 1), rtol=1e-4, atol=1e-4)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# deformable PSROI pooling (deform_pool_func.py / deform_pool_kernel_cuda.cu)
+def _psroi_case(seed, no_trans, gs, ncls=1, out_dim=4, P=3, part=3, spp=2, B=2, H=10, W=12, R=5, trans_std=0.1):
+    g = torch.Generator().manual_seed(seed)
+    data = torch.randn(B, out_dim * gs * gs, H, W, generator=g)
+    x1 = torch.rand(R, generator=g) * (W * 8 - 30) - 6      # some ROIs start left of / above the map
+    y1 = torch.rand(R, generator=g) * (H * 8 - 30) - 6
+    bw = torch.rand(R, generator=g) * 50 + 4
+    bh = torch.rand(R, generator=g) * 50 + 4
+    rois = torch.stack([torch.randint(0, B, (R,), generator=g).float(), x1, y1, x1 + bw, y1 + bh], 1)
+    trans = torch.randn(R, 2 * ncls, part, part, generator=g)
+    grad = torch.randn(R, out_dim, P, P, generator=g)
+    return data, rois, trans, grad, dict(spatial_scale=0.125, out_size=P, out_dim=out_dim, no_trans=no_trans,
+                                         group_size=gs, part_size=part, sample_per_part=spp, trans_std=trans_std)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("no_trans,gs,ncls,out_dim", [(True, 1, 1, 4), (False, 1, 1, 4), (False, 3, 2, 4),
+                                                      (True, 3, 1, 6), (False, 1, 1, 72)])
+def test_deform_psroi_pool_matches_oracle(no_trans, gs, ncls, out_dim):
+    from da_detect_amd.layers.dcn import deform_roi_pooling
+    from oracle.deform_ref import deform_psroi_pool
+    data, rois, trans, grad, kw = _psroi_case(7 + gs + ncls, no_trans, gs, ncls, out_dim)
+    ref_out, ref_cnt, ref_gd, ref_gt = deform_psroi_pool(data, rois, trans, grad_out=grad, **kw)
+    d = data.cuda().contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    t = trans.cuda().requires_grad_(not no_trans)
+    out = deform_roi_pooling(d, rois.cuda(), t, kw["spatial_scale"], kw["out_size"], kw["out_dim"], no_trans,
+                             gs, kw["part_size"], kw["sample_per_part"], kw["trans_std"])
+    out.backward(grad.cuda())
+    assert (ref_cnt > 0).any() and (ref_cnt < kw["sample_per_part"] ** 2).any()   # partially-outside bins are covered
+    torch.testing.assert_close(out.cpu(), ref_out, rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(d.grad.cpu(), ref_gd, rtol=1e-4, atol=1e-5)
+    if not no_trans:
+        torch.testing.assert_close(t.grad.cpu(), ref_gt, rtol=1e-4, atol=2e-5)
+
+
+@pytest.mark.gpu
+def test_deform_psroi_pool_identities_and_packs():
+    from da_detect_amd.layers.dcn import (DeformRoIPooling, DeformRoIPoolingPack, ModulatedDeformRoIPoolingPack,
+                                          deform_roi_pooling)
+    data, rois, trans, grad, kw = _psroi_case(3, False, 1, out_dim=8)
+    d, r, t = data.cuda(), rois.cuda(), trans.cuda()
+    args = (kw["spatial_scale"], kw["out_size"], 8)
+    plain = deform_roi_pooling(d, r, d.new_empty(0), *args, True, 1, 3, 2, 0.1)
+    # zero offsets, or trans_std = 0, reduce the deformable pooling to the undeformed one
+    torch.testing.assert_close(deform_roi_pooling(d, r, torch.zeros_like(t), *args, False, 1, 3, 2, 0.1), plain)
+    torch.testing.assert_close(deform_roi_pooling(d, r, t, *args, False, 1, 3, 2, 0.0), plain)
+    # a constant map pools to the constant wherever at least one sample is inside
+    const = torch.full_like(d, 2.5)
+    out = deform_roi_pooling(const, r, t, *args, False, 1, 3, 2, 0.1)
+    assert torch.all((out == 0) | ((out - 2.5).abs() < 1e-5))
+    torch.testing.assert_close(DeformRoIPooling(*args, no_trans=True)(d, r, t), plain)
+    # the packs initialise their last layers to zero (deform_pool_module.py:63-64, :125-126): v1 == plain,
+    # v2 == plain * sigmoid(0)
+    torch.manual_seed(0)
+    pack = DeformRoIPoolingPack(*args, no_trans=False, trans_std=0.1, sample_per_part=2, deform_fc_channels=64).cuda()
+    torch.testing.assert_close(pack(d, r), plain)
+    mpack = ModulatedDeformRoIPoolingPack(*args, no_trans=False, trans_std=0.1, sample_per_part=2,
+                                          deform_fc_channels=64).cuda()
+    torch.testing.assert_close(mpack(d, r), plain * 0.5)
+    # gradients reach the offset branch once its last layer is non-zero
+    torch.nn.init.normal_(pack.offset_fc[-1].weight, std=0.01)
+    dd = d.clone().requires_grad_(True)
+    pack(dd, r).square().sum().backward()
+    assert dd.grad.abs().sum() > 0 and pack.offset_fc[0].weight.grad.abs().sum() > 0
+    # zero ROIs
+    e = deform_roi_pooling(d, r[:0], d.new_empty(0), *args, True, 1, 3, 2, 0.1)
+    assert e.shape == (0, 8, 3, 3)
