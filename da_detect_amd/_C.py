@@ -424,6 +424,34 @@ def deform_sample_backward(x, offset, mask, gcols, kh, kw, stride, pad, dil, dg,
     return gx, goffset, gmask
 
 
+def roi_pool_forward(input, rois, spatial_scale, pooled_height, pooled_width):
+    """-> (output, argmax int32) [R, C, ph, pw] channels_last; reference ROIPool.h:11-24"""
+    _dev(input, "input"), _dev(rois, "rois")
+    x = _nhwc(input)
+    rois = rois.contiguous().float()
+    B, C, H, W = x.shape
+    R = rois.shape[0]
+    out = torch.empty((R, C, pooled_height, pooled_width), dtype=torch.float32, device=x.device, memory_format=CL)
+    arg = torch.empty((R, C, pooled_height, pooled_width), dtype=torch.int32, device=x.device, memory_format=CL)
+    _lib.call("dadet_roi_pool_forward", _p(x), _p(rois), _p(out), _p(arg), B, C, H, W, R, pooled_height,
+              pooled_width, float(spatial_scale), _stream())
+    return out, arg
+
+
+def roi_pool_backward(grad, input, rois, argmax, spatial_scale, pooled_height, pooled_width, batch_size, channels,
+                      height, width):
+    """argument order of ROIPool.h:26-46 (`input` and `spatial_scale` are unused, as in the reference kernel)"""
+    _dev(grad, "grad")
+    grad = _nhwc(grad)
+    argmax = argmax.contiguous(memory_format=CL)
+    rois = rois.contiguous().float()
+    gin = torch.empty((batch_size, channels, height, width), dtype=torch.float32, device=grad.device,
+                      memory_format=CL)
+    _lib.call("dadet_roi_pool_backward", _p(grad), _p(argmax), _p(rois), _p(gin), batch_size, channels, height, width,
+              rois.shape[0], pooled_height, pooled_width, _stream())
+    return gin
+
+
 def _psroi_args(data, rois, offset, out_size, out_channels, no_trans, group_size, part_size, sample_per_part):
     B, C, H, W = data.shape
     R = rois.shape[0]

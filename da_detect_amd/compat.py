@@ -10,7 +10,7 @@ import importlib
 import sys
 
 _SUBMODULES = [
-    "_C", "config", "config.defaults", "layers", "layers.roi_align", "layers.misc", "structures",
+    "_C", "config", "config.defaults", "layers", "layers.roi_align", "layers.roi_pool", "layers.dcn", "layers.misc", "structures",
     "structures.bounding_box", "structures.boxlist_ops", "structures.image_list", "modeling", "modeling.registry",
     "modeling.box_coder", "modeling.matcher", "modeling.balanced_positive_negative_sampler", "modeling.poolers",
     "modeling.utils", "modeling.backbone", "modeling.backbone.resnet", "modeling.backbone.backbone", "modeling.rpn",

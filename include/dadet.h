@@ -168,6 +168,15 @@ int dadet_deform_sample_backward(const float* x, const float* offset, const floa
                                  int KW, int stride, int pad, int dil, int deformable_groups, int Ho, int Wo,
                                  void* stream);
 
+/* ROIPool — replaces `_C.roi_pool_forward / roi_pool_backward` (csrc/vision.cpp:11-12, ROIPool.h:11-46,
+ * cuda/ROIPool_cuda.cu:16-108).  input [B][H][W][C] NHWC, rois [R][5] = (batch, x1, y1, x2, y2), output and
+ * argmax [R][PH][PW][C]; argmax = h*W + w of the first maximum of the bin, -1 for an empty bin (output 0).
+ * Backward zero-fills grad_input [B][H][W][C] and routes every output gradient to its argmax cell. */
+int dadet_roi_pool_forward(const float* input, const float* rois, float* output, int* argmax, int B, int C, int H,
+                           int W, int R, int pooled_h, int pooled_w, float spatial_scale, void* stream);
+int dadet_roi_pool_backward(const float* grad_output, const int* argmax, const float* rois, float* grad_input, int B,
+                            int C, int H, int W, int R, int pooled_h, int pooled_w, void* stream);
+
 /* Deformable position-sensitive ROI pooling — replaces the vendored tree's `_C.deform_psroi_pooling_forward /
  * _backward` (tools/cityscapes/maskrcnn_benchmark/csrc/vision.cpp:22-23, cuda/deform_pool_kernel_cuda.cu:30-264).
  * data [B][H][W][C] NHWC with C = output_dim*group_size^2; rois [R][5]; trans [R][num_classes*2][part][part]

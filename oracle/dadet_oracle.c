@@ -240,3 +240,57 @@ void oracle_decode_clip(const float* deltas, const float* anchors, int K, float 
     out[4 * k] = x1; out[4 * k + 1] = y1; out[4 * k + 2] = x2; out[4 * k + 3] = y2;
   }
 }
+
+/* ---------------------------------------------------------------------------------------------------------------
+ * ROIPool forward / backward, NCHW.  The reference has no CPU ROIPool (csrc/ROIPool.h:20-22 "Not implemented on
+ * the CPU"), so this restates its CUDA kernels (csrc/cuda/ROIPool_cuda.cu:16-75 forward, :77-108 backward) and is
+ * NOT pinned against reference outputs ("parity unpinned"); tests pin it by properties (whole-map ROI == global
+ * max, 1x1-bin ROI == the pixel, adaptive_max_pool2d on an exactly divisible ROI). */
+void oracle_roi_pool_forward(const float* input, const float* rois, float* output, int* argmax, int B, int C, int H,
+                             int W, int R, int PH, int PW, float scale) {
+  (void)B;
+  for (int n = 0; n < R; ++n) {
+    const float* r = rois + (size_t)n * 5;
+    const int b = (int)r[0];
+    const int sw = (int)roundf(r[1] * scale), sh = (int)roundf(r[2] * scale);
+    const int ew = (int)roundf(r[3] * scale), eh = (int)roundf(r[4] * scale);
+    const int rw = (ew - sw + 1) > 1 ? (ew - sw + 1) : 1, rh = (eh - sh + 1) > 1 ? (eh - sh + 1) : 1;
+    const float bin_h = (float)rh / (float)PH, bin_w = (float)rw / (float)PW;
+    for (int c = 0; c < C; ++c)
+      for (int ph = 0; ph < PH; ++ph)
+        for (int pw = 0; pw < PW; ++pw) {
+          int hs = (int)floorf((float)ph * bin_h) + sh, he = (int)ceilf((float)(ph + 1) * bin_h) + sh;
+          int ws = (int)floorf((float)pw * bin_w) + sw, we = (int)ceilf((float)(pw + 1) * bin_w) + sw;
+          hs = hs < 0 ? 0 : (hs > H ? H : hs);
+          he = he < 0 ? 0 : (he > H ? H : he);
+          ws = ws < 0 ? 0 : (ws > W ? W : ws);
+          we = we < 0 ? 0 : (we > W ? W : we);
+          const int empty = (he <= hs) || (we <= ws);
+          float best = empty ? 0.f : -FLT_MAX;
+          int idx = -1;
+          const float* plane = input + ((size_t)b * C + c) * H * W;
+          for (int h = hs; h < he; ++h)
+            for (int w = ws; w < we; ++w)
+              if (plane[h * W + w] > best) {
+                best = plane[h * W + w];
+                idx = h * W + w;
+              }
+          const size_t o = (((size_t)n * C + c) * PH + ph) * PW + pw;
+          output[o] = best;
+          argmax[o] = idx;
+        }
+  }
+}
+
+void oracle_roi_pool_backward(const float* grad_out, const int* argmax, const float* rois, float* grad_in, int B,
+                              int C, int H, int W, int R, int PH, int PW) {
+  memset(grad_in, 0, sizeof(float) * (size_t)B * C * H * W);
+  for (int n = 0; n < R; ++n) {
+    const int b = (int)rois[(size_t)n * 5];
+    for (int c = 0; c < C; ++c)
+      for (int k = 0; k < PH * PW; ++k) {
+        const size_t o = ((size_t)n * C + c) * PH * PW + k;
+        if (argmax[o] >= 0) grad_in[((size_t)b * C + c) * H * W + argmax[o]] += grad_out[o];
+      }
+  }
+}

@@ -90,3 +90,23 @@ def decode_clip(deltas, anchors, weights, xform_clip, im_w, im_h):
                              ctypes.c_float(ww), ctypes.c_float(wh), ctypes.c_float(xform_clip),
                              ctypes.c_float(im_w), ctypes.c_float(im_h), _fp(out))
     return out
+
+
+def roi_pool_forward(inp, rois, spatial_scale, ph, pw):
+    inp, rois = _f(inp), _f(rois).reshape(-1, 5)
+    B, C, H, W = inp.shape
+    R = rois.shape[0]
+    out = np.empty((R, C, ph, pw), dtype=np.float32)
+    arg = np.empty((R, C, ph, pw), dtype=np.int32)
+    lib().oracle_roi_pool_forward(_fp(inp), _fp(rois), _fp(out), _fp(arg), B, C, H, W, R, ph, pw,
+                                  ctypes.c_float(spatial_scale))
+    return out, arg
+
+
+def roi_pool_backward(grad, argmax, rois, B, C, H, W):
+    grad, rois = _f(grad), _f(rois).reshape(-1, 5)
+    argmax = np.ascontiguousarray(argmax, dtype=np.int32)
+    R, _, ph, pw = grad.shape
+    gin = np.empty((B, C, H, W), dtype=np.float32)
+    lib().oracle_roi_pool_backward(_fp(grad), _fp(argmax), _fp(rois), _fp(gin), B, C, H, W, R, ph, pw)
+    return gin

@@ -131,6 +131,44 @@ def test_roi_align_empty(device):
     assert out.shape == (0, 8, 7, 7)
 
 
+# --------------------------------------------------------------------------------- ROIPool
+@pytest.mark.parametrize("C,H,W,R,ph", [(8, 20, 32, 16, 7), (64, 38, 76, 40, 14), (12, 25, 31, 9, 7), (3, 9, 7, 50, 2)])
+def test_roi_pool_forward_backward_bit_exact(device, C, H, W, R, ph):
+    from da_detect_amd import _C
+    from oracle import ops as O
+
+    rng = np.random.default_rng(C + R)
+    x = rng.standard_normal((2, C, H, W)).astype(np.float32)
+    rois = _rois(rng, R, 2, W * 16, H * 16)
+    rois[0, 1:] = [-40, -40, -30, -30]            # fully outside -> empty bins (0, argmax -1)
+    rois[1, 1:] = [50, 60, 20, 10]                # malformed -> forced to 1x1
+    want, warg = O.roi_pool_forward(x, rois, 1 / 16.0, ph, ph)
+    xd, rd = torch.from_numpy(x).to(device), torch.from_numpy(rois).to(device)
+    got, garg = _C.roi_pool_forward(xd, rd, 1 / 16.0, ph, ph)
+    assert garg.dtype == torch.int32 and (warg == -1).any()
+    assert np.array_equal(got.cpu().numpy(), want) and np.array_equal(garg.cpu().numpy(), warg)
+    # backward: a power-of-two gradient makes the atomic accumulation order-independent -> bit exact
+    g = (2.0 ** rng.integers(-3, 3, size=want.shape)).astype(np.float32)
+    gwant = O.roi_pool_backward(g, warg, rois, 2, C, H, W)
+    ggot = _C.roi_pool_backward(torch.from_numpy(g).to(device), xd, rd, garg, 1 / 16.0, ph, ph, 2, C, H, W)
+    assert np.array_equal(ggot.cpu().numpy(), gwant)
+
+
+def test_roi_pool_layer_autograd_and_empty(device):
+    from da_detect_amd.layers import ROIPool
+
+    torch.manual_seed(0)
+    x = torch.randn(2, 16, 12, 20, device=device, requires_grad=True)
+    rois = torch.tensor([[0, 0, 0, 19 * 16, 11 * 16], [1, 32, 32, 95, 95]], dtype=torch.float32, device=device)
+    pool = ROIPool((2, 2), 1 / 16.0)
+    y = pool(x, rois)
+    # ROI 0 covers the whole map: max over the 2x2 quadrant grid equals adaptive max pooling of image 0
+    torch.testing.assert_close(y[0], torch.nn.functional.adaptive_max_pool2d(x[0].detach(), 2))
+    y.sum().backward()
+    assert x.grad.sum().item() == y.numel() and set(x.grad.unique().tolist()) <= {0.0, 1.0}
+    assert pool(x, rois[:0]).shape == (0, 16, 2, 2)
+
+
 # --------------------------------------------------------------------------------- convolution
 def _conv_case(rng, N, Cin, H, W, Cout, k, stride, pad):
     x = rng.standard_normal((N, Cin, H, W)).astype(np.float32)

@@ -111,3 +111,23 @@ def test_model_ref_reproduces_reference_losses(case):
     assert nprop == min(nimg, 2)  # the box head sees [source, target] only, also in triplet mode
     for i in range(nprop):
         np.testing.assert_allclose(inter["proposals"][i][0].numpy(), z["proposals/%d/boxes" % i], atol=1e-3)
+
+
+def test_roi_pool_oracle_properties():
+    """the ROIPool restatement has no CPU reference to run against (ROIPool.h:20-22): pin it by properties"""
+    from oracle import ops as O
+
+    rng = np.random.default_rng(5)
+    x = rng.standard_normal((2, 6, 12, 20)).astype(np.float32)
+    rois = np.array([[0, 0, 0, 19 * 16, 11 * 16],      # the whole map, exactly divisible by 2x2 bins
+                     [1, 48, 32, 48, 32],               # a single cell
+                     [1, -400, -400, -300, -300]], dtype=np.float32)   # outside: empty
+    out, arg = O.roi_pool_forward(x, rois, 1 / 16.0, 2, 2)
+    want = torch.nn.functional.adaptive_max_pool2d(torch.from_numpy(x[0]), 2).numpy()
+    assert np.array_equal(out[0], want)
+    assert np.array_equal(out[1], np.broadcast_to(x[1, :, 2, 3][:, None, None], (6, 2, 2)))
+    assert np.all(arg[1] == 2 * 20 + 3)
+    assert np.all(out[2] == 0) and np.all(arg[2] == -1)
+    g = np.ones_like(out)
+    gin = O.roi_pool_backward(g, arg, rois, 2, 6, 12, 20)
+    assert gin.sum() == (arg >= 0).sum() and gin[1, :, 2, 3].tolist() == [4.0] * 6
