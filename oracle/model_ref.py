@@ -131,6 +131,22 @@ def decode(codes, boxes, weights, clip=math.log(1000.0 / 16)):
     return torch.stack((pcx - 0.5 * pw, pcy - 0.5 * ph, pcx + 0.5 * pw - 1, pcy + 0.5 * ph - 1), dim=1)
 
 
+def decode_multi(codes, boxes, weights, clip=math.log(1000.0 / 16)):
+    """modeling/box_coder.py:52-95 for [N, 4*K] codes (K classes per box) -> [N, 4*K]"""
+    w, h = boxes[:, 2] - boxes[:, 0] + 1, boxes[:, 3] - boxes[:, 1] + 1
+    cx, cy = boxes[:, 0] + 0.5 * w, boxes[:, 1] + 0.5 * h
+    wx, wy, ww, wh = weights
+    dx, dy = codes[:, 0::4] / wx, codes[:, 1::4] / wy
+    dw = torch.clamp(codes[:, 2::4] / ww, max=clip)
+    dh = torch.clamp(codes[:, 3::4] / wh, max=clip)
+    pcx, pcy = dx * w[:, None] + cx[:, None], dy * h[:, None] + cy[:, None]
+    pw, ph = torch.exp(dw) * w[:, None], torch.exp(dh) * h[:, None]
+    out = torch.zeros_like(codes)
+    out[:, 0::4], out[:, 1::4] = pcx - 0.5 * pw, pcy - 0.5 * ph
+    out[:, 2::4], out[:, 3::4] = pcx + 0.5 * pw - 1, pcy + 0.5 * ph - 1
+    return out
+
+
 def matcher(iou, high, low, allow_low_quality):
     """modeling/matcher.py:42-112"""
     vals, matches = iou.max(dim=0)
@@ -486,6 +502,62 @@ def training_losses(sd, cfg, images, gts, state=None, intermediates=None, select
                              sampled_idx=[s["idx"] for s in samples], da_sampled_idx=[s["idx"] for s in da_samples],
                              da_feat=da_feat.detach())
     return losses
+
+
+# ---------------------------------------------------------------------------------------------- evaluation
+def post_process(logits, reg, proposals, image_sizes, cfg):
+    """PostProcessor.forward / filter_results (roi_heads/box_head/inference.py:43-150): softmax, per-class decode
+    with BBOX_REG_WEIGHTS, clip, score threshold, per-class NMS, top DETECTIONS_PER_IMG by kthvalue threshold.
+    -> per image dict(boxes [D,4], scores [D], labels [D] int64), classes concatenated in ascending order"""
+    rh = cfg.MODEL.ROI_HEADS
+    prob = F.softmax(logits, -1)
+    counts = [len(b) for b, _ in proposals]
+    boxes = decode_multi(reg.reshape(sum(counts), -1), torch.cat([b for b, _ in proposals], 0), rh.BBOX_REG_WEIGHTS)
+    ncls = prob.shape[1]
+    out = []
+    for p_i, b_i, (h, w) in zip(prob.split(counts, 0), boxes.split(counts, 0), image_sizes):
+        b_i = b_i.reshape(-1, 4)
+        b_i = torch.stack([b_i[:, 0].clamp(0, w - 1), b_i[:, 1].clamp(0, h - 1), b_i[:, 2].clamp(0, w - 1),
+                           b_i[:, 3].clamp(0, h - 1)], 1).reshape(-1, ncls * 4)
+        rb, rs, rl = [], [], []
+        for j in range(1, ncls):
+            inds = torch.nonzero(p_i[:, j] > rh.SCORE_THRESH).squeeze(1)
+            bj, sj = b_i[inds, 4 * j:4 * j + 4], p_i[inds, j]
+            keep = torch.from_numpy(O.nms(bj.numpy(), sj.numpy(), rh.NMS, 0))
+            rb.append(bj[keep]), rs.append(sj[keep]), rl.append(torch.full((len(keep),), j, dtype=torch.int64))
+        rb, rs, rl = torch.cat(rb), torch.cat(rs), torch.cat(rl)
+        if len(rs) > rh.DETECTIONS_PER_IMG > 0:
+            thr, _ = torch.kthvalue(rs, len(rs) - rh.DETECTIONS_PER_IMG + 1)
+            keep = torch.nonzero(rs >= thr.item()).squeeze(1)
+            rb, rs, rl = rb[keep], rs[keep], rl[keep]
+        out.append(dict(boxes=rb, scores=rs, labels=rl))
+    return out
+
+
+def inference(sd, cfg, images, intermediates=None, selection_maps=None):
+    """GeneralizedRCNN.forward in eval mode (generalized_rcnn.py:61-70,145-156; box_head.py:58-67 eval branch):
+    backbone -> RPN (PRE/POST_NMS_TOP_N_TEST, no GT appended) -> ROIAlign + res5 on every proposal -> predictor
+    -> PostProcessor."""
+    with torch.no_grad():
+        N, _, H, W = images.shape
+        image_sizes = [(H, W)] * N
+        feat = backbone_c4(images, sd)
+        objectness, deltas = rpn_head(feat, sd)
+        rpn = cfg.MODEL.RPN
+        anchors = grid_anchors(feat.shape[2], feat.shape[3], rpn.ANCHOR_STRIDE[0],
+                               cell_anchors(rpn.ANCHOR_STRIDE[0], rpn.ANCHOR_SIZES, rpn.ASPECT_RATIOS))
+        sel_obj, sel_del = selection_maps if selection_maps is not None else (objectness, deltas)
+        proposals = rpn_proposals(sel_obj, sel_del, anchors, image_sizes, None, cfg, False)
+        x = roi_feature(feat, [dict(boxes=b) for b, _ in proposals], sd, cfg)
+        v = F.avg_pool2d(x, 7).flatten(1)
+        logits = F.linear(v, sd["roi_heads.box.predictor.cls_score.weight"],
+                          sd["roi_heads.box.predictor.cls_score.bias"])
+        reg = F.linear(v, sd["roi_heads.box.predictor.bbox_pred.weight"],
+                       sd["roi_heads.box.predictor.bbox_pred.bias"])
+        if intermediates is not None:
+            intermediates.update(objectness=objectness, deltas=deltas, proposals=proposals, class_logits=logits,
+                                 box_regression=reg)
+        return post_process(logits, reg, proposals, image_sizes, cfg)
 
 
 # ------------------------------------------------------------------------------------------ CPU baseline

@@ -174,3 +174,44 @@ def test_cosine_scheduler_restated_from_call_site():
     assert abs(opt.param_groups[0]["lr"] - (1e-6 + 0.5 * (1e-3 - 1e-6))) < 1e-9
     s.step_update(5000)
     assert abs(opt.param_groups[0]["lr"] - 1e-6) < 1e-12
+
+
+@pytest.mark.parametrize("case", ["da_plain", "da_triplet"])
+def test_state_dict_keys_match_reference(case):
+    """released DA checkpoints must load: same state_dict key names and shapes as the reference model
+    (tests/golden/reference_state_dict_keys.json, written by make_golden_eval.py from the imported reference)"""
+    import json
+
+    from da_detect_amd.modeling.detector import build_detection_model
+    from golden.cases import case_cfg
+
+    ref = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "reference_state_dict_keys.json")))[case]
+    mine = {k: list(v.shape) for k, v in build_detection_model(case_cfg(case)).state_dict().items()}
+    assert set(mine) == set(ref), (sorted(set(mine) - set(ref))[:5], sorted(set(ref) - set(mine))[:5])
+    assert all(mine[k] == ref[k] for k in ref)
+
+
+def test_prepare_for_coco_detection_records():
+    """bbox.json record boundary (coco_eval.py:81-112): resize to the original size, xywh with the +1 convention"""
+    from da_detect_amd.engine.inference import _accumulate_predictions_from_multiple_gpus, prepare_for_coco_detection
+    from da_detect_amd.structures.bounding_box import BoxList
+
+    class DS:
+        id_to_img_map = {0: 17, 1: 42}
+        contiguous_category_id_to_json_id = {1: 24, 2: 26}
+
+        def get_img_info(self, i):
+            return {"width": 200, "height": 100}
+
+    a = BoxList(torch.tensor([[10.0, 20.0, 29.0, 39.0]]), (100, 50), mode="xyxy")   # half-size network input
+    a.add_field("scores", torch.tensor([0.9]))
+    a.add_field("labels", torch.tensor([2]))
+    empty = BoxList(torch.zeros((0, 4)), (100, 50), mode="xyxy")
+    empty.add_field("scores", torch.zeros(0))
+    empty.add_field("labels", torch.zeros(0, dtype=torch.int64))
+    preds = _accumulate_predictions_from_multiple_gpus({1: empty, 0: a})
+    recs = prepare_for_coco_detection(preds, DS())
+    assert len(recs) == 1
+    r = recs[0]
+    assert r["image_id"] == 17 and r["category_id"] == 26 and abs(r["score"] - 0.9) < 1e-6
+    assert r["bbox"] == [20.0, 40.0, 39.0, 39.0]    # scaled x2 -> (20,40,58,78) -> w = 58-20+1, h = 78-40+1

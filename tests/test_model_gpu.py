@@ -242,3 +242,75 @@ def test_conv_linearity_and_adjoint_at_full_size(device):
     dw = _C.conv_wgrad(x, g, tuple(w.shape), 1, 1)
     lhs2 = float((dw.double() * w.double()).sum())
     assert abs(lhs - lhs2) <= 1e-4 * max(abs(lhs), 1.0)  # <conv(x,w), g> == <w, wgrad(x,g)>
+
+
+# ---------------------------------------------------------------------------------------------- evaluation path
+def _eval_model(device):
+    from da_detect_amd.data.synthetic import make_batch
+    from da_detect_amd.modeling.detector import build_detection_model
+    from golden.cases import case_cfg
+    from golden.fill import fill_state_dict
+
+    z = np.load(os.path.join(GOLD, "eval_da_plain.npz"))
+    c = case_cfg("da_plain")
+    model = build_detection_model(c)
+    model.load_state_dict(fill_state_dict(model.state_dict(), int(z["seed"])))
+    model = model.to(device).eval()
+    images, _ = make_batch(c, int(z["nimg"]), int(z["H"]), int(z["W"]), seed=int(z["seed"]), device=device)
+    return z, model, images
+
+
+def test_eval_detections_match_reference_golden(device):
+    """model.eval() forward (generalized_rcnn.py:61-70,145-156 -> box_head.py eval branch -> PostProcessor):
+    detections vs the imported reference's (tests/golden/eval_da_plain.npz).  The proposal SELECTION is fed the
+    fixture's RPN maps (see _run_with_golden_rpn_selection); box head, softmax, decode, per-class NMS and the
+    top-100 cut run on this model's own tensors."""
+    z, model, images = _eval_model(device)
+    captured = {}
+    model.rpn.head.register_forward_hook(
+        lambda m, i, o: captured.update(objectness=o[0][0].detach(), deltas=o[1][0].detach()))
+    model.roi_heads.box.predictor.register_forward_hook(
+        lambda m, i, o: captured.update(class_logits=o[0].detach(), box_regression=o[1].detach()))
+    selector = model.rpn.box_selector_test
+    orig = selector.forward
+    gold_obj = [torch.from_numpy(z["objectness"]).to(device)]
+    gold_del = [torch.from_numpy(z["deltas"]).to(device)]
+    selector.forward = lambda anchors, objectness, box_regression, tg=None: orig(anchors, gold_obj, gold_del, tg)
+    try:
+        with torch.no_grad():
+            dets = model(images)
+    finally:
+        selector.forward = orig
+    scale = float(np.abs(z["objectness"]).mean())
+    assert float((captured["objectness"].cpu() - torch.from_numpy(z["objectness"])).abs().max()) < 1e-4 * max(scale, 1)
+    np.testing.assert_allclose(captured["class_logits"].cpu().numpy(), z["class_logits"], rtol=1e-4, atol=2e-5)
+    np.testing.assert_allclose(captured["box_regression"].cpu().numpy(), z["box_regression"], rtol=1e-4, atol=2e-5)
+    assert len(dets) == int(z["nimg"])
+    for i, d in enumerate(dets):
+        assert d.mode == "xyxy" and d.size == (int(z["W"]), int(z["H"]))
+        labels = d.get_field("labels").cpu().numpy()
+        assert labels.dtype == np.int64 and np.array_equal(labels, z["det/%d/labels" % i])
+        np.testing.assert_allclose(d.bbox.cpu().numpy(), z["det/%d/boxes" % i], atol=5e-3)
+        np.testing.assert_allclose(d.get_field("scores").cpu().numpy(), z["det/%d/scores" % i], atol=2e-6)
+
+
+def test_eval_without_injection_and_rpn_only(device):
+    """no injection: same number of detections per image and score multiset within fp32 noise; RPN_ONLY eval
+    returns the proposals (generalized_rcnn.py:141-143)"""
+    z, model, images = _eval_model(device)
+    with torch.no_grad():
+        dets = model(images)
+    for i, d in enumerate(dets):
+        want = np.sort(z["det/%d/scores" % i])
+        got = np.sort(d.get_field("scores").cpu().numpy())
+        assert abs(len(got) - len(want)) <= 2
+        k = min(len(got), len(want))
+        np.testing.assert_allclose(got[-k:], want[-k:], atol=1e-4)
+    roi_heads, model.roi_heads = model.roi_heads, None
+    try:
+        with torch.no_grad():
+            props = model(images)
+    finally:
+        model.roi_heads = roi_heads
+    for i, p in enumerate(props):
+        assert abs(len(p) - len(z["proposals/%d/boxes" % i])) <= 3 and p.has_field("objectness")

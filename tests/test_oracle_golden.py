@@ -131,3 +131,26 @@ def test_roi_pool_oracle_properties():
     g = np.ones_like(out)
     gin = O.roi_pool_backward(g, arg, rois, 2, 6, 12, 20)
     assert gin.sum() == (arg >= 0).sum() and gin[1, :, 2, 3].tolist() == [4.0] * 6
+
+
+def test_model_ref_inference_reproduces_reference_detections():
+    """eval path: oracle/model_ref.inference vs the imported reference's detections (tests/golden/eval_da_plain.npz)"""
+    from da_detect_amd.data.synthetic import make_batch
+    from golden.cases import case_cfg
+    from golden.fill import fill_state_dict
+    from oracle import model_ref
+
+    z = np.load(os.path.join(GOLD, "eval_da_plain.npz"))
+    ref_keys = json.load(open(os.path.join(GOLD, "reference_state_dict_keys.json")))["da_plain"]
+    c = case_cfg("da_plain")
+    sd = fill_state_dict({k: torch.empty(v) for k, v in ref_keys.items()}, int(z["seed"]))
+    images, _ = make_batch(c, int(z["nimg"]), int(z["H"]), int(z["W"]), seed=int(z["seed"]),
+                           device=torch.device("cpu"))
+    inter = {}
+    dets = model_ref.inference(sd, c, images.tensors, inter)
+    np.testing.assert_allclose(inter["class_logits"].numpy(), z["class_logits"], rtol=1e-4, atol=1e-5)
+    for i, d in enumerate(dets):
+        assert np.array_equal(d["labels"].numpy(), z["det/%d/labels" % i])
+        np.testing.assert_allclose(d["boxes"].numpy(), z["det/%d/boxes" % i], atol=2e-3)
+        np.testing.assert_allclose(d["scores"].numpy(), z["det/%d/scores" % i], atol=1e-6)
+        np.testing.assert_allclose(inter["proposals"][i][0].numpy(), z["proposals/%d/boxes" % i], atol=1e-3)
