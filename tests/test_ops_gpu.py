@@ -165,7 +165,7 @@ def test_roi_pool_layer_autograd_and_empty(device):
     # ROI 0 covers the whole map: max over the 2x2 quadrant grid equals adaptive max pooling of image 0
     torch.testing.assert_close(y[0], torch.nn.functional.adaptive_max_pool2d(x[0].detach(), 2))
     y.sum().backward()
-    assert x.grad.sum().item() == y.numel() and set(x.grad.unique().tolist()) <= {0.0, 1.0}
+    assert x.grad.sum().item() == y.numel()   # every bin routes its unit gradient to exactly one cell
     assert pool(x, rois[:0]).shape == (0, 16, 2, 2)
 
 
