@@ -1,8 +1,10 @@
 """ROI feature extractors (reference: maskrcnn_benchmark/modeling/roi_heads/box_head/roi_box_feature_extractors.py)."""
 from torch import nn
 
+from ....layers import conv2d_affine_act
 from ... import registry
 from ...backbone import resnet
+from ...make_layers import make_fc
 from ...poolers import Pooler
 
 
@@ -25,6 +27,33 @@ class ResNet50Conv5ROIFeatureExtractor(nn.Module):
 
     def forward(self, x, proposals):
         return self.head(self.pooler(x, proposals))
+
+
+@registry.ROI_BOX_FEATURE_EXTRACTORS.register("FPN2MLPFeatureExtractor")
+class FPN2MLPFeatureExtractor(nn.Module):
+    """per-level ROIAlign (7x7) -> fc6 -> ReLU -> fc7 -> ReLU (roi_box_feature_extractors.py:48-79).
+
+    fc6 consumes the pooled tensor flattened in (c, h, w) order.  The pooled ROIs live as NHWC here, so instead of
+    transposing every ROI, fc6 runs as a 7x7 VALID convolution with its weight viewed as [rep, C, 7, 7] — the same
+    contraction, summed over (h, w, c) in the layout the data already has."""
+
+    def __init__(self, cfg):
+        super(FPN2MLPFeatureExtractor, self).__init__()
+        resolution = cfg.MODEL.ROI_BOX_HEAD.POOLER_RESOLUTION
+        self.pooler = Pooler(output_size=(resolution, resolution), scales=cfg.MODEL.ROI_BOX_HEAD.POOLER_SCALES,
+                             sampling_ratio=cfg.MODEL.ROI_BOX_HEAD.POOLER_SAMPLING_RATIO)
+        self.resolution, self.channels = resolution, cfg.MODEL.BACKBONE.OUT_CHANNELS
+        input_size = self.channels * resolution ** 2
+        representation_size = cfg.MODEL.ROI_BOX_HEAD.MLP_HEAD_DIM
+        use_gn = cfg.MODEL.ROI_BOX_HEAD.USE_GN
+        self.fc6 = make_fc(input_size, representation_size, use_gn)
+        self.fc7 = make_fc(representation_size, representation_size, use_gn)
+
+    def forward(self, x, proposals):
+        x = self.pooler(x, proposals)
+        w6 = self.fc6.weight.view(-1, self.channels, self.resolution, self.resolution)
+        x = conv2d_affine_act(x, w6, None, self.fc6.bias, relu=True)
+        return self.fc7(x.reshape(x.shape[0], -1), relu=True)
 
 
 def make_roi_box_feature_extractor(cfg):

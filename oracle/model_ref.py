@@ -560,6 +560,100 @@ def inference(sd, cfg, images, intermediates=None, selection_maps=None):
         return post_process(logits, reg, proposals, image_sizes, cfg)
 
 
+# ------------------------------------------------------------------------------------------- FPN variant
+def backbone_fpn(images, sd, blocks=(3, 4, 6, 3)):
+    """R-50-FPN body + FPN (backbone.py:21-42, fpn.py:43-79): C2..C5 -> (P2, P3, P4, P5, P6)"""
+    p = "backbone.body"
+    x = F.relu(frozen_bn(F.conv2d(images, sd[p + ".stem.conv1.weight"], None, 2, 3), sd, p + ".stem.bn1"))
+    x = F.max_pool2d(x, kernel_size=3, stride=2, padding=1)
+    cs = []
+    for i, nb in enumerate(blocks):
+        x = stage(x, sd, "%s.layer%d" % (p, i + 1), nb, 1 if i == 0 else 2)
+        cs.append(x)
+    f = "backbone.fpn.fpn_"
+    conv = lambda name, t, pad: F.conv2d(t, sd[f + name + ".weight"], sd[f + name + ".bias"], 1, pad)
+    last = conv("inner4", cs[3], 0)
+    out = [conv("layer4", last, 1)]
+    for lvl in (3, 2, 1):
+        last = conv("inner%d" % lvl, cs[lvl - 1], 0) + F.interpolate(last, scale_factor=2, mode="nearest")
+        out.insert(0, conv("layer%d" % lvl, last, 1))
+    out.append(F.max_pool2d(out[-1], 1, 2, 0))
+    return out
+
+
+def rpn_proposals_fpn(objectness, deltas, image_sizes, cfg):
+    """test-mode RPNPostProcessor over pyramid levels (rpn/inference.py:76-181): per level top PRE_NMS_TOP_N_TEST
+    -> decode/clip -> NMS -> first POST_NMS_TOP_N_TEST; concatenate levels; per image top FPN_POST_NMS_TOP_N_TEST
+    by objectness (ties: ascending position, as a stable sort)"""
+    rpn = cfg.MODEL.RPN
+    N = objectness[0].shape[0]
+    per_image = [[] for _ in range(N)]
+    for lvl, (obj, dlt) in enumerate(zip(objectness, deltas)):
+        stride = rpn.ANCHOR_STRIDE[lvl]
+        anchors = grid_anchors(obj.shape[2], obj.shape[3], stride,
+                               cell_anchors(stride, (rpn.ANCHOR_SIZES[lvl],), rpn.ASPECT_RATIOS))
+        scores = flatten_hwa(obj, 1).reshape(N, -1).sigmoid()
+        d = flatten_hwa(dlt, 4)
+        pre = min(rpn.PRE_NMS_TOP_N_TEST, scores.shape[1])
+        for i in range(N):
+            s, order = torch.sort(scores[i], descending=True, stable=True)
+            s, order = s[:pre], order[:pre]
+            h, w = image_sizes[i]
+            boxes = torch.from_numpy(O.decode_clip(d[i][order].numpy(), anchors[order].numpy(),
+                                                   (1.0, 1.0, 1.0, 1.0), math.log(1000.0 / 16), w, h))
+            keep = torch.from_numpy(O.nms(boxes.numpy(), s.numpy(), rpn.NMS_THRESH, 0))[:rpn.POST_NMS_TOP_N_TEST]
+            per_image[i].append((boxes[keep], s[keep]))
+    out = []
+    for lv in per_image:
+        boxes, s = torch.cat([b for b, _ in lv]), torch.cat([x for _, x in lv])
+        k = min(rpn.FPN_POST_NMS_TOP_N_TEST, len(s))
+        _, inds = torch.sort(s, descending=True, stable=True)
+        out.append((boxes[inds[:k]], s[inds[:k]]))
+    return out
+
+
+def pool_fpn(feats, proposals, cfg):
+    """Pooler with LevelMapper (poolers.py:11-42, 91-121): level = floor(4 + log2(sqrt(area)/224 + 1e-6)) clamped"""
+    bh = cfg.MODEL.ROI_BOX_HEAD
+    scales = bh.POOLER_SCALES
+    k_min, k_max = -math.log2(scales[0]), -math.log2(scales[-1])
+    rois = torch.cat([torch.cat([torch.full((len(b), 1), float(i)), b], 1) for i, (b, _) in enumerate(proposals)], 0)
+    s = torch.sqrt(box_area(rois[:, 1:]))
+    lvl = torch.clamp(torch.floor(4 + torch.log2(s / 224 + 1e-6)), min=k_min, max=k_max).to(torch.int64) - int(k_min)
+    res = bh.POOLER_RESOLUTION
+    out = torch.zeros((len(rois), feats[0].shape[1], res, res))
+    for l, (feat, sc) in enumerate(zip(feats, scales)):
+        idx = torch.nonzero(lvl == l).squeeze(1)
+        if len(idx):
+            out[idx] = roi_align(feat, rois[idx], sc, res, res, bh.POOLER_SAMPLING_RATIO)
+    return out, lvl
+
+
+def inference_fpn(sd, cfg, images, intermediates=None, selection_maps=None):
+    """eval forward of the FPN Faster R-CNN (configs/e2e_faster_rcnn_R_50_FPN_1x.yaml): FPN backbone, shared RPN head
+    on 5 levels, level-mapped ROIAlign, FPN2MLP head (roi_box_feature_extractors.py:48-79), FPNPredictor"""
+    with torch.no_grad():
+        N, _, H, W = images.shape
+        image_sizes = [(H, W)] * N
+        feats = backbone_fpn(images, sd)
+        maps = [rpn_head(f, sd) for f in feats]
+        objectness, deltas = [m[0] for m in maps], [m[1] for m in maps]
+        sel_obj, sel_del = selection_maps if selection_maps is not None else (objectness, deltas)
+        proposals = rpn_proposals_fpn(sel_obj, sel_del, image_sizes, cfg)
+        pooled, lvl = pool_fpn(feats[:len(cfg.MODEL.ROI_BOX_HEAD.POOLER_SCALES)], proposals, cfg)
+        fe = "roi_heads.box.feature_extractor."
+        x = F.relu(F.linear(pooled.flatten(1), sd[fe + "fc6.weight"], sd[fe + "fc6.bias"]))
+        x = F.relu(F.linear(x, sd[fe + "fc7.weight"], sd[fe + "fc7.bias"]))
+        logits = F.linear(x, sd["roi_heads.box.predictor.cls_score.weight"],
+                          sd["roi_heads.box.predictor.cls_score.bias"])
+        reg = F.linear(x, sd["roi_heads.box.predictor.bbox_pred.weight"],
+                       sd["roi_heads.box.predictor.bbox_pred.bias"])
+        if intermediates is not None:
+            intermediates.update(features=feats, objectness=objectness, deltas=deltas, proposals=proposals,
+                                 levels=lvl, class_logits=logits, box_regression=reg)
+        return post_process(logits, reg, proposals, image_sizes, cfg)
+
+
 # ------------------------------------------------------------------------------------------ CPU baseline
 def targets_to_dicts(targets):
     return [dict(boxes=t.bbox.cpu(), labels=t.get_field("labels").cpu(), is_source=t.get_field("is_source").cpu())

@@ -39,6 +39,8 @@ def fill_state_dict(sd, seed=0):
             std = (2.0 / fan_in) ** 0.5
             if "stem.conv1" in k:
                 std = std / 60.0
+            if "fpn_inner" in k:
+                std = std * 0.1  # keeps the pyramid O(1): saturated RPN sigmoids would tie at exactly 1.0
             if "predictor" in k or "rpn.head.cls_logits" in k or "rpn.head.bbox_pred" in k or "_da" in k:
                 std = std * 0.5
             t = torch.randn(shape, generator=g) * std

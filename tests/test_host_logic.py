@@ -176,7 +176,7 @@ def test_cosine_scheduler_restated_from_call_site():
     assert abs(opt.param_groups[0]["lr"] - 1e-6) < 1e-12
 
 
-@pytest.mark.parametrize("case", ["da_plain", "da_triplet"])
+@pytest.mark.parametrize("case", ["da_plain", "da_triplet", "fpn"])
 def test_state_dict_keys_match_reference(case):
     """released DA checkpoints must load: same state_dict key names and shapes as the reference model
     (tests/golden/reference_state_dict_keys.json, written by make_golden_eval.py from the imported reference)"""

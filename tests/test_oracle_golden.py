@@ -154,3 +154,28 @@ def test_model_ref_inference_reproduces_reference_detections():
         np.testing.assert_allclose(d["boxes"].numpy(), z["det/%d/boxes" % i], atol=2e-3)
         np.testing.assert_allclose(d["scores"].numpy(), z["det/%d/scores" % i], atol=1e-6)
         np.testing.assert_allclose(inter["proposals"][i][0].numpy(), z["proposals/%d/boxes" % i], atol=1e-3)
+
+
+def test_model_ref_inference_fpn_reproduces_reference_detections():
+    """FPN eval path (FPN, 5-level RPN, LevelMapper pooling, FPN2MLP head) vs tests/golden/eval_fpn.npz"""
+    from da_detect_amd.data.synthetic import make_batch
+    from golden.cases import case_cfg
+    from golden.fill import fill_state_dict
+    from oracle import model_ref
+
+    z = np.load(os.path.join(GOLD, "eval_fpn.npz"))
+    ref_keys = json.load(open(os.path.join(GOLD, "reference_state_dict_keys.json")))["fpn"]
+    c = case_cfg("fpn")
+    sd = fill_state_dict({k: torch.empty(v) for k, v in ref_keys.items()}, int(z["seed"]))
+    images, _ = make_batch(c, int(z["nimg"]), int(z["H"]), int(z["W"]), seed=int(z["seed"]),
+                           device=torch.device("cpu"))
+    inter = {}
+    dets = model_ref.inference_fpn(sd, c, images.tensors, inter)
+    assert len(torch.unique(inter["levels"])) >= 3          # the LevelMapper spreads ROIs over the pyramid
+    for l in range(5):
+        np.testing.assert_allclose(inter["objectness"][l].numpy(), z["objectness/%d" % l], rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(inter["class_logits"].numpy(), z["class_logits"], rtol=1e-4, atol=1e-5)
+    for i, d in enumerate(dets):
+        assert np.array_equal(d["labels"].numpy(), z["det/%d/labels" % i])
+        np.testing.assert_allclose(d["boxes"].numpy(), z["det/%d/boxes" % i], atol=2e-3)
+        np.testing.assert_allclose(d["scores"].numpy(), z["det/%d/scores" % i], atol=1e-6)
