@@ -89,6 +89,22 @@ def cpu_baseline(cfg_path, seed, budget_s=25.0):
                                            benchmark_init, budget_s)
 
 
+def pmc_traffic(kernel_name, gemm_mode):
+    """HBM bytes per launch of `kernel_name` from the committed PMC passes (profiles/r01_pmc_hbm_traffic.json, made
+    by tools/profile_pmc.sh from this same bench command in mode 3; counters cannot be read from inside the
+    process).  None when the summary does not cover the kernel / mode."""
+    path = os.path.join(ROOT, "profiles", "r01_pmc_hbm_traffic.json")
+    if gemm_mode != 3 or not os.path.exists(path):
+        return None, None
+    want = kernel_name.replace(" ", "")
+    with open(path) as f:
+        table = json.load(f)["kernels"]
+    for name, rec in table.items():
+        if want in name.replace(" ", ""):
+            return rec["hbm_bytes_per_launch"], os.path.relpath(path, ROOT)
+    return None, None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -159,9 +175,12 @@ def main():
             # peak for ALGORITHMIC flops: the fp32 pipe's peak in mode 0; in the split modes every fp32 product
             # costs `mfma_per_product` bf16 MFMAs, so the algorithmic ceiling is the bf16 dense peak divided by it
             peak = FP32_MFMA_PEAK_TFLOPS if args.gemm_mode == 0 else BF16_MFMA_PEAK_TFLOPS / mfma_per_product
+            traffic, traffic_src = pmc_traffic(name, args.gemm_mode)
             roofline = {"bound": "mfma", "kernel": name, "achieved": round(achieved, 2),
                         "peak": round(peak, 1), "unit": "TFLOP/s",
-                        "frac": round(achieved / peak, 4), "traffic": None,
+                        "frac": round(achieved / peak, 4), "traffic": traffic, "traffic_unit": "HBM bytes/launch",
+                        "traffic_source": traffic_src,
+                        "algorithmic_bytes_per_launch": round(k["bytes_per_launch"], 0),
                         "contraction": desc,
                         "executed_mfma_tflops": round(achieved * mfma_per_product, 1),
                         "vs_fp32_mfma_peak": round(achieved / FP32_MFMA_PEAK_TFLOPS, 3),

@@ -34,6 +34,7 @@ class KernelProfiler(object):
 
     def __init__(self):
         self.records = {}   # name -> list of (start_event, end_event, algorithmic_flops)
+        self.bytes = {}     # name -> summed algorithmic bytes (operands read once + result written once)
 
     class _Span(object):
         def __init__(self, prof, name, work):
@@ -47,9 +48,12 @@ class KernelProfiler(object):
         def __exit__(self, *exc):
             self.e.record()
             self.prof.records.setdefault(self.name, []).append((self.s, self.e, self.work))
+            self.prof.bytes[self.name] = self.prof.bytes.get(self.name, 0.0) + self.nbytes
 
-    def span(self, name, work):
-        return KernelProfiler._Span(self, name, work)
+    def span(self, name, work, nbytes=0.0):
+        sp = KernelProfiler._Span(self, name, work)
+        sp.nbytes = nbytes
+        return sp
 
     def summary(self):
         """name -> dict(launches, total_ms, avg_ms, work_per_launch, achieved = work / time per second)"""
@@ -59,6 +63,7 @@ class KernelProfiler(object):
             ms = sum(s.elapsed_time(e) for s, e, _ in recs)
             work = sum(w for _, _, w in recs)
             out[name] = dict(launches=len(recs), total_ms=ms, avg_ms=ms / len(recs),
+                             bytes_per_launch=self.bytes.get(name, 0.0) / len(recs),
                              work_per_launch=work / len(recs), achieved=work / (ms * 1e-3) if ms > 0 else 0.0)
         return out
 
@@ -215,7 +220,9 @@ def conv_forward(x, w, scale=None, bias=None, addend=None, mask_ref=None, stride
         mode = get_gemm_mode()
         kname = "conv_fwd_kernel<%s>" if mode == 0 else ("conv_fwd_split_kernel<%%s,%d>" % mode)
         with PROFILER.span(kname % ("2,2", "2,1", "1,1")[variant],
-                           2.0 * N * Ho * Wo * Cout * Cin * KH * KW):
+                           2.0 * N * Ho * Wo * Cout * Cin * KH * KW,
+                           4.0 * (x.numel() + w.numel() + out.numel() + (addend.numel() if addend is not None else 0)
+                                  + (mask_ref.numel() if mask_ref is not None else 0))):
             _lib.call("dadet_conv_forward", ctypes.byref(d), _p(x), _p(w), _p(scale), _p(bias), _p(addend),
                       _p(mask_ref), _p(out), _stream())
         return out
@@ -253,7 +260,8 @@ def conv_wgrad(x, gy, weight_shape, stride=1, pad=0, out_scale=None, dw=None, ac
     if PROFILER is not None:
         mode = get_gemm_mode()
         with PROFILER.span("conv_wgrad_kernel" if mode == 0 else "conv_wgrad_split_kernel<%d>" % mode,
-                           2.0 * N * Ho * Wo * Cout * Cin * KH * KW):
+                           2.0 * N * Ho * Wo * Cout * Cin * KH * KW,
+                           4.0 * (x.numel() + gy.numel() + dw.numel())):
             _lib.call("dadet_conv_wgrad", ctypes.byref(d), _p(x), _p(gy), _p(out_scale), _p(dw),
                       1 if accumulate else 0, _p(ws), ctypes.c_size_t(ws.numel()), _stream())
         return dw

@@ -34,6 +34,65 @@ ResNet101FPNStagesTo5 = _specs((1, 3, True), (2, 4, True), (3, 23, True), (4, 3,
 ResNet152FPNStagesTo5 = _specs((1, 3, True), (2, 8, True), (3, 36, True), (4, 3, True))
 
 
+class _BottleneckFn(torch.autograd.Function):
+    """One bottleneck (resnet.py:294-314) as ONE autograd node with a hand-scheduled backward.
+
+    forward : 3 (or 4) fused conv launches, exactly as Bottleneck.forward.
+    backward: every ReLU / FrozenBN gate rides in a GEMM epilogue instead of its own elementwise pass —
+      S3 = G * [out > 0]                         (skipped when the only consumer of `out` already gated, see below)
+      S2 = [y2 > 0] * dgrad_conv3(S3)             S1 = [y1 > 0] * dgrad_conv2(S2)        (relu_mode 2 epilogue)
+      dX = [x > 0]? * (dgrad_conv1(S1) + S3 | dgrad_downsample(S3))                      (addend epilogue)
+      dW_k = scale_k * wgrad(input_k, S_k)                                                (out_scale of the reduce)
+    the FrozenBN scales are folded into the transposed weights / the wgrad reduce, so no scaled copy of any S exists.
+    in_relu    : x is the output of a ReLU whose producer gates its incoming gradient by [x > 0] anyway; returning
+                 dX already gated is then exact for every parameter gradient and lets that producer skip its pass.
+    out_private: `out` feeds ONLY a following _BottleneckFn with in_relu (inside _Stage), so G arrives gated."""
+
+    @staticmethod
+    def forward(ctx, x, w1, w2, w3, wd, s1, b1, s2, b2, s3, b3, sd, bd, stride, in_relu, out_private):
+        y1 = _C.conv_forward(x, w1, s1, b1, stride=stride, relu_mode=1)
+        y2 = _C.conv_forward(y1, w2, s2, b2, pad=1, relu_mode=1)
+        idn = x if wd is None else _C.conv_forward(x, wd, sd, bd, stride=stride)
+        out = _C.conv_forward(y2, w3, s3, b3, addend=idn, relu_mode=1)
+        ctx.stride, ctx.in_relu, ctx.out_private = stride, in_relu, out_private
+        ctx.save_for_backward(x, y1, y2, out, w1, w2, w3, wd, s1, s2, s3, sd)
+        return out
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, G):
+        x, y1, y2, out, w1, w2, w3, wd, s1, s2, s3, sd = ctx.saved_tensors
+        need_x, n1, n2, n3, nd = ctx.needs_input_grad[:5]
+        stride = ctx.stride
+        S3 = G.contiguous(memory_format=torch.channels_last) if ctx.out_private else \
+            _C.relu_bn_backward(G, out, None)[1]
+        dw1 = dw2 = dw3 = dwd = dx = None
+        if n3:
+            dw3 = _C.conv_wgrad(y2, S3, tuple(w3.shape), 1, 0, out_scale=s3)
+        S2 = _C.conv_forward(S3, _C.conv_weight_transpose(w3, s3), relu_mode=2, mask_ref=y2)
+        if n2:
+            dw2 = _C.conv_wgrad(y1, S2, tuple(w2.shape), 1, 1, out_scale=s2)
+        if n1 or need_x:
+            S1 = _C.conv_forward(S2, _C.conv_weight_transpose(w2, s2), pad=1, relu_mode=2, mask_ref=y1)
+        if n1:
+            dw1 = _C.conv_wgrad(x, S1, tuple(w1.shape), stride, 0, out_scale=s1)
+        if nd and wd is not None:
+            dwd = _C.conv_wgrad(x, S3, tuple(wd.shape), stride, 0, out_scale=sd)
+        if need_x:
+            gate = dict(relu_mode=2, mask_ref=x) if ctx.in_relu else {}
+            hw = tuple(x.shape[2:])
+            if wd is None:
+                dx = _C.conv_forward(S1, _C.conv_weight_transpose(w1, s1), addend=S3, **gate)
+            elif stride == 1:
+                t = _C.conv_forward(S3, _C.conv_weight_transpose(wd, sd))
+                dx = _C.conv_forward(S1, _C.conv_weight_transpose(w1, s1), addend=t, out=t, **gate)
+            else:  # both 1x1 stride-s data gradients scatter onto the same (s*h, s*w) lattice of a zero map
+                t = _C.conv_forward(S3, _C.conv_weight_transpose(wd, sd), out_spatial_stride=stride, out_hw=hw)
+                dx = _C.conv_forward(S1, _C.conv_weight_transpose(w1, s1), addend=t, out=t,
+                                     out_spatial_stride=stride, out_hw=hw, **gate)
+        return (dx, dw1, dw2, dw3, dwd) + (None,) * 11
+
+
 class Bottleneck(nn.Module):
     """1x1 (carries the stride when stride_in_1x1) -> 3x3 -> 1x1, FrozenBN after each, projection shortcut
     when the channel count changes (resnet.py:227-314)."""
@@ -60,7 +119,20 @@ class Bottleneck(nn.Module):
         for l in (self.conv1, self.conv2, self.conv3):
             nn.init.kaiming_uniform_(l.weight, a=1)
 
-    def forward(self, x):
+    def forward(self, x, in_relu=False, out_private=False):
+        """in_relu / out_private: structural promises made by _Stage (see _BottleneckFn); a direct call makes none"""
+        if self.conv2.stride[0] == 1:   # STRIDE_IN_1X1: the stride (if any) sits in conv1 and the shortcut
+            if x.shape[0] == 0:
+                return self._forward_per_conv(x)
+            wd = sd = bd = None
+            if self.downsample is not None:
+                wd, (sd, bd) = self.downsample[0].weight, self.downsample[1].folded()
+            return _BottleneckFn.apply(x, self.conv1.weight, self.conv2.weight, self.conv3.weight, wd,
+                                       *self.bn1.folded(), *self.bn2.folded(), *self.bn3.folded(), sd, bd,
+                                       self.conv1.stride[0], in_relu, out_private)
+        return self._forward_per_conv(x)
+
+    def _forward_per_conv(self, x):
         out = self.conv1(x, *self.bn1.folded(), relu=True)
         out = self.conv2(out, *self.bn2.folded(), relu=True)
         identity = x if self.downsample is None else self.downsample[0](x, *self.downsample[1].folded())
@@ -124,7 +196,20 @@ def _make_stage(block, in_channels, bottleneck_channels, out_channels, block_cou
                             dilation=dilation))
         stride = 1
         in_channels = out_channels
-    return nn.Sequential(*blocks)
+    return _Stage(*blocks)
+
+
+class _Stage(nn.Sequential):
+    """nn.Sequential of bottlenecks (same parameter names) that tells each block what its neighbours are: every
+    block but the first consumes a ReLU output, every block but the last feeds only its successor."""
+
+    input_is_relu = False   # set by the owner when the stage input is itself a ReLU output (ResNet.layer2..4)
+
+    def forward(self, x):
+        n = len(self)
+        for i, block in enumerate(self):
+            x = block(x, in_relu=(i > 0 or self.input_is_relu), out_private=(i < n - 1))
+        return x
 
 
 class ResNet(nn.Module):
@@ -147,6 +232,8 @@ class ResNet(nn.Module):
                                               spec.block_count, num_groups, cfg.MODEL.RESNETS.STRIDE_IN_1X1,
                                               first_stride=int(spec.index > 1) + 1))
             in_channels = out_channels
+            # layer1 consumes max-pooled ReLU output (frozen, no data gradient); layer2.. consume a block's ReLU
+            getattr(self, name).input_is_relu = spec.index > 1
             self.stages.append(name)
             self.return_features[name] = spec.return_features
         self._freeze_backbone(cfg.MODEL.BACKBONE.FREEZE_CONV_BODY_AT)
