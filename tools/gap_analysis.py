@@ -1,0 +1,36 @@
+#!/usr/bin/env python
+"""Idle gaps between consecutive kernels in a rocprofv3 kernel_trace.csv: where does the GPU wait for the host?
+usage: gap_analysis.py <kernel_trace.csv> [min_gap_us]"""
+import csv
+import sys
+from collections import defaultdict
+
+path = sys.argv[1]
+min_gap = float(sys.argv[2]) if len(sys.argv) > 2 else 20.0
+rows = []
+with open(path, newline="") as f:
+    for r in csv.DictReader(f):
+        rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"][:70]))
+rows.sort()
+busy = sum(e - s for s, e, _ in rows)
+span = rows[-1][1] - rows[0][0]
+print("kernels %d  busy %.1f ms  span %.1f ms  idle %.1f ms (%.1f%%)" % (len(rows), busy / 1e6, span / 1e6,
+                                                                       (span - busy) / 1e6, 100.0 * (span - busy) / span))
+gaps = defaultdict(lambda: [0, 0.0])
+hist = defaultdict(float)
+prev_end, prev_name = rows[0][1], rows[0][2]
+for s, e, name in rows[1:]:
+    g = (s - prev_end) / 1e3
+    if g > 0:
+        b = "<5us" if g < 5 else "<20us" if g < 20 else "<100us" if g < 100 else "<1ms" if g < 1000 else ">=1ms"
+        hist[b] += g
+    if g >= min_gap:
+        k = (prev_name, name)
+        gaps[k][0] += 1
+        gaps[k][1] += g
+    if e > prev_end:
+        prev_end, prev_name = e, name
+print("idle time by gap size (ms):", {k: round(v / 1e3, 2) for k, v in hist.items()})
+print("top gaps >= %.0f us (count, total ms, after -> before):" % min_gap)
+for (a, b), (n, t) in sorted(gaps.items(), key=lambda kv: -kv[1][1])[:40]:
+    print("%5d %8.2f  %s  ->  %s" % (n, t / 1e3, a, b))
