@@ -1,6 +1,6 @@
 #!/usr/bin/env python
 """Idle gaps between consecutive kernels in a rocprofv3 kernel_trace.csv: where does the GPU wait for the host?
-usage: gap_analysis.py <kernel_trace.csv> [min_gap_us]"""
+usage: gap_analysis.py <kernel_trace.csv> [min_gap_us] [last_n_steps]"""
 import csv
 import sys
 from collections import defaultdict
@@ -12,6 +12,12 @@ with open(path, newline="") as f:
     for r in csv.DictReader(f):
         rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"][:70]))
 rows.sort()
+steps = int(sys.argv[3]) if len(sys.argv) > 3 else 0
+if steps:  # steady-state window: from the end of the (steps+1)-th last optimizer kernel to the end of the last one
+    ends = [e for _, e, n in rows if "sgd_kernel" in n]
+    lo, hi = ends[-steps - 1], ends[-1]
+    rows = [r for r in rows if r[0] >= lo and r[1] <= hi]
+    print("window: last %d steps, %.2f ms/step" % (steps, (hi - lo) / 1e6 / steps))
 busy = sum(e - s for s, e, _ in rows)
 span = rows[-1][1] - rows[0][0]
 print("kernels %d  busy %.1f ms  span %.1f ms  idle %.1f ms (%.1f%%)" % (len(rows), busy / 1e6, span / 1e6,
