@@ -40,3 +40,28 @@ print("idle time by gap size (ms):", {k: round(v / 1e3, 2) for k, v in hist.item
 print("top gaps >= %.0f us (count, total ms, after -> before):" % min_gap)
 for (a, b), (n, t) in sorted(gaps.items(), key=lambda kv: -kv[1][1])[:40]:
     print("%5d %8.2f  %s  ->  %s" % (n, t / 1e3, a, b))
+
+# ---- runs of small (library) kernels between this repo's kernels, last step only
+if steps:
+    ends = [e for _, e, n in rows if "sgd_kernel" in n]
+    lo = ends[-2] if len(ends) > 1 else rows[0][0]
+    last = [r for r in rows if r[0] >= lo]
+    print("\nlast step: runs of library kernels between dadet:: kernels (n >= 8): n, wall us (incl. gaps), busy us, after-kernel")
+    run_n, run_start, run_busy, prev = 0, None, 0.0, "step start"
+    prev_end = last[0][0]
+    tot_n = tot_wall = 0
+    for s, e, name in last:
+        if "dadet::" in name:
+            if run_n >= 8:
+                print("%5d %9.1f %9.1f   after %s  -> before %s" % (run_n, (s - run_start) / 1e3, run_busy / 1e3, prev[:48], name[:48]))
+            if run_n:
+                tot_n += run_n
+                tot_wall += (s - run_start) / 1e3
+            run_n, run_busy, prev, run_start = 0, 0.0, name, None
+            prev_end = e
+        else:
+            if run_n == 0:
+                run_start = prev_end
+            run_n += 1
+            run_busy += e - s
+    print("library kernels in the step: %d, wall %.2f ms (incl. their gaps)" % (tot_n, tot_wall / 1e3))
