@@ -5,12 +5,13 @@ from torch import nn
 from torch.nn import functional as F
 
 from ...layers import consistency_loss
+from ...structures.bounding_box import is_source_image
 from .fused import triplet_margin_loss_w
 
 
 def image_domain_labels(targets):
     """float [N]: 1 for source-domain images, 0 for target-domain images (loss.py:46-53 `prepare_masks`)"""
-    vals = [1.0 if bool(t.get_field("is_source").any()) else 0.0 for t in targets]
+    vals = [1.0 if is_source_image(t) else 0.0 for t in targets]
     return torch.tensor(vals, dtype=torch.float32, device=targets[0].bbox.device)
 
 

@@ -30,6 +30,9 @@ class GeneralizedRCNN(nn.Module):
         if self.training and targets is None:
             raise ValueError("In training mode, targets should be passed")
         images = to_image_list(images)
+        if self.training and images.tensors.is_cuda:
+            # lets the RPN prepare its loss targets on a side stream without waiting for the backbone
+            self.rpn.inputs_ready = torch.cuda.current_stream(images.tensors.device).record_event()
         features = self.backbone(images.tensors)
         proposals, proposal_losses = self.rpn(images, features, targets)
         da_losses, detector_losses = {}, {}

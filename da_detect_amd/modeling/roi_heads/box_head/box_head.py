@@ -28,13 +28,15 @@ class ROIBoxHead(torch.nn.Module):
         if self.training:
             with torch.no_grad():
                 proposals = self.loss_evaluator.subsample(proposals, targets)
+                # the reference draws the DA ROI sample after the detection losses (box_head.py:102-104); nothing
+                # between the two draws from the random stream, so drawing it here is the same sample — and it keeps
+                # every host synchronisation of the box head in front of the res5 head instead of behind it
+                da_proposals = self.loss_evaluator.subsample_for_da(proposals, targets)
         x = self.feature_extractor(features, proposals)
         class_logits, box_regression = self.predictor(x)
         if not self.training:
             return x, self.post_processor((class_logits, box_regression), proposals), {}, x, None
         loss_classifier, loss_box_reg, _ = self.loss_evaluator([class_logits], [box_regression])
-        with torch.no_grad():
-            da_proposals = self.loss_evaluator.subsample_for_da(proposals, targets)
         # The reference samples the DA ROIs FROM THE ALREADY SUBSAMPLED `proposals` (box_head.py:50-104: the name
         # is rebound by subsample()).  With every label forced to 0 the sampler takes min(n, BATCH_SIZE_PER_IMAGE)
         # "negatives"; n <= BATCH_SIZE_PER_IMAGE here, so it takes ALL of them, in ascending index order: the DA

@@ -4,6 +4,7 @@ import torch
 from torch.nn import functional as F
 
 from ....layers import smooth_l1_loss
+from ....structures.bounding_box import is_source_image
 from ....structures.boxlist_ops import boxlist_iou
 from ...balanced_positive_negative_sampler import BalancedPositiveNegativeSampler
 from ...box_coder import BoxCoder
@@ -30,7 +31,7 @@ class FastRCNNLossComputation(object):
     def prepare_targets(self, proposals, targets, sample_for_da=False):
         labels, regression_targets, domain_labels = [], [], []
         for proposals_per_image, targets_per_image in zip(proposals, targets):
-            is_source = bool(targets_per_image.get_field("is_source").any())
+            is_source = is_source_image(targets_per_image)
             matched = self.match_targets_to_proposals(proposals_per_image, targets_per_image, is_source)
             matched_idxs = matched.get_field("matched_idxs")
             lab = matched.get_field("labels").to(dtype=torch.int64)
@@ -60,7 +61,28 @@ class FastRCNNLossComputation(object):
             prop.add_field("regression_targets", reg)
             prop.add_field("domain_labels", dom)
         self._proposals = self._take_sampled(proposals, pos_masks, neg_masks)
+        self._prepare_loss_indices()
         return self._proposals
+
+    def _prepare_loss_indices(self):
+        """index tensors of __call__ (source-domain rows, their positives, the per-class regression columns) depend
+        on the sampled proposals only: they are built here, where the host synchronises anyway, so that the loss
+        itself — issued behind the res5 head — needs no device->host round trip (loss.py:186-213)"""
+        proposals = self._proposals
+        labels = cat([p.get_field("labels") for p in proposals], dim=0)
+        regression_targets = cat([p.get_field("regression_targets") for p in proposals], dim=0)
+        domain_masks = cat([p.get_field("domain_labels") for p in proposals], dim=0)
+        src = torch.nonzero(domain_masks).squeeze(1)
+        labels_src = labels[src]
+        pos = torch.nonzero(labels_src > 0).squeeze(1)
+        labels_pos = labels_src[pos]
+        if self.cls_agnostic_bbox_reg:
+            map_inds = torch.tensor([4, 5, 6, 7], device=labels.device)
+        else:
+            map_inds = 4 * labels_pos[:, None] + torch.tensor([0, 1, 2, 3], device=labels.device)
+        self._loss_prep = dict(domain_masks=domain_masks, src=src, labels_src=labels_src,
+                               rows_pos=src[pos][:, None], map_inds=map_inds,
+                               regression_targets_pos=regression_targets[src][pos])
 
     def subsample_for_da(self, proposals, targets):
         """uniformly sampled proposals (all labels forced to 0) for the instance-level domain classifier
@@ -77,28 +99,15 @@ class FastRCNNLossComputation(object):
         losses (loss.py:165-221)"""
         class_logits = cat(class_logits, dim=0)
         box_regression = cat(box_regression, dim=0)
-        device = class_logits.device
         if not hasattr(self, "_proposals"):
             raise RuntimeError("subsample needs to be called before")
-        proposals = self._proposals
-        labels = cat([p.get_field("labels") for p in proposals], dim=0)
-        regression_targets = cat([p.get_field("regression_targets") for p in proposals], dim=0)
-        domain_masks = cat([p.get_field("domain_labels") for p in proposals], dim=0)
-        class_logits = class_logits[domain_masks, :]
-        box_regression = box_regression[domain_masks, :]
-        labels = labels[domain_masks]
-        regression_targets = regression_targets[domain_masks, :]
-        classification_loss = F.cross_entropy(class_logits, labels)
-        pos = torch.nonzero(labels > 0).squeeze(1)
-        labels_pos = labels[pos]
-        if self.cls_agnostic_bbox_reg:
-            map_inds = torch.tensor([4, 5, 6, 7], device=device)
-        else:
-            map_inds = 4 * labels_pos[:, None] + torch.tensor([0, 1, 2, 3], device=device)
-        box_loss = smooth_l1_loss(box_regression[pos[:, None], map_inds], regression_targets[pos],
+        prep = self._loss_prep
+        labels = prep["labels_src"]
+        classification_loss = F.cross_entropy(class_logits.index_select(0, prep["src"]), labels)
+        box_loss = smooth_l1_loss(box_regression[prep["rows_pos"], prep["map_inds"]], prep["regression_targets_pos"],
                                   size_average=False, beta=1)
         box_loss = box_loss / labels.numel()
-        return classification_loss, box_loss, domain_masks
+        return classification_loss, box_loss, prep["domain_masks"]
 
 
 def make_roi_box_loss_evaluator(cfg):

@@ -69,6 +69,8 @@ class AnchorGenerator(nn.Module):
         self.strides = anchor_strides
         self.cell_anchors = BufferList(cell_anchors)
         self.straddle_thresh = straddle_thresh
+        self._cache = {}
+        self.last_call_was_cached = False
 
     def num_anchors_per_location(self):
         return [len(c) for c in self.cell_anchors]
@@ -97,15 +99,32 @@ class AnchorGenerator(nn.Module):
         boxlist.add_field("visibility", inside)
 
     def forward(self, image_list, feature_maps):
-        per_level = self.grid_anchors([fm.shape[-2:] for fm in feature_maps])
+        """anchors depend on the image / feature-map sizes only: the tensors are built once per size signature and
+        re-wrapped in fresh BoxLists afterwards (training batches of one crop size hit the cache every step)."""
+        grid_sizes = [tuple(fm.shape[-2:]) for fm in feature_maps]
+        key = (tuple(tuple(s) for s in image_list.image_sizes), tuple(grid_sizes), str(self.cell_anchors[0].device))
+        self.last_call_was_cached = key in self._cache
+        if not self.last_call_was_cached:
+            per_level = self.grid_anchors(grid_sizes)
+            entry = []
+            for (ih, iw) in image_list.image_sizes:
+                in_image = []
+                for a in per_level:
+                    bl = BoxList(a, (iw, ih), mode="xyxy")
+                    self.add_visibility_to(bl)
+                    in_image.append((a, (iw, ih), bl.get_field("visibility")))
+                entry.append(in_image)
+            if len(self._cache) >= 8:
+                self._cache.clear()
+            self._cache[key] = entry
         anchors = []
-        for (ih, iw) in image_list.image_sizes:
-            in_image = []
-            for a in per_level:
-                bl = BoxList(a, (iw, ih), mode="xyxy")
-                self.add_visibility_to(bl)
-                in_image.append(bl)
-            anchors.append(in_image)
+        for in_image in self._cache[key]:
+            row = []
+            for a, size, vis in in_image:
+                bl = BoxList(a, size, mode="xyxy")
+                bl.add_field("visibility", vis)
+                row.append(bl)
+            anchors.append(row)
         return anchors
 
 

@@ -13,7 +13,7 @@ reference's.
 import torch
 
 from ... import _C
-from ...structures.bounding_box import BoxList
+from ...structures.bounding_box import BoxList, is_source_image
 from ...structures.boxlist_ops import cat_boxlist
 from ..box_coder import BoxCoder
 from .utils import permute_and_flatten
@@ -35,7 +35,7 @@ class RPNPostProcessor(torch.nn.Module):
         device = proposals[0].bbox.device
         out = []
         for proposal, target in zip(proposals, targets):
-            if target.get_field("is_source").any():
+            if is_source_image(target):
                 gt = target.copy_with_fields([])
                 gt.add_field("objectness", torch.ones(len(gt), device=device))
                 out.append(cat_boxlist((proposal, gt)))

@@ -7,6 +7,7 @@ import torch
 from torch.nn import functional as F
 
 from ...layers import smooth_l1_loss
+from ...structures.bounding_box import is_source_image
 from ...structures.boxlist_ops import boxlist_iou, cat_boxlist
 from ..balanced_positive_negative_sampler import BalancedPositiveNegativeSampler
 from ..matcher import Matcher
@@ -33,7 +34,7 @@ class RPNLossComputation(object):
         labels, regression_targets, masks = [], [], []
         seen_target_domain = False
         for anchors_per_image, targets_per_image in zip(anchors, targets):
-            is_source = bool(targets_per_image.get_field("is_source").any())
+            is_source = is_source_image(targets_per_image)
             masks.append(is_source)
             if not is_source:
                 seen_target_domain = True
@@ -51,21 +52,34 @@ class RPNLossComputation(object):
             regression_targets.append(self.box_coder.encode(matched.bbox, anchors_per_image.bbox))
         return labels, regression_targets, masks
 
-    def __call__(self, anchors, objectness, box_regression, targets):
+    def prepare(self, anchors, targets):
+        """everything of the loss that depends on anchors and ground truth only (labels, regression targets, the
+        sampled anchor indices — loss.py:101-123): none of it needs the network's output, so RPNModule issues it
+        on a side stream while the backbone is still running; its host synchronisations (nonzero) then wait for
+        that stream alone."""
         anchors = [cat_boxlist(a) for a in anchors]
         labels, regression_targets, _ = self.prepare_targets(anchors, targets)
         pos_masks, neg_masks = self.fg_bg_sampler(labels)
         pos_inds = torch.nonzero(torch.cat(pos_masks, dim=0)).squeeze(1)
         neg_inds = torch.nonzero(torch.cat(neg_masks, dim=0)).squeeze(1)
         sampled_inds = torch.cat([pos_inds, neg_inds], dim=0)
-        objectness, box_regression = concat_box_prediction_layers(objectness, box_regression)
-        objectness = objectness.squeeze()
         labels = torch.cat(labels, dim=0)
         regression_targets = torch.cat(regression_targets, dim=0)
-        box_loss = smooth_l1_loss(box_regression[pos_inds], regression_targets[pos_inds], beta=1.0 / 9,
+        return dict(pos_inds=pos_inds, sampled_inds=sampled_inds, labels_sampled=labels[sampled_inds],
+                    regression_targets_pos=regression_targets[pos_inds])
+
+    def finish(self, objectness, box_regression, prep):
+        """the part that needs the predictions (loss.py:125-143); no host synchronisation"""
+        objectness, box_regression = concat_box_prediction_layers(objectness, box_regression)
+        objectness = objectness.squeeze()
+        pos_inds, sampled_inds = prep["pos_inds"], prep["sampled_inds"]
+        box_loss = smooth_l1_loss(box_regression[pos_inds], prep["regression_targets_pos"], beta=1.0 / 9,
                                   size_average=False) / (sampled_inds.numel())
-        objectness_loss = F.binary_cross_entropy_with_logits(objectness[sampled_inds], labels[sampled_inds])
+        objectness_loss = F.binary_cross_entropy_with_logits(objectness[sampled_inds], prep["labels_sampled"])
         return objectness_loss, box_loss
+
+    def __call__(self, anchors, objectness, box_regression, targets):
+        return self.finish(objectness, box_regression, self.prepare(anchors, targets))
 
 
 def generate_rpn_labels(matched_targets):

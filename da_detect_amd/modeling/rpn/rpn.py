@@ -49,6 +49,8 @@ class RPNModule(torch.nn.Module):
         self.box_selector_train = make_rpn_postprocessor(cfg, rpn_box_coder, is_train=True)
         self.box_selector_test = make_rpn_postprocessor(cfg, rpn_box_coder, is_train=False)
         self.loss_evaluator = make_rpn_loss_evaluator(cfg, rpn_box_coder)
+        self._side_stream = None
+        self.inputs_ready = None     # event recorded by the detector before the backbone is queued
 
     def forward(self, images, features, targets=None):
         objectness, rpn_box_regression = self.head(features)
@@ -57,13 +59,40 @@ class RPNModule(torch.nn.Module):
             return self._forward_train(anchors, objectness, rpn_box_regression, targets)
         return self._forward_test(anchors, objectness, rpn_box_regression)
 
+    def _prepare_loss_targets(self, anchors, targets):
+        """RPNLossComputation.prepare on a side stream: its ~150 small launches and host synchronisations overlap
+        the backbone instead of stalling behind it (program order — hence the order of the random draws — is
+        unchanged: it still runs before the box head's sampler)."""
+        dev = anchors[0][0].bbox.device
+        if dev.type != "cuda":
+            with torch.no_grad():
+                return self.loss_evaluator.prepare(anchors, targets)
+        main = torch.cuda.current_stream(dev)
+        if self._side_stream is None:
+            self._side_stream = torch.cuda.Stream(dev)
+        side = self._side_stream
+        fresh = getattr(self.anchor_generator, "last_call_was_cached", False) is False
+        ready = self.inputs_ready
+        self.inputs_ready = None
+        if ready is not None and not fresh:
+            side.wait_event(ready)        # ground truth / cached anchors exist since before the backbone was queued
+        else:
+            side.wait_stream(main)        # first step: anchors were just built on the main stream
+        with torch.cuda.stream(side), torch.no_grad():
+            prep = self.loss_evaluator.prepare(anchors, targets)
+        for t in prep.values():
+            t.record_stream(main)
+        main.wait_stream(side)
+        return prep
+
     def _forward_train(self, anchors, objectness, rpn_box_regression, targets):
+        prep = self._prepare_loss_targets(anchors, targets)
         if self.cfg.MODEL.RPN_ONLY:
             boxes = anchors
         else:
             with torch.no_grad():
                 boxes = self.box_selector_train(anchors, objectness, rpn_box_regression, targets)
-        loss_objectness, loss_rpn_box_reg = self.loss_evaluator(anchors, objectness, rpn_box_regression, targets)
+        loss_objectness, loss_rpn_box_reg = self.loss_evaluator.finish(objectness, rpn_box_regression, prep)
         return boxes, {"loss_objectness": loss_objectness, "loss_rpn_box_reg": loss_rpn_box_reg}
 
     def _forward_test(self, anchors, objectness, rpn_box_regression):

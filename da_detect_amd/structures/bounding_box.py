@@ -148,3 +148,15 @@ class BoxList(object):
     def __repr__(self):
         return "BoxList(num_boxes={}, image_width={}, image_height={}, mode={})".format(
             len(self), self.size[0], self.size[1], self.mode)
+
+
+def is_source_image(target):
+    """True when the image's ground truth comes from the source domain (`is_source` field, any element set).
+    The answer is read back from the device ONCE per BoxList and kept on the object: the training path asks for
+    it in several places per step (rpn/loss.py:66, rpn/inference.py:64, box_head/loss.py:80, da_heads/loss.py:85
+    of the reference each synchronise on it)."""
+    flag = getattr(target, "_is_source_host", None)
+    if flag is None:
+        flag = bool(target.get_field("is_source").any())
+        target._is_source_host = flag
+    return flag
