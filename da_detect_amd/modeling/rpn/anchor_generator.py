@@ -102,7 +102,7 @@ class AnchorGenerator(nn.Module):
         """anchors depend on the image / feature-map sizes only: the tensors are built once per size signature and
         re-wrapped in fresh BoxLists afterwards (training batches of one crop size hit the cache every step)."""
         grid_sizes = [tuple(fm.shape[-2:]) for fm in feature_maps]
-        key = (tuple(tuple(s) for s in image_list.image_sizes), tuple(grid_sizes), str(self.cell_anchors[0].device))
+        key = (tuple(tuple(s) for s in image_list.image_sizes), tuple(grid_sizes), str(next(iter(self.cell_anchors)).device))
         self.last_call_was_cached = key in self._cache
         if not self.last_call_was_cached:
             per_level = self.grid_anchors(grid_sizes)
