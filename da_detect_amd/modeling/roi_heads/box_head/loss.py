@@ -32,6 +32,16 @@ class FastRCNNLossComputation(object):
         labels, regression_targets, domain_labels = [], [], []
         for proposals_per_image, targets_per_image in zip(proposals, targets):
             is_source = is_source_image(targets_per_image)
+            if not is_source or sample_for_da:
+                # every label is overwritten with 0 below (loss.py:85-88) and the regression targets of these rows
+                # never reach a loss (target-domain rows are masked out, loss.py:193-198; subsample_for_da drops
+                # them, loss.py:143): the IoU / matcher / encode work of the reference is dead here and skipped.
+                # The sampler still sees an all-zero label vector, i.e. draws the same permutations.
+                n, dev = len(proposals_per_image), proposals_per_image.bbox.device
+                labels.append(torch.zeros(n, dtype=torch.int64, device=dev))
+                regression_targets.append(torch.zeros((n, 4), dtype=torch.float32, device=dev))
+                domain_labels.append(torch.full((n,), bool(is_source), dtype=torch.bool, device=dev))
+                continue
             matched = self.match_targets_to_proposals(proposals_per_image, targets_per_image, is_source)
             matched_idxs = matched.get_field("matched_idxs")
             lab = matched.get_field("labels").to(dtype=torch.int64)
