@@ -112,6 +112,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
+    ap.add_argument("--no-overlap", action="store_true", help="keep the RPN backward inside the main backward pass")
     ap.add_argument("--gemm-mode", type=int, default=int(os.environ.get("DADET_GEMM_MODE", "3")),
                     help="3: fp32 operands as 3 bf16 terms, 6 bf16 MFMAs per K=16 (fp32-class accuracy, default); "
                          "0: exact fp32 MFMA; 2: 2-term split (~2^-16 products)")
@@ -131,10 +132,11 @@ def main():
 
     from da_detect_amd import _C
     from da_detect_amd.data.synthetic import make_batch
-    from da_detect_amd.engine.trainer import train_step
+    from da_detect_amd.engine.trainer import enable_overlapped_rpn_backward, train_step
 
     _C.set_gemm_mode(args.gemm_mode)
     c, model, opt, reducer = build(YAML, device, seed=100)
+    enable_overlapped_rpn_backward(model, not args.no_overlap)
     images, targets = make_batch(c, IMAGES_PER_GPU, HEIGHT, WIDTH, seed=100 + rank, device=device)
 
     def barrier():

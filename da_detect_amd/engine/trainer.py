@@ -26,11 +26,21 @@ def reduce_loss_dict(loss_dict):
         return {k: v for k, v in zip(names, vals)}
 
 
+def enable_overlapped_rpn_backward(model, flag=True):
+    """opt the model into RPNModule.early_backward (see its docstring); only valid with train_step's schedule"""
+    rpn = getattr(model, "rpn", None)
+    if rpn is not None and getattr(model, "roi_heads", None):
+        rpn.early_backward = bool(flag)
+    return model
+
+
 def train_step(model, optimizer, images, targets, scheduler=None, iteration=0):
-    """one optimizer step; returns the (un-synchronised) loss dict"""
+    """one optimizer step; returns the (un-synchronised) loss dict.  Gradients are cleared BEFORE the forward pass
+    (the reference clears them after it, trainer.py:237 — equivalent) so that a model opted into
+    enable_overlapped_rpn_backward may start accumulating during its forward."""
+    optimizer.zero_grad()
     loss_dict = model(images, targets)
     losses = sum(loss for loss in loss_dict.values())
-    optimizer.zero_grad()
     losses.backward()
     optimizer.step()
     if scheduler is not None and hasattr(scheduler, "step_update"):
@@ -43,6 +53,7 @@ def do_da_train(model, source_data_loader, target_data_loader, optimizer, schedu
     """joint iteration over the source / target (/ auxiliary) loaders (trainer.py:150-336).  Each loader yields
     (ImageList, list[BoxList], ids); batches are concatenated source-first exactly as trainer.py:215-224."""
     model.train()
+    enable_overlapped_rpn_backward(model)
     start_iter = arguments.get("iteration", 0)
     loaders = [source_data_loader, target_data_loader] + ([negative_data_loader] if negative_data_loader else [])
     max_iter = len(source_data_loader)

@@ -35,6 +35,8 @@ class GeneralizedRCNN(nn.Module):
             self.rpn.inputs_ready = torch.cuda.current_stream(images.tensors.device).record_event()
         features = self.backbone(images.tensors)
         proposals, proposal_losses = self.rpn(images, features, targets)
+        if self.training:
+            features = self.rpn.bridge_features(features)
         da_losses, detector_losses = {}, {}
         if self.roi_heads:
             if self.training and self.da_heads_triplet:

@@ -35,7 +35,32 @@ class RPNHead(nn.Module):
         return logits, bbox_reg
 
 
+class _InjectGrad(torch.autograd.Function):
+    """identity whose backward adds a gradient computed earlier (the RPN branch's, see RPNModule.early_backward)"""
+
+    @staticmethod
+    def forward(ctx, x, g):
+        ctx.save_for_backward(g)
+        return x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        (g,) = ctx.saved_tensors
+        return grad_out + g, None
+
+
 class RPNModule(torch.nn.Module):
+    """early_backward (opt-in, set by engine.trainer.train_step's schedule): the RPN branch is cut out of the main
+    autograd graph and its backward (RPN head dgrad / wgrad, ~4 ms of MFMA work at 1024x2048) is queued as soon as
+    the RPN losses exist — i.e. right in front of the box head's proposal sampling, a stretch of a few hundred
+    tiny launches and host synchronisations during which the GPU would otherwise idle.  The gradient w.r.t. the
+    feature maps is handed back to the main graph through `bridge_features`, so parameter gradients are the same
+    sums as without the option.  Requirements on the caller: gradients are zeroed BEFORE the forward pass, the RPN
+    losses enter the total loss with weight 1, and something downstream (the box head) back-propagates into the
+    features."""
+
+    early_backward = False
+
     def __init__(self, cfg):
         super(RPNModule, self).__init__()
         self.cfg = cfg.clone()
@@ -50,14 +75,31 @@ class RPNModule(torch.nn.Module):
         self.box_selector_test = make_rpn_postprocessor(cfg, rpn_box_coder, is_train=False)
         self.loss_evaluator = make_rpn_loss_evaluator(cfg, rpn_box_coder)
         self._side_stream = None
+        self._feature_grads = None
         self.inputs_ready = None     # event recorded by the detector before the backbone is queued
 
     def forward(self, images, features, targets=None):
-        objectness, rpn_box_regression = self.head(features)
+        self._feature_grads = None
+        early = (self.training and self.early_backward and torch.is_grad_enabled() and not self.cfg.MODEL.RPN_ONLY
+                 and all(f.requires_grad for f in features))
+        head_in = [f.detach().requires_grad_(True) for f in features] if early else features
+        objectness, rpn_box_regression = self.head(head_in)
         anchors = self.anchor_generator(images, features)
-        if self.training:
-            return self._forward_train(anchors, objectness, rpn_box_regression, targets)
-        return self._forward_test(anchors, objectness, rpn_box_regression)
+        if not self.training:
+            return self._forward_test(anchors, objectness, rpn_box_regression)
+        boxes, losses = self._forward_train(anchors, objectness, rpn_box_regression, targets)
+        if early:
+            torch.autograd.backward([losses["loss_objectness"] + losses["loss_rpn_box_reg"]])
+            self._feature_grads = [f.grad for f in head_in]
+            losses = {k: v.detach() for k, v in losses.items()}
+        return boxes, losses
+
+    def bridge_features(self, features):
+        """features whose backward also delivers the RPN branch's gradient (no-op unless early_backward ran)"""
+        grads, self._feature_grads = self._feature_grads, None
+        if grads is None:
+            return features
+        return [_InjectGrad.apply(f, g) for f, g in zip(features, grads)]
 
     def _prepare_loss_targets(self, anchors, targets):
         """RPNLossComputation.prepare on a side stream: its ~150 small launches and host synchronisations overlap

@@ -388,3 +388,34 @@ def test_fpn_training_step_runs_and_grads_flow(device):
             # output convs of the two coarsest levels may legitimately see a zero gradient
             if "fpn_layer3" not in name and "fpn_layer4" not in name:
                 assert p.grad.abs().sum() > 0, name
+
+
+def test_overlapped_rpn_backward_gives_the_same_gradients(device):
+    """RPNModule.early_backward queues the RPN branch's backward during the forward pass and bridges its feature
+    gradient back into the main graph: every parameter gradient must equal the single-pass one (same sums, the
+    feature-gradient additions merely associate differently)."""
+    from da_detect_amd.data.synthetic import make_batch
+    from da_detect_amd.engine.trainer import enable_overlapped_rpn_backward
+    from da_detect_amd.utils import rng
+
+    z, c, model, sd = _build("da_plain", device)
+    images, targets = make_batch(c, int(z["nimg"]), int(z["H"]), int(z["W"]), seed=int(z["seed"]), device=device)
+    grads = []
+    for early in (False, True):
+        enable_overlapped_rpn_backward(model, early)
+        model.zero_grad(set_to_none=True)
+        rng.use_cpu_stream(True)
+        try:
+            torch.manual_seed(3)
+            losses = model(images, targets)
+            if early:
+                assert not losses["loss_objectness"].requires_grad and losses["loss_classifier"].requires_grad
+            sum(losses.values()).backward()
+        finally:
+            rng.use_cpu_stream(False)
+        grads.append({n: p.grad.clone() for n, p in model.named_parameters() if p.grad is not None})
+    enable_overlapped_rpn_backward(model, False)
+    assert set(grads[0]) == set(grads[1]) and any(n.startswith("rpn.head") for n in grads[0])
+    for n in grads[0]:
+        a, b = grads[0][n], grads[1][n]
+        assert float((a - b).norm()) <= 1e-5 * float(a.norm()) + 1e-10, n
