@@ -37,6 +37,8 @@ class GeneralizedRCNN(nn.Module):
         proposals, proposal_losses = self.rpn(images, features, targets)
         if self.training:
             features = self.rpn.bridge_features(features)
+            if self.roi_heads:
+                self.roi_heads.box.proposals_ready, self.rpn.proposals_ready = self.rpn.proposals_ready, None
         da_losses, detector_losses = {}, {}
         if self.roi_heads:
             if self.training and self.da_heads_triplet:

@@ -4,6 +4,7 @@ import os
 
 import torch
 
+from ....utils.streams import side_section
 from .inference import make_roi_box_post_processor
 from .loss import make_roi_box_loss_evaluator
 from .roi_box_feature_extractors import make_roi_box_feature_extractor
@@ -20,18 +21,23 @@ class ROIBoxHead(torch.nn.Module):
         self.predictor = make_roi_box_predictor(cfg)
         self.post_processor = make_roi_box_post_processor(cfg)
         self.loss_evaluator = make_roi_box_loss_evaluator(cfg)
+        self.proposals_ready = None   # optional event of the compute stream: the proposals passed to forward exist
 
     def forward(self, features, proposals, targets=None):
         """-> (x, proposals | detections, losses, da_ins_feas, da_ins_labels).  Training runs two passes of
         pooler + res5 + predictor: the sampled detection ROIs, then BATCH_SIZE_PER_IMAGE uniformly sampled
         ROIs per image whose features / domain labels feed the instance-level domain classifier."""
         if self.training:
-            with torch.no_grad():
+            # sampling runs on the side stream: its host round trips then do not wait for the RPN-head backward
+            # queued on the compute stream just before (RPNModule.early_backward)
+            after, self.proposals_ready = self.proposals_ready, None
+            with side_section(proposals[0].bbox.device, after=after) as done, torch.no_grad():
                 proposals = self.loss_evaluator.subsample(proposals, targets)
                 # the reference draws the DA ROI sample after the detection losses (box_head.py:102-104); nothing
                 # between the two draws from the random stream, so drawing it here is the same sample — and it keeps
                 # every host synchronisation of the box head in front of the res5 head instead of behind it
                 da_proposals = self.loss_evaluator.subsample_for_da(proposals, targets)
+                done(proposals, da_proposals, self.loss_evaluator._proposals, self.loss_evaluator._loss_prep)
         x = self.feature_extractor(features, proposals)
         class_logits, box_regression = self.predictor(x)
         if not self.training:

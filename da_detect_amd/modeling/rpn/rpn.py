@@ -8,6 +8,7 @@ from ..box_coder import BoxCoder
 from .anchor_generator import make_anchor_generator
 from .inference import make_rpn_postprocessor
 from .loss import make_rpn_loss_evaluator
+from ...utils.streams import side_section
 
 
 @registry.RPN_HEADS.register("SingleConvRPNHead")
@@ -74,7 +75,7 @@ class RPNModule(torch.nn.Module):
         self.box_selector_train = make_rpn_postprocessor(cfg, rpn_box_coder, is_train=True)
         self.box_selector_test = make_rpn_postprocessor(cfg, rpn_box_coder, is_train=False)
         self.loss_evaluator = make_rpn_loss_evaluator(cfg, rpn_box_coder)
-        self._side_stream = None
+        self.proposals_ready = None  # event: proposals exist (recorded before the RPN losses / early backward)
         self._feature_grads = None
         self.inputs_ready = None     # event recorded by the detector before the backbone is queued
 
@@ -106,25 +107,12 @@ class RPNModule(torch.nn.Module):
         the backbone instead of stalling behind it (program order — hence the order of the random draws — is
         unchanged: it still runs before the box head's sampler)."""
         dev = anchors[0][0].bbox.device
-        if dev.type != "cuda":
-            with torch.no_grad():
-                return self.loss_evaluator.prepare(anchors, targets)
-        main = torch.cuda.current_stream(dev)
-        if self._side_stream is None:
-            self._side_stream = torch.cuda.Stream(dev)
-        side = self._side_stream
-        fresh = getattr(self.anchor_generator, "last_call_was_cached", False) is False
-        ready = self.inputs_ready
-        self.inputs_ready = None
-        if ready is not None and not fresh:
-            side.wait_event(ready)        # ground truth / cached anchors exist since before the backbone was queued
-        else:
-            side.wait_stream(main)        # first step: anchors were just built on the main stream
-        with torch.cuda.stream(side), torch.no_grad():
+        ready, self.inputs_ready = self.inputs_ready, None
+        if not self.anchor_generator.last_call_was_cached:
+            ready = None                  # first step: the anchors were just built on the compute stream
+        with side_section(dev, after=ready) as done, torch.no_grad():
             prep = self.loss_evaluator.prepare(anchors, targets)
-        for t in prep.values():
-            t.record_stream(main)
-        main.wait_stream(side)
+            done(prep)
         return prep
 
     def _forward_train(self, anchors, objectness, rpn_box_regression, targets):
@@ -134,6 +122,8 @@ class RPNModule(torch.nn.Module):
         else:
             with torch.no_grad():
                 boxes = self.box_selector_train(anchors, objectness, rpn_box_regression, targets)
+            if boxes[0].bbox.is_cuda:     # the box head's sampling (side stream) may start from here
+                self.proposals_ready = torch.cuda.current_stream(boxes[0].bbox.device).record_event()
         loss_objectness, loss_rpn_box_reg = self.loss_evaluator.finish(objectness, rpn_box_regression, prep)
         return boxes, {"loss_objectness": loss_objectness, "loss_rpn_box_reg": loss_rpn_box_reg}
 

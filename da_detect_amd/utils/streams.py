@@ -1,0 +1,57 @@
+"""Side-stream sections for the host-synchronising bookkeeping of the training step.
+
+Target assignment and proposal sampling (reference: rpn/loss.py:57-123, box_head/loss.py:55-163) are a few hundred
+tiny launches with device->host round trips (nonzero, randperm sizes) in between.  On the compute stream every one of
+those round trips waits for ALL queued work — backbone, RPN-head backward — and the GPU then idles while the host
+issues the next tiny launch.  Issued on a side stream they wait for that stream alone, so the compute stream keeps
+executing the large kernels queued in front of them.  Ordering is explicit: the section starts after an event of
+the compute stream (its inputs exist), the compute stream waits for the section's end before it continues, and
+every tensor handed across is registered with the caching allocator (record_stream)."""
+import contextlib
+
+import torch
+
+_SIDE = {}
+
+
+def side_stream(device):
+    key = (device.type, device.index)
+    if key not in _SIDE:
+        _SIDE[key] = torch.cuda.Stream(device)
+    return _SIDE[key]
+
+
+def record(obj, stream):
+    """register every tensor reachable from obj (tensor / BoxList / dict / list) as used on `stream`"""
+    if isinstance(obj, torch.Tensor):
+        if obj.is_cuda:
+            obj.record_stream(stream)
+    elif isinstance(obj, dict):
+        for v in obj.values():
+            record(v, stream)
+    elif isinstance(obj, (list, tuple)):
+        for v in obj:
+            record(v, stream)
+    elif hasattr(obj, "bbox") and hasattr(obj, "extra_fields"):
+        record(obj.bbox, stream)
+        record(obj.extra_fields, stream)
+
+
+@contextlib.contextmanager
+def side_section(device, after=None):
+    """with side_section(dev, after=event) as done: ... ; done(outputs) registers the hand-over.  On a CPU device it
+    is a no-op.  `after`: event of the compute stream the section must wait for (None: everything queued so far)."""
+    if device.type != "cuda":
+        yield lambda *outs: None
+        return
+    main = torch.cuda.current_stream(device)
+    side = side_stream(device)
+    if after is not None:
+        side.wait_event(after)
+    else:
+        side.wait_stream(main)
+    handed = []
+    with torch.cuda.stream(side):
+        yield lambda *outs: handed.extend(outs)
+    record(handed, main)
+    main.wait_stream(side)
