@@ -169,18 +169,25 @@ __global__ __launch_bounds__(1024) void nms_sweep_kernel(const unsigned long lon
       unsigned long long diag = 0;
       if (box < n) diag = mask[(size_t)box * col_blocks + c];
       const unsigned lo = (unsigned)diag, hi = (unsigned)(diag >> 32);
-      unsigned long long rem = s_removed_c;
-      unsigned long long keep = 0;
+      // the whole resolution is wavefront-uniform: keep it on the scalar unit (SGPR state, v_readlane of the
+      // diagonal rows) and visit only the boxes that are still alive instead of all 64 positions
+      const unsigned long long rem0 = s_removed_c;
+      unsigned long long rem = ((unsigned long long)__builtin_amdgcn_readfirstlane((unsigned)(rem0 >> 32)) << 32) |
+                               (unsigned long long)__builtin_amdgcn_readfirstlane((unsigned)rem0);
       const int limit = min(64, n - c * 64);
-      int kept_total = s_kept_total;
-      for (int j = 0; j < limit; ++j) {
-        if (!((rem >> j) & 1ULL)) {
-          if (max_keep > 0 && kept_total >= max_keep) break;
-          keep |= 1ULL << j;
-          ++kept_total;
-          const unsigned dlo = __shfl(lo, j, 64), dhi = __shfl(hi, j, 64);
-          rem |= ((unsigned long long)dhi << 32) | dlo;
-        }
+      const unsigned long long valid = limit >= 64 ? ~0ULL : ((1ULL << limit) - 1ULL);
+      unsigned long long keep = 0;
+      int kept_total = __builtin_amdgcn_readfirstlane(s_kept_total);
+      unsigned long long alive = ~rem & valid;
+      while (alive) {
+        if (max_keep > 0 && kept_total >= max_keep) break;
+        const int j = __ffsll((long long)alive) - 1;
+        keep |= 1ULL << j;
+        ++kept_total;
+        const unsigned dlo = __builtin_amdgcn_readlane(lo, j), dhi = __builtin_amdgcn_readlane(hi, j);
+        rem |= ((unsigned long long)dhi << 32) | dlo;
+        // positions <= j are decided; the mask only holds pairs (i, k > i), so rows never clear earlier bits
+        alive = ~rem & valid & ~((2ULL << j) - 1ULL);
       }
       if (lane == 0) {
         s_keep = keep;
@@ -191,21 +198,21 @@ __global__ __launch_bounds__(1024) void nms_sweep_kernel(const unsigned long lon
     __syncthreads();
     const unsigned long long keep = s_keep;
     if (w > c && w < col_blocks) {
-      // the keep word is wavefront-uniform: peel four kept rows per step so four independent
+      // the keep word is wavefront-uniform: peel eight kept rows per step so eight independent
       // loads are in flight instead of one dependent round trip per kept box
       unsigned long long k = keep;
       const unsigned long long* mrow = mask + (size_t)c * 64 * col_blocks + w;
       while (k) {
-        int j[4];
+        int j[8];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+        for (int u = 0; u < 8; ++u) {
           j[u] = k ? (__ffsll((long long)k) - 1) : -1;
           k &= (k - 1);
         }
-        unsigned long long v[4];
+        unsigned long long v[8];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) v[u] = (j[u] >= 0) ? mrow[(size_t)j[u] * col_blocks] : 0ULL;
-        removed |= (v[0] | v[1]) | (v[2] | v[3]);
+        for (int u = 0; u < 8; ++u) v[u] = (j[u] >= 0) ? mrow[(size_t)j[u] * col_blocks] : 0ULL;
+        removed |= ((v[0] | v[1]) | (v[2] | v[3])) | ((v[4] | v[5]) | (v[6] | v[7]));
       }
     }
     // early out once the quota is filled: later chunks keep nothing

@@ -10,9 +10,12 @@ differs between its CPU and CUDA builds).  Here equal scores are ordered by asce
 stable descending sort), which makes proposal indices reproducible; with distinct scores the result is the
 reference's.
 """
+import contextlib
+
 import torch
 
 from ... import _C
+from ...utils.streams import record, side_stream
 from ...structures.bounding_box import BoxList, is_source_image
 from ...structures.boxlist_ops import cat_boxlist
 from ..box_coder import BoxCoder
@@ -54,21 +57,41 @@ class RPNPostProcessor(torch.nn.Module):
         sorted_scores = sorted_scores[:, :pre_nms_top_n].contiguous()
         topk_idx = order[:, :pre_nms_top_n].contiguous()
 
-        result = []
+        # The greedy sweep of one image is a single workgroup: images are independent, so every second image runs
+        # on the side stream and the sweeps overlap; the kept counts come back in ONE host round trip.
+        dev = objectness.device
+        use_side = dev.type == "cuda" and N > 1 and self.nms_thresh > 0 and self.min_size <= 0
+        if use_side:
+            main, side = torch.cuda.current_stream(dev), side_stream(dev)
+            side.wait_stream(main)      # sorted scores / deltas exist
+        pending = []
         for i in range(N):
             im_w, im_h = anchors[i].size
-            boxes = _C.rpn_decode_clip(deltas_all[i], anchors[i].bbox.contiguous(), topk_idx[i],
-                                       self.box_coder.weights, self.box_coder.bbox_xform_clip, im_w, im_h)
-            scores = sorted_scores[i]
-            if self.min_size > 0:  # with min_size == 0 every clipped box passes (w, h >= 1)
-                keep = ((boxes[:, 2] - boxes[:, 0] + 1 >= self.min_size) &
-                        (boxes[:, 3] - boxes[:, 1] + 1 >= self.min_size)).nonzero().squeeze(1)
-                boxes, scores = boxes[keep].contiguous(), scores[keep].contiguous()
-            if self.nms_thresh > 0:
-                keep, count = _C.nms_with_count(boxes, scores, self.nms_thresh, max_keep=self.post_nms_top_n)
-                keep = keep[: int(count.item())]
+            ctx = torch.cuda.stream(side) if (use_side and i % 2 == 1) else contextlib.nullcontext()
+            with ctx:
+                boxes = _C.rpn_decode_clip(deltas_all[i], anchors[i].bbox.contiguous(), topk_idx[i],
+                                           self.box_coder.weights, self.box_coder.bbox_xform_clip, im_w, im_h)
+                scores = sorted_scores[i]
+                if self.min_size > 0:  # with min_size == 0 every clipped box passes (w, h >= 1)
+                    keep = ((boxes[:, 2] - boxes[:, 0] + 1 >= self.min_size) &
+                            (boxes[:, 3] - boxes[:, 1] + 1 >= self.min_size)).nonzero().squeeze(1)
+                    boxes, scores = boxes[keep].contiguous(), scores[keep].contiguous()
+                keep = count = None
+                if self.nms_thresh > 0:
+                    keep, count = _C.nms_with_count(boxes, scores, self.nms_thresh, max_keep=self.post_nms_top_n)
+            pending.append((boxes, scores, keep, count, (im_w, im_h)))
+        if use_side:
+            record([p[:4] for p in pending[1::2]], main)
+            main.wait_stream(side)
+        counts = None
+        if self.nms_thresh > 0:
+            counts = torch.cat([p[3] for p in pending]).tolist()
+        result = []
+        for i, (boxes, scores, keep, _, size) in enumerate(pending):
+            if keep is not None:
+                keep = keep[: counts[i]]
                 boxes, scores = boxes[keep], scores[keep]
-            boxlist = BoxList(boxes, (im_w, im_h), mode="xyxy")
+            boxlist = BoxList(boxes, size, mode="xyxy")
             boxlist.add_field("objectness", scores)
             result.append(boxlist)
         return result
