@@ -172,8 +172,10 @@ __global__ __launch_bounds__(1024) void nms_sweep_kernel(const unsigned long lon
       // the whole resolution is wavefront-uniform: keep it on the scalar unit (SGPR state, v_readlane of the
       // diagonal rows) and visit only the boxes that are still alive instead of all 64 positions
       const unsigned long long rem0 = s_removed_c;
-      unsigned long long rem = ((unsigned long long)__builtin_amdgcn_readfirstlane((unsigned)(rem0 >> 32)) << 32) |
-                               (unsigned long long)__builtin_amdgcn_readfirstlane((unsigned)rem0);
+      // (the builtin returns a signed int: widen through unsigned, or bit 31 smears over the upper word)
+      const unsigned rem_lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)rem0);
+      const unsigned rem_hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(rem0 >> 32));
+      unsigned long long rem = ((unsigned long long)rem_hi << 32) | (unsigned long long)rem_lo;
       const int limit = min(64, n - c * 64);
       const unsigned long long valid = limit >= 64 ? ~0ULL : ((1ULL << limit) - 1ULL);
       unsigned long long keep = 0;
@@ -184,7 +186,8 @@ __global__ __launch_bounds__(1024) void nms_sweep_kernel(const unsigned long lon
         const int j = __ffsll((long long)alive) - 1;
         keep |= 1ULL << j;
         ++kept_total;
-        const unsigned dlo = __builtin_amdgcn_readlane(lo, j), dhi = __builtin_amdgcn_readlane(hi, j);
+        const unsigned dlo = (unsigned)__builtin_amdgcn_readlane((int)lo, j);
+        const unsigned dhi = (unsigned)__builtin_amdgcn_readlane((int)hi, j);
         rem |= ((unsigned long long)dhi << 32) | dlo;
         // positions <= j are decided; the mask only holds pairs (i, k > i), so rows never clear earlier bits
         alive = ~rem & valid & ~((2ULL << j) - 1ULL);
