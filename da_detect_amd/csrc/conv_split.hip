@@ -208,7 +208,7 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_split_kernel(const ConvArgs a
       // the next tile's operands have landed by now: split one operand behind each k16 group of MFMAs
       if (more && !(ab & 1)) {
         if (step == 0) split_a();
-        else split_b();
+        else if (!(ab & 32)) split_b();
       }
     }
     if (more) {

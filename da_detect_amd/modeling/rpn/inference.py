@@ -15,7 +15,7 @@ import contextlib
 import torch
 
 from ... import _C
-from ...utils.streams import record, side_stream
+from ...utils.streams import other_stream, record
 from ...structures.bounding_box import BoxList, is_source_image
 from ...structures.boxlist_ops import cat_boxlist
 from ..box_coder import BoxCoder
@@ -62,7 +62,7 @@ class RPNPostProcessor(torch.nn.Module):
         dev = objectness.device
         use_side = dev.type == "cuda" and N > 1 and self.nms_thresh > 0 and self.min_size <= 0
         if use_side:
-            main, side = torch.cuda.current_stream(dev), side_stream(dev)
+            main, side = torch.cuda.current_stream(dev), other_stream(dev)
             side.wait_stream(main)      # sorted scores / deltas exist
         pending = []
         for i in range(N):

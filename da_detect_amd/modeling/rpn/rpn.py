@@ -8,7 +8,7 @@ from ..box_coder import BoxCoder
 from .anchor_generator import make_anchor_generator
 from .inference import make_rpn_postprocessor
 from .loss import make_rpn_loss_evaluator
-from ...utils.streams import side_section
+from ...utils.streams import record, side_section, side_stream
 
 
 @registry.RPN_HEADS.register("SingleConvRPNHead")
@@ -88,12 +88,26 @@ class RPNModule(torch.nn.Module):
         anchors = self.anchor_generator(images, features)
         if not self.training:
             return self._forward_test(anchors, objectness, rpn_box_regression)
-        boxes, losses = self._forward_train(anchors, objectness, rpn_box_regression, targets)
-        if early:
-            torch.autograd.backward([losses["loss_objectness"] + losses["loss_rpn_box_reg"]])
-            self._feature_grads = [f.grad for f in head_in]
-            losses = {k: v.detach() for k, v in losses.items()}
-        return boxes, losses
+        if not (early and objectness[0].is_cuda):
+            return self._forward_train(anchors, objectness, rpn_box_regression, targets)
+        # overlapped schedule: losses + the RPN branch's backward go to the compute stream first; proposal selection
+        # (sort, decode, single-workgroup NMS sweeps, one host round trip) then runs on the side stream underneath
+        # them, and the box head's sampling continues there (ROIBoxHead.forward)
+        dev = objectness[0].device
+        prep = self._prepare_loss_targets(anchors, targets)
+        main = torch.cuda.current_stream(dev)
+        head_done = main.record_event()
+        loss_objectness, loss_rpn_box_reg = self.loss_evaluator.finish(objectness, rpn_box_regression, prep)
+        torch.autograd.backward([loss_objectness + loss_rpn_box_reg])
+        self._feature_grads = [f.grad for f in head_in]
+        side = side_stream(dev)
+        side.wait_event(head_done)
+        with torch.cuda.stream(side), torch.no_grad():
+            boxes = self.box_selector_train(anchors, [o.detach() for o in objectness],
+                                            [r.detach() for r in rpn_box_regression], targets)
+            self.proposals_ready = side.record_event()
+        record(boxes, main)
+        return boxes, {"loss_objectness": loss_objectness.detach(), "loss_rpn_box_reg": loss_rpn_box_reg.detach()}
 
     def bridge_features(self, features):
         """features whose backward also delivers the RPN branch's gradient (no-op unless early_backward ran)"""

@@ -14,11 +14,18 @@ import torch
 _SIDE = {}
 
 
-def side_stream(device):
-    key = (device.type, device.index)
+def side_stream(device, which=0):
+    key = (device.type, device.index, which)
     if key not in _SIDE:
         _SIDE[key] = torch.cuda.Stream(device)
     return _SIDE[key]
+
+
+def other_stream(device):
+    """a stream different from the current one: side stream 0, or side stream 1 when already running on 0"""
+    cur = torch.cuda.current_stream(device)
+    s0 = side_stream(device, 0)
+    return s0 if cur != s0 else side_stream(device, 1)
 
 
 def record(obj, stream):
