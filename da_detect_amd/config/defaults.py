@@ -60,6 +60,8 @@ _DEFAULTS = {
             "NUM_GROUPS": 1, "WIDTH_PER_GROUP": 64, "STRIDE_IN_1X1": True,
             "TRANS_FUNC": "BottleneckWithFixedBatchNorm", "STEM_FUNC": "StemWithFixedBatchNorm",
             "RES5_DILATION": 1, "RES2_OUT_CHANNELS": 256, "STEM_OUT_CHANNELS": 64,
+            # vendored tree (tools/cityscapes/maskrcnn_benchmark/config/defaults.py:287-289)
+            "STAGE_WITH_DCN": (False, False, False, False), "WITH_MODULATED_DCN": False, "DEFORMABLE_GROUPS": 1,
         },
         "RETINANET": {
             "NUM_CLASSES": 81, "ANCHOR_SIZES": (32, 64, 128, 256, 512), "ASPECT_RATIOS": (0.5, 1.0, 2.0),

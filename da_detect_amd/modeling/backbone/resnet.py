@@ -98,8 +98,9 @@ class Bottleneck(nn.Module):
     when the channel count changes (resnet.py:227-314)."""
 
     def __init__(self, in_channels, bottleneck_channels, out_channels, num_groups, stride_in_1x1, stride,
-                 dilation, norm_func):
+                 dilation, norm_func, dcn_config=None):
         super(Bottleneck, self).__init__()
+        dcn_config = dcn_config or {}
         if num_groups != 1 or dilation != 1:
             raise NotImplementedError("grouped / dilated bottlenecks are outside the DA Faster R-CNN path")
         self.downsample = None
@@ -111,16 +112,27 @@ class Bottleneck(nn.Module):
         stride_1x1, stride_3x3 = (stride, 1) if stride_in_1x1 else (1, stride)
         self.conv1 = Conv2d(in_channels, bottleneck_channels, kernel_size=1, stride=stride_1x1, bias=False)
         self.bn1 = norm_func(bottleneck_channels)
-        self.conv2 = Conv2d(bottleneck_channels, bottleneck_channels, kernel_size=3, stride=stride_3x3,
-                            padding=1, bias=False)
+        self.with_dcn = bool(dcn_config.get("stage_with_dcn", False))
+        if self.with_dcn:
+            # vendored tree only (tools/cityscapes/maskrcnn_benchmark/modeling/backbone/resnet.py:286-300)
+            from ...layers.dcn import DFConv2d
+            self.conv2 = DFConv2d(bottleneck_channels, bottleneck_channels,
+                                  with_modulated_dcn=dcn_config.get("with_modulated_dcn", False), kernel_size=3,
+                                  stride=stride_3x3, groups=num_groups, dilation=dilation,
+                                  deformable_groups=dcn_config.get("deformable_groups", 1), bias=False)
+        else:
+            self.conv2 = Conv2d(bottleneck_channels, bottleneck_channels, kernel_size=3, stride=stride_3x3,
+                                padding=1, bias=False)
         self.bn2 = norm_func(bottleneck_channels)
         self.conv3 = Conv2d(bottleneck_channels, out_channels, kernel_size=1, bias=False)
         self.bn3 = norm_func(out_channels)
-        for l in (self.conv1, self.conv2, self.conv3):
+        for l in (self.conv1, self.conv3) + (() if self.with_dcn else (self.conv2,)):
             nn.init.kaiming_uniform_(l.weight, a=1)
 
     def forward(self, x, in_relu=False, out_private=False):
         """in_relu / out_private: structural promises made by _Stage (see _BottleneckFn); a direct call makes none"""
+        if self.with_dcn:
+            return self._forward_dcn(x)
         if self.conv2.stride[0] == 1:   # STRIDE_IN_1X1: the stride (if any) sits in conv1 and the shortcut
             if x.shape[0] == 0:
                 return self._forward_per_conv(x)
@@ -132,6 +144,16 @@ class Bottleneck(nn.Module):
                                        self.conv1.stride[0], in_relu, out_private)
         return self._forward_per_conv(x)
 
+    def uses_fused_path(self):
+        return (not self.with_dcn) and self.conv2.stride[0] == 1
+
+    def _forward_dcn(self, x):
+        """conv2 is a DFConv2d (offset conv + deformable conv): bn2 + ReLU run as the standalone affine kernel"""
+        out = self.conv1(x, *self.bn1.folded(), relu=True)
+        out = F.relu(self.bn2(self.conv2(out)))
+        identity = x if self.downsample is None else self.downsample[0](x, *self.downsample[1].folded())
+        return self.conv3(out, *self.bn3.folded(), residual=identity, relu=True)
+
     def _forward_per_conv(self, x):
         out = self.conv1(x, *self.bn1.folded(), relu=True)
         out = self.conv2(out, *self.bn2.folded(), relu=True)
@@ -142,10 +164,10 @@ class Bottleneck(nn.Module):
 
 class BottleneckWithFixedBatchNorm(Bottleneck):
     def __init__(self, in_channels, bottleneck_channels, out_channels, num_groups=1, stride_in_1x1=True,
-                 stride=1, dilation=1):
+                 stride=1, dilation=1, dcn_config=None):
         super(BottleneckWithFixedBatchNorm, self).__init__(
             in_channels, bottleneck_channels, out_channels, num_groups, stride_in_1x1, stride, dilation,
-            norm_func=FrozenBatchNorm2d)
+            norm_func=FrozenBatchNorm2d, dcn_config=dcn_config)
 
 
 class BaseStem(nn.Module):
@@ -189,11 +211,11 @@ class StemWithFixedBatchNorm(BaseStem):
 
 
 def _make_stage(block, in_channels, bottleneck_channels, out_channels, block_count, num_groups,
-                stride_in_1x1, first_stride, dilation=1):
+                stride_in_1x1, first_stride, dilation=1, dcn_config=None):
     blocks, stride = [], first_stride
     for _ in range(block_count):
         blocks.append(block(in_channels, bottleneck_channels, out_channels, num_groups, stride_in_1x1, stride,
-                            dilation=dilation))
+                            dilation=dilation, dcn_config=dcn_config))
         stride = 1
         in_channels = out_channels
     return _Stage(*blocks)
@@ -207,8 +229,11 @@ class _Stage(nn.Sequential):
 
     def forward(self, x):
         n = len(self)
-        for i, block in enumerate(self):
-            x = block(x, in_relu=(i > 0 or self.input_is_relu), out_private=(i < n - 1))
+        blocks = list(self)
+        for i, block in enumerate(blocks):
+            # "private" only if the consumer really is a fused block that gates what it returns
+            private = i < n - 1 and blocks[i + 1].uses_fused_path()
+            x = block(x, in_relu=(i > 0 or self.input_is_relu), out_private=private)
         return x
 
 
@@ -230,7 +255,11 @@ class ResNet(nn.Module):
             out_channels = stage2_out * factor
             self.add_module(name, _make_stage(block, in_channels, stage2_bottleneck * factor, out_channels,
                                               spec.block_count, num_groups, cfg.MODEL.RESNETS.STRIDE_IN_1X1,
-                                              first_stride=int(spec.index > 1) + 1))
+                                              first_stride=int(spec.index > 1) + 1,
+                                              dcn_config={
+                                                  "stage_with_dcn": cfg.MODEL.RESNETS.STAGE_WITH_DCN[spec.index - 1],
+                                                  "with_modulated_dcn": cfg.MODEL.RESNETS.WITH_MODULATED_DCN,
+                                                  "deformable_groups": cfg.MODEL.RESNETS.DEFORMABLE_GROUPS}))
             in_channels = out_channels
             # layer1 consumes max-pooled ReLU output (frozen, no data gradient); layer2.. consume a block's ReLU
             getattr(self, name).input_is_relu = spec.index > 1

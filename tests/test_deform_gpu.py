@@ -149,3 +149,44 @@ def test_deform_psroi_pool_identities_and_packs():
     # zero ROIs
     e = deform_roi_pooling(d, r[:0], d.new_empty(0), *args, True, 1, 3, 2, 0.1)
     assert e.shape == (0, 8, 3, 3)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("modulated", [False, True])
+def test_dcn_bottleneck_stage_matches_plain_stage_at_zero_offsets(modulated):
+    """STAGE_WITH_DCN wiring (vendored modeling/backbone/resnet.py:110-124,286-300): with the offset conv zeroed a
+    DFConv2d bottleneck equals the plain one (x0.5 through sigmoid(0) when modulated) — forward and gradients —
+    also next to fused plain blocks inside one stage (the `out_private` promise must not be made to a DCN block)."""
+    from da_detect_amd.modeling.backbone.resnet import BottleneckWithFixedBatchNorm, _Stage
+
+    torch.manual_seed(0)
+    dcn = {"stage_with_dcn": True, "with_modulated_dcn": modulated, "deformable_groups": 1}
+
+    def make(cfgs):
+        return _Stage(*[BottleneckWithFixedBatchNorm(64 if i == 0 else 128, 32, 128, stride=1, dcn_config=c)
+                        for i, c in enumerate(cfgs)]).cuda()
+
+    plain, mixed = make([None, None, None]), make([None, dcn, None])
+    sd = plain.state_dict()
+    msd = mixed.state_dict()
+    for k, v in sd.items():
+        if k.startswith("1.conv2."):
+            msd["1.conv2.conv.weight"] = v * (2.0 if modulated else 1.0)   # undo the sigmoid(0) = 0.5 modulation
+        else:
+            msd[k] = v
+    msd["1.conv2.offset.weight"].zero_()
+    msd["1.conv2.offset.bias"].zero_()
+    mixed.load_state_dict(msd)
+    x = torch.randn(2, 64, 12, 16, device="cuda").contiguous(memory_format=torch.channels_last)
+    xa, xb = x.clone().requires_grad_(True), x.clone().requires_grad_(True)
+    ya, yb = plain(xa), mixed(xb)
+    torch.testing.assert_close(yb, ya, rtol=1e-4, atol=1e-4)
+    g = torch.randn_like(ya)
+    ya.backward(g)
+    yb.backward(g)
+    torch.testing.assert_close(xb.grad, xa.grad, rtol=1e-3, atol=1e-4)
+    pa, pb = dict(plain.named_parameters()), dict(mixed.named_parameters())
+    for k in ("0.conv1.weight", "2.conv3.weight", "1.conv1.weight"):
+        torch.testing.assert_close(pb[k].grad, pa[k].grad, rtol=1e-3, atol=1e-4)
+    scale = 0.5 if modulated else 1.0
+    torch.testing.assert_close(pb["1.conv2.conv.weight"].grad, pa["1.conv2.weight"].grad * scale, rtol=1e-3, atol=1e-4)

@@ -390,7 +390,8 @@ def test_fpn_training_step_runs_and_grads_flow(device):
                 assert p.grad.abs().sum() > 0, name
 
 
-def test_overlapped_rpn_backward_gives_the_same_gradients(device):
+@pytest.mark.parametrize("case", ["da_plain", "da_triplet_aligned"])
+def test_overlapped_rpn_backward_gives_the_same_gradients(device, case):
     """RPNModule.early_backward queues the RPN branch's backward during the forward pass and bridges its feature
     gradient back into the main graph: every parameter gradient must equal the single-pass one (same sums, the
     feature-gradient additions merely associate differently)."""
@@ -398,7 +399,7 @@ def test_overlapped_rpn_backward_gives_the_same_gradients(device):
     from da_detect_amd.engine.trainer import enable_overlapped_rpn_backward
     from da_detect_amd.utils import rng
 
-    z, c, model, sd = _build("da_plain", device)
+    z, c, model, sd = _build(case, device)
     images, targets = make_batch(c, int(z["nimg"]), int(z["H"]), int(z["W"]), seed=int(z["seed"]), device=device)
     grads = []
     for early in (False, True):
