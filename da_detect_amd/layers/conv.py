@@ -68,6 +68,15 @@ def conv2d_affine_act(x, weight, scale=None, bias=None, residual=None, stride=1,
         Ho, Wo = out_size or _C.conv_out_size(x.shape[2], x.shape[3], weight.shape[2], weight.shape[3], stride,
                                               padding)
         return x.new_empty((0, weight.shape[0], Ho, Wo))
+    pad = (-weight.shape[0]) % 4
+    if pad and residual is None:
+        # output widths that are not a multiple of 4 (e.g. the 18 / 27 offset channels of DFConv2d): zero rows are
+        # appended for the kernels (their data-gradient GEMM contracts over Cout) and sliced off again
+        w = F.pad(weight, (0, 0, 0, 0, 0, 0, 0, pad))
+        sc = F.pad(scale, (0, pad), value=1.0) if scale is not None else None
+        bi = F.pad(bias, (0, pad)) if bias is not None else None
+        y = _ConvAffineAct.apply(x, w, sc, bi, None, stride, padding, relu, out_size)
+        return y[:, :weight.shape[0]]
     return _ConvAffineAct.apply(x, weight, scale, bias, residual, stride, padding, relu, out_size)
 
 
