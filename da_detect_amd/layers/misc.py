@@ -114,7 +114,9 @@ def consistency_loss(img_feas, ins_fea, ins_labels, size_average=True):
     """|mean_hw(p_img_i) - p_ins_ij| (layers/consistency_loss.py:3-27).  `img_feas` is a list of per-level
     [N,1,H,W] probability maps, or (fused path) of per-level [N] tensors that already hold the spatial mean."""
     loss = []
-    n_src = int(torch.nonzero(ins_labels).size(0))
+    n_src = getattr(ins_labels, "_n_src_host", None)   # set by the box head, which knows it without a round trip
+    if n_src is None:
+        n_src = int(torch.nonzero(ins_labels).size(0))
     intervals = [n_src, ins_fea.size(0) - n_src]
     for lvl in img_feas:
         means = lvl if lvl.dim() == 1 else torch.mean(lvl.reshape(lvl.shape[0], -1), 1)

@@ -73,15 +73,23 @@ class DAInsHead(nn.Module):
         return linear(x, self.fc3_da.weight, self.fc3_da.bias)
 
 
+def _vector_ins_features(cfg):
+    """True when the box head already yields one vector per ROI.  The reference tests CONV_BODY.startswith('V')
+    (da_heads.py:367-369); its FPN combination was never wired (AvgPool2d on the FPN2MLP vector and a 2048-wide
+    first layer) — here an MLP box head (FPN2MLPFeatureExtractor) counts as "vector" too."""
+    return (cfg.MODEL.BACKBONE.CONV_BODY.startswith("V")
+            or "MLP" in cfg.MODEL.ROI_BOX_HEAD.FEATURE_EXTRACTOR)
+
+
 def _ins_input_dim(cfg):
-    if cfg.MODEL.BACKBONE.CONV_BODY.startswith("V"):
+    if _vector_ins_features(cfg):
         return cfg.MODEL.ROI_BOX_HEAD.MLP_HEAD_DIM
     return cfg.MODEL.RESNETS.RES2_OUT_CHANNELS * 8
 
 
 def _pool_ins(feat, resnet_backbone):
     """AvgPool2d(7) + flatten of the [R,2048,7,7] ROI features (da_heads.py:402-407)"""
-    if resnet_backbone:
+    if resnet_backbone and feat.dim() == 4:
         return global_avg_pool(feat)
     return feat.reshape(feat.size(0), -1)
 
@@ -108,15 +116,24 @@ class DomainAdaptationModule(torch.nn.Module):
     def forward(self, img_features, da_ins_feature, da_ins_labels, targets=None):
         if not self.training:
             return {}
-        assert len(img_features) == 1, "the DA heads operate on a single feature level (C4), like the reference"
         da_ins_feature = _pool_ins(da_ins_feature, self.resnet_backbone)
         # instance head: adversarial pass then consistency pass, each with its own dropout masks
         da_ins_features = self.inshead(self.grl_ins(da_ins_feature))
         da_ins_consist = self.inshead(self.grl_ins_consist(da_ins_feature)).sigmoid()
         # image head: one fused evaluation serves both the BCE (GRL -w) and the consistency (GRL +w) paths
+        # Several levels (FPN): the reference concatenates the per-level logits along dim 0 (loss.py:81-92), which
+        # only works for equal map sizes, i.e. never for a pyramid.  The extension used here is what a dim-1
+        # concatenation would give: one BCE mean over the elements of all levels, and the consistency term averaged
+        # over levels (consistency_loss.py:13-27 already concatenates its per-level columns along dim 1).
         labels = image_domain_labels(targets)
-        da_img_loss, img_mean_sig, _ = self.imghead.fused(img_features[0], labels, self.grl_img.weight,
-                                                         self.grl_img_consist.weight)
+        per_level = [self.imghead.fused(f, labels, self.grl_img.weight, self.grl_img_consist.weight)
+                     for f in img_features]
+        if len(per_level) == 1:
+            da_img_loss = per_level[0][0]
+        else:
+            sizes = [float(f.shape[2] * f.shape[3]) for f in img_features]
+            da_img_loss = sum(l[0] * s for l, s in zip(per_level, sizes)) / sum(sizes)
+        img_mean_sig = [l[1] for l in per_level]
         losses = {}
         if self.img_weight > 0:
             losses["loss_da_image"] = self.img_weight * da_img_loss

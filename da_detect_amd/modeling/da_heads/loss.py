@@ -21,7 +21,9 @@ def da_ins_loss(da_ins, da_ins_labels):
 
 
 def da_consist_loss(img_mean_sig, da_ins_consist, da_ins_labels):
-    return consistency_loss([img_mean_sig], da_ins_consist, da_ins_labels, size_average=True)
+    """img_mean_sig: per-image mean sigmoid of one level, or a list with one entry per level"""
+    levels = img_mean_sig if isinstance(img_mean_sig, (list, tuple)) else [img_mean_sig]
+    return consistency_loss(levels, da_ins_consist, da_ins_labels, size_average=True)
 
 
 class TripletMargins(object):

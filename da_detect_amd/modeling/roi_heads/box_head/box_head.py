@@ -4,6 +4,7 @@ import os
 
 import torch
 
+from ....structures.bounding_box import is_source_image
 from ....utils.streams import side_section
 from .inference import make_roi_box_post_processor
 from .loss import make_roi_box_loss_evaluator
@@ -60,6 +61,9 @@ class ROIBoxHead(torch.nn.Module):
         # the reference runs the predictor on the DA features too and only keeps the domain mask, which
         # depends on self._proposals alone (box_head.py:107-110); the dead predictor call is skipped
         da_ins_labels = torch.cat([p.get_field("domain_labels") for p in self.loss_evaluator._proposals], dim=0)
+        # number of source-domain rows, known on the host: spares consistency_loss its nonzero() round trip
+        da_ins_labels._n_src_host = sum(len(p) for p, t in zip(self.loss_evaluator._proposals, targets)
+                                        if is_source_image(t))
         return (x, proposals, dict(loss_classifier=loss_classifier, loss_box_reg=loss_box_reg), da_ins_feas,
                 da_ins_labels)
 

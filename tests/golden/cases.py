@@ -23,3 +23,13 @@ def case_cfg(name):
     c.merge_from_file(os.path.join(ROOT, yaml))
     c.merge_from_list(list(overrides))
     return c
+
+
+def fpn_dcn_da_cfg():
+    """BASELINE.json configs[4]: R-101-FPN + DCN under DA (this repo's documented extension, no reference yaml)"""
+    from da_detect_amd.config import cfg
+
+    c = cfg.clone()
+    c.merge_from_file(os.path.join(ROOT, "configs/da_faster_rcnn/"
+                                         "e2e_da_faster_rcnn_R_101_FPN_DCN_cityscapes_to_foggy_cityscapes.yaml"))
+    return c

@@ -420,3 +420,53 @@ def test_overlapped_rpn_backward_gives_the_same_gradients(device, case):
     for n in grads[0]:
         a, b = grads[0][n], grads[1][n]
         assert float((a - b).norm()) <= 1e-5 * float(a.norm()) + 1e-10, n
+
+
+def test_fpn_dcn_da_training_step(device):
+    """BASELINE configs[4] (R-101-FPN + DCN + DA heads).  The reference cannot run this combination (da_heads loss
+    concatenates per-level logits along dim 0; instance head sized for C4), so there is no golden: check (1) the step
+    runs through DFConv2d bottlenecks, FPN, per-level image heads, the FPN2MLP instance features, with finite losses
+    and gradients everywhere; (2) the multi-level image loss equals torch's BCE over the elements of ALL levels and
+    the consistency term equals the reference's formula applied per level (consistency_loss.py:13-27)."""
+    import torch.nn.functional as F
+
+    from da_detect_amd.data.synthetic import make_batch
+    from da_detect_amd.modeling.detector import build_detection_model
+    from golden.cases import fpn_dcn_da_cfg
+    from golden.fill import fill_state_dict
+
+    c = fpn_dcn_da_cfg()
+    model = build_detection_model(c)
+    sd = fill_state_dict(model.state_dict(), 2)
+    for k in sd:
+        if ".conv2.offset." in k:
+            sd[k] = sd[k] * 0.05      # small but non-zero sampling offsets
+    model.load_state_dict(sd)
+    model = model.to(device).train()
+    images, targets = make_batch(c, 2, 192, 320, seed=2, device=device)
+    captured = {}
+    model.backbone.register_forward_hook(lambda m, i, o: captured.__setitem__("feats", [t.detach() for t in o]))
+    losses = model(images, targets)
+    assert set(losses) == {"loss_classifier", "loss_box_reg", "loss_objectness", "loss_rpn_box_reg", "loss_da_image",
+                           "loss_da_instance", "loss_da_consistency"}
+    total = sum(losses.values())
+    assert torch.isfinite(total)
+    total.backward()
+    seen = set()
+    for name, p in model.named_parameters():
+        if p.requires_grad:
+            assert p.grad is not None and torch.isfinite(p.grad).all(), name
+            if p.grad.abs().sum() > 0:
+                seen.add(name.split(".")[0] + "." + name.split(".")[1])
+    assert {"backbone.body", "backbone.fpn", "rpn.head", "roi_heads.box", "da_heads.imghead",
+            "da_heads.inshead"} <= seen, seen
+    assert any(p.grad.abs().sum() > 0 for n, p in model.named_parameters() if ".conv2.offset.weight" in n)
+    # (2) image-level loss over the pyramid
+    head = model.da_heads.imghead
+    with torch.no_grad():
+        logits = head(captured["feats"])
+        labels = torch.tensor([1.0, 0.0], device=device)
+        flat = torch.cat([l.reshape(2, -1) for l in logits], dim=1)
+        want = F.binary_cross_entropy_with_logits(flat, labels[:, None].expand_as(flat))
+    got = losses["loss_da_image"].detach() / c.MODEL.DA_HEADS.DA_IMG_LOSS_WEIGHT
+    assert abs(float(got) - float(want)) <= 1e-4 * abs(float(want)), (float(got), float(want))
