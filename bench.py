@@ -123,11 +123,14 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device: the product path has no CPU fallback")
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
+    # DADET_BENCH_SHARE_GPU=1 (test rigs with fewer GPUs than ranks): every rank on device 0, gloo instead of RCCL
+    share = os.environ.get("DADET_BENCH_SHARE_GPU", "0") == "1"
+    dev_index = 0 if share else local_rank
+    torch.cuda.set_device(dev_index)
+    device = torch.device("cuda", dev_index)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", init_method="env://")  # "nccl" is RCCL on ROCm
+        dist.init_process_group(backend="gloo" if share else "nccl", init_method="env://")  # "nccl" is RCCL on ROCm
     assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
 
     from da_detect_amd import _C
