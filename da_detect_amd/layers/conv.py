@@ -12,6 +12,7 @@ from torch.autograd import Function
 from torch.autograd.function import once_differentiable
 
 from .. import _C
+from ..utils.streams import WgradLane
 
 CL = torch.channels_last
 
@@ -42,6 +43,9 @@ class _ConvAffineAct(Function):
             if S is None:
                 S = g
         gx = gw = gb = None
+        lane = WgradLane(gy.device)
+        if need_w:      # beside the data gradient, on the weight-gradient stream
+            gw = lane.run(lambda: _C.conv_wgrad(x, g, tuple(weight.shape), ctx.stride, ctx.pad), x, g)
         if need_x:
             wt = _C.conv_weight_transpose(weight)
             if ctx.stride == 1:
@@ -54,10 +58,9 @@ class _ConvAffineAct(Function):
             else:
                 raise NotImplementedError("data gradient of a strided %dx%d convolution (the reference's "
                                           "configs keep the stride in the 1x1, STRIDE_IN_1X1=True)" % (k, k))
-        if need_w:
-            gw = _C.conv_wgrad(x, g, tuple(weight.shape), ctx.stride, ctx.pad)
         if need_b:
             gb = _C.colsum(S)
+        lane.join()
         return gx, gw, None, gb, (S if need_res else None), None, None, None, None
 
 

@@ -16,6 +16,7 @@ from torch import nn
 from ... import _C
 from ...layers import Conv2d, FrozenBatchNorm2d, conv2d_affine_act
 from ...utils.registry import Registry
+from ...utils.streams import WgradLane
 
 StageSpec = namedtuple("StageSpec", ["index", "block_count", "return_features"])
 
@@ -67,17 +68,18 @@ class _BottleneckFn(torch.autograd.Function):
         S3 = G.contiguous(memory_format=torch.channels_last) if ctx.out_private else \
             _C.relu_bn_backward(G, out, None)[1]
         dw1 = dw2 = dw3 = dwd = dx = None
+        lane = WgradLane(G.device)
         if n3:
-            dw3 = _C.conv_wgrad(y2, S3, tuple(w3.shape), 1, 0, out_scale=s3)
+            dw3 = lane.run(lambda: _C.conv_wgrad(y2, S3, tuple(w3.shape), 1, 0, out_scale=s3), y2, S3)
         S2 = _C.conv_forward(S3, _C.conv_weight_transpose(w3, s3), relu_mode=2, mask_ref=y2)
         if n2:
-            dw2 = _C.conv_wgrad(y1, S2, tuple(w2.shape), 1, 1, out_scale=s2)
+            dw2 = lane.run(lambda: _C.conv_wgrad(y1, S2, tuple(w2.shape), 1, 1, out_scale=s2), y1, S2)
         if n1 or need_x:
             S1 = _C.conv_forward(S2, _C.conv_weight_transpose(w2, s2), pad=1, relu_mode=2, mask_ref=y1)
         if n1:
-            dw1 = _C.conv_wgrad(x, S1, tuple(w1.shape), stride, 0, out_scale=s1)
+            dw1 = lane.run(lambda: _C.conv_wgrad(x, S1, tuple(w1.shape), stride, 0, out_scale=s1), x, S1)
         if nd and wd is not None:
-            dwd = _C.conv_wgrad(x, S3, tuple(wd.shape), stride, 0, out_scale=sd)
+            dwd = lane.run(lambda: _C.conv_wgrad(x, S3, tuple(wd.shape), stride, 0, out_scale=sd), x, S3)
         if need_x:
             gate = dict(relu_mode=2, mask_ref=x) if ctx.in_relu else {}
             hw = tuple(x.shape[2:])
@@ -90,6 +92,7 @@ class _BottleneckFn(torch.autograd.Function):
                 t = _C.conv_forward(S3, _C.conv_weight_transpose(wd, sd), out_spatial_stride=stride, out_hw=hw)
                 dx = _C.conv_forward(S1, _C.conv_weight_transpose(w1, s1), addend=t, out=t,
                                      out_spatial_stride=stride, out_hw=hw, **gate)
+        lane.join()
         return (dx, dw1, dw2, dw3, dwd) + (None,) * 11
 
 

@@ -62,3 +62,40 @@ def side_section(device, after=None):
         yield lambda *outs: handed.extend(outs)
     record(handed, main)
     main.wait_stream(side)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# weight gradients beside data gradients
+import os  # noqa: E402
+
+WGRAD_OVERLAP = os.environ.get("DADET_WGRAD_STREAM", "1") == "1"
+
+
+class WgradLane(object):
+    """Inside one backward node the weight-gradient GEMMs do not feed the data-gradient chain.  Issued on their own
+    stream they run BESIDE the dgrad kernels, so the partial last waves and launch gaps of one fill with the other's
+    workgroups.  `run(fn, *tensors)` queues fn() there once the tensors exist on the compute stream; `join()` makes
+    the compute stream wait before the gradients are handed to autograd."""
+
+    def __init__(self, device):
+        self.on = WGRAD_OVERLAP and device.type == "cuda"
+        if self.on:
+            self.main = torch.cuda.current_stream(device)
+            self.lane = side_stream(device, 2)
+            self.out = []
+
+    def run(self, fn, *inputs):
+        if not self.on:
+            return fn()
+        self.lane.wait_event(self.main.record_event())
+        with torch.cuda.stream(self.lane):
+            res = fn()
+        for t in inputs:
+            t.record_stream(self.lane)
+        self.out.append(res)
+        return res
+
+    def join(self):
+        if self.on and self.out:
+            record(self.out, self.main)
+            self.main.wait_stream(self.lane)
