@@ -35,6 +35,8 @@ class KernelProfiler(object):
     def __init__(self):
         self.records = {}   # name -> list of (start_event, end_event, algorithmic_flops)
         self.bytes = {}     # name -> summed algorithmic bytes (operands read once + result written once)
+        self.origin = torch.cuda.Event(enable_timing=True)   # common time origin for the union of busy intervals
+        self.origin.record()
 
     class _Span(object):
         def __init__(self, prof, name, work):
@@ -66,6 +68,28 @@ class KernelProfiler(object):
                              bytes_per_launch=self.bytes.get(name, 0.0) / len(recs),
                              work_per_launch=work / len(recs), achieved=work / (ms * 1e-3) if ms > 0 else 0.0)
         return out
+
+    def union(self):
+        """(total work, milliseconds during which AT LEAST ONE bracketed kernel was running): kernels of the
+        data-gradient and weight-gradient streams overlap, so summed durations count that time twice"""
+        torch.cuda.synchronize()
+        spans, work = [], 0.0
+        for recs in self.records.values():
+            for s, e, w in recs:
+                spans.append((self.origin.elapsed_time(s), self.origin.elapsed_time(e)))
+                work += w
+        spans.sort()
+        busy, cur_s, cur_e = 0.0, None, None
+        for s, e in spans:
+            if cur_e is None or s > cur_e:
+                if cur_e is not None:
+                    busy += cur_e - cur_s
+                cur_s, cur_e = s, e
+            else:
+                cur_e = max(cur_e, e)
+        if cur_e is not None:
+            busy += cur_e - cur_s
+        return work, busy
 
 
 def _stream():
