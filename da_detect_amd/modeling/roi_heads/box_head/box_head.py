@@ -5,7 +5,7 @@ import os
 import torch
 
 from ....structures.bounding_box import is_source_image
-from ....utils.streams import side_section, side_stream
+from ....utils.streams import side_section
 from .inference import make_roi_box_post_processor
 from .loss import make_roi_box_loss_evaluator
 from .roi_box_feature_extractors import make_roi_box_feature_extractor
@@ -13,7 +13,6 @@ from .roi_box_predictors import make_roi_box_predictor
 
 
 _NO_DEDUP = os.environ.get("DADET_NO_ROI_DEDUP", "0") == "1"
-_SPLIT_HEAD = os.environ.get("DADET_SPLIT_HEAD", "1") == "1"
 
 
 class ROIBoxHead(torch.nn.Module):
@@ -40,7 +39,7 @@ class ROIBoxHead(torch.nn.Module):
                 # every host synchronisation of the box head in front of the res5 head instead of behind it
                 da_proposals = self.loss_evaluator.subsample_for_da(proposals, targets)
                 done(proposals, da_proposals, self.loss_evaluator._proposals, self.loss_evaluator._loss_prep)
-        x = self._extract(features, proposals)
+        x = self.feature_extractor(features, proposals)
         class_logits, box_regression = self.predictor(x)
         if not self.training:
             return x, self.post_processor((class_logits, box_regression), proposals), {}, x, None
@@ -67,35 +66,6 @@ class ROIBoxHead(torch.nn.Module):
                                         if is_source_image(t))
         return (x, proposals, dict(loss_classifier=loss_classifier, loss_box_reg=loss_box_reg), da_ins_feas,
                 da_ins_labels)
-
-
-def _extract_per_image(self, features, proposals):
-    """pooler + head, one image per stream.  The per-image chains (ROIAlign -> res5 bottlenecks) are independent;
-    on two streams the partial last wave of one chain's GEMM (e.g. 392 of 512 workgroup slots for 256 ROIs) fills
-    with the other chain's next kernel.  Autograd replays each chain's backward on the stream its forward ran on."""
-    dev = features[0].device
-    main = torch.cuda.current_stream(dev)
-    lanes = [main] + [side_stream(dev, 3 + i) for i in range(len(proposals) - 1)]
-    outs = []
-    for i, (p, st) in enumerate(zip(proposals, lanes)):
-        if st is not main:
-            st.wait_stream(main)
-        with torch.cuda.stream(st):
-            outs.append(self.feature_extractor([f[i:i + 1] for f in features], [p]))
-    for o, st in zip(outs[1:], lanes[1:]):
-        o.record_stream(main)
-        main.wait_stream(st)
-    return torch.cat(outs, dim=0)
-
-
-def _extract(self, features, proposals):
-    if (_SPLIT_HEAD and self.training and features[0].is_cuda and 1 < len(proposals) <= 4
-            and all(len(p) > 0 for p in proposals) and len(proposals) == features[0].shape[0]):
-        return _extract_per_image(self, features, proposals)
-    return self.feature_extractor(features, proposals)
-
-
-ROIBoxHead._extract = _extract
 
 
 def build_roi_box_head(cfg):
