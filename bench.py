@@ -153,7 +153,7 @@ def main():
         loss_dict = train_step(model, opt, images, targets)
     profiler = None
     if not args.no_kernel_timing and rank == 0:
-        profiler = _C.KernelProfiler()
+        profiler = _C.KernelProfiler(pool=2 * 200 * args.steps)
         _C.PROFILER = profiler
     barrier()
     t0 = time.perf_counter()

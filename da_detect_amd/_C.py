@@ -32,7 +32,14 @@ class KernelProfiler(object):
     """HIP-event bracket around kernel launches on the CURRENT stream (the stream the kernels are launched
     on); elapsed times are read after a device synchronise, never inside the timed region."""
 
-    def __init__(self):
+    def __init__(self, pool=0):
+        # events are created (and once recorded, which is what instantiates the HIP object) up front so that the
+        # timed region only pays for hipEventRecord
+        self._pool = []
+        for _ in range(pool):
+            ev = torch.cuda.Event(enable_timing=True)
+            ev.record()
+            self._pool.append(ev)
         self.records = {}   # name -> list of (start_event, end_event, algorithmic_flops)
         self.bytes = {}     # name -> summed algorithmic bytes (operands read once + result written once)
         self.origin = torch.cuda.Event(enable_timing=True)   # common time origin for the union of busy intervals
@@ -43,8 +50,9 @@ class KernelProfiler(object):
             self.prof, self.name, self.work = prof, name, work
 
         def __enter__(self):
-            self.s = torch.cuda.Event(enable_timing=True)
-            self.e = torch.cuda.Event(enable_timing=True)
+            pool = self.prof._pool
+            self.s = pool.pop() if pool else torch.cuda.Event(enable_timing=True)
+            self.e = pool.pop() if pool else torch.cuda.Event(enable_timing=True)
             self.s.record()
 
         def __exit__(self, *exc):
