@@ -10,6 +10,7 @@ Layout contract: 4-D activations are logical NCHW tensors in torch.channels_last
 NHWC), weights are logical [Cout,Cin,KH,KW] in channels_last (physical [Cout,KH,KW,Cin]).  Inputs in any
 other layout are converted (one copy); outputs are always channels_last.
 """
+import contextlib
 import ctypes
 
 import torch
@@ -32,7 +33,8 @@ class KernelProfiler(object):
     """HIP-event bracket around kernel launches on the CURRENT stream (the stream the kernels are launched
     on); elapsed times are read after a device synchronise, never inside the timed region."""
 
-    def __init__(self, pool=0):
+    def __init__(self, pool=0, only=None):
+        self.only = only    # optional substring: bracket only the kernels whose name contains it
         # events are created (and once recorded, which is what instantiates the HIP object) up front so that the
         # timed region only pays for hipEventRecord
         self._pool = []
@@ -61,6 +63,8 @@ class KernelProfiler(object):
             self.prof.bytes[self.name] = self.prof.bytes.get(self.name, 0.0) + self.nbytes
 
     def span(self, name, work, nbytes=0.0):
+        if self.only is not None and self.only not in name:
+            return contextlib.nullcontext()
         sp = KernelProfiler._Span(self, name, work)
         sp.nbytes = nbytes
         return sp
