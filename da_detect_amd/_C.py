@@ -27,6 +27,7 @@ NMS_TIE_RULE = 0
 
 # optional per-launch timing of the GEMM kernels (bench.py sets this to a KernelProfiler; None = off)
 PROFILER = None
+_KNAME_CACHE = {}   # (M, Cout) -> kernel name of the forward GEMM variant (profiling only)
 
 
 class KernelProfiler(object):
@@ -252,10 +253,15 @@ def conv_forward(x, w, scale=None, bias=None, addend=None, mask_ref=None, stride
         mask_ref = _nhwc(mask_ref)
     d = _desc(N, H, W, Cin, Cout, KH, KW, stride, pad, Ho, Wo, OutH, OutW, out_spatial_stride, relu_mode)
     if PROFILER is not None:
-        variant = _lib.load().dadet_conv_forward_variant(ctypes.byref(d))
-        mode = get_gemm_mode()
-        kname = "conv_fwd_kernel<%s>" if mode == 0 else ("conv_fwd_split_kernel<%%s,%d>" % mode)
-        with PROFILER.span(kname % ("2,2", "2,1", "1,1")[variant],
+        key = (N * Ho * Wo, Cout)
+        kname = _KNAME_CACHE.get(key)
+        if kname is None:
+            variant = _lib.load().dadet_conv_forward_variant(ctypes.byref(d))
+            mode = get_gemm_mode()
+            kname = ("conv_fwd_kernel<%s>" if mode == 0 else ("conv_fwd_split_kernel<%%s,%d>" % mode)) % \
+                ("2,2", "2,1", "1,1")[variant]
+            _KNAME_CACHE[key] = kname
+        with PROFILER.span(kname,
                            2.0 * N * Ho * Wo * Cout * Cin * KH * KW,
                            4.0 * (x.numel() + w.numel() + out.numel() + (addend.numel() if addend is not None else 0)
                                   + (mask_ref.numel() if mask_ref is not None else 0))):
@@ -542,6 +548,7 @@ def deform_psroi_pooling_backward(grad_out, data, rois, offset, count, no_trans,
 def set_gemm_mode(mode):
     """0 exact fp32 MFMA | 3 three-term bf16 split (fp32-class accuracy) | 2 two-term split; see include/dadet.h"""
     _lib.call("dadet_set_gemm_mode", int(mode))
+    _KNAME_CACHE.clear()
 
 
 def get_gemm_mode():
