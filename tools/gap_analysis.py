@@ -16,6 +16,7 @@ steps = int(sys.argv[3]) if len(sys.argv) > 3 else 0
 if steps:  # steady-state window: from the end of the (steps+1)-th last optimizer kernel to the end of the last one
     ends = [e for _, e, n in rows if "sgd_kernel" in n]
     lo, hi = ends[-steps - 1], ends[-1]
+    lo_window, hi_window = lo, hi
     rows = [r for r in rows if r[0] >= lo and r[1] <= hi]
     print("window: last %d steps, %.2f ms/step" % (steps, (hi - lo) / 1e6 / steps))
 busy = sum(e - s for s, e, _ in rows)
@@ -65,3 +66,27 @@ if steps:
             run_n += 1
             run_busy += e - s
     print("library kernels in the step: %d, wall %.2f ms (incl. their gaps)" % (tot_n, tot_wall / 1e3))
+
+# ---- per-queue view (streams map to HSA queues): busy time per queue and the compute queue's largest idle gaps
+if steps:
+    import collections
+    qrows = collections.defaultdict(list)
+    with open(path, newline="") as f:
+        for r in csv.DictReader(f):
+            s_, e_ = int(r["Start_Timestamp"]), int(r["End_Timestamp"])
+            if s_ >= lo_window and e_ <= hi_window:
+                qrows[r.get("Queue_Id", "?")].append((s_, e_, r["Kernel_Name"][:60]))
+    print("\nper queue (window of %d steps): kernels, busy ms/step" % steps)
+    for q, rs in sorted(qrows.items(), key=lambda kv: -sum(e - s for s, e, _ in kv[1])):
+        print("  queue %s: %5d kernels  %.2f ms/step" % (q, len(rs), sum(e - s for s, e, _ in rs) / 1e6 / steps))
+    mainq = max(qrows, key=lambda q: sum(e - s for s, e, _ in qrows[q]))
+    rs = sorted(qrows[mainq])
+    gaps2 = []
+    for (s0, e0, n0), (s1, e1, n1) in zip(rs, rs[1:]):
+        if s1 - e0 > 30000:
+            gaps2.append((s1 - e0, n0, n1))
+    gaps2.sort(reverse=True)
+    print("compute queue %s: idle gaps > 30 us: %d, total %.2f ms/step; largest:" % (
+        mainq, len(gaps2), sum(g for g, _, _ in gaps2) / 1e6 / steps))
+    for g, a, b in gaps2[:25]:
+        print("  %8.1f us  after %s -> before %s" % (g / 1e3, a[:50], b[:50]))
