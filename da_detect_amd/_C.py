@@ -474,6 +474,22 @@ def deform_sample_backward(x, offset, mask, gcols, kh, kw, stride, pad, dil, dg,
     return gx, goffset, gmask
 
 
+def box_match_encode(proposals, gt_boxes, gt_labels, high_threshold, low_threshold, weights):
+    """-> (matched_idxs int64 [P], labels int64 [P], regression_targets [P,4]); see dadet_box_match_encode"""
+    _dev(proposals, "proposals"), _dev(gt_boxes, "gt_boxes")
+    proposals = proposals.contiguous().float()
+    gt_boxes = gt_boxes.contiguous().float()
+    gt_labels = gt_labels.contiguous().to(torch.int64)
+    P, G = proposals.shape[0], gt_boxes.shape[0]
+    matched = torch.empty(P, dtype=torch.int64, device=proposals.device)
+    labels = torch.empty(P, dtype=torch.int64, device=proposals.device)
+    targets = torch.empty((P, 4), dtype=torch.float32, device=proposals.device)
+    wx, wy, ww, wh = [float(v) for v in weights]
+    _lib.call("dadet_box_match_encode", _p(proposals), P, _p(gt_boxes), _p(gt_labels), G, float(high_threshold),
+              float(low_threshold), wx, wy, ww, wh, _p(matched), _p(labels), _p(targets), _stream())
+    return matched, labels, targets
+
+
 def roi_pool_forward(input, rois, spatial_scale, pooled_height, pooled_width):
     """-> (output, argmax int32) [R, C, ph, pw] channels_last; reference ROIPool.h:11-24"""
     _dev(input, "input"), _dev(rois, "rois")

@@ -207,6 +207,56 @@ __global__ void rpn_decode_clip_kernel(const float4* __restrict__ deltas, const 
   out[k] = make_float4(x1, y1, x2, y2);
 }
 
+// ---- box-head target assignment: IoU vs ground truth -> Matcher -> labels -> BoxCoder.encode, one launch --------
+// reference chain (each step a handful of ATen launches there): boxlist_iou (structures/boxlist_ops.py:56-91), Matcher
+// without low-quality matches (modeling/matcher.py:42-92), label rules of FastRCNNLossComputation.prepare_targets
+// (roi_heads/box_head/loss.py:69-93: below-low -> 0, between thresholds -> -1) and BoxCoder.encode
+// (modeling/box_coder.py:22-50).  Operation order is the reference's (contraction is off for this file), first
+// maximum wins on equal IoU.  One thread per proposal; the G ground-truth boxes sit in LDS.
+__global__ void box_match_encode_kernel(const float4* __restrict__ props, int P, const float4* __restrict__ gts,
+                                        const int64_t* __restrict__ gt_labels, int G, float high, float low,
+                                        float wx, float wy, float ww, float wh, int64_t* __restrict__ matched,
+                                        int64_t* __restrict__ labels, float4* __restrict__ targets) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float4* g_box = reinterpret_cast<float4*>(smem);
+  float* g_area = reinterpret_cast<float*>(g_box + G);
+  for (int g = threadIdx.x; g < G; g += blockDim.x) {
+    const float4 b = gts[g];
+    g_box[g] = b;
+    g_area[g] = (b.z - b.x + 1.f) * (b.w - b.y + 1.f);
+  }
+  __syncthreads();
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= P) return;
+  const float4 p = props[i];
+  const float area = (p.z - p.x + 1.f) * (p.w - p.y + 1.f);
+  float best = -1.f;
+  int arg = 0;
+  for (int g = 0; g < G; ++g) {
+    const float4 b = g_box[g];
+    const float w = fmaxf(fminf(b.z, p.z) - fmaxf(b.x, p.x) + 1.f, 0.f);
+    const float h = fmaxf(fminf(b.w, p.w) - fmaxf(b.y, p.y) + 1.f, 0.f);
+    const float inter = w * h;
+    const float iou = inter / (g_area[g] + area - inter);
+    if (iou > best) {
+      best = iou;
+      arg = g;
+    }
+  }
+  int64_t m = arg;
+  if (best < low) m = -1;
+  else if (best < high) m = -2;
+  matched[i] = m;
+  const int src = m < 0 ? 0 : (int)m;   // matched_idxs.clamp(min=0)
+  labels[i] = m == -1 ? 0 : (m == -2 ? -1 : gt_labels[src]);
+  const float4 r = g_box[src];
+  const float ew = p.z - p.x + 1.f, eh = p.w - p.y + 1.f;
+  const float ecx = p.x + 0.5f * ew, ecy = p.y + 0.5f * eh;
+  const float gw = r.z - r.x + 1.f, gh = r.w - r.y + 1.f;
+  const float gcx = r.x + 0.5f * gw, gcy = r.y + 0.5f * gh;
+  targets[i] = make_float4(wx * (gcx - ecx) / ew, wy * (gcy - ecy) / eh, ww * logf(gw / ew), wh * logf(gh / eh));
+}
+
 // ---- sigmoid focal loss (reference: csrc/cuda/SigmoidFocalLoss_cuda.cu:21-101) ----------------
 __global__ void focal_fwd_kernel(const float* __restrict__ logits, const int* __restrict__ targets,
                                  float* __restrict__ losses, int64_t total, int C, float gamma,
@@ -412,6 +462,24 @@ extern "C" int dadet_rpn_decode_clip(const float* deltas, const float* anchors, 
                      topk_idx, K, wx, wy, ww, wh, xform_clip, im_w, im_h,
                      reinterpret_cast<float4*>(boxes_out));
   return check_launch("rpn_decode_clip");
+}
+
+extern "C" int dadet_box_match_encode(const float* proposals, int P, const float* gt_boxes, const int64_t* gt_labels,
+                                      int G, float high_threshold, float low_threshold, float wx, float wy, float ww,
+                                      float wh, int64_t* matched_idxs, int64_t* labels, float* regression_targets,
+                                      void* stream) {
+  DADET_REQUIRE(P >= 0 && G > 0, "box_match_encode: needs P >= 0 proposals and G > 0 ground-truth boxes");
+  if (P == 0) return DADET_OK;
+  DADET_REQUIRE(proposals && gt_boxes && gt_labels && matched_idxs && labels && regression_targets,
+                "box_match_encode: null pointer");
+  DADET_REQUIRE(aligned16(proposals) && aligned16(gt_boxes) && aligned16(regression_targets),
+                "box_match_encode: box pointers must be 16-byte aligned");
+  DADET_REQUIRE(G <= 3000, "box_match_encode: G=%d ground-truth boxes exceed the LDS table", G);
+  hipLaunchKernelGGL(box_match_encode_kernel, dim3(ceil_div(P, 256)), dim3(256), (size_t)G * 20, as_stream(stream),
+                     reinterpret_cast<const float4*>(proposals), P, reinterpret_cast<const float4*>(gt_boxes),
+                     gt_labels, G, high_threshold, low_threshold, wx, wy, ww, wh, matched_idxs, labels,
+                     reinterpret_cast<float4*>(regression_targets));
+  return check_launch("box_match_encode");
 }
 
 extern "C" int dadet_sigmoid_focal_loss_forward(const float* logits, const int32_t* targets, float* losses,

@@ -11,10 +11,23 @@ class BalancedPositiveNegativeSampler(object):
         self.batch_size_per_image = batch_size_per_image
         self.positive_fraction = positive_fraction
 
-    def __call__(self, matched_idxs):
-        """per image labels (-1 ignore, 0 negative, >0 positive) -> (list of pos masks, list of neg masks)"""
+    def __call__(self, matched_idxs, all_negative=None):
+        """per image labels (-1 ignore, 0 negative, >0 positive) -> (list of pos masks, list of neg masks).
+        all_negative[i] = True: the caller built image i's labels as all zeros (target-domain images, the DA ROI
+        sample) — the index lists are then known without reading the labels back (no nonzero round trips); the two
+        permutations are drawn exactly as in the general path (same sizes, same order)."""
         pos_idx, neg_idx = [], []
-        for m in matched_idxs:
+        for i, m in enumerate(matched_idxs):
+            if all_negative is not None and all_negative[i]:
+                n = m.numel()
+                num_neg = min(n, self.batch_size_per_image)
+                rng.randperm(0, m.device)
+                perm2 = rng.randperm(n, m.device)[:num_neg]
+                nm = torch.zeros_like(m, dtype=torch.bool)
+                nm[perm2] = 1
+                pos_idx.append(torch.zeros_like(m, dtype=torch.bool))
+                neg_idx.append(nm)
+                continue
             positive = torch.nonzero(m >= 1).squeeze(1)
             negative = torch.nonzero(m == 0).squeeze(1)
             num_pos = min(positive.numel(), int(self.batch_size_per_image * self.positive_fraction))

@@ -3,6 +3,7 @@
 import torch
 from torch.nn import functional as F
 
+from .... import _C
 from ....layers import smooth_l1_loss
 from ....structures.bounding_box import is_source_image
 from ....structures.boxlist_ops import boxlist_iou
@@ -30,8 +31,10 @@ class FastRCNNLossComputation(object):
 
     def prepare_targets(self, proposals, targets, sample_for_da=False):
         labels, regression_targets, domain_labels = [], [], []
+        self._all_negative = []
         for proposals_per_image, targets_per_image in zip(proposals, targets):
             is_source = is_source_image(targets_per_image)
+            self._all_negative.append(bool(not is_source or sample_for_da))
             if not is_source or sample_for_da:
                 # every label is overwritten with 0 below (loss.py:85-88) and the regression targets of these rows
                 # never reach a loss (target-domain rows are masked out, loss.py:193-198; subsample_for_da drops
@@ -41,6 +44,17 @@ class FastRCNNLossComputation(object):
                 labels.append(torch.zeros(n, dtype=torch.int64, device=dev))
                 regression_targets.append(torch.zeros((n, 4), dtype=torch.float32, device=dev))
                 domain_labels.append(torch.full((n,), bool(is_source), dtype=torch.bool, device=dev))
+                continue
+            if proposals_per_image.bbox.is_cuda and not self.proposal_matcher.allow_low_quality_matches:
+                # IoU + matcher + label rules + encode in ONE launch (the ATen chain below is ~60 launches)
+                if len(targets_per_image) == 0:
+                    raise ValueError("No ground-truth boxes available for one of the images during training")
+                _, lab, reg = _C.box_match_encode(
+                    proposals_per_image.bbox, targets_per_image.bbox, targets_per_image.get_field("labels"),
+                    self.proposal_matcher.high_threshold, self.proposal_matcher.low_threshold, self.box_coder.weights)
+                regression_targets.append(reg)
+                domain_labels.append(torch.ones_like(lab, dtype=torch.bool))
+                labels.append(lab)
                 continue
             matched = self.match_targets_to_proposals(proposals_per_image, targets_per_image, is_source)
             matched_idxs = matched.get_field("matched_idxs")
@@ -56,7 +70,10 @@ class FastRCNNLossComputation(object):
         return labels, regression_targets, domain_labels
 
     def _take_sampled(self, proposals, pos_masks, neg_masks):
+        limit = self.fg_bg_sampler.batch_size_per_image
         for i, (pm, nm) in enumerate(zip(pos_masks, neg_masks)):
+            if self._all_negative[i] and len(proposals[i]) <= limit:
+                continue      # every row is taken, in ascending order: the gather would be the identity
             proposals[i] = proposals[i][torch.nonzero(pm | nm).squeeze(1)]
         return proposals
 
@@ -64,7 +81,7 @@ class FastRCNNLossComputation(object):
         """sample BATCH_SIZE_PER_IMAGE proposals per image for the detection loss; keeps them in
         self._proposals for the following __call__ (loss.py:95-130)"""
         labels, regression_targets, domain_labels = self.prepare_targets(proposals, targets)
-        pos_masks, neg_masks = self.fg_bg_sampler(labels)
+        pos_masks, neg_masks = self.fg_bg_sampler(labels, self._all_negative)
         proposals = list(proposals)
         for lab, reg, prop, dom in zip(labels, regression_targets, proposals, domain_labels):
             prop.add_field("labels", lab)
@@ -98,7 +115,7 @@ class FastRCNNLossComputation(object):
         """uniformly sampled proposals (all labels forced to 0) for the instance-level domain classifier
         (loss.py:132-163); does NOT replace self._proposals"""
         labels, _, domain_labels = self.prepare_targets(proposals, targets, sample_for_da=True)
-        pos_masks, neg_masks = self.fg_bg_sampler(labels)
+        pos_masks, neg_masks = self.fg_bg_sampler(labels, self._all_negative)
         proposals = list(proposals)
         for prop, dom in zip(proposals, domain_labels):
             prop.add_field("domain_labels", dom)

@@ -177,6 +177,16 @@ int dadet_roi_pool_forward(const float* input, const float* rois, float* output,
 int dadet_roi_pool_backward(const float* grad_output, const int* argmax, const float* rois, float* grad_input, int B,
                             int C, int H, int W, int R, int pooled_h, int pooled_w, void* stream);
 
+/* Box-head target assignment in one launch: IoU of every proposal with the G ground-truth boxes, Matcher without
+ * low-quality matches, label rules and regression targets — replaces the ATen chain boxlist_iou
+ * (structures/boxlist_ops.py:56-91) -> Matcher.__call__ (modeling/matcher.py:42-92) -> prepare_targets label rules
+ * (modeling/roi_heads/box_head/loss.py:69-93) -> BoxCoder.encode (modeling/box_coder.py:22-50).
+ * matched_idxs[i] = argmax_g IoU (first maximum), or -1 (max < low) / -2 (low <= max < high);
+ * labels[i] = 0 / -1 for those, else gt_labels[matched]; targets from gt[max(matched,0)] with weights (wx,wy,ww,wh). */
+int dadet_box_match_encode(const float* proposals, int P, const float* gt_boxes, const int64_t* gt_labels, int G,
+                           float high_threshold, float low_threshold, float wx, float wy, float ww, float wh,
+                           int64_t* matched_idxs, int64_t* labels, float* regression_targets, void* stream);
+
 /* Deformable position-sensitive ROI pooling — replaces the vendored tree's `_C.deform_psroi_pooling_forward /
  * _backward` (tools/cityscapes/maskrcnn_benchmark/csrc/vision.cpp:22-23, cuda/deform_pool_kernel_cuda.cu:30-264).
  * data [B][H][W][C] NHWC with C = output_dim*group_size^2; rois [R][5]; trans [R][num_classes*2][part][part]

@@ -432,3 +432,28 @@ def test_triplet_w_loss(device):
     torch.testing.assert_close(ga.cpu(), a.grad, rtol=1e-4, atol=1e-7)
     torch.testing.assert_close(gp.cpu(), p.grad, rtol=1e-4, atol=1e-7)
     torch.testing.assert_close(gn.cpu(), n.grad, rtol=1e-4, atol=1e-7)
+
+
+# --------------------------------------------------------------------------------- box-head target assignment
+@pytest.mark.parametrize("P,G,high,low", [(2000, 12, 0.5, 0.5), (517, 1, 0.7, 0.3), (64, 37, 0.5, 0.0)])
+def test_box_match_encode_matches_the_aten_chain(device, P, G, high, low):
+    """one-launch IoU -> Matcher -> labels -> BoxCoder.encode vs the reference-order torch chain on the CPU
+    (structures/boxlist_ops.py:56-91, modeling/matcher.py:42-92, box_head/loss.py:69-93, box_coder.py:22-50)"""
+    from da_detect_amd import _C
+    from oracle import model_ref as M
+
+    rng = np.random.default_rng(P + G)
+    props = torch.from_numpy(_rand_boxes(rng, P))
+    gts = torch.from_numpy(_rand_boxes(rng, G))
+    props[:G] = gts                                     # exact matches (IoU 1) like add_gt_proposals produces
+    gl = torch.from_numpy(rng.integers(1, 9, G)).to(torch.int64)
+    weights = (10.0, 10.0, 5.0, 5.0)
+    iou = M.box_iou(gts, props)
+    want_m = M.matcher(iou, high, low, False)
+    want_lab = gl[want_m.clamp(min=0)].clone()
+    want_lab[want_m == M.BELOW_LOW] = 0
+    want_lab[want_m == M.BETWEEN] = -1
+    want_reg = M.encode(gts[want_m.clamp(min=0)], props, weights)
+    m, lab, reg = _C.box_match_encode(props.to(device), gts.to(device), gl.to(device), high, low, weights)
+    assert m.dtype == torch.int64 and torch.equal(m.cpu(), want_m) and torch.equal(lab.cpu(), want_lab)
+    torch.testing.assert_close(reg.cpu(), want_reg, rtol=1e-5, atol=1e-6)
