@@ -21,6 +21,20 @@ if steps:  # steady-state window: from the end of the (steps+1)-th last optimize
     print("window: last %d steps, %.2f ms/step" % (steps, (hi - lo) / 1e6 / steps))
 busy = sum(e - s for s, e, _ in rows)
 span = rows[-1][1] - rows[0][0]
+union, cur_s, cur_e = 0, rows[0][0], rows[0][1]
+big_idle = []
+for s_, e_, n_ in rows[1:]:
+    if s_ > cur_e:
+        union += cur_e - cur_s
+        if s_ - cur_e > 50000:
+            big_idle.append((s_ - cur_e, n_))
+        cur_s, cur_e = s_, e_
+    else:
+        cur_e = max(cur_e, e_)
+union += cur_e - cur_s
+print("union of all queues: GPU executing something %.1f ms, nothing %.1f ms (%.1f%%); idle stretches > 50 us: %s" % (
+    union / 1e6, (span - union) / 1e6, 100.0 * (span - union) / span,
+    ", ".join("%.0fus before %s" % (g / 1e3, n[:40]) for g, n in sorted(big_idle, reverse=True)[:12])))
 print("kernels %d  busy %.1f ms  span %.1f ms  idle %.1f ms (%.1f%%)" % (len(rows), busy / 1e6, span / 1e6,
                                                                        (span - busy) / 1e6, 100.0 * (span - busy) / span))
 gaps = defaultdict(lambda: [0, 0.0])
