@@ -474,6 +474,32 @@ def deform_sample_backward(x, offset, mask, gcols, kh, kw, stride, pad, dil, dg,
     return gx, goffset, gmask
 
 
+def rpn_loss(objectness, box_regression, sampled_inds, labels_sampled, pos_inds, targets_pos, beta):
+    """single-level RPN losses + their gradients in one launch (dadet_rpn_loss).  objectness [N,A,H,W] and
+    box_regression [N,4A,H,W] channels_last -> (losses [2], grad_objectness, grad_box_regression)"""
+    _dev(objectness, "objectness"), _dev(box_regression, "box_regression")
+    obj, reg = _nhwc(objectness), _nhwc(box_regression)
+    losses = torch.empty(2, dtype=torch.float32, device=obj.device)
+    g_obj = torch.empty_like(obj).zero_()
+    g_reg = torch.empty_like(reg).zero_()
+    _lib.call("dadet_rpn_loss", _p(obj), _p(reg), _p(sampled_inds.contiguous()), _p(labels_sampled.contiguous()),
+              int(sampled_inds.numel()), _p(pos_inds.contiguous()), _p(targets_pos.contiguous()),
+              int(pos_inds.numel()), float(beta), _p(losses), _p(g_obj), _p(g_reg), _stream())
+    return losses, g_obj, g_reg
+
+
+def fast_rcnn_loss(class_logits, box_regression, src, labels_src, rows_pos, map_inds, targets_pos):
+    """Fast R-CNN losses + gradients in one launch (dadet_fast_rcnn_loss) -> (losses [2], g_cls, g_reg)"""
+    _dev(class_logits, "class_logits"), _dev(box_regression, "box_regression")
+    cls, reg = class_logits.contiguous(), box_regression.contiguous()
+    losses = torch.empty(2, dtype=torch.float32, device=cls.device)
+    g_cls, g_reg = torch.zeros_like(cls), torch.zeros_like(reg)
+    _lib.call("dadet_fast_rcnn_loss", _p(cls), _p(reg), cls.shape[1], reg.shape[1], _p(src.contiguous()),
+              _p(labels_src.contiguous()), int(src.numel()), _p(rows_pos.contiguous()), _p(map_inds.contiguous()),
+              _p(targets_pos.contiguous()), int(rows_pos.numel()), _p(losses), _p(g_cls), _p(g_reg), _stream())
+    return losses, g_cls, g_reg
+
+
 def box_match_encode(proposals, gt_boxes, gt_labels, high_threshold, low_threshold, weights):
     """-> (matched_idxs int64 [P], labels int64 [P], regression_targets [P,4]); see dadet_box_match_encode"""
     _dev(proposals, "proposals"), _dev(gt_boxes, "gt_boxes")

@@ -1,0 +1,141 @@
+// Fused detection losses: value AND gradient in one single-workgroup launch each (gfx950).
+//
+// The reference evaluates each of these as a chain of ATen calls (gather, log-softmax / BCE / smooth-L1, reductions,
+// and the mirror chain in backward): ~80 launches of a few hundred elements for the RPN losses
+// (modeling/rpn/loss.py:125-143) and ~60 for the Fast R-CNN losses (modeling/roi_heads/box_head/loss.py:165-221).
+// They touch <= 512 sampled rows, so one 256-thread workgroup does the whole job: per-row terms, a deterministic
+// block reduction (wave shuffle + LDS, fixed order), and the gradient rows scattered into zero-filled dense maps.
+// Formulas: binary_cross_entropy_with_logits = max(x,0) - x*y + log1p(exp(-|x|)); smooth-L1 with beta
+// (layers/smooth_l1_loss.py:6-16); cross_entropy = logsumexp(x) - x[label].
+#include "common.h"
+
+namespace dadet {
+
+__device__ inline float block_sum_256(float v, float* red) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  return (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+__device__ inline float smooth_l1_term(float x, float t, float beta, float* grad) {
+  const float d = x - t, n = fabsf(d);
+  if (n < beta) {
+    *grad = d / beta;
+    return 0.5f * n * n / beta;
+  }
+  *grad = d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f);
+  return n - 0.5f * beta;
+}
+
+// objectness: flat logits (the NHWC map, index = ((n*H+h)*W+w)*A+a), box_regression: flat [.,4] (NHWC, 4A channels)
+__global__ __launch_bounds__(256) void rpn_loss_kernel(const float* __restrict__ objectness,
+                                                       const float* __restrict__ box_regression,
+                                                       const int64_t* __restrict__ sampled_inds,
+                                                       const float* __restrict__ labels_sampled, int S,
+                                                       const int64_t* __restrict__ pos_inds,
+                                                       const float* __restrict__ targets_pos, int Pn, float beta,
+                                                       float* __restrict__ losses, float* __restrict__ g_obj,
+                                                       float* __restrict__ g_reg) {
+  __shared__ float red[4];
+  const float inv = S > 0 ? 1.f / (float)S : 0.f;
+  float bce = 0.f;
+  for (int i = threadIdx.x; i < S; i += 256) {
+    const int64_t a = sampled_inds[i];
+    const float x = objectness[a], y = labels_sampled[i];
+    bce += fmaxf(x, 0.f) - x * y + log1pf(expf(-fabsf(x)));
+    g_obj[a] = (1.f / (1.f + expf(-x)) - y) * inv;
+  }
+  float box = 0.f;
+  for (int i = threadIdx.x; i < Pn * 4; i += 256) {
+    const int64_t a = pos_inds[i >> 2];
+    float g;
+    box += smooth_l1_term(box_regression[a * 4 + (i & 3)], targets_pos[i], beta, &g);
+    g_reg[a * 4 + (i & 3)] = g * inv;
+  }
+  bce = block_sum_256(bce, red);
+  box = block_sum_256(box, red);
+  if (threadIdx.x == 0) {
+    losses[0] = bce * inv;   // mean over the sampled anchors
+    losses[1] = box * inv;   // sum over positives / number of sampled anchors (rpn/loss.py:131-136)
+  }
+}
+
+// class_logits [R][C], box_regression [R][4*Cb]; src rows (source-domain ROIs) with their labels; positives with their
+// 4 regression columns (map_inds) and targets
+__global__ __launch_bounds__(256) void frcnn_loss_kernel(const float* __restrict__ class_logits,
+                                                         const float* __restrict__ box_regression, int C,
+                                                         int reg_cols, const int64_t* __restrict__ src,
+                                                         const int64_t* __restrict__ labels_src, int Ns,
+                                                         const int64_t* __restrict__ rows_pos,
+                                                         const int64_t* __restrict__ map_inds,
+                                                         const float* __restrict__ targets_pos, int Pn,
+                                                         float* __restrict__ losses, float* __restrict__ g_cls,
+                                                         float* __restrict__ g_reg) {
+  __shared__ float red[4];
+  const float inv = Ns > 0 ? 1.f / (float)Ns : 0.f;
+  float ce = 0.f;
+  for (int i = threadIdx.x; i < Ns; i += 256) {
+    const int64_t r = src[i];
+    const float* x = class_logits + r * C;
+    float m = x[0];
+    for (int c = 1; c < C; ++c) m = fmaxf(m, x[c]);
+    float z = 0.f;
+    for (int c = 0; c < C; ++c) z += expf(x[c] - m);
+    const float lse = m + logf(z);
+    const int lab = (int)labels_src[i];
+    ce += lse - x[lab];
+    for (int c = 0; c < C; ++c) g_cls[r * C + c] = (expf(x[c] - lse) - (c == lab ? 1.f : 0.f)) * inv;
+  }
+  float box = 0.f;
+  for (int i = threadIdx.x; i < Pn * 4; i += 256) {
+    const int64_t r = rows_pos[i >> 2];
+    const int64_t col = map_inds[i];
+    float g;
+    box += smooth_l1_term(box_regression[r * reg_cols + col], targets_pos[i], 1.f, &g);
+    g_reg[r * reg_cols + col] = g * inv;
+  }
+  ce = block_sum_256(ce, red);
+  box = block_sum_256(box, red);
+  if (threadIdx.x == 0) {
+    losses[0] = ce * inv;    // mean over the source-domain rows
+    losses[1] = box * inv;   // sum over positives / number of source-domain rows (box_head/loss.py:213-219)
+  }
+}
+
+}  // namespace dadet
+
+using namespace dadet;
+
+extern "C" int dadet_rpn_loss(const float* objectness, const float* box_regression, const int64_t* sampled_inds,
+                              const float* labels_sampled, int num_sampled, const int64_t* pos_inds,
+                              const float* regression_targets_pos, int num_pos, float beta, float* losses_out,
+                              float* grad_objectness, float* grad_box_regression, void* stream) {
+  DADET_REQUIRE(num_sampled >= 0 && num_pos >= 0, "rpn_loss: negative count");
+  DADET_REQUIRE(objectness && box_regression && losses_out && grad_objectness && grad_box_regression,
+                "rpn_loss: null pointer");
+  DADET_REQUIRE(num_sampled == 0 || (sampled_inds && labels_sampled), "rpn_loss: null sample arrays");
+  DADET_REQUIRE(num_pos == 0 || (pos_inds && regression_targets_pos), "rpn_loss: null positive arrays");
+  hipLaunchKernelGGL(rpn_loss_kernel, dim3(1), dim3(256), 0, as_stream(stream), objectness, box_regression,
+                     sampled_inds, labels_sampled, num_sampled, pos_inds, regression_targets_pos, num_pos, beta,
+                     losses_out, grad_objectness, grad_box_regression);
+  return check_launch("rpn_loss");
+}
+
+extern "C" int dadet_fast_rcnn_loss(const float* class_logits, const float* box_regression, int num_classes,
+                                    int reg_cols, const int64_t* src_rows, const int64_t* labels_src, int num_src,
+                                    const int64_t* rows_pos, const int64_t* map_inds,
+                                    const float* regression_targets_pos, int num_pos, float* losses_out,
+                                    float* grad_class_logits, float* grad_box_regression, void* stream) {
+  DADET_REQUIRE(num_src >= 0 && num_pos >= 0 && num_classes > 0 && reg_cols > 0, "fast_rcnn_loss: bad counts");
+  DADET_REQUIRE(class_logits && box_regression && losses_out && grad_class_logits && grad_box_regression,
+                "fast_rcnn_loss: null pointer");
+  DADET_REQUIRE(num_src == 0 || (src_rows && labels_src), "fast_rcnn_loss: null source arrays");
+  DADET_REQUIRE(num_pos == 0 || (rows_pos && map_inds && regression_targets_pos), "fast_rcnn_loss: null positives");
+  hipLaunchKernelGGL(frcnn_loss_kernel, dim3(1), dim3(256), 0, as_stream(stream), class_logits, box_regression,
+                     num_classes, reg_cols, src_rows, labels_src, num_src, rows_pos, map_inds,
+                     regression_targets_pos, num_pos, losses_out, grad_class_logits, grad_box_regression);
+  return check_launch("fast_rcnn_loss");
+}

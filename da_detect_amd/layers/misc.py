@@ -110,6 +110,44 @@ def smooth_l1_loss(input, target, beta=1.0 / 9, size_average=True):
     return loss.mean() if size_average else loss.sum()
 
 
+class _RPNLoss(Function):
+    """(loss_objectness, loss_rpn_box_reg) of one level with the gradients produced by the same launch"""
+
+    @staticmethod
+    def forward(ctx, objectness, box_regression, sampled_inds, labels_sampled, pos_inds, targets_pos, beta):
+        losses, g_obj, g_reg = _C.rpn_loss(objectness, box_regression, sampled_inds, labels_sampled, pos_inds,
+                                           targets_pos, beta)
+        ctx.save_for_backward(g_obj, g_reg)
+        return losses[0], losses[1]
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g0, g1):
+        g_obj, g_reg = ctx.saved_tensors
+        return g_obj * g0, g_reg * g1, None, None, None, None, None
+
+
+class _FastRCNNLoss(Function):
+    """(classification_loss, box_loss) with the gradients produced by the same launch"""
+
+    @staticmethod
+    def forward(ctx, class_logits, box_regression, src, labels_src, rows_pos, map_inds, targets_pos):
+        losses, g_cls, g_reg = _C.fast_rcnn_loss(class_logits, box_regression, src, labels_src, rows_pos, map_inds,
+                                                 targets_pos)
+        ctx.save_for_backward(g_cls, g_reg)
+        return losses[0], losses[1]
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g0, g1):
+        g_cls, g_reg = ctx.saved_tensors
+        return g_cls * g0, g_reg * g1, None, None, None, None, None
+
+
+rpn_loss_fused = _RPNLoss.apply
+fast_rcnn_loss_fused = _FastRCNNLoss.apply
+
+
 def consistency_loss(img_feas, ins_fea, ins_labels, size_average=True):
     """|mean_hw(p_img_i) - p_ins_ij| (layers/consistency_loss.py:3-27).  `img_feas` is a list of per-level
     [N,1,H,W] probability maps, or (fused path) of per-level [N] tensors that already hold the spatial mean."""

@@ -5,6 +5,7 @@ from torch.nn import functional as F
 
 from .... import _C
 from ....layers import smooth_l1_loss
+from ....layers.misc import fast_rcnn_loss_fused
 from ....structures.bounding_box import is_source_image
 from ....structures.boxlist_ops import boxlist_iou
 from ...balanced_positive_negative_sampler import BalancedPositiveNegativeSampler
@@ -130,6 +131,11 @@ class FastRCNNLossComputation(object):
             raise RuntimeError("subsample needs to be called before")
         prep = self._loss_prep
         labels = prep["labels_src"]
+        if class_logits.is_cuda and not self.cls_agnostic_bbox_reg:
+            cls_loss, box_loss = fast_rcnn_loss_fused(class_logits, box_regression, prep["src"], labels,
+                                                      prep["rows_pos"].reshape(-1), prep["map_inds"],
+                                                      prep["regression_targets_pos"])
+            return cls_loss, box_loss, prep["domain_masks"]
         classification_loss = F.cross_entropy(class_logits.index_select(0, prep["src"]), labels)
         box_loss = smooth_l1_loss(box_regression[prep["rows_pos"], prep["map_inds"]], prep["regression_targets_pos"],
                                   size_average=False, beta=1)

@@ -7,6 +7,7 @@ import torch
 from torch.nn import functional as F
 
 from ...layers import smooth_l1_loss
+from ...layers.misc import rpn_loss_fused
 from ...structures.bounding_box import is_source_image
 from ...structures.boxlist_ops import boxlist_iou, cat_boxlist
 from ..balanced_positive_negative_sampler import BalancedPositiveNegativeSampler
@@ -70,6 +71,11 @@ class RPNLossComputation(object):
 
     def finish(self, objectness, box_regression, prep):
         """the part that needs the predictions (loss.py:125-143); no host synchronisation"""
+        if len(objectness) == 1 and objectness[0].is_cuda:
+            # one level: the flattening of concat_box_prediction_layers IS the NHWC map's memory order, so the fused
+            # kernel indexes the head's outputs directly (no permute / gather / elementwise chain, forward or backward)
+            return rpn_loss_fused(objectness[0], box_regression[0], prep["sampled_inds"], prep["labels_sampled"],
+                                  prep["pos_inds"], prep["regression_targets_pos"], 1.0 / 9)
         objectness, box_regression = concat_box_prediction_layers(objectness, box_regression)
         objectness = objectness.squeeze()
         pos_inds, sampled_inds = prep["pos_inds"], prep["sampled_inds"]

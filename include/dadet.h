@@ -177,6 +177,24 @@ int dadet_roi_pool_forward(const float* input, const float* rois, float* output,
 int dadet_roi_pool_backward(const float* grad_output, const int* argmax, const float* rois, float* grad_input, int B,
                             int C, int H, int W, int R, int pooled_h, int pooled_w, void* stream);
 
+/* Fused detection losses: value and gradient in one single-workgroup launch (losses.hip).
+ * dadet_rpn_loss replaces RPNLossComputation.__call__'s loss part (modeling/rpn/loss.py:125-143): objectness /
+ * box_regression are the flattened NHWC prediction maps ([N*H*W*A] and [N*H*W*A][4], the order of
+ * concat_box_prediction_layers, rpn/utils.py:17-43, for one level); losses_out[0] = BCE-with-logits mean over the
+ * sampled anchors, losses_out[1] = smooth-L1(beta) sum over positives / num_sampled.  The gradient maps must be
+ * zero-filled by the caller; the kernel writes d(loss0 + loss1)/d(prediction) at the sampled positions.
+ * dadet_fast_rcnn_loss replaces FastRCNNLossComputation.__call__ (modeling/roi_heads/box_head/loss.py:165-221):
+ * losses_out[0] = cross-entropy mean over the source-domain rows, losses_out[1] = smooth-L1(beta 1) over the
+ * positives' class columns / num_src; map_inds [num_pos][4] are the regression columns of each positive. */
+int dadet_rpn_loss(const float* objectness, const float* box_regression, const int64_t* sampled_inds,
+                   const float* labels_sampled, int num_sampled, const int64_t* pos_inds,
+                   const float* regression_targets_pos, int num_pos, float beta, float* losses_out,
+                   float* grad_objectness, float* grad_box_regression, void* stream);
+int dadet_fast_rcnn_loss(const float* class_logits, const float* box_regression, int num_classes, int reg_cols,
+                         const int64_t* src_rows, const int64_t* labels_src, int num_src, const int64_t* rows_pos,
+                         const int64_t* map_inds, const float* regression_targets_pos, int num_pos,
+                         float* losses_out, float* grad_class_logits, float* grad_box_regression, void* stream);
+
 /* Box-head target assignment in one launch: IoU of every proposal with the G ground-truth boxes, Matcher without
  * low-quality matches, label rules and regression targets — replaces the ATen chain boxlist_iou
  * (structures/boxlist_ops.py:56-91) -> Matcher.__call__ (modeling/matcher.py:42-92) -> prepare_targets label rules

@@ -457,3 +457,62 @@ def test_box_match_encode_matches_the_aten_chain(device, P, G, high, low):
     m, lab, reg = _C.box_match_encode(props.to(device), gts.to(device), gl.to(device), high, low, weights)
     assert m.dtype == torch.int64 and torch.equal(m.cpu(), want_m) and torch.equal(lab.cpu(), want_lab)
     torch.testing.assert_close(reg.cpu(), want_reg, rtol=1e-5, atol=1e-6)
+
+
+# --------------------------------------------------------------------------------- fused detection losses
+def test_fused_rpn_loss_matches_torch(device):
+    import torch.nn.functional as F
+
+    from da_detect_amd.layers.misc import rpn_loss_fused, smooth_l1_loss
+
+    g = torch.Generator().manual_seed(0)
+    N, A, H, W = 2, 15, 12, 20
+    obj = (torch.randn(N, A, H, W, generator=g) * 3).to(device).contiguous(memory_format=torch.channels_last)
+    reg = torch.randn(N, 4 * A, H, W, generator=g).to(device).contiguous(memory_format=torch.channels_last)
+    total = N * A * H * W
+    perm = torch.randperm(total, generator=g)
+    pos, neg = perm[:70].sort().values.to(device), perm[70:256].sort().values.to(device)
+    sampled = torch.cat([pos, neg])
+    labels = torch.cat([torch.ones(70), torch.zeros(186)]).to(device)
+    tgt = (torch.randn(70, 4, generator=g) * 0.3).to(device)
+    a, b = obj.clone().requires_grad_(True), reg.clone().requires_grad_(True)
+    l0, l1 = rpn_loss_fused(a, b, sampled, labels, pos, tgt, 1.0 / 9)
+    (2.0 * l0 + 0.5 * l1).backward()
+    c, d = obj.clone().requires_grad_(True), reg.clone().requires_grad_(True)
+    flat_o = c.permute(0, 2, 3, 1).reshape(-1)
+    flat_r = d.view(N, A, 4, H, W).permute(0, 3, 4, 1, 2).reshape(-1, 4)
+    w0 = F.binary_cross_entropy_with_logits(flat_o[sampled], labels)
+    w1 = smooth_l1_loss(flat_r[pos], tgt, beta=1.0 / 9, size_average=False) / sampled.numel()
+    (2.0 * w0 + 0.5 * w1).backward()
+    torch.testing.assert_close(l0, w0, rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(l1, w1, rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(a.grad, c.grad, rtol=1e-5, atol=1e-7)
+    torch.testing.assert_close(b.grad, d.grad, rtol=1e-5, atol=1e-7)
+
+
+def test_fused_fast_rcnn_loss_matches_torch(device):
+    import torch.nn.functional as F
+
+    from da_detect_amd.layers.misc import fast_rcnn_loss_fused, smooth_l1_loss
+
+    g = torch.Generator().manual_seed(1)
+    R, C = 512, 9
+    logits = (torch.randn(R, C, generator=g) * 2).to(device)
+    reg = torch.randn(R, 4 * C, generator=g).to(device)
+    src = torch.arange(0, 256, device=device)                       # source-domain rows
+    labels = torch.randint(0, C, (256,), generator=g).to(device)
+    pos = torch.nonzero(labels > 0).squeeze(1)
+    map_inds = 4 * labels[pos][:, None] + torch.tensor([0, 1, 2, 3], device=device)
+    tgt = (torch.randn(pos.numel(), 4, generator=g) * 0.5).to(device)
+    a, b = logits.clone().requires_grad_(True), reg.clone().requires_grad_(True)
+    l0, l1 = fast_rcnn_loss_fused(a, b, src, labels, src[pos], map_inds, tgt)
+    (l0 + 3.0 * l1).backward()
+    c, d = logits.clone().requires_grad_(True), reg.clone().requires_grad_(True)
+    w0 = F.cross_entropy(c.index_select(0, src), labels)
+    w1 = smooth_l1_loss(d[src[pos][:, None], map_inds], tgt, size_average=False, beta=1) / labels.numel()
+    (w0 + 3.0 * w1).backward()
+    torch.testing.assert_close(l0, w0, rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(l1, w1, rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(a.grad, c.grad, rtol=1e-5, atol=1e-7)
+    torch.testing.assert_close(b.grad, d.grad, rtol=1e-5, atol=1e-7)
+    assert float(a.grad[256:].abs().sum()) == 0.0                    # target-domain rows get no detection gradient
