@@ -11,13 +11,19 @@ import contextlib
 
 import torch
 
+import os
+
 _SIDE = {}
+_HIGH_PRIORITY = os.environ.get("DADET_SIDE_PRIORITY", "1") == "1"
 
 
 def side_stream(device, which=0):
     key = (device.type, device.index, which)
     if key not in _SIDE:
-        _SIDE[key] = torch.cuda.Stream(device)
+        # streams 0 / 1 carry the latency-bound bookkeeping (single-workgroup NMS sweeps, sampling): high priority, so
+        # their workgroups are dispatched ahead of the GEMM waves they run beside; the weight-gradient lane (2) is not
+        prio = -1 if (which < 2 and _HIGH_PRIORITY) else 0
+        _SIDE[key] = torch.cuda.Stream(device, priority=prio)
     return _SIDE[key]
 
 
