@@ -135,11 +135,14 @@ def _workspace(nbytes, device):
 # reference `_C` surface
 # ------------------------------------------------------------------------------------------------
 def nms_with_count(dets, scores, threshold, max_keep=-1, tie_rule=None):
-    """device-resident result: (keep_buffer int64[n], num_keep int32[1]); no host sync."""
-    _dev(dets, "dets"), _dev(scores, "scores")
+    """device-resident result: (keep_buffer int64[n], num_keep int32[1]); no host sync.
+    scores=None: `dets` are already ranked best-first (the internal ranking pass is skipped)."""
+    _dev(dets, "dets")
     n = dets.shape[0]
     dets = dets.contiguous()
-    scores = scores.contiguous()
+    if scores is not None:
+        _dev(scores, "scores")
+        scores = scores.contiguous()
     keep = torch.empty(n, dtype=torch.int64, device=dets.device)
     count = torch.empty(1, dtype=torch.int32, device=dets.device)
     nbytes = ctypes.c_size_t(0)

@@ -233,7 +233,7 @@ __global__ void nms_flag_kernel(const unsigned long long* __restrict__ keep_bits
   const int i = blockIdx.x * blockDim.x + threadIdx.x;  // sorted position
   if (i >= n) return;
   const bool kept = (keep_bits[i >> 6] >> (i & 63)) & 1ULL;
-  flag[order[i]] = kept ? 1 : 0;
+  flag[order ? order[i] : i] = kept ? 1 : 0;
 }
 
 __global__ __launch_bounds__(1024) void nms_compact_kernel(const unsigned char* __restrict__ flag, int n,
@@ -313,7 +313,8 @@ extern "C" int dadet_nms(const float* boxes_xyxy, const float* scores, int n, fl
     (void)hipMemsetAsync(num_keep_out, 0, sizeof(int), st);
     return check_launch("nms(empty)");
   }
-  DADET_REQUIRE(boxes_xyxy && scores && keep_out && workspace, "nms: null pointer");
+  DADET_REQUIRE(boxes_xyxy && keep_out && workspace, "nms: null pointer");
+  const bool presorted = scores == nullptr;   // boxes already ranked by the caller (e.g. the RPN's top-k sort)
   DADET_REQUIRE(tie_rule == 0 || tie_rule == 1, "nms: tie_rule must be 0 (>=) or 1 (>)");
   DADET_REQUIRE((reinterpret_cast<uintptr_t>(boxes_xyxy) & 15) == 0, "nms: boxes must be 16-byte aligned");
   const int col_blocks = ceil_div(n, 64);
@@ -331,7 +332,10 @@ extern "C" int dadet_nms(const float* boxes_xyxy, const float* scores, int n, fl
   unsigned char* flag = reinterpret_cast<unsigned char*>(base + ws.flag_off);
 
   const int p2 = next_pow2(n);
-  if (p2 <= kSortLdsMax) {
+  if (presorted) {
+    order = nullptr;
+    sorted = const_cast<float4*>(reinterpret_cast<const float4*>(boxes_xyxy));
+  } else if (p2 <= kSortLdsMax) {
     const int threads = p2 / 2 >= 1024 ? 1024 : (p2 / 2 < 64 ? 64 : p2 / 2);
     const size_t lds = sizeof(Key) * (size_t)p2;
     if (lds > 48 * 1024) {
@@ -353,8 +357,9 @@ extern "C" int dadet_nms(const float* boxes_xyxy, const float* scores, int n, fl
                            size, stride);
     hipLaunchKernelGGL(nms_sort_finish_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, st, keys, n, order);
   }
-  hipLaunchKernelGGL(nms_gather_boxes_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, st,
-                     reinterpret_cast<const float4*>(boxes_xyxy), order, n, sorted);
+  if (!presorted)
+    hipLaunchKernelGGL(nms_gather_boxes_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, st,
+                       reinterpret_cast<const float4*>(boxes_xyxy), order, n, sorted);
   const dim3 mgrid(col_blocks, col_blocks);
   if (tie_rule == 0)
     hipLaunchKernelGGL(nms_mask_kernel<0>, mgrid, dim3(64), 0, st, sorted, n, thresh, col_blocks, mask);

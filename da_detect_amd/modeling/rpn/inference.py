@@ -78,7 +78,9 @@ class RPNPostProcessor(torch.nn.Module):
                     boxes, scores = boxes[keep].contiguous(), scores[keep].contiguous()
                 keep = count = None
                 if self.nms_thresh > 0:
-                    keep, count = _C.nms_with_count(boxes, scores, self.nms_thresh, max_keep=self.post_nms_top_n)
+                    # boxes arrive in the order of the stable descending score sort above: NMS needs no ranking pass
+                    # (a min_size filter keeps the relative order too)
+                    keep, count = _C.nms_with_count(boxes, None, self.nms_thresh, max_keep=self.post_nms_top_n)
             pending.append((boxes, scores, keep, count, (im_w, im_h)))
         if use_side:
             record([p[:4] for p in pending[1::2]], main)

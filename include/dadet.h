@@ -57,6 +57,8 @@ int dadet_device_info(int* cu_count, int* clock_khz, size_t* hbm_bytes, char* ar
  *               structures/boxlist_ops.py:30-31, when the input is already score-sorted as in the RPN).
  *   keep_out  : int64[n] device; num_keep_out: int32[1] device.
  * ----------------------------------------------------------------------------------------------*/
+/* scores == NULL: the boxes are already ranked (best first) by the caller — e.g. the RPN's stable top-k sort,
+ * rpn/inference.py:88-101 — and the internal ranking pass is skipped; kept indices are positions in that order. */
 int dadet_nms_workspace_bytes(int n, size_t* bytes_out);
 int dadet_nms(const float* boxes_xyxy, const float* scores, int n, float thresh, int tie_rule,
               int max_keep, void* workspace, size_t workspace_bytes, int64_t* keep_out,

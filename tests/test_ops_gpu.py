@@ -516,3 +516,16 @@ def test_fused_fast_rcnn_loss_matches_torch(device):
     torch.testing.assert_close(a.grad, c.grad, rtol=1e-5, atol=1e-7)
     torch.testing.assert_close(b.grad, d.grad, rtol=1e-5, atol=1e-7)
     assert float(a.grad[256:].abs().sum()) == 0.0                    # target-domain rows get no detection gradient
+
+
+def test_nms_presorted_equals_ranked(device):
+    """scores=None: the caller's order is the ranking (RPN top-k output) — same kept set as the ranked call"""
+    from da_detect_amd import _C
+
+    rng = np.random.default_rng(11)
+    boxes = torch.from_numpy(_rand_boxes(rng, 5000)).to(device)
+    scores = torch.from_numpy(np.sort(rng.uniform(0, 1, 5000).astype(np.float32))[::-1].copy()).to(device)
+    for max_keep in (-1, 300):
+        k0, c0 = _C.nms_with_count(boxes, scores, 0.7, max_keep=max_keep)
+        k1, c1 = _C.nms_with_count(boxes, None, 0.7, max_keep=max_keep)
+        assert int(c0) == int(c1) and torch.equal(k0[: int(c0)], k1[: int(c1)])
