@@ -37,6 +37,21 @@ GEMM_MODES = {
 }
 
 
+WORKLOADS = {
+    # name: (yaml, overrides, images per GPU per step, description)
+    "img_only": (YAML, [], 2, "R-50-C4, image-level DA head only, 1 source + 1 target"),
+    "da": ("configs/da_faster_rcnn/e2e_da_faster_rcnn_R_50_C4_cityscapes_to_foggy_cityscapes.yaml", [], 2,
+           "R-50-C4, image + instance DA heads + consistency, 1 source + 1 target"),
+    "triplet": ("configs/da_faster_rcnn/e2e_triplet_da_faster_rcnn_R_50_C4_cityscapes_to_foggy_cityscapes.yaml", [],
+                3, "R-50-C4 triplet recipe as shipped (AdvGRL, image triplet), source + foggy + rainy"),
+    "triplet_aligned": ("configs/da_faster_rcnn/e2e_triplet_da_faster_rcnn_R_50_C4_cityscapes_to_foggy_cityscapes.yaml",
+                        ["MODEL.DA_HEADS.ALIGNMENT", True, "MODEL.DA_HEADS.DA_TRIPLET_INS_WEIGHT", 1.0], 3,
+                        "R-50-C4 triplet recipe with ALIGNMENT (3 extra box-head passes) + instance triplet"),
+    "fpn_dcn_da": ("configs/da_faster_rcnn/e2e_da_faster_rcnn_R_101_FPN_DCN_cityscapes_to_foggy_cityscapes.yaml", [],
+                   2, "R-101-FPN + DCN (res3-5) + DA heads over the pyramid, 1 source + 1 target"),
+}
+
+
 def benchmark_init(model, seed):
     """seeded variance-preserving random init (no network for the MSRA R-50 pickle): He-normal conv weights,
     identity FrozenBN statistics, the last BN of every bottleneck scaled by 0.25 so that 16 un-normalised
@@ -60,7 +75,7 @@ def benchmark_init(model, seed):
             mod._cache = None
 
 
-def build(cfg_path, device, seed):
+def build(cfg_path, device, seed, overrides=()):
     from da_detect_amd.config import cfg
     from da_detect_amd.modeling.detector import build_detection_model
     from da_detect_amd.parallel.reducer import BucketedGradReducer
@@ -68,6 +83,8 @@ def build(cfg_path, device, seed):
 
     c = cfg.clone()
     c.merge_from_file(os.path.join(ROOT, cfg_path))
+    if overrides:
+        c.merge_from_list(list(overrides))
     torch.manual_seed(seed)
     model = build_detection_model(c)
     benchmark_init(model, seed)
@@ -112,6 +129,10 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
+    ap.add_argument("--workload", default="img_only", choices=sorted(WORKLOADS),
+                    help="img_only (default, BASELINE configs[1]) | da (configs[2]) | triplet (configs[3]) | "
+                         "triplet_aligned | fpn_dcn_da (configs[4]); non-default workloads are extra measurements")
+    ap.add_argument("--image-hw", default=None, help="HxW of the synthetic images (default 1024x2048)")
     ap.add_argument("--no-overlap", action="store_true", help="keep the RPN backward inside the main backward pass")
     ap.add_argument("--gemm-mode", type=int, default=int(os.environ.get("DADET_GEMM_MODE", "3")),
                     help="3: fp32 operands as 3 bf16 terms, 6 bf16 MFMAs per K=16 (fp32-class accuracy, default); "
@@ -139,9 +160,11 @@ def main():
     from da_detect_amd.engine.trainer import enable_overlapped_rpn_backward, train_step
 
     _C.set_gemm_mode(args.gemm_mode)
-    c, model, opt, reducer = build(YAML, device, seed=100)
+    yaml_path, overrides, images_per_gpu, workload_desc = WORKLOADS[args.workload]
+    height, width = (HEIGHT, WIDTH) if args.image_hw is None else [int(v) for v in args.image_hw.lower().split("x")]
+    c, model, opt, reducer = build(yaml_path, device, seed=100, overrides=overrides)
     enable_overlapped_rpn_backward(model, not args.no_overlap)
-    images, targets = make_batch(c, IMAGES_PER_GPU, HEIGHT, WIDTH, seed=100 + rank, device=device)
+    images, targets = make_batch(c, images_per_gpu, height, width, seed=100 + rank, device=device)
 
     def barrier():
         torch.cuda.synchronize()
@@ -195,7 +218,7 @@ def main():
     losses = {k: float(v.detach()) for k, v in loss_dict.items()}
 
     if rank == 0:
-        value = world * IMAGES_PER_GPU * args.steps / elapsed
+        value = world * images_per_gpu * args.steps / elapsed
         roofline = None
         kernels = {}
         if profiler is not None:
@@ -240,7 +263,7 @@ def main():
         cpu = None
         if not args.no_cpu_baseline and world == 1:
             try:
-                cpu = cpu_baseline(YAML, seed=100)
+                cpu = cpu_baseline(YAML, seed=100) if args.workload == "img_only" and args.image_hw is None else None
             except Exception as e:  # the baseline is reported, never required for the GPU number
                 cpu = {"value": None, "unit": "images/s", "cores": os.cpu_count(), "kind": "port",
                        "sample": "failed: %r" % (e,)}
@@ -250,9 +273,10 @@ def main():
             "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
             "data": "synthetic (seeded rand*255 - PIXEL_MEAN images, 8-20 seeded boxes/image, seeded random-init weights)",
-            "config": {"workload": "configs/da_faster_rcnn R-50-C4, image-level DA head only, 1 source + 1 target "
-                                   "1024x2048 image per GPU per step, 2x256 ROIs x 2 box-head passes, fwd+bwd+SGD",
-                       "yaml": YAML, "global_batch": world * IMAGES_PER_GPU, "image_hw": [HEIGHT, WIDTH],
+            "config": {"workload": "configs/da_faster_rcnn %s %dx%d image per GPU per step, 256 ROIs per image and "
+                                   "box-head pass, fwd+bwd+SGD" % (workload_desc, height, width),
+                       "yaml": yaml_path, "overrides": list(overrides), "global_batch": world * images_per_gpu,
+                       "image_hw": [height, width],
                        "parallelism": "dp%d" % world},
             "roofline": roofline, "cpu_baseline": cpu,
             "kernel_timing": {k: {"launches": v["launches"], "total_ms": round(v["total_ms"], 3),
