@@ -62,7 +62,8 @@ def benchmark_init(model, seed):
     g = torch.Generator().manual_seed(seed)
     for mod in model.modules():
         if isinstance(mod, Bottleneck):
-            convs = [mod.conv1, mod.conv2, mod.conv3] + ([mod.downsample[0]] if mod.downsample is not None else [])
+            conv2 = mod.conv2.conv if getattr(mod, "with_dcn", False) else mod.conv2   # DFConv2d wraps the 3x3
+            convs = [mod.conv1, conv2, mod.conv3] + ([mod.downsample[0]] if mod.downsample is not None else [])
             for conv in convs:
                 fan_in = conv.weight.shape[1] * conv.weight.shape[2] * conv.weight.shape[3]
                 w = torch.randn(conv.weight.shape, generator=g) * (2.0 / fan_in) ** 0.5
