@@ -9,10 +9,19 @@ from ...structures.bounding_box import is_source_image
 from .fused import triplet_margin_loss_w
 
 
+_LABEL_CACHE = {}
+
+
 def image_domain_labels(targets):
     """float [N]: 1 for source-domain images, 0 for target-domain images (loss.py:46-53 `prepare_masks`)"""
-    vals = [1.0 if is_source_image(t) else 0.0 for t in targets]
-    return torch.tensor(vals, dtype=torch.float32, device=targets[0].bbox.device)
+    # built from the host-side flags with ONE cached device tensor per flag pattern: torch.tensor(list, device=...)
+    # is a pageable host->device copy that blocks until the compute stream has drained
+    key = (tuple(bool(is_source_image(t)) for t in targets), str(targets[0].bbox.device))
+    lab = _LABEL_CACHE.get(key)
+    if lab is None:
+        lab = torch.tensor([1.0 if f else 0.0 for f in key[0]], dtype=torch.float32, device=targets[0].bbox.device)
+        _LABEL_CACHE[key] = lab
+    return lab
 
 
 def da_ins_loss(da_ins, da_ins_labels):

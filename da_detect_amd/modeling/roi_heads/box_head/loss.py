@@ -105,9 +105,9 @@ class FastRCNNLossComputation(object):
         pos = torch.nonzero(labels_src > 0).squeeze(1)
         labels_pos = labels_src[pos]
         if self.cls_agnostic_bbox_reg:
-            map_inds = torch.tensor([4, 5, 6, 7], device=labels.device)
+            map_inds = torch.arange(4, 8, device=labels.device)
         else:
-            map_inds = 4 * labels_pos[:, None] + torch.tensor([0, 1, 2, 3], device=labels.device)
+            map_inds = 4 * labels_pos[:, None] + torch.arange(4, device=labels.device)
         self._loss_prep = dict(domain_masks=domain_masks, src=src, labels_src=labels_src,
                                rows_pos=src[pos][:, None], map_inds=map_inds,
                                regression_targets_pos=regression_targets[src][pos])

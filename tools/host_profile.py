@@ -13,10 +13,11 @@ import torch  # noqa: E402
 import bench  # noqa: E402
 from da_detect_amd import _C  # noqa: E402
 from da_detect_amd.data.synthetic import make_batch  # noqa: E402
-from da_detect_amd.engine.trainer import train_step  # noqa: E402
+from da_detect_amd.engine.trainer import enable_overlapped_rpn_backward, train_step  # noqa: E402
 
 device = torch.device("cuda", 0)
 c, model, opt, reducer = bench.build(bench.YAML, device, seed=100)
+enable_overlapped_rpn_backward(model)
 images, targets = make_batch(c, 2, bench.HEIGHT, bench.WIDTH, seed=100, device=device)
 for _ in range(3):
     train_step(model, opt, images, targets)
