@@ -503,6 +503,21 @@ def fast_rcnn_loss(class_logits, box_regression, src, labels_src, rows_pos, map_
     return losses, g_cls, g_reg
 
 
+def rpn_anchor_targets(anchors, visible, gt_boxes, high_threshold, low_threshold):
+    """-> (labels float [A] in {1, 0, -1}, regression_targets [A,4]); see dadet_rpn_anchor_targets"""
+    _dev(anchors, "anchors"), _dev(gt_boxes, "gt_boxes")
+    anchors = anchors.contiguous().float()
+    gt_boxes = gt_boxes.contiguous().float()
+    vis = visible.contiguous().to(torch.uint8) if visible.dtype != torch.bool else visible.contiguous().view(torch.uint8)
+    A, G = anchors.shape[0], gt_boxes.shape[0]
+    ws = torch.empty(G, dtype=torch.int32, device=anchors.device)
+    labels = torch.empty(A, dtype=torch.float32, device=anchors.device)
+    targets = torch.empty((A, 4), dtype=torch.float32, device=anchors.device)
+    _lib.call("dadet_rpn_anchor_targets", _p(anchors), _p(vis), A, _p(gt_boxes), G, float(high_threshold),
+              float(low_threshold), _p(ws), _p(labels), _p(targets), _stream())
+    return labels, targets
+
+
 def box_match_encode(proposals, gt_boxes, gt_labels, high_threshold, low_threshold, weights):
     """-> (matched_idxs int64 [P], labels int64 [P], regression_targets [P,4]); see dadet_box_match_encode"""
     _dev(proposals, "proposals"), _dev(gt_boxes, "gt_boxes")

@@ -51,6 +51,7 @@ _SIGNATURES = {
     "dadet_deform_sample_backward": [_P, _P, _P, _P, _P, _P, _P] + [c_int] * 12 + [_P],
     "dadet_rpn_loss": [_P, _P, _P, _P, c_int, _P, _P, c_int, c_float, _P, _P, _P, _P],
     "dadet_fast_rcnn_loss": [_P, _P, c_int, c_int, _P, _P, c_int, _P, _P, _P, c_int, _P, _P, _P, _P],
+    "dadet_rpn_anchor_targets": [_P, _P, c_int, _P, c_int, c_float, c_float, _P, _P, _P, _P],
     "dadet_box_match_encode": [_P, c_int, _P, _P, c_int, c_float, c_float, c_float, c_float, c_float, c_float, _P, _P,
                                _P, _P],
     "dadet_roi_pool_forward": [_P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_float, _P],

@@ -207,6 +207,93 @@ __global__ void rpn_decode_clip_kernel(const float4* __restrict__ deltas, const 
   out[k] = make_float4(x1, y1, x2, y2);
 }
 
+// ---- RPN anchor labelling: IoU vs ground truth -> Matcher WITH low-quality matches -> labels -> encode ------------
+// reference chain: boxlist_iou (structures/boxlist_ops.py:56-91), Matcher(0.7, 0.3, allow_low_quality_matches=True)
+// (modeling/matcher.py:42-112), RPNLossComputation.prepare_targets label rules (modeling/rpn/loss.py:78-96: matched -> 1,
+// below-low -> 0, outside the image -> -1, between thresholds -> -1), BoxCoder(1,1,1,1).encode.  Two passes over the
+// anchors: (1) best IoU of every ground-truth box (atomicMax on the float's bit pattern, IoU >= 0), (2) the per-anchor
+// decision, where an anchor whose IoU with some box EQUALS that box's best keeps its argmax ("low-quality match").
+// Both passes evaluate the IoU with the same instruction sequence, so the equality test is exact.
+__device__ inline float iou_ref_order(const float4 g, float garea, const float4 p, float parea) {
+  const float w = fmaxf(fminf(g.z, p.z) - fmaxf(g.x, p.x) + 1.f, 0.f);
+  const float h = fmaxf(fminf(g.w, p.w) - fmaxf(g.y, p.y) + 1.f, 0.f);
+  const float inter = w * h;
+  return inter / (garea + parea - inter);
+}
+
+__global__ void rpn_gt_best_kernel(const float4* __restrict__ anchors, int A, const float4* __restrict__ gts, int G,
+                                   unsigned* __restrict__ best_bits) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float4* g_box = reinterpret_cast<float4*>(smem);
+  float* g_area = reinterpret_cast<float*>(g_box + G);
+  unsigned* g_best = reinterpret_cast<unsigned*>(g_area + G);
+  for (int g = threadIdx.x; g < G; g += blockDim.x) {
+    const float4 b = gts[g];
+    g_box[g] = b;
+    g_area[g] = (b.z - b.x + 1.f) * (b.w - b.y + 1.f);
+    g_best[g] = 0u;
+  }
+  __syncthreads();
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < A; i += gridDim.x * blockDim.x) {
+    const float4 p = anchors[i];
+    const float area = (p.z - p.x + 1.f) * (p.w - p.y + 1.f);
+    for (int g = 0; g < G; ++g) {
+      const float v = iou_ref_order(g_box[g], g_area[g], p, area);
+      if (v > 0.f) atomicMax(&g_best[g], __float_as_uint(v));
+    }
+  }
+  __syncthreads();
+  for (int g = threadIdx.x; g < G; g += blockDim.x)
+    if (g_best[g]) atomicMax(&best_bits[g], g_best[g]);
+}
+
+__global__ void rpn_anchor_targets_kernel(const float4* __restrict__ anchors, const unsigned char* __restrict__ visible,
+                                          int A, const float4* __restrict__ gts, int G,
+                                          const unsigned* __restrict__ best_bits, float high, float low,
+                                          float* __restrict__ labels, float4* __restrict__ targets) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float4* g_box = reinterpret_cast<float4*>(smem);
+  float* g_area = reinterpret_cast<float*>(g_box + G);
+  float* g_best = g_area + G;
+  for (int g = threadIdx.x; g < G; g += blockDim.x) {
+    const float4 b = gts[g];
+    g_box[g] = b;
+    g_area[g] = (b.z - b.x + 1.f) * (b.w - b.y + 1.f);
+    g_best[g] = __uint_as_float(best_bits[g]);
+  }
+  __syncthreads();
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= A) return;
+  const float4 p = anchors[i];
+  const float area = (p.z - p.x + 1.f) * (p.w - p.y + 1.f);
+  float best = -1.f;
+  int arg = 0;
+  bool low_quality = false;
+  for (int g = 0; g < G; ++g) {
+    const float v = iou_ref_order(g_box[g], g_area[g], p, area);
+    if (v > best) {
+      best = v;
+      arg = g;
+    }
+    low_quality = low_quality || (v == g_best[g]);
+  }
+  int m = arg;
+  if (best < low) m = -1;
+  else if (best < high) m = -2;
+  if (low_quality) m = arg;
+  float lab = m >= 0 ? 1.f : 0.f;
+  if (m == -1) lab = 0.f;
+  if (!visible[i]) lab = -1.f;
+  if (m == -2) lab = -1.f;
+  labels[i] = lab;
+  const float4 r = g_box[m < 0 ? 0 : m];
+  const float ew = p.z - p.x + 1.f, eh = p.w - p.y + 1.f;
+  const float ecx = p.x + 0.5f * ew, ecy = p.y + 0.5f * eh;
+  const float gw = r.z - r.x + 1.f, gh = r.w - r.y + 1.f;
+  const float gcx = r.x + 0.5f * gw, gcy = r.y + 0.5f * gh;
+  targets[i] = make_float4((gcx - ecx) / ew, (gcy - ecy) / eh, logf(gw / ew), logf(gh / eh));
+}
+
 // ---- box-head target assignment: IoU vs ground truth -> Matcher -> labels -> BoxCoder.encode, one launch --------
 // reference chain (each step a handful of ATen launches there): boxlist_iou (structures/boxlist_ops.py:56-91), Matcher
 // without low-quality matches (modeling/matcher.py:42-92), label rules of FastRCNNLossComputation.prepare_targets
@@ -462,6 +549,31 @@ extern "C" int dadet_rpn_decode_clip(const float* deltas, const float* anchors, 
                      topk_idx, K, wx, wy, ww, wh, xform_clip, im_w, im_h,
                      reinterpret_cast<float4*>(boxes_out));
   return check_launch("rpn_decode_clip");
+}
+
+extern "C" int dadet_rpn_anchor_targets(const float* anchors, const unsigned char* visible, int A,
+                                        const float* gt_boxes, int G, float high_threshold, float low_threshold,
+                                        unsigned* workspace_G, float* labels, float* regression_targets,
+                                        void* stream) {
+  DADET_REQUIRE(A >= 0 && G > 0, "rpn_anchor_targets: needs A >= 0 anchors and G > 0 ground-truth boxes");
+  if (A == 0) return DADET_OK;
+  DADET_REQUIRE(anchors && visible && gt_boxes && workspace_G && labels && regression_targets,
+                "rpn_anchor_targets: null pointer");
+  DADET_REQUIRE(aligned16(anchors) && aligned16(gt_boxes) && aligned16(regression_targets),
+                "rpn_anchor_targets: box pointers must be 16-byte aligned");
+  DADET_REQUIRE(G <= 3000, "rpn_anchor_targets: G=%d ground-truth boxes exceed the LDS table", G);
+  hipStream_t st = as_stream(stream);
+  (void)hipMemsetAsync(workspace_G, 0, sizeof(unsigned) * (size_t)G, st);
+  int blocks = ceil_div(A, 256);
+  if (blocks > kNumCU * 2) blocks = kNumCU * 2;
+  hipLaunchKernelGGL(rpn_gt_best_kernel, dim3(blocks), dim3(256), (size_t)G * 24, st,
+                     reinterpret_cast<const float4*>(anchors), A, reinterpret_cast<const float4*>(gt_boxes), G,
+                     workspace_G);
+  hipLaunchKernelGGL(rpn_anchor_targets_kernel, dim3(ceil_div(A, 256)), dim3(256), (size_t)G * 24, st,
+                     reinterpret_cast<const float4*>(anchors), visible, A, reinterpret_cast<const float4*>(gt_boxes),
+                     G, workspace_G, high_threshold, low_threshold, labels,
+                     reinterpret_cast<float4*>(regression_targets));
+  return check_launch("rpn_anchor_targets");
 }
 
 extern "C" int dadet_box_match_encode(const float* proposals, int P, const float* gt_boxes, const int64_t* gt_labels,

@@ -6,6 +6,7 @@ batch, which is only meaningful because source images come first (asserted here)
 import torch
 from torch.nn import functional as F
 
+from ... import _C
 from ...layers import smooth_l1_loss
 from ...layers.misc import rpn_loss_fused
 from ...structures.bounding_box import is_source_image
@@ -41,6 +42,18 @@ class RPNLossComputation(object):
                 seen_target_domain = True
                 continue
             assert not seen_target_domain, "source-domain images must precede target-domain images in a batch"
+            if (anchors_per_image.bbox.is_cuda and self.generate_labels_func is generate_rpn_labels
+                    and self.proposal_matcher.allow_low_quality_matches and not self.copied_fields
+                    and set(self.discard_cases) == {"not_visibility", "between_thresholds"}):
+                # IoU + matcher (with low-quality matches) + label rules + encode: two launches instead of ~100
+                if len(targets_per_image) == 0:
+                    raise ValueError("No ground-truth boxes available for one of the images during training")
+                lab, reg = _C.rpn_anchor_targets(anchors_per_image.bbox, anchors_per_image.get_field("visibility"),
+                                                 targets_per_image.bbox, self.proposal_matcher.high_threshold,
+                                                 self.proposal_matcher.low_threshold)
+                labels.append(lab)
+                regression_targets.append(reg)
+                continue
             matched = self.match_targets_to_anchors(anchors_per_image, targets_per_image, self.copied_fields)
             matched_idxs = matched.get_field("matched_idxs")
             lab = self.generate_labels_func(matched).to(dtype=torch.float32)

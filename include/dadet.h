@@ -197,6 +197,15 @@ int dadet_fast_rcnn_loss(const float* class_logits, const float* box_regression,
                          const int64_t* map_inds, const float* regression_targets_pos, int num_pos,
                          float* losses_out, float* grad_class_logits, float* grad_box_regression, void* stream);
 
+/* RPN anchor labelling in two launches: replaces boxlist_iou + Matcher(high, low, allow_low_quality_matches=True) +
+ * the label rules of RPNLossComputation.prepare_targets (modeling/rpn/loss.py:57-98, modeling/matcher.py:42-112) +
+ * BoxCoder((1,1,1,1)).encode.  visible[a] != 0: anchor inside the image.  labels: 1 matched, 0 below the low threshold,
+ * -1 ignored (outside the image, or between the thresholds); anchors holding some ground-truth box's best IoU keep
+ * their argmax match.  workspace_G: G uint32 scratch words. */
+int dadet_rpn_anchor_targets(const float* anchors, const unsigned char* visible, int A, const float* gt_boxes, int G,
+                             float high_threshold, float low_threshold, unsigned* workspace_G, float* labels,
+                             float* regression_targets, void* stream);
+
 /* Box-head target assignment in one launch: IoU of every proposal with the G ground-truth boxes, Matcher without
  * low-quality matches, label rules and regression targets — replaces the ATen chain boxlist_iou
  * (structures/boxlist_ops.py:56-91) -> Matcher.__call__ (modeling/matcher.py:42-92) -> prepare_targets label rules

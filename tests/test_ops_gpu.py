@@ -529,3 +529,28 @@ def test_nms_presorted_equals_ranked(device):
         k0, c0 = _C.nms_with_count(boxes, scores, 0.7, max_keep=max_keep)
         k1, c1 = _C.nms_with_count(boxes, None, 0.7, max_keep=max_keep)
         assert int(c0) == int(c1) and torch.equal(k0[: int(c0)], k1[: int(c1)])
+
+
+@pytest.mark.parametrize("A,G", [(20000, 14), (3000, 1), (122880, 20)])
+def test_rpn_anchor_targets_match_the_aten_chain(device, A, G):
+    """two-launch anchor labelling vs the reference-order chain on the CPU (boxlist_iou, Matcher with low-quality
+    matches, rpn/loss.py:78-96 label rules, BoxCoder(1,1,1,1).encode) — labels bit-exact, targets to 1e-5"""
+    from da_detect_amd import _C
+    from oracle import model_ref as M
+
+    rng = np.random.default_rng(A + G)
+    anchors = torch.from_numpy(_rand_boxes(rng, A, max_side=600))
+    anchors[:, :2] -= 30.0                                # some anchors stick out of the image
+    gts = torch.from_numpy(_rand_boxes(rng, G, max_side=500))
+    anchors[5] = gts[0]                                   # one exact match
+    vis = (anchors[:, 0] >= 0) & (anchors[:, 1] >= 0) & (anchors[:, 2] < 2048) & (anchors[:, 3] < 1024)
+    iou = M.box_iou(gts, anchors)
+    m = M.matcher(iou, 0.7, 0.3, True)
+    want = (m >= 0).float()
+    want[m == M.BELOW_LOW] = 0
+    want[~vis] = -1
+    want[m == M.BETWEEN] = -1
+    want_reg = M.encode(gts[m.clamp(min=0)], anchors, (1.0, 1.0, 1.0, 1.0))
+    lab, reg = _C.rpn_anchor_targets(anchors.to(device), vis.to(device), gts.to(device), 0.7, 0.3)
+    assert torch.equal(lab.cpu(), want) and int((want == 1).sum()) >= G
+    torch.testing.assert_close(reg.cpu(), want_reg, rtol=1e-5, atol=1e-6)
