@@ -282,41 +282,55 @@ __global__ __launch_bounds__(256) void roi_align_bwd_gather_kernel(
   }
 }
 
-// ---- backward, gather form with per-pixel contribution lists ------------------------------------------------
-// Same mathematics and the same summation order (ROI ascending, sample row, sample column) as
-// roi_align_bwd_gather_kernel, but the wave-uniform coordinate / weight arithmetic is no longer executed by all
-// 256 lanes for every ROI: per range of 256 ROIs the lanes test one ROI each, the touching ones are compacted in
-// order, then ONE LANE PER ROI lists that ROI's non-zero contributions (row of the output gradient, weight, sample
-// count) into LDS, and finally all lanes stream over the list: one 16-byte load and four FMAs per entry and lane.
+// ---- backward, gather form with contribution lists over 2x2 pixel tiles ----------------------------------------
+// Same mathematics as roi_align_bwd_gather_kernel (every pixel sums its contributions in the order ROI ascending,
+// sample row, sample column).  Two things change the cost:
+//  * a bilinear sample lands on a 2x2 block of pixels, so a one-pixel workgroup re-reads every output-gradient row
+//    up to four times (PMC: 1.5 GB fetched for 411 MB of gradient).  Here a workgroup owns a 2x2 pixel tile and a
+//    row is loaded once for all the tile pixels it reaches;
+//  * the wave-uniform coordinate / weight arithmetic is not executed by all 256 lanes for every ROI: per range of
+//    256 ROIs the lanes test one ROI each, the touching ones are compacted in order, ONE LANE PER ROI lists that
+//    ROI's non-zero contributions into LDS, and all lanes then stream over the list.
 struct Contribution {
-  int row;       // (r * pooled_h + ph) * pooled_w + pw
-  float w;       // wy * wx
-  float count;   // samples per bin of that ROI
-  int pad;
+  int row;        // (r * pooled_h + ph) * pooled_w + pw
+  float count;    // samples per bin of that ROI
+  float w[4];     // wy * wx for the tile pixels (y0,x0) (y0,x0+1) (y0+1,x0) (y0+1,x0+1)
+  int pad[2];
 };
-constexpr int kListCap = 2048;   // entries per round (32 KB of LDS)
+constexpr int kListCap = 1024;   // entries per round (32 KB of LDS)
 
-__device__ inline int roi_contributions(const RoiGeom& g, int r, int H, int W, int pooled_h, int pooled_w, int y, int x,
-                                        Contribution* out) {
-  int sy0, sy1, sx0, sx1, n = 0;
-  candidate_range(g.start_h, g.bin_h, g.grid_h, pooled_h, y, &sy0, &sy1);
-  candidate_range(g.start_w, g.bin_w, g.grid_w, pooled_w, x, &sx0, &sx1);
+__device__ inline int roi_contributions(const RoiGeom& g, int r, int H, int W, int pooled_h, int pooled_w, int y0,
+                                        int x0, Contribution* out) {
+  int sy0, sy1, sx0, sx1, lo, hi, n = 0;
+  candidate_range(g.start_h, g.bin_h, g.grid_h, pooled_h, y0, &sy0, &hi);
+  candidate_range(g.start_h, g.bin_h, g.grid_h, pooled_h, y0 + 1, &lo, &sy1);
+  candidate_range(g.start_w, g.bin_w, g.grid_w, pooled_w, x0, &sx0, &hi);
+  candidate_range(g.start_w, g.bin_w, g.grid_w, pooled_w, x0 + 1, &lo, &sx1);
   for (int sy = sy0; sy <= sy1; ++sy) {
     const int ph = sy / g.grid_h, iy = sy - ph * g.grid_h;
-    const float wy = axis_weight(sample_coord(g.start_h, ph, g.bin_h, iy, g.grid_h), H, y);
-    if (wy == 0.f) continue;
+    const float cy = sample_coord(g.start_h, ph, g.bin_h, iy, g.grid_h);
+    const float wy0 = axis_weight(cy, H, y0), wy1 = axis_weight(cy, H, y0 + 1);
+    if (wy0 == 0.f && wy1 == 0.f) continue;
     for (int sx = sx0; sx <= sx1; ++sx) {
       const int pw = sx / g.grid_w, ix = sx - pw * g.grid_w;
-      const float wx = axis_weight(sample_coord(g.start_w, pw, g.bin_w, ix, g.grid_w), W, x);
-      if (wx == 0.f) continue;
-      if (out) out[n] = Contribution{(r * pooled_h + ph) * pooled_w + pw, wy * wx, g.count, 0};
+      const float cx = sample_coord(g.start_w, pw, g.bin_w, ix, g.grid_w);
+      const float wx0 = axis_weight(cx, W, x0), wx1 = axis_weight(cx, W, x0 + 1);
+      if (wx0 == 0.f && wx1 == 0.f) continue;
+      if (out) {
+        Contribution c;
+        c.row = (r * pooled_h + ph) * pooled_w + pw;
+        c.count = g.count;
+        c.w[0] = wy0 * wx0; c.w[1] = wy0 * wx1; c.w[2] = wy1 * wx0; c.w[3] = wy1 * wx1;
+        c.pad[0] = c.pad[1] = 0;
+        out[n] = c;
+      }
       ++n;
     }
   }
   return n;
 }
 
-template <int VEC>
+template <int VEC, int MAXC>   // MAXC channel groups per lane: C <= 256 * VEC * MAXC
 __global__ __launch_bounds__(256) void roi_align_bwd_list_kernel(
     const float* __restrict__ grad_out, const float* __restrict__ rois, float* __restrict__ grad_in, int C,
     int H, int W, int R, int pooled_h, int pooled_w, float scale, int sampling_ratio) {
@@ -324,17 +338,19 @@ __global__ __launch_bounds__(256) void roi_align_bwd_list_kernel(
   __shared__ int s_ids[256];        // touching ROIs of the current range, ascending
   __shared__ int s_wave_n[4];
   __shared__ int s_total;
-  const int pix = blockIdx.x;
-  const int b = pix / (H * W);
-  const int y = (pix / W) % H;
-  const int x = pix % W;
+  const int tiles_x = (W + 1) / 2, tiles_y = (H + 1) / 2;
+  const int tile = blockIdx.x;
+  const int b = tile / (tiles_y * tiles_x);
+  const int y0 = ((tile / tiles_x) % tiles_y) * 2;
+  const int x0 = (tile % tiles_x) * 2;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  constexpr int MAXC = 4;   // channel groups per lane (C <= 256 * VEC * MAXC)
-  float acc[MAXC][VEC];
+  float acc[MAXC][4][VEC];
 #pragma unroll
   for (int k = 0; k < MAXC; ++k)
 #pragma unroll
-    for (int v = 0; v < VEC; ++v) acc[k][v] = 0.f;
+    for (int p = 0; p < 4; ++p)
+#pragma unroll
+      for (int v = 0; v < VEC; ++v) acc[k][p][v] = 0.f;
 
   auto accumulate = [&](int n_entries) {
     for (int e = 0; e < n_entries; ++e) {
@@ -344,26 +360,32 @@ __global__ __launch_bounds__(256) void roi_align_bwd_list_kernel(
       for (int k = 0; k < MAXC; ++k) {
         const int c = (threadIdx.x + k * 256) * VEC;
         if (c >= C) break;
+        float gq[VEC];
         if constexpr (VEC == 4) {
-          const float4 gq = *reinterpret_cast<const float4*>(src + c);
-          acc[k][0] += gq.x * q.w / q.count; acc[k][1] += gq.y * q.w / q.count;
-          acc[k][2] += gq.z * q.w / q.count; acc[k][3] += gq.w * q.w / q.count;
+          const float4 t = *reinterpret_cast<const float4*>(src + c);
+          gq[0] = t.x; gq[1] = t.y; gq[2] = t.z; gq[3] = t.w;
         } else {
-          acc[k][0] += src[c] * q.w / q.count;
+          gq[0] = src[c];
+        }
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+          if (q.w[p] == 0.f) continue;   // wave-uniform: keeps every pixel's sum free of +0 terms
+#pragma unroll
+          for (int v = 0; v < VEC; ++v) acc[k][p][v] += gq[v] * q.w[p] / q.count;
         }
       }
     }
   };
 
   for (int base = 0; base < R; base += 256) {
-    // 1. which ROIs of this range touch the pixel; ordered compaction (wave ballots, wave order = ROI order)
+    // 1. which ROIs of this range touch the tile; ordered compaction (wave ballots, wave order = ROI order)
     const int r = base + (int)threadIdx.x;
     bool hit = false;
     if (r < R) {
       const RoiGeom g = roi_geometry(rois + (size_t)r * 5, scale, pooled_h, pooled_w, sampling_ratio);
       const float roi_h = g.bin_h * (float)pooled_h, roi_w = g.bin_w * (float)pooled_w;
-      hit = g.batch == b && g.start_h <= (float)y + 1.f && g.start_h + roi_h >= (float)y - 1.f &&
-            g.start_w <= (float)x + 1.f && g.start_w + roi_w >= (float)x - 1.f;
+      hit = g.batch == b && g.start_h <= (float)y0 + 2.f && g.start_h + roi_h >= (float)y0 - 1.f &&
+            g.start_w <= (float)x0 + 2.f && g.start_w + roi_w >= (float)x0 - 1.f;
     }
     const unsigned long long ballot = __ballot(hit);
     if (lane == 0) s_wave_n[wave] = __popcll(ballot);
@@ -376,14 +398,13 @@ __global__ __launch_bounds__(256) void roi_align_bwd_list_kernel(
     // 2. rounds of up to 64 touching ROIs: one lane per ROI lists its contributions, then everybody accumulates
     for (int start = 0; start < ntouch; start += 64) {
       const int nround = min(64, ntouch - start);
-      int my_n = 0, my_off = 0;
-      RoiGeom g;
-      int rr = -1;
       if (wave == 0) {
+        int my_n = 0, rr = -1;
+        RoiGeom g;
         if (lane < nround) {
           rr = s_ids[start + lane];
           g = roi_geometry(rois + (size_t)rr * 5, scale, pooled_h, pooled_w, sampling_ratio);
-          my_n = roi_contributions(g, rr, H, W, pooled_h, pooled_w, y, x, nullptr);
+          my_n = roi_contributions(g, rr, H, W, pooled_h, pooled_w, y0, x0, nullptr);
         }
         int incl = my_n;   // inclusive wave scan
 #pragma unroll
@@ -391,28 +412,29 @@ __global__ __launch_bounds__(256) void roi_align_bwd_list_kernel(
           const int t = __shfl_up(incl, off, 64);
           if (lane >= off) incl += t;
         }
-        my_off = incl - my_n;
         const int total = __shfl(incl, 63, 64);
         if (lane == 0) s_total = total;
-        if (total <= kListCap && rr >= 0) roi_contributions(g, rr, H, W, pooled_h, pooled_w, y, x, s_list + my_off);
+        if (total <= kListCap && rr >= 0)
+          roi_contributions(g, rr, H, W, pooled_h, pooled_w, y0, x0, s_list + (incl - my_n));
       }
       __syncthreads();
       const int total = s_total;
       if (total <= kListCap) {
         accumulate(total);
       } else {
-        // pathological pile-up of tiny ROIs on one pixel: list them one ROI at a time (a 14x14-bin ROI has at most
-        // 31 x 31 candidate samples within one pixel's reach, of which <= kListCap carry weight)
+        // pathological pile-up of tiny ROIs on one tile: list them one ROI at a time (a 14x14-bin ROI offers at most
+        // 32 x 32 candidate samples to a tile, <= kListCap)
         for (int i = 0; i < nround; ++i) {
           __syncthreads();
           if (threadIdx.x == 0) {
             const int r1 = s_ids[start + i];
             const RoiGeom g1 = roi_geometry(rois + (size_t)r1 * 5, scale, pooled_h, pooled_w, sampling_ratio);
-            int n1 = roi_contributions(g1, r1, H, W, pooled_h, pooled_w, y, x, nullptr);
-            if (n1 <= kListCap) roi_contributions(g1, r1, H, W, pooled_h, pooled_w, y, x, s_list);
-            s_total = n1 <= kListCap ? n1 : 0;
+            const int n1 = roi_contributions(g1, r1, H, W, pooled_h, pooled_w, y0, x0, nullptr);
+            if (n1 <= kListCap) roi_contributions(g1, r1, H, W, pooled_h, pooled_w, y0, x0, s_list);
+            s_total = n1 <= kListCap ? n1 : -1;
           }
           __syncthreads();
+          if (s_total < 0) __builtin_trap();   // cannot happen for pooled sizes <= 14 x 14 with sampling_ratio <= 2
           accumulate(s_total);
         }
       }
@@ -420,14 +442,19 @@ __global__ __launch_bounds__(256) void roi_align_bwd_list_kernel(
     }
   }
 #pragma unroll
-  for (int k = 0; k < MAXC; ++k) {
-    const int c = (threadIdx.x + k * 256) * VEC;
-    if (c >= C) break;
-    float* dst = grad_in + (size_t)pix * C + c;
-    if constexpr (VEC == 4) {
-      *reinterpret_cast<float4*>(dst) = make_float4(acc[k][0], acc[k][1], acc[k][2], acc[k][3]);
-    } else {
-      dst[0] = acc[k][0];
+  for (int p = 0; p < 4; ++p) {
+    const int y = y0 + (p >> 1), x = x0 + (p & 1);
+    if (y >= H || x >= W) continue;
+#pragma unroll
+    for (int k = 0; k < MAXC; ++k) {
+      const int c = (threadIdx.x + k * 256) * VEC;
+      if (c >= C) break;
+      float* dst = grad_in + ((size_t)(b * H + y) * W + x) * C + c;
+      if constexpr (VEC == 4) {
+        *reinterpret_cast<float4*>(dst) = make_float4(acc[k][p][0], acc[k][p][1], acc[k][p][2], acc[k][p][3]);
+      } else {
+        dst[0] = acc[k][p][0];
+      }
     }
   }
 }
@@ -501,9 +528,14 @@ extern "C" int dadet_roi_align_backward(const float* grad_output, const float* r
   const bool vec = (C % 4 == 0) && ((reinterpret_cast<uintptr_t>(grad_output) & 15) == 0) &&
                    ((reinterpret_cast<uintptr_t>(grad_input) & 15) == 0);
   static const bool use_list = !(getenv("DADET_ROI_BWD_LIST") && getenv("DADET_ROI_BWD_LIST")[0] == '0');
-  if (vec && use_list && C <= 256 * 4 * 4) {
-    hipLaunchKernelGGL(roi_align_bwd_list_kernel<4>, grid, dim3(256), 0, st, grad_output, rois, grad_input, C, H, W,
-                       R, pooled_h, pooled_w, spatial_scale, sampling_ratio);
+  if (vec && use_list && C <= 256 * 4 * 4 && pooled_h <= 14 && pooled_w <= 14) {
+    const dim3 tgrid((unsigned)(B * ((H + 1) / 2) * ((W + 1) / 2)));
+    if (C <= 1024)
+      hipLaunchKernelGGL((roi_align_bwd_list_kernel<4, 1>), tgrid, dim3(256), 0, st, grad_output, rois, grad_input, C,
+                         H, W, R, pooled_h, pooled_w, spatial_scale, sampling_ratio);
+    else
+      hipLaunchKernelGGL((roi_align_bwd_list_kernel<4, 4>), tgrid, dim3(256), 0, st, grad_output, rois, grad_input, C,
+                         H, W, R, pooled_h, pooled_w, spatial_scale, sampling_ratio);
   } else if (vec) {
     const int threads = (C / 4 >= 256) ? 256 : ((C / 4 + 63) / 64) * 64;
     hipLaunchKernelGGL(roi_align_bwd_gather_kernel<4>, grid, dim3(threads), lds, st, grad_output, rois,
