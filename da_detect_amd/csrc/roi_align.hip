@@ -353,25 +353,35 @@ __global__ __launch_bounds__(256) void roi_align_bwd_list_kernel(
       for (int v = 0; v < VEC; ++v) acc[k][p][v] = 0.f;
 
   auto accumulate = [&](int n_entries) {
-    for (int e = 0; e < n_entries; ++e) {
-      const Contribution q = s_list[e];
-      const float* src = grad_out + (size_t)q.row * C;
+    constexpr int U = 4;   // entries in flight per lane: the loop is otherwise one dependent 16-byte load at a time
+#pragma unroll 1
+    for (int e0 = 0; e0 < n_entries; e0 += U) {
 #pragma unroll
       for (int k = 0; k < MAXC; ++k) {
         const int c = (threadIdx.x + k * 256) * VEC;
         if (c >= C) break;
-        float gq[VEC];
-        if constexpr (VEC == 4) {
-          const float4 t = *reinterpret_cast<const float4*>(src + c);
-          gq[0] = t.x; gq[1] = t.y; gq[2] = t.z; gq[3] = t.w;
-        } else {
-          gq[0] = src[c];
+        float gq[U][VEC];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          const int e = min(e0 + u, n_entries - 1);     // the tail re-reads the last row; its weights are skipped
+          const float* src = grad_out + (size_t)s_list[e].row * C + c;
+          if constexpr (VEC == 4) {
+            const float4 t = *reinterpret_cast<const float4*>(src);
+            gq[u][0] = t.x; gq[u][1] = t.y; gq[u][2] = t.z; gq[u][3] = t.w;
+          } else {
+            gq[u][0] = src[0];
+          }
         }
 #pragma unroll
-        for (int p = 0; p < 4; ++p) {
-          if (q.w[p] == 0.f) continue;   // wave-uniform: keeps every pixel's sum free of +0 terms
+        for (int u = 0; u < U; ++u) {
+          if (e0 + u >= n_entries) break;
+          const Contribution q = s_list[e0 + u];
 #pragma unroll
-          for (int v = 0; v < VEC; ++v) acc[k][p][v] += gq[v] * q.w[p] / q.count;
+          for (int p = 0; p < 4; ++p) {
+            if (q.w[p] == 0.f) continue;   // wave-uniform: keeps every pixel's sum free of +0 terms
+#pragma unroll
+            for (int v = 0; v < VEC; ++v) acc[k][p][v] += gq[u][v] * q.w[p] / q.count;
+          }
         }
       }
     }
