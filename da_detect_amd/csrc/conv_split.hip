@@ -48,7 +48,10 @@ __device__ inline void split4(const float4 v, uint2 (&out)[TERMS]) {
   }
 }
 
-template <int TM, int TN, int TERMS>
+// AB: stage-ablation mask for profiling experiments (tools/ablate.py).  It is a COMPILE-TIME parameter: as run-time
+// branches the checks cut the K loop into a dozen basic blocks and the scheduler could no longer interleave the
+// MFMAs with the split / LDS traffic across them.  Production launches use AB = 0.
+template <int TM, int TN, int TERMS, int AB = 0>
 __global__ __launch_bounds__(256, 2) void conv_fwd_split_kernel(const ConvArgs a) {
   constexpr int BM = 2 * TM * 32, BN = 2 * TN * 32;
   constexpr int A_LOADS = BM / 32, B_LOADS = BN / 32;
@@ -172,7 +175,7 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_split_kernel(const ConvArgs a
   const int frag_k = (lane >> 5) * 8;
   const __bf16* Ab = As + (wm * TM * 32 + frag_row) * PLANE_STRIDE + frag_k;
   const __bf16* Bb = Bs + (wn * TN * 32 + frag_row) * PLANE_STRIDE + frag_k;
-  const int ab = a.ablate;
+  constexpr int ab = AB;
   for (int kt = 0; kt < nk; ++kt) {
     const bool more = kt + 1 < nk;
     if (more && !(ab & 4)) load_tile();
@@ -516,7 +519,7 @@ static int launch_split_ws(ConvArgs& a, hipStream_t st) {
   return check_launch("conv_forward(split, wave-specialised)");
 }
 
-template <int TM, int TN, int TERMS>
+template <int TM, int TN, int TERMS, int AB = 0>
 static int launch_split(ConvArgs& a, hipStream_t st) {
   constexpr int BM = 2 * TM * 32, BN = 2 * TN * 32;
   a.tiles_m = ceil_div(a.M, BM);
@@ -524,7 +527,7 @@ static int launch_split(ConvArgs& a, hipStream_t st) {
   const size_t lds = sizeof(__bf16) * TERMS * (BM + BN) * PLANE_STRIDE;
   static bool attr_set = false;
   if (!attr_set && lds > 48 * 1024) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_fwd_split_kernel<TM, TN, TERMS>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_fwd_split_kernel<TM, TN, TERMS, AB>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) {
       set_error("conv_forward(split): hipFuncSetAttribute: %s", hipGetErrorString(e));
@@ -532,7 +535,8 @@ static int launch_split(ConvArgs& a, hipStream_t st) {
     }
     attr_set = true;
   }
-  hipLaunchKernelGGL((conv_fwd_split_kernel<TM, TN, TERMS>), dim3(a.tiles_m * a.tiles_n), dim3(256), lds, st, a);
+  hipLaunchKernelGGL((conv_fwd_split_kernel<TM, TN, TERMS, AB>), dim3(a.tiles_m * a.tiles_n), dim3(256), lds, st,
+                     a);
   return check_launch("conv_forward(split)");
 }
 
@@ -541,6 +545,18 @@ int launch_fwd_split(ConvArgs& a, int variant, int terms, hipStream_t st) {
   // ones (one workgroup per CU): opt-in for experiments only
   static const bool use_ws = getenv("DADET_WS") && atoi(getenv("DADET_WS"));
   if (variant == 0 && use_ws) return terms == 2 ? launch_split_ws<2>(a, st) : launch_split_ws<3>(a, st);
+  if (a.ablate && variant == 0 && terms == 3) {   // profiling experiments only (DADET_ABLATE)
+    switch (a.ablate) {
+      case 1: return launch_split<2, 2, 3, 1>(a, st);
+      case 2: return launch_split<2, 2, 3, 2>(a, st);
+      case 3: return launch_split<2, 2, 3, 3>(a, st);
+      case 8: return launch_split<2, 2, 3, 8>(a, st);
+      case 16: return launch_split<2, 2, 3, 16>(a, st);
+      case 19: return launch_split<2, 2, 3, 19>(a, st);
+      case 23: return launch_split<2, 2, 3, 23>(a, st);
+      default: set_error("conv_forward(split): no kernel compiled for ablation mask %d", a.ablate); return DADET_EINVAL;
+    }
+  }
   if (terms == 2) {
     switch (variant) {
       case 0: return launch_split<2, 2, 2>(a, st);
