@@ -27,7 +27,7 @@ int gemm_mode() { return g_gemm_mode; }
 
 __device__ inline unsigned pack_bf16(float lo, float hi) {
   unsigned r;
-  asm volatile("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
+  asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));   // pure: free to be scheduled between MFMAs
   return r;
 }
 __device__ inline float lo_as_float(unsigned p) { return __builtin_bit_cast(float, p << 16); }
@@ -178,7 +178,11 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_split_kernel(const ConvArgs a
   constexpr int ab = AB;
   for (int kt = 0; kt < nk; ++kt) {
     const bool more = kt + 1 < nk;
-    if (more && !(ab & 4)) load_tile();
+    // Unconditional on purpose: past the last K-tile every offset is out of range (the loads return 0) and the split
+    // works on dead registers — that keeps loads, MFMAs and the operand split in ONE basic block, so the scheduler
+    // can place the split's VALU instructions in the shadow of the MFMAs (each 32x32x16 occupies the matrix pipe for
+    // 32 cycles = 8 issue slots) instead of after the whole cluster.
+    if (!(ab & 4)) load_tile();
 #pragma unroll
     for (int step = 0; step < BK / 16; ++step) {
       bf16x8 fa[TERMS][TM], fb[TERMS][TN];
@@ -191,6 +195,11 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_split_kernel(const ConvArgs a
 #pragma unroll
         for (int i = 0; i < TN; ++i)
           fb[p][i] = *reinterpret_cast<const bf16x8*>(Bb + p * B_PLANE + i * 32 * PLANE_STRIDE + step * 16);
+      }
+      // the next tile's operands have landed by now: split one operand per k16 group of MFMAs
+      if (!(ab & 1)) {
+        if (step == 0) split_a();
+        else if (!(ab & 32)) split_b();
       }
       // smallest cross terms first, the leading a0*b0 last
 #pragma unroll
@@ -208,10 +217,17 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_split_kernel(const ConvArgs a
               acc[im][in] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[pa][im], fb[pb][in], acc[im][in], 0, 0, 0);
         }
       }
-      // the next tile's operands have landed by now: split one operand behind each k16 group of MFMAs
-      if (more && !(ab & 1)) {
-        if (step == 0) split_a();
-        else if (!(ab & 32)) split_b();
+      if (AB == 0) {
+        // desired issue order for this k16 group: fragment reads up front, then every MFMA followed by the VALU
+        // instructions that fit in its shadow
+        constexpr int kMfma = TM * TN * (TERMS == 3 ? 6 : 3);
+        constexpr int kValuPerMfma = (TM == 2 ? A_LOADS : B_LOADS) * (TERMS == 3 ? 26 : 14) / kMfma + 1;
+        __builtin_amdgcn_sched_group_barrier(0x100, TERMS * (TM + TN), 0);   // DS reads
+#pragma unroll
+        for (int i = 0; i < kMfma; ++i) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                 // one MFMA
+          __builtin_amdgcn_sched_group_barrier(0x002, kValuPerMfma, 0);      // VALU in its shadow
+        }
       }
     }
     if (more) {
