@@ -108,7 +108,10 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_split_kernel(const ConvArgs a
   int kr = tap / a.KW;
   int ks = tap - kr * a.KW;
 
-  auto load_tile = [&]() {
+  // one K-tile of raw fp32 operands in registers.  A and B are fetched by separate calls so that each can be issued
+  // right after ITS registers were consumed by the split (see the K loop): a fetch then has a whole K-tile of MFMAs
+  // to land before it is needed.
+  auto load_a = [&]() {
     const bool kvalid = kk < a.K;
 #pragma unroll
     for (int i = 0; i < A_LOADS; ++i) {
@@ -117,9 +120,14 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_split_kernel(const ConvArgs a
       const unsigned off = ((unsigned)(pixbase[i] + hi * a.W + wi) * (unsigned)a.Cin + (unsigned)kc) * 4u;
       ra[i] = buf_load4(xr, ok ? off : kOOB);
     }
+  };
+  auto load_b = [&]() {
+    const bool kvalid = kk < a.K;
 #pragma unroll
     for (int i = 0; i < B_LOADS; ++i)
       rb[i] = buf_load4(wr, (kvalid && wrow[i] != kOOB) ? wrow[i] + (unsigned)kk * 4u : kOOB);
+  };
+  auto advance = [&]() {
     kk += BK;
     kc += BK;
     while (kc >= a.Cin) {
@@ -164,11 +172,18 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_split_kernel(const ConvArgs a
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
   const int nk = (a.K + BK - 1) / BK;
-  load_tile();
+  load_a();
+  load_b();
+  advance();
   split_a();
   split_b();
   store_tile();
   __syncthreads();
+  if (!(AB & 4)) {   // tile 1 is in flight while tile 0 is multiplied
+    load_a();
+    load_b();
+  }
+  advance();
 
   // MFMA 32x32x16 bf16 fragments: lane l feeds row (l & 31), k = 8*(l >> 5) .. +7 of each 16-wide k step
   const int frag_row = lane & 31;
@@ -178,11 +193,11 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_split_kernel(const ConvArgs a
   constexpr int ab = AB;
   for (int kt = 0; kt < nk; ++kt) {
     const bool more = kt + 1 < nk;
-    // Unconditional on purpose: past the last K-tile every offset is out of range (the loads return 0) and the split
-    // works on dead registers — that keeps loads, MFMAs and the operand split in ONE basic block, so the scheduler
-    // can place the split's VALU instructions in the shadow of the MFMAs (each 32x32x16 occupies the matrix pipe for
-    // 32 cycles = 8 issue slots) instead of after the whole cluster.
-    if (!(ab & 4)) load_tile();
+    // LDS holds tile kt, the registers hold tile kt + 1 (fetched one iteration ago).  Per k16 group: split one
+    // operand of tile kt + 1 in the shadow of the MFMAs (each 32x32x16 occupies the matrix pipe for 32 cycles = 8 issue
+    // slots), then fetch that operand of tile kt + 2 into the registers just freed.  Everything is unconditional on
+    // purpose: past the last K-tile every offset is out of range (the loads return 0) and the split works on dead
+    // registers — loads, MFMAs and split stay in ONE basic block for the scheduler.
 #pragma unroll
     for (int step = 0; step < BK / 16; ++step) {
       bf16x8 fa[TERMS][TM], fb[TERMS][TN];
@@ -229,7 +244,13 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_split_kernel(const ConvArgs a
           __builtin_amdgcn_sched_group_barrier(0x002, kValuPerMfma, 0);      // VALU in its shadow
         }
       }
+      // registers of the operand just split are free: fetch that operand of tile kt + 2
+      if (!(ab & 4)) {
+        if (step == 0) load_a();
+        else load_b();
+      }
     }
+    advance();
     if (more) {
       __syncthreads();
       if (!(ab & 2)) store_tile();
