@@ -21,6 +21,10 @@ namespace dadet {
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 constexpr int PLANE_STRIDE = 40;  // bf16 per staged row: 32 + 8 pad = 80 bytes
+#ifndef DADET_PRIO_SPLIT
+#define DADET_PRIO_SPLIT 1
+#endif
+constexpr bool PRIO_SPLIT = DADET_PRIO_SPLIT != 0;
 
 static int g_gemm_mode = 0;
 int gemm_mode() { return g_gemm_mode; }
@@ -68,6 +72,14 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_split_kernel(const ConvArgs a
   const int lane = t & 63, wave = t >> 6;
   const int wm = wave >> 1, wn = wave & 1;
   const int lcol = t & 7;
+  // Two workgroups share a CU, i.e. two waves share each SIMD's matrix pipe.  With equal priority they advance in
+  // lockstep and reach their barrier / LDS-store sections at the same time, leaving the pipe idle; a static priority
+  // by hardware wave slot (HW_ID.wave_id bit 0: co-resident waves of one SIMD sit in different slots) lets one run
+  // its MFMA phase at full rate while the other fills the gaps.
+  if (PRIO_SPLIT) {
+    const unsigned slot = __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 4);   // HW_REG_HW_ID, wave_id[3:0]
+    if (slot & 1u) __builtin_amdgcn_s_setprio(2);
+  }
   // staged row of this thread.  Eight lanes write one row's 64 bytes; a ds_write_b64 is serviced in 16-lane
   // groups over 32 banks, and with 80-byte rows two rows are bank-disjoint exactly when they are 4 (mod 8) apart,
   // so consecutive 8-lane groups take rows r and r + 4 (PMC: 33% of LDS cycles were conflicts with r, r + 1).
