@@ -264,9 +264,9 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_split_kernel(const ConvArgs a
     }
     advance();
     if (more) {
-      __syncthreads();
+      if (!(ab & 64)) __syncthreads();
       if (!(ab & 2)) store_tile();
-      __syncthreads();
+      if (!(ab & 64)) __syncthreads();
     }
   }
 
@@ -603,6 +603,7 @@ int launch_fwd_split(ConvArgs& a, int variant, int terms, hipStream_t st) {
       case 16: return launch_split<2, 2, 3, 16>(a, st);
       case 19: return launch_split<2, 2, 3, 19>(a, st);
       case 23: return launch_split<2, 2, 3, 23>(a, st);
+      case 87: return launch_split<2, 2, 3, 87>(a, st);    // MFMAs only, no barriers either
       default: set_error("conv_forward(split): no kernel compiled for ablation mask %d", a.ablate); return DADET_EINVAL;
     }
   }
