@@ -674,15 +674,21 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_split_kernel(const WgradArg
     r_wo[j] = rem - r_ho[j] * a.Wo;
   }
   int m_cur = m_begin;
-  auto load_tile = [&]() {
+  // the two operands are fetched by separate calls so that each is issued right after ITS registers were split
+  auto load_g = [&]() {
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const int m = m_cur + mg * 4 + j;
-      const bool mv = m < m_end;
-      rg[j] = buf_load4(gr, (mv && covalid) ? (unsigned)m * (unsigned)a.Cout * 4u + co_off : kOOB);
+      rg[j] = buf_load4(gr, (m < m_end && covalid) ? (unsigned)m * (unsigned)a.Cout * 4u + co_off : kOOB);
+    }
+  };
+  auto load_x = [&]() {   // also advances to the next 32-row step
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int m = m_cur + mg * 4 + j;
       const int hi = r_ho[j] * a.stride - a.pad + r;
       const int wi = r_wo[j] * a.stride - a.pad + s;
-      const bool ok = mv && kvalid && (unsigned)hi < (unsigned)a.H && (unsigned)wi < (unsigned)a.W;
+      const bool ok = m < m_end && kvalid && (unsigned)hi < (unsigned)a.H && (unsigned)wi < (unsigned)a.W;
       const unsigned off = ((unsigned)((r_img[j] * a.H + hi) * a.W + wi) * (unsigned)a.Cin + (unsigned)ci) * 4u;
       rx[j] = buf_load4(xr, ok ? off : kOOB);
       r_wo[j] += RK;
@@ -722,11 +728,14 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_split_kernel(const WgradArg
 
   const int nsteps = (m_end - m_begin + RK - 1) / RK;
   if (nsteps > 0) {
-    load_tile();
+    load_g();
+    load_x();
     split_block(rg, pg_);
     split_block(rx, px_);
     store_plane(Gs, pg_);
     store_plane(Xs, px_);
+    load_g();   // step 1 is in flight while step 0 is multiplied
+    load_x();
   }
   __syncthreads();
   const int frag_row = lane & 31;
@@ -735,7 +744,9 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_split_kernel(const WgradArg
   const __bf16* Xb = Xs + (wn * 64 + frag_row) * PLANE_STRIDE + frag_k;
   for (int st = 0; st < nsteps; ++st) {
     const bool more = st + 1 < nsteps;
-    if (more) load_tile();
+    // LDS holds step st, the registers hold step st + 1.  Per k16 group: split (and 4x4-transpose) one operand of
+    // step st + 1 in the shadow of the MFMAs, then fetch that operand of step st + 2 into the freed registers.  All
+    // unconditional (rows past m_end load zeros): loads, MFMAs and split stay in one basic block for the scheduler.
 #pragma unroll
     for (int step = 0; step < RK / 16; ++step) {
       bf16x8 fg[TERMS][2], fx[TERMS][2];
@@ -746,6 +757,8 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_split_kernel(const WgradArg
           fg[p][i] = *reinterpret_cast<const bf16x8*>(Gb + p * PLANE + i * 32 * PLANE_STRIDE + step * 16);
           fx[p][i] = *reinterpret_cast<const bf16x8*>(Xb + p * PLANE + i * 32 * PLANE_STRIDE + step * 16);
         }
+      if (step == 0) split_block(rg, pg_);
+      else split_block(rx, px_);
 #pragma unroll
       for (int order = 2 * (TERMS - 1); order >= 0; --order) {
 #pragma unroll
@@ -760,10 +773,18 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_split_kernel(const WgradArg
               acc[im][in] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fg[pa][im], fx[pb][in], acc[im][in], 0, 0, 0);
         }
       }
-      if (more) {
-        if (step == 0) split_block(rg, pg_);
-        else split_block(rx, px_);
+      {
+        constexpr int kMfma = 4 * (TERMS == 3 ? 6 : 3);
+        constexpr int kValuPerMfma = 4 * (TERMS == 3 ? 26 : 14) / kMfma + 1;
+        __builtin_amdgcn_sched_group_barrier(0x100, TERMS * 4, 0);          // DS reads
+#pragma unroll
+        for (int i = 0; i < kMfma; ++i) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                // one MFMA
+          __builtin_amdgcn_sched_group_barrier(0x002, kValuPerMfma, 0);     // VALU in its shadow
+        }
       }
+      if (step == 0) load_g();
+      else load_x();
     }
     if (more) {
       __syncthreads();
