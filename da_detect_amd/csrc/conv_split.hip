@@ -22,7 +22,7 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 constexpr int PLANE_STRIDE = 40;  // bf16 per staged row: 32 + 8 pad = 80 bytes
 #ifndef DADET_PRIO_SPLIT
-#define DADET_PRIO_SPLIT 1
+#define DADET_PRIO_SPLIT 0   /* measured: no effect on MFMA-only or full kernels; kept for experiments */
 #endif
 constexpr bool PRIO_SPLIT = DADET_PRIO_SPLIT != 0;
 
