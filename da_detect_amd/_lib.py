@@ -49,6 +49,9 @@ _SIGNATURES = {
     "dadet_conv_weight_transpose": [_P, _P, _P, c_int, c_int, c_int, c_int, _P],
     "dadet_deform_sample_forward": [_P, _P, _P, _P] + [c_int] * 12 + [_P],
     "dadet_deform_sample_backward": [_P, _P, _P, _P, _P, _P, _P] + [c_int] * 12 + [_P],
+    "dadet_image_resample_h": [_P, c_int, c_int, _P, _P, c_int, c_int, _P, _P],
+    "dadet_image_resample_v_normalize": [_P, c_int, c_int, _P, _P, c_int, c_int, c_int, c_int, POINTER(c_float),
+                                         POINTER(c_float), _P, c_int, _P],
     "dadet_rpn_loss": [_P, _P, _P, _P, c_int, _P, _P, c_int, c_float, _P, _P, _P, _P],
     "dadet_fast_rcnn_loss": [_P, _P, c_int, c_int, _P, _P, c_int, _P, _P, _P, c_int, _P, _P, _P, _P],
     "dadet_rpn_anchor_targets": [_P, _P, c_int, _P, c_int, c_float, c_float, _P, _P, _P, _P],

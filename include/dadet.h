@@ -179,6 +179,20 @@ int dadet_roi_pool_forward(const float* input, const float* rois, float* output,
 int dadet_roi_pool_backward(const float* grad_output, const int* argmax, const float* rois, float* grad_input, int B,
                             int C, int H, int W, int R, int pooled_h, int pooled_w, void* stream);
 
+/* Device-side input pipeline (image.hip): Pillow-exact bilinear resize + flip + BGR-255 + normalisation, replacing
+ * the host transforms of maskrcnn_benchmark/data/transforms/transforms.py:32-97 (Resize -> torchvision F.resize ->
+ * PIL BILINEAR, RandomHorizontalFlip, ToTensor, Normalize(to_bgr255)).  Images are uint8 [H][W][3] (RGB, device
+ * memory); bounds [out][2] = (first input index, tap count) and coeffs [out][ksize] (22-bit fixed point) are Pillow's
+ * per-axis tables (computed on the host, da_detect_amd/data/device_prep.py).  Pass 1 resamples rows to out_w and
+ * rounds to 8 bits; pass 2 resamples columns (bounds NULL: none), optionally mirrors, converts and writes fp32
+ * [out_h][out_row_stride][3] — a slot of the zero-filled padded batch tensor.  mean3 / std3 are HOST pointers. */
+int dadet_image_resample_h(const unsigned char* image_hwc, int H, int W, const int* bounds, const int* coeffs,
+                           int ksize, int out_w, unsigned char* out_hwc, void* stream);
+int dadet_image_resample_v_normalize(const unsigned char* image_hwc, int in_h, int w, const int* bounds,
+                                     const int* coeffs, int ksize, int out_h, int flip, int to_bgr255,
+                                     const float* mean3, const float* std3, float* out_hw3, int out_row_stride,
+                                     void* stream);
+
 /* Fused detection losses: value and gradient in one single-workgroup launch (losses.hip).
  * dadet_rpn_loss replaces RPNLossComputation.__call__'s loss part (modeling/rpn/loss.py:125-143): objectness /
  * box_regression are the flattened NHWC prediction maps ([N*H*W*A] and [N*H*W*A][4], the order of

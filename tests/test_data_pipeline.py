@@ -1,0 +1,207 @@
+"""Data side: transforms, samplers, datasets on the CPU; the device-side batch
+preparation on the GPU.  Pins: Pillow itself for the resize arithmetic, index streams recorded from the reference's
+sampler modules (tests/golden/reference_samplers.json), the host transform chain for the device path."""
+import json
+import os
+import random
+
+import numpy as np
+import pytest
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+GOLD = os.path.join(HERE, "golden")
+PIL = pytest.importorskip("PIL")
+from PIL import Image  # noqa: E402
+
+RESIZE_CASES = [(64, 128, 38, 75), (100, 60, 100, 33), (37, 53, 80, 101), (128, 256, 75, 150), (17, 19, 17, 19),
+                (50, 50, 7, 93)]
+
+
+def _image(rng, H, W):
+    return rng.integers(0, 256, (H, W, 3), dtype=np.uint8)
+
+
+@pytest.mark.parametrize("H,W,oh,ow", RESIZE_CASES)
+def test_resize_restatement_equals_pillow(H, W, oh, ow):
+    """oracle/image_ref.py vs Pillow's own Image.resize(BILINEAR) — what torchvision's F.resize calls for PIL images"""
+    from oracle.image_ref import pil_bilinear_resize
+
+    img = _image(np.random.default_rng(H + ow), H, W)
+    want = np.asarray(Image.fromarray(img).resize((ow, oh), Image.BILINEAR))
+    assert np.array_equal(pil_bilinear_resize(img, oh, ow), want)
+
+
+def test_vectorised_tables_equal_the_scalar_restatement():
+    from da_detect_amd.data.device_prep import resample_tables
+    from oracle.image_ref import resample_coeffs
+
+    for a, b in [(2048, 1200), (1024, 600), (53, 101), (60, 33), (50, 7), (50, 93), (1914, 1052), (9, 9)]:
+        b1, c1 = resample_tables(a, b)
+        b2, c2 = resample_coeffs(a, b)
+        assert np.array_equal(b1, b2) and np.array_equal(c1, c2), (a, b)
+
+
+def test_get_size_rules():
+    """transforms.py:41-62: shorter side to min_size unless the longer side would exceed max_size"""
+    from da_detect_amd.data.transforms import Resize
+
+    r = Resize(600, 1200)
+    assert r.get_size((2048, 1024)) == (600, 1200)          # Cityscapes: the DA yamls' 600 / 1200
+    assert r.get_size((1024, 2048)) == (1200, 600)
+    assert r.get_size((500, 375)) == (600, 800)
+    assert Resize(800, 1333).get_size((1000, 300)) == (400, 1333)   # capped by max_size: int(round(1333 * .3)) = 400
+    assert Resize(800, 1333).get_size((640, 480)) == (800, 1066)
+    assert Resize((600,), 1200).get_size((1200, 600)) == (600, 1200)   # already there: returned as is
+
+
+def test_host_transform_chain_equals_the_oracle():
+    """build_transforms(cfg) (PIL resize / flip, ToTensor, Normalize to_bgr255) vs oracle/image_ref.preprocess, same
+    random decisions; boxes follow the image"""
+    from da_detect_amd.config import cfg
+    from da_detect_amd.data.transforms import build_transforms
+    from da_detect_amd.structures.bounding_box import BoxList
+    from oracle.image_ref import preprocess
+
+    c = cfg.clone()
+    c.merge_from_list(["INPUT.MIN_SIZE_TRAIN", (40,), "INPUT.MAX_SIZE_TRAIN", 70])
+    tf = build_transforms(c, True)
+    rng = np.random.default_rng(3)
+    for seed in range(4):
+        img = _image(rng, 48, 96)
+        boxes = BoxList(torch.tensor([[4.0, 6.0, 40.0, 30.0], [50.0, 10.0, 95.0, 47.0]]), (96, 48), mode="xyxy")
+        random.seed(seed)
+        out, tgt = tf(Image.fromarray(img), boxes)
+        random.seed(seed)
+        oh, ow = tf.transforms[0].get_size((96, 48))
+        flip = tf.transforms[1].toss()
+        want = preprocess(img, oh, ow, flip, c.INPUT.PIXEL_MEAN, c.INPUT.PIXEL_STD, c.INPUT.TO_BGR255)
+        assert (oh, ow) == (35, 70) and tuple(out.shape) == (3, 35, 70)
+        assert np.array_equal(out.numpy(), want)
+        ref = boxes.resize((ow, oh))
+        if flip:
+            ref = ref.transpose(0)
+        assert torch.equal(tgt.bbox, ref.bbox) and tgt.size == (ow, oh)
+
+
+def test_samplers_reproduce_the_reference_streams():
+    from da_detect_amd.data import samplers as S
+
+    gold = json.load(open(os.path.join(GOLD, "reference_samplers.json")))
+    for case in gold["distributed"]:
+        for rank, want in enumerate(case["indices"]):
+            s = S.DistributedSampler(list(range(case["n"])), num_replicas=case["world"], rank=rank, shuffle=True)
+            s.set_epoch(case["epoch"])
+            assert list(s) == want and len(s) == len(want)
+    for case in gold["grouped"]:
+        base = S.DistributedSampler(list(range(case["n"])), num_replicas=1, rank=0, shuffle=True)
+        base.set_epoch(case["epoch"])
+        b = S.GroupedBatchSampler(base, case["groups"], case["batch_size"], drop_uneven=case["drop_uneven"])
+        assert len(b) == len(case["batches"]) and [list(x) for x in b] == case["batches"]
+    for case in gold["iteration"]:
+        base = S.DistributedSampler(list(range(case["n"])), num_replicas=1, rank=0, shuffle=True)
+        bs = torch.utils.data.sampler.BatchSampler(base, case["batch_size"], drop_last=False)
+        it = S.IterationBasedBatchSampler(bs, case["num_iterations"], case["start_iter"])
+        assert [list(x) for x in it] == case["batches"]
+
+
+def _write_coco(tmp, name, n_images, rng, sizes=None):
+    root = os.path.join(tmp, name)
+    os.makedirs(root)
+    images, annos = [], []
+    aid = 1
+    for i in range(n_images):
+        H, W = sizes[i] if sizes else (40, 80)
+        Image.fromarray(_image(rng, H, W)).save(os.path.join(root, "im%d.png" % i))
+        images.append({"id": 100 + i, "file_name": "im%d.png" % i, "height": H, "width": W})
+        for k in range(0 if i == 1 else 2):                  # image 1 has no annotation
+            annos.append({"id": aid, "image_id": 100 + i, "category_id": 24 + 2 * k, "iscrowd": 0,
+                          "bbox": [5 + k, 6, 20, 15], "area": 300})
+            aid += 1
+    ann = os.path.join(tmp, name + ".json")
+    json.dump({"images": images, "annotations": annos,
+               "categories": [{"id": 24, "name": "person"}, {"id": 26, "name": "car"}]}, open(ann, "w"))
+    return ann, root
+
+
+def test_datasets_and_loaders(tmp_path):
+    from da_detect_amd.config import cfg
+    from da_detect_amd.data.build import make_da_data_loaders, make_triplet_data_loader
+    from da_detect_amd.data.datasets import COCODataset, TripletDataset
+
+    rng = np.random.default_rng(0)
+    specs = {k: _write_coco(str(tmp_path), k, 4, rng) for k in ("source", "target", "auxiliary")}
+    ds = COCODataset(*specs["source"], remove_images_without_annotations=True, is_source=True, decode_to_tensor=True)
+    assert len(ds) == 3 and ds.id_to_img_map == {0: 100, 1: 102, 2: 103}          # image 101 has no boxes
+    img, tgt, idx = ds[0]
+    assert img.dtype == torch.uint8 and tuple(img.shape) == (40, 80, 3) and idx == 0
+    assert tgt.mode == "xyxy" and tgt.bbox.tolist() == [[5.0, 6.0, 24.0, 20.0], [6.0, 6.0, 25.0, 20.0]]
+    assert tgt.get_field("labels").tolist() == [1, 2] and tgt.get_field("is_source").tolist() == [True, True]
+    assert ds.contiguous_category_id_to_json_id == {1: 24, 2: 26} and ds.get_img_info(1)["file_name"] == "im2.png"
+    tds = TripletDataset([COCODataset(*specs[k], remove_images_without_annotations=True, is_source=(k == "source"),
+                                      decode_to_tensor=True) for k in ("source", "target", "auxiliary")])
+    s = tds[1]
+    assert torch.equal(s[3].bbox, s[1].bbox) and s[3].get_field("is_source").tolist() == [False, False]
+    assert s[5].get_field("is_source").tolist() == [False, False] and s[1].get_field("is_source").all()
+    c = cfg.clone()
+    c.merge_from_list(["SOLVER.IMS_PER_BATCH", 2, "SOLVER.MAX_ITER", 3, "DATALOADER.NUM_WORKERS", 0,
+                       "DATALOADER.SIZE_DIVISIBILITY", 32, "INPUT.MIN_SIZE_TRAIN", (32,), "INPUT.MAX_SIZE_TRAIN", 64,
+                       "MODEL.DOMAIN_ADAPTATION_ON", True])
+    loaders = make_da_data_loaders(c, {k: specs[k] for k in ("source", "target")})
+    batches = [list(l) for l in loaders]
+    assert [len(b) for b in batches] == [3, 3]
+    images, targets, ids = batches[0][0]
+    assert tuple(images.tensors.shape) == (1, 3, 32, 64) and len(targets) == 1 and targets[0].get_field("is_source").all()
+    assert not batches[1][0][1][0].get_field("is_source").any()
+    trip = list(make_triplet_data_loader(c, specs))
+    assert len(trip) == 3 and len(trip[0]) == 9 and tuple(trip[0][2].tensors.shape) == (1, 3, 32, 64)
+
+
+# ----------------------------------------------------------------------------------------------------- GPU
+@pytest.mark.gpu
+def test_device_batch_preparation_is_bit_exact():
+    """DeviceBatchPreparer (csrc/image.hip) vs the host chain restated in oracle/image_ref.py (itself equal to Pillow):
+    resized / mirrored / normalised pixels bit for bit, zero padding to SIZE_DIVISIBILITY, targets transformed alike"""
+    from da_detect_amd.config import cfg
+    from da_detect_amd.data.device_prep import DeviceBatchPreparer
+    from da_detect_amd.structures.bounding_box import BoxList
+    from oracle.image_ref import preprocess
+
+    c = cfg.clone()
+    c.merge_from_list(["DATALOADER.SIZE_DIVISIBILITY", 32])
+    prep = DeviceBatchPreparer(c, is_train=True)
+    rng = np.random.default_rng(7)
+    imgs = [_image(rng, 64, 128), _image(rng, 90, 100), _image(rng, 50, 120)]
+    decisions = [((38, 75), True), ((90, 100), False), ((77, 50), True)]    # down-scale + flip, identity, mixed
+    targets = [BoxList(torch.tensor([[3.0, 4.0, 60.0, 40.0]]), (im.shape[1], im.shape[0]), mode="xyxy") for im in imgs]
+    for t in targets:
+        t.add_field("labels", torch.tensor([1]))
+    batch, out_t = prep([torch.from_numpy(i).cuda() for i in imgs], [t.to("cuda") for t in targets], decisions)
+    assert tuple(batch.tensors.shape) == (3, 3, 96, 128) and batch.image_sizes == [(38, 75), (90, 100), (77, 50)]
+    got = batch.tensors.cpu().numpy()
+    for i, (im, ((oh, ow), flip)) in enumerate(zip(imgs, decisions)):
+        want = preprocess(im, oh, ow, flip, c.INPUT.PIXEL_MEAN, c.INPUT.PIXEL_STD, c.INPUT.TO_BGR255)
+        assert np.array_equal(got[i, :, :oh, :ow], want), i
+        assert not got[i, :, oh:, :].any() and not got[i, :, :, ow:].any()
+        ref = targets[i].resize((ow, oh))
+        if flip:
+            ref = ref.transpose(0)
+        assert torch.equal(out_t[i].bbox.cpu(), ref.bbox) and out_t[i].size == (ow, oh)
+
+
+@pytest.mark.gpu
+def test_device_batch_preparation_at_cityscapes_size_and_model_input():
+    """1024x2048 -> 600x1200 (the DA yamls' training size) against Pillow directly; the result feeds the model"""
+    from da_detect_amd.config import cfg
+    from da_detect_amd.data.device_prep import DeviceBatchPreparer
+
+    c = cfg.clone()
+    c.merge_from_list(["INPUT.MIN_SIZE_TRAIN", (600,), "INPUT.MAX_SIZE_TRAIN", 1200, "DATALOADER.SIZE_DIVISIBILITY", 32])
+    prep = DeviceBatchPreparer(c, is_train=False)
+    img = _image(np.random.default_rng(1), 1024, 2048)
+    batch, _ = prep([torch.from_numpy(img).cuda()], None, [((600, 1200), False)])
+    assert tuple(batch.tensors.shape) == (1, 3, 608, 1216)
+    pil = np.asarray(Image.fromarray(img).resize((1200, 600), Image.BILINEAR)).astype(np.float32)
+    want = (pil / np.float32(255.0))[:, :, ::-1] * np.float32(255.0) - np.asarray(c.INPUT.PIXEL_MEAN, np.float32)
+    got = batch.tensors[0, :, :600, :1200].permute(1, 2, 0).cpu().numpy()
+    assert np.array_equal(got, want.astype(np.float32))
