@@ -55,16 +55,10 @@ __device__ inline void split4(const float4 v, uint2 (&out)[TERMS]) {
 // AB: stage-ablation mask for profiling experiments (tools/ablate.py).  It is a COMPILE-TIME parameter: as run-time
 // branches the checks cut the K loop into a dozen basic blocks and the scheduler could no longer interleave the
 // MFMAs with the split / LDS traffic across them.  Production launches use AB = 0.
-// W128: every lane stages 8 consecutive k (two adjacent 16-byte loads) of its rows instead of 4, so a term plane is
-// written with ds_write_b128 — half as many LDS store instructions in the section between the two barriers.  Needs
-// Cin % 8 == 0 (both halves must lie in the same filter tap); the stem (Cin = 4) keeps the 4-wide staging.
-template <int TM, int TN, int TERMS, int AB = 0, bool W128 = false>
+template <int TM, int TN, int TERMS, int AB = 0>
 __global__ __launch_bounds__(256, 2) void conv_fwd_split_kernel(const ConvArgs a) {
   constexpr int BM = 2 * TM * 32, BN = 2 * TN * 32;
-  constexpr int RPP = W128 ? 64 : 32;      // rows staged per pass
-  constexpr int HALVES = W128 ? 2 : 1;     // 16-byte loads per lane, row and pass
-  constexpr int LSH = W128 ? 2 : 3;        // lanes per row = 1 << LSH
-  constexpr int A_LOADS = BM / RPP * HALVES, B_LOADS = BN / RPP * HALVES;
+  constexpr int A_LOADS = BM / 32, B_LOADS = BN / 32;
   constexpr int A_PLANE = BM * PLANE_STRIDE, B_PLANE = BN * PLANE_STRIDE;  // bf16 elements
   extern __shared__ __attribute__((aligned(16))) char smem[];
   __bf16* As = reinterpret_cast<__bf16*>(smem);   // [TERMS][BM][PLANE_STRIDE]
@@ -77,7 +71,7 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_split_kernel(const ConvArgs a
   const int t = threadIdx.x;
   const int lane = t & 63, wave = t >> 6;
   const int wm = wave >> 1, wn = wave & 1;
-  const int lcol = t & ((1 << LSH) - 1);
+  const int lcol = t & 7;
   // Two workgroups share a CU, i.e. two waves share each SIMD's matrix pipe.  With equal priority they advance in
   // lockstep and reach their barrier / LDS-store sections at the same time, leaving the pipe idle; a static priority
   // by hardware wave slot (HW_ID.wave_id bit 0: co-resident waves of one SIMD sit in different slots) lets one run
@@ -89,8 +83,7 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_split_kernel(const ConvArgs a
   // staged row of this thread.  Eight lanes write one row's 64 bytes; a ds_write_b64 is serviced in 16-lane
   // groups over 32 banks, and with 80-byte rows two rows are bank-disjoint exactly when they are 4 (mod 8) apart,
   // so consecutive 8-lane groups take rows r and r + 4 (PMC: 33% of LDS cycles were conflicts with r, r + 1).
-  // (W128: four lanes write one row's 64 bytes with ds_write_b128, serviced in 8-lane groups: same r / r + 4 pairing)
-  const int lgrp = t >> LSH;
+  const int lgrp = t >> 3;
   const int lrow = (lgrp >> 3) * 8 + (lgrp & 1) * 4 + ((lgrp >> 1) & 3);
 
   const __amdgpu_buffer_rsrc_t xr = make_rsrc(a.x, a.x_bytes);
@@ -99,7 +92,7 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_split_kernel(const ConvArgs a
   const int HoWo = a.Ho * a.Wo;
 #pragma unroll
   for (int i = 0; i < A_LOADS; ++i) {
-    const int m = bm0 + lrow + RPP * (i / HALVES);
+    const int m = bm0 + lrow + 32 * i;
     if (m < a.M) {
       const int img = m / HoWo;
       const int rem = m - img * HoWo;
@@ -117,11 +110,11 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_split_kernel(const ConvArgs a
   unsigned wrow[B_LOADS];
 #pragma unroll
   for (int i = 0; i < B_LOADS; ++i) {
-    const int n = bn0 + lrow + RPP * (i / HALVES);
+    const int n = bn0 + lrow + 32 * i;
     wrow[i] = n < a.Cout ? (unsigned)n * (unsigned)a.K * 4u : kOOB;
   }
   float4 ra[A_LOADS], rb[B_LOADS];
-  int kk = lcol * 4 * HALVES;
+  int kk = lcol * 4;
   int tap = kk / a.Cin;
   int kc = kk - tap * a.Cin;
   int kr = tap / a.KW;
@@ -136,8 +129,7 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_split_kernel(const ConvArgs a
     for (int i = 0; i < A_LOADS; ++i) {
       const int hi = hi0[i] + kr, wi = wi0[i] + ks;
       const bool ok = kvalid && (unsigned)hi < (unsigned)a.H && (unsigned)wi < (unsigned)a.W;
-      const unsigned off = ((unsigned)(pixbase[i] + hi * a.W + wi) * (unsigned)a.Cin + (unsigned)kc) * 4u +
-                           16u * (unsigned)(i % HALVES);
+      const unsigned off = ((unsigned)(pixbase[i] + hi * a.W + wi) * (unsigned)a.Cin + (unsigned)kc) * 4u;
       ra[i] = buf_load4(xr, ok ? off : kOOB);
     }
   };
@@ -145,8 +137,7 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_split_kernel(const ConvArgs a
     const bool kvalid = kk < a.K;
 #pragma unroll
     for (int i = 0; i < B_LOADS; ++i)
-      rb[i] = buf_load4(wr, (kvalid && wrow[i] != kOOB) ? wrow[i] + (unsigned)kk * 4u + 16u * (unsigned)(i % HALVES)
-                                                         : kOOB);
+      rb[i] = buf_load4(wr, (kvalid && wrow[i] != kOOB) ? wrow[i] + (unsigned)kk * 4u : kOOB);
   };
   auto advance = [&]() {
     kk += BK;
@@ -172,31 +163,16 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_split_kernel(const ConvArgs a
     for (int i = 0; i < B_LOADS; ++i) split4<TERMS>(rb[i], pb_[i]);
   };
   auto store_tile = [&]() {
-    if constexpr (W128) {
 #pragma unroll
-      for (int i = 0; i < A_LOADS; i += 2)
+    for (int i = 0; i < A_LOADS; ++i)
 #pragma unroll
-        for (int p = 0; p < TERMS; ++p)
-          *reinterpret_cast<uint4*>(As + p * A_PLANE + (lrow + RPP * (i / 2)) * PLANE_STRIDE + lcol * 8) =
-              make_uint4(pa_[i][p].x, pa_[i][p].y, pa_[i + 1][p].x, pa_[i + 1][p].y);
+      for (int p = 0; p < TERMS; ++p)
+        *reinterpret_cast<uint2*>(As + p * A_PLANE + (lrow + 32 * i) * PLANE_STRIDE + lcol * 4) = pa_[i][p];
 #pragma unroll
-      for (int i = 0; i < B_LOADS; i += 2)
+    for (int i = 0; i < B_LOADS; ++i)
 #pragma unroll
-        for (int p = 0; p < TERMS; ++p)
-          *reinterpret_cast<uint4*>(Bs + p * B_PLANE + (lrow + RPP * (i / 2)) * PLANE_STRIDE + lcol * 8) =
-              make_uint4(pb_[i][p].x, pb_[i][p].y, pb_[i + 1][p].x, pb_[i + 1][p].y);
-    } else {
-#pragma unroll
-      for (int i = 0; i < A_LOADS; ++i)
-#pragma unroll
-        for (int p = 0; p < TERMS; ++p)
-          *reinterpret_cast<uint2*>(As + p * A_PLANE + (lrow + 32 * i) * PLANE_STRIDE + lcol * 4) = pa_[i][p];
-#pragma unroll
-      for (int i = 0; i < B_LOADS; ++i)
-#pragma unroll
-        for (int p = 0; p < TERMS; ++p)
-          *reinterpret_cast<uint2*>(Bs + p * B_PLANE + (lrow + 32 * i) * PLANE_STRIDE + lcol * 4) = pb_[i][p];
-    }
+      for (int p = 0; p < TERMS; ++p)
+        *reinterpret_cast<uint2*>(Bs + p * B_PLANE + (lrow + 32 * i) * PLANE_STRIDE + lcol * 4) = pb_[i][p];
   };
 
   f32x16 acc[TM][TN];
@@ -592,15 +568,15 @@ static int launch_split_ws(ConvArgs& a, hipStream_t st) {
   return check_launch("conv_forward(split, wave-specialised)");
 }
 
-template <int TM, int TN, int TERMS, int AB = 0, bool W128 = false>
-static int launch_split_w(ConvArgs& a, hipStream_t st) {
+template <int TM, int TN, int TERMS, int AB = 0>
+static int launch_split(ConvArgs& a, hipStream_t st) {
   constexpr int BM = 2 * TM * 32, BN = 2 * TN * 32;
   a.tiles_m = ceil_div(a.M, BM);
   a.tiles_n = ceil_div(a.Cout, BN);
   const size_t lds = sizeof(__bf16) * TERMS * (BM + BN) * PLANE_STRIDE;
   static bool attr_set = false;
   if (!attr_set && lds > 48 * 1024) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_fwd_split_kernel<TM, TN, TERMS, AB, W128>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_fwd_split_kernel<TM, TN, TERMS, AB>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) {
       set_error("conv_forward(split): hipFuncSetAttribute: %s", hipGetErrorString(e));
@@ -608,16 +584,9 @@ static int launch_split_w(ConvArgs& a, hipStream_t st) {
     }
     attr_set = true;
   }
-  hipLaunchKernelGGL((conv_fwd_split_kernel<TM, TN, TERMS, AB, W128>), dim3(a.tiles_m * a.tiles_n), dim3(256), lds,
-                     st, a);
+  hipLaunchKernelGGL((conv_fwd_split_kernel<TM, TN, TERMS, AB>), dim3(a.tiles_m * a.tiles_n), dim3(256), lds, st,
+                     a);
   return check_launch("conv_forward(split)");
-}
-
-template <int TM, int TN, int TERMS, int AB = 0>
-static int launch_split(ConvArgs& a, hipStream_t st) {
-  static const bool allow_w128 = !(getenv("DADET_W128") && getenv("DADET_W128")[0] == '0');
-  if (AB == 0 && TERMS == 3 && allow_w128 && a.Cin % 8 == 0) return launch_split_w<TM, TN, TERMS, 0, true>(a, st);
-  return launch_split_w<TM, TN, TERMS, AB, false>(a, st);
 }
 
 int launch_fwd_split(ConvArgs& a, int variant, int terms, hipStream_t st) {
