@@ -75,7 +75,8 @@ class FastRCNNLossComputation(object):
         for i, (pm, nm) in enumerate(zip(pos_masks, neg_masks)):
             if self._all_negative[i] and len(proposals[i]) <= limit:
                 continue      # every row is taken, in ascending order: the gather would be the identity
-            proposals[i] = proposals[i][torch.nonzero(pm | nm).squeeze(1)]
+            k = sum(self.fg_bg_sampler.last_counts[i])        # known on the host: no round trip for the index list
+            proposals[i] = proposals[i][torch.nonzero_static(pm | nm, size=k).squeeze(1)]
         return proposals
 
     def subsample(self, proposals, targets):
@@ -89,6 +90,8 @@ class FastRCNNLossComputation(object):
             prop.add_field("regression_targets", reg)
             prop.add_field("domain_labels", dom)
         self._proposals = self._take_sampled(proposals, pos_masks, neg_masks)
+        self._sampled_pos = [c[0] for c in self.fg_bg_sampler.last_counts]
+        self._is_source = [not neg for neg in self._all_negative]
         self._prepare_loss_indices()
         return self._proposals
 
@@ -100,9 +103,12 @@ class FastRCNNLossComputation(object):
         labels = cat([p.get_field("labels") for p in proposals], dim=0)
         regression_targets = cat([p.get_field("regression_targets") for p in proposals], dim=0)
         domain_masks = cat([p.get_field("domain_labels") for p in proposals], dim=0)
-        src = torch.nonzero(domain_masks).squeeze(1)
+        # both counts are known on the host (rows of source-domain images; positives the sampler kept among them)
+        n_src = sum(len(p) for p, s in zip(proposals, self._is_source) if s)
+        n_pos = sum(k for k, s in zip(self._sampled_pos, self._is_source) if s)
+        src = torch.nonzero_static(domain_masks, size=n_src).squeeze(1)
         labels_src = labels[src]
-        pos = torch.nonzero(labels_src > 0).squeeze(1)
+        pos = torch.nonzero_static(labels_src > 0, size=n_pos).squeeze(1)
         labels_pos = labels_src[pos]
         if self.cls_agnostic_bbox_reg:
             map_inds = torch.arange(4, 8, device=labels.device)

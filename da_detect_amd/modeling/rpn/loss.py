@@ -74,8 +74,10 @@ class RPNLossComputation(object):
         anchors = [cat_boxlist(a) for a in anchors]
         labels, regression_targets, _ = self.prepare_targets(anchors, targets)
         pos_masks, neg_masks = self.fg_bg_sampler(labels)
-        pos_inds = torch.nonzero(torch.cat(pos_masks, dim=0)).squeeze(1)
-        neg_inds = torch.nonzero(torch.cat(neg_masks, dim=0)).squeeze(1)
+        n_pos = sum(c[0] for c in self.fg_bg_sampler.last_counts)     # host-side counts: no round trips
+        n_neg = sum(c[1] for c in self.fg_bg_sampler.last_counts)
+        pos_inds = torch.nonzero_static(torch.cat(pos_masks, dim=0), size=n_pos).squeeze(1)
+        neg_inds = torch.nonzero_static(torch.cat(neg_masks, dim=0), size=n_neg).squeeze(1)
         sampled_inds = torch.cat([pos_inds, neg_inds], dim=0)
         labels = torch.cat(labels, dim=0)
         regression_targets = torch.cat(regression_targets, dim=0)
