@@ -6,6 +6,16 @@ import torch
 from ..utils import rng
 
 
+
+def _nz(mask, size):
+    """nonzero with a host-known result size (no device->host round trip); DADET_NONZERO_STATIC=0 restores nonzero()"""
+    if _STATIC:
+        return torch.nonzero_static(mask, size=size)
+    return torch.nonzero(mask)
+
+
+_STATIC = __import__("os").environ.get("DADET_NONZERO_STATIC", "1") == "1"
+
 class BalancedPositiveNegativeSampler(object):
     def __init__(self, batch_size_per_image, positive_fraction):
         self.batch_size_per_image = batch_size_per_image
@@ -47,8 +57,8 @@ class BalancedPositiveNegativeSampler(object):
                 self.last_counts.append((0, num_neg))
                 continue
             n_pos, n_neg = counts[i]
-            positive = torch.nonzero_static(masks[i][0], size=n_pos).squeeze(1)
-            negative = torch.nonzero_static(masks[i][1], size=n_neg).squeeze(1)
+            positive = _nz(masks[i][0], size=n_pos).squeeze(1)
+            negative = _nz(masks[i][1], size=n_neg).squeeze(1)
             num_pos = min(n_pos, int(self.batch_size_per_image * self.positive_fraction))
             num_neg = min(n_neg, self.batch_size_per_image - num_pos)
             perm1 = rng.randperm(n_pos, positive.device)[:num_pos]

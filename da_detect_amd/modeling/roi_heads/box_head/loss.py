@@ -14,6 +14,16 @@ from ...matcher import Matcher
 from ...utils import cat
 
 
+
+def _nz(mask, size):
+    """nonzero with a host-known result size (no device->host round trip); DADET_NONZERO_STATIC=0 restores nonzero()"""
+    if _STATIC:
+        return torch.nonzero_static(mask, size=size)
+    return torch.nonzero(mask)
+
+
+_STATIC = __import__("os").environ.get("DADET_NONZERO_STATIC", "1") == "1"
+
 class FastRCNNLossComputation(object):
     def __init__(self, proposal_matcher, fg_bg_sampler, box_coder, cls_agnostic_bbox_reg=False):
         self.proposal_matcher = proposal_matcher
@@ -76,7 +86,7 @@ class FastRCNNLossComputation(object):
             if self._all_negative[i] and len(proposals[i]) <= limit:
                 continue      # every row is taken, in ascending order: the gather would be the identity
             k = sum(self.fg_bg_sampler.last_counts[i])        # known on the host: no round trip for the index list
-            proposals[i] = proposals[i][torch.nonzero_static(pm | nm, size=k).squeeze(1)]
+            proposals[i] = proposals[i][_nz(pm | nm, size=k).squeeze(1)]
         return proposals
 
     def subsample(self, proposals, targets):
@@ -106,9 +116,9 @@ class FastRCNNLossComputation(object):
         # both counts are known on the host (rows of source-domain images; positives the sampler kept among them)
         n_src = sum(len(p) for p, s in zip(proposals, self._is_source) if s)
         n_pos = sum(k for k, s in zip(self._sampled_pos, self._is_source) if s)
-        src = torch.nonzero_static(domain_masks, size=n_src).squeeze(1)
+        src = _nz(domain_masks, size=n_src).squeeze(1)
         labels_src = labels[src]
-        pos = torch.nonzero_static(labels_src > 0, size=n_pos).squeeze(1)
+        pos = _nz(labels_src > 0, size=n_pos).squeeze(1)
         labels_pos = labels_src[pos]
         if self.cls_agnostic_bbox_reg:
             map_inds = torch.arange(4, 8, device=labels.device)

@@ -16,6 +16,16 @@ from ..matcher import Matcher
 from .utils import concat_box_prediction_layers
 
 
+
+def _nz(mask, size):
+    """nonzero with a host-known result size (no device->host round trip); DADET_NONZERO_STATIC=0 restores nonzero()"""
+    if _STATIC:
+        return torch.nonzero_static(mask, size=size)
+    return torch.nonzero(mask)
+
+
+_STATIC = __import__("os").environ.get("DADET_NONZERO_STATIC", "1") == "1"
+
 class RPNLossComputation(object):
     def __init__(self, proposal_matcher, fg_bg_sampler, box_coder, generate_labels_func):
         self.proposal_matcher = proposal_matcher
@@ -76,8 +86,8 @@ class RPNLossComputation(object):
         pos_masks, neg_masks = self.fg_bg_sampler(labels)
         n_pos = sum(c[0] for c in self.fg_bg_sampler.last_counts)     # host-side counts: no round trips
         n_neg = sum(c[1] for c in self.fg_bg_sampler.last_counts)
-        pos_inds = torch.nonzero_static(torch.cat(pos_masks, dim=0), size=n_pos).squeeze(1)
-        neg_inds = torch.nonzero_static(torch.cat(neg_masks, dim=0), size=n_neg).squeeze(1)
+        pos_inds = _nz(torch.cat(pos_masks, dim=0), size=n_pos).squeeze(1)
+        neg_inds = _nz(torch.cat(neg_masks, dim=0), size=n_neg).squeeze(1)
         sampled_inds = torch.cat([pos_inds, neg_inds], dim=0)
         labels = torch.cat(labels, dim=0)
         regression_targets = torch.cat(regression_targets, dim=0)
