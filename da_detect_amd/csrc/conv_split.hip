@@ -25,10 +25,6 @@ constexpr int PLANE_STRIDE = 40;  // bf16 per staged row: 32 + 8 pad = 80 bytes
 #define DADET_PRIO_SPLIT 0   /* measured: no effect on MFMA-only or full kernels; kept for experiments */
 #endif
 constexpr bool PRIO_SPLIT = DADET_PRIO_SPLIT != 0;
-#ifndef DADET_EARLY_BARRIER
-#define DADET_EARLY_BARRIER 1
-#endif
-constexpr bool EARLY_BARRIER = DADET_EARLY_BARRIER != 0;
 
 static int g_gemm_mode = 0;
 int gemm_mode() { return g_gemm_mode; }
@@ -179,21 +175,6 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_split_kernel(const ConvArgs a
         *reinterpret_cast<uint2*>(Bs + p * B_PLANE + (lrow + 32 * i) * PLANE_STRIDE + lcol * 4) = pb_[i][p];
   };
 
-  auto store_a = [&]() {
-#pragma unroll
-    for (int i = 0; i < A_LOADS; ++i)
-#pragma unroll
-      for (int p = 0; p < TERMS; ++p)
-        *reinterpret_cast<uint2*>(As + p * A_PLANE + (lrow + 32 * i) * PLANE_STRIDE + lcol * 4) = pa_[i][p];
-  };
-  auto store_b = [&]() {
-#pragma unroll
-    for (int i = 0; i < B_LOADS; ++i)
-#pragma unroll
-      for (int p = 0; p < TERMS; ++p)
-        *reinterpret_cast<uint2*>(Bs + p * B_PLANE + (lrow + 32 * i) * PLANE_STRIDE + lcol * 4) = pb_[i][p];
-  };
-
   f32x16 acc[TM][TN];
 #pragma unroll
   for (int i = 0; i < TM; ++i)
@@ -242,14 +223,6 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_split_kernel(const ConvArgs a
         for (int i = 0; i < TN; ++i)
           fb[p][i] = *reinterpret_cast<const bf16x8*>(Bb + p * B_PLANE + i * 32 * PLANE_STRIDE + step * 16);
       }
-      // EARLY BARRIER: once every wave holds its fragments of the tile's second half in registers nobody reads the
-      // LDS tile any more, so the barrier that protects it from being overwritten sits HERE — in front of the second
-      // group of MFMAs, not behind it — and the A planes of tile kt + 1 (split during the first group) are stored in
-      // the shadow of those MFMAs.  Only the B planes (split during this group) are stored after it.
-      if (EARLY_BARRIER && step == 1) {
-        if (!(ab & 64)) __syncthreads();
-        if (!(ab & 2)) store_a();
-      }
       // the next tile's operands have landed by now: split one operand per k16 group of MFMAs
       if (!(ab & 1)) {
         if (step == 0) split_a();
@@ -276,13 +249,10 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_split_kernel(const ConvArgs a
         // instructions that fit in its shadow
         constexpr int kMfma = TM * TN * (TERMS == 3 ? 6 : 3);
         constexpr int kValuPerMfma = (TM == 2 ? A_LOADS : B_LOADS) * (TERMS == 3 ? 26 : 14) / kMfma + 1;
-        if (!(EARLY_BARRIER && step == 1))
-          __builtin_amdgcn_sched_group_barrier(0x100, TERMS * (TM + TN), 0);   // DS reads
+        __builtin_amdgcn_sched_group_barrier(0x100, TERMS * (TM + TN), 0);   // DS reads
 #pragma unroll
         for (int i = 0; i < kMfma; ++i) {
           __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                 // one MFMA
-          if (EARLY_BARRIER && step == 1 && i < A_LOADS * TERMS)
-            __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);               // one LDS store of the A planes
           __builtin_amdgcn_sched_group_barrier(0x002, kValuPerMfma, 0);      // VALU in its shadow
         }
       }
@@ -293,10 +263,7 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_split_kernel(const ConvArgs a
       }
     }
     advance();
-    if (EARLY_BARRIER) {
-      if (!(ab & 2)) store_b();
-      if (!(ab & 64)) __syncthreads();
-    } else if (more) {
+    if (more) {
       if (!(ab & 64)) __syncthreads();
       if (!(ab & 2)) store_tile();
       if (!(ab & 64)) __syncthreads();
