@@ -21,7 +21,7 @@ _SUBMODULES = [
     "modeling.roi_heads.box_head.roi_box_predictors", "modeling.da_heads", "modeling.da_heads.da_heads",
     "modeling.da_heads.loss", "modeling.detector", "modeling.detector.detectors",
     "modeling.detector.generalized_rcnn", "solver", "solver.build", "solver.lr_scheduler", "engine",
-    "engine.trainer", "engine.inference", "data", "data.build", "data.transforms", "data.samplers", "data.collate_batch", "data.datasets", "utils", "utils.comm", "utils.registry",
+    "engine.trainer", "engine.inference", "data", "data.build", "data.transforms", "data.samplers", "data.collate_batch", "data.datasets", "utils", "utils.comm", "utils.registry", "utils.checkpoint", "utils.model_serialization", "utils.c2_model_loading",
 ]
 
 
