@@ -205,3 +205,27 @@ def test_device_batch_preparation_at_cityscapes_size_and_model_input():
     want = (pil / np.float32(255.0))[:, :, ::-1] * np.float32(255.0) - np.asarray(c.INPUT.PIXEL_MEAN, np.float32)
     got = batch.tensors[0, :, :600, :1200].permute(1, 2, 0).cpu().numpy()
     assert np.array_equal(got, want.astype(np.float32))
+
+
+@pytest.mark.gpu
+def test_training_entry_point_on_a_tiny_dataset(tmp_path):
+    """tools/train_net_da.py end to end: json datasets -> host transforms -> loaders -> do_da_train -> checkpoints"""
+    import subprocess
+    import sys
+
+    rng = np.random.default_rng(0)
+    specs = {k: _write_coco(str(tmp_path), k, 4, rng, sizes=[(96, 192)] * 4) for k in ("source", "target")}
+    out = str(tmp_path / "out")
+    os.makedirs(out)
+    root = os.path.dirname(HERE)
+    cmd = [sys.executable, os.path.join(root, "tools", "train_net_da.py"), "--config-file",
+           os.path.join(root, "configs/da_faster_rcnn/e2e_da_faster_rcnn_R_50_C4_cityscapes_to_foggy_cityscapes.yaml"),
+           "--source", ",".join(specs["source"]), "--target", ",".join(specs["target"]),
+           "SOLVER.MAX_ITER", "4", "SOLVER.CHECKPOINT_PERIOD", "2", "DATALOADER.NUM_WORKERS", "0",
+           "INPUT.MIN_SIZE_TRAIN", "(96,)", "INPUT.MAX_SIZE_TRAIN", "192", "MODEL.OUTPUT_DIR", out, "MODEL.WEIGHT", ""]
+    res = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0, res.stderr[-2000:]
+    assert "iter 0" in res.stderr and "loss" in res.stderr
+    assert os.path.exists(os.path.join(out, "model_final.pth")) and os.path.exists(os.path.join(out, "model_0000002.pth"))
+    ck = torch.load(os.path.join(out, "model_final.pth"), map_location="cpu", weights_only=False)
+    assert set(ck) >= {"model", "optimizer", "scheduler", "iteration"}
