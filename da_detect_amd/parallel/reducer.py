@@ -33,6 +33,7 @@ class BucketedGradReducer(object):
         self._hooks = [p.register_post_accumulate_grad_hook(self._on_grad) for p in self.params]
         self._next = 0
         self._finalized = True
+        self.touched = set()       # ids of the parameters that received a gradient since zero_grad()
 
     def _build(self, bucket_bytes):
         cur, cur_bytes = [], 0
@@ -67,6 +68,7 @@ class BucketedGradReducer(object):
             b["work"] = None
         self._next = 0
         self._finalized = False
+        self.touched = set()
 
     def _launch_ready(self, force=False):
         """collectives must be issued in the same order on every rank: buckets are launched strictly by index,
@@ -81,6 +83,7 @@ class BucketedGradReducer(object):
 
     def _on_grad(self, p):
         b = self._bucket_of[id(p)]
+        self.touched.add(id(p))
         b["pending"] -= 1
         if b["pending"] == 0 and not self._finalized:
             self._launch_ready()

@@ -39,6 +39,11 @@ class FusedSGD(torch.optim.Optimizer):
             for p in group["params"]:
                 if p.grad is None:
                     continue
+                # with the reducer every .grad is a persistent (zeroed) bucket view: a parameter that received no
+                # gradient this step must still be SKIPPED, as torch.optim.SGD skips `grad is None` (no weight decay,
+                # no momentum update) — e.g. the instance head when its loss weight is 0
+                if self.reducer is not None and id(p) not in self.reducer.touched:
+                    continue
                 out.append((p, group["lr"], group["weight_decay"], group["momentum"]))
         return out
 
@@ -67,12 +72,12 @@ class FusedSGD(torch.optim.Optimizer):
                 p.grad = g
             st = self.state[p]
             if "momentum_buffer" not in st:
-                st["momentum_buffer"] = torch.empty_strided(p.size(), p.stride(), dtype=p.dtype, device=p.device)
-                first.append(True)
-            else:
-                first.append(False)
+                # a zero buffer makes the general update `buf = momentum * buf + d` equal torch's first-step rule
+                # `buf = d` exactly, also for a parameter that joins later (first gradient after some steps)
+                st["momentum_buffer"] = torch.empty_strided(p.size(), p.stride(), dtype=p.dtype,
+                                                            device=p.device).zero_()
+            first.append(False)
             rows.append((p.data_ptr(), g.data_ptr(), st["momentum_buffer"].data_ptr(), p.numel(), lr, wd))
-        assert all(first) or not any(first), "FusedSGD: parameters joined after the first step are not supported"
         key = tuple(rows)
         if self._table is None or self._table[0] != key:
             arr = (SgdEntry * len(rows))()

@@ -171,13 +171,17 @@ def test_fused_sgd_matches_torch_sgd(device):
         fused.zero_grad()
         ref.zero_grad()
         gs = [torch.randn(s, device=device) for s in shapes]
-        for p, q, g in zip(ps, qs, gs):
+        for i, (p, q, g) in enumerate(zip(ps, qs, gs)):
+            if i == 3 or (i == 2 and step < 2):
+                continue      # parameter 3 never gets a gradient, parameter 2 only from the third step on:
+                              # torch skips `grad is None` parameters (no weight decay, no momentum)
             (p * g).sum().backward()
             (q * g).sum().backward()
         fused.step()
         ref.step()
     for p, q in zip(ps, qs):
         torch.testing.assert_close(p.detach(), q.detach(), rtol=1e-6, atol=1e-7)
+    assert torch.equal(ps[3].detach(), qs[3].detach())
 
 
 # ---- size-independent properties at the BASELINE sizes ------------------------------------------------------
