@@ -41,7 +41,11 @@ def test_oracle_identities_cpu():
 @pytest.mark.gpu
 @pytest.mark.parametrize("cfg", [(2, 16, 9, 11, 24, 3, 1, 1, False), (2, 32, 12, 10, 16, 3, 1, 1, True),
                                  (1, 64, 15, 13, 32, 3, 2, 2, True), (1, 1024, 6, 7, 8, 3, 1, 4, True),
-                                 (2, 8, 7, 7, 8, 1, 1, 1, True)])
+                                 (2, 8, 7, 7, 8, 1, 1, 1, True),
+                                 # LDS-window backward (stride 1, C % 64 == 0): ragged tiles, 2 groups, and 4 groups of
+                                 # 16 channels (lanes of one chunk in different deformable groups)
+                                 (2, 64, 20, 19, 16, 3, 1, 1, True), (1, 128, 9, 17, 8, 3, 1, 2, False),
+                                 (1, 64, 10, 10, 8, 3, 1, 4, True)])
 def test_deform_conv_matches_oracle(device, cfg):
     from da_detect_amd.layers.dcn import deform_conv, modulated_deform_conv
     from oracle import deform_ref as R
