@@ -106,3 +106,33 @@ def main():
 
 if __name__ == "__main__":
     main()
+
+
+def image_prep():
+    """device-side Resize + flip + BGR-255 + normalise + pad of one 1024x2048 image to the DA yamls' 600x1200"""
+    import numpy as np
+    from da_detect_amd.config import cfg
+    from da_detect_amd.data.device_prep import DeviceBatchPreparer
+
+    c = cfg.clone()
+    c.merge_from_list(["INPUT.MIN_SIZE_TRAIN", (600,), "INPUT.MAX_SIZE_TRAIN", 1200, "DATALOADER.SIZE_DIVISIBILITY", 32])
+    prep = DeviceBatchPreparer(c, is_train=True)
+    img = torch.from_numpy(np.random.default_rng(0).integers(0, 256, (1024, 2048, 3), dtype=np.uint8)).to(dev)
+    ms = timeit(lambda: prep([img], None, [((600, 1200), True)]))
+    print("image prep 1024x2048 -> 600x1200 (+pad 608x1216): %.3f ms  (%.0f MB/s of input pixels)" % (
+        ms, 1024 * 2048 * 3 / ms / 1e3))
+    try:
+        import time
+        from PIL import Image
+        pil = Image.fromarray(img.cpu().numpy())
+        t0 = time.perf_counter()
+        for _ in range(5):
+            r = np.asarray(pil.resize((1200, 600), Image.BILINEAR), dtype=np.float32)
+            r = (r[:, ::-1, ::-1] / 255.0 * 255.0 - np.asarray(c.INPUT.PIXEL_MEAN, np.float32))
+        print("  host chain (Pillow resize + numpy normalise, 1 core): %.1f ms" % ((time.perf_counter() - t0) / 5 * 1e3))
+    except ImportError:
+        pass
+
+
+if __name__ == "__main__" and os.environ.get("DADET_MICROBENCH_IMAGE", "1") == "1":
+    image_prep()
