@@ -264,6 +264,9 @@ def conv_forward(x, w, scale=None, bias=None, addend=None, mask_ref=None, stride
             kname = ("conv_fwd_kernel<%s>" if mode == 0 else ("conv_fwd_split_kernel<%%s,%d>" % mode)) % \
                 ("2,2", "2,1", "1,1")[variant]
             _KNAME_CACHE[key] = kname
+        if getattr(PROFILER, "detail", False):   # tools/gemm_table.py: one row per problem shape
+            kname = "%s|M=%d N=%d K=%d k%dx%d s%d%s" % (kname, N * Ho * Wo, Cout, Cin * KH * KW, KH, KW, stride,
+                                                        " +add" if addend is not None else "")
         with PROFILER.span(kname,
                            2.0 * N * Ho * Wo * Cout * Cin * KH * KW,
                            4.0 * (x.numel() + w.numel() + out.numel() + (addend.numel() if addend is not None else 0)
@@ -304,7 +307,10 @@ def conv_wgrad(x, gy, weight_shape, stride=1, pad=0, out_scale=None, dw=None, ac
     ws = _workspace(nbytes.value, x.device)
     if PROFILER is not None:
         mode = get_gemm_mode()
-        with PROFILER.span("conv_wgrad_kernel" if mode == 0 else "conv_wgrad_split_kernel<%d>" % mode,
+        kname = "conv_wgrad_kernel" if mode == 0 else "conv_wgrad_split_kernel<%d>" % mode
+        if getattr(PROFILER, "detail", False):
+            kname = "%s|M=%d N=%d K=%d k%dx%d s%d" % (kname, N * Ho * Wo, Cout, Cin * KH * KW, KH, KW, stride)
+        with PROFILER.span(kname,
                            2.0 * N * Ho * Wo * Cout * Cin * KH * KW,
                            4.0 * (x.numel() + gy.numel() + dw.numel())):
             _lib.call("dadet_conv_wgrad", ctypes.byref(d), _p(x), _p(gy), _p(out_scale), _p(dw),
