@@ -25,6 +25,7 @@
 // this cross-workgroup overlap that keeps the matrix pipe fed across the two barriers of a K-tile (PMC on
 // the double-buffered / 2-workgroup variant: 38% of wave cycles parked in s_waitcnt/s_barrier).
 // Workgroup ids are remapped so that each XCD (private L2) walks a contiguous range of m-tiles.
+#include <cstdlib>
 #include "conv_common.h"
 #include <stdlib.h>
 
@@ -507,8 +508,13 @@ static void wgrad_plan(const dadet_conv_desc* d, int* tiles_co, int* tiles_kc, i
   *tiles_co = ceil_div(d->Cout, 128);
   *tiles_kc = ceil_div(K, 128);
   const int tiles = (*tiles_co) * (*tiles_kc);
-  int want = ceil_div(3 * kNumCU, tiles);       // ~3 workgroups per CU in total
-  const int max_splits = ceil_div(M, 256);      // at least 8 K-steps per split
+  // total workgroups aimed at (tiles x splits); DADET_WGRAD_TARGET overrides it (tools/wgrad_sweep.py)
+  int target = 3 * kNumCU;
+  int min_rows = 256;                           // at least 8 K-steps per split
+  if (const char* e = getenv("DADET_WGRAD_TARGET")) { int v = atoi(e); if (v > 0) target = v; }
+  if (const char* e = getenv("DADET_WGRAD_MIN_ROWS")) { int v = atoi(e); if (v >= 32) min_rows = v; }
+  int want = ceil_div(target, tiles);
+  const int max_splits = ceil_div(M, min_rows);
   if (want > max_splits) want = max_splits;
   if (want < 1) want = 1;
   int rows = ceil_div(M, want);

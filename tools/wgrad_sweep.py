@@ -1,0 +1,63 @@
+"""Sweep of the weight-gradient split plan (total workgroups aimed at, minimum rows per split) over the step's
+weight-gradient shapes.  Usage (GPU box): python tools/wgrad_sweep.py"""
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from da_detect_amd import _C  # noqa: E402
+
+CL = torch.channels_last
+# (name, N, H, W, Cin, Cout, k, stride, launches per step)
+SHAPES = [
+    ("res5 3x3", 512, 7, 7, 512, 512, 3, 1, 3),
+    ("rpn 3x3", 2, 64, 128, 1024, 1024, 3, 1, 1),
+    ("res5 1x1 512->2048", 512, 7, 7, 512, 2048, 1, 1, 3),
+    ("res5 1x1 2048->512", 512, 7, 7, 2048, 512, 1, 1, 2),
+    ("res5 ds 1024->2048 s2", 512, 14, 14, 1024, 2048, 1, 2, 1),
+    ("res4 3x3", 2, 64, 128, 256, 256, 3, 1, 6),
+    ("res3 3x3", 2, 128, 256, 128, 128, 3, 1, 4),
+    ("res4 1x1 256->1024", 2, 64, 128, 256, 1024, 1, 1, 6),
+    ("res4 1x1 1024->256", 2, 64, 128, 1024, 256, 1, 1, 5),
+    ("res3 1x1 128->512", 2, 128, 256, 128, 512, 1, 1, 4),
+    ("res3 1x1 512->128", 2, 128, 256, 512, 128, 1, 1, 3),
+]
+
+
+def timeit(fn, iters=20):
+    for _ in range(3):
+        fn()
+    torch.cuda.synchronize()
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record()
+    for _ in range(iters):
+        fn()
+    e.record()
+    torch.cuda.synchronize()
+    return s.elapsed_time(e) / iters
+
+
+def main():
+    dev = torch.device("cuda", 0)
+    plans = [(768, 256), (512, 256), (1024, 256), (1024, 128), (1536, 128), (2048, 128), (2048, 64), (4096, 64)]
+    print("%-26s" % "shape" + "".join("%12s" % ("%d/%d" % p) for p in plans))
+    totals = [0.0] * len(plans)
+    for name, N, H, W, Cin, Cout, k, stride, per_step in SHAPES:
+        pad = k // 2
+        Ho, Wo = (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
+        x = torch.randn(N, Cin, H, W, device=dev).contiguous(memory_format=CL)
+        gy = torch.randn(N, Cout, Ho, Wo, device=dev).contiguous(memory_format=CL)
+        row = []
+        for i, (target, min_rows) in enumerate(plans):
+            os.environ["DADET_WGRAD_TARGET"] = str(target)
+            os.environ["DADET_WGRAD_MIN_ROWS"] = str(min_rows)
+            ms = timeit(lambda: _C.conv_wgrad(x, gy, (Cout, Cin, k, k), stride, pad))
+            row.append(ms)
+            totals[i] += ms * per_step
+        print("%-26s" % name + "".join("%12.4f" % v for v in row))
+    print("%-26s" % "per step (ms)" + "".join("%12.3f" % v for v in totals))
+
+
+if __name__ == "__main__":
+    main()
