@@ -40,7 +40,7 @@ def timeit(fn, iters=20):
 
 def main():
     dev = torch.device("cuda", 0)
-    plans = [(768, 256), (512, 256), (1024, 256), (1024, 128), (1536, 128), (2048, 128), (2048, 64), (4096, 64)]
+    plans = [(t, 128) for t in (128, 256, 384, 512, 640, 768, 1024, 1280, 1536, 2048, 2560, 3072)]
     print("%-26s" % "shape" + "".join("%12s" % ("%d/%d" % p) for p in plans))
     totals = [0.0] * len(plans)
     for name, N, H, W, Cin, Cout, k, stride, per_step in SHAPES:
