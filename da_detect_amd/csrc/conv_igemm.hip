@@ -514,6 +514,7 @@ static void wgrad_plan(const dadet_conv_desc* d, int* tiles_co, int* tiles_kc, i
   if (const char* e = getenv("DADET_WGRAD_TARGET")) { int v = atoi(e); if (v > 0) target = v; }
   if (const char* e = getenv("DADET_WGRAD_MIN_ROWS")) { int v = atoi(e); if (v >= 32) min_rows = v; }
   int want = ceil_div(target, tiles);
+  if (const char* e = getenv("DADET_WGRAD_SPLITS")) { int v = atoi(e); if (v > 0) want = v; }
   const int max_splits = ceil_div(M, min_rows);
   if (want > max_splits) want = max_splits;
   if (want < 1) want = 1;

@@ -40,23 +40,25 @@ def timeit(fn, iters=20):
 
 def main():
     dev = torch.device("cuda", 0)
-    plans = [(t, 128) for t in (128, 256, 384, 512, 640, 768, 1024, 1280, 1536, 2048, 2560, 3072)]
-    print("%-26s" % "shape" + "".join("%12s" % ("%d/%d" % p) for p in plans))
-    totals = [0.0] * len(plans)
+    slots = [256, 384, 512, 768, 1024, 1536, 2048, 3072, 4096]
+    print("%-26s %5s " % ("shape", "tiles") + "".join("%16s" % ("<=%d" % p) for p in slots))
+    os.environ["DADET_WGRAD_MIN_ROWS"] = "64"
+    best_total = 0.0
     for name, N, H, W, Cin, Cout, k, stride, per_step in SHAPES:
         pad = k // 2
         Ho, Wo = (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
         x = torch.randn(N, Cin, H, W, device=dev).contiguous(memory_format=CL)
         gy = torch.randn(N, Cout, Ho, Wo, device=dev).contiguous(memory_format=CL)
+        tiles = -(-Cout // 128) * -(-(Cin * k * k) // 128)
         row = []
-        for i, (target, min_rows) in enumerate(plans):
-            os.environ["DADET_WGRAD_TARGET"] = str(target)
-            os.environ["DADET_WGRAD_MIN_ROWS"] = str(min_rows)
+        for n in slots:
+            s = max(1, n // tiles)
+            os.environ["DADET_WGRAD_SPLITS"] = str(s)
             ms = timeit(lambda: _C.conv_wgrad(x, gy, (Cout, Cin, k, k), stride, pad))
-            row.append(ms)
-            totals[i] += ms * per_step
-        print("%-26s" % name + "".join("%12.4f" % v for v in row))
-    print("%-26s" % "per step (ms)" + "".join("%12.3f" % v for v in totals))
+            row.append((s, ms))
+        best_total += min(v for _, v in row) * per_step
+        print("%-26s %5d " % (name, tiles) + "".join("%16s" % ("s=%d %.4f" % v) for v in row))
+    print("per step with the best plan of every shape: %.3f ms" % best_total)
 
 
 if __name__ == "__main__":
