@@ -503,23 +503,42 @@ extern "C" int dadet_conv_forward_variant(const dadet_conv_desc* d) {
   return fwd_variant(d->N * d->Ho * d->Wo, d->Cout);
 }
 
+// Split plan of the weight gradient: the (co tile, kc tile) grid is small (4 ... 576 tiles), so the reduction over the
+// M = N*Ho*Wo rows is cut into `splits` ranges to fill the 2 x 256 workgroup slots of the chip.  The number of
+// workgroups matters in steps of 512: one more than a multiple of 512 costs a whole extra pass of mostly idle CUs
+// (tools/wgrad_sweep.py: res5 3x3, 144 tiles: 3 splits = 432 workgroups 0.80 ms, 4 splits = 576 workgroups 0.99 ms,
+// 7 splits = 1008 workgroups 0.73 ms).  The plan minimises a small cost model fitted to that sweep, in microseconds:
+// passes x (fixed + K-steps x step time) + the reduction pass over the partial results.
 static void wgrad_plan(const dadet_conv_desc* d, int* tiles_co, int* tiles_kc, int* splits, int* rps) {
   const int M = d->N * d->Ho * d->Wo, K = d->KH * d->KW * d->Cin;
   *tiles_co = ceil_div(d->Cout, 128);
   *tiles_kc = ceil_div(K, 128);
   const int tiles = (*tiles_co) * (*tiles_kc);
-  // total workgroups aimed at (tiles x splits); DADET_WGRAD_TARGET overrides it (tools/wgrad_sweep.py)
-  int target = 3 * kNumCU;
-  int min_rows = 256;                           // at least 8 K-steps per split
-  if (const char* e = getenv("DADET_WGRAD_TARGET")) { int v = atoi(e); if (v > 0) target = v; }
+  int min_rows = 128;                           // at least 4 K-steps per split
   if (const char* e = getenv("DADET_WGRAD_MIN_ROWS")) { int v = atoi(e); if (v >= 32) min_rows = v; }
-  int want = ceil_div(target, tiles);
-  if (const char* e = getenv("DADET_WGRAD_SPLITS")) { int v = atoi(e); if (v > 0) want = v; }
   const int max_splits = ceil_div(M, min_rows);
-  if (want > max_splits) want = max_splits;
-  if (want < 1) want = 1;
-  int rows = ceil_div(M, want);
-  rows = ceil_div(rows, 32) * 32;
+  const int slots = 2 * kNumCU;                 // two workgroups per CU
+  const double kStep2 = 3.0, kStep1 = 2.0;      // one 32-row K-step with two / one workgroup(s) on the CU
+  const double kFixed = 9.0;                    // prologue + epilogue of a workgroup
+  const double dw_bytes = 4.0 * d->Cout * (double)K;
+  int best = 1;
+  double best_cost = 1e30;
+  for (int s = 1; s <= max_splits && (s == 1 || (long)tiles * s <= 8 * slots); ++s) {
+    int rows = ceil_div(ceil_div(M, s), 32) * 32;
+    if (ceil_div(M, rows) != s) continue;       // same plan as a smaller s
+    const double steps = rows / 32.0;
+    const long wgs = (long)tiles * s;
+    const long full = wgs / slots, rem = wgs % slots;
+    double cost = full * (kFixed + steps * kStep2);
+    if (rem > 0) {
+      const double step = rem <= slots / 2 ? kStep1 : kStep1 + (kStep2 - kStep1) * (rem - slots / 2) / (slots / 2);
+      cost += kFixed + steps * step;
+    }
+    if (s > 1) cost += 5.0 + (s + 1) * dw_bytes / 3.0e6;   // reduction pass: launch + (s reads + 1 write) at 3 TB/s
+    if (cost < best_cost) { best_cost = cost; best = s; }
+  }
+  if (const char* e = getenv("DADET_WGRAD_SPLITS")) { int v = atoi(e); if (v > 0) best = v < max_splits ? v : max_splits; }
+  int rows = ceil_div(ceil_div(M, best), 32) * 32;
   *rps = rows;
   *splits = ceil_div(M, rows);
 }

@@ -1,5 +1,5 @@
-"""Sweep of the weight-gradient split plan (total workgroups aimed at, minimum rows per split) over the step's
-weight-gradient shapes.  Usage (GPU box): python tools/wgrad_sweep.py"""
+"""Sweep of the weight-gradient split count (workgroups just below multiples of the chip's slots) over the step's
+weight-gradient shapes, next to the library's own plan.  Usage (GPU box): python tools/wgrad_sweep.py"""
 import os
 import sys
 
@@ -40,10 +40,9 @@ def timeit(fn, iters=20):
 
 def main():
     dev = torch.device("cuda", 0)
-    slots = [256, 384, 512, 768, 1024, 1536, 2048, 3072, 4096]
-    print("%-26s %5s " % ("shape", "tiles") + "".join("%16s" % ("<=%d" % p) for p in slots))
-    os.environ["DADET_WGRAD_MIN_ROWS"] = "64"
-    best_total = 0.0
+    slots = [0, 256, 384, 512, 768, 1024, 1536, 2048, 3072, 4096]
+    print("%-26s %5s " % ("shape", "tiles") + "".join("%16s" % ("<=%d" % p if p else "plan") for p in slots))
+    best_total = plan_total = 0.0
     for name, N, H, W, Cin, Cout, k, stride, per_step in SHAPES:
         pad = k // 2
         Ho, Wo = (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
@@ -53,12 +52,17 @@ def main():
         row = []
         for n in slots:
             s = max(1, n // tiles)
-            os.environ["DADET_WGRAD_SPLITS"] = str(s)
+            if n:
+                os.environ["DADET_WGRAD_SPLITS"] = str(s)
+            else:
+                os.environ.pop("DADET_WGRAD_SPLITS", None)   # the library's own plan
             ms = timeit(lambda: _C.conv_wgrad(x, gy, (Cout, Cin, k, k), stride, pad))
             row.append((s, ms))
         best_total += min(v for _, v in row) * per_step
+        plan_total += row[0][1] * per_step
         print("%-26s %5d " % (name, tiles) + "".join("%16s" % ("s=%d %.4f" % v) for v in row))
-    print("per step with the best plan of every shape: %.3f ms" % best_total)
+    print("per step with the best plan of every shape: %.3f ms; with the library's plan: %.3f ms" % (best_total,
+                                                                                                    plan_total))
 
 
 if __name__ == "__main__":
