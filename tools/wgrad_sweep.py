@@ -38,6 +38,15 @@ def timeit(fn, iters=20):
     return s.elapsed_time(e) / iters
 
 
+def planned_splits(x, gy, Cout, Cin, k, stride, pad):
+    import ctypes
+    from da_detect_amd import _lib
+    d = _C._desc(x.shape[0], x.shape[2], x.shape[3], Cin, Cout, k, k, stride, pad, gy.shape[2], gy.shape[3])
+    nbytes = ctypes.c_size_t(0)
+    _lib.call("dadet_conv_wgrad_workspace_bytes", ctypes.byref(d), ctypes.byref(nbytes))
+    return max(1, nbytes.value // (4 * Cout * Cin * k * k))
+
+
 def main():
     dev = torch.device("cuda", 0)
     slots = [0, 256, 384, 512, 768, 1024, 1536, 2048, 3072, 4096]
@@ -57,6 +66,8 @@ def main():
             else:
                 os.environ.pop("DADET_WGRAD_SPLITS", None)   # the library's own plan
             ms = timeit(lambda: _C.conv_wgrad(x, gy, (Cout, Cin, k, k), stride, pad))
+            if not n:
+                s = planned_splits(x, gy, Cout, Cin, k, stride, pad)
             row.append((s, ms))
         best_total += min(v for _, v in row) * per_step
         plan_total += row[0][1] * per_step
