@@ -280,6 +280,7 @@ __global__ __launch_bounds__(256, 3) void conv_wgrad_kernel(const WgradArgs a) {
     r_ho[i] = rem / a.Wo;
     r_wo[i] = rem - r_ho[i] * a.Wo;
   }
+  const int d_img = RK / HoWo, d_ho = (RK - d_img * HoWo) / a.Wo, d_wo = RK - d_img * HoWo - d_ho * a.Wo;
   int m_cur = m_begin;
   auto load_tile = [&]() {
 #pragma unroll
@@ -293,14 +294,15 @@ __global__ __launch_bounds__(256, 3) void conv_wgrad_kernel(const WgradArgs a) {
       const unsigned off = ((unsigned)((r_img[i] * a.H + hi) * a.W + wi) * (unsigned)a.Cin + (unsigned)ci) * 4u;
       rx[i] = buf_load4(xr, ok ? off : kOOB);
       // advance this row by RK output pixels
-      r_wo[i] += RK;
-      while (r_wo[i] >= a.Wo) {
-        r_wo[i] -= a.Wo;
-        if (++r_ho[i] == a.Ho) {
-          r_ho[i] = 0;
-          ++r_img[i];
-        }
-      }
+      int wo = r_wo[i] + d_wo;
+      const int cw = wo >= a.Wo;
+      wo -= cw ? a.Wo : 0;
+      int ho = r_ho[i] + d_ho + cw;
+      const int ch = ho >= a.Ho;
+      ho -= ch ? a.Ho : 0;
+      r_wo[i] = wo;
+      r_ho[i] = ho;
+      r_img[i] += d_img + ch;
     }
     m_cur += RK;
   };
