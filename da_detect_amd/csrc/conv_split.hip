@@ -628,7 +628,7 @@ int launch_fwd_split(ConvArgs& a, int variant, int terms, hipStream_t st) {
 // and writes for each channel the four m-values as one 8-byte ds_write into a [channel][m] plane
 // ([128][32 + 8 pad] bf16 per term).  Lane -> (m-group = t % 8, channel-quad = t / 8) keeps the global loads as
 // 128-byte row segments and the LDS writes bank-conflict free.
-template <int TERMS>
+template <int TERMS, bool SMALL_MAP>
 __global__ __launch_bounds__(256, 2) void conv_wgrad_split_kernel(const WgradArgs a) {
   constexpr int TILE = 128, RK = 32;
   constexpr int PLANE = TILE * PLANE_STRIDE;
@@ -692,17 +692,28 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_split_kernel(const WgradArg
       const bool ok = m < m_end && kvalid && (unsigned)hi < (unsigned)a.H && (unsigned)wi < (unsigned)a.W;
       const unsigned off = ((unsigned)((r_img[j] * a.H + hi) * a.W + wi) * (unsigned)a.Cin + (unsigned)ci) * 4u;
       rx[j] = buf_load4(xr, ok ? off : kOOB);
-      // advance the row by RK output pixels: mixed-radix add of (d_img, d_ho, d_wo), branch-free (a loop over the
-      // wrap-arounds costs 16% on 7x7 maps, where 32 pixels are 4.6 rows, and breaks the basic block)
-      int wo = r_wo[j] + d_wo;
-      const int cw = wo >= a.Wo;
-      wo -= cw ? a.Wo : 0;
-      int ho = r_ho[j] + d_ho + cw;
-      const int ch = ho >= a.Ho;
-      ho -= ch ? a.Ho : 0;
-      r_wo[j] = wo;
-      r_ho[j] = ho;
-      r_img[j] += d_img + ch;
+      // advance the row by RK output pixels.  Maps narrower than RK (the 7x7 maps of the box head: 32 pixels are 4.6
+      // rows): branch-free mixed-radix add of (d_img, d_ho, d_wo) — a loop over the wrap-arounds costs 16% there
+      if (SMALL_MAP) {
+        int wo = r_wo[j] + d_wo;
+        const int cw = wo >= a.Wo;
+        wo -= cw ? a.Wo : 0;
+        int ho = r_ho[j] + d_ho + cw;
+        const int ch = ho >= a.Ho;
+        ho -= ch ? a.Ho : 0;
+        r_wo[j] = wo;
+        r_ho[j] = ho;
+        r_img[j] += d_img + ch;
+      } else {   // Wo >= RK: at most one wrap, rarely taken
+        r_wo[j] += RK;
+        if (r_wo[j] >= a.Wo) {
+          r_wo[j] -= a.Wo;
+          if (++r_ho[j] == a.Ho) {
+            r_ho[j] = 0;
+            ++r_img[j];
+          }
+        }
+      }
     }
     m_cur += RK;
   };
@@ -821,12 +832,12 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_split_kernel(const WgradArg
   }
 }
 
-template <int TERMS>
+template <int TERMS, bool SMALL_MAP>
 static int launch_wgrad_terms(WgradArgs& a, hipStream_t st) {
   const size_t lds = sizeof(__bf16) * TERMS * 2 * 128 * PLANE_STRIDE;
   static bool attr_set = false;
   if (!attr_set && lds > 48 * 1024) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad_split_kernel<TERMS>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad_split_kernel<TERMS, SMALL_MAP>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) {
       set_error("conv_wgrad(split): hipFuncSetAttribute: %s", hipGetErrorString(e));
@@ -834,12 +845,15 @@ static int launch_wgrad_terms(WgradArgs& a, hipStream_t st) {
     }
     attr_set = true;
   }
-  hipLaunchKernelGGL(conv_wgrad_split_kernel<TERMS>, dim3(a.tiles_co * a.tiles_kc, a.splits), dim3(256), lds, st, a);
+  hipLaunchKernelGGL((conv_wgrad_split_kernel<TERMS, SMALL_MAP>), dim3(a.tiles_co * a.tiles_kc, a.splits), dim3(256),
+                     lds, st, a);
   return check_launch("conv_wgrad(split)");
 }
 
 int launch_wgrad_split(WgradArgs& a, int terms, hipStream_t st) {
-  return terms == 2 ? launch_wgrad_terms<2>(a, st) : launch_wgrad_terms<3>(a, st);
+  const bool small_map = a.Wo < 32;   // narrower than one K-step of rows
+  if (terms == 2) return small_map ? launch_wgrad_terms<2, true>(a, st) : launch_wgrad_terms<2, false>(a, st);
+  return small_map ? launch_wgrad_terms<3, true>(a, st) : launch_wgrad_terms<3, false>(a, st);
 }
 
 }  // namespace dadet
