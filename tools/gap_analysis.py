@@ -104,3 +104,45 @@ if steps:
         mainq, len(gaps2), sum(g for g, _, _ in gaps2) / 1e6 / steps))
     for g, a, b in gaps2[:25]:
         print("  %8.1f us  after %s -> before %s" % (g / 1e3, a[:50], b[:50]))
+
+# ---- stretches with NO GEMM kernel running: what does the GPU do there? (last step of the window)
+if steps:
+    ends = [e for _, e, n in rows if "sgd_kernel" in n]
+    lo, hi = (ends[-2], ends[-1]) if len(ends) >= 2 else (rows[0][0], rows[-1][1])
+    last = [r for r in rows if r[0] >= lo and r[1] <= hi]
+    is_gemm = lambda n: "conv_fwd" in n or "conv_wgrad_split" in n or "conv_wgrad_kernel" in n  # noqa: E731
+    gemm = sorted((s, e) for s, e, n in last if is_gemm(n))
+    merged = []
+    for s, e in gemm:
+        if merged and s <= merged[-1][1]:
+            merged[-1][1] = max(merged[-1][1], e)
+        else:
+            merged.append([s, e])
+    holes, prev = [], lo
+    for s, e in merged:
+        if s > prev:
+            holes.append((prev, s))
+        prev = max(prev, e)
+    if hi > prev:
+        holes.append((prev, hi))
+    total = sum(b - a for a, b in holes)
+    print("\nlast step %.2f ms: no GEMM kernel running for %.2f ms in %d stretches; the longest, with the kernels that "
+          "run inside (us of the stretch they cover):" % ((hi - lo) / 1e6, total / 1e6, len(holes)))
+    others = [(s, e, n) for s, e, n in last if not is_gemm(n)]
+    for a, b in sorted(holes, key=lambda h: h[0] - h[1])[:14]:
+        inside = defaultdict(float)
+        covered = []
+        for s, e, n in others:
+            if e > a and s < b:
+                inside[n[:48]] += (min(e, b) - max(s, a)) / 1e3
+                covered.append((max(s, a), min(e, b)))
+        covered.sort()
+        cov, ce = 0.0, a
+        for s, e in covered:
+            if e > ce:
+                cov += e - max(s, ce)
+                ce = e
+        after = [n for s, e, n in last if is_gemm(n) and s >= b][:1]
+        print("  %7.1f us at +%.2f ms (GPU idle %5.1f us) before %s: %s" % (
+            (b - a) / 1e3, (a - lo) / 1e6, (b - a - cov) / 1e3, (after[0][:40] if after else "end"),
+            ", ".join("%s %.0f" % (k, v) for k, v in sorted(inside.items(), key=lambda kv: -kv[1])[:5])))
