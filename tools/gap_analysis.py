@@ -146,3 +146,22 @@ if steps:
         print("  %7.1f us at +%.2f ms (GPU idle %5.1f us) before %s: %s" % (
             (b - a) / 1e3, (a - lo) / 1e6, (b - a - cov) / 1e3, (after[0][:40] if after else "end"),
             ", ".join("%s %.0f" % (k, v) for k, v in sorted(inside.items(), key=lambda kv: -kv[1])[:5])))
+
+# ---- optional timeline of the last step: DADET_TIMELINE="from_ms:to_ms" prints every kernel (runs of one name merged)
+import os  # noqa: E402
+if steps and os.environ.get("DADET_TIMELINE"):
+    t0, t1 = [float(v) for v in os.environ["DADET_TIMELINE"].split(":")]
+    with open(path, newline="") as f:
+        full = [(int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"][:60], r.get("Queue_Id", "?"))
+                for r in csv.DictReader(f)]
+    full = sorted(r for r in full if r[0] >= lo + t0 * 1e6 and r[0] <= lo + t1 * 1e6)
+    print("\ntimeline of the last step, +%.1f .. +%.1f ms (start ms, dur us, queue, kernel [x count])" % (t0, t1))
+    i = 0
+    while i < len(full):
+        j = i
+        while j + 1 < len(full) and full[j + 1][2] == full[i][2] and full[j + 1][3] == full[i][3]:
+            j += 1
+        dur = sum(e - s for s, e, _, _ in full[i:j + 1]) / 1e3
+        print("  %8.3f %8.1f  q%-3s %s%s" % ((full[i][0] - lo) / 1e6, dur, full[i][3], full[i][2],
+                                           " x%d" % (j - i + 1) if j > i else ""))
+        i = j + 1
