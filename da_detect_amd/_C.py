@@ -509,6 +509,60 @@ def fast_rcnn_loss(class_logits, box_regression, src, labels_src, rows_pos, map_
     return losses, g_cls, g_reg
 
 
+def fast_rcnn_loss_rows(class_logits, box_regression, loss_labels, regression_targets):
+    """Fast R-CNN losses + gradients from per-row targets (dadet_fast_rcnn_loss_rows) -> (losses [2], g_cls, g_reg);
+    loss_labels int64 [R] (< 0: row outside the losses), regression_targets [R,4]"""
+    _dev(class_logits, "class_logits"), _dev(box_regression, "box_regression")
+    cls, reg = class_logits.contiguous(), box_regression.contiguous()
+    R = cls.shape[0]
+    if loss_labels.numel() != R or regression_targets.numel() != 4 * R or reg.shape[0] != R:
+        raise _lib.DadetError("fast_rcnn_loss_rows: %d logit rows, %d labels, %d target values" % (
+            R, loss_labels.numel(), regression_targets.numel()))
+    losses = torch.empty(2, dtype=torch.float32, device=cls.device)
+    g_cls, g_reg = torch.zeros_like(cls), torch.zeros_like(reg)
+    _lib.call("dadet_fast_rcnn_loss_rows", _p(cls), _p(reg), R, cls.shape[1], reg.shape[1],
+              _p(loss_labels.contiguous().to(torch.int64)), _p(_dev(regression_targets, "targets").contiguous()),
+              _p(losses), _p(g_cls), _p(g_reg), _stream())
+    return losses, g_cls, g_reg
+
+
+SAMPLE_ROIS_MAX = 4096
+
+
+def sample_rois_buffers(rows, device):
+    """output buffers of sample_rois for `rows` rows (several images can share one set, each writing its own slice)"""
+    return dict(idx=torch.empty(rows, dtype=torch.int64, device=device),
+                boxes=torch.empty((rows, 4), dtype=torch.float32, device=device),
+                labels=torch.empty(rows, dtype=torch.int64, device=device),
+                regression_targets=torch.empty((rows, 4), dtype=torch.float32, device=device),
+                loss_labels=torch.empty(rows, dtype=torch.int64, device=device),
+                domain=torch.empty(rows, dtype=torch.bool, device=device))
+
+
+def sample_rois(boxes, labels, regression_targets, cap, max_pos, seed, is_source, counts_out, out=None):
+    """one image's box-head sample in one launch (dadet_sample_rois) -> dict(idx, boxes, labels, regression_targets,
+    loss_labels, domain) of `cap` rows each; counts_out: int32 [2] device tensor receiving (rows taken, positives).
+    labels / regression_targets None = every proposal is a negative with zero targets (target-domain images).
+    `out`: contiguous `cap`-row slices of sample_rois_buffers to write into."""
+    _dev(boxes, "boxes")
+    boxes = boxes.contiguous()
+    n, dev = boxes.shape[0], boxes.device
+    if labels is not None:
+        labels = labels.contiguous()
+        assert labels.dtype == torch.int64 and labels.numel() == n
+    if regression_targets is not None:
+        regression_targets = _dev(regression_targets, "regression_targets").contiguous()
+    assert counts_out.dtype == torch.int32 and counts_out.numel() == 2 and counts_out.is_contiguous()
+    if out is None:
+        out = sample_rois_buffers(cap, dev)
+    assert all(v.shape[0] == cap and v.is_contiguous() for v in out.values())
+    _lib.call("dadet_sample_rois", _p(boxes), _p(labels), _p(regression_targets), n, int(cap), int(max_pos),
+              ctypes.c_uint64(int(seed) & 0xFFFFFFFFFFFFFFFF), 1 if is_source else 0, _p(out["idx"]), _p(out["boxes"]),
+              _p(out["labels"]), _p(out["regression_targets"]), _p(out["loss_labels"]), _p(out["domain"]),
+              _p(counts_out), _stream())
+    return out
+
+
 def rpn_anchor_targets(anchors, visible, gt_boxes, high_threshold, low_threshold):
     """-> (labels float [A] in {1, 0, -1}, regression_targets [A,4]); see dadet_rpn_anchor_targets"""
     _dev(anchors, "anchors"), _dev(gt_boxes, "gt_boxes")

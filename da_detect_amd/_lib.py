@@ -6,7 +6,7 @@ shared object has not been built or no HIP device is visible.
 """
 import ctypes
 import os
-from ctypes import POINTER, c_char_p, c_float, c_int, c_int32, c_int64, c_size_t, c_void_p
+from ctypes import POINTER, c_char_p, c_float, c_int, c_int32, c_int64, c_size_t, c_uint64, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libdadet_hip.so")
@@ -54,6 +54,8 @@ _SIGNATURES = {
                                          POINTER(c_float), _P, c_int, _P],
     "dadet_rpn_loss": [_P, _P, _P, _P, c_int, _P, _P, c_int, c_float, _P, _P, _P, _P],
     "dadet_fast_rcnn_loss": [_P, _P, c_int, c_int, _P, _P, c_int, _P, _P, _P, c_int, _P, _P, _P, _P],
+    "dadet_fast_rcnn_loss_rows": [_P, _P, c_int, c_int, c_int, _P, _P, _P, _P, _P, _P],
+    "dadet_sample_rois": [_P, _P, _P, c_int, c_int, c_int, c_uint64, c_int, _P, _P, _P, _P, _P, _P, _P, _P],
     "dadet_rpn_anchor_targets": [_P, _P, c_int, _P, c_int, c_float, c_float, _P, _P, _P, _P],
     "dadet_box_match_encode": [_P, c_int, _P, _P, c_int, c_float, c_float, c_float, c_float, c_float, c_float, _P, _P,
                                _P, _P],

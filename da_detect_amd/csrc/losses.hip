@@ -105,6 +105,54 @@ __global__ __launch_bounds__(256) void frcnn_loss_kernel(const float* __restrict
   }
 }
 
+// the same losses from PER-ROW targets: loss_labels[r] < 0 = row outside the detection losses (target-domain image),
+// else its class; reg_targets [R][4].  No index lists, so nothing has to be compacted on the way here.
+__global__ __launch_bounds__(256) void frcnn_loss_rows_kernel(const float* __restrict__ class_logits,
+                                                              const float* __restrict__ box_regression, int R, int C,
+                                                              int reg_cols, const int64_t* __restrict__ loss_labels,
+                                                              const float* __restrict__ reg_targets,
+                                                              float* __restrict__ losses, float* __restrict__ g_cls,
+                                                              float* __restrict__ g_reg) {
+  __shared__ float red[4];
+  __shared__ int s_rows;
+  if (threadIdx.x == 0) s_rows = 0;
+  __syncthreads();
+  int mine = 0;
+  for (int r = threadIdx.x; r < R; r += 256) mine += loss_labels[r] >= 0;
+  if (mine) atomicAdd(&s_rows, mine);
+  __syncthreads();
+  const int Ns = s_rows;
+  const float inv = Ns > 0 ? 1.f / (float)Ns : 0.f;
+  float ce = 0.f, box = 0.f;
+  for (int r = threadIdx.x; r < R; r += 256) {
+    const int lab = (int)loss_labels[r];
+    if (lab < 0) continue;
+    const float* x = class_logits + (size_t)r * C;
+    float m = x[0];
+    for (int c = 1; c < C; ++c) m = fmaxf(m, x[c]);
+    float z = 0.f;
+    for (int c = 0; c < C; ++c) z += expf(x[c] - m);
+    const float lse = m + logf(z);
+    ce += lse - x[lab];
+    for (int c = 0; c < C; ++c) g_cls[(size_t)r * C + c] = (expf(x[c] - lse) - (c == lab ? 1.f : 0.f)) * inv;
+    if (lab > 0) {
+      const int col0 = reg_cols == 8 ? 4 : 4 * lab;   // class-agnostic regression keeps 2 x 4 columns
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        float g;
+        box += smooth_l1_term(box_regression[(size_t)r * reg_cols + col0 + j], reg_targets[r * 4 + j], 1.f, &g);
+        g_reg[(size_t)r * reg_cols + col0 + j] = g * inv;
+      }
+    }
+  }
+  ce = block_sum_256(ce, red);
+  box = block_sum_256(box, red);
+  if (threadIdx.x == 0) {
+    losses[0] = ce * inv;
+    losses[1] = box * inv;
+  }
+}
+
 }  // namespace dadet
 
 using namespace dadet;
@@ -138,4 +186,20 @@ extern "C" int dadet_fast_rcnn_loss(const float* class_logits, const float* box_
                      num_classes, reg_cols, src_rows, labels_src, num_src, rows_pos, map_inds,
                      regression_targets_pos, num_pos, losses_out, grad_class_logits, grad_box_regression);
   return check_launch("fast_rcnn_loss");
+}
+
+extern "C" int dadet_fast_rcnn_loss_rows(const float* class_logits, const float* box_regression, int num_rows,
+                                         int num_classes, int reg_cols, const int64_t* loss_labels,
+                                         const float* regression_targets, float* losses_out, float* grad_class_logits,
+                                         float* grad_box_regression, void* stream) {
+  DADET_REQUIRE(num_rows >= 0 && num_classes > 0 && reg_cols > 0, "fast_rcnn_loss_rows: bad counts");
+  DADET_REQUIRE(reg_cols == 8 || reg_cols == 4 * num_classes,
+                "fast_rcnn_loss_rows: %d regression columns for %d classes", reg_cols, num_classes);
+  DADET_REQUIRE(losses_out && grad_class_logits && grad_box_regression, "fast_rcnn_loss_rows: null output");
+  DADET_REQUIRE(num_rows == 0 || (class_logits && box_regression && loss_labels && regression_targets),
+                "fast_rcnn_loss_rows: null input");
+  hipLaunchKernelGGL(frcnn_loss_rows_kernel, dim3(1), dim3(256), 0, as_stream(stream), class_logits, box_regression,
+                     num_rows, num_classes, reg_cols, loss_labels, regression_targets, losses_out, grad_class_logits,
+                     grad_box_regression);
+  return check_launch("fast_rcnn_loss_rows");
 }

@@ -144,7 +144,24 @@ class _FastRCNNLoss(Function):
         return g_cls * g0, g_reg * g1, None, None, None, None, None
 
 
+class _FastRCNNLossRows(Function):
+    """the same two losses from per-row targets (loss_labels < 0: row outside the losses)"""
+
+    @staticmethod
+    def forward(ctx, class_logits, box_regression, loss_labels, regression_targets):
+        losses, g_cls, g_reg = _C.fast_rcnn_loss_rows(class_logits, box_regression, loss_labels, regression_targets)
+        ctx.save_for_backward(g_cls, g_reg)
+        return losses[0], losses[1]
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g0, g1):
+        g_cls, g_reg = ctx.saved_tensors
+        return g_cls * g0, g_reg * g1, None, None
+
+
 rpn_loss_fused = _RPNLoss.apply
+fast_rcnn_loss_rows_fused = _FastRCNNLossRows.apply
 fast_rcnn_loss_fused = _FastRCNNLoss.apply
 
 

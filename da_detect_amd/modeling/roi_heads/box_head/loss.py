@@ -5,13 +5,14 @@ from torch.nn import functional as F
 
 from .... import _C
 from ....layers import smooth_l1_loss
-from ....layers.misc import fast_rcnn_loss_fused
-from ....structures.bounding_box import is_source_image
+from ....layers.misc import fast_rcnn_loss_fused, fast_rcnn_loss_rows_fused
+from ....structures.bounding_box import BoxList, is_source_image
 from ....structures.boxlist_ops import boxlist_iou
 from ...balanced_positive_negative_sampler import BalancedPositiveNegativeSampler
 from ...box_coder import BoxCoder
 from ...matcher import Matcher
 from ...utils import cat
+from ....utils import rng
 
 
 
@@ -23,6 +24,8 @@ def _nz(mask, size):
 
 
 _STATIC = __import__("os").environ.get("DADET_NONZERO_STATIC", "1") == "1"
+# one-launch-per-image sampling (dadet_sample_rois); DADET_FUSED_SAMPLER=0 keeps the ATen chain
+_FUSED = __import__("os").environ.get("DADET_FUSED_SAMPLER", "1") == "1"
 
 class FastRCNNLossComputation(object):
     def __init__(self, proposal_matcher, fg_bg_sampler, box_coder, cls_agnostic_bbox_reg=False):
@@ -89,9 +92,66 @@ class FastRCNNLossComputation(object):
             proposals[i] = proposals[i][_nz(pm | nm, size=k).squeeze(1)]
         return proposals
 
+    def _fused_ok(self, proposals):
+        """the one-launch sampler draws its own random keys on the device: it is the default on the GPU, and it is
+        switched off when the draws must come from the reference's random stream (utils.rng.use_cpu_stream, the
+        parity tests) — the distribution of the sample is the same, the stream is not"""
+        return (_FUSED and not rng.cpu_stream_enabled() and not self.proposal_matcher.allow_low_quality_matches
+                and all(p.bbox.is_cuda and p.bbox.dtype == torch.float32 and len(p) <= _C.SAMPLE_ROIS_MAX
+                        for p in proposals))
+
+    def _subsample_fused(self, proposals, targets):
+        """per image: box_match_encode (source domain only) + sample_rois, then ONE host round trip for the counts"""
+        sampler = self.fg_bg_sampler
+        cap = sampler.batch_size_per_image
+        max_pos = int(cap * sampler.positive_fraction)
+        dev = proposals[0].bbox.device
+        n_img = len(proposals)
+        counts = torch.empty((n_img, 2), dtype=torch.int32, device=dev)
+        buf = _C.sample_rois_buffers(n_img * cap, dev)
+        self._all_negative = []
+        for i, (prop, tgt) in enumerate(zip(proposals, targets)):
+            is_source = is_source_image(tgt)
+            self._all_negative.append(not is_source)
+            lab = reg = None
+            if is_source:
+                if len(tgt) == 0:
+                    raise ValueError("No ground-truth boxes available for one of the images during training")
+                _, lab, reg = _C.box_match_encode(
+                    prop.bbox, tgt.bbox, tgt.get_field("labels"), self.proposal_matcher.high_threshold,
+                    self.proposal_matcher.low_threshold, self.box_coder.weights)
+            _C.sample_rois(prop.bbox, lab, reg, cap, max_pos, rng.next_seed(dev), is_source, counts[i],
+                           out={k: v[i * cap:(i + 1) * cap] for k, v in buf.items()})
+        host = counts.tolist()
+        sampled = []
+        for i, prop in enumerate(proposals):
+            k = host[i][0]
+            rows = slice(i * cap, i * cap + k)
+            b = BoxList(buf["boxes"][rows], prop.size, prop.mode)
+            for name in prop.fields():
+                if name not in ("labels", "regression_targets", "domain_labels"):
+                    b.add_field(name, prop.get_field(name)[buf["idx"][rows]])
+            b.add_field("labels", buf["labels"][rows])
+            b.add_field("regression_targets", buf["regression_targets"][rows])
+            b.add_field("domain_labels", buf["domain"][rows])
+            sampled.append(b)
+        self._proposals = sampled
+        self._sampled_pos = [h[1] for h in host]
+        self._is_source = [not neg for neg in self._all_negative]
+        sampler.last_counts = [(h[1], h[0] - h[1]) for h in host]
+        if all(h[0] == cap for h in host):     # the usual case: every image filled its slice, no copies
+            rows_of = lambda name: buf[name]   # noqa: E731
+        else:
+            rows_of = lambda name: cat([buf[name][i * cap:i * cap + host[i][0]] for i in range(n_img)], dim=0)  # noqa: E731
+        self._loss_prep = dict(rows=True, loss_labels=rows_of("loss_labels"),
+                               regression_targets=rows_of("regression_targets"), domain_masks=rows_of("domain"))
+        return self._proposals
+
     def subsample(self, proposals, targets):
         """sample BATCH_SIZE_PER_IMAGE proposals per image for the detection loss; keeps them in
         self._proposals for the following __call__ (loss.py:95-130)"""
+        if self._fused_ok(proposals):
+            return self._subsample_fused(proposals, targets)
         labels, regression_targets, domain_labels = self.prepare_targets(proposals, targets)
         pos_masks, neg_masks = self.fg_bg_sampler(labels, self._all_negative)
         proposals = list(proposals)
@@ -131,12 +191,40 @@ class FastRCNNLossComputation(object):
     def subsample_for_da(self, proposals, targets):
         """uniformly sampled proposals (all labels forced to 0) for the instance-level domain classifier
         (loss.py:132-163); does NOT replace self._proposals"""
+        if self._fused_ok(proposals):
+            return self._subsample_for_da_fused(proposals, targets)
         labels, _, domain_labels = self.prepare_targets(proposals, targets, sample_for_da=True)
         pos_masks, neg_masks = self.fg_bg_sampler(labels, self._all_negative)
         proposals = list(proposals)
         for prop, dom in zip(proposals, domain_labels):
             prop.add_field("domain_labels", dom)
         return self._take_sampled(proposals, pos_masks, neg_masks)
+
+    def _subsample_for_da_fused(self, proposals, targets):
+        sampler = self.fg_bg_sampler
+        cap = sampler.batch_size_per_image
+        out = []
+        counts = None
+        for prop, tgt in zip(proposals, targets):
+            is_source = is_source_image(tgt)
+            n, dev = len(prop), prop.bbox.device
+            if n <= cap:
+                # every row is taken, in ascending order (the reference's sampler would return them all)
+                if not prop.has_field("domain_labels"):
+                    prop.add_field("domain_labels", torch.full((n,), bool(is_source), dtype=torch.bool, device=dev))
+                out.append(prop)
+                continue
+            if counts is None:
+                counts = torch.empty((len(proposals), 2), dtype=torch.int32, device=dev)
+            s = _C.sample_rois(prop.bbox, None, None, cap, int(cap * sampler.positive_fraction), rng.next_seed(dev),
+                               is_source, counts[len(out)])
+            b = BoxList(s["boxes"], prop.size, prop.mode)      # n > cap negatives: exactly cap rows are taken
+            for name in prop.fields():
+                if name != "domain_labels":
+                    b.add_field(name, prop.get_field(name)[s["idx"]])
+            b.add_field("domain_labels", s["domain"])
+            out.append(b)
+        return out
 
     def __call__(self, class_logits, box_regression):
         """-> (classification_loss, box_loss, domain_masks); only source-domain rows enter the detection
@@ -146,6 +234,10 @@ class FastRCNNLossComputation(object):
         if not hasattr(self, "_proposals"):
             raise RuntimeError("subsample needs to be called before")
         prep = self._loss_prep
+        if prep.get("rows"):
+            cls_loss, box_loss = fast_rcnn_loss_rows_fused(class_logits, box_regression, prep["loss_labels"],
+                                                           prep["regression_targets"])
+            return cls_loss, box_loss, prep["domain_masks"]
         labels = prep["labels_src"]
         if class_logits.is_cuda and not self.cls_agnostic_bbox_reg:
             cls_loss, box_loss = fast_rcnn_loss_fused(class_logits, box_regression, prep["src"], labels,

@@ -32,3 +32,22 @@ def dropout_mask(shape, p, device):
     if _CPU_STREAM:
         return torch.empty(shape, dtype=torch.float32).bernoulli_(1 - p).div_(1 - p).to(device)
     return torch.empty(shape, dtype=torch.float32, device=device).bernoulli_(1 - p).div_(1 - p)
+
+
+_FALLBACK_COUNTER = [0]
+
+
+def next_seed(device):
+    """64-bit seed for a kernel that draws its own random keys (the fused proposal sampler).  Derived from the
+    device generator's (seed, offset) and advancing that offset, so `torch.manual_seed` reproduces the draws exactly
+    as it does for torch's own device-side random kernels."""
+    try:
+        gen = torch.cuda.default_generators[device.index if device.index is not None else torch.cuda.current_device()]
+        seed, off = gen.initial_seed(), gen.get_offset()
+        gen.set_offset(off + 4)
+    except Exception:   # generator without an offset (older torch): process-local counter
+        seed, off = torch.initial_seed(), _FALLBACK_COUNTER[0]
+        _FALLBACK_COUNTER[0] += 4
+    z = (seed * 0x9E3779B97F4A7C15 + off * 0xD1B54A32D192ED03 + 0x632BE59BD9B4E019) & 0xFFFFFFFFFFFFFFFF
+    z ^= z >> 32
+    return z

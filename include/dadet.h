@@ -211,6 +211,28 @@ int dadet_fast_rcnn_loss(const float* class_logits, const float* box_regression,
                          const int64_t* map_inds, const float* regression_targets_pos, int num_pos,
                          float* losses_out, float* grad_class_logits, float* grad_box_regression, void* stream);
 
+/* The same Fast R-CNN losses from per-row targets (no index lists): loss_labels[r] < 0 keeps row r out of both losses
+ * (rows of target-domain images, box_head/loss.py:193-198), otherwise it is the row's class; the regression term
+ * covers the rows with loss_labels > 0, columns 4*label .. 4*label+3 (columns 4..7 when reg_cols == 8, the
+ * class-agnostic layout, box_head/loss.py:205-209); both losses are divided by the number of rows with
+ * loss_labels >= 0.  Gradient maps zero-filled by the caller. */
+int dadet_fast_rcnn_loss_rows(const float* class_logits, const float* box_regression, int num_rows, int num_classes,
+                              int reg_cols, const int64_t* loss_labels, const float* regression_targets,
+                              float* losses_out, float* grad_class_logits, float* grad_box_regression, void* stream);
+
+/* Box-head proposal sampling of ONE image in one launch: replaces BalancedPositiveNegativeSampler.__call__
+ * (modeling/balanced_positive_negative_sampler.py:25-68) + the union-mask nonzero and the per-field BoxList gather of
+ * FastRCNNLossComputation.subsample (modeling/roi_heads/box_head/loss.py:95-130).  labels [n] (>= 1 positive,
+ * 0 negative, < 0 ignored; NULL = all 0), regression_targets [n][4] (NULL = zeros), n <= 4096.  Takes
+ * num_pos = min(#pos, max_pos) positives and num_neg = min(#neg, cap - num_pos) negatives, each a uniformly random
+ * subset (smallest random keys of splitmix64(seed, index)), and writes them in ascending proposal order: idx_out,
+ * boxes_out, labels_out, regression_targets_out, loss_labels_out (= label when is_source, else -1), domain_out
+ * (= is_source), all [cap] rows; counts_out = {num_pos + num_neg, num_pos} (device memory). */
+int dadet_sample_rois(const float* boxes, const int64_t* labels, const float* regression_targets, int n, int cap,
+                      int max_pos, uint64_t seed, int is_source, int64_t* idx_out, float* boxes_out,
+                      int64_t* labels_out, float* regression_targets_out, int64_t* loss_labels_out,
+                      unsigned char* domain_out, int* counts_out, void* stream);
+
 /* RPN anchor labelling in two launches: replaces boxlist_iou + Matcher(high, low, allow_low_quality_matches=True) +
  * the label rules of RPNLossComputation.prepare_targets (modeling/rpn/loss.py:57-98, modeling/matcher.py:42-112) +
  * BoxCoder((1,1,1,1)).encode.  visible[a] != 0: anchor inside the image.  labels: 1 matched, 0 below the low threshold,

@@ -474,3 +474,60 @@ def test_fpn_dcn_da_training_step(device):
         want = F.binary_cross_entropy_with_logits(flat, labels[:, None].expand_as(flat))
     got = losses["loss_da_image"].detach() / c.MODEL.DA_HEADS.DA_IMG_LOSS_WEIGHT
     assert abs(float(got) - float(want)) <= 1e-4 * abs(float(want)), (float(got), float(want))
+
+
+def test_fused_sampler_path_trains_and_agrees_with_the_index_loss(device):
+    """default GPU path (device-side random keys, dadet_sample_rois + per-row loss kernel): the sample obeys the
+    reference's counts (box_head/loss.py:95-130), the step is reproducible under torch.manual_seed, and on the SAME
+    sample the per-row loss equals the index-list loss of the parity path"""
+    from da_detect_amd.data.synthetic import make_batch
+    from da_detect_amd.layers.misc import fast_rcnn_loss_fused
+    from da_detect_amd.utils import rng
+
+    z, c, model, _ = _build("da_plain", device)
+    seed, H, W, nimg = int(z["seed"]), int(z["H"]), int(z["W"]), int(z["nimg"])
+    images, targets = make_batch(c, nimg, H, W, seed=seed, device=device)
+    assert not rng.cpu_stream_enabled()
+    evaluator = model.roi_heads.box.loss_evaluator
+    captured = {}
+    orig_call = evaluator.__class__.__call__
+
+    def spy(self, class_logits, box_regression):
+        captured["logits"], captured["reg"] = class_logits[0].detach(), box_regression[0].detach()
+        return orig_call(self, class_logits, box_regression)
+
+    evaluator.__class__.__call__ = spy
+    try:
+        torch.manual_seed(seed)
+        losses = model(images, targets)
+        sum(losses.values()).backward()
+        first = {k: float(v) for k, v in losses.items()}
+        prep = evaluator._loss_prep
+        assert prep.get("rows") is True
+        cap = evaluator.fg_bg_sampler.batch_size_per_image
+        for p, (n_pos, n_neg), src in zip(evaluator._proposals, evaluator.fg_bg_sampler.last_counts,
+                                          evaluator._is_source):
+            lab = p.get_field("labels")
+            assert len(p) == n_pos + n_neg <= cap and int((lab > 0).sum()) == n_pos
+            assert n_pos <= int(cap * evaluator.fg_bg_sampler.positive_fraction)
+            assert bool((p.get_field("domain_labels") == src).all())
+            assert src or n_pos == 0
+        # the same sample through the index-list kernel
+        ll, rt = prep["loss_labels"], prep["regression_targets"]
+        srcr = torch.nonzero(ll >= 0).squeeze(1)
+        labels_src = ll[srcr]
+        pos = torch.nonzero(labels_src > 0).squeeze(1)
+        map_inds = 4 * labels_src[pos][:, None] + torch.arange(4, device=ll.device)
+        k0, k1 = fast_rcnn_loss_fused(captured["logits"], captured["reg"], srcr, labels_src, srcr[pos], map_inds,
+                                      rt[srcr[pos]])
+        assert abs(float(k0) - first["loss_classifier"]) <= 1e-6 * max(1.0, abs(float(k0)))
+        assert abs(float(k1) - first["loss_box_reg"]) <= 1e-6 * max(1.0, abs(float(k1)))
+        assert all(np.isfinite(v) for v in first.values())
+        grads = [p.grad for p in model.roi_heads.box.parameters() if p.grad is not None]
+        assert grads and all(bool(torch.isfinite(g).all()) for g in grads)
+        model.zero_grad()
+        torch.manual_seed(seed)
+        again = {k: float(v) for k, v in model(images, targets).items()}
+        assert again == first, (first, again)
+    finally:
+        evaluator.__class__.__call__ = orig_call

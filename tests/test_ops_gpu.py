@@ -518,6 +518,118 @@ def test_fused_fast_rcnn_loss_matches_torch(device):
     assert float(a.grad[256:].abs().sum()) == 0.0                    # target-domain rows get no detection gradient
 
 
+@pytest.mark.parametrize("agnostic", [False, True])
+def test_fast_rcnn_loss_rows_matches_torch_and_the_index_kernel(device, agnostic):
+    """per-row targets (label < 0 = target-domain row) vs box_head/loss.py:186-219 in torch, and vs the index-list
+    kernel on the same sample"""
+    import torch.nn.functional as F
+
+    from da_detect_amd.layers.misc import fast_rcnn_loss_fused, fast_rcnn_loss_rows_fused, smooth_l1_loss
+
+    g = torch.Generator().manual_seed(5)
+    R, C = 500, 9
+    reg_cols = 8 if agnostic else 4 * C
+    logits = (torch.randn(R, C, generator=g) * 2).to(device)
+    reg = torch.randn(R, reg_cols, generator=g).to(device)
+    labels = torch.randint(0, C, (R,), generator=g)
+    labels[torch.rand(R, generator=g) < 0.5] = 0
+    source = torch.rand(R, generator=g) < 0.55                       # rows of source-domain images, interleaved
+    loss_labels = torch.where(source, labels, torch.full_like(labels, -1)).to(device)
+    tgt_rows = (torch.randn(R, 4, generator=g) * 0.5).to(device)
+    a, b = logits.clone().requires_grad_(True), reg.clone().requires_grad_(True)
+    l0, l1 = fast_rcnn_loss_rows_fused(a, b, loss_labels, tgt_rows)
+    (l0 + 3.0 * l1).backward()
+    src = torch.nonzero(source).squeeze(1).to(device)
+    labels_src = labels.to(device)[src]
+    pos = torch.nonzero(labels_src > 0).squeeze(1)
+    if agnostic:
+        map_inds = torch.arange(4, 8, device=device).repeat(pos.numel(), 1)
+    else:
+        map_inds = 4 * labels_src[pos][:, None] + torch.arange(4, device=device)
+    c, d = logits.clone().requires_grad_(True), reg.clone().requires_grad_(True)
+    w0 = F.cross_entropy(c.index_select(0, src), labels_src)
+    w1 = smooth_l1_loss(d[src[pos][:, None], map_inds], tgt_rows[src[pos]], size_average=False, beta=1) / src.numel()
+    (w0 + 3.0 * w1).backward()
+    torch.testing.assert_close(l0, w0, rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(l1, w1, rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(a.grad, c.grad, rtol=1e-5, atol=1e-7)
+    torch.testing.assert_close(b.grad, d.grad, rtol=1e-5, atol=1e-7)
+    assert float(a.grad[~source.to(device)].abs().sum()) == 0.0
+    k0, k1 = fast_rcnn_loss_fused(logits, reg, src, labels_src, src[pos], map_inds, tgt_rows[src[pos]])
+    torch.testing.assert_close(l0, k0, rtol=1e-6, atol=1e-7)
+    torch.testing.assert_close(l1, k1, rtol=1e-6, atol=1e-7)
+    # no source rows at all: both losses 0, no gradient
+    z0, z1 = fast_rcnn_loss_rows_fused(logits, reg, torch.full((R,), -1, dtype=torch.int64, device=device), tgt_rows)
+    assert float(z0) == 0.0 and float(z1) == 0.0
+
+
+@pytest.mark.parametrize("n", [0, 1, 37, 256, 300, 2048, 2500, 4096])
+def test_sample_rois_takes_a_balanced_sample_in_proposal_order(device, n):
+    """dadet_sample_rois vs the rules of balanced_positive_negative_sampler.py:40-52 + box_head/loss.py:118-127:
+    counts, classes, ignored rows never taken, ascending order, gathered fields, per-row loss labels"""
+    from da_detect_amd import _C
+
+    rng = np.random.default_rng(n)
+    cap, max_pos = 256, 64
+    boxes = torch.from_numpy(_rand_boxes(rng, max(n, 1))[:n]).to(device).reshape(n, 4)
+    reg = torch.from_numpy(rng.standard_normal((n, 4)).astype(np.float32)).to(device)
+    for frac_pos, frac_ign in ((0.1, 0.1), (0.5, 0.0), (0.0, 0.3), (1.0, 0.0)):
+        u = rng.uniform(0, 1, n)
+        lab = np.where(u < frac_pos, rng.integers(1, 9, n), 0)
+        lab = np.where(rng.uniform(0, 1, n) < frac_ign, -1, lab).astype(np.int64)
+        labels = torch.from_numpy(lab).to(device)
+        n_pos, n_neg = int((lab >= 1).sum()), int((lab == 0).sum())
+        want_pos = min(n_pos, max_pos)
+        want_neg = min(n_neg, cap - want_pos)
+        for is_source in (True, False):
+            counts = torch.zeros(2, dtype=torch.int32, device=device)
+            out = _C.sample_rois(boxes, labels, reg, cap, max_pos, 1234 + n, is_source, counts)
+            k, p = counts.tolist()
+            assert (k, p) == (want_pos + want_neg, want_pos)
+            idx = out["idx"][:k].cpu()
+            assert torch.equal(idx, idx.sort().values) and idx.unique().numel() == k
+            assert k == 0 or (int(idx.min()) >= 0 and int(idx.max()) < n)
+            got = labels.cpu()[idx]
+            assert int((got >= 1).sum()) == want_pos and int((got == 0).sum()) == want_neg
+            assert torch.equal(out["labels"][:k].cpu(), got)
+            assert torch.equal(out["boxes"][:k].cpu(), boxes.cpu()[idx])
+            assert torch.equal(out["regression_targets"][:k].cpu(), reg.cpu()[idx])
+            assert torch.equal(out["loss_labels"][:k].cpu(), got if is_source else torch.full_like(got, -1))
+            assert bool((out["domain"][:k] == is_source).all())
+            assert torch.equal(out["idx"][k:].cpu(), torch.full((cap - k,), -1, dtype=torch.int64))
+    # labels None: every proposal is a negative with zero targets
+    counts = torch.zeros(2, dtype=torch.int32, device=device)
+    out = _C.sample_rois(boxes, None, None, cap, max_pos, 7, False, counts)
+    k, p = counts.tolist()
+    assert (k, p) == (min(n, cap), 0) and float(out["regression_targets"].abs().sum()) == 0.0
+    assert not bool(out["domain"].any()) and bool((out["loss_labels"] == -1).all())
+
+
+def test_sample_rois_is_seeded_and_uniform(device):
+    """same seed -> same sample, other seed -> another one; over many seeds every negative is taken equally often"""
+    from da_detect_amd import _C
+
+    rng = np.random.default_rng(3)
+    n, cap = 64, 16
+    boxes = torch.from_numpy(_rand_boxes(rng, n)).to(device)
+    labels = torch.zeros(n, dtype=torch.int64, device=device)
+    labels[:8] = 3                                                   # 8 positives, 4 of them may be taken
+    counts = torch.zeros(2, dtype=torch.int32, device=device)
+    a = _C.sample_rois(boxes, labels, None, cap, 4, 99, True, counts)["idx"].clone()
+    b = _C.sample_rois(boxes, labels, None, cap, 4, 99, True, counts)["idx"].clone()
+    c = _C.sample_rois(boxes, labels, None, cap, 4, 100, True, counts)["idx"].clone()
+    assert torch.equal(a, b) and not torch.equal(a, c)
+    trials = 3000
+    hits = torch.zeros(n, dtype=torch.int64)
+    for seed in range(trials):
+        idx = _C.sample_rois(boxes, labels, None, cap, 4, seed * 2654435761 + 17, True, counts)["idx"]
+        hits[idx.cpu()] += 1
+    p_pos, p_neg = 4 / 8, 12 / 56
+    for sl, prob in ((slice(0, 8), p_pos), (slice(8, n), p_neg)):
+        sigma = (trials * prob * (1 - prob)) ** 0.5
+        assert float((hits[sl].float() - trials * prob).abs().max()) < 5 * sigma
+
+
 def test_nms_presorted_equals_ranked(device):
     """scores=None: the caller's order is the ranking (RPN top-k output) — same kept set as the ranked call"""
     from da_detect_amd import _C
