@@ -501,7 +501,7 @@ def test_fused_sampler_path_trains_and_agrees_with_the_index_loss(device):
         torch.manual_seed(seed)
         losses = model(images, targets)
         sum(losses.values()).backward()
-        first = {k: float(v) for k, v in losses.items()}
+        first = {k: float(v.detach()) for k, v in losses.items()}
         prep = evaluator._loss_prep
         assert prep.get("rows") is True
         cap = evaluator.fg_bg_sampler.batch_size_per_image
@@ -527,7 +527,9 @@ def test_fused_sampler_path_trains_and_agrees_with_the_index_loss(device):
         assert grads and all(bool(torch.isfinite(g).all()) for g in grads)
         model.zero_grad()
         torch.manual_seed(seed)
-        again = {k: float(v) for k, v in model(images, targets).items()}
-        assert again == first, (first, again)
+        again = {k: float(v.detach()) for k, v in model(images, targets).items()}
+        for k in first:     # same seed -> same sample -> the box-head losses repeat bit for bit; the image-level DA
+            tol = 0.0 if k in ("loss_classifier", "loss_box_reg") else 1e-5   # loss sums with atomics
+            assert abs(again[k] - first[k]) <= tol * max(1.0, abs(first[k])), (k, first[k], again[k])
     finally:
         evaluator.__class__.__call__ = orig_call
