@@ -13,12 +13,40 @@ sys.path.insert(0, ROOT)
 import bench  # noqa: E402
 
 
+def holes_report(prof, step_marks):
+    """stretches of the LAST step in which no GEMM kernel runs (HIP events around every GEMM launch, no tracer: the
+    host runs at its normal speed), with the GEMMs on either side"""
+    t0 = prof.origin.elapsed_time(step_marks[-2])
+    t1 = prof.origin.elapsed_time(step_marks[-1])
+    spans = []
+    for name, recs in prof.records.items():
+        for s, e, _ in recs:
+            a, b = prof.origin.elapsed_time(s), prof.origin.elapsed_time(e)
+            if a >= t0 and b <= t1 + 1.0:
+                spans.append((a, b, name))
+    spans.sort()
+    holes, cur_e, cur_name = [], t0, "step start"
+    for a, b, name in spans:
+        if a > cur_e:
+            holes.append((a - cur_e, cur_e - t0, cur_name, name))
+        if b > cur_e:
+            cur_e, cur_name = b, name
+    if t1 > cur_e:
+        holes.append((t1 - cur_e, cur_e - t0, cur_name, "step end"))
+    total = sum(h[0] for h in holes)
+    print("last step %.2f ms: no GEMM running for %.2f ms in %d stretches" % (t1 - t0, total, len(holes)))
+    for d, at, before, after in sorted(holes, reverse=True)[:25]:
+        print("  %7.1f us at +%6.2f ms   after %-62s before %s" % (d * 1e3, at, before.replace("conv_", "")[:62],
+                                                                  after.replace("conv_", "")[:62]))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--workload", default="img_only", choices=sorted(bench.WORKLOADS))
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--top", type=int, default=60)
     ap.add_argument("--overlap", action="store_true", help="keep the weight-gradient lane on (concurrent kernels)")
+    ap.add_argument("--holes", action="store_true", help="list the stretches of the last step without a GEMM kernel")
     args = ap.parse_args()
     from da_detect_amd import _C
     from da_detect_amd.data.synthetic import make_batch
@@ -36,10 +64,20 @@ def main():
     prof = _C.KernelProfiler()
     prof.detail = True
     _C.PROFILER = prof
+    step_marks = []
     for _ in range(args.steps):
+        ev = torch.cuda.Event(enable_timing=True)
+        ev.record()
+        step_marks.append(ev)
         train_step(model, opt, images, targets)
+    ev = torch.cuda.Event(enable_timing=True)
+    ev.record()
+    step_marks.append(ev)
     torch.cuda.synchronize()
     _C.PROFILER = None
+    if args.holes:
+        holes_report(prof, step_marks)
+        return
     table = prof.summary()
     mode = _C.get_gemm_mode()
     peak = bench.FP32_MFMA_PEAK_TFLOPS if mode == 0 else bench.BF16_MFMA_PEAK_TFLOPS / bench.GEMM_MODES[mode][1]
