@@ -21,6 +21,8 @@ World size 1 keeps the flat views and skips communication.
 import torch
 import torch.distributed as dist
 
+from ..utils import streams
+
 
 class BucketedGradReducer(object):
     def __init__(self, params, bucket_bytes=25 * 1024 * 1024, process_group=None):
@@ -78,6 +80,9 @@ class BucketedGradReducer(object):
             if b["pending"] > 0 and not force:
                 return
             if self.world_size > 1:
+                # weight gradients accumulated directly on the weight-gradient lane must have landed: the collective is
+                # ordered after the stream it is issued from, so that stream first waits for the lane
+                streams.join_wgrad_lane(b["flat"].device)
                 b["work"] = dist.all_reduce(b["flat"], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
             self._next += 1
 
@@ -92,6 +97,8 @@ class BucketedGradReducer(object):
         """reduce buckets that never completed, wait for every collective, turn sums into means"""
         if self._finalized:
             return
+        if self.buckets:
+            streams.join_wgrad_lane(self.buckets[0]["flat"].device)
         self._launch_ready(force=True)
         if self.world_size > 1:
             for b in self.buckets:

@@ -26,6 +26,9 @@ class FusedSGD(torch.optim.Optimizer):
         """gradients live in the reducer's flat buckets: zero_grad() clears them in place (stable pointers)
         and step() first completes the outstanding all-reduces"""
         self.reducer = reducer
+        # with persistent zeroed .grad buffers the weight-gradient kernels may accumulate into them directly
+        from ..utils import streams
+        streams.enable_direct_wgrad(True)
 
     def zero_grad(self, set_to_none=True):
         if self.reducer is not None:

@@ -101,7 +101,54 @@ class WgradLane(object):
         self.out.append(res)
         return res
 
+    def run_into(self, param, direct_fn, plain_fn, *inputs):
+        """weight gradient of `param`: with direct accumulation enabled (enable_direct_wgrad) direct_fn(param.grad)
+        ADDS it into the persistent gradient buffer on the lane and None is returned — autograd then has nothing to
+        accumulate (its post-accumulate hooks still fire once every use of the parameter has run its backward), and
+        the compute stream never waits for the lane until join_wgrad_lane().  Otherwise: run(plain_fn)."""
+        tgt = direct_grad_target(param)
+        if tgt is None:
+            return self.run(plain_fn, *inputs)
+        if not self.on:
+            direct_fn(tgt)
+            return None
+        self.lane.wait_event(self.main.record_event())
+        with torch.cuda.stream(self.lane):
+            direct_fn(tgt)
+        for t in inputs:
+            t.record_stream(self.lane)
+        return None
+
     def join(self):
         if self.on and self.out:
             record(self.out, self.main)
             self.main.wait_stream(self.lane)
+
+
+# Direct accumulation of weight gradients into the parameters' persistent .grad buffers (the flat buckets of
+# parallel.reducer): removes, per backward node, the compute stream's wait for the lane and autograd's `grad += dw`
+# launches.  Switched on by FusedSGD.attach_reducer — with a reducer every .grad is a zeroed persistent view and every
+# consumer of the gradients (collectives, optimizer) first calls join_wgrad_lane().  DADET_DIRECT_WGRAD=0 disables it.
+DIRECT_WGRAD = False
+
+
+def enable_direct_wgrad(flag=True):
+    global DIRECT_WGRAD
+    DIRECT_WGRAD = bool(flag) and os.environ.get("DADET_DIRECT_WGRAD", "1") == "1"
+
+
+def direct_grad_target(param):
+    if not DIRECT_WGRAD or param is None or not param.requires_grad:
+        return None
+    g = param.grad
+    if g is None or not g.is_cuda or g.dtype != torch.float32 or g.stride() != param.stride():
+        return None
+    if g.dim() != 4 or not g.is_contiguous(memory_format=torch.channels_last) or g.data_ptr() % 16:
+        return None      # the kernels write [Cout][KH][KW][Cin]
+    return g
+
+
+def join_wgrad_lane(device):
+    """the current stream waits for every weight gradient queued on the lane (call before reading .grad)"""
+    if device.type == "cuda" and WGRAD_OVERLAP:
+        torch.cuda.current_stream(device).wait_stream(side_stream(device, 2))

@@ -533,3 +533,41 @@ def test_fused_sampler_path_trains_and_agrees_with_the_index_loss(device):
             assert abs(again[k] - first[k]) <= tol * max(1.0, abs(first[k])), (k, first[k], again[k])
     finally:
         evaluator.__class__.__call__ = orig_call
+
+
+def test_direct_weight_gradient_accumulation_matches_the_autograd_path(device):
+    """weight gradients added straight into the reducer's flat buckets on the lane (utils.streams.enable_direct_wgrad)
+    vs the same step with autograd accumulating them: identical parameters after one optimizer step"""
+    from da_detect_amd.data.synthetic import make_batch
+    from da_detect_amd.engine.trainer import train_step
+    from da_detect_amd.parallel.reducer import BucketedGradReducer
+    from da_detect_amd.solver import make_optimizer
+    from da_detect_amd.utils import rng, streams
+
+    results = []
+    for direct in (False, True):
+        z, c, model, _ = _build("da_plain", device)
+        seed, H, W, nimg = int(z["seed"]), int(z["H"]), int(z["W"]), int(z["nimg"])
+        images, targets = make_batch(c, nimg, H, W, seed=seed, device=device)
+        opt = make_optimizer(c, model)
+        reducer = BucketedGradReducer([p for p in model.parameters() if p.requires_grad])
+        opt.attach_reducer(reducer)
+        streams.enable_direct_wgrad(direct)
+        rng.use_cpu_stream(True)
+        try:
+            torch.manual_seed(seed)
+            train_step(model, opt, images, targets)
+            grads = {n: p.grad.clone() for n, p in model.named_parameters() if p.requires_grad}
+            torch.manual_seed(seed + 1)
+            train_step(model, opt, images, targets)
+        finally:
+            rng.use_cpu_stream(False)
+            streams.enable_direct_wgrad(False)
+        torch.cuda.synchronize()
+        results.append((grads, {n: p.detach().clone() for n, p in model.named_parameters()}, set(reducer.touched)))
+    (g0, p0, t0), (g1, p1, t1) = results
+    assert len(t0) == len(t1) > 50
+    for n in g0:
+        torch.testing.assert_close(g1[n], g0[n], rtol=1e-5, atol=1e-7, msg=lambda m, n=n: "%s: %s" % (n, m))
+    for n in p0:
+        torch.testing.assert_close(p1[n], p0[n], rtol=1e-5, atol=1e-7, msg=lambda m, n=n: "%s: %s" % (n, m))
