@@ -138,7 +138,7 @@ def enable_direct_wgrad(flag=True):
 
 
 def direct_grad_target(param):
-    if not DIRECT_WGRAD or param is None or not param.requires_grad:
+    if not DIRECT_WGRAD or param is None or not param.requires_grad or not param.is_leaf:
         return None
     g = param.grad
     if g is None or not g.is_cuda or g.dtype != torch.float32 or g.stride() != param.stride():
