@@ -173,10 +173,6 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    if os.environ.get("DADET_MAIN_PRIORITY", "0") == "1":
-        # experiment: the compute stream itself at high priority, above the weight-gradient lane
-        torch.cuda.synchronize()
-        torch.cuda.set_stream(torch.cuda.Stream(device, priority=-1))
     for _ in range(args.warmup):
         loss_dict = train_step(model, opt, images, targets)
     profiler = None

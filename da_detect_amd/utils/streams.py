@@ -23,8 +23,6 @@ def side_stream(device, which=0):
         # streams 0 / 1 carry the latency-bound bookkeeping (single-workgroup NMS sweeps, sampling): high priority, so
         # their workgroups are dispatched ahead of the GEMM waves they run beside; the weight-gradient lane (2) is not
         prio = -1 if (which < 2 and _HIGH_PRIORITY) else 0
-        if which == 2 and "DADET_LANE_PRIORITY" in os.environ:   # experiment: weight-gradient lane below the compute stream
-            prio = int(os.environ["DADET_LANE_PRIORITY"])
         _SIDE[key] = torch.cuda.Stream(device, priority=prio)
     return _SIDE[key]
 
