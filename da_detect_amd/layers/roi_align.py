@@ -1,10 +1,12 @@
 """ROIAlign layer (reference: maskrcnn_benchmark/layers/roi_align.py:11-68) on the HIP kernels."""
+import torch
 from torch import nn
 from torch.autograd import Function
 from torch.autograd.function import once_differentiable
 from torch.nn.modules.utils import _pair
 
 from .. import _C
+from ..utils import streams
 
 
 class _ROIAlign(Function):
@@ -23,8 +25,13 @@ class _ROIAlign(Function):
     def backward(ctx, grad_output):
         (rois,) = ctx.saved_tensors
         bs, ch, h, w = ctx.input_shape
+        # weight gradients queued by the preceding node (ROI head's first block) run on the lane beside this gather
+        after = None
+        if grad_output.is_cuda and streams.deferred_pending():
+            after = torch.cuda.current_stream(grad_output.device).record_event()
         grad_input = _C.roi_align_backward(grad_output, rois, ctx.spatial_scale, ctx.output_size[0],
                                            ctx.output_size[1], bs, ch, h, w, ctx.sampling_ratio)
+        streams.flush_deferred_wgrads(grad_output.device, after)
         return grad_input, None, None, None, None
 
 

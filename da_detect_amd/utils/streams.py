@@ -83,7 +83,8 @@ class WgradLane(object):
     workgroups.  `run(fn, *tensors)` queues fn() there once the tensors exist on the compute stream; `join()` makes
     the compute stream wait before the gradients are handed to autograd."""
 
-    def __init__(self, device):
+    def __init__(self, device, defer=False):
+        self.defer = defer      # direct accumulations are queued until flush_deferred_wgrads() (see there)
         self.on = WGRAD_OVERLAP and device.type == "cuda"
         if self.on:
             self.main = torch.cuda.current_stream(device)
@@ -109,6 +110,9 @@ class WgradLane(object):
         tgt = direct_grad_target(param)
         if tgt is None:
             return self.run(plain_fn, *inputs)
+        if self.defer and _DEFER_ENABLED:
+            _DEFERRED.append((direct_fn, tgt, inputs))
+            return None
         if not self.on:
             direct_fn(tgt)
             return None
@@ -148,7 +152,42 @@ def direct_grad_target(param):
     return g
 
 
+# Deferred weight gradients: the backward node that ends the box head (first res5 block) is followed by the ROIAlign
+# backward — an L2-bound gather during which no GEMM can run, because the backbone's backward needs its result
+# (tools/gemm_table.py --holes: 1.0 ms per step).  That block's weight gradients do not feed anything: they are queued
+# and issued on the lane together with the ROIAlign backward, so the matrix pipe has work while the gather runs.
+_DEFERRED = []
+_DEFER_ENABLED = os.environ.get("DADET_DEFER_WGRAD", "1") == "1"
+
+
+def flush_deferred_wgrads(device, after=None):
+    """issue the queued accumulations on the lane; `after`: event of the compute stream they must wait for (default:
+    everything queued on it so far)"""
+    global _DEFERRED
+    if not _DEFERRED:
+        return
+    items, _DEFERRED = _DEFERRED, []
+    if device.type == "cuda" and WGRAD_OVERLAP:
+        main = torch.cuda.current_stream(device)
+        lane = side_stream(device, 2)
+        lane.wait_event(after if after is not None else main.record_event())
+        with torch.cuda.stream(lane):
+            for fn, tgt, _ in items:
+                fn(tgt)
+        for _, _, inputs in items:
+            for t in inputs:
+                t.record_stream(lane)
+    else:
+        for fn, tgt, _ in items:
+            fn(tgt)
+
+
+def deferred_pending():
+    return bool(_DEFERRED)
+
+
 def join_wgrad_lane(device):
     """the current stream waits for every weight gradient queued on the lane (call before reading .grad)"""
+    flush_deferred_wgrads(device)
     if device.type == "cuda" and WGRAD_OVERLAP:
         torch.cuda.current_stream(device).wait_stream(side_stream(device, 2))
