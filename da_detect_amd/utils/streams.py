@@ -157,7 +157,9 @@ def direct_grad_target(param):
 # (tools/gemm_table.py --holes: 1.0 ms per step).  That block's weight gradients do not feed anything: they are queued
 # and issued on the lane together with the ROIAlign backward, so the matrix pipe has work while the gather runs.
 _DEFERRED = []
-_DEFER_ENABLED = os.environ.get("DADET_DEFER_WGRAD", "1") == "1"
+# MEASURED: slower (31.05 vs 30.53 ms per step on the same box): the GEMMs slow the gather, which is on the critical
+# path, by more than they gain — off by default, DADET_DEFER_WGRAD=1 to reproduce.
+_DEFER_ENABLED = os.environ.get("DADET_DEFER_WGRAD", "0") == "1"
 
 
 def flush_deferred_wgrads(device, after=None):
