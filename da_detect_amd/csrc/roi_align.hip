@@ -295,7 +295,9 @@ struct Contribution {
   int row;        // (r * pooled_h + ph) * pooled_w + pw
   float count;    // samples per bin of that ROI
   float w[4];     // wy * wx for the tile pixels (y0,x0) (y0,x0+1) (y0+1,x0) (y0+1,x0+1)
-  int pad[2];
+  float inv;      // 1 / count
+  int pow2;       // count is a power of two: (g * w) * inv == (g * w) / count bit for bit, and 16 IEEE divisions per
+                  // entry and lane (~10 VALU instructions each) become multiplications — the kernel was VALU bound on them
 };
 constexpr int kListCap = 1024;   // entries per round (32 KB of LDS)
 
@@ -321,7 +323,9 @@ __device__ inline int roi_contributions(const RoiGeom& g, int r, int H, int W, i
         c.row = (r * pooled_h + ph) * pooled_w + pw;
         c.count = g.count;
         c.w[0] = wy0 * wx0; c.w[1] = wy0 * wx1; c.w[2] = wy1 * wx0; c.w[3] = wy1 * wx1;
-        c.pad[0] = c.pad[1] = 0;
+        c.inv = 1.f / g.count;
+        const int ci = (int)g.count;
+        c.pow2 = (ci & (ci - 1)) == 0;
         out[n] = c;
       }
       ++n;
@@ -380,7 +384,10 @@ __global__ __launch_bounds__(256) void roi_align_bwd_list_kernel(
           for (int p = 0; p < 4; ++p) {
             if (q.w[p] == 0.f) continue;   // wave-uniform: keeps every pixel's sum free of +0 terms
 #pragma unroll
-            for (int v = 0; v < VEC; ++v) acc[k][p][v] += gq[u][v] * q.w[p] / q.count;
+            for (int v = 0; v < VEC; ++v) {
+              const float t = gq[u][v] * q.w[p];
+              acc[k][p][v] += q.pow2 ? t * q.inv : t / q.count;   // wave-uniform choice
+            }
           }
         }
       }
