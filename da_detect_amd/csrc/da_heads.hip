@@ -45,11 +45,27 @@ __global__ __launch_bounds__(256) void da_img_fwd_kernel(const float* __restrict
                                                          float* __restrict__ logits_out,
                                                          float* __restrict__ sums_out, int num_images,
                                                          int rows_per_image, int C1) {
+  // per-image sums are collected in LDS first: one global atomic per workgroup, image and quantity (4096 same-address
+  // global atomics — one pair per wavefront — serialised in L2 and made this 33 MB kernel take 112 us)
+  constexpr int kMaxImg = 8;
+  __shared__ float s_acc[kMaxImg * 2];
+  const bool use_lds = num_images <= kMaxImg;
+  if (threadIdx.x < kMaxImg * 2) s_acc[threadIdx.x] = 0.f;
+  __syncthreads();
   const int lane = threadIdx.x & 63;
   const int wave_global = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   const int nwaves = (gridDim.x * blockDim.x) >> 6;
   const int64_t M = (int64_t)num_images * rows_per_image;
   const float bias = b2[0];
+  auto flush = [&](int img, float bce, float sig) {
+    if (use_lds) {
+      atomicAdd(&s_acc[img * 2 + 0], bce);
+      atomicAdd(&s_acc[img * 2 + 1], sig);
+    } else {
+      atomicAdd(&sums_out[img * 2 + 0], bce);
+      atomicAdd(&sums_out[img * 2 + 1], sig);
+    }
+  };
   // a wavefront walks rows m = wave_global, wave_global + nwaves, ...; partial sums are flushed whenever the
   // image index changes (rows of one image are contiguous)
   float bce_acc = 0.f, sig_acc = 0.f;
@@ -66,10 +82,7 @@ __global__ __launch_bounds__(256) void da_img_fwd_kernel(const float* __restrict
     const float logit = dot + bias;
     const int img = (int)(m / rows_per_image);
     if (img != cur_img) {
-      if (cur_img >= 0 && lane == 0) {
-        atomicAdd(&sums_out[cur_img * 2 + 0], bce_acc);
-        atomicAdd(&sums_out[cur_img * 2 + 1], sig_acc);
-      }
+      if (cur_img >= 0 && lane == 0) flush(cur_img, bce_acc, sig_acc);
       bce_acc = 0.f;
       sig_acc = 0.f;
       cur_img = img;
@@ -80,10 +93,10 @@ __global__ __launch_bounds__(256) void da_img_fwd_kernel(const float* __restrict
       sig_acc += sigmoidf(logit);
     }
   }
-  if (cur_img >= 0 && lane == 0) {
-    atomicAdd(&sums_out[cur_img * 2 + 0], bce_acc);
-    atomicAdd(&sums_out[cur_img * 2 + 1], sig_acc);
-  }
+  if (cur_img >= 0 && lane == 0) flush(cur_img, bce_acc, sig_acc);
+  __syncthreads();
+  if (use_lds && threadIdx.x < num_images * 2 && s_acc[threadIdx.x] != 0.f)
+    atomicAdd(&sums_out[threadIdx.x], s_acc[threadIdx.x]);
 }
 
 // backward.  coef[img] = (a_bce_w, a_sig_w, a_bce_x, a_sig_x):
