@@ -217,6 +217,18 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     losses = {k: float(v.detach()) for k, v in loss_dict.items()}
+    ranks_in_sync = None
+    if world > 1:
+        # data-parallel invariant, checked after the timed region: every rank applied the same averaged gradients to
+        # the same parameters, so the parameters are still identical bit for bit
+        chk = torch.stack([p.detach().double().sum() for p in model.parameters()])
+        lo, hi = chk.clone(), chk.clone()
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+        dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+        ranks_in_sync = bool((lo == hi).all().item())
+        if not ranks_in_sync and rank == 0:
+            print("WARNING: parameters differ between ranks after %d steps (max checksum spread %.3e)" % (
+                args.steps + args.warmup, float((hi - lo).abs().max())), file=sys.stderr, flush=True)
 
     if rank == 0:
         value = world * images_per_gpu * args.steps / elapsed
@@ -284,6 +296,8 @@ def main():
                                   "tflops": round(v["achieved"] / 1e12, 2)} for k, v in kernels.items()},
             "final_losses": {k: round(v, 5) for k, v in losses.items()},
         }
+        if ranks_in_sync is not None:
+            line["config"]["ranks_in_sync_after_run"] = ranks_in_sync
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()

@@ -80,11 +80,22 @@ class BucketedGradReducer(object):
             if b["pending"] > 0 and not force:
                 return
             if self.world_size > 1:
-                # weight gradients accumulated directly on the weight-gradient lane must have landed: the collective is
-                # ordered after the stream it is issued from, so that stream first waits for the lane
-                streams.join_wgrad_lane(b["flat"].device)
-                b["work"] = dist.all_reduce(b["flat"], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+                b["work"] = self._all_reduce(b["flat"])
             self._next += 1
+
+    def _all_reduce(self, flat):
+        """a collective is ordered after the stream it is issued from.  Weight gradients accumulated directly on the
+        weight-gradient lane (utils.streams.run_into) must have landed, and so must the gradients autograd accumulated
+        on the compute stream: the collective is issued FROM THE LANE after the lane waited for the compute stream's
+        current position — the compute stream itself is not held up."""
+        dev = flat.device
+        if dev.type == "cuda" and streams.DIRECT_WGRAD and streams.WGRAD_OVERLAP:
+            streams.flush_deferred_wgrads(dev)
+            lane = streams.side_stream(dev, 2)
+            lane.wait_event(torch.cuda.current_stream(dev).record_event())
+            with torch.cuda.stream(lane):
+                return dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        return dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
 
     def _on_grad(self, p):
         b = self._bucket_of[id(p)]
