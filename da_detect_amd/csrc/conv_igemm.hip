@@ -26,6 +26,8 @@
 // the double-buffered / 2-workgroup variant: 38% of wave cycles parked in s_waitcnt/s_barrier).
 // Workgroup ids are remapped so that each XCD (private L2) walks a contiguous range of m-tiles.
 #include <cstdlib>
+#include <mutex>
+#include <unordered_map>
 #include "conv_common.h"
 #include <stdlib.h>
 
@@ -462,6 +464,77 @@ static int launch_fwd(ConvArgs& a, hipStream_t st) {
   return check_launch("conv_forward");
 }
 
+// ---- split-K for GEMMs whose tile grid cannot fill the chip (the M = 512 linear layers of the box / instance heads:
+// 4 x 16 workgroups walking K = 2048 alone took 40 - 70 us each, one after the other in the loss turn-around).
+// The K range is cut over blockIdx.y, partial sums go to a per-stream scratch buffer owned by the library (grown on
+// demand, reused in stream order), and one pass sums them in split order and applies the epilogue.
+__global__ void splitk_reduce_kernel(const float4* __restrict__ partial, int splits, size_t stride4,
+                                     const float4* __restrict__ scale, const float4* __restrict__ bias,
+                                     const float4* __restrict__ addend, const float4* __restrict__ mask,
+                                     float4* __restrict__ y, int64_t total4, int C4, int relu_mode) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total4;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    float4 v = partial[i];
+    for (int p = 1; p < splits; ++p) {
+      const float4 q = partial[(size_t)p * stride4 + i];
+      v.x += q.x; v.y += q.y; v.z += q.z; v.w += q.w;
+    }
+    const int c = (int)(i % C4);
+    if (scale) { const float4 q = scale[c]; v.x *= q.x; v.y *= q.y; v.z *= q.z; v.w *= q.w; }
+    if (bias) { const float4 q = bias[c]; v.x += q.x; v.y += q.y; v.z += q.z; v.w += q.w; }
+    if (addend) { const float4 q = addend[i]; v.x += q.x; v.y += q.y; v.z += q.z; v.w += q.w; }
+    if (relu_mode == 1) {
+      v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+    } else if (relu_mode == 2) {
+      const float4 q = mask[i];
+      v.x = q.x > 0.f ? v.x : 0.f; v.y = q.y > 0.f ? v.y : 0.f;
+      v.z = q.z > 0.f ? v.z : 0.f; v.w = q.w > 0.f ? v.w : 0.f;
+    }
+    y[i] = v;
+  }
+}
+
+namespace {
+struct Scratch { void* p = nullptr; size_t bytes = 0; };
+std::mutex g_scratch_mutex;
+std::unordered_map<hipStream_t, Scratch> g_scratch;
+
+// scratch of `bytes` for work queued on `st`; contents are only valid in stream order
+void* stream_scratch(hipStream_t st, size_t bytes) {
+  std::lock_guard<std::mutex> lock(g_scratch_mutex);
+  Scratch& s = g_scratch[st];
+  if (s.bytes < bytes) {
+    if (s.p) {
+      (void)hipStreamSynchronize(st);   // the old buffer may still be read by queued work
+      (void)hipFree(s.p);
+      s.p = nullptr;
+      s.bytes = 0;
+    }
+    const size_t want = bytes < (size_t)(8u << 20) ? (size_t)(8u << 20) : bytes * 2;
+    if (hipMalloc(&s.p, want) != hipSuccess) {
+      s.p = nullptr;
+      return nullptr;
+    }
+    s.bytes = want;
+  }
+  return s.p;
+}
+
+// number of K elements per split (multiple of BK), or 0 when the launch should not be split
+int splitk_plan(const ConvArgs& a, int variant) {
+  static const bool enabled = !(getenv("DADET_SPLITK") && getenv("DADET_SPLITK")[0] == '0');
+  if (!enabled || a.os != 1 || a.Cout % 4 != 0 || a.K < 256) return 0;
+  const int bm = variant == 2 ? 64 : 128, bn = variant == 0 ? 128 : 64;
+  const int tiles = ceil_div(a.M, bm) * ceil_div(a.Cout, bn);
+  if (tiles > kNumCU / 2) return 0;
+  int want = ceil_div(2 * kNumCU, tiles);
+  if (want > a.K / 128) want = a.K / 128;     // at least four K-tiles per workgroup
+  if (want < 2) return 0;
+  const int ksplit = ceil_div(ceil_div(a.K, want), BK) * BK;
+  return ceil_div(a.K, ksplit) >= 2 ? ksplit : 0;
+}
+}  // namespace
+
 extern "C" int dadet_conv_forward(const dadet_conv_desc* d, const float* x, const float* w,
                                   const float* scale, const float* bias, const float* addend,
                                   const float* mask_ref, float* y, void* stream) {
@@ -492,7 +565,40 @@ extern "C" int dadet_conv_forward(const dadet_conv_desc* d, const float* x, cons
     a.ablate = ablate;
   }
   hipStream_t st = as_stream(stream);
-  if (gemm_mode() != 0) return launch_fwd_split(a, fwd_variant(a.M, a.Cout), gemm_mode(), st);
+  a.ksplit = 0;
+  a.split_stride = 0;
+  if (gemm_mode() != 0) {
+    const int variant = fwd_variant(a.M, a.Cout);
+    const int ksplit = splitk_plan(a, variant);
+    if (ksplit && al16(y) && (!addend || al16(addend)) && (!mask_ref || al16(mask_ref)) &&
+        (!scale || al16(scale)) && (!bias || al16(bias))) {
+      const int splits = ceil_div(a.K, ksplit);
+      const size_t per = (size_t)a.M * a.Cout;
+      float* ws = static_cast<float*>(stream_scratch(st, sizeof(float) * per * splits));
+      if (!ws) {
+        set_error("conv_forward: could not allocate %zu bytes of split-K scratch", sizeof(float) * per * splits);
+        return DADET_ELAUNCH;
+      }
+      ConvArgs p = a;
+      p.scale = p.bias = p.addend = p.mask_ref = nullptr;
+      p.relu_mode = 0;
+      p.y = ws;
+      p.ksplit = ksplit;
+      p.split_stride = (unsigned)per;
+      rc = launch_fwd_split(p, variant, gemm_mode(), st);
+      if (rc) return rc;
+      const int64_t total4 = (int64_t)per / 4;
+      int64_t blocks = ceil_div64(total4, 256);
+      if (blocks > kMaxStreamBlocks) blocks = kMaxStreamBlocks;
+      hipLaunchKernelGGL(splitk_reduce_kernel, dim3((int)blocks), dim3(256), 0, st,
+                         reinterpret_cast<const float4*>(ws), splits, per / 4,
+                         reinterpret_cast<const float4*>(scale), reinterpret_cast<const float4*>(bias),
+                         reinterpret_cast<const float4*>(addend), reinterpret_cast<const float4*>(mask_ref),
+                         reinterpret_cast<float4*>(y), total4, a.Cout / 4, a.relu_mode);
+      return check_launch("conv_forward(split-K reduce)");
+    }
+    return launch_fwd_split(a, variant, gemm_mode(), st);
+  }
   switch (fwd_variant(a.M, a.Cout)) {
     case 0: return launch_fwd<2, 2>(a, st);
     case 1: return launch_fwd<2, 1>(a, st);

@@ -114,7 +114,9 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_split_kernel(const ConvArgs a
     wrow[i] = n < a.Cout ? (unsigned)n * (unsigned)a.K * 4u : kOOB;
   }
   float4 ra[A_LOADS], rb[B_LOADS];
-  int kk = lcol * 4;
+  const int k_lo = a.ksplit ? (int)blockIdx.y * a.ksplit : 0;
+  const int k_hi = a.ksplit ? min(a.K, k_lo + a.ksplit) : a.K;
+  int kk = k_lo + lcol * 4;
   int tap = kk / a.Cin;
   int kc = kk - tap * a.Cin;
   int kr = tap / a.KW;
@@ -124,7 +126,7 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_split_kernel(const ConvArgs a
   // right after ITS registers were consumed by the split (see the K loop): a fetch then has a whole K-tile of MFMAs
   // to land before it is needed.
   auto load_a = [&]() {
-    const bool kvalid = kk < a.K;
+    const bool kvalid = kk < k_hi;
 #pragma unroll
     for (int i = 0; i < A_LOADS; ++i) {
       const int hi = hi0[i] + kr, wi = wi0[i] + ks;
@@ -134,7 +136,7 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_split_kernel(const ConvArgs a
     }
   };
   auto load_b = [&]() {
-    const bool kvalid = kk < a.K;
+    const bool kvalid = kk < k_hi;
 #pragma unroll
     for (int i = 0; i < B_LOADS; ++i)
       rb[i] = buf_load4(wr, (kvalid && wrow[i] != kOOB) ? wrow[i] + (unsigned)kk * 4u : kOOB);
@@ -183,7 +185,7 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_split_kernel(const ConvArgs a
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
-  const int nk = (a.K + BK - 1) / BK;
+  const int nk = (k_hi - k_lo + BK - 1) / BK;
   load_a();
   load_b();
   advance();
@@ -270,8 +272,8 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_split_kernel(const ConvArgs a
     }
   }
 
-  // epilogue (same as conv_igemm.hip)
-  const __amdgpu_buffer_rsrc_t yr = make_rsrc(a.y, a.y_bytes);
+  // epilogue (same as conv_igemm.hip); a split-K launch stores raw partial sums (no scale / bias / addend / gate)
+  const __amdgpu_buffer_rsrc_t yr = make_rsrc(a.y + (size_t)blockIdx.y * a.split_stride, a.y_bytes);
   const __amdgpu_buffer_rsrc_t ar = make_rsrc(a.addend ? a.addend : a.y, a.addend ? a.y_bytes : 0u);
   const __amdgpu_buffer_rsrc_t mr = make_rsrc(a.mask_ref ? a.mask_ref : a.y, a.mask_ref ? a.y_bytes : 0u);
   const int col_in = lane & 31;
@@ -584,8 +586,9 @@ static int launch_split(ConvArgs& a, hipStream_t st) {
     }
     attr_set = true;
   }
-  hipLaunchKernelGGL((conv_fwd_split_kernel<TM, TN, TERMS, AB>), dim3(a.tiles_m * a.tiles_n), dim3(256), lds, st,
-                     a);
+  const int ksplits = a.ksplit ? ceil_div(a.K, a.ksplit) : 1;
+  hipLaunchKernelGGL((conv_fwd_split_kernel<TM, TN, TERMS, AB>), dim3(a.tiles_m * a.tiles_n, ksplits), dim3(256), lds,
+                     st, a);
   return check_launch("conv_forward(split)");
 }
 

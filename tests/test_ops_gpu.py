@@ -260,12 +260,14 @@ def test_conv_forward_split_bf16_modes(device, case, mode, tol):
     x, w = _conv_case(rng, *case)
     ref64 = F.conv2d(x.double(), w.double(), None, stride, pad)
     xd, wd = x.to(device).contiguous(memory_format=CL), w.to(device).contiguous(memory_format=CL)
-    exact = _C.conv_forward(xd, wd, stride=stride, pad=pad).cpu()
-    _C.set_gemm_mode(mode)
+    prev = _C.get_gemm_mode()
     try:
+        _C.set_gemm_mode(0)
+        exact = _C.conv_forward(xd, wd, stride=stride, pad=pad).cpu()
+        _C.set_gemm_mode(mode)
         got = _C.conv_forward(xd, wd, stride=stride, pad=pad).cpu()
     finally:
-        _C.set_gemm_mode(0)
+        _C.set_gemm_mode(prev)
     scale = float(ref64.abs().mean())
     err_exact = float((exact.double() - ref64).abs().max()) / scale
     err_split = float((got.double() - ref64).abs().max()) / scale
@@ -288,12 +290,14 @@ def test_conv_wgrad_split_bf16_modes(device, case, mode, tol):
     w64 = w.double().requires_grad_(True)
     F.conv2d(x.double(), w64, None, stride, pad).backward(gy.double())
     xd, gyd = x.to(device).contiguous(memory_format=CL), gy.to(device).contiguous(memory_format=CL)
-    exact = _C.conv_wgrad(xd, gyd, tuple(w.shape), stride, pad).cpu()
-    _C.set_gemm_mode(mode)
+    prev = _C.get_gemm_mode()
     try:
+        _C.set_gemm_mode(0)
+        exact = _C.conv_wgrad(xd, gyd, tuple(w.shape), stride, pad).cpu()
+        _C.set_gemm_mode(mode)
         got = _C.conv_wgrad(xd, gyd, tuple(w.shape), stride, pad).cpu()
     finally:
-        _C.set_gemm_mode(0)
+        _C.set_gemm_mode(prev)
     scale = float(w64.grad.abs().mean())
     err_exact = float((exact.double() - w64.grad).abs().max()) / scale
     err_split = float((got.double() - w64.grad).abs().max()) / scale
@@ -301,6 +305,53 @@ def test_conv_wgrad_split_bf16_modes(device, case, mode, tol):
     assert err_split < tol
     if mode == 3:
         assert err_split < max(4 * err_exact, 1e-6)
+
+
+SPLITK_CASES = [
+    # small tile grids: the K range is cut over blockIdx.y and a reduce pass applies the epilogue (mode 3 only)
+    (512, 2048, 1, 1, 1024, 1, 1, 0),    # instance-head fc1 on 512 ROIs
+    (512, 1024, 1, 1, 4, 1, 1, 0),       # instance-head logit (Cout padded to 4)
+    (300, 2048, 1, 1, 48, 1, 1, 0),      # box predictor
+    (1, 64, 16, 16, 64, 3, 1, 1),        # M = 256, K = 576
+    (2, 256, 8, 8, 256, 3, 1, 1),        # M = 128, K = 2304 (a coarse pyramid level)
+    (1, 260, 9, 7, 36, 1, 1, 0),         # ragged everything: M = 63, K = 260, Cout = 36
+]
+
+
+@pytest.mark.parametrize("case", SPLITK_CASES)
+def test_conv_forward_split_k_epilogues(device, case):
+    """same results as the unsplit kernel (DADET_SPLITK=0 is the library default off-switch; here the reference is
+    torch fp64) for every epilogue, with the K reduction cut over several workgroups"""
+    from da_detect_amd import _C
+
+    N, Cin, H, W, Cout, k, stride, pad = case
+    rng = np.random.default_rng(sum(case) + 3)
+    x, w = _conv_case(rng, *case)
+    scale = torch.from_numpy(rng.uniform(0.5, 1.5, Cout).astype(np.float32))
+    bias = torch.from_numpy(rng.standard_normal(Cout).astype(np.float32))
+    ref = F.conv2d(x.double(), w.double(), None, stride, pad)
+    res = torch.from_numpy(rng.standard_normal(tuple(ref.shape)).astype(np.float32))
+    xd, wd = x.to(device).contiguous(memory_format=CL), w.to(device).contiguous(memory_format=CL)
+    sd, bd, rd = scale.to(device), bias.to(device), res.to(device).contiguous(memory_format=CL)
+    tol = dict(rtol=2e-5, atol=2e-5)
+    prev = _C.get_gemm_mode()
+    try:
+        _C.set_gemm_mode(3)
+        got = _C.conv_forward(xd, wd, stride=stride, pad=pad).cpu()
+        torch.testing.assert_close(got.double(), ref, **tol)
+        got = _C.conv_forward(xd, wd, sd, bd, stride=stride, pad=pad, relu_mode=1).cpu()
+        want = F.relu(ref * scale.double().view(1, -1, 1, 1) + bias.double().view(1, -1, 1, 1))
+        torch.testing.assert_close(got.double(), want, **tol)
+        got = _C.conv_forward(xd, wd, sd, bd, addend=rd, stride=stride, pad=pad, relu_mode=1).cpu()
+        torch.testing.assert_close(got.double(), F.relu(ref * scale.double().view(1, -1, 1, 1) +
+                                                        bias.double().view(1, -1, 1, 1) + res.double()), **tol)
+        got = _C.conv_forward(xd, wd, addend=rd, mask_ref=rd, stride=stride, pad=pad, relu_mode=2).cpu()
+        torch.testing.assert_close(got.double(), (ref + res.double()) * (res > 0), **tol)
+        out = rd.clone()                                 # in-place: the addend is also the output
+        _C.conv_forward(xd, wd, addend=out, out=out, stride=stride, pad=pad)
+        torch.testing.assert_close(out.cpu().double(), ref + res.double(), **tol)
+    finally:
+        _C.set_gemm_mode(prev)
 
 
 def test_stem_conv7x7_as_padded_7x8(device):
