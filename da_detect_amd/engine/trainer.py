@@ -31,6 +31,9 @@ def enable_overlapped_rpn_backward(model, flag=True):
     rpn = getattr(model, "rpn", None)
     if rpn is not None and getattr(model, "roi_heads", None):
         rpn.early_backward = bool(flag)
+        da = getattr(model, "da_heads", None)
+        if da and hasattr(da, "early_image_level"):
+            da.early_backward = bool(flag)     # image-level DA loss + backward in front of the box head
     return model
 
 

@@ -5,6 +5,8 @@ Execution differs: the image-level classifier is evaluated once by the fused ker
 two (three with AdvGRL) full passes; the instance-level classifier keeps the reference's separate passes
 because each pass draws its own dropout masks (da_heads.py:61-68).
 """
+import contextlib
+
 import torch
 import torch.nn.functional as F
 from torch import nn
@@ -12,6 +14,7 @@ from torch import nn
 from ...layers import Conv2d, GradientScalarLayer, global_avg_pool, linear
 from ...layers.misc import gradient_scalar
 from ...utils import rng
+from ...utils.streams import other_stream
 from .fused import da_image_head
 from .loss import TripletMargins, da_consist_loss, da_ins_loss, image_domain_labels
 
@@ -113,18 +116,15 @@ class DomainAdaptationModule(torch.nn.Module):
         self.imghead = DAImgHead(cfg.MODEL.BACKBONE.OUT_CHANNELS)
         self.inshead = DAInsHead(_ins_input_dim(cfg))
 
-    def forward(self, img_features, da_ins_feature, da_ins_labels, targets=None):
-        if not self.training:
-            return {}
-        da_ins_feature = _pool_ins(da_ins_feature, self.resnet_backbone)
-        # instance head: adversarial pass then consistency pass, each with its own dropout masks
-        da_ins_features = self.inshead(self.grl_ins(da_ins_feature))
-        da_ins_consist = self.inshead(self.grl_ins_consist(da_ins_feature)).sigmoid()
-        # image head: one fused evaluation serves both the BCE (GRL -w) and the consistency (GRL +w) paths
-        # Several levels (FPN): the reference concatenates the per-level logits along dim 0 (loss.py:81-92), which
-        # only works for equal map sizes, i.e. never for a pyramid.  The extension used here is what a dim-1
-        # concatenation would give: one BCE mean over the elements of all levels, and the consistency term averaged
-        # over levels (consistency_loss.py:13-27 already concatenates its per-level columns along dim 1).
+    # opt-in (engine.trainer.enable_overlapped_rpn_backward), same contract as RPNModule.early_backward
+    early_backward = False
+
+    def _image_level(self, img_features, targets):
+        """image head: one fused evaluation serves both the BCE (GRL -w) and the consistency (GRL +w) paths.
+        Several levels (FPN): the reference concatenates the per-level logits along dim 0 (loss.py:81-92), which
+        only works for equal map sizes, i.e. never for a pyramid.  The extension used here is what a dim-1
+        concatenation would give: one BCE mean over the elements of all levels, and the consistency term averaged
+        over levels (consistency_loss.py:13-27 already concatenates its per-level columns along dim 1)."""
         labels = image_domain_labels(targets)
         per_level = [self.imghead.fused(f, labels, self.grl_img.weight, self.grl_img_consist.weight)
                      for f in img_features]
@@ -133,9 +133,56 @@ class DomainAdaptationModule(torch.nn.Module):
         else:
             sizes = [float(f.shape[2] * f.shape[3]) for f in img_features]
             da_img_loss = sum(l[0] * s for l, s in zip(per_level, sizes)) / sum(sizes)
-        img_mean_sig = [l[1] for l in per_level]
+        return da_img_loss, [l[1] for l in per_level]
+
+    def early_image_level(self, img_features, targets):
+        """The image-level loss needs the backbone features only.  In the reference's order it is evaluated after
+        the box head, in the stretch between the box head's forward and backward where nothing large can run
+        (tools/gap_analysis.py: 1.5 ms of small kernels).  With `early_backward` it — and its backward — is queued
+        right behind the RPN branch's backward instead, in front of the box head, where the compute stream otherwise
+        waits for the proposals.  Returns the gradients w.r.t. the feature maps (to be injected by
+        RPNModule.bridge_features) or None when not applicable: the consistency term back-propagates through the
+        image head together with the instance head, so it keeps the reference's order."""
+        self._early = None
+        if not (self.training and self.early_backward and torch.is_grad_enabled() and self.cst_weight == 0
+                and self.img_weight > 0 and all(f.is_cuda and f.requires_grad for f in img_features)):
+            return None
+        head_in = [f.detach().requires_grad_(True) for f in img_features]
+        da_img_loss, _ = self._image_level(head_in, targets)
+        loss = self.img_weight * da_img_loss
+        torch.autograd.backward([loss])
+        self._early = loss.detach()
+        return [f.grad for f in head_in]
+
+    def forward(self, img_features, da_ins_feature, da_ins_labels, targets=None):
+        if not self.training:
+            return {}
+        early, self._early = getattr(self, "_early", None), None
+        da_ins_feature = _pool_ins(da_ins_feature, self.resnet_backbone)
+        # instance head: adversarial pass then consistency pass, each with its own dropout masks (same program order
+        # of the random draws as the reference).  They are independent of the image head: on the GPU they run on a
+        # side stream beside it, and the compute stream only waits for them if a loss uses them.
+        need_ins = self.ins_weight > 0 or self.cst_weight > 0
+        side = main = None
+        if da_ins_feature.is_cuda:
+            main = torch.cuda.current_stream(da_ins_feature.device)
+            side = other_stream(da_ins_feature.device)
+            side.wait_stream(main)
+            da_ins_feature.record_stream(side)
+        with (torch.cuda.stream(side) if side is not None else contextlib.nullcontext()):
+            da_ins_features = self.inshead(self.grl_ins(da_ins_feature))
+            da_ins_consist = self.inshead(self.grl_ins_consist(da_ins_feature)).sigmoid()
+        if side is not None and need_ins:
+            main.wait_stream(side)
+            da_ins_features.record_stream(main)
+            da_ins_consist.record_stream(main)
         losses = {}
-        if self.img_weight > 0:
+        if early is not None:
+            losses["loss_da_image"] = early
+            img_mean_sig = None        # only the consistency term reads it, and that excludes the early path
+        else:
+            da_img_loss, img_mean_sig = self._image_level(img_features, targets)
+        if self.img_weight > 0 and early is None:
             losses["loss_da_image"] = self.img_weight * da_img_loss
         if self.ins_weight > 0:
             losses["loss_da_instance"] = self.ins_weight * da_ins_loss(da_ins_features, da_ins_labels)

@@ -36,7 +36,10 @@ class GeneralizedRCNN(nn.Module):
         features = self.backbone(images.tensors)
         proposals, proposal_losses = self.rpn(images, features, targets)
         if self.training:
-            features = self.rpn.bridge_features(features)
+            early_da = None
+            if self.da_heads and not self.da_heads_triplet and hasattr(self.da_heads, "early_image_level"):
+                early_da = self.da_heads.early_image_level(features, targets)
+            features = self.rpn.bridge_features(features, early_da)
             if self.roi_heads:
                 self.roi_heads.box.proposals_ready, self.rpn.proposals_ready = self.rpn.proposals_ready, None
         da_losses, detector_losses = {}, {}

@@ -109,9 +109,14 @@ class RPNModule(torch.nn.Module):
         record(boxes, main)
         return boxes, {"loss_objectness": loss_objectness.detach(), "loss_rpn_box_reg": loss_rpn_box_reg.detach()}
 
-    def bridge_features(self, features):
-        """features whose backward also delivers the RPN branch's gradient (no-op unless early_backward ran)"""
+    def bridge_features(self, features, extra=None):
+        """features whose backward also delivers the RPN branch's gradient (no-op unless early_backward ran);
+        `extra`: gradients of another branch that ran its backward early (the image-level DA head), same layout"""
         grads, self._feature_grads = self._feature_grads, None
+        if grads is None:
+            grads = extra
+        elif extra is not None:
+            grads = [g + e for g, e in zip(grads, extra)]
         if grads is None:
             return features
         return [_InjectGrad.apply(f, g) for f, g in zip(features, grads)]

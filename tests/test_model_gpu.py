@@ -571,3 +571,46 @@ def test_direct_weight_gradient_accumulation_matches_the_autograd_path(device):
         torch.testing.assert_close(g1[n], g0[n], rtol=1e-5, atol=1e-7, msg=lambda m, n=n: "%s: %s" % (n, m))
     for n in p0:
         torch.testing.assert_close(p1[n], p0[n], rtol=1e-5, atol=1e-7, msg=lambda m, n=n: "%s: %s" % (n, m))
+
+
+def test_early_image_level_da_backward_gives_the_same_gradients(device):
+    """without a consistency term the image-level DA loss and its backward are queued in front of the box head
+    (DomainAdaptationModule.early_image_level) and the instance-head passes run on a side stream: losses and every
+    parameter gradient equal the reference-order schedule's"""
+    from golden.cases import case_cfg
+    from golden.fill import fill_state_dict
+
+    from da_detect_amd.data.synthetic import make_batch
+    from da_detect_amd.engine.trainer import enable_overlapped_rpn_backward
+    from da_detect_amd.utils import rng
+
+    z = np.load(os.path.join(GOLD, "da_plain.npz"))
+    c = case_cfg("da_plain")
+    c.merge_from_list(["MODEL.DA_HEADS.DA_CST_LOSS_WEIGHT", 0.0])
+    model = build_detection_model(c)
+    model.load_state_dict(fill_state_dict(model.state_dict(), int(z["seed"])))
+    model = model.to(device).train()
+    images, targets = make_batch(c, int(z["nimg"]), int(z["H"]), int(z["W"]), seed=int(z["seed"]), device=device)
+    runs = []
+    for early in (False, True):
+        enable_overlapped_rpn_backward(model, early)
+        model.zero_grad(set_to_none=True)
+        rng.use_cpu_stream(True)
+        try:
+            torch.manual_seed(3)
+            losses = model(images, targets)
+            assert "loss_da_image" in losses and "loss_da_instance" in losses and "loss_da_consistency" not in losses
+            assert losses["loss_da_image"].requires_grad != early
+            sum(losses.values()).backward()
+        finally:
+            rng.use_cpu_stream(False)
+        torch.cuda.synchronize()
+        runs.append(({k: float(v.detach()) for k, v in losses.items()},
+                     {n: p.grad.clone() for n, p in model.named_parameters() if p.grad is not None}))
+    enable_overlapped_rpn_backward(model, False)
+    (l0, g0), (l1, g1) = runs
+    for k in l0:
+        assert abs(l0[k] - l1[k]) <= 1e-5 * max(1.0, abs(l0[k])), (k, l0[k], l1[k])
+    assert set(g0) == set(g1) and any(n.startswith("da_heads.imghead") for n in g0)
+    for n in g0:
+        assert float((g0[n] - g1[n]).norm()) <= 1e-5 * float(g0[n].norm()) + 1e-10, n
