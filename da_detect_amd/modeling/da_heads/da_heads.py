@@ -19,6 +19,9 @@ from .fused import da_image_head
 from .loss import TripletMargins, da_consist_loss, da_ins_loss, image_domain_labels
 
 
+_EARLY_DA = __import__("os").environ.get("DADET_EARLY_DA", "1") == "1"   # A/B switch of early_image_level
+
+
 class DAImgHead(nn.Module):
     """1x1 conv C->512, ReLU, 1x1 conv 512->1 (da_heads.py:12-37)"""
 
@@ -144,7 +147,7 @@ class DomainAdaptationModule(torch.nn.Module):
         RPNModule.bridge_features) or None when not applicable: the consistency term back-propagates through the
         image head together with the instance head, so it keeps the reference's order."""
         self._early = None
-        if not (self.training and self.early_backward and torch.is_grad_enabled() and self.cst_weight == 0
+        if not (_EARLY_DA and self.training and self.early_backward and torch.is_grad_enabled() and self.cst_weight == 0
                 and self.img_weight > 0 and all(f.is_cuda and f.requires_grad for f in img_features)):
             return None
         head_in = [f.detach().requires_grad_(True) for f in img_features]

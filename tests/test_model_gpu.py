@@ -582,6 +582,7 @@ def test_early_image_level_da_backward_gives_the_same_gradients(device):
 
     from da_detect_amd.data.synthetic import make_batch
     from da_detect_amd.engine.trainer import enable_overlapped_rpn_backward
+    from da_detect_amd.modeling.detector import build_detection_model
     from da_detect_amd.utils import rng
 
     z = np.load(os.path.join(GOLD, "da_plain.npz"))
