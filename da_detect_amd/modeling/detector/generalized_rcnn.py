@@ -9,6 +9,7 @@ import torch
 from torch import nn
 
 from ...structures.image_list import to_image_list
+from ...utils.streams import record, side_stream
 from ..backbone import build_backbone
 from ..da_heads.da_heads import build_da_heads, build_da_heads_triplet
 from ..roi_heads.roi_heads import build_roi_heads
@@ -34,11 +35,25 @@ class GeneralizedRCNN(nn.Module):
             # lets the RPN prepare its loss targets on a side stream without waiting for the backbone
             self.rpn.inputs_ready = torch.cuda.current_stream(images.tensors.device).record_event()
         features = self.backbone(images.tensors)
+        early_da = da_stream = None
+        if self.training and self.da_heads and not self.da_heads_triplet and features[0].is_cuda:
+            # image-level DA loss + its backward (DomainAdaptationModule.early_image_level) on their own stream, beside
+            # the RPN branch and the box head: they need nothing but the backbone features
+            dev = features[0].device
+            main = torch.cuda.current_stream(dev)
+            da_stream = side_stream(dev, 3)
+            da_stream.wait_stream(main)
+            with torch.cuda.stream(da_stream):
+                early_da = self.da_heads.early_image_level(features, targets)
+            if early_da is None:
+                da_stream = None
+            else:
+                record(features, da_stream)
         proposals, proposal_losses = self.rpn(images, features, targets)
         if self.training:
-            early_da = None
-            if self.da_heads and not self.da_heads_triplet and hasattr(self.da_heads, "early_image_level"):
-                early_da = self.da_heads.early_image_level(features, targets)
+            if da_stream is not None:
+                torch.cuda.current_stream(features[0].device).wait_stream(da_stream)
+                record(early_da, torch.cuda.current_stream(features[0].device))
             features = self.rpn.bridge_features(features, early_da)
             if self.roi_heads:
                 self.roi_heads.box.proposals_ready, self.rpn.proposals_ready = self.rpn.proposals_ready, None
