@@ -563,6 +563,29 @@ def sample_rois(boxes, labels, regression_targets, cap, max_pos, seed, is_source
     return out
 
 
+SAMPLE_ANCHORS_MAX_CAP = 1024
+
+
+def sample_anchors(labels, regression_targets, cap, max_pos, seed, index_offset, counts_out, out=None):
+    """one image's RPN anchor sample in one launch (dadet_sample_anchors) -> dict(pos, neg: int64 [cap] anchor indices
+    + index_offset, ascending; regression_targets_pos [cap,4]); counts_out: int32 [2] device tensor receiving
+    (positives, negatives).  `out`: cap-row slices of buffers shared by several images."""
+    _dev(labels, "labels"), _dev(regression_targets, "regression_targets")
+    labels, regression_targets = labels.contiguous(), regression_targets.contiguous()
+    A, dev = labels.numel(), labels.device
+    assert regression_targets.numel() == 4 * A and 0 < cap <= SAMPLE_ANCHORS_MAX_CAP
+    assert counts_out.dtype == torch.int32 and counts_out.numel() == 2 and counts_out.is_contiguous()
+    if out is None:
+        out = dict(pos=torch.empty(cap, dtype=torch.int64, device=dev),
+                   neg=torch.empty(cap, dtype=torch.int64, device=dev),
+                   regression_targets_pos=torch.empty((cap, 4), dtype=torch.float32, device=dev))
+    assert all(v.shape[0] == cap and v.is_contiguous() for v in out.values())
+    _lib.call("dadet_sample_anchors", _p(labels), _p(regression_targets), A, int(cap), int(max_pos),
+              ctypes.c_uint64(int(seed) & 0xFFFFFFFFFFFFFFFF), ctypes.c_int64(int(index_offset)), _p(out["pos"]),
+              _p(out["neg"]), _p(out["regression_targets_pos"]), _p(counts_out), _stream())
+    return out
+
+
 def rpn_anchor_targets(anchors, visible, gt_boxes, high_threshold, low_threshold):
     """-> (labels float [A] in {1, 0, -1}, regression_targets [A,4]); see dadet_rpn_anchor_targets"""
     _dev(anchors, "anchors"), _dev(gt_boxes, "gt_boxes")

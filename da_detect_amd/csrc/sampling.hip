@@ -153,3 +153,175 @@ extern "C" int dadet_sample_rois(const float* boxes, const int64_t* labels, cons
                      counts_out);
   return check_launch("sample_rois");
 }
+
+// ------------------------------------------------------------------------------------------------------------------
+// RPN anchor sampling of ONE image in one launch: replaces BalancedPositiveNegativeSampler.__call__ on the anchor
+// labels (modeling/balanced_positive_negative_sampler.py:25-68: two nonzero over ~10^5 anchors, two randperm, two
+// index_put per image) + the nonzero / gathers of RPNLossComputation.__call__ (modeling/rpn/loss.py:101-123).  On a
+// busy GPU the library's nonzero kernels alone took 0.2 - 0.5 ms each, and on slower hosts the chain ended after
+// the RPN head, i.e. on the critical path (tools/gemm_table.py --holes: 0.7 ms).
+//
+// Same rule as sample_rois_kernel — the k smallest random keys of each class — but the anchors do not fit a sort in
+// LDS: a 4-pass radix select (8 bits per pass, both classes in the same pass) finds each class's threshold key, one
+// more pass appends the selected indices to LDS lists, and the (<= 256-entry) lists are sorted to restore the
+// ascending anchor order of the reference's nonzero.  One workgroup; all passes read labels[t + 1024 j] (coalesced,
+// L2 resident after the first).
+namespace dadet {
+
+constexpr int kAnchorCapMax = 1024;   // largest batch_size_per_image supported
+constexpr int kTieCap = 1024;
+
+__device__ inline void lds_bitonic_sort(int* v, int n_pow2, int t, int nthreads) {
+  for (int k = 2; k <= n_pow2; k <<= 1)
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      for (int i = t; i < n_pow2; i += nthreads) {
+        const int p = i ^ j;
+        if (p > i) {
+          const int a = v[i], b = v[p];
+          if ((a > b) == ((i & k) == 0)) {
+            v[i] = b;
+            v[p] = a;
+          }
+        }
+      }
+      __syncthreads();
+    }
+}
+
+__global__ __launch_bounds__(kSampleThreads) void sample_anchors_kernel(
+    const float* __restrict__ labels, const float4* __restrict__ reg, int A, int cap, int max_pos, uint64_t seed,
+    int64_t index_offset, int64_t* __restrict__ pos_out, int64_t* __restrict__ neg_out, float4* __restrict__ reg_pos_out,
+    int* __restrict__ counts) {
+  __shared__ int s_hist[2][256];
+  __shared__ int s_n[2];          // candidates per class
+  __shared__ int s_k[2];          // still to take inside the current prefix
+  __shared__ unsigned s_prefix[2];
+  __shared__ int s_all[2];        // class takes every candidate (no threshold)
+  __shared__ int s_list[2][kAnchorCapMax];
+  __shared__ int s_len[2];
+  __shared__ int s_tie[2][kTieCap];
+  __shared__ int s_tie_len[2];
+  const int t = threadIdx.x;
+  auto cls_of = [&](int i) -> int {
+    const float l = labels[i];
+    return l >= 1.f ? 0 : (l == 0.f ? 1 : 2);
+  };
+  if (t < 2) { s_n[t] = 0; s_len[t] = 0; s_tie_len[t] = 0; s_prefix[t] = 0u; }
+  __syncthreads();
+  int mine[2] = {0, 0};
+  for (int i = t; i < A; i += kSampleThreads) {
+    const int c = cls_of(i);
+    if (c < 2) ++mine[c];
+  }
+  if (mine[0]) atomicAdd(&s_n[0], mine[0]);
+  if (mine[1]) atomicAdd(&s_n[1], mine[1]);
+  __syncthreads();
+  const int n_pos = s_n[0], n_neg = s_n[1];
+  const int num_pos = n_pos < max_pos ? n_pos : max_pos;
+  const int num_neg = n_neg < cap - num_pos ? n_neg : cap - num_pos;
+  if (t == 0) {
+    s_k[0] = num_pos; s_k[1] = num_neg;
+    s_all[0] = num_pos == n_pos; s_all[1] = num_neg == n_neg;
+  }
+  __syncthreads();
+  // radix select, most significant byte first: after pass p the prefix holds the top 8(p+1) bits of the threshold key
+  // and s_k the number of keys still to take among those sharing the prefix
+  for (int pass = 0; pass < 4; ++pass) {
+    const int shift = 24 - 8 * pass;
+    for (int b = t; b < 512; b += kSampleThreads) (&s_hist[0][0])[b] = 0;
+    __syncthreads();
+    const bool need0 = !s_all[0], need1 = !s_all[1];
+    if (need0 || need1) {
+      for (int i = t; i < A; i += kSampleThreads) {
+        const int c = cls_of(i);
+        if (c == 2 || (c == 0 ? !need0 : !need1)) continue;
+        const unsigned key = sample_key(seed, (unsigned)i);
+        const unsigned hi = pass == 0 ? 0u : key >> (shift + 8);
+        if (hi == (pass == 0 ? 0u : s_prefix[c] >> (shift + 8))) atomicAdd(&s_hist[c][(key >> shift) & 255u], 1);
+      }
+    }
+    __syncthreads();
+    if (t < 2 && !s_all[t]) {
+      int k = s_k[t], b = 0;
+      while (b < 255 && s_hist[t][b] < k) {   // keys in lower buckets are all taken
+        k -= s_hist[t][b];
+        ++b;
+      }
+      s_k[t] = k;                             // 1 <= k <= hist[b] keys of bucket b remain to be taken
+      s_prefix[t] |= (unsigned)b << shift;
+    }
+    __syncthreads();
+  }
+  // selection: key < threshold -> taken; key == threshold -> tie list (s_k of them are taken, lowest indices first)
+  for (int i = t; i < A; i += kSampleThreads) {
+    const int c = cls_of(i);
+    if (c == 2) continue;
+    bool take = s_all[c] != 0, tie = false;
+    if (!take) {
+      const unsigned key = sample_key(seed, (unsigned)i);
+      take = key < s_prefix[c];
+      tie = key == s_prefix[c];
+    }
+    if (take) {
+      const int slot = atomicAdd(&s_len[c], 1);
+      if (slot < kAnchorCapMax) s_list[c][slot] = i;
+    } else if (tie) {
+      const int slot = atomicAdd(&s_tie_len[c], 1);
+      if (slot < kTieCap) s_tie[c][slot] = i;
+    }
+  }
+  __syncthreads();
+  for (int c = 0; c < 2; ++c) {
+    if (s_all[c]) continue;
+    // ties (practically always exactly one key): lowest indices first
+    const int nt = s_tie_len[c] < kTieCap ? s_tie_len[c] : kTieCap;
+    int p2 = 1;
+    while (p2 < nt) p2 <<= 1;
+    for (int i = nt + t; i < p2; i += kSampleThreads) s_tie[c][i] = 0x7FFFFFFF;
+    __syncthreads();
+    if (p2 > 1) lds_bitonic_sort(s_tie[c], p2, t, kSampleThreads);
+    const int want = c == 0 ? num_pos : num_neg;
+    const int have = s_len[c];
+    for (int i = t; i < want - have && i < nt; i += kSampleThreads) s_list[c][have + i] = s_tie[c][i];
+    __syncthreads();
+  }
+  // ascending anchor order
+  for (int c = 0; c < 2; ++c) {
+    const int n = c == 0 ? num_pos : num_neg;
+    int p2 = 1;
+    while (p2 < n) p2 <<= 1;
+    for (int i = n + t; i < p2; i += kSampleThreads) s_list[c][i] = 0x7FFFFFFF;
+    __syncthreads();
+    if (p2 > 1) lds_bitonic_sort(s_list[c], p2, t, kSampleThreads);
+  }
+  __syncthreads();
+  for (int i = t; i < cap; i += kSampleThreads) {
+    const bool vp = i < num_pos, vn = i < num_neg;
+    pos_out[i] = vp ? index_offset + s_list[0][i] : -1;
+    neg_out[i] = vn ? index_offset + s_list[1][i] : -1;
+    reg_pos_out[i] = vp ? reg[s_list[0][i]] : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  if (t == 0) {
+    counts[0] = num_pos;
+    counts[1] = num_neg;
+  }
+}
+
+}  // namespace dadet
+
+extern "C" int dadet_sample_anchors(const float* labels, const float* regression_targets, int A, int cap, int max_pos,
+                                    uint64_t seed, int64_t index_offset, int64_t* pos_inds_out, int64_t* neg_inds_out,
+                                    float* regression_targets_pos_out, int* counts_out, void* stream) {
+  DADET_REQUIRE(A >= 0 && cap > 0 && cap <= kAnchorCapMax && max_pos >= 0 && max_pos <= cap,
+                "sample_anchors: A=%d cap=%d (<= %d) max_pos=%d", A, cap, kAnchorCapMax, max_pos);
+  DADET_REQUIRE((A == 0 || (labels && regression_targets)) && pos_inds_out && neg_inds_out &&
+                    regression_targets_pos_out && counts_out,
+                "sample_anchors: null pointer");
+  DADET_REQUIRE(al16(regression_targets) && al16(regression_targets_pos_out),
+                "sample_anchors: regression targets must be 16-byte aligned");
+  hipLaunchKernelGGL(sample_anchors_kernel, dim3(1), dim3(kSampleThreads), 0, as_stream(stream), labels,
+                     reinterpret_cast<const float4*>(regression_targets), A, cap, max_pos, (uint64_t)seed,
+                     index_offset, pos_inds_out, neg_inds_out, reinterpret_cast<float4*>(regression_targets_pos_out),
+                     counts_out);
+  return check_launch("sample_anchors");
+}

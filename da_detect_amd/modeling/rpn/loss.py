@@ -11,6 +11,7 @@ from ...layers import smooth_l1_loss
 from ...layers.misc import rpn_loss_fused
 from ...structures.bounding_box import is_source_image
 from ...structures.boxlist_ops import boxlist_iou, cat_boxlist
+from ...utils import rng
 from ..balanced_positive_negative_sampler import BalancedPositiveNegativeSampler
 from ..matcher import Matcher
 from .utils import concat_box_prediction_layers
@@ -25,6 +26,8 @@ def _nz(mask, size):
 
 
 _STATIC = __import__("os").environ.get("DADET_NONZERO_STATIC", "1") == "1"
+# one-launch-per-image anchor sampling (dadet_sample_anchors); DADET_FUSED_SAMPLER=0 keeps the ATen chain
+_FUSED = __import__("os").environ.get("DADET_FUSED_SAMPLER", "1") == "1"
 
 class RPNLossComputation(object):
     def __init__(self, proposal_matcher, fg_bg_sampler, box_coder, generate_labels_func):
@@ -83,6 +86,10 @@ class RPNLossComputation(object):
         that stream alone."""
         anchors = [cat_boxlist(a) for a in anchors]
         labels, regression_targets, _ = self.prepare_targets(anchors, targets)
+        cap = self.fg_bg_sampler.batch_size_per_image
+        if (_FUSED and not rng.cpu_stream_enabled() and labels and cap <= _C.SAMPLE_ANCHORS_MAX_CAP
+                and all(l.is_cuda and l.dtype == torch.float32 for l in labels)):
+            return self._prepare_fused(labels, regression_targets)
         pos_masks, neg_masks = self.fg_bg_sampler(labels)
         n_pos = sum(c[0] for c in self.fg_bg_sampler.last_counts)     # host-side counts: no round trips
         n_neg = sum(c[1] for c in self.fg_bg_sampler.last_counts)
@@ -93,6 +100,39 @@ class RPNLossComputation(object):
         regression_targets = torch.cat(regression_targets, dim=0)
         return dict(pos_inds=pos_inds, sampled_inds=sampled_inds, labels_sampled=labels[sampled_inds],
                     regression_targets_pos=regression_targets[pos_inds])
+
+    def _prepare_fused(self, labels, regression_targets):
+        """one dadet_sample_anchors launch per labelled image (device-side random keys, same counts and distribution
+        as the sampler), then ONE host round trip for the counts.  Not used when the draws must come from the
+        reference's random stream (utils.rng.use_cpu_stream, the loss-parity tests)."""
+        sampler = self.fg_bg_sampler
+        cap = sampler.batch_size_per_image
+        max_pos = int(cap * sampler.positive_fraction)
+        dev, n_img = labels[0].device, len(labels)
+        counts = torch.empty((n_img, 2), dtype=torch.int32, device=dev)
+        pos = torch.empty(n_img * cap, dtype=torch.int64, device=dev)
+        neg = torch.empty(n_img * cap, dtype=torch.int64, device=dev)
+        reg = torch.empty((n_img * cap, 4), dtype=torch.float32, device=dev)
+        offset = 0
+        for i, (lab, tgt) in enumerate(zip(labels, regression_targets)):
+            rows = slice(i * cap, (i + 1) * cap)
+            _C.sample_anchors(lab, tgt, cap, max_pos, rng.next_seed(dev), offset, counts[i],
+                              out=dict(pos=pos[rows], neg=neg[rows], regression_targets_pos=reg[rows]))
+            offset += lab.numel()
+        host = counts.tolist()
+        sampler.last_counts = [(h[0], h[1]) for h in host]
+        if n_img == 1:
+            (n_pos, n_neg), = host
+            pos_inds, neg_inds, reg_pos = pos[:n_pos], neg[:n_neg], reg[:n_pos]
+        else:
+            pos_inds = torch.cat([pos[i * cap:i * cap + h[0]] for i, h in enumerate(host)])
+            neg_inds = torch.cat([neg[i * cap:i * cap + h[1]] for i, h in enumerate(host)])
+            reg_pos = torch.cat([reg[i * cap:i * cap + h[0]] for i, h in enumerate(host)])
+            n_pos, n_neg = pos_inds.numel(), neg_inds.numel()
+        sampled_inds = torch.cat([pos_inds, neg_inds], dim=0)
+        labels_sampled = (torch.arange(n_pos + n_neg, device=dev) < n_pos).to(torch.float32)
+        return dict(pos_inds=pos_inds, sampled_inds=sampled_inds, labels_sampled=labels_sampled,
+                    regression_targets_pos=reg_pos)
 
     def finish(self, objectness, box_regression, prep):
         """the part that needs the predictions (loss.py:125-143); no host synchronisation"""

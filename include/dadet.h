@@ -233,6 +233,17 @@ int dadet_sample_rois(const float* boxes, const int64_t* labels, const float* re
                       int64_t* labels_out, float* regression_targets_out, int64_t* loss_labels_out,
                       unsigned char* domain_out, int* counts_out, void* stream);
 
+/* RPN anchor sampling of ONE image in one launch: replaces BalancedPositiveNegativeSampler.__call__ on the anchor
+ * labels (modeling/balanced_positive_negative_sampler.py:25-68) + the nonzero / gathers of
+ * RPNLossComputation.__call__ (modeling/rpn/loss.py:101-123).  labels [A] float (1 positive, 0 negative, -1 ignored),
+ * regression_targets [A][4].  Takes num_pos = min(#pos, max_pos) positives and num_neg = min(#neg, cap - num_pos)
+ * negatives, each a uniformly random subset (smallest splitmix64(seed, anchor) keys, radix select), cap <= 1024.
+ * pos_inds_out / neg_inds_out [cap]: index_offset + anchor index, ascending (-1 past the count);
+ * regression_targets_pos_out [cap][4]: the positives' targets; counts_out = {num_pos, num_neg} (device memory). */
+int dadet_sample_anchors(const float* labels, const float* regression_targets, int A, int cap, int max_pos,
+                         uint64_t seed, int64_t index_offset, int64_t* pos_inds_out, int64_t* neg_inds_out,
+                         float* regression_targets_pos_out, int* counts_out, void* stream);
+
 /* RPN anchor labelling in two launches: replaces boxlist_iou + Matcher(high, low, allow_low_quality_matches=True) +
  * the label rules of RPNLossComputation.prepare_targets (modeling/rpn/loss.py:57-98, modeling/matcher.py:42-112) +
  * BoxCoder((1,1,1,1)).encode.  visible[a] != 0: anchor inside the image.  labels: 1 matched, 0 below the low threshold,

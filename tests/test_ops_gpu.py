@@ -656,6 +656,64 @@ def test_sample_rois_takes_a_balanced_sample_in_proposal_order(device, n):
     assert not bool(out["domain"].any()) and bool((out["loss_labels"] == -1).all())
 
 
+@pytest.mark.parametrize("A,frac_pos,frac_ign", [(0, 0.0, 0.0), (5, 0.5, 0.0), (3000, 0.001, 0.3),
+                                                   (122880, 0.0005, 0.4), (122880, 0.01, 0.2), (40000, 0.0, 0.1),
+                                                   (523776, 0.0003, 0.5), (700, 1.0, 0.0)])
+def test_sample_anchors_takes_a_balanced_sample_in_anchor_order(device, A, frac_pos, frac_ign):
+    """dadet_sample_anchors vs the rules of balanced_positive_negative_sampler.py:40-52 on RPN-sized label vectors:
+    counts, classes, ignored anchors never taken, ascending order, index offset, gathered positive targets"""
+    from da_detect_amd import _C
+
+    rng = np.random.default_rng(A + 1)
+    cap, max_pos, offset = 256, 128, 1000000
+    u = rng.uniform(0, 1, A)
+    lab = np.where(u < frac_pos, 1.0, 0.0)
+    lab = np.where(rng.uniform(0, 1, A) < frac_ign, -1.0, lab).astype(np.float32)
+    labels = torch.from_numpy(lab).to(device)
+    reg = torch.from_numpy(rng.standard_normal((A, 4)).astype(np.float32)).to(device)
+    n_pos, n_neg = int((lab >= 1).sum()), int((lab == 0).sum())
+    want_pos = min(n_pos, max_pos)
+    want_neg = min(n_neg, cap - want_pos)
+    counts = torch.zeros(2, dtype=torch.int32, device=device)
+    out = _C.sample_anchors(labels, reg, cap, max_pos, 77 + A, offset, counts)
+    p, q = counts.tolist()
+    assert (p, q) == (want_pos, want_neg)
+    pos, neg = out["pos"][:p].cpu() - offset, out["neg"][:q].cpu() - offset
+    for idx, cls, k in ((pos, 1.0, p), (neg, 0.0, q)):
+        assert torch.equal(idx, idx.sort().values) and idx.unique().numel() == k
+        assert k == 0 or (int(idx.min()) >= 0 and int(idx.max()) < A)
+        assert bool((labels.cpu()[idx] == cls).all())
+    assert torch.equal(out["regression_targets_pos"][:p].cpu(), reg.cpu()[pos])
+    assert bool((out["pos"][p:] == -1).all()) and bool((out["neg"][q:] == -1).all())
+    again = _C.sample_anchors(labels, reg, cap, max_pos, 77 + A, offset, counts)
+    assert torch.equal(again["neg"], out["neg"]) and torch.equal(again["pos"], out["pos"])
+    if n_neg > cap:
+        other = _C.sample_anchors(labels, reg, cap, max_pos, 78 + A, offset, counts)
+        assert not torch.equal(other["neg"], out["neg"])
+
+
+def test_sample_anchors_is_uniform(device):
+    """over many seeds every negative (and every positive when there are more than max_pos) is taken equally often"""
+    from da_detect_amd import _C
+
+    A, cap, max_pos = 400, 64, 16
+    labels = torch.zeros(A, dtype=torch.float32, device=device)
+    labels[:40] = 1.0
+    labels[40:60] = -1.0
+    reg = torch.zeros((A, 4), dtype=torch.float32, device=device)
+    counts = torch.zeros(2, dtype=torch.int32, device=device)
+    trials = 3000
+    hits = torch.zeros(A, dtype=torch.int64)
+    for seed in range(trials):
+        out = _C.sample_anchors(labels, reg, cap, max_pos, seed * 2654435761 + 5, 0, counts)
+        hits[out["pos"][:max_pos].cpu()] += 1
+        hits[out["neg"][:cap - max_pos].cpu()] += 1
+    assert int(hits[40:60].sum()) == 0
+    for sl, prob in ((slice(0, 40), 16 / 40), (slice(60, A), 48 / 340)):
+        sigma = (trials * prob * (1 - prob)) ** 0.5
+        assert float((hits[sl].float() - trials * prob).abs().max()) < 5 * sigma
+
+
 def test_sample_rois_is_seeded_and_uniform(device):
     """same seed -> same sample, other seed -> another one; over many seeds every negative is taken equally often"""
     from da_detect_amd import _C
