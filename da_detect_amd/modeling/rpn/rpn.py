@@ -11,9 +11,6 @@ from .loss import make_rpn_loss_evaluator
 from ...utils.streams import record, side_section, side_stream
 
 
-_MARK = __import__("os").environ.get("DADET_RPN_MARK", "1") == "1"   # A/B switch, see RPNModule.forward
-
-
 @registry.RPN_HEADS.register("SingleConvRPNHead")
 class RPNHead(nn.Module):
     """3x3 conv + ReLU, then 1x1 objectness (A) and 1x1 box deltas (4A) (rpn.py:13-46).  The bias + ReLU is
@@ -28,22 +25,10 @@ class RPNHead(nn.Module):
             torch.nn.init.normal_(l.weight, std=0.01)
             torch.nn.init.constant_(l.bias, 0)
 
-    # set by RPNModule's overlapped schedule: record an event once the gradient w.r.t. the 3x3 conv's output exists,
-    # i.e. when the short chain of small kernels (losses, 1x1 data / weight gradients) is through
-    small_chain_done = None
-    mark_small_chain = False
-
-    def _mark(self, grad):
-        if grad.is_cuda:
-            self.small_chain_done = torch.cuda.current_stream(grad.device).record_event()
-        return None
-
     def forward(self, x):
         logits, bbox_reg = [], []
         for feature in x:
             t = self.conv(feature, relu=True)
-            if self.mark_small_chain and t.requires_grad:
-                t.register_hook(self._mark)
             cls, box = conv1x1_multi(t, [self.cls_logits.weight, self.bbox_pred.weight],
                                      [self.cls_logits.bias, self.bbox_pred.bias])
             logits.append(cls)
@@ -99,9 +84,6 @@ class RPNModule(torch.nn.Module):
         early = (self.training and self.early_backward and torch.is_grad_enabled() and not self.cfg.MODEL.RPN_ONLY
                  and all(f.requires_grad for f in features))
         head_in = [f.detach().requires_grad_(True) for f in features] if early else features
-        if hasattr(self.head, "mark_small_chain"):
-            self.head.mark_small_chain = bool(early and _MARK)
-            self.head.small_chain_done = None
         objectness, rpn_box_regression = self.head(head_in)
         anchors = self.anchor_generator(images, features)
         if not self.training:
@@ -119,10 +101,7 @@ class RPNModule(torch.nn.Module):
         torch.autograd.backward([loss_objectness + loss_rpn_box_reg])
         self._feature_grads = [f.grad for f in head_in]
         side = side_stream(dev)
-        # Proposal selection starts behind the losses and the 1x1 gradients, not beside them: its kernels (sort, the
-        # IoU mask — large grids on a high-priority stream) otherwise take the CUs from that chain of small kernels
-        # and the two big RPN GEMMs start ~0.7 ms late (tools/gemm_table.py --holes); it still runs under those GEMMs.
-        side.wait_event(getattr(self.head, "small_chain_done", None) or head_done)
+        side.wait_event(head_done)
         with torch.cuda.stream(side), torch.no_grad():
             boxes = self.box_selector_train(anchors, [o.detach() for o in objectness],
                                             [r.detach() for r in rpn_box_regression], targets)
