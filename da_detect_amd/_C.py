@@ -12,6 +12,7 @@ other layout are converted (one copy); outputs are always channels_last.
 """
 import contextlib
 import ctypes
+import time
 
 import torch
 
@@ -46,13 +47,19 @@ class KernelProfiler(object):
         self.records = {}   # name -> list of (start_event, end_event, algorithmic_flops)
         self.bytes = {}     # name -> summed algorithmic bytes (operands read once + result written once)
         self.origin = torch.cuda.Event(enable_timing=True)   # common time origin for the union of busy intervals
+        torch.cuda.synchronize()
         self.origin.record()
+        self.host_origin = time.perf_counter()   # the same instant on the host clock (idle device: recorded at once)
+        self.host_times = {}                     # name -> host time (ms since origin) of every bracketed launch
 
     class _Span(object):
         def __init__(self, prof, name, work):
             self.prof, self.name, self.work = prof, name, work
 
         def __enter__(self):
+            if getattr(self.prof, "detail", False):
+                self.prof.host_times.setdefault(self.name, []).append(
+                    (time.perf_counter() - self.prof.host_origin) * 1e3)
             pool = self.prof._pool
             self.s = pool.pop() if pool else torch.cuda.Event(enable_timing=True)
             self.e = pool.pop() if pool else torch.cuda.Event(enable_timing=True)

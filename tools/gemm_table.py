@@ -20,15 +20,18 @@ def holes_report(prof, step_marks):
     t1 = prof.origin.elapsed_time(step_marks[-1])
     spans = []
     for name, recs in prof.records.items():
-        for s, e, _ in recs:
+        hosts = prof.host_times.get(name, [None] * len(recs))
+        for (s, e, _), h in zip(recs, hosts):
             a, b = prof.origin.elapsed_time(s), prof.origin.elapsed_time(e)
             if a >= t0 and b <= t1 + 1.0:
-                spans.append((a, b, name))
+                spans.append((a, b, name, h))
     spans.sort()
     holes, cur_e, cur_name = [], t0, "step start"
-    for a, b, name in spans:
+    for a, b, name, h in spans:
         if a > cur_e:
-            holes.append((a - cur_e, cur_e - t0, cur_name, name))
+            # lead = how long before its start on the GPU the host had issued the launch that ends the stretch
+            holes.append((a - cur_e, cur_e - t0, cur_name, "%s [issued %.2f ms earlier]" % (name, a - h)
+                          if h is not None else name))
         if b > cur_e:
             cur_e, cur_name = b, name
     if t1 > cur_e:
@@ -37,7 +40,7 @@ def holes_report(prof, step_marks):
     print("last step %.2f ms: no GEMM running for %.2f ms in %d stretches" % (t1 - t0, total, len(holes)))
     for d, at, before, after in sorted(holes, reverse=True)[:25]:
         print("  %7.1f us at +%6.2f ms   after %-62s before %s" % (d * 1e3, at, before.replace("conv_", "")[:62],
-                                                                  after.replace("conv_", "")[:62]))
+                                                                  after.replace("conv_", "")[:90]))
 
 
 def main():
