@@ -286,15 +286,12 @@ def conv_forward(x, w, scale=None, bias=None, addend=None, mask_ref=None, stride
     return out
 
 
-def conv_weight_transpose(w, scale=None, out=None):
+def conv_weight_transpose(w, scale=None):
     """[Cout,Cin,KH,KW] -> data-gradient weights [Cin,Cout,KH,KW] (flipped taps, `scale[cout]` folded in)."""
     _dev(w, "w")
     Cout, Cin, KH, KW = w.shape
     w = _nhwc(w)
-    if out is not None:
-        assert tuple(out.shape) == (Cin, Cout, KH, KW) and out.is_contiguous(memory_format=CL)
-    wt = out if out is not None else torch.empty((Cin, Cout, KH, KW), dtype=torch.float32, device=w.device,
-                                                 memory_format=CL)
+    wt = torch.empty((Cin, Cout, KH, KW), dtype=torch.float32, device=w.device, memory_format=CL)
     _lib.call("dadet_conv_weight_transpose", _p(w), _p(scale), _p(wt), Cout, KH, KW, Cin, _stream())
     return wt
 

@@ -12,7 +12,6 @@ from torch.autograd import Function
 from torch.autograd.function import once_differentiable
 
 from .. import _C
-from ..utils import wt_cache
 from ..utils.streams import WgradLane
 
 CL = torch.channels_last
@@ -50,7 +49,7 @@ class _ConvAffineAct(Function):
                                                                  dw=acc, accumulate=True),
                                lambda: _C.conv_wgrad(x, g, tuple(weight.shape), ctx.stride, ctx.pad), x, g)
         if need_x:
-            wt = wt_cache.transposed(weight)
+            wt = _C.conv_weight_transpose(weight)
             if ctx.stride == 1:
                 gx = _C.conv_forward(g, wt, stride=1, pad=k - 1 - ctx.pad)
                 if tuple(gx.shape) != ctx.x_shape:  # out_size-trimmed forward (stem): not needed by any caller

@@ -16,7 +16,6 @@ from torch import nn
 from ... import _C
 from ...layers import Conv2d, FrozenBatchNorm2d, conv2d_affine_act
 from ...utils.registry import Registry
-from ...utils import wt_cache
 from ...utils.streams import WgradLane
 
 StageSpec = namedtuple("StageSpec", ["index", "block_count", "return_features"])
@@ -76,13 +75,13 @@ class _BottleneckFn(torch.autograd.Function):
             dw3 = lane.run_into(w3, lambda acc: _C.conv_wgrad(y2, S3, tuple(w3.shape), 1, 0, out_scale=s3, dw=acc,
                                                               accumulate=True),
                                 lambda: _C.conv_wgrad(y2, S3, tuple(w3.shape), 1, 0, out_scale=s3), y2, S3)
-        S2 = _C.conv_forward(S3, wt_cache.transposed(w3, s3), relu_mode=2, mask_ref=y2)
+        S2 = _C.conv_forward(S3, _C.conv_weight_transpose(w3, s3), relu_mode=2, mask_ref=y2)
         if n2:
             dw2 = lane.run_into(w2, lambda acc: _C.conv_wgrad(y1, S2, tuple(w2.shape), 1, 1, out_scale=s2, dw=acc,
                                                               accumulate=True),
                                 lambda: _C.conv_wgrad(y1, S2, tuple(w2.shape), 1, 1, out_scale=s2), y1, S2)
         if n1 or need_x:
-            S1 = _C.conv_forward(S2, wt_cache.transposed(w2, s2), pad=1, relu_mode=2, mask_ref=y1)
+            S1 = _C.conv_forward(S2, _C.conv_weight_transpose(w2, s2), pad=1, relu_mode=2, mask_ref=y1)
         if n1:
             dw1 = lane.run_into(w1, lambda acc: _C.conv_wgrad(x, S1, tuple(w1.shape), stride, 0, out_scale=s1,
                                                               dw=acc, accumulate=True),
@@ -95,13 +94,13 @@ class _BottleneckFn(torch.autograd.Function):
             gate = dict(relu_mode=2, mask_ref=x) if ctx.in_relu else {}
             hw = tuple(x.shape[2:])
             if wd is None:
-                dx = _C.conv_forward(S1, wt_cache.transposed(w1, s1), addend=S3, **gate)
+                dx = _C.conv_forward(S1, _C.conv_weight_transpose(w1, s1), addend=S3, **gate)
             elif stride == 1:
-                t = _C.conv_forward(S3, wt_cache.transposed(wd, sd))
-                dx = _C.conv_forward(S1, wt_cache.transposed(w1, s1), addend=t, out=t, **gate)
+                t = _C.conv_forward(S3, _C.conv_weight_transpose(wd, sd))
+                dx = _C.conv_forward(S1, _C.conv_weight_transpose(w1, s1), addend=t, out=t, **gate)
             else:  # both 1x1 stride-s data gradients scatter onto the same (s*h, s*w) lattice of a zero map
-                t = _C.conv_forward(S3, wt_cache.transposed(wd, sd), out_spatial_stride=stride, out_hw=hw)
-                dx = _C.conv_forward(S1, wt_cache.transposed(w1, s1), addend=t, out=t,
+                t = _C.conv_forward(S3, _C.conv_weight_transpose(wd, sd), out_spatial_stride=stride, out_hw=hw)
+                dx = _C.conv_forward(S1, _C.conv_weight_transpose(w1, s1), addend=t, out=t,
                                      out_spatial_stride=stride, out_hw=hw, **gate)
         lane.join()
         return (dx, dw1, dw2, dw3, dwd) + (None,) * 12

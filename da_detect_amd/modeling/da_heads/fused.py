@@ -14,7 +14,6 @@ from torch.autograd import Function
 from torch.autograd.function import once_differentiable
 
 from ... import _C
-from ...utils import wt_cache
 
 CL = torch.channels_last
 
@@ -52,7 +51,7 @@ class _DAImageHead(Function):
                                                                 need_x=need_x)
         g_w1 = _C.conv_wgrad(x, g_t_w, tuple(w1.shape), 1, 0)
         g_b1 = _C.colsum(g_t_w)
-        g_x = _C.conv_forward(g_t_x, wt_cache.transposed(w1)) if need_x else None
+        g_x = _C.conv_forward(g_t_x, _C.conv_weight_transpose(w1)) if need_x else None
         return g_x, g_w1, g_b1, g_w2.view(ctx.w2_shape), g_b2, None, None, None
 
 

@@ -95,9 +95,6 @@ class FusedSGD(torch.optim.Optimizer):
                   float(momentum), 1 if all(first) else 0, float(grad_scale),
                   ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
         self._steps += 1
-        # the data-gradient copies of the weights follow the update on a side stream (utils/wt_cache.py)
-        from ..utils import wt_cache
-        wt_cache.refresh_all(entries[0][0].device)
         return loss
 
 

@@ -615,43 +615,3 @@ def test_early_image_level_da_backward_gives_the_same_gradients(device):
     assert set(g0) == set(g1) and any(n.startswith("da_heads.imghead") for n in g0)
     for n in g0:
         assert float((g0[n] - g1[n]).norm()) <= 1e-5 * float(g0[n].norm()) + 1e-10, n
-
-
-def test_cached_data_gradient_weights_follow_the_optimizer(device):
-    """utils.wt_cache keeps the transposed / BN-folded weights of the data-gradient GEMMs across steps and refreshes
-    them behind the fused SGD kernel: three optimizer steps give the same parameters as with the copies recomputed in
-    front of every GEMM, and an in-place change of a weight outside the optimizer is picked up"""
-    from da_detect_amd.data.synthetic import make_batch
-    from da_detect_amd.engine.trainer import train_step
-    from da_detect_amd.parallel.reducer import BucketedGradReducer
-    from da_detect_amd.solver import make_optimizer
-    from da_detect_amd.utils import rng, streams, wt_cache
-
-    results = []
-    for cached in (False, True):
-        wt_cache.clear()
-        wt_cache.ALLOWED = cached
-        z, c, model, _ = _build("da_plain", device)
-        seed, H, W, nimg = int(z["seed"]), int(z["H"]), int(z["W"]), int(z["nimg"])
-        images, targets = make_batch(c, nimg, H, W, seed=seed, device=device)
-        opt = make_optimizer(c, model)
-        opt.attach_reducer(BucketedGradReducer([p for p in model.parameters() if p.requires_grad]))
-        rng.use_cpu_stream(True)
-        try:
-            for step in range(3):
-                torch.manual_seed(seed + step)
-                train_step(model, opt, images, targets)
-                if step == 1:       # a change the optimizer does not know about
-                    with torch.no_grad():
-                        model.rpn.head.conv.weight.mul_(0.5)
-        finally:
-            rng.use_cpu_stream(False)
-            streams.enable_direct_wgrad(False)
-        torch.cuda.synchronize()
-        if cached:
-            assert wt_cache.ENABLED and len(wt_cache._ENTRIES) > 20
-        results.append({n: p.detach().clone() for n, p in model.named_parameters()})
-    wt_cache.ALLOWED = True
-    wt_cache.clear()
-    for n in results[0]:
-        torch.testing.assert_close(results[1][n], results[0][n], rtol=1e-5, atol=1e-7, msg=lambda m, n=n: "%s: %s" % (n, m))
