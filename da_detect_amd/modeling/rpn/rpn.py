@@ -11,9 +11,6 @@ from .loss import make_rpn_loss_evaluator
 from ...utils.streams import record, side_section, side_stream
 
 
-_BRANCH_STREAM = __import__("os").environ.get("DADET_RPN_BRANCH_STREAM", "1") == "1"   # A/B switch
-
-
 @registry.RPN_HEADS.register("SingleConvRPNHead")
 class RPNHead(nn.Module):
     """3x3 conv + ReLU, then 1x1 objectness (A) and 1x1 box deltas (4A) (rpn.py:13-46).  The bias + ReLU is
@@ -114,7 +111,7 @@ class RPNModule(torch.nn.Module):
         dev = features[0].device
         main = torch.cuda.current_stream(dev)
         anchors = self.anchor_generator(images, features)
-        branch = side_stream(dev, 4) if _BRANCH_STREAM else main
+        branch = side_stream(dev, 4)
         branch.wait_stream(main)
         record(features, branch)
         with torch.cuda.stream(branch):
