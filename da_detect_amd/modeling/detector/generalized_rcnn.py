@@ -35,7 +35,7 @@ class GeneralizedRCNN(nn.Module):
             # lets the RPN prepare its loss targets on a side stream without waiting for the backbone
             self.rpn.inputs_ready = torch.cuda.current_stream(images.tensors.device).record_event()
         features = self.backbone(images.tensors)
-        early_da = da_stream = da_done = None
+        early_da = da_stream = None
         if self.training and self.da_heads and not self.da_heads_triplet and features[0].is_cuda:
             # image-level DA loss + its backward (DomainAdaptationModule.early_image_level) on their own stream, beside
             # the RPN branch and the box head: they need nothing but the backbone features
@@ -51,8 +51,10 @@ class GeneralizedRCNN(nn.Module):
                 record(features, da_stream)
         proposals, proposal_losses = self.rpn(images, features, targets)
         if self.training:
-            da_done = da_stream.record_event() if da_stream is not None else None
-            features = self.rpn.bridge_features(features, early_da, da_done)
+            if da_stream is not None:
+                torch.cuda.current_stream(features[0].device).wait_stream(da_stream)
+                record(early_da, torch.cuda.current_stream(features[0].device))
+            features = self.rpn.bridge_features(features, early_da)
             if self.roi_heads:
                 self.roi_heads.box.proposals_ready, self.rpn.proposals_ready = self.rpn.proposals_ready, None
         da_losses, detector_losses = {}, {}
@@ -84,12 +86,6 @@ class GeneralizedRCNN(nn.Module):
         else:
             result = proposals
         if self.training:
-            if images.tensors.is_cuda:
-                # loss values of the branches that ran on their own streams are about to be summed on this one
-                cur = torch.cuda.current_stream(images.tensors.device)
-                for ev in (getattr(self.rpn, "branch_done", None), da_done):
-                    if ev is not None:
-                        cur.wait_event(ev)
             losses = {}
             losses.update(detector_losses)
             losses.update(proposal_losses)

@@ -37,27 +37,17 @@ class RPNHead(nn.Module):
 
 
 class _InjectGrad(torch.autograd.Function):
-    """identity whose backward adds gradients computed earlier, on other streams (the RPN branch's, the image-level
-    DA head's — see RPNModule.early_backward); `ready`: events after which they exist"""
+    """identity whose backward adds a gradient computed earlier (the RPN branch's, see RPNModule.early_backward)"""
 
     @staticmethod
-    def forward(ctx, x, ready, *grads):
-        ctx.ready = ready
-        ctx.save_for_backward(*grads)
+    def forward(ctx, x, g):
+        ctx.save_for_backward(g)
         return x.view_as(x)
 
     @staticmethod
     def backward(ctx, grad_out):
-        if grad_out.is_cuda:
-            cur = torch.cuda.current_stream(grad_out.device)
-            for ev in ctx.ready:
-                cur.wait_event(ev)
-        out = grad_out
-        for g in ctx.saved_tensors:
-            if g.is_cuda:
-                g.record_stream(torch.cuda.current_stream(g.device))
-            out = out + g
-        return (out, None) + (None,) * len(ctx.saved_tensors)
+        (g,) = ctx.saved_tensors
+        return grad_out + g, None
 
 
 class RPNModule(torch.nn.Module):
@@ -87,45 +77,31 @@ class RPNModule(torch.nn.Module):
         self.loss_evaluator = make_rpn_loss_evaluator(cfg, rpn_box_coder)
         self.proposals_ready = None  # event: proposals exist (recorded before the RPN losses / early backward)
         self._feature_grads = None
-        self._grads_ready = None
-        self.branch_done = None      # event: the early RPN branch (losses + backward) has finished on its stream
         self.inputs_ready = None     # event recorded by the detector before the backbone is queued
 
     def forward(self, images, features, targets=None):
         self._feature_grads = None
         early = (self.training and self.early_backward and torch.is_grad_enabled() and not self.cfg.MODEL.RPN_ONLY
                  and all(f.requires_grad for f in features))
-        self._grads_ready = self.branch_done = None
-        if not (early and features[0].is_cuda):
-            objectness, rpn_box_regression = self.head(features)
-            anchors = self.anchor_generator(images, features)
-            if not self.training:
-                return self._forward_test(anchors, objectness, rpn_box_regression)
-            return self._forward_train(anchors, objectness, rpn_box_regression, targets)
-        # Overlapped schedule.  The whole RPN branch — head, losses and the branch's backward (autograd runs a node's
-        # backward on the stream of its forward) — goes to its OWN stream: the compute stream needs none of it, only the
-        # proposals, so the box head is not queued behind the RPN data-gradient GEMM and its first kernels (ROIAlign,
-        # the res5 convs) overlap the tail of the RPN backward.  Proposal selection (sort, decode, single-workgroup NMS
-        # sweeps, one host round trip) runs on the side stream underneath the RPN backward, and the box head's sampling
-        # continues there (ROIBoxHead.forward).
-        dev = features[0].device
-        main = torch.cuda.current_stream(dev)
+        head_in = [f.detach().requires_grad_(True) for f in features] if early else features
+        objectness, rpn_box_regression = self.head(head_in)
         anchors = self.anchor_generator(images, features)
-        branch = side_stream(dev, 4)
-        branch.wait_stream(main)
-        record(features, branch)
-        with torch.cuda.stream(branch):
-            head_in = [f.detach().requires_grad_(True) for f in features]
-            objectness, rpn_box_regression = self.head(head_in)
-            head_done = branch.record_event()
-            prep = self._prepare_loss_targets(anchors, targets)
-            loss_objectness, loss_rpn_box_reg = self.loss_evaluator.finish(objectness, rpn_box_regression, prep)
-            torch.autograd.backward([loss_objectness + loss_rpn_box_reg])
-            self._feature_grads = [f.grad for f in head_in]
-            self._grads_ready = self.branch_done = branch.record_event()
+        if not self.training:
+            return self._forward_test(anchors, objectness, rpn_box_regression)
+        if not (early and objectness[0].is_cuda):
+            return self._forward_train(anchors, objectness, rpn_box_regression, targets)
+        # overlapped schedule: losses + the RPN branch's backward go to the compute stream first; proposal selection
+        # (sort, decode, single-workgroup NMS sweeps, one host round trip) then runs on the side stream underneath
+        # them, and the box head's sampling continues there (ROIBoxHead.forward)
+        dev = objectness[0].device
+        prep = self._prepare_loss_targets(anchors, targets)
+        main = torch.cuda.current_stream(dev)
+        head_done = main.record_event()
+        loss_objectness, loss_rpn_box_reg = self.loss_evaluator.finish(objectness, rpn_box_regression, prep)
+        torch.autograd.backward([loss_objectness + loss_rpn_box_reg])
+        self._feature_grads = [f.grad for f in head_in]
         side = side_stream(dev)
         side.wait_event(head_done)
-        record([objectness, rpn_box_regression], side)
         with torch.cuda.stream(side), torch.no_grad():
             boxes = self.box_selector_train(anchors, [o.detach() for o in objectness],
                                             [r.detach() for r in rpn_box_regression], targets)
@@ -133,18 +109,17 @@ class RPNModule(torch.nn.Module):
         record(boxes, main)
         return boxes, {"loss_objectness": loss_objectness.detach(), "loss_rpn_box_reg": loss_rpn_box_reg.detach()}
 
-    def bridge_features(self, features, extra=None, extra_ready=None):
+    def bridge_features(self, features, extra=None):
         """features whose backward also delivers the RPN branch's gradient (no-op unless early_backward ran);
-        `extra`: gradients of another branch that ran its backward early (the image-level DA head), same layout, and
-        the event after which they exist.  Nothing waits here: the gradients are only needed in backward."""
+        `extra`: gradients of another branch that ran its backward early (the image-level DA head), same layout"""
         grads, self._feature_grads = self._feature_grads, None
-        ready = [ev for ev in (self._grads_ready, extra_ready) if ev is not None]
-        self._grads_ready = None
-        if grads is None and extra is None:
+        if grads is None:
+            grads = extra
+        elif extra is not None:
+            grads = [g + e for g, e in zip(grads, extra)]
+        if grads is None:
             return features
-        per_level = [[g for g in pair if g is not None]
-                     for pair in zip(grads or [None] * len(features), extra or [None] * len(features))]
-        return [_InjectGrad.apply(f, ready, *gs) for f, gs in zip(features, per_level)]
+        return [_InjectGrad.apply(f, g) for f, g in zip(features, grads)]
 
     def _prepare_loss_targets(self, anchors, targets):
         """RPNLossComputation.prepare on a side stream: its ~150 small launches and host synchronisations overlap
