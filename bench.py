@@ -114,7 +114,7 @@ def pmc_traffic(kernel_name, gemm_mode):
     path = os.path.join(ROOT, "profiles", "r01_pmc_hbm_traffic.json")
     if gemm_mode != 3 or not os.path.exists(path):
         return None, None
-    want = kernel_name.replace(" ", "")
+    want = kernel_name.replace(" ", "").rstrip(">")      # "conv_fwd_split_kernel<2,2,3" also matches "...<2,2,3,0>"
     with open(path) as f:
         table = json.load(f)["kernels"]
     for name, rec in table.items():
