@@ -340,17 +340,25 @@ __device__ inline int roi_contributions(const RoiGeom& g, int r, int H, int W, i
 
 template <int VEC, int MAXC>   // MAXC channel groups per lane: C <= 256 * VEC * MAXC
 __global__ __launch_bounds__(256) void roi_align_bwd_list_kernel(
-    const float* __restrict__ grad_out, const float* __restrict__ rois, float* __restrict__ grad_in, int C,
+    const float* __restrict__ grad_out, const float* __restrict__ rois, float* __restrict__ grad_in, int B, int C,
     int H, int W, int R, int pooled_h, int pooled_w, float scale, int sampling_ratio) {
   __shared__ Contribution s_list[kListCap];
   __shared__ int s_ids[256];        // touching ROIs of the current range, ascending
   __shared__ int s_wave_n[4];
   __shared__ int s_total;
   const int tiles_x = (W + 1) / 2, tiles_y = (H + 1) / 2;
-  const int tile = xcd_remap(blockIdx.x, gridDim.x);   // neighbouring tiles read the same gradient rows: same XCD / L2
-  const int b = tile / (tiles_y * tiles_x);
-  const int y0 = ((tile / tiles_x) % tiles_y) * 2;
-  const int x0 = (tile % tiles_x) * 2;
+  // Neighbouring tiles read the same gradient rows (a bin's four samples reach over up to 3 x 3 pixels).  Hardware
+  // deals consecutive workgroup ids to the 8 XCDs round-robin: the four tiles of a 2 x 2 super-tile are given to ONE
+  // XCD (one L2 fetch of the shared rows), super-tiles go round-robin over the XCDs so that regions crowded with ROIs
+  // spread evenly (a contiguous band per XCD measured slower: the ROIs are not spread evenly over the image).
+  const int sx = (tiles_x + 1) / 2, sy = (tiles_y + 1) / 2;
+  const int xcd = blockIdx.x % kNumXCD, idx = blockIdx.x / kNumXCD;
+  const int super = (idx >> 2) * kNumXCD + xcd, q = idx & 3;
+  const int b = super / (sx * sy);
+  const int ty = ((super / sx) % sy) * 2 + (q >> 1), tx = (super % sx) * 2 + (q & 1);
+  if (b >= B || ty >= tiles_y || tx >= tiles_x) return;
+  const int y0 = ty * 2;
+  const int x0 = tx * 2;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   float acc[MAXC][4][VEC];
 #pragma unroll
@@ -550,12 +558,14 @@ extern "C" int dadet_roi_align_backward(const float* grad_output, const float* r
                    ((reinterpret_cast<uintptr_t>(grad_input) & 15) == 0);
   static const bool use_list = !(getenv("DADET_ROI_BWD_LIST") && getenv("DADET_ROI_BWD_LIST")[0] == '0');
   if (vec && use_list && C <= 256 * 4 * 4 && pooled_h <= 14 && pooled_w <= 14) {
-    const dim3 tgrid((unsigned)(B * ((H + 1) / 2) * ((W + 1) / 2)));
+    // 2 x 2 super-tiles of 2 x 2-pixel tiles, padded to whole rounds of the 8 XCDs; grid.y only carries B
+    const int supers = B * (((W + 1) / 2 + 1) / 2) * (((H + 1) / 2 + 1) / 2);
+    const dim3 tgrid((unsigned)(((supers + kNumXCD - 1) / kNumXCD) * kNumXCD * 4), 1, 1);
     if (C <= 1024)
-      hipLaunchKernelGGL((roi_align_bwd_list_kernel<4, 1>), tgrid, dim3(256), 0, st, grad_output, rois, grad_input, C,
+      hipLaunchKernelGGL((roi_align_bwd_list_kernel<4, 1>), tgrid, dim3(256), 0, st, grad_output, rois, grad_input, B, C,
                          H, W, R, pooled_h, pooled_w, spatial_scale, sampling_ratio);
     else
-      hipLaunchKernelGGL((roi_align_bwd_list_kernel<4, 4>), tgrid, dim3(256), 0, st, grad_output, rois, grad_input, C,
+      hipLaunchKernelGGL((roi_align_bwd_list_kernel<4, 4>), tgrid, dim3(256), 0, st, grad_output, rois, grad_input, B, C,
                          H, W, R, pooled_h, pooled_w, spatial_scale, sampling_ratio);
   } else if (vec) {
     const int threads = (C / 4 >= 256) ? 256 : ((C / 4 + 63) / 64) * 64;
