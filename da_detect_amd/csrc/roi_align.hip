@@ -344,7 +344,6 @@ __global__ __launch_bounds__(256) void roi_align_bwd_list_kernel(
     int H, int W, int R, int pooled_h, int pooled_w, float scale, int sampling_ratio) {
   __shared__ Contribution s_list[kListCap];
   __shared__ int s_ids[256];        // touching ROIs of the current range, ascending
-  __shared__ float s_roi[256 * 5];  // the range's ROI records
   __shared__ int s_wave_n[4];
   __shared__ int s_total;
   const int tiles_x = (W + 1) / 2, tiles_y = (H + 1) / 2;
@@ -409,21 +408,13 @@ __global__ __launch_bounds__(256) void roi_align_bwd_list_kernel(
 
   for (int base = 0; base < R; base += 256) {
     // 1. which ROIs of this range touch the tile; ordered compaction (wave ballots, wave order = ROI order)
-    // the range's ROI records arrive through LDS (five coalesced loads instead of five 20-byte-strided ones), and
-    // the hit test needs the extent only — no bin sizes, i.e. no divisions.  It is a superset filter with a pixel of
-    // slack on every side; which samples really reach the tile is decided exactly by roi_contributions().
     const int r = base + (int)threadIdx.x;
-    const int nrange = min(256, R - base);
-    __syncthreads();
-    for (int i = threadIdx.x; i < nrange * 5; i += 256) s_roi[i] = rois[(size_t)base * 5 + i];
-    __syncthreads();
     bool hit = false;
     if (r < R) {
-      const float* q = s_roi + threadIdx.x * 5;
-      const float sw = q[1] * scale, sh = q[2] * scale;
-      const float roi_w = fmaxf(q[3] * scale - sw, 1.f), roi_h = fmaxf(q[4] * scale - sh, 1.f);
-      hit = (int)q[0] == b && sh <= (float)y0 + 2.f && sh + roi_h >= (float)y0 - 1.f &&
-            sw <= (float)x0 + 2.f && sw + roi_w >= (float)x0 - 1.f;
+      const RoiGeom g = roi_geometry(rois + (size_t)r * 5, scale, pooled_h, pooled_w, sampling_ratio);
+      const float roi_h = g.bin_h * (float)pooled_h, roi_w = g.bin_w * (float)pooled_w;
+      hit = g.batch == b && g.start_h <= (float)y0 + 2.f && g.start_h + roi_h >= (float)y0 - 1.f &&
+            g.start_w <= (float)x0 + 2.f && g.start_w + roi_w >= (float)x0 - 1.f;
     }
     const unsigned long long ballot = __ballot(hit);
     if (lane == 0) s_wave_n[wave] = __popcll(ballot);
