@@ -1,7 +1,6 @@
 """Index samplers of the training loop (reference: maskrcnn_benchmark/data/samplers/{distributed,
 grouped_batch_sampler,iteration_based_batch_sampler}.py).  Same index streams as the reference for the same seeds /
 epochs (tests compare them on recorded sequences); pure host code."""
-import itertools
 import math
 
 import torch

@@ -1,7 +1,6 @@
 """Deformable position-sensitive ROI pooling — operator API of the reference's vendored tree
 (tools/cityscapes/maskrcnn_benchmark/layers/dcn/deform_pool_func.py:10-95, deform_pool_module.py:6-150),
 served by csrc/deform.hip (NHWC)."""
-import torch
 from torch import nn
 from torch.autograd import Function
 from torch.autograd.function import once_differentiable

@@ -1,6 +1,5 @@
 """Small layers of the reference's operator API (reference: maskrcnn_benchmark/layers/{batch_norm,misc,
 gradient_scalar_layer,smooth_l1_loss,consistency_loss,sigmoid_focal_loss}.py), backed by the HIP library."""
-import math
 
 import torch
 from torch import nn
