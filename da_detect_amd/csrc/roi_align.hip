@@ -417,15 +417,12 @@ __global__ __launch_bounds__(256) void roi_align_bwd_list_kernel(
         for (int u = 0; u < U; ++u) {
           if (e0 + u >= n_entries) break;
           const Contribution<T>& q = s_list[e0 + u];
-          // the entry is the same for every lane: reading it through the scalar unit makes the zero-weight test a real
-          // (scalar) branch — as vector code the skipped pixels were computed and masked, 4x the work on 4 x 4 tiles
-          const float cnt = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(q.count)));
-          const float inv = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(q.inv)));
-          const bool pow2 = __builtin_amdgcn_readfirstlane(q.pow2) != 0;
+          const float cnt = q.count, inv = q.inv;
+          const bool pow2 = q.pow2 != 0;
 #pragma unroll
           for (int p = 0; p < TT; ++p) {
-            const float w = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(q.w[p])));
-            if (w == 0.f) continue;   // keeps every pixel's sum free of +0 terms
+            const float w = q.w[p];
+            if (w == 0.f) continue;   // wave-uniform: keeps every pixel's sum free of +0 terms
 #pragma unroll
             for (int v = 0; v < VEC; ++v) {
               const float t = gq[u][v] * w;
