@@ -295,62 +295,41 @@ __global__ __launch_bounds__(256) void roi_align_bwd_gather_kernel(
 //  * the wave-uniform coordinate / weight arithmetic is not executed by all 256 lanes for every ROI: per range of
 //    256 ROIs the lanes test one ROI each, the touching ones are compacted in order, ONE LANE PER ROI lists that
 //    ROI's non-zero contributions into LDS, and all lanes then stream over the list.
-template <int T>
 struct Contribution {
   int row;        // (r * pooled_h + ph) * pooled_w + pw
   float count;    // samples per bin of that ROI
+  float w[4];     // wy * wx for the tile pixels (y0,x0) (y0,x0+1) (y0+1,x0) (y0+1,x0+1)
   float inv;      // 1 / count
-  int pow2;       // count is a power of two: (g * w) * inv == (g * w) / count bit for bit, and the IEEE divisions of
-                  // the inner loop (~10 VALU instructions each) become multiplications — the kernel was VALU bound on them
-  float w[T * T]; // wy * wx for the tile pixels, row major from (y0, x0)
+  int pow2;       // count is a power of two: (g * w) * inv == (g * w) / count bit for bit, and 16 IEEE divisions per
+                  // entry and lane (~10 VALU instructions each) become multiplications — the kernel was VALU bound on them
 };
-template <int T> constexpr int list_cap() { return T == 2 ? 1024 : 512; }   // entries per round: 32 KB / 40 KB of LDS
+constexpr int kListCap = 1024;   // entries per round (32 KB of LDS)
 
-// contributions of ROI r to the T x T tile at (y0, x0), in (sample row, sample column) order; only_sy >= 0 restricts
-// the listing to that sample row (at most pooled_w * grid_w <= list_cap entries)
-template <int T>
 __device__ inline int roi_contributions(const RoiGeom& g, int r, int H, int W, int pooled_h, int pooled_w, int y0,
-                                        int x0, Contribution<T>* out, int only_sy, int* sy_lo, int* sy_hi) {
+                                        int x0, Contribution* out) {
   int sy0, sy1, sx0, sx1, lo, hi, n = 0;
   candidate_range(g.start_h, g.bin_h, g.grid_h, pooled_h, y0, &sy0, &hi);
-  candidate_range(g.start_h, g.bin_h, g.grid_h, pooled_h, y0 + T - 1, &lo, &sy1);
+  candidate_range(g.start_h, g.bin_h, g.grid_h, pooled_h, y0 + 1, &lo, &sy1);
   candidate_range(g.start_w, g.bin_w, g.grid_w, pooled_w, x0, &sx0, &hi);
-  candidate_range(g.start_w, g.bin_w, g.grid_w, pooled_w, x0 + T - 1, &lo, &sx1);
-  if (sy_lo) { *sy_lo = sy0; *sy_hi = sy1; }
-  if (only_sy >= 0) sy0 = sy1 = only_sy;
+  candidate_range(g.start_w, g.bin_w, g.grid_w, pooled_w, x0 + 1, &lo, &sx1);
   for (int sy = sy0; sy <= sy1; ++sy) {
     const int ph = sy / g.grid_h, iy = sy - ph * g.grid_h;
     const float cy = sample_coord(g.start_h, ph, g.bin_h, iy, g.grid_h);
-    float wy[T];
-    bool any = false;
-#pragma unroll
-    for (int i = 0; i < T; ++i) {
-      wy[i] = axis_weight(cy, H, y0 + i);
-      any = any || wy[i] != 0.f;
-    }
-    if (!any) continue;
+    const float wy0 = axis_weight(cy, H, y0), wy1 = axis_weight(cy, H, y0 + 1);
+    if (wy0 == 0.f && wy1 == 0.f) continue;
     for (int sx = sx0; sx <= sx1; ++sx) {
       const int pw = sx / g.grid_w, ix = sx - pw * g.grid_w;
       const float cx = sample_coord(g.start_w, pw, g.bin_w, ix, g.grid_w);
-      float wx[T];
-      any = false;
-#pragma unroll
-      for (int j = 0; j < T; ++j) {
-        wx[j] = axis_weight(cx, W, x0 + j);
-        any = any || wx[j] != 0.f;
-      }
-      if (!any) continue;
+      const float wx0 = axis_weight(cx, W, x0), wx1 = axis_weight(cx, W, x0 + 1);
+      if (wx0 == 0.f && wx1 == 0.f) continue;
       if (out) {
-        Contribution<T> c;
+        Contribution c;
         c.row = (r * pooled_h + ph) * pooled_w + pw;
         c.count = g.count;
+        c.w[0] = wy0 * wx0; c.w[1] = wy0 * wx1; c.w[2] = wy1 * wx0; c.w[3] = wy1 * wx1;
         c.inv = 1.f / g.count;
         const int ci = (int)g.count;
         c.pow2 = (ci & (ci - 1)) == 0;
-#pragma unroll
-        for (int i = 0; i < T; ++i)
-#pragma unroll
-          for (int j = 0; j < T; ++j) c.w[i * T + j] = wy[i] * wx[j];
         out[n] = c;
       }
       ++n;
@@ -359,19 +338,15 @@ __device__ inline int roi_contributions(const RoiGeom& g, int r, int H, int W, i
   return n;
 }
 
-// MAXC channel groups per lane: C <= 256 * VEC * MAXC.  T: edge of the pixel tile a workgroup owns.
-template <int VEC, int MAXC, int T>
+template <int VEC, int MAXC>   // MAXC channel groups per lane: C <= 256 * VEC * MAXC
 __global__ __launch_bounds__(256) void roi_align_bwd_list_kernel(
     const float* __restrict__ grad_out, const float* __restrict__ rois, float* __restrict__ grad_in, int B, int C,
     int H, int W, int R, int pooled_h, int pooled_w, float scale, int sampling_ratio) {
-  constexpr int TT = T * T;
-  constexpr int kCap = list_cap<T>();
-  __shared__ Contribution<T> s_list[kCap];
+  __shared__ Contribution s_list[kListCap];
   __shared__ int s_ids[256];        // touching ROIs of the current range, ascending
   __shared__ int s_wave_n[4];
   __shared__ int s_total;
-  __shared__ int s_sy[2];
-  const int tiles_x = (W + T - 1) / T, tiles_y = (H + T - 1) / T;
+  const int tiles_x = (W + 1) / 2, tiles_y = (H + 1) / 2;
   // Neighbouring tiles read the same gradient rows (a bin's four samples reach over up to 3 x 3 pixels).  Hardware
   // deals consecutive workgroup ids to the 8 XCDs round-robin: the four tiles of a 2 x 2 super-tile are given to ONE
   // XCD (one L2 fetch of the shared rows), super-tiles go round-robin over the XCDs so that regions crowded with ROIs
@@ -382,14 +357,14 @@ __global__ __launch_bounds__(256) void roi_align_bwd_list_kernel(
   const int b = super / (sx * sy);
   const int ty = ((super / sx) % sy) * 2 + (q >> 1), tx = (super % sx) * 2 + (q & 1);
   if (b >= B || ty >= tiles_y || tx >= tiles_x) return;
-  const int y0 = ty * T;
-  const int x0 = tx * T;
+  const int y0 = ty * 2;
+  const int x0 = tx * 2;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  float acc[MAXC][TT][VEC];
+  float acc[MAXC][4][VEC];
 #pragma unroll
   for (int k = 0; k < MAXC; ++k)
 #pragma unroll
-    for (int p = 0; p < TT; ++p)
+    for (int p = 0; p < 4; ++p)
 #pragma unroll
       for (int v = 0; v < VEC; ++v) acc[k][p][v] = 0.f;
 
@@ -416,17 +391,14 @@ __global__ __launch_bounds__(256) void roi_align_bwd_list_kernel(
 #pragma unroll
         for (int u = 0; u < U; ++u) {
           if (e0 + u >= n_entries) break;
-          const Contribution<T>& q = s_list[e0 + u];
-          const float cnt = q.count, inv = q.inv;
-          const bool pow2 = q.pow2 != 0;
+          const Contribution q = s_list[e0 + u];
 #pragma unroll
-          for (int p = 0; p < TT; ++p) {
-            const float w = q.w[p];
-            if (w == 0.f) continue;   // wave-uniform: keeps every pixel's sum free of +0 terms
+          for (int p = 0; p < 4; ++p) {
+            if (q.w[p] == 0.f) continue;   // wave-uniform: keeps every pixel's sum free of +0 terms
 #pragma unroll
             for (int v = 0; v < VEC; ++v) {
-              const float t = gq[u][v] * w;
-              acc[k][p][v] += pow2 ? t * inv : t / cnt;   // wave-uniform choice
+              const float t = gq[u][v] * q.w[p];
+              acc[k][p][v] += q.pow2 ? t * q.inv : t / q.count;   // wave-uniform choice
             }
           }
         }
@@ -441,8 +413,8 @@ __global__ __launch_bounds__(256) void roi_align_bwd_list_kernel(
     if (r < R) {
       const RoiGeom g = roi_geometry(rois + (size_t)r * 5, scale, pooled_h, pooled_w, sampling_ratio);
       const float roi_h = g.bin_h * (float)pooled_h, roi_w = g.bin_w * (float)pooled_w;
-      hit = g.batch == b && g.start_h <= (float)(y0 + T) && g.start_h + roi_h >= (float)y0 - 1.f &&
-            g.start_w <= (float)(x0 + T) && g.start_w + roi_w >= (float)x0 - 1.f;
+      hit = g.batch == b && g.start_h <= (float)y0 + 2.f && g.start_h + roi_h >= (float)y0 - 1.f &&
+            g.start_w <= (float)x0 + 2.f && g.start_w + roi_w >= (float)x0 - 1.f;
     }
     const unsigned long long ballot = __ballot(hit);
     if (lane == 0) s_wave_n[wave] = __popcll(ballot);
@@ -461,7 +433,7 @@ __global__ __launch_bounds__(256) void roi_align_bwd_list_kernel(
         if (lane < nround) {
           rr = s_ids[start + lane];
           g = roi_geometry(rois + (size_t)rr * 5, scale, pooled_h, pooled_w, sampling_ratio);
-          my_n = roi_contributions<T>(g, rr, H, W, pooled_h, pooled_w, y0, x0, nullptr, -1, nullptr, nullptr);
+          my_n = roi_contributions(g, rr, H, W, pooled_h, pooled_w, y0, x0, nullptr);
         }
         int incl = my_n;   // inclusive wave scan
 #pragma unroll
@@ -471,43 +443,36 @@ __global__ __launch_bounds__(256) void roi_align_bwd_list_kernel(
         }
         const int total = __shfl(incl, 63, 64);
         if (lane == 0) s_total = total;
-        if (total <= kCap && rr >= 0)
-          roi_contributions<T>(g, rr, H, W, pooled_h, pooled_w, y0, x0, s_list + (incl - my_n), -1, nullptr, nullptr);
+        if (total <= kListCap && rr >= 0)
+          roi_contributions(g, rr, H, W, pooled_h, pooled_w, y0, x0, s_list + (incl - my_n));
       }
       __syncthreads();
       const int total = s_total;
-      if (total <= kCap) {
+      if (total <= kListCap) {
         accumulate(total);
       } else {
-        // pile-up of many / tiny ROIs on one tile: one ROI and one sample row at a time (a row offers at most
-        // pooled_w * grid_w candidate samples, far below the list capacity); same (ROI, row, column) order
+        // pathological pile-up of tiny ROIs on one tile: list them one ROI at a time (a 14x14-bin ROI offers at most
+        // 32 x 32 candidate samples to a tile, <= kListCap)
         for (int i = 0; i < nround; ++i) {
-          const int r1 = s_ids[start + i];
-          const RoiGeom g1 = roi_geometry(rois + (size_t)r1 * 5, scale, pooled_h, pooled_w, sampling_ratio);
           __syncthreads();
-          if (threadIdx.x == 0)
-            roi_contributions<T>(g1, r1, H, W, pooled_h, pooled_w, y0, x0, nullptr, -1, &s_sy[0], &s_sy[1]);
-          __syncthreads();
-          const int lo = s_sy[0], hi = s_sy[1];
-          for (int row = lo; row <= hi; ++row) {
-            __syncthreads();
-            if (threadIdx.x == 0) {
-              const int n1 = roi_contributions<T>(g1, r1, H, W, pooled_h, pooled_w, y0, x0, nullptr, row, nullptr, nullptr);
-              if (n1 <= kCap) roi_contributions<T>(g1, r1, H, W, pooled_h, pooled_w, y0, x0, s_list, row, nullptr, nullptr);
-              s_total = n1 <= kCap ? n1 : -1;
-            }
-            __syncthreads();
-            if (s_total < 0) __builtin_trap();   // a sample row never holds more than pooled_w * grid_w entries
-            accumulate(s_total);
+          if (threadIdx.x == 0) {
+            const int r1 = s_ids[start + i];
+            const RoiGeom g1 = roi_geometry(rois + (size_t)r1 * 5, scale, pooled_h, pooled_w, sampling_ratio);
+            const int n1 = roi_contributions(g1, r1, H, W, pooled_h, pooled_w, y0, x0, nullptr);
+            if (n1 <= kListCap) roi_contributions(g1, r1, H, W, pooled_h, pooled_w, y0, x0, s_list);
+            s_total = n1 <= kListCap ? n1 : -1;
           }
+          __syncthreads();
+          if (s_total < 0) __builtin_trap();   // cannot happen for pooled sizes <= 14 x 14 with sampling_ratio <= 2
+          accumulate(s_total);
         }
       }
       __syncthreads();
     }
   }
 #pragma unroll
-  for (int p = 0; p < TT; ++p) {
-    const int y = y0 + p / T, x = x0 + p % T;
+  for (int p = 0; p < 4; ++p) {
+    const int y = y0 + (p >> 1), x = x0 + (p & 1);
     if (y >= H || x >= W) continue;
 #pragma unroll
     for (int k = 0; k < MAXC; ++k) {
@@ -593,22 +558,15 @@ extern "C" int dadet_roi_align_backward(const float* grad_output, const float* r
                    ((reinterpret_cast<uintptr_t>(grad_input) & 15) == 0);
   static const bool use_list = !(getenv("DADET_ROI_BWD_LIST") && getenv("DADET_ROI_BWD_LIST")[0] == '0');
   if (vec && use_list && C <= 256 * 4 * 4 && pooled_h <= 14 && pooled_w <= 14) {
-    // 2 x 2 super-tiles of T x T-pixel tiles, padded to whole rounds of the 8 XCDs
-    static const int tile_edge = (getenv("DADET_ROI_BWD_TILE") && atoi(getenv("DADET_ROI_BWD_TILE")) == 2) ? 2 : 4;
-    const int T = (C <= 1024) ? tile_edge : 2;   // 4 x 4 accumulators per lane only with one channel group
-    const int tiles_x = (W + T - 1) / T, tiles_y = (H + T - 1) / T;
-    const int supers = B * ((tiles_x + 1) / 2) * ((tiles_y + 1) / 2);
+    // 2 x 2 super-tiles of 2 x 2-pixel tiles, padded to whole rounds of the 8 XCDs; grid.y only carries B
+    const int supers = B * (((W + 1) / 2 + 1) / 2) * (((H + 1) / 2 + 1) / 2);
     const dim3 tgrid((unsigned)(((supers + kNumXCD - 1) / kNumXCD) * kNumXCD * 4), 1, 1);
-    if (C <= 1024 && T == 4)
-      hipLaunchKernelGGL((roi_align_bwd_list_kernel<4, 1, 4>), tgrid, dim3(256), 0, st, grad_output, rois, grad_input, B,
-                         C, H, W, R, pooled_h, pooled_w, spatial_scale, sampling_ratio);
-    else if (C <= 1024)
-      hipLaunchKernelGGL((roi_align_bwd_list_kernel<4, 1, 2>), tgrid, dim3(256), 0, st, grad_output, rois, grad_input, B,
-                         C, H, W, R, pooled_h, pooled_w, spatial_scale, sampling_ratio);
+    if (C <= 1024)
+      hipLaunchKernelGGL((roi_align_bwd_list_kernel<4, 1>), tgrid, dim3(256), 0, st, grad_output, rois, grad_input, B, C,
+                         H, W, R, pooled_h, pooled_w, spatial_scale, sampling_ratio);
     else
-      hipLaunchKernelGGL((roi_align_bwd_list_kernel<4, 4, 2>), tgrid, dim3(256), 0, st, grad_output, rois, grad_input, B,
-                         C, H, W, R, pooled_h, pooled_w, spatial_scale, sampling_ratio);
-    return check_launch("roi_align_backward");
+      hipLaunchKernelGGL((roi_align_bwd_list_kernel<4, 4>), tgrid, dim3(256), 0, st, grad_output, rois, grad_input, B, C,
+                         H, W, R, pooled_h, pooled_w, spatial_scale, sampling_ratio);
   } else if (vec) {
     const int threads = (C / 4 >= 256) ? 256 : ((C / 4 + 63) / 64) * 64;
     hipLaunchKernelGGL(roi_align_bwd_gather_kernel<4>, grid, dim3(threads), lds, st, grad_output, rois,
