@@ -215,3 +215,38 @@ def test_prepare_for_coco_detection_records():
     r = recs[0]
     assert r["image_id"] == 17 and r["category_id"] == 26 and abs(r["score"] - 0.9) < 1e-6
     assert r["bbox"] == [20.0, 40.0, 39.0, 39.0]    # scaled x2 -> (20,40,58,78) -> w = 58-20+1, h = 78-40+1
+
+
+def test_weight_gradient_split_plan_respects_the_workgroup_slots():
+    """dadet_conv_wgrad_workspace_bytes is pure host code (the split plan of conv_igemm.hip::wgrad_plan): the number
+    of workgroups (tiles x splits) must not land just above a multiple of the chip's 512 slots — the configuration the
+    sweep in profiles/r01_wgrad_split_sweep.txt showed to cost a whole extra pass — and every split keeps >= 4 K-steps"""
+    import ctypes
+
+    from da_detect_amd import _C, _lib
+
+    def splits(N, H, W, Cin, Cout, k, stride):
+        pad = k // 2
+        Ho, Wo = (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
+        d = _C._desc(N, H, W, Cin, Cout, k, k, stride, pad, Ho, Wo)
+        nbytes = ctypes.c_size_t(0)
+        _lib.call("dadet_conv_wgrad_workspace_bytes", ctypes.byref(d), ctypes.byref(nbytes))
+        per = 4 * Cout * Cin * k * k
+        assert nbytes.value % per == 0
+        return max(1, nbytes.value // per), N * Ho * Wo
+
+    shapes = [(512, 7, 7, 512, 512, 3, 1), (2, 64, 128, 1024, 1024, 3, 1), (512, 7, 7, 512, 2048, 1, 1),
+              (512, 14, 14, 1024, 2048, 1, 2), (2, 64, 128, 256, 256, 3, 1), (2, 128, 256, 128, 128, 3, 1),
+              (2, 64, 128, 256, 1024, 1, 1), (2, 128, 256, 128, 512, 1, 1), (1, 8, 8, 64, 64, 3, 1)]
+    for N, H, W, Cin, Cout, k, stride in shapes:
+        s, M = splits(N, H, W, Cin, Cout, k, stride)
+        tiles = -(-Cout // 128) * -(-(Cin * k * k) // 128)
+        wgs = tiles * s
+        rows = -(-M // s)
+        assert s == 1 or rows >= 128, (N, H, W, Cin, Cout, k, s, rows)
+        over = wgs % 512
+        assert wgs <= 512 or over == 0 or over > 128, ("%d workgroups: a nearly empty extra pass" % wgs, Cin, Cout, k)
+    # the shapes the sweep pinned down
+    assert splits(512, 7, 7, 512, 512, 3, 1)[0] == 7           # 144 tiles -> 1008 workgroups
+    assert splits(512, 7, 7, 512, 2048, 1, 1)[0] == 8          # 64 tiles  -> 512 workgroups
+    assert splits(2, 64, 128, 256, 1024, 1, 1)[0] == 32        # 16 tiles  -> 512 workgroups
