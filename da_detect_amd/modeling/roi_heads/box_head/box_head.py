@@ -13,7 +13,6 @@ from .roi_box_predictors import make_roi_box_predictor
 
 
 _NO_DEDUP = os.environ.get("DADET_NO_ROI_DEDUP", "0") == "1"
-_POOL_ON_SIDE = os.environ.get("DADET_POOL_ON_SIDE", "1") == "1"   # A/B switch, see ROIBoxHead.forward
 
 
 class ROIBoxHead(torch.nn.Module):
@@ -29,7 +28,6 @@ class ROIBoxHead(torch.nn.Module):
         """-> (x, proposals | detections, losses, da_ins_feas, da_ins_labels).  Training runs two passes of
         pooler + res5 + predictor: the sampled detection ROIs, then BATCH_SIZE_PER_IMAGE uniformly sampled
         ROIs per image whose features / domain labels feed the instance-level domain classifier."""
-        pooled = None
         if self.training:
             # sampling runs on the side stream: its host round trips then do not wait for the RPN-head backward
             # queued on the compute stream just before (RPNModule.early_backward)
@@ -41,16 +39,7 @@ class ROIBoxHead(torch.nn.Module):
                 # every host synchronisation of the box head in front of the res5 head instead of behind it
                 da_proposals = self.loss_evaluator.subsample_for_da(proposals, targets)
                 done(proposals, da_proposals, self.loss_evaluator._proposals, self.loss_evaluator._loss_prep)
-                if _POOL_ON_SIDE and features[0].is_cuda and hasattr(self.feature_extractor, "pooler"):
-                    # ROIAlign needs the proposals and the backbone features, nothing of the compute stream's queue:
-                    # issued here, on the sampling stream, it runs under the RPN branch's backward instead of behind
-                    # it (tools/gap_analysis.py: 0.4 ms with no GEMM running in front of the res5 head).  Autograd runs
-                    # its backward on this stream too, with the engine's stream synchronisation.
-                    with torch.enable_grad():
-                        pooled = self.feature_extractor.pooler(features, proposals)
-                    done(pooled)
-        x = self.feature_extractor(features, proposals) if pooled is None else \
-            self.feature_extractor(features, proposals, pooled=pooled)
+        x = self.feature_extractor(features, proposals)
         class_logits, box_regression = self.predictor(x)
         if not self.training:
             return x, self.post_processor((class_logits, box_regression), proposals), {}, x, None

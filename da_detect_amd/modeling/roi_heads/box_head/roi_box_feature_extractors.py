@@ -25,9 +25,8 @@ class ResNet50Conv5ROIFeatureExtractor(nn.Module):
             stride_in_1x1=config.MODEL.RESNETS.STRIDE_IN_1X1, stride_init=None,
             res2_out_channels=config.MODEL.RESNETS.RES2_OUT_CHANNELS, dilation=config.MODEL.RESNETS.RES5_DILATION)
 
-    def forward(self, x, proposals, pooled=None):
-        """pooled: the pooler's output when the caller already ran it (ROIBoxHead issues it on the sampling stream)"""
-        return self.head(self.pooler(x, proposals) if pooled is None else pooled)
+    def forward(self, x, proposals):
+        return self.head(self.pooler(x, proposals))
 
 
 @registry.ROI_BOX_FEATURE_EXTRACTORS.register("FPN2MLPFeatureExtractor")
@@ -50,8 +49,8 @@ class FPN2MLPFeatureExtractor(nn.Module):
         self.fc6 = make_fc(input_size, representation_size, use_gn)
         self.fc7 = make_fc(representation_size, representation_size, use_gn)
 
-    def forward(self, x, proposals, pooled=None):
-        x = self.pooler(x, proposals) if pooled is None else pooled
+    def forward(self, x, proposals):
+        x = self.pooler(x, proposals)
         w6 = self.fc6.weight.view(-1, self.channels, self.resolution, self.resolution)
         x = conv2d_affine_act(x, w6, None, self.fc6.bias, relu=True)
         return self.fc7(x.reshape(x.shape[0], -1), relu=True)
