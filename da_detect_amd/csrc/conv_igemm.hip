@@ -568,7 +568,14 @@ extern "C" int dadet_conv_forward(const dadet_conv_desc* d, const float* x, cons
   a.ksplit = 0;
   a.split_stride = 0;
   if (gemm_mode() != 0) {
-    const int variant = fwd_variant(a.M, a.Cout);
+    int variant = fwd_variant(a.M, a.Cout);
+    {
+      // experiment (DADET_SHORTK_VARIANT=1|2, DADET_SHORTK_MAX=K): smaller tiles for short reductions — those GEMMs are
+      // HBM bound and a workgroup's load / compute / store phases only overlap across the workgroups of a CU
+      static const int v = getenv("DADET_SHORTK_VARIANT") ? atoi(getenv("DADET_SHORTK_VARIANT")) : -1;
+      static const int kmax = getenv("DADET_SHORTK_MAX") ? atoi(getenv("DADET_SHORTK_MAX")) : 256;
+      if (v >= 0 && a.K <= kmax && variant < v) variant = v;
+    }
     const int ksplit = splitk_plan(a, variant);
     if (ksplit && al16(y) && (!addend || al16(addend)) && (!mask_ref || al16(mask_ref)) &&
         (!scale || al16(scale)) && (!bias || al16(bias))) {
