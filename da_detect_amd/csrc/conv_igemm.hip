@@ -570,11 +570,12 @@ extern "C" int dadet_conv_forward(const dadet_conv_desc* d, const float* x, cons
   if (gemm_mode() != 0) {
     int variant = fwd_variant(a.M, a.Cout);
     {
-      // experiment (DADET_SHORTK_VARIANT=1|2, DADET_SHORTK_MAX=K): smaller tiles for short reductions — those GEMMs are
-      // HBM bound and a workgroup's load / compute / store phases only overlap across the workgroups of a CU
-      static const int v = getenv("DADET_SHORTK_VARIANT") ? atoi(getenv("DADET_SHORTK_VARIANT")) : -1;
+      // Short reductions are HBM bound, and a workgroup's load / compute / store phases overlap only across the
+      // workgroups that share a CU: 64x64 tiles (30 KB of LDS, 5 workgroups per CU instead of 2) run the K <= 256 layers
+      // 3 - 38% faster (tools/gemm_table.py: res2 1x1 64->256 0.211 -> 0.153 ms, res3 1x1 128->512 0.156 -> 0.130).
+      // Only whole K-tiles (the K = 76 RPN data gradient got 44% slower) and only where the 128x128 tile was chosen.
       static const int kmax = getenv("DADET_SHORTK_MAX") ? atoi(getenv("DADET_SHORTK_MAX")) : 256;
-      if (v >= 0 && a.K <= kmax && variant < v) variant = v;
+      if (variant == 0 && a.K <= kmax && a.K % BK == 0) variant = 2;
     }
     const int ksplit = splitk_plan(a, variant);
     if (ksplit && al16(y) && (!addend || al16(addend)) && (!mask_ref || al16(mask_ref)) &&
