@@ -576,6 +576,10 @@ extern "C" int dadet_conv_forward(const dadet_conv_desc* d, const float* x, cons
       // Only whole K-tiles (the K = 76 RPN data gradient got 44% slower) and only where the 128x128 tile was chosen.
       static const int kmax = getenv("DADET_SHORTK_MAX") ? atoi(getenv("DADET_SHORTK_MAX")) : 256;
       if (variant == 0 && a.K <= kmax && a.K % BK == 0) variant = 2;
+      if (const char* e = getenv("DADET_FWD_VARIANT")) {   // tools/fwd_sweep.py: force a tile variant (read per call)
+        const int v = atoi(e);
+        if (v >= 0 && v <= 2) variant = v;
+      }
     }
     const int ksplit = splitk_plan(a, variant);
     if (ksplit && al16(y) && (!addend || al16(addend)) && (!mask_ref || al16(mask_ref)) &&
