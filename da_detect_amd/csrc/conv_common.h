@@ -1,7 +1,6 @@
 // Shared declarations of the implicit-GEMM convolution kernels (conv_igemm.hip: exact fp32 MFMA;
 // conv_split.hip: split-bf16 MFMA).
 #pragma once
-#include <cstdlib>
 #include "common.h"
 
 namespace dadet {
@@ -67,10 +66,7 @@ struct WgradArgs {
 //   0: 128x128 (TM=2,TN=2)   1: 128x64 (TM=2,TN=1)   2: 64x64 (TM=1,TN=1)
 inline int fwd_variant(int M, int Cout) {
   const int64_t t128 = (int64_t)ceil_div(M, 128) * ceil_div(Cout, 128);
-  // one 128x128 workgroup per CU already beats two or three 128x64 ones (tools/fwd_sweep.py, res4 3x3 256->256:
-  // 0.115 vs 0.128 ms; res4 1x1 1024->256: 0.061 vs 0.064)
-  static const int min_tiles = getenv("DADET_FWD_MIN_TILES128") ? atoi(getenv("DADET_FWD_MIN_TILES128")) : kNumCU;
-  if (Cout > 64 && t128 >= min_tiles) return 0;
+  if (Cout > 64 && t128 >= 2 * kNumCU) return 0;
   if (Cout > 32) {
     const int64_t t64 = (int64_t)ceil_div(M, 128) * ceil_div(Cout, 64);
     if (t64 >= kNumCU || M <= 64 * 64) return 1;
