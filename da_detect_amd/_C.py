@@ -28,7 +28,7 @@ NMS_TIE_RULE = 0
 
 # optional per-launch timing of the GEMM kernels (bench.py sets this to a KernelProfiler; None = off)
 PROFILER = None
-_KNAME_CACHE = {}   # (M, Cout) -> kernel name of the forward GEMM variant (profiling only)
+_KNAME_CACHE = {}   # (M, Cout, K) -> kernel name of the forward GEMM variant (profiling only)
 
 
 class KernelProfiler(object):
@@ -263,7 +263,7 @@ def conv_forward(x, w, scale=None, bias=None, addend=None, mask_ref=None, stride
         mask_ref = _nhwc(mask_ref)
     d = _desc(N, H, W, Cin, Cout, KH, KW, stride, pad, Ho, Wo, OutH, OutW, out_spatial_stride, relu_mode)
     if PROFILER is not None:
-        key = (N * Ho * Wo, Cout)
+        key = (N * Ho * Wo, Cout, Cin * KH * KW)
         kname = _KNAME_CACHE.get(key)
         if kname is None:
             variant = _lib.load().dadet_conv_forward_variant(ctypes.byref(d))

@@ -464,6 +464,22 @@ static int launch_fwd(ConvArgs& a, hipStream_t st) {
   return check_launch("conv_forward");
 }
 
+// Tile variant of the split-bf16 forward / data-gradient GEMM.  Short reductions are HBM bound, and a workgroup's load /
+// compute / store phases overlap only across the workgroups that share a CU: 64x64 tiles (30 KB of LDS, 5 workgroups per
+// CU instead of 2) run the K <= 256 layers 3 - 38% faster (tools/gemm_table.py: res2 1x1 64->256 0.211 -> 0.153 ms, res3
+// 1x1 128->512 0.156 -> 0.130).  Only whole K-tiles (the K = 76 RPN data gradient got 44% slower) and only where the
+// 128x128 tile would be chosen.  DADET_FWD_VARIANT forces a variant (tools/fwd_sweep.py; read per call).
+static int split_fwd_variant(int M, int Cout, int K) {
+  int variant = fwd_variant(M, Cout);
+  static const int kmax = getenv("DADET_SHORTK_MAX") ? atoi(getenv("DADET_SHORTK_MAX")) : 256;
+  if (variant == 0 && K <= kmax && K % BK == 0) variant = 2;
+  if (const char* e = getenv("DADET_FWD_VARIANT")) {
+    const int v = atoi(e);
+    if (v >= 0 && v <= 2) variant = v;
+  }
+  return variant;
+}
+
 // ---- split-K for GEMMs whose tile grid cannot fill the chip (the M = 512 linear layers of the box / instance heads:
 // 4 x 16 workgroups walking K = 2048 alone took 40 - 70 us each, one after the other in the loss turn-around).
 // The K range is cut over blockIdx.y, partial sums go to a per-stream scratch buffer owned by the library (grown on
@@ -568,19 +584,7 @@ extern "C" int dadet_conv_forward(const dadet_conv_desc* d, const float* x, cons
   a.ksplit = 0;
   a.split_stride = 0;
   if (gemm_mode() != 0) {
-    int variant = fwd_variant(a.M, a.Cout);
-    {
-      // Short reductions are HBM bound, and a workgroup's load / compute / store phases overlap only across the
-      // workgroups that share a CU: 64x64 tiles (30 KB of LDS, 5 workgroups per CU instead of 2) run the K <= 256 layers
-      // 3 - 38% faster (tools/gemm_table.py: res2 1x1 64->256 0.211 -> 0.153 ms, res3 1x1 128->512 0.156 -> 0.130).
-      // Only whole K-tiles (the K = 76 RPN data gradient got 44% slower) and only where the 128x128 tile was chosen.
-      static const int kmax = getenv("DADET_SHORTK_MAX") ? atoi(getenv("DADET_SHORTK_MAX")) : 256;
-      if (variant == 0 && a.K <= kmax && a.K % BK == 0) variant = 2;
-      if (const char* e = getenv("DADET_FWD_VARIANT")) {   // tools/fwd_sweep.py: force a tile variant (read per call)
-        const int v = atoi(e);
-        if (v >= 0 && v <= 2) variant = v;
-      }
-    }
+    const int variant = split_fwd_variant(a.M, a.Cout, a.K);
     const int ksplit = splitk_plan(a, variant);
     if (ksplit && al16(y) && (!addend || al16(addend)) && (!mask_ref || al16(mask_ref)) &&
         (!scale || al16(scale)) && (!bias || al16(bias))) {
@@ -620,7 +624,8 @@ extern "C" int dadet_conv_forward(const dadet_conv_desc* d, const float* x, cons
 
 extern "C" int dadet_conv_forward_variant(const dadet_conv_desc* d) {
   if (!d) return -1;
-  return fwd_variant(d->N * d->Ho * d->Wo, d->Cout);
+  const int M = d->N * d->Ho * d->Wo;
+  return gemm_mode() != 0 ? split_fwd_variant(M, d->Cout, d->KH * d->KW * d->Cin) : fwd_variant(M, d->Cout);
 }
 
 // Split plan of the weight gradient: the (co tile, kc tile) grid is small (4 ... 576 tiles), so the reduction over the
