@@ -11,50 +11,46 @@ import torch
 
 
 class Compose(object):
+    """chain of (image, target) -> (image, target) callables"""
+
     def __init__(self, transforms):
-        self.transforms = transforms
+        self.transforms = list(transforms)
 
     def __call__(self, image, target):
-        for t in self.transforms:
-            image, target = t(image, target)
+        for step in self.transforms:
+            image, target = step(image, target)
         return image, target
 
     def __repr__(self):
-        return self.__class__.__name__ + "(" + "".join("\n    {0}".format(t) for t in self.transforms) + "\n)"
+        return "Compose(%s)" % ", ".join(type(t).__name__ for t in self.transforms)
 
 
 class Resize(object):
+    """shorter side to one of `min_size` (drawn per sample), longer side capped at `max_size`"""
+
     def __init__(self, min_size, max_size):
-        if not isinstance(min_size, (list, tuple)):
-            min_size = (min_size,)
-        self.min_size = min_size
+        self.min_size = tuple(min_size) if isinstance(min_size, (list, tuple)) else (min_size,)
         self.max_size = max_size
 
     def get_size(self, image_size):
-        """(w, h) -> (oh, ow): shorter side to a randomly chosen min_size unless that pushes the longer side past
-        max_size (transforms.py:41-62)"""
+        """(w, h) -> (out_h, out_w), the arithmetic of transforms.py:41-62 (float ratio first, truncation of the
+        longer side, rounding only when the cap applies) written on (short, long) instead of per orientation"""
         w, h = image_size
-        size = random.choice(self.min_size)
-        max_size = self.max_size
-        if max_size is not None:
-            min_original_size = float(min((w, h)))
-            max_original_size = float(max((w, h)))
-            if max_original_size / min_original_size * size > max_size:
-                size = int(round(max_size * min_original_size / max_original_size))
-        if (w <= h and w == size) or (h <= w and h == size):
+        short, long_ = (w, h) if w <= h else (h, w)
+        goal = random.choice(self.min_size)
+        if self.max_size is not None and float(long_) / float(short) * goal > self.max_size:
+            goal = int(round(self.max_size * float(short) / float(long_)))
+        if short == goal:
             return (h, w)
-        if w < h:
-            return (int(size * h / w), size)
-        return (size, int(size * w / h))
+        stretched = int(goal * long_ / short)
+        return (stretched, goal) if w < h else (goal, stretched)
 
     def __call__(self, image, target):
         from PIL import Image
 
-        oh, ow = self.get_size(image.size)
-        image = image.resize((ow, oh), Image.BILINEAR)      # == torchvision F.resize(image, (oh, ow))
-        if target is not None:
-            target = target.resize(image.size)
-        return image, target
+        out_h, out_w = self.get_size(image.size)
+        image = image.resize((out_w, out_h), Image.BILINEAR)   # what torchvision's F.resize does for a PIL image
+        return image, (target.resize(image.size) if target is not None else None)
 
 
 class RandomHorizontalFlip(object):
@@ -62,39 +58,39 @@ class RandomHorizontalFlip(object):
         self.prob = prob
 
     def toss(self):
+        """one draw per sample from the global `random` stream (the device path calls this too, in the same order)"""
         return random.random() < self.prob
 
     def __call__(self, image, target):
+        if not self.toss():
+            return image, target
         from PIL import Image
 
-        if self.toss():
-            image = image.transpose(Image.FLIP_LEFT_RIGHT)
-            if target is not None:
-                target = target.transpose(0)
-        return image, target
+        flipped = image.transpose(Image.FLIP_LEFT_RIGHT)
+        return flipped, (target.transpose(0) if target is not None else None)
 
 
 class ToTensor(object):
+    """uint8 HWC image -> float CHW in [0, 1]"""
+
     def __call__(self, image, target):
-        arr = np.array(image, dtype=np.uint8)       # a writable copy (torch.from_numpy warns on read-only views)
-        if arr.ndim == 2:
-            arr = arr[:, :, None]
-        t = torch.from_numpy(np.ascontiguousarray(arr)).permute(2, 0, 1).to(torch.float32).div(255)
-        return t, target
+        pixels = np.array(image, dtype=np.uint8)    # a writable copy (torch.from_numpy warns on read-only views)
+        pixels = pixels[:, :, None] if pixels.ndim == 2 else pixels
+        chw = torch.from_numpy(np.ascontiguousarray(pixels)).permute(2, 0, 1)
+        return chw.to(torch.float32).div(255), target
 
 
 class Normalize(object):
+    """optionally RGB [0,1] -> BGR [0,255], then (x - mean) / std per channel"""
+
     def __init__(self, mean, std, to_bgr255=True):
-        self.mean = mean
-        self.std = std
-        self.to_bgr255 = to_bgr255
+        self.mean, self.std, self.to_bgr255 = mean, std, to_bgr255
 
     def __call__(self, image, target):
-        if self.to_bgr255:
-            image = image[[2, 1, 0]] * 255
-        mean = torch.as_tensor(self.mean, dtype=image.dtype).view(-1, 1, 1)
-        std = torch.as_tensor(self.std, dtype=image.dtype).view(-1, 1, 1)
-        return (image - mean) / std, target
+        x = image[[2, 1, 0]] * 255 if self.to_bgr255 else image
+        shift = torch.as_tensor(self.mean, dtype=x.dtype).view(-1, 1, 1)
+        scale = torch.as_tensor(self.std, dtype=x.dtype).view(-1, 1, 1)
+        return (x - shift) / scale, target
 
 
 def transform_params(cfg, is_train=True):

@@ -3,36 +3,37 @@ import torch
 from torch import nn
 from torch.autograd import Function
 from torch.autograd.function import once_differentiable
-from torch.nn.modules.utils import _pair
 
 from .. import _C
 from ..utils import streams
 
 
+def _hw(output_size):
+    return (output_size, output_size) if isinstance(output_size, int) else tuple(output_size)
+
+
 class _ROIAlign(Function):
+    """bilinear ROI pooling; forward bit-exact with the reference's CPU operator, backward a deterministic gather"""
+
     @staticmethod
-    def forward(ctx, input, roi, output_size, spatial_scale, sampling_ratio):
-        ctx.save_for_backward(roi)
-        ctx.output_size = _pair(output_size)
-        ctx.spatial_scale = spatial_scale
-        ctx.sampling_ratio = sampling_ratio
-        ctx.input_shape = input.size()
-        return _C.roi_align_forward(input, roi, spatial_scale, ctx.output_size[0], ctx.output_size[1],
-                                    sampling_ratio)
+    def forward(ctx, features, rois, output_size, spatial_scale, sampling_ratio):
+        ph, pw = _hw(output_size)
+        ctx.geometry = (spatial_scale, ph, pw, sampling_ratio) + tuple(features.shape)
+        ctx.save_for_backward(rois)
+        return _C.roi_align_forward(features, rois, spatial_scale, ph, pw, sampling_ratio)
 
     @staticmethod
     @once_differentiable
-    def backward(ctx, grad_output):
+    def backward(ctx, grad_pooled):
         (rois,) = ctx.saved_tensors
-        bs, ch, h, w = ctx.input_shape
+        scale, ph, pw, ratio, n, c, h, w = ctx.geometry
         # weight gradients queued by the preceding node (ROI head's first block) run on the lane beside this gather
         after = None
-        if grad_output.is_cuda and streams.deferred_pending():
-            after = torch.cuda.current_stream(grad_output.device).record_event()
-        grad_input = _C.roi_align_backward(grad_output, rois, ctx.spatial_scale, ctx.output_size[0],
-                                           ctx.output_size[1], bs, ch, h, w, ctx.sampling_ratio)
-        streams.flush_deferred_wgrads(grad_output.device, after)
-        return grad_input, None, None, None, None
+        if grad_pooled.is_cuda and streams.deferred_pending():
+            after = torch.cuda.current_stream(grad_pooled.device).record_event()
+        grad_features = _C.roi_align_backward(grad_pooled, rois, scale, ph, pw, n, c, h, w, ratio)
+        streams.flush_deferred_wgrads(grad_pooled.device, after)
+        return grad_features, None, None, None, None
 
 
 roi_align = _ROIAlign.apply
@@ -41,13 +42,11 @@ roi_align = _ROIAlign.apply
 class ROIAlign(nn.Module):
     def __init__(self, output_size, spatial_scale, sampling_ratio):
         super(ROIAlign, self).__init__()
-        self.output_size = output_size
-        self.spatial_scale = spatial_scale
-        self.sampling_ratio = sampling_ratio
+        self.output_size, self.spatial_scale, self.sampling_ratio = output_size, spatial_scale, sampling_ratio
 
     def forward(self, input, rois):
         return roi_align(input, rois, self.output_size, self.spatial_scale, self.sampling_ratio)
 
-    def __repr__(self):
-        return "{}(output_size={}, spatial_scale={}, sampling_ratio={})".format(
-            self.__class__.__name__, self.output_size, self.spatial_scale, self.sampling_ratio)
+    def extra_repr(self):
+        return "output_size=%s, spatial_scale=%s, sampling_ratio=%s" % (self.output_size, self.spatial_scale,
+                                                                        self.sampling_ratio)
