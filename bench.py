@@ -22,6 +22,11 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
+# ROCm runtime knob, read when the HIP runtime initialises: kernel arguments are written straight to device memory
+# instead of being staged through host-coherent memory — lower launch latency for the ~480 launches of a step
+# (measured on one box, 4 alternating runs each: 63.8 vs 62.8 images/s)
+os.environ.setdefault("HIP_FORCE_DEV_KERNARG", "1")
+
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
