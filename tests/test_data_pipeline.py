@@ -229,3 +229,38 @@ def test_training_entry_point_on_a_tiny_dataset(tmp_path):
     assert os.path.exists(os.path.join(out, "model_final.pth")) and os.path.exists(os.path.join(out, "model_0000002.pth"))
     ck = torch.load(os.path.join(out, "model_final.pth"), map_location="cpu", weights_only=False)
     assert set(ck) >= {"model", "optimizer", "scheduler", "iteration"}
+
+
+@pytest.mark.gpu
+def test_evaluation_entry_point_on_a_tiny_dataset(tmp_path):
+    """tools/train_net_da.py -> checkpoint -> tools/test_net_da.py: json dataset -> host transforms -> eval forward ->
+    COCO-style detection records (reference flow: tools/test_net.py + engine/inference.py:76-129)"""
+    import subprocess
+    import sys
+
+    rng = np.random.default_rng(1)
+    specs = {k: _write_coco(str(tmp_path), k, 3, rng, sizes=[(96, 192)] * 3) for k in ("source", "target")}
+    out = str(tmp_path / "out")
+    os.makedirs(out)
+    root = os.path.dirname(HERE)
+    yaml = os.path.join(root, "configs/da_faster_rcnn/e2e_da_faster_rcnn_R_50_C4_cityscapes_to_foggy_cityscapes.yaml")
+    small = ["DATALOADER.NUM_WORKERS", "0", "INPUT.MIN_SIZE_TRAIN", "(96,)", "INPUT.MAX_SIZE_TRAIN", "192",
+             "INPUT.MIN_SIZE_TEST", "96", "INPUT.MAX_SIZE_TEST", "192", "MODEL.WEIGHT", ""]
+    train = [sys.executable, os.path.join(root, "tools", "train_net_da.py"), "--config-file", yaml,
+             "--source", ",".join(specs["source"]), "--target", ",".join(specs["target"]),
+             "SOLVER.MAX_ITER", "2", "SOLVER.CHECKPOINT_PERIOD", "0", "MODEL.OUTPUT_DIR", out] + small
+    res = subprocess.run(train, capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0, res.stderr[-2000:]
+    ckpt = os.path.join(out, "model_final.pth")
+    test = [sys.executable, os.path.join(root, "tools", "test_net_da.py"), "--config-file", yaml,
+            "--dataset", ",".join(specs["target"]), "--ckpt", ckpt, "--output-dir", out,
+            "TEST.IMS_PER_BATCH", "1", "MODEL.ROI_HEADS.SCORE_THRESH", "0.0"] + small
+    res = subprocess.run(test, capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0, res.stderr[-2000:]
+    folder = os.path.join(out, "inference", "target")
+    records = json.load(open(os.path.join(folder, "bbox.json")))
+    assert os.path.exists(os.path.join(folder, "predictions.pth")) and len(records) > 0
+    ids = {r["image_id"] for r in records}
+    assert ids <= {100, 101, 102} and all(r["category_id"] in (24, 26) for r in records)
+    assert all(len(r["bbox"]) == 4 and r["bbox"][2] >= 0 and r["bbox"][3] >= 0 and 0.0 <= r["score"] <= 1.0
+               for r in records)
