@@ -82,7 +82,7 @@ def do_da_train(model, source_data_loader, target_data_loader, optimizer, schedu
                 logger.info("iter %d  loss %.4f  %s  lr %.6f  %.3f s/it", iteration, total,
                             "  ".join("%s %.4f" % (k, float(v)) for k, v in reduced.items()),
                             optimizer.param_groups[0]["lr"], (time.time() - t0) / max(iteration - start_iter + 1, 1))
-        if checkpointer is not None and iteration % checkpoint_period == 0 and iteration > 0:
+        if checkpointer is not None and checkpoint_period > 0 and iteration % checkpoint_period == 0 and iteration > 0:
             checkpointer.save("model_{:07d}".format(iteration), **arguments)
     if checkpointer is not None:
         checkpointer.save("model_final", **arguments)
