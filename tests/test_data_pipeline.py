@@ -245,7 +245,8 @@ def test_evaluation_entry_point_on_a_tiny_dataset(tmp_path):
     root = os.path.dirname(HERE)
     yaml = os.path.join(root, "configs/da_faster_rcnn/e2e_da_faster_rcnn_R_50_C4_cityscapes_to_foggy_cityscapes.yaml")
     small = ["DATALOADER.NUM_WORKERS", "0", "INPUT.MIN_SIZE_TRAIN", "(96,)", "INPUT.MAX_SIZE_TRAIN", "192",
-             "INPUT.MIN_SIZE_TEST", "96", "INPUT.MAX_SIZE_TEST", "192", "MODEL.WEIGHT", ""]
+             "INPUT.MIN_SIZE_TEST", "96", "INPUT.MAX_SIZE_TEST", "192", "MODEL.WEIGHT", "",
+             "MODEL.ROI_BOX_HEAD.NUM_CLASSES", "3"]          # background + the dataset's two categories
     train = [sys.executable, os.path.join(root, "tools", "train_net_da.py"), "--config-file", yaml,
              "--source", ",".join(specs["source"]), "--target", ",".join(specs["target"]),
              "SOLVER.MAX_ITER", "2", "SOLVER.CHECKPOINT_PERIOD", "0", "MODEL.OUTPUT_DIR", out] + small
