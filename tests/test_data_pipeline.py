@@ -265,3 +265,28 @@ def test_evaluation_entry_point_on_a_tiny_dataset(tmp_path):
     assert ids <= {100, 101, 102} and all(r["category_id"] in (24, 26) for r in records)
     assert all(len(r["bbox"]) == 4 and r["bbox"][2] >= 0 and r["bbox"][3] >= 0 and 0.0 <= r["score"] <= 1.0
                for r in records)
+
+
+@pytest.mark.gpu
+def test_triplet_training_entry_point_on_a_tiny_dataset(tmp_path):
+    """the triplet recipe (source + foggy target + rainy auxiliary loaders, reference flow tools/train_net_triplet.py:
+    118-197) through tools/train_net_da.py on generated datasets"""
+    import subprocess
+    import sys
+
+    rng = np.random.default_rng(2)
+    specs = {k: _write_coco(str(tmp_path), k, 4, rng, sizes=[(96, 192)] * 4) for k in ("source", "target", "auxiliary")}
+    out = str(tmp_path / "out")
+    os.makedirs(out)
+    root = os.path.dirname(HERE)
+    yaml = os.path.join(root, "configs/da_faster_rcnn/"
+                              "e2e_triplet_da_faster_rcnn_R_50_C4_cityscapes_to_foggy_cityscapes.yaml")
+    cmd = [sys.executable, os.path.join(root, "tools", "train_net_da.py"), "--config-file", yaml,
+           "--source", ",".join(specs["source"]), "--target", ",".join(specs["target"]),
+           "--auxiliary", ",".join(specs["auxiliary"]),
+           "SOLVER.MAX_ITER", "3", "SOLVER.CHECKPOINT_PERIOD", "0", "DATALOADER.NUM_WORKERS", "0",
+           "INPUT.MIN_SIZE_TRAIN", "(96,)", "INPUT.MAX_SIZE_TRAIN", "192", "MODEL.OUTPUT_DIR", out, "MODEL.WEIGHT", ""]
+    res = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0, res.stderr[-2500:]
+    assert "iter 0" in res.stderr and "triplet_loss_image" in res.stderr
+    assert os.path.exists(os.path.join(out, "model_final.pth"))
