@@ -290,3 +290,36 @@ def test_triplet_training_entry_point_on_a_tiny_dataset(tmp_path):
     assert res.returncode == 0, res.stderr[-2500:]
     assert "iter 0" in res.stderr and "triplet_loss_image" in res.stderr
     assert os.path.exists(os.path.join(out, "model_final.pth"))
+
+
+@pytest.mark.gpu
+def test_training_resumes_from_a_checkpoint_given_as_weight(tmp_path):
+    """a checkpoint passed as MODEL.WEIGHT restores the model and its `iteration` (tools/train_net_triplet.py:97-101:
+    `arguments.update(checkpointer.load(cfg.MODEL.WEIGHT))`), so the loaders and the schedule continue from there"""
+    import subprocess
+    import sys
+
+    rng = np.random.default_rng(3)
+    specs = {k: _write_coco(str(tmp_path), k, 4, rng, sizes=[(96, 192)] * 4) for k in ("source", "target")}
+    root = os.path.dirname(HERE)
+    yaml = os.path.join(root, "configs/da_faster_rcnn/e2e_da_faster_rcnn_R_50_C4_cityscapes_to_foggy_cityscapes.yaml")
+
+    def run(out, weight, max_iter):
+        os.makedirs(out, exist_ok=True)
+        cmd = [sys.executable, os.path.join(root, "tools", "train_net_da.py"), "--config-file", yaml,
+               "--source", ",".join(specs["source"]), "--target", ",".join(specs["target"]),
+               "SOLVER.MAX_ITER", str(max_iter), "SOLVER.CHECKPOINT_PERIOD", "2", "DATALOADER.NUM_WORKERS", "0",
+               "INPUT.MIN_SIZE_TRAIN", "(96,)", "INPUT.MAX_SIZE_TRAIN", "192", "MODEL.OUTPUT_DIR", out,
+               "MODEL.WEIGHT", weight]
+        res = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+        assert res.returncode == 0, res.stderr[-2500:]
+        return res.stderr
+
+    first = str(tmp_path / "first")
+    run(first, "", 3)
+    ck = os.path.join(first, "model_0000002.pth")
+    assert torch.load(ck, map_location="cpu", weights_only=False)["iteration"] == 2
+    log = run(str(tmp_path / "second"), ck, 5)
+    assert "iter 0 " not in log and "iter 2 " in log and "iter 4 " in log
+    final = torch.load(os.path.join(str(tmp_path / "second"), "model_final.pth"), map_location="cpu", weights_only=False)
+    assert final["iteration"] == 4
