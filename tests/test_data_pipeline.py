@@ -320,6 +320,8 @@ def test_training_resumes_from_a_checkpoint_given_as_weight(tmp_path):
     ck = os.path.join(first, "model_0000002.pth")
     assert torch.load(ck, map_location="cpu", weights_only=False)["iteration"] == 2
     log = run(str(tmp_path / "second"), ck, 5)
-    assert "iter 0 " not in log and "iter 2 " in log and "iter 4 " in log
+    assert "Loading checkpoint from " + ck in log
+    assert "iter 0  loss" not in log and "iter 4  loss" in log      # iterations 2, 3, 4 ran; the last one is logged
+    assert os.path.exists(os.path.join(str(tmp_path / "second"), "model_0000004.pth"))
     final = torch.load(os.path.join(str(tmp_path / "second"), "model_final.pth"), map_location="cpu", weights_only=False)
     assert final["iteration"] == 4
