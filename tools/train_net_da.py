@@ -93,6 +93,13 @@ def main():
     if args.synthetic:
         from da_detect_amd.data.synthetic import make_batch
 
+        if not (weight and os.path.exists(weight)):
+            # no pretrained weights: the variance-preserving seeded init of bench.py — a ResNet with identity FrozenBN
+            # statistics and the modules' own initialisers blows up within a few steps (R-101-FPN + DCN: NaN at step 2)
+            import bench
+
+            with torch.no_grad():
+                bench.benchmark_init(model, 100)
         model.train()
         enable_overlapped_rpn_backward(model)
         n_img = 3 if cfg.MODEL.DA_HEADS.TRIPLET_USE else 2
