@@ -239,7 +239,8 @@ def test_evaluation_entry_point_on_a_tiny_dataset(tmp_path):
     import sys
 
     rng = np.random.default_rng(1)
-    specs = {k: _write_coco(str(tmp_path), k, 3, rng, sizes=[(96, 192)] * 3) for k in ("source", "target")}
+    sizes = [(96, 192), (80, 160), (96, 128)]          # ragged test images: batches of 2 are zero-padded to a common size
+    specs = {k: _write_coco(str(tmp_path), k, 3, rng, sizes=sizes) for k in ("source", "target")}
     out = str(tmp_path / "out")
     os.makedirs(out)
     root = os.path.dirname(HERE)
@@ -255,7 +256,7 @@ def test_evaluation_entry_point_on_a_tiny_dataset(tmp_path):
     ckpt = os.path.join(out, "model_final.pth")
     test = [sys.executable, os.path.join(root, "tools", "test_net_da.py"), "--config-file", yaml,
             "--dataset", ",".join(specs["target"]), "--ckpt", ckpt, "--output-dir", out,
-            "TEST.IMS_PER_BATCH", "1", "MODEL.ROI_HEADS.SCORE_THRESH", "0.0"] + small
+            "TEST.IMS_PER_BATCH", "2", "MODEL.ROI_HEADS.SCORE_THRESH", "0.0"] + small
     res = subprocess.run(test, capture_output=True, text=True, timeout=600)
     assert res.returncode == 0, res.stderr[-2000:]
     folder = os.path.join(out, "inference", "target")
@@ -265,6 +266,10 @@ def test_evaluation_entry_point_on_a_tiny_dataset(tmp_path):
     assert ids <= {100, 101, 102} and all(r["category_id"] in (24, 26) for r in records)
     assert all(len(r["bbox"]) == 4 and r["bbox"][2] >= 0 and r["bbox"][3] >= 0 and 0.0 <= r["score"] <= 1.0
                for r in records)
+    for r in records:                                    # xywh in the ORIGINAL image's pixels, clipped to it
+        H, W = sizes[r["image_id"] - 100]
+        x, y, w, h = r["bbox"]
+        assert x >= -1e-3 and y >= -1e-3 and x + w <= W + 1e-3 and y + h <= H + 1e-3, (r, H, W)
 
 
 @pytest.mark.gpu
