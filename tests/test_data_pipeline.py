@@ -214,7 +214,9 @@ def test_training_entry_point_on_a_tiny_dataset(tmp_path):
     import sys
 
     rng = np.random.default_rng(0)
-    specs = {k: _write_coco(str(tmp_path), k, 4, rng, sizes=[(96, 192)] * 4) for k in ("source", "target")}
+    # ragged sizes: source and target images of a step are zero-padded to a common (divisible-by-32) size
+    specs = {"source": _write_coco(str(tmp_path), "source", 4, rng, sizes=[(96, 192), (96, 160), (80, 192), (96, 192)]),
+             "target": _write_coco(str(tmp_path), "target", 4, rng, sizes=[(90, 180), (96, 192), (96, 140), (64, 192)])}
     out = str(tmp_path / "out")
     os.makedirs(out)
     root = os.path.dirname(HERE)
