@@ -74,7 +74,12 @@ def side_section(device, after=None):
 # weight gradients beside data gradients
 import os  # noqa: E402
 
-WGRAD_OVERLAP = os.environ.get("DADET_WGRAD_STREAM", "1") == "1"
+# Two GEMM streams were worth 2 ms of a 37 ms step when they were introduced (partial last waves and launch gaps of one
+# GEMM filled with the other's workgroups).  With the weight-gradient split plan, the direct accumulation and the tile
+# rules of the later work the same switch costs 2 - 9% (img_only 64.0 vs 65.8, da 60.9 vs 63.1, R-101-FPN+DCN 19.3 vs
+# 21.0 images/s on one box): two 1000-workgroup GEMMs sharing the CUs run slower than one after the other.  Off by
+# default since then; DADET_WGRAD_STREAM=1 restores the lane.
+WGRAD_OVERLAP = os.environ.get("DADET_WGRAD_STREAM", "0") == "1"
 
 
 class WgradLane(object):
