@@ -272,9 +272,12 @@ def main():
                 kernels = everything.summary()      # table of all GEMM kernels (extra pass, `extra` steps)
                 dominant = max(kernels, key=lambda k: kernels[k]["total_ms"])
                 roofline["gemm_streams"] = {
-                    "note": "forward/data-gradient and weight-gradient GEMMs run on two streams; `achieved` is per "
-                            "launch WHILE the other stream's kernel shares the GPU; this block comes from extra "
-                            "untimed passes with every GEMM bracketed",
+                    "note": ("forward/data-gradient and weight-gradient GEMMs run on two streams "
+                             "(DADET_WGRAD_STREAM=1); `achieved` is per launch WHILE the other stream's kernel shares "
+                             "the GPU; " if streams.WGRAD_OVERLAP else
+                             "one GEMM stream (default): a bracketed launch has the GPU to itself except for the "
+                             "latency-bound side-stream kernels; ") +
+                            "this block comes from extra untimed passes with every GEMM bracketed",
                     "dominant_kernel_all_bracketed": dominant,
                     "all_gemm_tflops_while_any_runs": round(work / (busy_ms * 1e-3) / 1e12, 2),
                     "all_gemm_frac": round(work / (busy_ms * 1e-3) / 1e12 / peak, 4),
