@@ -1,6 +1,7 @@
 // Shared declarations of the implicit-GEMM convolution kernels (conv_igemm.hip: exact fp32 MFMA;
 // conv_split.hip: split-bf16 MFMA).
 #pragma once
+#include <cstdlib>
 #include "common.h"
 
 namespace dadet {
@@ -66,7 +67,8 @@ struct WgradArgs {
 //   0: 128x128 (TM=2,TN=2)   1: 128x64 (TM=2,TN=1)   2: 64x64 (TM=1,TN=1)
 inline int fwd_variant(int M, int Cout) {
   const int64_t t128 = (int64_t)ceil_div(M, 128) * ceil_div(Cout, 128);
-  if (Cout > 64 && t128 >= 2 * kNumCU) return 0;
+  static const int min_tiles = getenv("DADET_FWD_MIN_TILES128") ? atoi(getenv("DADET_FWD_MIN_TILES128")) : 2 * kNumCU;
+  if (Cout > 64 && t128 >= min_tiles) return 0;
   if (Cout > 32) {
     const int64_t t64 = (int64_t)ceil_div(M, 128) * ceil_div(Cout, 64);
     if (t64 >= kNumCU || M <= 64 * 64) return 1;
