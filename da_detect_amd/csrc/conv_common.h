@@ -67,7 +67,9 @@ struct WgradArgs {
 //   0: 128x128 (TM=2,TN=2)   1: 128x64 (TM=2,TN=1)   2: 64x64 (TM=1,TN=1)
 inline int fwd_variant(int M, int Cout) {
   const int64_t t128 = (int64_t)ceil_div(M, 128) * ceil_div(Cout, 128);
-  static const int min_tiles = getenv("DADET_FWD_MIN_TILES128") ? atoi(getenv("DADET_FWD_MIN_TILES128")) : 2 * kNumCU;
+  // 128x128 tiles from one workgroup per CU on: tools/fwd_sweep.py, res4 3x3 256->256 0.115 ms against 0.128 ms with
+  // 128x64 tiles, res4 1x1 1024->256 0.061 against 0.064 (with two GEMM streams the step did not notice; with one: +0.3%)
+  static const int min_tiles = getenv("DADET_FWD_MIN_TILES128") ? atoi(getenv("DADET_FWD_MIN_TILES128")) : kNumCU;
   if (Cout > 64 && t128 >= min_tiles) return 0;
   if (Cout > 32) {
     const int64_t t64 = (int64_t)ceil_div(M, 128) * ceil_div(Cout, 64);
