@@ -296,11 +296,8 @@ def conv_weight_transpose(w, scale=None):
     return wt
 
 
-def conv_wgrad(x, gy, weight_shape, stride=1, pad=0, out_scale=None, dw=None, accumulate=False, reduce_stream=None):
-    """dw[co,ci,r,s] = out_scale[co] * sum_m gy[m,co] * x[gather(m,r,s),ci]  (channels_last weight layout).
-    reduce_stream (torch.cuda.Stream): the reduction pass over the split partial results goes there (dw is then
-    complete only once that stream has drained — for gradients accumulated in place that nobody reads before the
-    optimizer, see utils.streams)."""
+def conv_wgrad(x, gy, weight_shape, stride=1, pad=0, out_scale=None, dw=None, accumulate=False):
+    """dw[co,ci,r,s] = out_scale[co] * sum_m gy[m,co] * x[gather(m,r,s),ci]  (channels_last weight layout)."""
     _dev(x, "x"), _dev(gy, "gy")
     N, Cin, H, W = x.shape
     Cout, Cin_w, KH, KW = weight_shape
@@ -323,23 +320,12 @@ def conv_wgrad(x, gy, weight_shape, stride=1, pad=0, out_scale=None, dw=None, ac
         with PROFILER.span(kname,
                            2.0 * N * Ho * Wo * Cout * Cin * KH * KW,
                            4.0 * (x.numel() + gy.numel() + dw.numel())):
-            _wgrad_call(d, x, gy, out_scale, dw, accumulate, ws, reduce_stream)
+            _lib.call("dadet_conv_wgrad", ctypes.byref(d), _p(x), _p(gy), _p(out_scale), _p(dw),
+                      1 if accumulate else 0, _p(ws), ctypes.c_size_t(ws.numel()), _stream())
         return dw
-    _wgrad_call(d, x, gy, out_scale, dw, accumulate, ws, reduce_stream)
+    _lib.call("dadet_conv_wgrad", ctypes.byref(d), _p(x), _p(gy), _p(out_scale), _p(dw),
+              1 if accumulate else 0, _p(ws), ctypes.c_size_t(ws.numel()), _stream())
     return dw
-
-
-def _wgrad_call(d, x, gy, out_scale, dw, accumulate, ws, reduce_stream):
-    if reduce_stream is None:
-        _lib.call("dadet_conv_wgrad", ctypes.byref(d), _p(x), _p(gy), _p(out_scale), _p(dw),
-                  1 if accumulate else 0, _p(ws), ctypes.c_size_t(ws.numel()), _stream())
-        return
-    _lib.call("dadet_conv_wgrad_on", ctypes.byref(d), _p(x), _p(gy), _p(out_scale), _p(dw),
-              1 if accumulate else 0, _p(ws), ctypes.c_size_t(ws.numel()), _stream(),
-              ctypes.c_void_p(reduce_stream.cuda_stream))
-    for t in (ws, dw, out_scale):         # read / written on the reduction stream
-        if t is not None:
-            t.record_stream(reduce_stream)
 
 
 def relu_bn_backward(g, y=None, scale=None, want_unscaled=False):

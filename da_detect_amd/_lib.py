@@ -46,7 +46,6 @@ _SIGNATURES = {
     "dadet_get_gemm_mode": [],
     "dadet_conv_wgrad_workspace_bytes": [POINTER(ConvDesc), POINTER(c_size_t)],
     "dadet_conv_wgrad": [POINTER(ConvDesc), _P, _P, _P, _P, c_int, _P, c_size_t, _P],
-    "dadet_conv_wgrad_on": [POINTER(ConvDesc), _P, _P, _P, _P, c_int, _P, c_size_t, _P, _P],
     "dadet_conv_weight_transpose": [_P, _P, _P, c_int, c_int, c_int, c_int, _P],
     "dadet_deform_sample_forward": [_P, _P, _P, _P] + [c_int] * 12 + [_P],
     "dadet_deform_sample_backward": [_P, _P, _P, _P, _P, _P, _P] + [c_int] * 12 + [_P],

@@ -682,29 +682,6 @@ extern "C" int dadet_conv_wgrad_workspace_bytes(const dadet_conv_desc* d, size_t
 extern "C" int dadet_conv_wgrad(const dadet_conv_desc* d, const float* x, const float* gy,
                                 const float* out_scale, float* dw, int accumulate, void* workspace,
                                 size_t workspace_bytes, void* stream) {
-  return dadet_conv_wgrad_on(d, x, gy, out_scale, dw, accumulate, workspace, workspace_bytes, stream, stream);
-}
-
-// `reduce_stream` waits for `stream` through an event; a wait captures the event's last record, so one event object can
-// be re-recorded for every call
-static int order_after(hipStream_t later, hipStream_t earlier) {
-  static std::mutex m;
-  static hipEvent_t ev = nullptr;
-  std::lock_guard<std::mutex> lock(m);
-  if (!ev && hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) {
-    set_error("conv_wgrad: hipEventCreateWithFlags failed");
-    return DADET_ELAUNCH;
-  }
-  if (hipEventRecord(ev, earlier) != hipSuccess || hipStreamWaitEvent(later, ev, 0) != hipSuccess) {
-    set_error("conv_wgrad: could not order the reduction stream after the GEMM stream");
-    return DADET_ELAUNCH;
-  }
-  return DADET_OK;
-}
-
-extern "C" int dadet_conv_wgrad_on(const dadet_conv_desc* d, const float* x, const float* gy,
-                                   const float* out_scale, float* dw, int accumulate, void* workspace,
-                                   size_t workspace_bytes, void* stream, void* reduce_stream) {
   int rc = conv_desc_check(d, "conv_wgrad");
   if (rc) return rc;
   DADET_REQUIRE(dw, "conv_wgrad: null dw");
@@ -761,12 +738,7 @@ extern "C" int dadet_conv_wgrad_on(const dadet_conv_desc* d, const float* x, con
     const int64_t total4 = (int64_t)d->Cout * K / 4;
     int64_t blocks = ceil_div64(total4, 256);
     if (blocks > kMaxStreamBlocks) blocks = kMaxStreamBlocks;
-    hipStream_t rs = as_stream(reduce_stream);
-    if (rs != st) {
-      rc = order_after(rs, st);
-      if (rc) return rc;
-    }
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((int)blocks), dim3(256), 0, rs,
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((int)blocks), dim3(256), 0, st,
                        reinterpret_cast<const float4*>(workspace), out_scale, reinterpret_cast<float4*>(dw),
                        total4, K / 4, a.splits, accumulate);
     rc = check_launch("conv_wgrad(reduce)");

@@ -45,8 +45,8 @@ class _ConvAffineAct(Function):
         gx = gw = gb = None
         lane = WgradLane(gy.device)
         if need_w:      # beside the data gradient, on the weight-gradient stream
-            gw = lane.run_into(weight, lambda acc, rs: _C.conv_wgrad(x, g, tuple(weight.shape), ctx.stride, ctx.pad,
-                                                                 dw=acc, accumulate=True, reduce_stream=rs),
+            gw = lane.run_into(weight, lambda acc: _C.conv_wgrad(x, g, tuple(weight.shape), ctx.stride, ctx.pad,
+                                                                 dw=acc, accumulate=True),
                                lambda: _C.conv_wgrad(x, g, tuple(weight.shape), ctx.stride, ctx.pad), x, g)
         if need_x:
             wt = _C.conv_weight_transpose(weight)

@@ -72,23 +72,23 @@ class _BottleneckFn(torch.autograd.Function):
         dw1 = dw2 = dw3 = dwd = dx = None
         lane = WgradLane(G.device, defer=ctx.defer_wgrad)
         if n3:
-            dw3 = lane.run_into(w3, lambda acc, rs: _C.conv_wgrad(y2, S3, tuple(w3.shape), 1, 0, out_scale=s3, dw=acc,
-                                                              accumulate=True, reduce_stream=rs),
+            dw3 = lane.run_into(w3, lambda acc: _C.conv_wgrad(y2, S3, tuple(w3.shape), 1, 0, out_scale=s3, dw=acc,
+                                                              accumulate=True),
                                 lambda: _C.conv_wgrad(y2, S3, tuple(w3.shape), 1, 0, out_scale=s3), y2, S3)
         S2 = _C.conv_forward(S3, _C.conv_weight_transpose(w3, s3), relu_mode=2, mask_ref=y2)
         if n2:
-            dw2 = lane.run_into(w2, lambda acc, rs: _C.conv_wgrad(y1, S2, tuple(w2.shape), 1, 1, out_scale=s2, dw=acc,
-                                                              accumulate=True, reduce_stream=rs),
+            dw2 = lane.run_into(w2, lambda acc: _C.conv_wgrad(y1, S2, tuple(w2.shape), 1, 1, out_scale=s2, dw=acc,
+                                                              accumulate=True),
                                 lambda: _C.conv_wgrad(y1, S2, tuple(w2.shape), 1, 1, out_scale=s2), y1, S2)
         if n1 or need_x:
             S1 = _C.conv_forward(S2, _C.conv_weight_transpose(w2, s2), pad=1, relu_mode=2, mask_ref=y1)
         if n1:
-            dw1 = lane.run_into(w1, lambda acc, rs: _C.conv_wgrad(x, S1, tuple(w1.shape), stride, 0, out_scale=s1,
-                                                              dw=acc, accumulate=True, reduce_stream=rs),
+            dw1 = lane.run_into(w1, lambda acc: _C.conv_wgrad(x, S1, tuple(w1.shape), stride, 0, out_scale=s1,
+                                                              dw=acc, accumulate=True),
                                 lambda: _C.conv_wgrad(x, S1, tuple(w1.shape), stride, 0, out_scale=s1), x, S1)
         if nd and wd is not None:
-            dwd = lane.run_into(wd, lambda acc, rs: _C.conv_wgrad(x, S3, tuple(wd.shape), stride, 0, out_scale=sd,
-                                                              dw=acc, accumulate=True, reduce_stream=rs),
+            dwd = lane.run_into(wd, lambda acc: _C.conv_wgrad(x, S3, tuple(wd.shape), stride, 0, out_scale=sd,
+                                                              dw=acc, accumulate=True),
                                 lambda: _C.conv_wgrad(x, S3, tuple(wd.shape), stride, 0, out_scale=sd), x, S3)
         if need_x:
             gate = dict(relu_mode=2, mask_ref=x) if ctx.in_relu else {}

@@ -119,13 +119,11 @@ class WgradLane(object):
             _DEFERRED.append((direct_fn, tgt, inputs))
             return None
         if not self.on:
-            # one GEMM stream: the GEMM runs here, only its reduction pass over the split partial results (HBM bound,
-            # nobody but the optimizer waits for it) goes to the lane and overlaps the next GEMM
-            direct_fn(tgt, reduce_stream(tgt.device))
+            direct_fn(tgt)
             return None
         self.lane.wait_event(self.main.record_event())
         with torch.cuda.stream(self.lane):
-            direct_fn(tgt, None)
+            direct_fn(tgt)
         for t in inputs:
             t.record_stream(self.lane)
         return None
@@ -182,31 +180,21 @@ def flush_deferred_wgrads(device, after=None):
         lane.wait_event(after if after is not None else main.record_event())
         with torch.cuda.stream(lane):
             for fn, tgt, _ in items:
-                fn(tgt, None)
+                fn(tgt)
         for _, _, inputs in items:
             for t in inputs:
                 t.record_stream(lane)
     else:
         for fn, tgt, _ in items:
-            fn(tgt, None)
+            fn(tgt)
 
 
 def deferred_pending():
     return bool(_DEFERRED)
 
 
-_REDUCE_ON_LANE = os.environ.get("DADET_REDUCE_LANE", "1") == "1"
-
-
-def reduce_stream(device):
-    """stream for the reduction passes of directly accumulated weight gradients (None: the caller's stream)"""
-    if device.type == "cuda" and _REDUCE_ON_LANE and DIRECT_WGRAD:
-        return side_stream(device, 2)
-    return None
-
-
 def join_wgrad_lane(device):
     """the current stream waits for every weight gradient queued on the lane (call before reading .grad)"""
     flush_deferred_wgrads(device)
-    if device.type == "cuda" and (WGRAD_OVERLAP or _REDUCE_ON_LANE):
+    if device.type == "cuda" and WGRAD_OVERLAP:
         torch.cuda.current_stream(device).wait_stream(side_stream(device, 2))

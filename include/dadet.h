@@ -143,13 +143,6 @@ int dadet_conv_forward_variant(const dadet_conv_desc* d);
 int dadet_conv_wgrad_workspace_bytes(const dadet_conv_desc* d, size_t* bytes_out);
 int dadet_conv_wgrad(const dadet_conv_desc* d, const float* x, const float* gy, const float* out_scale,
                      float* dw, int accumulate, void* workspace, size_t workspace_bytes, void* stream);
-/* the same with the reduction pass over the split partial results (an HBM-bound streaming kernel that nothing but the
- * optimizer waits for) issued on `reduce_stream`, ordered after the GEMM on `stream`: it then runs beside the caller's
- * next GEMM instead of in front of it.  dw is complete once `reduce_stream` has drained; when the M range is not split
- * (no workspace) the GEMM itself writes dw on `stream`. */
-int dadet_conv_wgrad_on(const dadet_conv_desc* d, const float* x, const float* gy, const float* out_scale,
-                        float* dw, int accumulate, void* workspace, size_t workspace_bytes, void* stream,
-                        void* reduce_stream);
 
 /* weight re-layout for the data gradient: wt[ci][KH-1-r][KW-1-s][co] = w[co][r][s][ci] * scale[co].
  * dgrad of a stride-1 conv is then dadet_conv_forward(gy, wt) with pad' = K-1-pad. */
