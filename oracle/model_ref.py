@@ -13,6 +13,12 @@ intermediate tensors under tests/golden/; tests/test_oracle_golden.py replays th
 Random draws follow the reference's call order on the global CPU generator (sampler randperm:
 modeling/balanced_positive_negative_sampler.py:57-58; F.dropout in da_heads.py:63,65), so one torch.manual_seed
 reproduces the reference's sampled indices and dropout masks.
+
+`DeviceDraws` (below) is the one piece that restates the PRODUCT instead of the reference: the HIP path's default
+samplers (da_detect_amd/csrc/sampling.hip) keep the reference's sampling RULE (counts per class, ignored rows, ascending
+order) but draw the random subset from splitmix64 keys instead of torch.randperm.  Given the seeds the product consumed,
+the oracle takes the same subsets, so the default (benchmarked) GPU path can be compared with this file on the same
+sample (tests/test_default_path_gpu.py).
 """
 import math
 import os
@@ -175,6 +181,58 @@ def sample_pos_neg(labels, batch_size, positive_fraction):
     return pm, nm
 
 
+class DeviceDraws(object):
+    """random draws of the product's default GPU path, replayed on the CPU: `seeds` are the 64-bit values the
+    product passed to dadet_sample_anchors / dadet_sample_rois (da_detect_amd/utils/rng.py next_seed), in call order;
+    `masks` the multiplicative dropout masks it drew for DAInsHead (da_heads.py:63,65), in call order."""
+
+    def __init__(self, seeds, masks=()):
+        self.seeds, self.masks = list(seeds), [m.detach().cpu() for m in masks]
+        self.taken_seeds = self.taken_masks = 0
+
+    def seed(self):
+        self.taken_seeds += 1
+        return int(self.seeds[self.taken_seeds - 1])
+
+    def mask(self, shape):
+        self.taken_masks += 1
+        m = self.masks[self.taken_masks - 1]
+        assert tuple(m.shape) == tuple(shape), (tuple(m.shape), tuple(shape))
+        return m
+
+    def exhausted(self):
+        return self.taken_seeds == len(self.seeds) and self.taken_masks == len(self.masks)
+
+
+def device_sample_keys(seed, n):
+    """32-bit random key of row i = top half of the splitmix64 finaliser of seed + (i + 1) * 0x9E3779B97F4A7C15
+    (da_detect_amd/csrc/sampling.hip `sample_key`)"""
+    with np.errstate(over="ignore"):
+        z = np.uint64(seed) + np.arange(1, n + 1, dtype=np.uint64) * np.uint64(0x9E3779B97F4A7C15)
+        z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+        z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+        z = z ^ (z >> np.uint64(31))
+    return (z >> np.uint64(32)).astype(np.uint32)
+
+
+def sample_pos_neg_device(labels, batch_size, positive_fraction, seed):
+    """same counts as sample_pos_neg (balanced_positive_negative_sampler.py:27-76); the uniformly random subset of
+    each class is "the k rows with the smallest keys, ties to the lower index" (sample_rois_kernel: bitonic sort of
+    (class, key, index); sample_anchors_kernel: radix select of the k-th key + lowest-index ties) -> (pos mask, neg mask)"""
+    lab = labels.numpy()
+    keys = device_sample_keys(seed, lab.shape[0])
+    positive = np.nonzero(lab >= 1)[0]
+    negative = np.nonzero(lab == 0)[0]
+    num_pos = min(positive.size, int(batch_size * positive_fraction))
+    num_neg = min(negative.size, batch_size - num_pos)
+    pm = torch.zeros(lab.shape[0], dtype=torch.bool)
+    nm = torch.zeros(lab.shape[0], dtype=torch.bool)
+    for rows, k, mask in ((positive, num_pos, pm), (negative, num_neg, nm)):
+        order = np.lexsort((rows, keys[rows]))      # by key, then by index
+        mask[torch.from_numpy(rows[order[:k]])] = True
+    return pm, nm
+
+
 def smooth_l1(x, t, beta):
     """layers/smooth_l1_loss.py:6-16, summed"""
     n = torch.abs(x - t)
@@ -189,14 +247,16 @@ class _RoiAlign(torch.autograd.Function):
     def forward(ctx, x, rois, scale, ph, pw, sr):
         ctx.save_for_backward(rois)
         ctx.args = (scale, ph, pw, sr, tuple(x.shape))
-        return torch.from_numpy(O.roi_align_forward(x.detach().numpy(), rois.numpy(), scale, ph, pw, sr))
+        # the C oracle is fp32 like the reference operator; a float64 run of this file (noise-floor measurements of
+        # the gradient tests) keeps its dtype around it
+        return torch.from_numpy(O.roi_align_forward(x.detach().numpy(), rois.numpy(), scale, ph, pw, sr)).to(x.dtype)
 
     @staticmethod
     def backward(ctx, g):
         (rois,) = ctx.saved_tensors
         scale, ph, pw, sr, (B, C, H, W) = ctx.args
         gin = O.roi_align_backward(g.contiguous().numpy(), rois.numpy(), scale, ph, pw, B, C, H, W, sr)
-        return torch.from_numpy(gin), None, None, None, None, None
+        return torch.from_numpy(gin).to(g.dtype), None, None, None, None, None
 
 
 def roi_align(x, rois, scale, ph, pw, sr):
@@ -246,7 +306,7 @@ def rpn_proposals(objectness, deltas, anchors, image_sizes, gts, cfg, training):
     return out
 
 
-def rpn_losses(objectness, deltas, anchors, image_sizes, gts, cfg):
+def rpn_losses(objectness, deltas, anchors, image_sizes, gts, cfg, draws=None, record=None):
     """rpn/loss.py:57-143"""
     rpn = cfg.MODEL.RPN
     labels, reg_targets = [], []
@@ -266,12 +326,17 @@ def rpn_losses(objectness, deltas, anchors, image_sizes, gts, cfg):
         reg_targets.append(encode(matched, anchors, (1.0, 1.0, 1.0, 1.0)))
     pos, neg = [], []
     for lab in labels:
-        pm, nm = sample_pos_neg(lab, rpn.BATCH_SIZE_PER_IMAGE, rpn.POSITIVE_FRACTION)
+        if draws is not None:
+            pm, nm = sample_pos_neg_device(lab, rpn.BATCH_SIZE_PER_IMAGE, rpn.POSITIVE_FRACTION, draws.seed())
+        else:
+            pm, nm = sample_pos_neg(lab, rpn.BATCH_SIZE_PER_IMAGE, rpn.POSITIVE_FRACTION)
         pos.append(pm)
         neg.append(nm)
     pos_inds = torch.nonzero(torch.cat(pos)).squeeze(1)
     neg_inds = torch.nonzero(torch.cat(neg)).squeeze(1)
     sampled = torch.cat([pos_inds, neg_inds])
+    if record is not None:
+        record.update(rpn_pos_inds=pos_inds, rpn_neg_inds=neg_inds)
     obj = flatten_hwa(objectness, 1).reshape(-1)
     reg = flatten_hwa(deltas, 4).reshape(-1, 4)
     labels, reg_targets = torch.cat(labels), torch.cat(reg_targets)
@@ -299,11 +364,20 @@ def box_head_targets(proposals, gts, cfg, sample_for_da):
     return out
 
 
-def subsample(proposals, gts, cfg, sample_for_da=False):
+def subsample(proposals, gts, cfg, sample_for_da=False, draws=None):
     """loss.py:95-163 -> per image dict(boxes, labels, reg, domain)"""
     rh = cfg.MODEL.ROI_HEADS
     tg = box_head_targets(proposals, gts, cfg, sample_for_da)
-    masks = [sample_pos_neg(lab, rh.BATCH_SIZE_PER_IMAGE, rh.POSITIVE_FRACTION) for lab, _, _ in tg]
+    masks = []
+    for (boxes, _), (lab, _, _) in zip(proposals, tg):
+        if draws is None:
+            masks.append(sample_pos_neg(lab, rh.BATCH_SIZE_PER_IMAGE, rh.POSITIVE_FRACTION))
+        elif sample_for_da and len(boxes) <= rh.BATCH_SIZE_PER_IMAGE:
+            # all labels are 0 and there are no more rows than the cap: every row is taken, and the product draws
+            # nothing (FastRCNNLossComputation._subsample_for_da_fused)
+            masks.append((torch.zeros(len(boxes), dtype=torch.bool), torch.ones(len(boxes), dtype=torch.bool)))
+        else:
+            masks.append(sample_pos_neg_device(lab, rh.BATCH_SIZE_PER_IMAGE, rh.POSITIVE_FRACTION, draws.seed()))
     out = []
     for (boxes, _), (lab, reg, src), (pm, nm) in zip(proposals, tg, masks):
         idx = torch.nonzero(pm | nm).squeeze(1)
@@ -345,12 +419,14 @@ def img_head(x, sd, p):
     return F.conv2d(t, sd[p + ".imghead.conv2_da.weight"], sd[p + ".imghead.conv2_da.bias"])
 
 
-def ins_head(x, sd, p, training=True):
-    """da_heads.py:61-68 (dropout masks drawn exactly like F.dropout on the CPU)"""
+def ins_head(x, sd, p, training=True, draws=None):
+    """da_heads.py:61-68 (dropout masks drawn exactly like F.dropout on the CPU, or replayed from `draws`)"""
+    drop = (lambda t: t * draws.mask(t.shape).to(t.dtype)) if (draws is not None and training) else \
+        (lambda t: F.dropout(t, p=0.5, training=training))
     x = F.relu(F.linear(x, sd[p + ".inshead.fc1_da.weight"], sd[p + ".inshead.fc1_da.bias"]))
-    x = F.dropout(x, p=0.5, training=training)
+    x = drop(x)
     x = F.relu(F.linear(x, sd[p + ".inshead.fc2_da.weight"], sd[p + ".inshead.fc2_da.bias"]))
-    x = F.dropout(x, p=0.5, training=training)
+    x = drop(x)
     return F.linear(x, sd[p + ".inshead.fc3_da.weight"], sd[p + ".inshead.fc3_da.bias"])
 
 
@@ -382,15 +458,15 @@ def consistency(img_sig, ins_sig, ins_labels):
     return torch.abs(rows - ins_sig).mean()
 
 
-def da_losses_plain(feat, ins_feat, ins_labels, img_labels, sd, cfg):
+def da_losses_plain(feat, ins_feat, ins_labels, img_labels, sd, cfg, draws=None):
     """DomainAdaptationModule.forward (da_heads.py:388-440)"""
     da = cfg.MODEL.DA_HEADS
     p = "da_heads"
     v = F.avg_pool2d(ins_feat, 7).flatten(1)
     img_logits = img_head(_GRL.apply(feat, -da.DA_IMG_GRL_WEIGHT), sd, p)
-    ins_logits = ins_head(_GRL.apply(v, -da.DA_INS_GRL_WEIGHT), sd, p)
+    ins_logits = ins_head(_GRL.apply(v, -da.DA_INS_GRL_WEIGHT), sd, p, draws=draws)
     img_cst = img_head(_GRL.apply(feat, da.DA_IMG_GRL_WEIGHT), sd, p).sigmoid()
-    ins_cst = ins_head(_GRL.apply(v, da.DA_INS_GRL_WEIGHT), sd, p).sigmoid()
+    ins_cst = ins_head(_GRL.apply(v, da.DA_INS_GRL_WEIGHT), sd, p, draws=draws).sigmoid()
     out = {}
     if da.DA_IMG_LOSS_WEIGHT > 0:
         out["loss_da_image"] = da.DA_IMG_LOSS_WEIGHT * img_bce(img_logits, img_labels)
@@ -409,7 +485,7 @@ def adv_weight(cur_loss, base, adv, threshold):
     return -adv * min(float(threshold), 1.0 / cur) if cur <= gate else -base
 
 
-def da_losses_triplet(feat2, ins_feat, ins_labels, img_labels, feat3, ins_set, state, sd, cfg):
+def da_losses_triplet(feat2, ins_feat, ins_labels, img_labels, feat3, ins_set, state, sd, cfg, draws=None):
     """DomainAdaptationModule_triplet.forward (da_heads.py:293-344); `state` carries the adaptive margins and
     the previous triplet losses"""
     da = cfg.MODEL.DA_HEADS
@@ -435,34 +511,35 @@ def da_losses_triplet(feat2, ins_feat, ins_labels, img_labels, feat3, ins_set, s
         out["loss_da_image"] = da.DA_IMG_LOSS_WEIGHT * img_bce(img_head(_GRL.apply(feat2, w), sd, p), img_labels)
     v = F.avg_pool2d(ins_feat, 7).flatten(1)
     if da.DA_INS_LOSS_WEIGHT > 0:
-        cur = F.binary_cross_entropy_with_logits(ins_head(v.detach(), sd, p).squeeze(), ins_labels.float())
+        cur = F.binary_cross_entropy_with_logits(ins_head(v.detach(), sd, p, draws=draws).squeeze(), ins_labels.float())
         w = adv_weight(cur, da.DA_INS_GRL_WEIGHT, da.DA_INS_advGRL_WEIGHT, da.DA_ADV_GRL_THRESHOLD) \
             if da.DA_ADV_GRL else -da.DA_INS_GRL_WEIGHT
         out["loss_da_instance"] = da.DA_INS_LOSS_WEIGHT * F.binary_cross_entropy_with_logits(
-            ins_head(_GRL.apply(v, w), sd, p).squeeze(), ins_labels.float())
+            ins_head(_GRL.apply(v, w), sd, p, draws=draws).squeeze(), ins_labels.float())
     if da.DA_CST_LOSS_WEIGHT > 0:
         img_cst = img_head(_GRL.apply(feat2, da.DA_IMG_GRL_WEIGHT), sd, p).sigmoid()
-        ins_cst = ins_head(_GRL.apply(v, da.DA_INS_GRL_WEIGHT), sd, p).sigmoid()
+        ins_cst = ins_head(_GRL.apply(v, da.DA_INS_GRL_WEIGHT), sd, p, draws=draws).sigmoid()
         out["loss_da_consistency"] = da.DA_CST_LOSS_WEIGHT * consistency(img_cst, ins_cst, ins_labels)
     return out
 
 
 # -------------------------------------------------------------------------------------------- full model
-def box_head_pass(feat, proposals, gts, sd, cfg, with_losses=True):
+def box_head_pass(feat, proposals, gts, sd, cfg, with_losses=True, draws=None):
     """ROIBoxHead.forward in training (box_head.py:36-118)"""
     with torch.no_grad():
-        samples = subsample(proposals, gts, cfg)
+        samples = subsample(proposals, gts, cfg, draws=draws)
     x = roi_feature(feat, samples, sd, cfg)
     cls_loss, box_loss, dom = box_losses(x, samples, sd, cfg)
     with torch.no_grad():
         # the reference samples the DA ROIs from the ALREADY SUBSAMPLED proposals (box_head.py:102-104)
         sub = [(s["boxes"], None) for s in samples]
-        da_samples = subsample(sub, gts, cfg, sample_for_da=True)
+        da_samples = subsample(sub, gts, cfg, sample_for_da=True, draws=draws)
     da_feat = roi_feature(feat, da_samples, sd, cfg)
     return dict(loss_classifier=cls_loss, loss_box_reg=box_loss), da_feat, dom, samples, da_samples
 
 
-def training_losses(sd, cfg, images, gts, state=None, intermediates=None, selection_maps=None):
+def training_losses(sd, cfg, images, gts, state=None, intermediates=None, selection_maps=None, draws=None,
+                    grad_probe=False):
     """GeneralizedRCNN.forward in training mode (modeling/detector/generalized_rcnn.py:61-153).
     images [N,3,H,W] (already padded), gts: list of dict(boxes [G,4], labels [G], is_source [G] bool).
     selection_maps=(objectness, deltas): tests may feed the proposal SELECTION fixed RPN maps (e.g. the golden
@@ -477,22 +554,22 @@ def training_losses(sd, cfg, images, gts, state=None, intermediates=None, select
     with torch.no_grad():
         sel_obj, sel_del = selection_maps if selection_maps is not None else (objectness, deltas)
         proposals = rpn_proposals(sel_obj, sel_del, anchors, image_sizes, gts, cfg, True)
-    obj_loss, rpn_box_loss = rpn_losses(objectness, deltas, anchors, image_sizes, gts, cfg)
+    obj_loss, rpn_box_loss = rpn_losses(objectness, deltas, anchors, image_sizes, gts, cfg, draws, intermediates)
     img_labels = torch.tensor([1.0 if g["is_source"].any() else 0.0 for g in gts])
     losses = {}
     if cfg.MODEL.DA_HEADS.TRIPLET_USE:
-        det, da_feat, dom, samples, da_samples = box_head_pass(feat[0:2], proposals[0:2], gts[0:2], sd, cfg)
+        det, da_feat, dom, samples, da_samples = box_head_pass(feat[0:2], proposals[0:2], gts[0:2], sd, cfg, draws=draws)
         ins_set = None
         if cfg.MODEL.DA_HEADS.ALIGNMENT:
             ins_set = []
             for k in range(3):
-                _, f_k, _, _, _ = box_head_pass(feat[k:k + 1], [proposals[1]], [gts[k]], sd, cfg)
+                _, f_k, _, _, _ = box_head_pass(feat[k:k + 1], [proposals[1]], [gts[k]], sd, cfg, draws=draws)
                 ins_set.append(f_k)
         da = da_losses_triplet(feat[0:2], da_feat, dom, img_labels[0:2], feat, ins_set,
-                               state if state is not None else {}, sd, cfg)
+                               state if state is not None else {}, sd, cfg, draws)
     else:
-        det, da_feat, dom, samples, da_samples = box_head_pass(feat, proposals, gts, sd, cfg)
-        da = da_losses_plain(feat, da_feat, dom, img_labels, sd, cfg)
+        det, da_feat, dom, samples, da_samples = box_head_pass(feat, proposals, gts, sd, cfg, draws=draws)
+        da = da_losses_plain(feat, da_feat, dom, img_labels, sd, cfg, draws)
     losses.update(det)
     losses.update({"loss_objectness": obj_loss, "loss_rpn_box_reg": rpn_box_loss})
     losses.update(da)
@@ -501,6 +578,8 @@ def training_losses(sd, cfg, images, gts, state=None, intermediates=None, select
                              proposals=[(b.clone(), s.clone()) for b, s in proposals],
                              sampled_idx=[s["idx"] for s in samples], da_sampled_idx=[s["idx"] for s in da_samples],
                              da_feat=da_feat.detach())
+        if grad_probe:   # graph-attached tensors for torch.autograd.grad(loss, tensor) probes (AdvGRL fixtures)
+            intermediates.update(feat_graph=feat, ins_feat_graph=da_feat)
     return losses
 
 

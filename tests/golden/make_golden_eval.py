@@ -83,7 +83,7 @@ def run_case(name, yaml_path, oracle_fn, H=192, W=320, nimg=2, seed=0):
                                                                            len(o["boxes"])))
         assert rb.shape == ob.shape and torch.allclose(rb, ob, atol=1e-3), "proposals"
         assert len(b) == len(o["boxes"]) and torch.equal(l, o["labels"]), "detections"
-        assert torch.allclose(b, o["boxes"], atol=2e-3) and torch.allclose(s, o["scores"], atol=1e-6)
+        assert torch.allclose(b, o["boxes"], atol=2e-3) and torch.allclose(s, o["scores"], atol=1e-6), "detections"
         out["proposals/%d/boxes" % i], out["proposals/%d/objectness" % i] = rb.numpy(), rs.numpy()
         out["det/%d/boxes" % i], out["det/%d/scores" % i], out["det/%d/labels" % i] = b.numpy(), s.numpy(), l.numpy()
     path = os.path.join(HERE, name + ".npz")

@@ -1,0 +1,33 @@
+"""noise-floor table for the default-path gradient test: GPU vs oracle fp64, oracle fp32 vs oracle fp64"""
+import sys, os
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import torch, pytest
+import test_default_path_gpu as T
+from oracle import model_ref
+from da_detect_amd.data.synthetic import make_batch
+
+class MP:
+    def setattr(self, obj, name, val): setattr(obj, name, val)
+
+case = sys.argv[1] if len(sys.argv) > 1 else "da_plain"
+seed, H, W = 11, 192, 320
+dev = torch.device("cuda:0")
+c, sd, rec, nimg = T._run_default_path(case, H, W, dev, seed, MP())
+res = {}
+for dt in (torch.float32, torch.float64):
+    osd = {k: v.clone().to(dt) if v.is_floating_point() else v.clone() for k, v in sd.items()}
+    for n in rec["grads"]:
+        osd[n].requires_grad_(True)
+    imgs, tg = make_batch(c, nimg, H, W, seed=seed, device=torch.device("cpu"))
+    draws = model_ref.DeviceDraws(rec["seeds"], [m.to(dt) for m in rec["masks"]])
+    l = model_ref.training_losses(osd, c, imgs.tensors.to(dt), model_ref.targets_to_dicts(tg), draws=draws,
+                                  selection_maps=(rec["objectness"].cpu(), rec["deltas"].cpu()))
+    sum(l.values()).backward()
+    res[dt] = {n: osd[n].grad.double() for n in rec["grads"]}
+def l2(a, b): return float((a.double() - b).norm() / (b.norm() + 1e-30))
+print("%-58s %9s %9s %9s | med %9s %9s" % ("tensor", "gpu-64", "cpu32-64", "gpu-cpu32", "gpu-64", "cpu32-64"))
+for n, g in rec["grads"].items():
+    a, b = res[torch.float32][n], res[torch.float64][n]
+    print("%-58s %9.2e %9.2e %9.2e | %13.2e %9.2e" % (n, l2(g, b), l2(a, b), l2(g, a),
+          float(0), float(0)))
