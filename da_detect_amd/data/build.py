@@ -1,11 +1,22 @@
-"""Data-loader assembly (reference: maskrcnn_benchmark/data/build.py:127-419): aspect-ratio grouping, the
-distributed / grouped / iteration-based sampler stack, and the source / target / auxiliary pairing of the DA
-trainers.  Dataset locations come from the caller (`dataset_specs`) instead of the reference's path catalog."""
+"""Data-loader assembly (reference: maskrcnn_benchmark/data/build.py:67-419): dataset construction from the path
+catalog, aspect-ratio grouping, the distributed / grouped / iteration-based sampler stack, and the source / target /
+auxiliary pairing of the DA trainers.
+
+Two entry families over the same machinery:
+  * the reference's own — `make_data_loader(cfg, is_train, is_source, is_negative, is_distributed, is_for_period,
+    start_iter)` and `make_data_loader_da(cfg, is_source=[...], ...)` — dataset NAMES from cfg.DATASETS resolved through
+    `DatasetCatalog` of the file cfg.PATHS_CATALOG (what tools/train_net_triplet.py:108-170 calls);
+  * explicit (annotation file, image root) pairs — `make_da_data_loaders`, `make_triplet_data_loader`
+    (tools/train_net_da.py).
+"""
 import bisect
+import logging
 
 import torch
 
 from ..utils.comm import get_world_size
+from ..utils.imports import import_file
+from . import datasets as D
 from . import samplers
 from .collate_batch import BatchCollator, BatchCollator_triplet
 from .datasets import COCODataset, TripletDataset
@@ -57,28 +68,132 @@ def images_per_gpu(cfg, is_train, domain_share=1):
     return total // (world * domain_share)
 
 
-def make_data_loader(cfg, dataset, is_train=True, is_distributed=False, start_iter=0, domain_share=1, collator=None):
-    per_gpu = images_per_gpu(cfg, is_train, domain_share)
-    sampler = make_data_sampler(dataset, shuffle=is_train, distributed=is_distributed)
+def _loader_for(cfg, dataset, per_gpu, shuffle, is_distributed, num_iters, start_iter, collator):
+    sampler = make_data_sampler(dataset, shuffle, is_distributed)
     batch_sampler = make_batch_data_sampler(dataset, sampler, [1] if cfg.DATALOADER.ASPECT_RATIO_GROUPING else [],
-                                            per_gpu, cfg.SOLVER.MAX_ITER if is_train else None, start_iter)
-    if collator is None:
-        collator = BatchCollator(cfg.DATALOADER.SIZE_DIVISIBILITY)
+                                            per_gpu, num_iters, start_iter)
     return torch.utils.data.DataLoader(dataset, num_workers=cfg.DATALOADER.NUM_WORKERS, batch_sampler=batch_sampler,
                                        collate_fn=collator)
 
 
+# ------------------------------------------------------------------------------------ the reference's entry points
+def _catalog(cfg):
+    return import_file("maskrcnn_benchmark.config.paths_catalog", cfg.PATHS_CATALOG, True).DatasetCatalog
+
+
+def _from_catalog(name, catalog, transforms, is_train, is_source):
+    """one dataset from its catalog entry (build.py:84-103, 141-169)"""
+    data = catalog.get(name)
+    factory = getattr(D, data["factory"])
+    args = dict(data["args"])
+    if data["factory"] == "COCODataset":
+        args["remove_images_without_annotations"] = is_train
+    args["transforms"] = transforms
+    args["is_source"] = is_source
+    return factory(**args)
+
+
+def build_dataset(dataset_list, transforms, dataset_catalog, is_train=True, is_source=True):
+    """training: ONE (possibly concatenated) dataset in a list; testing: one per name (build.py:124-181)"""
+    if not isinstance(dataset_list, (list, tuple)):
+        raise RuntimeError("dataset_list should be a list of strings, got {}".format(dataset_list))
+    datasets = [_from_catalog(n, dataset_catalog, transforms, is_train, is_source) for n in dataset_list]
+    if not is_train:
+        return datasets
+    return [datasets[0] if len(datasets) == 1 else D.ConcatDataset(datasets)]
+
+
+def build_dataset_da(dataset_list, transforms, dataset_catalog, is_source, is_train=True):
+    """`is_source` is a list parallel to `dataset_list` = [source, target, auxiliary]; training: the index-aligned
+    triplet dataset in a list, testing: the three datasets (build.py:67-121)"""
+    if not isinstance(dataset_list, (list, tuple)):
+        raise RuntimeError("dataset_list should be a list of strings, got {}".format(dataset_list))
+    datasets = [_from_catalog(n, dataset_catalog, transforms, is_train, src)
+                for n, src in zip(dataset_list, is_source)]
+    if not is_train:
+        return datasets
+    return [TripletDataset(datasets)]
+
+
+def _batch_plan(cfg, is_train, is_distributed, start_iter):
+    """-> (images per GPU and loader, shuffle, number of iterations, start_iter) — build.py:233-258"""
+    if is_train:
+        per_gpu = images_per_gpu(cfg, True, 2 if cfg.MODEL.DOMAIN_ADAPTATION_ON else 1)
+        plan = per_gpu, True, cfg.SOLVER.MAX_ITER, start_iter
+    else:
+        plan = images_per_gpu(cfg, False), bool(is_distributed), None, 0
+    if plan[0] > 1:
+        logging.getLogger(__name__).warning(
+            "More than one image per GPU and loader: memory grows with it; reduce SOLVER.IMS_PER_BATCH / "
+            "TEST.IMS_PER_BATCH if needed (and rescale the learning rate and schedule for training).")
+    return plan
+
+
+def make_data_loader(cfg, is_train=True, is_source=True, is_negative=False, is_distributed=False, is_for_period=False,
+                     start_iter=0):
+    """reference signature (build.py:232-329).  Training: the loader of ONE domain — SOURCE_TRAIN, TARGET_TRAIN or
+    TARGET_TRAIN_negative under DOMAIN_ADAPTATION_ON (each IMS_PER_BATCH // (2 * GPUs) images per step), TRAIN
+    otherwise; testing: a list with one loader per cfg.DATASETS.TEST entry."""
+    per_gpu, shuffle, num_iters, start_iter = _batch_plan(cfg, is_train, is_distributed, start_iter)
+    if not is_train:
+        names = cfg.DATASETS.TEST
+    elif not cfg.MODEL.DOMAIN_ADAPTATION_ON:
+        names = cfg.DATASETS.TRAIN
+    elif is_source:
+        names = cfg.DATASETS.SOURCE_TRAIN
+    else:
+        names = cfg.DATASETS.TARGET_TRAIN_negative if is_negative else cfg.DATASETS.TARGET_TRAIN
+    datasets = build_dataset(list(names), build_transforms(cfg, is_train), _catalog(cfg), is_train, is_source)
+    loaders = [_loader_for(cfg, ds, per_gpu, shuffle, is_distributed, num_iters, start_iter,
+                           BatchCollator(cfg.DATALOADER.SIZE_DIVISIBILITY)) for ds in datasets]
+    if is_train:
+        assert len(loaders) == 1
+        return loaders[0]
+    return loaders
+
+
+def make_data_loader_da(cfg, is_source, is_train=True, is_negative=False, is_distributed=False, is_for_period=False,
+                        start_iter=0):
+    """reference signature (build.py:332-419): the ALIGNED triplet loader over (SOURCE_TRAIN[0], TARGET_TRAIN[0],
+    TARGET_TRAIN_negative[0]); `is_source` = [True, False, False] flags the three domains.  Every batch is the nine
+    fields of BatchCollator_triplet."""
+    per_gpu, shuffle, num_iters, start_iter = _batch_plan(cfg, is_train, is_distributed, start_iter)
+    if is_train:
+        names = [cfg.DATASETS.SOURCE_TRAIN[0], cfg.DATASETS.TARGET_TRAIN[0], cfg.DATASETS.TARGET_TRAIN_negative[0]]
+    else:
+        names = list(cfg.DATASETS.TEST)
+    single = is_train or is_for_period
+    datasets = build_dataset_da(names, build_transforms(cfg, is_train), _catalog(cfg), is_source, single)
+    loaders = [_loader_for(cfg, ds, per_gpu, shuffle, is_distributed, num_iters, start_iter,
+                           BatchCollator_triplet(cfg.DATALOADER.SIZE_DIVISIBILITY)) for ds in datasets]
+    if single:
+        assert len(loaders) == 1
+        return loaders[0]
+    return loaders
+
+
+# ------------------------------------------------------------------------- explicit (annotation file, image root) pairs
+def _train_loader(cfg, dataset, is_distributed, start_iter, collator):
+    return _loader_for(cfg, dataset, images_per_gpu(cfg, True, 2), True, is_distributed, cfg.SOLVER.MAX_ITER,
+                       start_iter, collator)
+
+
+def make_test_data_loader(cfg, dataset, is_distributed=False):
+    """evaluation loader over an already constructed dataset (sequential, or sharded by rank when distributed)"""
+    return _loader_for(cfg, dataset, images_per_gpu(cfg, False), bool(is_distributed), is_distributed, None, 0,
+                       BatchCollator(cfg.DATALOADER.SIZE_DIVISIBILITY))
+
+
 def make_da_data_loaders(cfg, dataset_specs, is_distributed=False, start_iter=0):
-    """dataset_specs = {"source": (ann_file, root), "target": (...)[, "auxiliary": (...)]} -> the loaders
-    do_da_train iterates jointly (one per domain, each carrying IMS_PER_BATCH // (2 * num_gpus) images per step)"""
+    """dataset_specs = {"source": (ann_file, root), "target": (...)[, "auxiliary": (...)]} -> one loader per domain,
+    iterated jointly by do_da_train (each carrying IMS_PER_BATCH // (2 * num_gpus) images per step)"""
     tf = build_transforms(cfg, True)
-    names = [n for n in ("source", "target", "auxiliary") if n in dataset_specs]
     out = []
-    for name in names:
+    for name in [n for n in ("source", "target", "auxiliary") if n in dataset_specs]:
         ann, root = dataset_specs[name]
         ds = COCODataset(ann, root, remove_images_without_annotations=True, transforms=tf,
                          is_source=(name == "source"))
-        out.append(make_data_loader(cfg, ds, True, is_distributed, start_iter, domain_share=2))
+        out.append(_train_loader(cfg, ds, is_distributed, start_iter, BatchCollator(cfg.DATALOADER.SIZE_DIVISIBILITY)))
     return out
 
 
@@ -87,6 +202,5 @@ def make_triplet_data_loader(cfg, dataset_specs, is_distributed=False, start_ite
     tf = build_transforms(cfg, True)
     ds = [COCODataset(*dataset_specs[n], remove_images_without_annotations=True, transforms=tf,
                       is_source=(n == "source")) for n in ("source", "target", "auxiliary")]
-    triplet = TripletDataset(ds)
-    return make_data_loader(cfg, triplet, True, is_distributed, start_iter, domain_share=2,
-                            collator=BatchCollator_triplet(cfg.DATALOADER.SIZE_DIVISIBILITY))
+    return _train_loader(cfg, TripletDataset(ds), is_distributed, start_iter,
+                         BatchCollator_triplet(cfg.DATALOADER.SIZE_DIVISIBILITY))

@@ -73,6 +73,16 @@ class COCODataset(torch.utils.data.Dataset):
         return self.imgs[self.id_to_img_map[index]]
 
 
+class ConcatDataset(torch.utils.data.ConcatDataset):
+    """concatenation that still answers get_img_info (reference: data/datasets/concat_dataset.py:7-23)"""
+
+    def get_img_info(self, idx):
+        import bisect
+
+        which = bisect.bisect_right(self.cumulative_sizes, idx)
+        return self.datasets[which].get_img_info(idx if which == 0 else idx - self.cumulative_sizes[which - 1])
+
+
 class TripletDataset(torch.utils.data.Dataset):
     """index-aligned (source, target, auxiliary) samples; the target / auxiliary images are paired with a COPY of the
     source annotations carrying their own domain flag — build.py:34-46 (the datasets are renderings of the same
@@ -100,3 +110,6 @@ class TripletDataset(torch.utils.data.Dataset):
 
     def get_img_info(self, index):
         return self.dataset_s.get_img_info(index)
+
+
+Dataset_triplet = TripletDataset      # the reference's name (data/build.py:23)

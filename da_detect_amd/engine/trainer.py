@@ -2,14 +2,20 @@
 
 `train_step` is the body the reference repeats per iteration (trainer.py:228-242): forward -> sum of losses ->
 zero_grad -> backward (gradient buckets all-reduced while it runs) -> fused SGD -> scheduler update.
-`do_da_train` keeps the reference's calling convention for the source/target(/auxiliary) loaders; logging
-host syncs happen every 20 iterations only (the reference syncs every iteration through meters.update)."""
+`do_da_train` / `do_train` have the reference's signatures (trainer.py:150-167 / 66-75) and batch conventions, so
+tools/train_net_triplet.py:182-215 calls them unchanged.  What differs underneath: a DistributedDataParallel wrapper
+is unwrapped and replaced by the bucketed gradient reducer attached to the fused optimizer (parallel/reducer.py —
+DDP's one-backward-per-forward contract does not admit the overlapped RPN / DA backward); the per-iteration host
+synchronisations of the reference (meters.update -> .item(), the NaN test) are deferred to the logging period."""
+import datetime
+import logging
 import time
 
 import torch
 import torch.distributed as dist
 
-from ..utils.comm import get_world_size
+from ..utils.comm import get_world_size, synchronize
+from ..utils.metric_logger import MetricLogger
 
 
 def reduce_loss_dict(loss_dict):
@@ -51,38 +57,147 @@ def train_step(model, optimizer, images, targets, scheduler=None, iteration=0):
     return loss_dict
 
 
-def do_da_train(model, source_data_loader, target_data_loader, optimizer, scheduler, checkpointer, device,
-                checkpoint_period, arguments, cfg=None, negative_data_loader=None, logger=None, log_period=20):
-    """joint iteration over the source / target (/ auxiliary) loaders (trainer.py:150-336).  Each loader yields
-    (ImageList, list[BoxList], ids); batches are concatenated source-first exactly as trainer.py:215-224."""
-    model.train()
-    enable_overlapped_rpn_backward(model)
-    start_iter = arguments.get("iteration", 0)
-    loaders = [source_data_loader, target_data_loader] + ([negative_data_loader] if negative_data_loader else [])
-    max_iter = len(source_data_loader)
-    t0 = time.time()
-    for iteration, batches in enumerate(zip(*loaders), start_iter):
+def _unwrap(model):
+    return model.module if isinstance(model, torch.nn.parallel.DistributedDataParallel) else model
+
+
+def _prepare(model, optimizer, distributed):
+    """the network that is actually stepped + its gradient reducer (see the module docstring)"""
+    net = _unwrap(model)
+    if hasattr(optimizer, "attach_reducer") and getattr(optimizer, "reducer", None) is None \
+            and (distributed or get_world_size() > 1 or next(net.parameters()).is_cuda):
+        from ..parallel.reducer import BucketedGradReducer
+
+        reducer = BucketedGradReducer([p for p in net.parameters() if p.requires_grad])
+        reducer.broadcast_parameters(0)
+        optimizer.attach_reducer(reducer)
+    net.train()
+    enable_overlapped_rpn_backward(net)
+    return net
+
+
+def _log_line(logger, meters, iteration, max_iter, optimizer):
+    eta = str(datetime.timedelta(seconds=int(meters.time.global_avg * (max_iter - iteration))))
+    mem = torch.cuda.max_memory_allocated() / 1024.0 / 1024.0 if torch.cuda.is_available() else 0.0
+    logger.info(meters.delimiter.join(["eta: {eta}", "iter: {iter}", "{meters}", "lr: {lr:.6f}", "max mem: {memory:.0f}"])
+                .format(eta=eta, iter=iteration, meters=str(meters), lr=optimizer.param_groups[0]["lr"], memory=mem))
+
+
+def _update_meters(meters, loss_dict):
+    reduced = reduce_loss_dict(loss_dict)
+    vals = [v.detach() for v in reduced.values()]
+    total = torch.stack([v.reshape(()) for v in vals]).sum() if vals else torch.zeros(())
+    meters.update(loss=total, **{k: v.detach() for k, v in reduced.items()})
+    return total
+
+
+def do_train(model, data_loader, optimizer, scheduler, checkpointer, device, checkpoint_period, arguments):
+    """single-domain loop (trainer.py:66-146): iteration counts from arguments["iteration"] + 1, `scheduler.step()`
+    BEFORE the optimizer step, checkpoints every `checkpoint_period` and at the end"""
+    logger = logging.getLogger("maskrcnn_benchmark.trainer")
+    logger.info("Start training")
+    meters = MetricLogger(delimiter="  ")
+    max_iter = len(data_loader)
+    start_iter = arguments["iteration"]
+    net = _prepare(model, optimizer, get_world_size() > 1)
+    start_time = end = time.time()
+    for iteration, (images, targets, _) in enumerate(data_loader, start_iter):
+        data_time = time.time() - end
+        iteration = iteration + 1
         arguments["iteration"] = iteration
-        images = batches[0][0]
-        targets = list(batches[0][1])
-        for b in batches[1:]:
-            images = images + b[0]
-            targets = targets + list(b[1])
+        scheduler.step()
         images = images.to(device)
         targets = [t.to(device) for t in targets]
-        loss_dict = train_step(model, optimizer, images, targets, scheduler, iteration)
-        if iteration % log_period == 0 or iteration == max_iter - 1:
-            reduced = reduce_loss_dict(loss_dict)
-            total = float(sum(v for v in reduced.values()))
-            if torch.isnan(torch.tensor(total)):
-                if logger:
-                    logger.critical("NaN encountered!")
-                return
-            if logger:
-                logger.info("iter %d  loss %.4f  %s  lr %.6f  %.3f s/it", iteration, total,
-                            "  ".join("%s %.4f" % (k, float(v)) for k, v in reduced.items()),
-                            optimizer.param_groups[0]["lr"], (time.time() - t0) / max(iteration - start_iter + 1, 1))
-        if checkpointer is not None and checkpoint_period > 0 and iteration % checkpoint_period == 0 and iteration > 0:
+        loss_dict = train_step(net, optimizer, images, targets)
+        _update_meters(meters, loss_dict)
+        meters.update(time=time.time() - end, data=data_time)
+        end = time.time()
+        if iteration % 20 == 0 or iteration == max_iter:
+            _log_line(logger, meters, iteration, max_iter, optimizer)
+        if checkpoint_period > 0 and iteration % checkpoint_period == 0:
             checkpointer.save("model_{:07d}".format(iteration), **arguments)
-    if checkpointer is not None:
-        checkpointer.save("model_final", **arguments)
+        if iteration == max_iter:
+            checkpointer.save("model_final", **arguments)
+    total = time.time() - start_time
+    logger.info("Total training time: {} ({:.4f} s / it)".format(str(datetime.timedelta(seconds=total)),
+                                                                 total / max(max_iter, 1)))
+
+
+def _da_batches(source_data_loader, positive_target_data_loader, negative_target_data_loader, triplet_data_loading,
+                triplet_data_aligned):
+    """-> iterator over (ImageList, list[BoxList]) with the reference's batch layout: source images first, then the
+    target (positive) and — for the triplet recipes — the auxiliary (negative) ones (trainer.py:186-226)"""
+    if triplet_data_loading and triplet_data_aligned:
+        # ONE loader over index-aligned triplets (data.build.make_data_loader_da): nine fields per batch
+        for s_img, s_tgt, p_img, p_tgt, n_img, n_tgt, _, _, _ in positive_target_data_loader:
+            yield s_img + p_img + n_img, list(s_tgt) + list(p_tgt) + list(n_tgt)
+        return
+    loaders = [source_data_loader, positive_target_data_loader]
+    if triplet_data_loading:
+        loaders.append(negative_target_data_loader)
+    for parts in zip(*loaders):
+        images, targets = parts[0][0], list(parts[0][1])
+        for img, tgt, _ in parts[1:]:
+            images = images + img
+            targets = targets + list(tgt)
+        yield images, targets
+
+
+def do_da_train(model, source_data_loader, positive_target_data_loader, negative_target_data_loader, data_loader_val,
+                optimizer, scheduler, checkpointer, device, checkpoint_period, arguments, cfg, distributed, meters,
+                triplet_data_loading=True, triplet_data_aligned=True, start_iter=0):
+    """joint source / target (/ auxiliary) loop with the reference's signature and conventions (trainer.py:150-336):
+    the iteration index starts at 0 whatever `arguments` holds (trainer.py:177; `start_iter` — not in the reference —
+    is for a true resume, tools/train_net_da.py --resume), max_iter = len(positive loader),
+    `scheduler.step_update(iteration)` after the optimizer step, a checkpoint + `scheduler.step(epoch)` every
+    `checkpoint_period` iterations except at 0, `model_final` at max_iter - 1, periodic evaluation on
+    `data_loader_val[0]` when cfg.MODEL.EVAL_USE_IN_TRAINING.  NaN losses end the run (tested at the logging period
+    and at every checkpoint instead of every iteration: the test is a host synchronisation)."""
+    from .inference import inference
+
+    logger = logging.getLogger("maskrcnn_benchmark.trainer")
+    logger.info("Start training")
+    if meters is None:
+        meters = MetricLogger(delimiter="  ")
+    if triplet_data_loading and cfg is not None and cfg.MODEL.DA_HEADS.ALIGNMENT and not triplet_data_aligned:
+        raise ValueError("MODEL.DA_HEADS.ALIGNMENT pools all three domains with the TARGET image's proposals: it needs "
+                         "the index-aligned triplet loader (make_data_loader_da / make_triplet_data_loader, "
+                         "triplet_data_aligned=True); independent per-domain loaders feed it unrelated images")
+    eval_in_training = bool(cfg.MODEL.EVAL_USE_IN_TRAINING) if cfg is not None else False
+    max_iter = len(positive_target_data_loader)
+    net = _prepare(model, optimizer, distributed)
+    start_time = end = time.time()
+    batches = _da_batches(source_data_loader, positive_target_data_loader, negative_target_data_loader,
+                          triplet_data_loading, triplet_data_aligned)
+    for iteration, (images, targets) in enumerate(batches, start_iter):
+        data_time = time.time() - end
+        arguments["iteration"] = iteration
+        images = images.to(device)
+        targets = [t.to(device) for t in targets]
+        loss_dict = train_step(net, optimizer, images, targets, scheduler, iteration)
+        total = _update_meters(meters, loss_dict)
+        meters.update(time=time.time() - end, data=data_time)
+        end = time.time()
+        at_checkpoint = checkpoint_period > 0 and iteration % checkpoint_period == 0 and iteration != 0
+        if iteration % 20 == 0 or iteration == max_iter:
+            _log_line(logger, meters, iteration, max_iter, optimizer)
+        if at_checkpoint:
+            checkpointer.save("model_{:07d}".format(iteration), **arguments)
+            scheduler.step(int(iteration / checkpoint_period))
+        if iteration == max_iter - 1:
+            checkpointer.save("model_final", **arguments)
+        if (iteration % 20 == 0 or at_checkpoint or iteration == max_iter - 1) and bool(torch.isnan(total).any()):
+            logger.critical("Loss is NaN, exiting...")
+            return
+        if eval_in_training and at_checkpoint and data_loader_val is not None:
+            synchronize()
+            with torch.no_grad():
+                inference(net, data_loader_val[0], dataset_name="[Validation]", iou_types=("bbox",),
+                          box_only=False if cfg.MODEL.RETINANET_ON else cfg.MODEL.RPN_ONLY, device=cfg.MODEL.DEVICE,
+                          expected_results=cfg.TEST.EXPECTED_RESULTS,
+                          expected_results_sigma_tol=cfg.TEST.EXPECTED_RESULTS_SIGMA_TOL, output_folder=None)
+            synchronize()
+            net.train()
+    total_time = time.time() - start_time
+    logger.info("Total training time: {} ({:.4f} s / it)".format(str(datetime.timedelta(seconds=total_time)),
+                                                                 total_time / max(max_iter, 1)))

@@ -75,9 +75,25 @@ def _load_c2_pickled_weights(file_path):
     return data["blobs"] if "blobs" in data else data
 
 
+def rename_for_deformable_convs(state_dict, stage_with_dcn):
+    """stages built with deformable 3x3 convs keep that conv under `conv2.conv` (DFConv2d) — vendored reference
+    tools/cityscapes/maskrcnn_benchmark/utils/c2_model_loading.py:146-170.  Without this the pretrained 3x3 weights of
+    those stages match no parameter and silently keep their random init."""
+    out = OrderedDict()
+    for key, value in state_dict.items():
+        for ix, with_dcn in enumerate(stage_with_dcn, 1):
+            if with_dcn and ("layer%d." % ix) in key and ".conv2." in key and ".conv2.conv." not in key \
+                    and key.rsplit(".", 1)[-1] in ("weight", "bias"):
+                key = key.replace(".conv2.", ".conv2.conv.")
+                break
+        out[key] = value
+    return out
+
+
 def load_c2_format(cfg, f):
     body = cfg.MODEL.BACKBONE.CONV_BODY
     arch = body.replace("-C4", "").replace("-C5", "").replace("-FPN", "").replace("-RETINANET", "")
     if arch not in _C2_STAGE_NAMES:
         raise KeyError("no Caffe2 weight mapping for CONV_BODY {}".format(body))
-    return dict(model=_rename_weights_for_resnet(_load_c2_pickled_weights(f), _C2_STAGE_NAMES[arch]))
+    state = _rename_weights_for_resnet(_load_c2_pickled_weights(f), _C2_STAGE_NAMES[arch])
+    return dict(model=rename_for_deformable_convs(state, cfg.MODEL.RESNETS.STAGE_WITH_DCN))

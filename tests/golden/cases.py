@@ -5,8 +5,10 @@ ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)
 _PLAIN = "configs/da_faster_rcnn/e2e_da_faster_rcnn_R_50_C4_cityscapes_to_foggy_cityscapes.yaml"
 _TRIPLET = "configs/da_faster_rcnn/e2e_triplet_da_faster_rcnn_R_50_C4_cityscapes_to_foggy_cityscapes.yaml"
 _FPN = "configs/e2e_faster_rcnn_R_50_FPN_1x.yaml"
+_C4_PLAIN = "configs/e2e_faster_rcnn_R_50_C4_1x.yaml"      # BASELINE.json configs[0]
 _CASES = {
     "fpn": (_FPN, []),
+    "c4_plain": (_C4_PLAIN, []),
     "da_plain": (_PLAIN, []),
     "da_img_only": (_PLAIN, ["MODEL.DA_HEADS.DA_INS_LOSS_WEIGHT", 0.0, "MODEL.DA_HEADS.DA_CST_LOSS_WEIGHT", 0.0]),
     "da_triplet": (_TRIPLET, []),

@@ -227,7 +227,7 @@ def test_training_entry_point_on_a_tiny_dataset(tmp_path):
            "INPUT.MIN_SIZE_TRAIN", "(96,)", "INPUT.MAX_SIZE_TRAIN", "192", "MODEL.OUTPUT_DIR", out, "MODEL.WEIGHT", ""]
     res = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
     assert res.returncode == 0, res.stderr[-2000:]
-    assert "iter 0" in res.stderr and "loss" in res.stderr
+    assert "iter: 0" in res.stderr and "loss: " in res.stderr and "loss_da_consistency: " in res.stderr
     assert os.path.exists(os.path.join(out, "model_final.pth")) and os.path.exists(os.path.join(out, "model_0000002.pth"))
     ck = torch.load(os.path.join(out, "model_final.pth"), map_location="cpu", weights_only=False)
     assert set(ck) >= {"model", "optimizer", "scheduler", "iteration"}
@@ -295,14 +295,43 @@ def test_triplet_training_entry_point_on_a_tiny_dataset(tmp_path):
            "INPUT.MIN_SIZE_TRAIN", "(96,)", "INPUT.MAX_SIZE_TRAIN", "192", "MODEL.OUTPUT_DIR", out, "MODEL.WEIGHT", ""]
     res = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
     assert res.returncode == 0, res.stderr[-2500:]
-    assert "iter 0" in res.stderr and "triplet_loss_image" in res.stderr
+    assert "iter: 0" in res.stderr and "triplet_loss_image: " in res.stderr
     assert os.path.exists(os.path.join(out, "model_final.pth"))
 
 
 @pytest.mark.gpu
-def test_training_resumes_from_a_checkpoint_given_as_weight(tmp_path):
-    """a checkpoint passed as MODEL.WEIGHT restores the model and its `iteration` (tools/train_net_triplet.py:97-101:
-    `arguments.update(checkpointer.load(cfg.MODEL.WEIGHT))`), so the loaders and the schedule continue from there"""
+def test_aligned_triplet_recipe_uses_the_aligned_loader(tmp_path):
+    """with TRIPLET_USE + ALIGNMENT the reference feeds ONE loader over index-aligned (source, target,
+    auxiliary) samples (tools/train_net_triplet.py:123-134, data/build.py:23-63); independent loaders would pool
+    unrelated images with the target's proposals.  Without --auxiliary the entry point refuses to start."""
+    import subprocess
+    import sys
+
+    rng = np.random.default_rng(4)
+    specs = {k: _write_coco(str(tmp_path), k, 4, rng, sizes=[(96, 192)] * 4) for k in ("source", "target", "auxiliary")}
+    out = str(tmp_path / "out")
+    root = os.path.dirname(HERE)
+    yaml = os.path.join(root, "configs/da_faster_rcnn/"
+                              "e2e_triplet_da_faster_rcnn_R_50_C4_cityscapes_to_foggy_cityscapes.yaml")
+    base = [sys.executable, os.path.join(root, "tools", "train_net_da.py"), "--config-file", yaml,
+            "--source", ",".join(specs["source"]), "--target", ",".join(specs["target"])]
+    opts = ["SOLVER.MAX_ITER", "2", "SOLVER.CHECKPOINT_PERIOD", "0", "DATALOADER.NUM_WORKERS", "0",
+            "INPUT.MIN_SIZE_TRAIN", "(96,)", "INPUT.MAX_SIZE_TRAIN", "192", "MODEL.OUTPUT_DIR", out, "MODEL.WEIGHT", "",
+            "MODEL.DA_HEADS.ALIGNMENT", "True", "MODEL.DA_HEADS.DA_TRIPLET_INS_WEIGHT", "1.0"]
+    res = subprocess.run(base + opts, capture_output=True, text=True, timeout=600)
+    assert res.returncode != 0 and "--auxiliary" in res.stderr
+    res = subprocess.run(base + ["--auxiliary", ",".join(specs["auxiliary"])] + opts, capture_output=True, text=True,
+                         timeout=600)
+    assert res.returncode == 0, res.stderr[-2500:]
+    assert "triplet_loss_instance: " in res.stderr and os.path.exists(os.path.join(out, "model_final.pth"))
+
+
+@pytest.mark.gpu
+def test_fine_tune_and_resume_from_a_checkpoint_given_as_weight(tmp_path):
+    """MODEL.WEIGHT = a checkpoint.  Default (the reference fork: optimizer restore commented out, loop index forced to
+    0 — checkpoint.py:62-70, trainer.py:177): weights only, the full schedule runs.  --resume: optimizer / scheduler
+    state restored and the loop continues behind the stored iteration; every saved checkpoint carries the LIVE
+    optimizer state."""
     import subprocess
     import sys
 
@@ -311,24 +340,30 @@ def test_training_resumes_from_a_checkpoint_given_as_weight(tmp_path):
     root = os.path.dirname(HERE)
     yaml = os.path.join(root, "configs/da_faster_rcnn/e2e_da_faster_rcnn_R_50_C4_cityscapes_to_foggy_cityscapes.yaml")
 
-    def run(out, weight, max_iter):
-        os.makedirs(out, exist_ok=True)
+    def run(out, weight, max_iter, extra=()):
         cmd = [sys.executable, os.path.join(root, "tools", "train_net_da.py"), "--config-file", yaml,
-               "--source", ",".join(specs["source"]), "--target", ",".join(specs["target"]),
+               "--source", ",".join(specs["source"]), "--target", ",".join(specs["target"])] + list(extra) + [
                "SOLVER.MAX_ITER", str(max_iter), "SOLVER.CHECKPOINT_PERIOD", "2", "DATALOADER.NUM_WORKERS", "0",
                "INPUT.MIN_SIZE_TRAIN", "(96,)", "INPUT.MAX_SIZE_TRAIN", "192", "MODEL.OUTPUT_DIR", out,
-               "MODEL.WEIGHT", weight]
+               "MODEL.WEIGHT", weight, "SOLVER.WARMUP_ITERS", "2"]
         res = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
         assert res.returncode == 0, res.stderr[-2500:]
         return res.stderr
 
-    first = str(tmp_path / "first")
+    first = str(tmp_path / "first" / "nested")           # the output directory is created by the entry point
     run(first, "", 3)
     ck = os.path.join(first, "model_0000002.pth")
-    assert torch.load(ck, map_location="cpu", weights_only=False)["iteration"] == 2
+    stored = torch.load(ck, map_location="cpu", weights_only=False)
+    assert stored["iteration"] == 2
+    # fine-tune: full schedule from iteration 0
     log = run(str(tmp_path / "second"), ck, 5)
-    assert "Loading checkpoint from " + ck in log
-    assert "iter 0  loss" not in log and "iter 4  loss" in log      # iterations 2, 3, 4 ran; the last one is logged
-    assert os.path.exists(os.path.join(str(tmp_path / "second"), "model_0000004.pth"))
+    assert "Loading checkpoint from " + ck in log and "iter: 0" in log
     final = torch.load(os.path.join(str(tmp_path / "second"), "model_final.pth"), map_location="cpu", weights_only=False)
     assert final["iteration"] == 4
+    # resume: iterations 3 and 4 only; momentum buffers came from the checkpoint
+    log = run(str(tmp_path / "third"), ck, 5, extra=["--resume"])
+    assert "Loading optimizer from " + ck in log and "iter: 0" not in log
+    third = torch.load(os.path.join(str(tmp_path / "third"), "model_0000004.pth"), map_location="cpu", weights_only=False)
+    assert third["iteration"] == 4
+    lr_now = third["optimizer"]["param_groups"][0]["lr"]
+    assert lr_now != stored["optimizer"]["param_groups"][0]["lr"], "the saved optimizer state must be the live one"

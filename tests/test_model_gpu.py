@@ -298,6 +298,88 @@ def test_eval_detections_match_reference_golden(device):
         np.testing.assert_allclose(d.get_field("scores").cpu().numpy(), z["det/%d/scores" % i], atol=2e-5)  # softmax of logits good to 2e-5
 
 
+@pytest.mark.parametrize("fixture", ["eval_c4_plain_small", "eval_c4_plain_full"])
+def test_config1_plain_c4_eval_matches_reference_golden(device, fixture):
+    """BASELINE.json configs[0]: e2e_faster_rcnn_R_50_C4_1x.yaml (81 classes, no DA heads, SIZE_DIVISIBILITY 0) on
+    2 x 200 x 333 and on its own 2 x 800 x 1333 inputs — nothing is a multiple of 32 (C4 maps 13 x 21 / 50 x 84, every
+    stage has an odd extent).  Eval-mode detections of the imported reference (generalized_rcnn.py:134-136;
+    tests/golden/make_golden_config1.py); the proposal selection is fed the fixture's RPN maps."""
+    from da_detect_amd.data.synthetic import make_batch
+    from da_detect_amd.modeling.detector import build_detection_model
+    from golden.cases import case_cfg
+    from golden.fill import fill_state_dict
+
+    z = np.load(os.path.join(GOLD, fixture + ".npz"))
+    c = case_cfg("c4_plain")
+    assert c.DATALOADER.SIZE_DIVISIBILITY == 0 and c.MODEL.ROI_BOX_HEAD.NUM_CLASSES == 81
+    model = build_detection_model(c)
+    assert not model.da_heads
+    model.load_state_dict(fill_state_dict(model.state_dict(), int(z["seed"])))
+    model = model.to(device).eval()
+    H, W = int(z["H"]), int(z["W"])
+    images, _ = make_batch(c, int(z["nimg"]), H, W, seed=int(z["seed"]), device=device)
+    assert tuple(images.tensors.shape[-2:]) == (H, W), "SIZE_DIVISIBILITY 0: no padding"
+    captured = {}
+    model.rpn.head.register_forward_hook(
+        lambda m, i, o: captured.update(objectness=o[0][0].detach(), deltas=o[1][0].detach()))
+    model.roi_heads.box.predictor.register_forward_hook(
+        lambda m, i, o: captured.update(class_logits=o[0].detach(), box_regression=o[1].detach()))
+    selector = model.rpn.box_selector_test
+    orig = selector.forward
+    gold_obj = [torch.from_numpy(z["objectness"]).to(device)]
+    gold_del = [torch.from_numpy(z["deltas"]).to(device)]
+    selector.forward = lambda anchors, objectness, box_regression, tg=None: orig(anchors, gold_obj, gold_del, tg)
+    try:
+        with torch.no_grad():
+            dets = model(images)
+    finally:
+        selector.forward = orig
+    assert tuple(captured["objectness"].shape) == z["objectness"].shape
+    np.testing.assert_allclose(captured["objectness"].cpu().numpy(), z["objectness"], rtol=1e-4, atol=1e-4)
+    np.testing.assert_allclose(captured["deltas"].cpu().numpy(), z["deltas"], rtol=1e-4, atol=1e-4)
+    np.testing.assert_allclose(captured["class_logits"].cpu().numpy(), z["class_logits"], rtol=1e-4, atol=5e-5)
+    rows = int(z["box_regression_rows"])
+    np.testing.assert_allclose(captured["box_regression"].cpu().numpy()[::rows], z["box_regression"], rtol=1e-4,
+                               atol=5e-5)
+    assert len(dets) == int(z["nimg"])
+    for i, d in enumerate(dets):
+        assert d.size == (W, H)
+        assert np.array_equal(d.get_field("labels").cpu().numpy(), z["det/%d/labels" % i])
+        np.testing.assert_allclose(d.bbox.cpu().numpy(), z["det/%d/boxes" % i], atol=5e-3)
+        np.testing.assert_allclose(d.get_field("scores").cpu().numpy(), z["det/%d/scores" % i], atol=2e-5)
+
+
+def test_config1_plain_c4_training_step_at_800x1333(device):
+    """the same configuration in training mode at its own size.  The reference cannot run it (UnboundLocalError at
+    generalized_rcnn.py:150) so there is no golden: losses finite, every trainable parameter gets a
+    finite gradient, and the step is reproducible."""
+    from da_detect_amd.data.synthetic import make_batch
+    from da_detect_amd.engine.trainer import train_step
+    from da_detect_amd.modeling.detector import build_detection_model
+    from da_detect_amd.parallel.reducer import BucketedGradReducer
+    from da_detect_amd.solver import make_optimizer
+    from golden.cases import case_cfg
+    from golden.fill import fill_state_dict
+
+    c = case_cfg("c4_plain")
+    model = build_detection_model(c)
+    model.load_state_dict(fill_state_dict(model.state_dict(), 1))
+    model = model.to(device).train()
+    images, targets = make_batch(c, 2, 800, 1333, seed=1, device=device)
+    for t in targets:     # plain training: every image is labelled
+        t.add_field("is_source", torch.ones_like(t.get_field("is_source")))
+        t.add_field("labels", t.get_field("labels") % 80 + 1)
+    opt = make_optimizer(c, model)
+    opt.attach_reducer(BucketedGradReducer([p for p in model.parameters() if p.requires_grad]))
+    torch.manual_seed(1)
+    losses = train_step(model, opt, images, targets)
+    assert set(losses) == {"loss_classifier", "loss_box_reg", "loss_objectness", "loss_rpn_box_reg"}
+    assert all(bool(torch.isfinite(v)) for v in losses.values()), losses
+    for n, p in model.named_parameters():
+        if p.requires_grad:
+            assert p.grad is not None and bool(torch.isfinite(p.grad).all()) and float(p.grad.abs().sum()) > 0, n
+
+
 def test_eval_without_injection_and_rpn_only(device):
     """no injection: same number of detections per image and score multiset within fp32 noise; RPN_ONLY eval
     returns the proposals (generalized_rcnn.py:141-143)"""

@@ -23,7 +23,7 @@ import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
 from da_detect_amd.config import cfg  # noqa: E402
-from da_detect_amd.data.build import make_data_loader  # noqa: E402
+from da_detect_amd.data.build import make_test_data_loader  # noqa: E402
 from da_detect_amd.data.datasets import COCODataset  # noqa: E402
 from da_detect_amd.data.transforms import build_transforms  # noqa: E402
 from da_detect_amd.engine.inference import inference  # noqa: E402
@@ -65,7 +65,7 @@ def main():
     device = torch.device("cuda", local_rank)
 
     model = build_detection_model(c).to(device)
-    output_dir = args.output_dir or c.OUTPUT_DIR
+    output_dir = args.output_dir or c.MODEL.OUTPUT_DIR      # the tree has no top-level OUTPUT_DIR (defaults.py:427)
     checkpointer = DetectronCheckpointer(c, model, save_dir=output_dir)
     checkpointer.load(args.ckpt if args.ckpt else c.MODEL.WEIGHT)
     model.eval()
@@ -73,7 +73,7 @@ def main():
     ann, root = args.dataset
     dataset = COCODataset(ann, root, remove_images_without_annotations=False,
                           transforms=build_transforms(c, is_train=False))
-    loader = make_data_loader(c, dataset, is_train=False, is_distributed=world > 1)
+    loader = make_test_data_loader(c, dataset, is_distributed=world > 1)
     folder = None
     if output_dir:
         folder = os.path.join(output_dir, "inference", os.path.splitext(os.path.basename(ann))[0])

@@ -25,7 +25,7 @@ import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
 from da_detect_amd.config import cfg  # noqa: E402
-from da_detect_amd.data.build import make_da_data_loaders  # noqa: E402
+from da_detect_amd.data.build import make_da_data_loaders, make_triplet_data_loader  # noqa: E402
 from da_detect_amd.engine.trainer import do_da_train, enable_overlapped_rpn_backward, train_step  # noqa: E402
 from da_detect_amd.modeling.detector import build_detection_model  # noqa: E402
 from da_detect_amd.parallel.reducer import BucketedGradReducer  # noqa: E402
@@ -33,6 +33,7 @@ from da_detect_amd.solver import make_optimizer  # noqa: E402
 from da_detect_amd.solver.build import make_cosine_lr_scheduler  # noqa: E402
 from da_detect_amd.utils.checkpoint import DetectronCheckpointer  # noqa: E402
 from da_detect_amd.utils.comm import get_rank, synchronize  # noqa: E402
+from da_detect_amd.utils.metric_logger import MetricLogger  # noqa: E402
 
 
 def setup_seed(seed):
@@ -55,6 +56,10 @@ def main():
     ap.add_argument("--target", type=_pair)
     ap.add_argument("--auxiliary", type=_pair)
     ap.add_argument("--synthetic", type=int, default=0, help="run N steps on seeded synthetic batches instead of datasets")
+    ap.add_argument("--resume", action="store_true",
+                    help="MODEL.WEIGHT is a checkpoint of THIS run: restore optimizer / scheduler state too and shorten "
+                         "the loaders by its iteration (default: fine-tune — weights only, full schedule, as the "
+                         "reference fork does with its optimizer restore commented out)")
     ap.add_argument("opts", nargs=argparse.REMAINDER, help="KEY VALUE overrides of the yaml")
     args = ap.parse_args()
 
@@ -82,18 +87,30 @@ def main():
     optimizer.attach_reducer(reducer)
 
     output_dir = cfg.MODEL.OUTPUT_DIR
+    if output_dir and get_rank() == 0:
+        os.makedirs(output_dir, exist_ok=True)       # train_net_triplet.py:311-312
     checkpointer = DetectronCheckpointer(cfg, model, optimizer, scheduler, output_dir, save_to_disk=get_rank() == 0)
     weight = cfg.MODEL.WEIGHT
     arguments = {"iteration": 0}
-    if weight and not weight.startswith("catalog://") and os.path.exists(weight):
-        arguments.update(checkpointer.load(weight))
-    else:
-        logger.warning("MODEL.WEIGHT %r is not a local file: starting from the module initialisers", weight)
+    try:
+        extra = checkpointer.load(weight, load_optimizer=args.resume) if weight else {}
+    except FileNotFoundError as e:
+        if not args.synthetic:
+            raise
+        logger.warning("%s: starting from the module initialisers", e)
+        extra = {}
+    # the stored optimizer / scheduler state never travels into `arguments` (it would be written back, stale, by every
+    # later checkpoint); a stored iteration only counts on --resume
+    extra.pop("optimizer", None)
+    extra.pop("scheduler", None)
+    if not args.resume:
+        extra.pop("iteration", None)
+    arguments.update(extra)
 
     if args.synthetic:
         from da_detect_amd.data.synthetic import make_batch
 
-        if not (weight and os.path.exists(weight)):
+        if not (weight and os.path.exists(weight)):   # catalog:// names that resolve were loaded above
             # no pretrained weights: the variance-preserving seeded init of bench.py — a ResNet with identity FrozenBN
             # statistics and the modules' own initialisers blows up within a few steps (R-101-FPN + DCN: NaN at step 2)
             import bench
@@ -112,10 +129,24 @@ def main():
 
     specs = {k: v for k, v in (("source", args.source), ("target", args.target), ("auxiliary", args.auxiliary)) if v}
     assert "source" in specs and "target" in specs, "--source and --target are required (or --synthetic N)"
-    loaders = make_da_data_loaders(cfg, specs, is_distributed=world > 1, start_iter=arguments["iteration"])
-    do_da_train(model, loaders[0], loaders[1], optimizer, scheduler, checkpointer, device,
-                cfg.SOLVER.CHECKPOINT_PERIOD, arguments, cfg=cfg,
-                negative_data_loader=loaders[2] if len(loaders) > 2 else None, logger=logger)
+    triplet = bool(cfg.MODEL.DA_HEADS.TRIPLET_USE)
+    aligned = triplet and bool(cfg.MODEL.DA_HEADS.ALIGNMENT)
+    if triplet and "auxiliary" not in specs:
+        raise SystemExit("MODEL.DA_HEADS.TRIPLET_USE needs --auxiliary (the rainy / negative domain)")
+    # --resume: the checkpoint holds the last COMPLETED iteration; the loaders and the loop continue behind it
+    start = arguments["iteration"] + 1 if args.resume and "iteration" in extra else 0
+    if aligned:
+        # train_net_triplet.py:123-134: ALIGNMENT pools the three domains with the TARGET image's proposals, which is
+        # only meaningful for index-aligned renderings of one scene -> ONE loader over aligned triplets
+        source = negative = []
+        positive = make_triplet_data_loader(cfg, specs, is_distributed=world > 1, start_iter=start)
+    else:
+        loaders = make_da_data_loaders(cfg, specs, is_distributed=world > 1, start_iter=start)
+        source, positive = loaders[0], loaders[1]
+        negative = loaders[2] if triplet else []
+    do_da_train(model, source, positive, negative, None, optimizer, scheduler, checkpointer, device,
+                cfg.SOLVER.CHECKPOINT_PERIOD, arguments, cfg, world > 1, MetricLogger(delimiter="  "),
+                triplet_data_loading=triplet, triplet_data_aligned=aligned, start_iter=start)
 
 
 if __name__ == "__main__":
