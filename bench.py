@@ -103,9 +103,10 @@ def build(cfg_path, device, seed, overrides=()):
     return c, model, opt, reducer
 
 
-def cpu_baseline(cfg_path, seed, budget_s=25.0):
+def cpu_baseline(cfg_path, seed, budget_s=90.0):
     """the CPU oracle (oracle/model_ref.py: a torch-CPU fp32 restatement of the same training step, with the
-    C restatements of NMS / ROIAlign) timed on the host cores on a bounded sample of the same workload."""
+    C restatements of NMS / ROIAlign) timed on the host cores on ONE step of the same 2 x 1024 x 2048 batch (~25 s on
+    the GPU box's 64-core EPYC, plus a 2 s warm-up step)."""
     from oracle import model_ref
 
     return model_ref.timed_training_sample(os.path.join(ROOT, cfg_path), seed, HEIGHT, WIDTH, IMAGES_PER_GPU,
@@ -128,6 +129,30 @@ def pmc_traffic(kernel_name, gemm_mode):
     return None, None
 
 
+def self_spawn(n):
+    """one process per GPU on this node, rendezvous on 127.0.0.1 at a free port; rank 0 inherits stdout (the JSON
+    line), the other ranks' stdout is dropped, every rank's stderr is inherited.  Returns the worst exit code."""
+    import socket
+    import subprocess
+
+    have = torch.cuda.device_count()
+    if have < n and os.environ.get("DADET_BENCH_SHARE_GPU", "0") != "1":
+        print("bench.py --gpus %d: only %d HIP device(s) visible (DADET_BENCH_SHARE_GPU=1 runs every rank on device 0 "
+              "over gloo, a functional check only)" % (n, have), file=sys.stderr)
+        return 2
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    procs = []
+    for rank in range(n):
+        env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=None if rank == 0 else subprocess.DEVNULL))
+    codes = [p.wait() for p in procs]
+    return max(abs(c) for c in codes)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -146,6 +171,10 @@ def main():
                     help="3: fp32 operands as 3 bf16 terms, 6 bf16 MFMAs per K=16 (fp32-class accuracy, default); "
                          "0: exact fp32 MFMA; 2: 2-term split (~2^-16 products)")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # plain `python bench.py --gpus N`: start the N ranks ourselves (what torch.distributed.run would do)
+        raise SystemExit(self_spawn(args.gpus))
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -292,7 +321,7 @@ def main():
             try:
                 cpu = cpu_baseline(YAML, seed=100) if args.workload == "img_only" and args.image_hw is None else None
             except Exception as e:  # the baseline is reported, never required for the GPU number
-                cpu = {"value": None, "unit": "images/s", "cores": os.cpu_count(), "kind": "port",
+                cpu = {"value": None, "unit": "images/s", "cores": min(os.cpu_count() or 1, 64), "kind": "port",
                        "sample": "failed: %r" % (e,)}
         line = {
             "metric": "train images/sec, DA-Faster-RCNN R-50 Cityscapes->Foggy",

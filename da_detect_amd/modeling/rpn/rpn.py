@@ -102,6 +102,10 @@ class RPNModule(torch.nn.Module):
         self._feature_grads = [f.grad for f in head_in]
         side = side_stream(dev)
         side.wait_event(head_done)
+        # the head's maps were allocated on the compute stream and are released when forward() returns: without this the
+        # caching allocator may hand their blocks to a later compute-stream allocation while the side stream still reads
+        # them
+        record([objectness, rpn_box_regression], side)
         with torch.cuda.stream(side), torch.no_grad():
             boxes = self.box_selector_train(anchors, [o.detach() for o in objectness],
                                             [r.detach() for r in rpn_box_regression], targets)

@@ -1,0 +1,133 @@
+"""The data-parallel path of the REAL model with world_size 2 (reference
+tools/train_net_triplet.py:83-88, 304-309): two ranks share cuda:0 and exchange gradients over gloo (a functional rig
+— one GPU is what the test box has; with one rank per GPU the only difference is the backend string "nccl" = RCCL).
+
+Each rank runs the default training schedule (overlapped RPN backward, early image-level DA backward where the recipe
+allows it, weight gradients accumulated straight into the reducer's flat buckets, fused SGD) on its own seeded batch.
+Checked: (1) what every bucket holds after finalize() is the MEAN over ranks of what the ranks held locally when the
+collective was issued; (2) every parameter received its gradient before its bucket was reduced (the local snapshot
+equals the same step run single-process on that rank's batch); (3) after 3 steps the ranks' parameters are bit-identical
+and differ from the initial ones."""
+import os
+import socket
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _build(case, seed, device):
+    from da_detect_amd.modeling.detector import build_detection_model
+    from da_detect_amd.solver import make_optimizer
+    from golden.cases import case_cfg
+    from golden.fill import fill_state_dict
+
+    c = case_cfg(case)
+    model = build_detection_model(c)
+    model.load_state_dict(fill_state_dict(model.state_dict(), seed))
+    model = model.to(device).train()
+    return c, model, make_optimizer(c, model)
+
+
+def _worker(rank, world, port, case, out):
+    import sys
+
+    here = os.path.dirname(os.path.abspath(__file__))
+    for p in (os.path.dirname(here), here):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import torch.distributed as dist
+
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda", 0)
+    if world > 1:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    from da_detect_amd.data.synthetic import make_batch
+    from da_detect_amd.engine.trainer import enable_overlapped_rpn_backward, train_step
+    from da_detect_amd.parallel.reducer import BucketedGradReducer
+
+    c, model, opt = _build(case, 3, dev)
+    reducer = BucketedGradReducer([p for p in model.parameters() if p.requires_grad], bucket_bytes=8 << 20)
+    reducer.broadcast_parameters(0)
+    opt.attach_reducer(reducer)
+    enable_overlapped_rpn_backward(model)
+    nimg = 3 if c.MODEL.DA_HEADS.TRIPLET_USE else 2
+    batch_rank = rank if world > 1 else int(os.environ.get("DADET_TEST_BATCH_RANK", "0"))
+    images, targets = make_batch(c, nimg, 192, 320, seed=100 + batch_rank, device=dev)
+    local = {}
+    orig = reducer._all_reduce
+
+    def spy(flat):
+        local[flat.data_ptr()] = flat.detach().clone()      # what THIS rank holds when the collective is issued
+        return orig(flat)
+
+    reducer._all_reduce = spy
+    p0 = [p.detach().clone() for p in reducer.params]
+    torch.manual_seed(50 + batch_rank)                      # device sampler seeds: per-rank stream
+    train_step(model, opt, images, targets)
+    torch.cuda.synchronize()
+    after = [b["flat"].detach().clone().cpu() for b in reducer.buckets]
+    if world > 1:
+        snaps = [local[b["flat"].data_ptr()].cpu() for b in reducer.buckets]
+    else:
+        snaps = after                                        # single process: nothing is reduced
+    reducer._all_reduce = orig
+    for it in range(1, 3):
+        torch.manual_seed(50 + batch_rank + 10 * it)
+        train_step(model, opt, images, targets)
+    torch.cuda.synchronize()
+    moved = sum(int(not torch.equal(a, p.detach())) for a, p in zip(p0, reducer.params))
+    params = torch.cat([p.detach().reshape(-1).cpu() for p in reducer.params])
+    out.put((rank, [s.numpy() for s in snaps], [a.numpy() for a in after], params.numpy(), moved,
+             len(reducer.buckets), len(reducer.touched)))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def _run(world, case, batch_rank=0):
+    import torch.multiprocessing as mp
+
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    os.environ["DADET_TEST_BATCH_RANK"] = str(batch_rank)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    procs = [ctx.Process(target=_worker, args=(r, world, port, case, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = sorted([q.get(timeout=600) for _ in range(world)], key=lambda r: r[0])
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    return got
+
+
+@pytest.mark.parametrize("case", ["da_img_only", "da_plain"])
+def test_two_ranks_real_model_bucket_means_and_sync(device, case):
+    import numpy as np
+
+    r0, r1 = _run(2, case)
+    n_buckets = r0[5]
+    assert n_buckets >= 4 and r0[6] == r1[6] > 50
+    for b in range(n_buckets):
+        mean = (r0[1][b].astype(np.float64) + r1[1][b].astype(np.float64)) / 2
+        for r in (r0, r1):      # (1) bucket contents after finalize() == mean of the per-rank local gradients
+            np.testing.assert_allclose(r[2][b], mean, rtol=1e-6, atol=1e-9 + 1e-6 * float(np.abs(mean).max()))
+        assert float(np.abs(r0[1][b] - r1[1][b]).max()) > 0, "ranks must have seen different batches"
+    # (3) identical parameters on both ranks after 3 steps, and they moved
+    assert np.array_equal(r0[3], r1[3]), "parameters differ between ranks"
+    assert r0[4] == r1[4] and r0[4] > 50
+    # (2) nothing was reduced too early: rank 1's local snapshot == the same step run alone on rank 1's batch
+    solo, = _run(1, case, batch_rank=1)
+    for b in range(n_buckets):
+        scale = float(np.abs(solo[2][b]).max())
+        np.testing.assert_allclose(r1[1][b], solo[2][b], rtol=1e-4, atol=1e-6 * scale + 1e-12)
