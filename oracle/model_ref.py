@@ -337,8 +337,14 @@ def rpn_losses(objectness, deltas, anchors, image_sizes, gts, cfg, draws=None, r
     sampled = torch.cat([pos_inds, neg_inds])
     if record is not None:
         record.update(rpn_pos_inds=pos_inds, rpn_neg_inds=neg_inds)
-    obj = flatten_hwa(objectness, 1).reshape(-1)
-    reg = flatten_hwa(deltas, 4).reshape(-1, 4)
+    if isinstance(objectness, (list, tuple)):
+        # several feature levels: per image the levels are concatenated in order (rpn/utils.py:17-45
+        # concat_box_prediction_layers), `anchors` is the same concatenation of the per-level anchor grids
+        obj = torch.cat([flatten_hwa(o, 1) for o in objectness], dim=1).reshape(-1)
+        reg = torch.cat([flatten_hwa(d, 4) for d in deltas], dim=1).reshape(-1, 4)
+    else:
+        obj = flatten_hwa(objectness, 1).reshape(-1)
+        reg = flatten_hwa(deltas, 4).reshape(-1, 4)
     labels, reg_targets = torch.cat(labels), torch.cat(reg_targets)
     box_loss = smooth_l1(reg[pos_inds], reg_targets[pos_inds], 1.0 / 9) / sampled.numel()
     obj_loss = F.binary_cross_entropy_with_logits(obj[sampled], labels[sampled])
@@ -660,6 +666,49 @@ def backbone_fpn(images, sd, blocks=(3, 4, 6, 3)):
     return out
 
 
+def fpn_anchors(objectness, cfg):
+    """per-level anchor grids of a pyramid (anchor_generator.py:73-125: one size per level, all aspect ratios)"""
+    rpn = cfg.MODEL.RPN
+    return [grid_anchors(o.shape[2], o.shape[3], rpn.ANCHOR_STRIDE[l],
+                         cell_anchors(rpn.ANCHOR_STRIDE[l], (rpn.ANCHOR_SIZES[l],), rpn.ASPECT_RATIOS))
+            for l, o in enumerate(objectness)]
+
+
+def rpn_proposals_fpn_train(objectness, deltas, image_sizes, gts, cfg):
+    """training-mode RPNPostProcessor over pyramid levels (rpn/inference.py:124-181): per level and image top
+    PRE_NMS_TOP_N_TRAIN -> decode/clip -> NMS -> first POST_NMS_TOP_N_TRAIN; levels concatenated per image; then
+    FPN_POST_NMS_TOP_N_TRAIN best scores over the WHOLE BATCH (:161-172 — a mask, so every image keeps its survivors
+    in their level-major order); ground-truth boxes appended with objectness 1 (:51-74).  Ties: lower position first."""
+    rpn = cfg.MODEL.RPN
+    N = objectness[0].shape[0]
+    per_image = [[] for _ in range(N)]
+    for lvl, (obj, dlt, anchors) in enumerate(zip(objectness, deltas, fpn_anchors(objectness, cfg))):
+        scores = flatten_hwa(obj, 1).reshape(N, -1).sigmoid()
+        d = flatten_hwa(dlt, 4)
+        pre = min(rpn.PRE_NMS_TOP_N_TRAIN, scores.shape[1])
+        for i in range(N):
+            s, order = torch.sort(scores[i], descending=True, stable=True)
+            s, order = s[:pre], order[:pre]
+            h, w = image_sizes[i]
+            boxes = torch.from_numpy(O.decode_clip(d[i][order].numpy(), anchors[order].numpy(),
+                                                   (1.0, 1.0, 1.0, 1.0), math.log(1000.0 / 16), w, h))
+            keep = torch.from_numpy(O.nms(boxes.numpy(), s.numpy(), rpn.NMS_THRESH, 0))[:rpn.POST_NMS_TOP_N_TRAIN]
+            per_image[i].append((boxes[keep], s[keep]))
+    cat = [(torch.cat([b for b, _ in lv]), torch.cat([x for _, x in lv])) for lv in per_image]
+    all_scores = torch.cat([s for _, s in cat])
+    k = min(rpn.FPN_POST_NMS_TOP_N_TRAIN, all_scores.numel())
+    _, inds = torch.sort(all_scores, descending=True, stable=True)
+    mask = torch.zeros_like(all_scores, dtype=torch.bool)
+    mask[inds[:k]] = True
+    out = []
+    for (boxes, s), m, gt in zip(cat, mask.split([len(s) for _, s in cat]), gts):
+        boxes, s = boxes[m], s[m]
+        boxes = torch.cat([boxes, gt["boxes"]], 0)
+        s = torch.cat([s, torch.ones(len(gt["boxes"]))], 0)
+        out.append((boxes, s))
+    return out
+
+
 def rpn_proposals_fpn(objectness, deltas, image_sizes, cfg):
     """test-mode RPNPostProcessor over pyramid levels (rpn/inference.py:76-181): per level top PRE_NMS_TOP_N_TEST
     -> decode/clip -> NMS -> first POST_NMS_TOP_N_TEST; concatenate levels; per image top FPN_POST_NMS_TOP_N_TEST
@@ -792,7 +841,7 @@ def timed_training_sample(cfg_path, seed, height, width, images_per_step, init_f
             "kind": "port"}
     what = ("1 training step (fwd+bwd+SGD) of oracle/model_ref.py; torch CPU fp32 convs on %d host threads, "
             "single-thread C NMS/ROIAlign like the reference's CPU operators" % cores)
-    if spent + 14.0 * dt < budget_s:
+    if spent < budget_s / 3.0:      # the warm-up step is dominated by first-use costs (~10 s): it predicts nothing
         full = one_step(height, width)
         samples.append({"image_hw": [height, width], "seconds": round(full, 3)})
         base.update(value=round(images_per_step / full, 4), seconds=round(full, 2), samples=samples,

