@@ -593,6 +593,23 @@ def sample_anchors(labels, regression_targets, cap, max_pos, seed, index_offset,
     return out
 
 
+TOPK_SORTED_MAX = 16384
+
+
+def topk_sorted(scores, k):
+    """scores [rows, n] -> (values [rows, k], indices [rows, k] int64): the k largest per row, descending, equal scores
+    by ascending index — torch.sort(scores, dim=1, descending=True, stable=True) cut to k columns, in ONE launch
+    (dadet_topk_sorted)"""
+    _dev(scores, "scores")
+    assert scores.dim() == 2 and scores.stride(1) == 1 and 0 < k <= min(scores.shape[1], TOPK_SORTED_MAX)
+    rows, n = scores.shape
+    vals = torch.empty((rows, k), dtype=torch.float32, device=scores.device)
+    idx = torch.empty((rows, k), dtype=torch.int64, device=scores.device)
+    _lib.call("dadet_topk_sorted", _p(scores), rows, n, ctypes.c_int64(scores.stride(0)), int(k), _p(vals), _p(idx),
+              _stream())
+    return vals, idx
+
+
 def rpn_anchor_targets(anchors, visible, gt_boxes, high_threshold, low_threshold):
     """-> (labels float [A] in {1, 0, -1}, regression_targets [A,4]); see dadet_rpn_anchor_targets"""
     _dev(anchors, "anchors"), _dev(gt_boxes, "gt_boxes")

@@ -22,6 +22,9 @@ from ..box_coder import BoxCoder
 from .utils import permute_and_flatten
 
 
+_TOPK_KERNEL = __import__("os").environ.get("DADET_TOPK_KERNEL", "1") == "1"   # 0: torch.sort (A/B switch)
+
+
 class RPNPostProcessor(torch.nn.Module):
     def __init__(self, pre_nms_top_n, post_nms_top_n, nms_thresh, min_size, box_coder=None,
                  fpn_post_nms_top_n=None):
@@ -53,9 +56,13 @@ class RPNPostProcessor(torch.nn.Module):
         deltas_all = permute_and_flatten(box_regression, N, A, 4, H, W).contiguous()  # [N, HWA, 4]
         num_anchors = A * H * W
         pre_nms_top_n = min(self.pre_nms_top_n, num_anchors)
-        sorted_scores, order = torch.sort(scores_all, dim=1, descending=True, stable=True)
-        sorted_scores = sorted_scores[:, :pre_nms_top_n].contiguous()
-        topk_idx = order[:, :pre_nms_top_n].contiguous()
+        if scores_all.is_cuda and pre_nms_top_n <= _C.TOPK_SORTED_MAX and _TOPK_KERNEL:
+            # radix select + in-LDS sort of the selected scores, one launch for the batch (csrc/topk.hip)
+            sorted_scores, topk_idx = _C.topk_sorted(scores_all, pre_nms_top_n)
+        else:
+            sorted_scores, order = torch.sort(scores_all, dim=1, descending=True, stable=True)
+            sorted_scores = sorted_scores[:, :pre_nms_top_n].contiguous()
+            topk_idx = order[:, :pre_nms_top_n].contiguous()
 
         # The greedy sweep of one image is a single workgroup: images are independent, so every second image runs
         # on the side stream and the sweeps overlap; the kept counts come back in ONE host round trip.

@@ -244,6 +244,13 @@ int dadet_sample_anchors(const float* labels, const float* regression_targets, i
                          uint64_t seed, int64_t index_offset, int64_t* pos_inds_out, int64_t* neg_inds_out,
                          float* regression_targets_pos_out, int* counts_out, void* stream);
 
+/* Sorted top-k of every row of scores[rows][row_stride] (first n entries of a row are valid), k <= min(n, 16384): the k
+ * largest scores in descending order, EQUAL scores by ascending index (= torch.sort(descending=True, stable=True)[:k]).
+ * Replaces objectness.topk(pre_nms_top_n, dim=1, sorted=True) of RPNPostProcessor.forward_for_single_feature_map
+ * (modeling/rpn/inference.py:93-95).  out_scores [rows][k], out_idx [rows][k] int64.  One workgroup per row. */
+int dadet_topk_sorted(const float* scores, int rows, int n, int64_t row_stride, int k, float* out_scores,
+                      int64_t* out_idx, void* stream);
+
 /* RPN anchor labelling in two launches: replaces boxlist_iou + Matcher(high, low, allow_low_quality_matches=True) +
  * the label rules of RPNLossComputation.prepare_targets (modeling/rpn/loss.py:57-98, modeling/matcher.py:42-112) +
  * BoxCoder((1,1,1,1)).encode.  visible[a] != 0: anchor inside the image.  labels: 1 matched, 0 below the low threshold,
