@@ -11,6 +11,7 @@ NHWC), weights are logical [Cout,Cin,KH,KW] in channels_last (physical [Cout,KH,
 other layout are converted (one copy); outputs are always channels_last.
 """
 import contextlib
+import os
 import ctypes
 import time
 
@@ -178,9 +179,24 @@ def roi_align_forward(input, rois, spatial_scale, pooled_height, pooled_width, s
     rois = rois.contiguous()
     out = torch.empty((R, C, pooled_height, pooled_width), dtype=torch.float32, device=input.device,
                       memory_format=CL)
-    _lib.call("dadet_roi_align_forward", _p(x), _p(rois), _p(out), B, C, H, W, R, pooled_height,
-              pooled_width, float(spatial_scale), int(sampling_ratio), _stream())
+    if ROI_ALIGN_WORKSPACE:
+        ws = _roi_workspace(B, H, W, R, input.device)
+        _lib.call("dadet_roi_align_forward_ws", _p(x), _p(rois), _p(out), B, C, H, W, R, pooled_height, pooled_width,
+                  float(spatial_scale), int(sampling_ratio), _p(ws), ctypes.c_size_t(ws.numel()), _stream())
+    else:
+        _lib.call("dadet_roi_align_forward", _p(x), _p(rois), _p(out), B, C, H, W, R, pooled_height,
+                  pooled_width, float(spatial_scale), int(sampling_ratio), _stream())
     return out
+
+
+# forward: ROIs processed in spatial (Z-order) order through a scratch buffer; False = the plain entry point
+ROI_ALIGN_WORKSPACE = os.environ.get("DADET_ROI_WORKSPACE", "1") == "1"
+
+
+def _roi_workspace(B, H, W, R, device):
+    nbytes = ctypes.c_size_t(0)
+    _lib.call("dadet_roi_align_workspace_bytes", B, H, W, R, ctypes.byref(nbytes))
+    return _workspace(nbytes.value, device)
 
 
 def roi_align_backward(grad, rois, spatial_scale, pooled_height, pooled_width, batch_size, channels,

@@ -91,12 +91,16 @@ __device__ inline float sample_coord(float start, int p, float bin, int i, int g
 template <int VEC>
 __global__ __launch_bounds__(256) void roi_align_fwd_kernel(
     const float* __restrict__ input, const float* __restrict__ rois, float* __restrict__ output, int C,
-    int H, int W, int pooled_h, int pooled_w, float scale, int sampling_ratio) {
+    int H, int W, int pooled_h, int pooled_w, float scale, int sampling_ratio, const int* __restrict__ order) {
   // XCD-aware order: the 14 bin rows of one ROI read overlapping feature rows; hardware deals consecutive workgroup
   // ids to the 8 XCDs round-robin, which made every XCD's L2 fetch the same rows again (PMC: 1.95 GB through the
   // fabric for 0.48 GB of algorithmic traffic).  The remap gives each XCD a contiguous range of (roi, ph).
+  // `order` (roi_order_kernel): the ROIs in Z-order of their centres, image by image.  Proposals arrive in score order,
+  // i.e. spatially random: every XCD then pulls the whole feature map through its 4 MB L2 (PMC r01: 1.33 GB fetched +
+  // written per launch for 0.48 GB algorithmic).  With spatially sorted ROIs the contiguous range of an XCD covers a
+  // compact region and neighbouring ROIs share the rows already in L2.  Outputs stay at their original row r.
   const int wg = xcd_remap(blockIdx.x, gridDim.x);
-  const int r = wg / pooled_h;
+  const int r = order ? order[wg / pooled_h] : wg / pooled_h;
   const int ph = wg % pooled_h;
   const RoiGeom g = roi_geometry(rois + (size_t)r * 5, scale, pooled_h, pooled_w, sampling_ratio);
   const float* __restrict__ img = input + (size_t)g.batch * H * W * C;
@@ -146,6 +150,55 @@ __global__ __launch_bounds__(256) void roi_align_fwd_kernel(
       }
     }
   }
+}
+
+// ROI processing order of the forward kernel: ascending (image, Morton code of the ROI centre in feature pixels), ties by
+// ROI index.  One workgroup; bitonic sort of (key << 32 | r) in LDS.
+__device__ inline unsigned spread_bits(unsigned v) {   // abcdefgh -> 0a0b0c0d0e0f0g0h (up to 16 bits)
+  v &= 0xFFFFu;
+  v = (v | (v << 8)) & 0x00FF00FFu;
+  v = (v | (v << 4)) & 0x0F0F0F0Fu;
+  v = (v | (v << 2)) & 0x33333333u;
+  v = (v | (v << 1)) & 0x55555555u;
+  return v;
+}
+
+__global__ __launch_bounds__(1024) void roi_order_kernel(const float* __restrict__ rois, int R, int N, float scale, int H,
+                                                         int W, int* __restrict__ order) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  unsigned long long* keys = reinterpret_cast<unsigned long long*>(smem);   // [N], N = pow2 >= R
+  for (int i = threadIdx.x; i < N; i += blockDim.x) {
+    unsigned long long k = ~0ull;
+    if (i < R) {
+      const float* q = rois + (size_t)i * 5;
+      const float cx = 0.5f * (q[1] + q[3]) * scale, cy = 0.5f * (q[2] + q[4]) * scale;
+      const unsigned ux = (unsigned)fminf(fmaxf(cx, 0.f), (float)(W - 1));
+      const unsigned uy = (unsigned)fminf(fmaxf(cy, 0.f), (float)(H - 1));
+      const unsigned b = (unsigned)fmaxf(q[0], 0.f);
+      k = ((unsigned long long)((b << 24) | (spread_bits(uy >> 1) << 1) | spread_bits(ux >> 1)) << 32) | (unsigned)i;
+    }
+    keys[i] = k;
+  }
+  __syncthreads();
+  for (int kk = 2; kk <= N; kk <<= 1)
+    for (int j = kk >> 1; j > 0; j >>= 1) {
+      for (int i = threadIdx.x; i < N; i += blockDim.x) {
+        const int p = i ^ j;
+        if (p > i) {
+          const unsigned long long a = keys[i], b = keys[p];
+          if ((a > b) == ((i & kk) == 0)) { keys[i] = b; keys[p] = a; }
+        }
+      }
+      __syncthreads();
+    }
+  for (int i = threadIdx.x; i < R; i += blockDim.x) order[i] = (int)(unsigned)keys[i];
+}
+
+// conservative "ROI r can contribute to the 2x2 pixel tile at (y0, x0)" test of the gather backward
+__device__ inline bool roi_touches_tile(const RoiGeom& g, int pooled_h, int pooled_w, int y0, int x0) {
+  const float roi_h = g.bin_h * (float)pooled_h, roi_w = g.bin_w * (float)pooled_w;
+  return g.start_h <= (float)y0 + 2.f && g.start_h + roi_h >= (float)y0 - 1.f && g.start_w <= (float)x0 + 2.f &&
+         g.start_w + roi_w >= (float)x0 - 1.f;
 }
 
 // backward: scatter g * w / count to the four neighbours with hardware fp32 atomics
@@ -412,9 +465,7 @@ __global__ __launch_bounds__(256) void roi_align_bwd_list_kernel(
     bool hit = false;
     if (r < R) {
       const RoiGeom g = roi_geometry(rois + (size_t)r * 5, scale, pooled_h, pooled_w, sampling_ratio);
-      const float roi_h = g.bin_h * (float)pooled_h, roi_w = g.bin_w * (float)pooled_w;
-      hit = g.batch == b && g.start_h <= (float)y0 + 2.f && g.start_h + roi_h >= (float)y0 - 1.f &&
-            g.start_w <= (float)x0 + 2.f && g.start_w + roi_w >= (float)x0 - 1.f;
+      hit = g.batch == b && roi_touches_tile(g, pooled_h, pooled_w, y0, x0);
     }
     const unsigned long long ballot = __ballot(hit);
     if (lane == 0) s_wave_n[wave] = __popcll(ballot);
@@ -500,25 +551,55 @@ static int roi_args_ok(const void* a, const void* b, const void* c, int B, int C
   return DADET_OK;
 }
 
-extern "C" int dadet_roi_align_forward(const float* input, const float* rois, float* output, int B,
-                                       int C, int H, int W, int R, int pooled_h, int pooled_w,
-                                       float spatial_scale, int sampling_ratio, void* stream) {
+extern "C" int dadet_roi_align_workspace_bytes(int B, int H, int W, int R, size_t* bytes) {
+  DADET_REQUIRE(bytes && B > 0 && H > 0 && W > 0 && R >= 0, "roi_align_workspace_bytes: bad arguments");
+  *bytes = sizeof(int) * (size_t)R + 16;
+  return DADET_OK;
+}
+
+static int roi_align_forward_impl(const float* input, const float* rois, float* output, int B, int C, int H, int W, int R,
+                                  int pooled_h, int pooled_w, float spatial_scale, int sampling_ratio, void* workspace,
+                                  size_t workspace_bytes, void* stream) {
   int rc = roi_args_ok(input, rois, output, B, C, H, W, R, pooled_h, pooled_w);
   if (rc) return rc;
   if (R == 0) return DADET_OK;
+  int* order = nullptr;
+  if (workspace && R > 64 && R <= 4096) {     // spatial processing order (see roi_align_fwd_kernel)
+    DADET_REQUIRE(workspace_bytes >= sizeof(int) * (size_t)R, "roi_align_forward: workspace of %zu bytes is too small",
+                  workspace_bytes);
+    order = static_cast<int*>(workspace);
+    int N = 2;
+    while (N < R) N <<= 1;
+    hipLaunchKernelGGL(roi_order_kernel, dim3(1), dim3(1024), sizeof(unsigned long long) * (size_t)N, as_stream(stream),
+                       rois, R, N, spatial_scale, H, W, order);
+  }
   const dim3 grid((unsigned)(R * pooled_h));
   const bool vec = (C % 4 == 0) && ((reinterpret_cast<uintptr_t>(input) & 15) == 0) &&
                    ((reinterpret_cast<uintptr_t>(output) & 15) == 0);
   if (vec) {
     const int threads = (C / 4 >= 256) ? 256 : ((C / 4 + 63) / 64) * 64;
     hipLaunchKernelGGL(roi_align_fwd_kernel<4>, grid, dim3(threads), 0, as_stream(stream), input, rois,
-                       output, C, H, W, pooled_h, pooled_w, spatial_scale, sampling_ratio);
+                       output, C, H, W, pooled_h, pooled_w, spatial_scale, sampling_ratio, order);
   } else {
     const int threads = (C >= 256) ? 256 : ((C + 63) / 64) * 64;
     hipLaunchKernelGGL(roi_align_fwd_kernel<1>, grid, dim3(threads), 0, as_stream(stream), input, rois,
-                       output, C, H, W, pooled_h, pooled_w, spatial_scale, sampling_ratio);
+                       output, C, H, W, pooled_h, pooled_w, spatial_scale, sampling_ratio, order);
   }
   return check_launch("roi_align_forward");
+}
+
+extern "C" int dadet_roi_align_forward(const float* input, const float* rois, float* output, int B, int C, int H, int W,
+                                       int R, int pooled_h, int pooled_w, float spatial_scale, int sampling_ratio,
+                                       void* stream) {
+  return roi_align_forward_impl(input, rois, output, B, C, H, W, R, pooled_h, pooled_w, spatial_scale, sampling_ratio,
+                                nullptr, 0, stream);
+}
+
+extern "C" int dadet_roi_align_forward_ws(const float* input, const float* rois, float* output, int B, int C, int H,
+                                          int W, int R, int pooled_h, int pooled_w, float spatial_scale,
+                                          int sampling_ratio, void* workspace, size_t workspace_bytes, void* stream) {
+  return roi_align_forward_impl(input, rois, output, B, C, H, W, R, pooled_h, pooled_w, spatial_scale, sampling_ratio,
+                                workspace, workspace_bytes, stream);
 }
 
 extern "C" int dadet_roi_align_backward_atomic(const float* grad_output, const float* rois, float* grad_input,
@@ -541,9 +622,9 @@ extern "C" int dadet_roi_align_backward_atomic(const float* grad_output, const f
   return check_launch("roi_align_backward_atomic");
 }
 
-extern "C" int dadet_roi_align_backward(const float* grad_output, const float* rois, float* grad_input,
-                                        int B, int C, int H, int W, int R, int pooled_h, int pooled_w,
-                                        float spatial_scale, int sampling_ratio, void* stream) {
+extern "C" int dadet_roi_align_backward(const float* grad_output, const float* rois, float* grad_input, int B, int C,
+                                        int H, int W, int R, int pooled_h, int pooled_w, float spatial_scale,
+                                        int sampling_ratio, void* stream) {
   int rc = roi_args_ok(grad_output, rois, grad_input, B, C, H, W, R, pooled_h, pooled_w);
   if (rc) return rc;
   hipStream_t st = as_stream(stream);

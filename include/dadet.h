@@ -83,6 +83,13 @@ int dadet_roi_align_forward(const float* input, const float* rois, float* output
 int dadet_roi_align_backward(const float* grad_output, const float* rois, float* grad_input, int B,
                              int C, int H, int W, int R, int pooled_h, int pooled_w,
                              float spatial_scale, int sampling_ratio, void* stream);
+/* Forward with a caller-allocated scratch buffer (dadet_roi_align_workspace_bytes), result identical bit for bit: the ROIs
+ * are PROCESSED in Z-order of their centres (one extra tiny launch) so that the workgroups of an XCD share feature rows
+ * in its L2; every ROI is still written to its own output row. */
+int dadet_roi_align_workspace_bytes(int B, int H, int W, int R, size_t* bytes);
+int dadet_roi_align_forward_ws(const float* input, const float* rois, float* output, int B, int C, int H, int W, int R,
+                               int pooled_h, int pooled_w, float spatial_scale, int sampling_ratio, void* workspace,
+                               size_t workspace_bytes, void* stream);
 int dadet_roi_align_backward_atomic(const float* grad_output, const float* rois, float* grad_input, int B,
                                     int C, int H, int W, int R, int pooled_h, int pooled_w,
                                     float spatial_scale, int sampling_ratio, void* stream);

@@ -253,7 +253,11 @@ def test_three_step_trajectory_matches_oracle(device, monkeypatch):
     assert moved > 3e-4, "the losses did not move over three steps: the trajectory would test nothing (%.2e)" % moved
     # parameters: the update of a tensor is lr * (momentum-weighted gradients); compare the UPDATES with the gradient
     # metric of _check_gradients (a flipped ReLU perturbs an update like it perturbs a gradient)
+    # Tolerances: after the first step the two runs start each step from parameters that already differ by rounding and
+    # flipped ReLUs, so the per-step differences of _check_gradients compound (measured: 5e-4 .. 9e-4 on most tensors
+    # after three steps at this rate): "rounding level" is 2e-3 here, the hard bound 1e-2.
     _check_gradients({n: rec["params"][n].double() - sd[n].double() for n in names},
-                     {n: osd[n].detach() - sd[n].double() for n in names})
-    _check_gradients(rec["momentum"], {n: opt.state[osd[n]]["momentum_buffer"] for n in rec["momentum"]})
+                     {n: osd[n].detach() - sd[n].double() for n in names}, rounding_tol=2e-3, flip_tol=1e-2)
+    _check_gradients(rec["momentum"], {n: opt.state[osd[n]]["momentum_buffer"] for n in rec["momentum"]},
+                     rounding_tol=2e-3, flip_tol=1e-2)
     assert abs(state["margin_img"] - c.MODEL.DA_HEADS.TRIPLET_MARGIN_IMG) < 1e-9      # never exactly 0 here: no growth

@@ -50,7 +50,7 @@ def _one_step(workload, overlapped, seed, device):
 def test_full_size_step_schedules_agree(device, workload):
     l_ov, s_ov, g_ov = _one_step(workload, True, 7, device)
     assert all(v == v and abs(v) < 1e6 for v in l_ov.values()), l_ov
-    assert len(g_ov) > 60 and all(bool(torch.isfinite(g).all()) for g in g_ov.values())
+    assert len(g_ov) > 50 and all(bool(torch.isfinite(g).all()) for g in g_ov.values())
     assert all(len(b) == 256 for b in s_ov), [len(b) for b in s_ov]
     l_pl, s_pl, g_pl = _one_step(workload, False, 7, device)
     assert set(l_ov) == set(l_pl)

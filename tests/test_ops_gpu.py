@@ -775,3 +775,36 @@ def test_rpn_anchor_targets_match_the_aten_chain(device, A, G):
     lab, reg = _C.rpn_anchor_targets(anchors.to(device), vis.to(device), gts.to(device), 0.7, 0.3)
     assert torch.equal(lab.cpu(), want) and int((want == 1).sum()) >= G
     torch.testing.assert_close(reg.cpu(), want_reg, rtol=1e-5, atol=1e-6)
+
+
+def test_roi_align_workspace_variants_are_bit_identical_at_full_size(device, monkeypatch):
+    """dadet_roi_align_forward_ws (ROIs processed in Z-order of their centres) against the plain entry point at the
+    BASELINE shape: 512 ROIs on a [2, 1024, 64, 128] map — same bits"""
+    from da_detect_amd import _C
+
+    g = torch.Generator().manual_seed(9)
+    R = 512
+    xy = torch.rand((R, 2), generator=g) * torch.tensor([1800.0, 900.0])
+    wh = torch.rand((R, 2), generator=g) ** 2 * torch.tensor([900.0, 600.0]) + 4
+    rois = torch.cat([(torch.arange(R) >= 256).float().view(-1, 1), xy, torch.minimum(xy + wh, torch.tensor([2047.0, 1023.0]))],
+                     1).to(device)
+    rois[5] = torch.tensor([0.0, -40.0, -30.0, 2100.0, 1100.0])     # whole image and beyond
+    rois[300] = torch.tensor([1.0, 100.0, 100.0, 100.5, 100.5])     # degenerate
+    x = torch.randn((2, 1024, 64, 128), generator=g).to(device).contiguous(memory_format=torch.channels_last)
+    go = torch.randn((R, 1024, 14, 14), generator=g).to(device).contiguous(memory_format=torch.channels_last)
+    out, gin = [], []
+    for flag in (False, True):
+        monkeypatch.setattr(_C, "ROI_ALIGN_WORKSPACE", flag)
+        out.append(_C.roi_align_forward(x, rois, 1 / 16.0, 14, 14, 0))
+        gin.append(_C.roi_align_backward(go, rois, 1 / 16.0, 14, 14, 2, 1024, 64, 128, 0))
+    assert torch.equal(out[0], out[1]), "spatially ordered forward differs from the plain one"
+    assert torch.equal(gin[0], gin[1])
+    # interleaved batch indices and R not a multiple of 32
+    rois2 = rois[torch.randperm(R, generator=g)[:333].to(device)].contiguous()
+    a, b = [], []
+    for flag in (False, True):
+        monkeypatch.setattr(_C, "ROI_ALIGN_WORKSPACE", flag)
+        a.append(_C.roi_align_forward(x, rois2, 1 / 16.0, 7, 7, 2))
+        b.append(_C.roi_align_backward(go[:333, :, :7, :7].contiguous(memory_format=torch.channels_last), rois2, 1 / 16.0,
+                                       7, 7, 2, 1024, 64, 128, 2))
+    assert torch.equal(a[0], a[1]) and torch.equal(b[0], b[1])
