@@ -48,6 +48,12 @@ struct ConvArgs {
   // its raw partial sums to y + blockIdx.y * split_stride; 0 / 0 = the whole reduction in one workgroup
   int ksplit;
   unsigned split_stride;               // floats
+  // stream-K tail (conv_fwd_split_sk_kernel): tiles [0, sk_dp_tiles) one per workgroup, the K-tile iterations of the
+  // last sk_tiles tiles in sk_units contiguous ranges of sk_iters; partial tiles meet in sk_ws ([sk_tiles][sk_max_parts]
+  // [128 x 128] floats) under the arrival counters sk_counters[sk_tiles] (zeroed before the launch)
+  int sk_dp_tiles, sk_tiles, sk_units, sk_iters, sk_max_parts;
+  float* sk_ws;
+  int* sk_counters;
 };
 
 struct WgradArgs {
@@ -82,6 +88,7 @@ inline int fwd_variant(int M, int Cout) {
 // 0 = exact fp32 MFMA (default); 2 / 3 = products from a 2- / 3-term bf16 split of both operands
 int gemm_mode();
 int launch_fwd_split(ConvArgs& a, int variant, int terms, hipStream_t st);
+int launch_fwd_split_sk(ConvArgs& a, int terms, hipStream_t st);
 int launch_wgrad_split(WgradArgs& a, int terms, hipStream_t st);
 
 }  // namespace dadet

@@ -536,6 +536,32 @@ void* stream_scratch(hipStream_t st, size_t bytes) {
   return s.p;
 }
 
+// Stream-K tail plan for the 128x128 split kernel (conv_fwd_split_sk_kernel).  Returns false when the plain grid is at
+// least as good: the last pass of the tile grid over the 2 x 256 workgroup slots is (nearly) full, or K is so short that
+// parking / summing partial tiles would cost more than the idle slots.
+struct SkPlan { int dp_tiles, sk_tiles, units, iters, max_parts; };
+bool streamk_plan(const ConvArgs& a, int variant, SkPlan* p) {
+  const char* env = getenv("DADET_STREAMK");      // read per call: tests and A/B runs flip it at run time
+  if ((env && env[0] == '0') || variant != 0 || a.ablate) return false;
+  const int slots = 2 * kNumCU;
+  const int tiles = ceil_div(a.M, 128) * ceil_div(a.Cout, 128);
+  const int nk = ceil_div(a.K, BK);
+  const int tail = tiles % slots;
+  // a grid below one pass is not stream-K'd: cutting 256 tiles into 512 halves measured 7 - 22% SLOWER (the partial-tile
+  // round trip costs more than the second workgroup per CU gains; tools/streamk_bench.py)
+  if (tail == 0 || nk < 16 || tiles < slots) return false;
+  if (tail > slots * 7 / 8) return false;                 // the last pass is full enough
+  if (tiles > 6 * slots && tail > slots / 2) return false;  // many passes: the idle share is small
+  p->dp_tiles = tiles - tail;
+  p->sk_tiles = tail;
+  p->units = slots;
+  p->iters = ceil_div(tail * nk, slots);
+  if (p->iters < 8) return false;
+  p->units = ceil_div(tail * nk, p->iters);
+  p->max_parts = ceil_div(nk, p->iters) + 1;
+  return true;
+}
+
 // number of K elements per split (multiple of BK), or 0 when the launch should not be split
 int splitk_plan(const ConvArgs& a, int variant) {
   static const bool enabled = !(getenv("DADET_SPLITK") && getenv("DADET_SPLITK")[0] == '0');
@@ -583,8 +609,31 @@ extern "C" int dadet_conv_forward(const dadet_conv_desc* d, const float* x, cons
   hipStream_t st = as_stream(stream);
   a.ksplit = 0;
   a.split_stride = 0;
+  a.sk_dp_tiles = a.sk_tiles = a.sk_units = a.sk_iters = a.sk_max_parts = 0;
+  a.sk_ws = nullptr;
+  a.sk_counters = nullptr;
   if (gemm_mode() != 0) {
     const int variant = split_fwd_variant(a.M, a.Cout, a.K);
+    SkPlan sk;
+    if (streamk_plan(a, variant, &sk)) {
+      // workspace: [counters, 256-byte aligned][partial tiles]; per stream, reused in stream order
+      const size_t cnt_bytes = ((sizeof(int) * (size_t)sk.sk_tiles + 255) / 256) * 256;
+      const size_t ws_bytes = sizeof(float) * (size_t)sk.sk_tiles * sk.max_parts * 128 * 128;
+      char* base = static_cast<char*>(stream_scratch(st, cnt_bytes + ws_bytes));
+      if (!base) {
+        set_error("conv_forward: could not allocate %zu bytes of stream-K scratch", cnt_bytes + ws_bytes);
+        return DADET_ELAUNCH;
+      }
+      a.sk_counters = reinterpret_cast<int*>(base);
+      a.sk_ws = reinterpret_cast<float*>(base + cnt_bytes);
+      a.sk_dp_tiles = sk.dp_tiles; a.sk_tiles = sk.sk_tiles; a.sk_units = sk.units; a.sk_iters = sk.iters;
+      a.sk_max_parts = sk.max_parts;
+      if (hipMemsetAsync(a.sk_counters, 0, cnt_bytes, st) != hipSuccess) {
+        set_error("conv_forward: hipMemsetAsync of the stream-K counters failed");
+        return DADET_ELAUNCH;
+      }
+      return launch_fwd_split_sk(a, gemm_mode(), st);
+    }
     const int ksplit = splitk_plan(a, variant);
     if (ksplit && al16(y) && (!addend || al16(addend)) && (!mask_ref || al16(mask_ref)) &&
         (!scale || al16(scale)) && (!bias || al16(bias))) {

@@ -55,17 +55,24 @@ __device__ inline void split4(const float4 v, uint2 (&out)[TERMS]) {
 // AB: stage-ablation mask for profiling experiments (tools/ablate.py).  It is a COMPILE-TIME parameter: as run-time
 // branches the checks cut the K loop into a dozen basic blocks and the scheduler could no longer interleave the
 // MFMAs with the split / LDS traffic across them.  Production launches use AB = 0.
-template <int TM, int TN, int TERMS, int AB = 0>
-__global__ __launch_bounds__(256, 2) void conv_fwd_split_kernel(const ConvArgs a) {
+// One output tile over the K range [k_lo, k_hi) (whole K-tiles).  sk = nullptr: the result goes through the epilogue.
+// sk != nullptr (stream-K segment, see conv_fwd_split_sk_kernel): the raw partial sums are parked in the tile's workspace
+// slot; the workgroup that parks a tile's LAST missing part sums all parts in part order and runs the epilogue.
+struct SkPart {
+  float* tile_ws;      // [parts][128 x 128] partial sums of this tile
+  int* counter;        // arrivals of this tile
+  int part, parts;
+};
+
+template <int TM, int TN, int TERMS, int AB>
+__device__ __forceinline__ void conv_fwd_split_body(const ConvArgs& a, char* smem, const int tile, const int k_lo,
+                                                    const int k_hi, const unsigned split_y, const SkPart* sk) {
   constexpr int BM = 2 * TM * 32, BN = 2 * TN * 32;
   constexpr int A_LOADS = BM / 32, B_LOADS = BN / 32;
   constexpr int A_PLANE = BM * PLANE_STRIDE, B_PLANE = BN * PLANE_STRIDE;  // bf16 elements
-  extern __shared__ __attribute__((aligned(16))) char smem[];
   __bf16* As = reinterpret_cast<__bf16*>(smem);   // [TERMS][BM][PLANE_STRIDE]
   __bf16* Bs = As + TERMS * A_PLANE;              // [TERMS][BN][PLANE_STRIDE]
 
-  const int nwg = a.tiles_m * a.tiles_n;
-  const int tile = xcd_remap(blockIdx.x, nwg);
   const int bm0 = (tile / a.tiles_n) * BM;
   const int bn0 = (tile % a.tiles_n) * BN;
   const int t = threadIdx.x;
@@ -114,8 +121,6 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_split_kernel(const ConvArgs a
     wrow[i] = n < a.Cout ? (unsigned)n * (unsigned)a.K * 4u : kOOB;
   }
   float4 ra[A_LOADS], rb[B_LOADS];
-  const int k_lo = a.ksplit ? (int)blockIdx.y * a.ksplit : 0;
-  const int k_hi = a.ksplit ? min(a.K, k_lo + a.ksplit) : a.K;
   int kk = k_lo + lcol * 4;
   int tap = kk / a.Cin;
   int kc = kk - tap * a.Cin;
@@ -272,8 +277,55 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_split_kernel(const ConvArgs a
     }
   }
 
+  if (sk) {
+    // park the partial sums: lane-linear, 16 bytes per lane and store
+    __shared__ int s_ticket;
+    float4* mine = reinterpret_cast<float4*>(sk->tile_ws) + (size_t)sk->part * (BM * BN / 4);
+#pragma unroll
+    for (int im = 0; im < TM; ++im)
+#pragma unroll
+      for (int in = 0; in < TN; ++in)
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+          mine[((im * TN + in) * 4 + g) * 256 + t] = make_float4(acc[im][in][g * 4], acc[im][in][g * 4 + 1],
+                                                                 acc[im][in][g * 4 + 2], acc[im][in][g * 4 + 3]);
+    // hand-off (release by the parking workgroup, acquire by the one that completes the tile), agent scope: the parts
+    // of a tile come from workgroups on different XCDs, whose L2s are only made coherent by these fences
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (t == 0) {
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      s_ticket = __hip_atomic_fetch_add(sk->counter, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();
+    if (s_ticket != sk->parts - 1) return;
+    if (t == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    __syncthreads();
+    // all parts are in memory: sum them in part order (the same order whichever workgroup arrives last)
+#pragma unroll
+    for (int im = 0; im < TM; ++im)
+#pragma unroll
+      for (int in = 0; in < TN; ++in)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[im][in][e] = 0.f;
+    for (int p = 0; p < sk->parts; ++p) {
+      const float4* src = reinterpret_cast<const float4*>(sk->tile_ws) + (size_t)p * (BM * BN / 4);
+#pragma unroll
+      for (int im = 0; im < TM; ++im)
+#pragma unroll
+        for (int in = 0; in < TN; ++in)
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            const float4 v = src[((im * TN + in) * 4 + g) * 256 + t];
+            acc[im][in][g * 4] += v.x; acc[im][in][g * 4 + 1] += v.y;
+            acc[im][in][g * 4 + 2] += v.z; acc[im][in][g * 4 + 3] += v.w;
+          }
+    }
+  }
+
   // epilogue (same as conv_igemm.hip); a split-K launch stores raw partial sums (no scale / bias / addend / gate)
-  const __amdgpu_buffer_rsrc_t yr = make_rsrc(a.y + (size_t)blockIdx.y * a.split_stride, a.y_bytes);
+  const __amdgpu_buffer_rsrc_t yr = make_rsrc(a.y + (size_t)split_y * a.split_stride, a.y_bytes);
   const __amdgpu_buffer_rsrc_t ar = make_rsrc(a.addend ? a.addend : a.y, a.addend ? a.y_bytes : 0u);
   const __amdgpu_buffer_rsrc_t mr = make_rsrc(a.mask_ref ? a.mask_ref : a.y, a.mask_ref ? a.y_bytes : 0u);
   const int col_in = lane & 31;
@@ -324,6 +376,54 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_split_kernel(const ConvArgs a
         __builtin_amdgcn_sched_barrier(0);
       }
     }
+  }
+}
+
+template <int TM, int TN, int TERMS, int AB = 0>
+__global__ __launch_bounds__(256, 2) void conv_fwd_split_kernel(const ConvArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int k_lo = a.ksplit ? (int)blockIdx.y * a.ksplit : 0;
+  const int k_hi = a.ksplit ? min(a.K, k_lo + a.ksplit) : a.K;
+  conv_fwd_split_body<TM, TN, TERMS, AB>(a, smem, xcd_remap(blockIdx.x, a.tiles_m * a.tiles_n), k_lo, k_hi, blockIdx.y,
+                                         nullptr);
+}
+
+// Stream-K tail.  A grid of T output tiles runs on 512 workgroup slots (2 per CU) in ceil(T / 512) passes; the last pass
+// of e.g. the res5 3x3 convs (784 tiles) leaves 240 slots idle for the length of a whole tile (tools/gemm_table.py: ~10%
+// of those launches).  Here the first `sk_dp_tiles` tiles (a multiple of the slot count) are computed one per workgroup
+// as before; the remaining sk_tiles * nk K-tile iterations are cut into `sk_units` equal contiguous ranges, one per
+// extra workgroup, so the tail ends (T mod 512) / 512 of a pass after the full passes instead of a whole one.  A range
+// covers the end of one tile and the start of the next; the parts of a tile meet in the workspace (conv_fwd_split_body).
+template <int TERMS>
+__global__ __launch_bounds__(256, 2) void conv_fwd_split_sk_kernel(const ConvArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  if ((int)blockIdx.x < a.sk_dp_tiles) {
+    conv_fwd_split_body<2, 2, TERMS, 0>(a, smem, xcd_remap(blockIdx.x, a.sk_dp_tiles), 0, a.K, 0, nullptr);
+    return;
+  }
+  const int nk = (a.K + BK - 1) / BK;
+  const int unit = (int)blockIdx.x - a.sk_dp_tiles;
+  int it = unit * a.sk_iters;
+  const int end = min(it + a.sk_iters, a.sk_tiles * nk);
+  bool first = true;
+  while (it < end) {
+    const int tl = it / nk, k0 = it - tl * nk;
+    const int k1 = min(nk, k0 + (end - it));
+    if (!first) __syncthreads();      // the previous segment's fragment reads vs this segment's first LDS stores
+    first = false;
+    const int k_lo = k0 * BK, k_hi = min(a.K, k1 * BK);
+    if (k0 == 0 && k1 == nk) {
+      conv_fwd_split_body<2, 2, TERMS, 0>(a, smem, a.sk_dp_tiles + tl, k_lo, k_hi, 0, nullptr);
+    } else {
+      const int first_unit = (tl * nk) / a.sk_iters, last_unit = ((tl + 1) * nk - 1) / a.sk_iters;
+      SkPart part;
+      part.tile_ws = a.sk_ws + (size_t)tl * a.sk_max_parts * (128 * 128);
+      part.counter = a.sk_counters + tl;
+      part.part = unit - first_unit;
+      part.parts = last_unit - first_unit + 1;
+      conv_fwd_split_body<2, 2, TERMS, 0>(a, smem, a.sk_dp_tiles + tl, k_lo, k_hi, 0, &part);
+    }
+    it += k1 - k0;
   }
 }
 
@@ -590,6 +690,29 @@ static int launch_split(ConvArgs& a, hipStream_t st) {
   hipLaunchKernelGGL((conv_fwd_split_kernel<TM, TN, TERMS, AB>), dim3(a.tiles_m * a.tiles_n, ksplits), dim3(256), lds,
                      st, a);
   return check_launch("conv_forward(split)");
+}
+
+template <int TERMS>
+static int launch_split_sk(ConvArgs& a, hipStream_t st) {
+  const size_t lds = sizeof(__bf16) * TERMS * 256 * PLANE_STRIDE;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_fwd_split_sk_kernel<TERMS>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) {
+      set_error("conv_forward(split, stream-K): hipFuncSetAttribute: %s", hipGetErrorString(e));
+      return DADET_ELAUNCH;
+    }
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((conv_fwd_split_sk_kernel<TERMS>), dim3(a.sk_dp_tiles + a.sk_units), dim3(256), lds, st, a);
+  return check_launch("conv_forward(split, stream-K)");
+}
+
+int launch_fwd_split_sk(ConvArgs& a, int terms, hipStream_t st) {
+  a.tiles_m = ceil_div(a.M, 128);
+  a.tiles_n = ceil_div(a.Cout, 128);
+  return terms == 2 ? launch_split_sk<2>(a, st) : launch_split_sk<3>(a, st);
 }
 
 int launch_fwd_split(ConvArgs& a, int variant, int terms, hipStream_t st) {

@@ -36,6 +36,39 @@ __device__ inline float key_float(uint32_t k) {
   return __builtin_bit_cast(float, u);
 }
 
+// histogram update that survives clustered keys: when many lanes of a wave hit the same bin (sigmoid scores share their
+// exponent bits: the first radix pass would put ~10^5 same-address LDS atomics in a row), one lane adds the count per
+// distinct bin; spread-out bins take the plain per-lane atomic
+__device__ inline void hist_add(int* hist, int bin, bool active, int lane) {
+  unsigned long long todo = __ballot(active);
+  if (!todo) return;
+  const int first = __ffsll((long long)todo) - 1;
+  const unsigned long long same0 = __ballot(active && bin == __shfl(bin, first, 64));
+  if (__popcll(same0) < 8) {
+    if (active) atomicAdd(&hist[bin], 1);
+    return;
+  }
+  while (todo) {
+    const int leader = __ffsll((long long)todo) - 1;
+    const int lb = __shfl(bin, leader, 64);
+    const unsigned long long same = __ballot(active && bin == lb);
+    if (lane == leader) atomicAdd(&hist[lb], __popcll(same));
+    todo &= ~same;
+  }
+}
+
+// slot for every lane with `take` set: one LDS atomic per wave instead of one per element
+__device__ inline int wave_append(int* counter, bool take, int lane) {
+  const unsigned long long m = __ballot(take);
+  int base = 0;
+  if (m) {
+    const int leader = __ffsll((long long)m) - 1;
+    if (lane == leader) base = atomicAdd(counter, __popcll(m));
+    base = __shfl(base, leader, 64);
+  }
+  return base + __popcll(m & ((1ull << lane) - 1ull));
+}
+
 __global__ __launch_bounds__(kTopkThreads) void topk_sorted_kernel(const float* __restrict__ scores, int n, int64_t row_stride,
                                                                   int k, int sort_n, float* __restrict__ out_scores,
                                                                   int64_t* __restrict__ out_idx) {
@@ -46,8 +79,10 @@ __global__ __launch_bounds__(kTopkThreads) void topk_sorted_kernel(const float* 
   __shared__ uint32_t s_prefix, s_mask;
   __shared__ int s_need, s_count, s_nties;
   __shared__ int s_scan[kTopkThreads];
-  const int t = threadIdx.x;
+  const int t = threadIdx.x, lane = threadIdx.x & 63;
   const float* row = scores + (size_t)blockIdx.x * row_stride;
+  constexpr int U = 4;      // independent loads in flight per thread (the passes are latency bound: one CU reads 480 KB)
+  const int n_round = (n + kTopkThreads * U - 1) / (kTopkThreads * U) * (kTopkThreads * U);
   float* o_s = out_scores + (size_t)blockIdx.x * k;
   int64_t* o_i = out_idx + (size_t)blockIdx.x * k;
   auto pack = [](uint32_t key, int i) { return ((unsigned long long)key << 32) | (uint32_t)(0xFFFFFFFFu - (uint32_t)i); };
@@ -64,9 +99,15 @@ __global__ __launch_bounds__(kTopkThreads) void topk_sorted_kernel(const float* 
       for (int b = t; b < bins; b += kTopkThreads) hist[b] = 0;
       __syncthreads();
       const uint32_t prefix = s_prefix, mask = s_mask;
-      for (int i = t; i < n; i += kTopkThreads) {
-        const uint32_t key = float_key(row[i]);
-        if ((key & mask) == prefix) atomicAdd(&hist[(key >> shift) & (bins - 1)], 1);
+      for (int i0 = t; i0 < n_round; i0 += kTopkThreads * U) {
+        float v[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) v[u] = (i0 + u * kTopkThreads < n) ? row[i0 + u * kTopkThreads] : 0.f;
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          const uint32_t key = float_key(v[u]);
+          hist_add(hist, (int)((key >> shift) & (bins - 1)), (i0 + u * kTopkThreads < n) && (key & mask) == prefix, lane);
+        }
       }
       __syncthreads();
       if (t == 0) {
@@ -84,13 +125,19 @@ __global__ __launch_bounds__(kTopkThreads) void topk_sorted_kernel(const float* 
     const uint32_t thr = s_prefix;
     const int need = s_need;                   // how many of the keys == thr are taken (lowest indices first)
     // ---- (2) collect
-    for (int i = t; i < n; i += kTopkThreads) {
-      const uint32_t key = float_key(row[i]);
-      if (key > thr) {
-        buf[atomicAdd(&s_count, 1)] = pack(key, i);
-      } else if (key == thr) {
-        const int slot = atomicAdd(&s_nties, 1);
-        if (slot < kTopkTieCap) ties[slot] = i;
+    for (int i0 = t; i0 < n_round; i0 += kTopkThreads * U) {
+      float v[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) v[u] = (i0 + u * kTopkThreads < n) ? row[i0 + u * kTopkThreads] : 0.f;
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int i = i0 + u * kTopkThreads;
+        const uint32_t key = float_key(v[u]);
+        const bool above_thr = i < n && key > thr, tie = i < n && key == thr;
+        const int slot = wave_append(&s_count, above_thr, lane);
+        if (above_thr) buf[slot] = pack(key, i);
+        const int tslot = wave_append(&s_nties, tie, lane);
+        if (tie && tslot < kTopkTieCap) ties[tslot] = i;
       }
     }
     __syncthreads();

@@ -808,3 +808,46 @@ def test_roi_align_workspace_variants_are_bit_identical_at_full_size(device, mon
         b.append(_C.roi_align_backward(go[:333, :, :7, :7].contiguous(memory_format=torch.channels_last), rois2, 1 / 16.0,
                                        7, 7, 2, 1024, 64, 128, 2))
     assert torch.equal(a[0], a[1]) and torch.equal(b[0], b[1])
+
+
+@pytest.mark.parametrize("shape", [
+    # N, Cin, H, W, Cout, k, pad: tiles of 128 x 128 / K-tiles
+    (2, 256, 40, 64, 256, 3, 1),        # 80 tiles, 72 K-tiles: every tile is cut into 6 - 7 parts
+    (2, 256, 40, 60, 200, 3, 1),        # ragged M (4800 rows) and Cout
+    (1, 512, 7, 7 * 96, 512, 3, 1),     # 37 x 4 = 148 tiles, 144 K-tiles (the res5 3x3 shape, fewer ROIs)
+    (2, 1024, 52, 128, 1024, 1, 0),     # 104 x 8 = 832 tiles: 512 one per workgroup + 320 stream-K, 32 K-tiles
+])
+def test_stream_k_tail_matches_the_plain_grid(device, shape, monkeypatch):
+    """conv_fwd_split_sk_kernel (stream-K tail: partial tiles parked in a workspace, the last arriver sums the parts in
+    part order and runs the epilogue) against the one-tile-per-workgroup grid of the same kernel body: identical up to the
+    association of the K sum (1e-5 relative), with every epilogue (FrozenBN scale / bias / residual / ReLU, and the
+    dgrad gate), and bit-reproducible run to run"""
+    import os
+
+    from da_detect_amd import _C
+
+    N, Cin, H, W, Cout, k, pad = shape
+    g = torch.Generator().manual_seed(sum(shape))
+    CL = torch.channels_last
+    x = torch.randn((N, Cin, H, W), generator=g).to(device).contiguous(memory_format=CL)
+    w = (torch.randn((Cout, Cin, k, k), generator=g) * (2.0 / (Cin * k * k)) ** 0.5).to(device).contiguous(memory_format=CL)
+    scale = (torch.rand(Cout, generator=g) + 0.5).to(device)
+    bias = torch.randn(Cout, generator=g).to(device)
+    addend = torch.randn((N, Cout, H, W), generator=g).to(device).contiguous(memory_format=CL)
+    mask = torch.randn((N, Cout, H, W), generator=g).to(device).contiguous(memory_format=CL)
+    cases = [dict(), dict(scale=scale, bias=bias, relu_mode=1), dict(scale=scale, bias=bias, addend=addend, relu_mode=1),
+             dict(addend=addend, mask_ref=mask, relu_mode=2)]
+    out = {}
+    for flag in ("0", "1"):
+        monkeypatch.setenv("DADET_STREAMK", flag)
+        os.environ["DADET_STREAMK"] = flag
+        out[flag] = [_C.conv_forward(x, w, pad=pad, **kw) for kw in cases]
+        if flag == "1":
+            again = [_C.conv_forward(x, w, pad=pad, **kw) for kw in cases]
+            for a, b in zip(out[flag], again):
+                assert torch.equal(a, b), "stream-K result is not reproducible"
+    for a, b, kw in zip(out["0"], out["1"], cases):
+        scale_ = float(a.abs().max())
+        assert float((a - b).abs().max()) <= 1e-5 * scale_, (sorted(kw), float((a - b).abs().max()), scale_)
+    ref = F.conv2d(x.cpu(), w.cpu(), padding=pad)
+    torch.testing.assert_close(out["1"][0].cpu(), ref, rtol=1e-4, atol=1e-4)
