@@ -28,6 +28,19 @@ __device__ inline void buf_store1(__amdgpu_buffer_rsrc_t r, unsigned byte_off, f
   __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), r, (int)byte_off, 0, 0);
 }
 
+// Write-through (sc1) 16-byte stores and sc1 loads for tiles handed from one workgroup to another INSIDE a launch (the
+// stream-K tail, the in-kernel reduction of the weight-gradient splits).  The XCDs' L2s are not coherent with each other:
+// a plain store may sit dirty in the producer's L2.  An agent-scope release fence writes the whole L2 back (~2 - 6 us
+// each: with one per workgroup the fused weight-gradient reduction made the step 2x SLOWER); write-through stores drained
+// with s_waitcnt vmcnt(0) before the arrival counter is bumped, and sc1 loads on the consumer side, need no fence
+// (MI355X_MICROARCH.md, hand-off table: "publish-large").
+__device__ inline void buf_store4_wt(__amdgpu_buffer_rsrc_t r, unsigned byte_off, float4 v) {
+  __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), r, (int)byte_off, 0, 16);
+}
+__device__ inline float4 buf_load4_sc1(__amdgpu_buffer_rsrc_t r, unsigned byte_off) {
+  return __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)byte_off, 0, 16));
+}
+
 constexpr int BK = 32;          // K-tile
 constexpr int LDS_STRIDE = 36;  // floats per staged row (32 + 4 pad, keeps 16-byte alignment)
 
@@ -67,6 +80,11 @@ struct WgradArgs {
   int direct;       // 1: write dw with scale / accumulate applied here
   int accumulate;
   unsigned x_bytes, gy_bytes;
+  // in-kernel reduction of the splits (conv_wgrad_split_kernel): the workgroup that parks a tile's LAST partial result
+  // sums the `splits` partials in split order, applies out_scale / accumulate and writes `final`; nullptr: the partials
+  // are left for wgrad_reduce_kernel
+  int* counters;    // one per (co, kc) tile, zero between launches
+  float* final;
 };
 
 // tile variant chosen for a forward / dgrad GEMM of M rows and Cout columns

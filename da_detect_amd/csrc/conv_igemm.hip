@@ -536,6 +536,24 @@ void* stream_scratch(hipStream_t st, size_t bytes) {
   return s.p;
 }
 
+// arrival counters of the stream-K tail: one persistent zero-initialised buffer per stream (work queued on a stream is
+// ordered, so one launch owns it at a time); the workgroup that completes a tile resets that tile's counter
+constexpr int kSkCounters = 4096;
+int* stream_counters(hipStream_t st) {
+  static std::mutex m;
+  static std::unordered_map<hipStream_t, int*> table;
+  std::lock_guard<std::mutex> lock(m);
+  int*& p = table[st];
+  if (!p) {
+    if (hipMalloc(reinterpret_cast<void**>(&p), sizeof(int) * kSkCounters) != hipSuccess) {
+      p = nullptr;
+      return nullptr;
+    }
+    if (hipMemset(p, 0, sizeof(int) * kSkCounters) != hipSuccess) return nullptr;
+  }
+  return p;
+}
+
 // Stream-K tail plan for the 128x128 split kernel (conv_fwd_split_sk_kernel).  Returns false when the plain grid is at
 // least as good: the last pass of the tile grid over the 2 x 256 workgroup slots is (nearly) full, or K is so short that
 // parking / summing partial tiles would cost more than the idle slots.
@@ -549,7 +567,7 @@ bool streamk_plan(const ConvArgs& a, int variant, SkPlan* p) {
   const int tail = tiles % slots;
   // a grid below one pass is not stream-K'd: cutting 256 tiles into 512 halves measured 7 - 22% SLOWER (the partial-tile
   // round trip costs more than the second workgroup per CU gains; tools/streamk_bench.py)
-  if (tail == 0 || nk < 16 || tiles < slots) return false;
+  if (tail == 0 || nk < 16 || tiles < slots || tail > kSkCounters) return false;
   if (tail > slots * 7 / 8) return false;                 // the last pass is full enough
   if (tiles > 6 * slots && tail > slots / 2) return false;  // many passes: the idle share is small
   p->dp_tiles = tiles - tail;
@@ -616,22 +634,16 @@ extern "C" int dadet_conv_forward(const dadet_conv_desc* d, const float* x, cons
     const int variant = split_fwd_variant(a.M, a.Cout, a.K);
     SkPlan sk;
     if (streamk_plan(a, variant, &sk)) {
-      // workspace: [counters, 256-byte aligned][partial tiles]; per stream, reused in stream order
-      const size_t cnt_bytes = ((sizeof(int) * (size_t)sk.sk_tiles + 255) / 256) * 256;
+      // partial tiles in the per-stream scratch (reused in stream order), arrival counters in their own buffer
       const size_t ws_bytes = sizeof(float) * (size_t)sk.sk_tiles * sk.max_parts * 128 * 128;
-      char* base = static_cast<char*>(stream_scratch(st, cnt_bytes + ws_bytes));
-      if (!base) {
-        set_error("conv_forward: could not allocate %zu bytes of stream-K scratch", cnt_bytes + ws_bytes);
+      a.sk_ws = static_cast<float*>(stream_scratch(st, ws_bytes));
+      a.sk_counters = stream_counters(st);
+      if (!a.sk_ws || !a.sk_counters) {
+        set_error("conv_forward: could not allocate %zu bytes of stream-K scratch", ws_bytes);
         return DADET_ELAUNCH;
       }
-      a.sk_counters = reinterpret_cast<int*>(base);
-      a.sk_ws = reinterpret_cast<float*>(base + cnt_bytes);
       a.sk_dp_tiles = sk.dp_tiles; a.sk_tiles = sk.sk_tiles; a.sk_units = sk.units; a.sk_iters = sk.iters;
       a.sk_max_parts = sk.max_parts;
-      if (hipMemsetAsync(a.sk_counters, 0, cnt_bytes, st) != hipSuccess) {
-        set_error("conv_forward: hipMemsetAsync of the stream-K counters failed");
-        return DADET_ELAUNCH;
-      }
       return launch_fwd_split_sk(a, gemm_mode(), st);
     }
     const int ksplit = splitk_plan(a, variant);
@@ -724,7 +736,8 @@ extern "C" int dadet_conv_wgrad_workspace_bytes(const dadet_conv_desc* d, size_t
   if (d->N == 0) { *bytes_out = 0; return DADET_OK; }
   int tco, tkc, splits, rps;
   wgrad_plan(d, &tco, &tkc, &splits, &rps);
-  *bytes_out = splits > 1 ? sizeof(float) * (size_t)splits * d->Cout * d->KH * d->KW * d->Cin : 0;
+  // whole 128 x 128 tiles: the in-kernel reduction parks the partial tiles lane-linear, ragged edges included
+  *bytes_out = splits > 1 ? sizeof(float) * (size_t)splits * tco * tkc * 128 * 128 : 0;
   return DADET_OK;
 }
 
@@ -757,13 +770,32 @@ extern "C" int dadet_conv_wgrad(const dadet_conv_desc* d, const float* x, const 
     a.direct = 1;
     a.out = dw;
   } else {
-    const size_t need = sizeof(float) * (size_t)a.splits * d->Cout * K;
+    const size_t need = sizeof(float) * (size_t)a.splits * a.tiles_co * a.tiles_kc * 128 * 128;
     if (!workspace || workspace_bytes < need) {
       set_error("conv_wgrad: workspace %zu < required %zu", workspace_bytes, need);
       return DADET_EWORKSPACE;
     }
     a.direct = 0;
     a.out = static_cast<float*>(workspace);
+  }
+  a.counters = nullptr;
+  a.final = dw;
+  {
+    // DADET_WGRAD_FUSED=1: the last-arriving split of a tile sums the partials inside the GEMM kernel instead of the
+    // separate wgrad_reduce_kernel pass (46 launches, 0.7 ms of kernel time per step).  OFF by default — measured on the
+    // BASELINE step: 32.1 ms against 28.8 ms.  Every one of the ~800 workgroups of a launch must publish its 64 KB tile
+    // write-through (2.4 GB per step through the fabric, ~3 us on every workgroup's tail), where the separate pass reads
+    // partials that mostly still sit in L2 / MALL; with agent-scope release fences instead it was 66.7 ms (one L2
+    // write-back per workgroup).  The stream-K tail of the forward kernels uses the same hand-off and wins because only
+    // the few workgroups that cut a tile publish.  Results are bit-identical either way (tests/test_ops_gpu.py).
+    const char* env = getenv("DADET_WGRAD_FUSED");
+    if (a.splits > 1 && gemm_mode() != 0 && env && env[0] == '1' && a.tiles_co * a.tiles_kc <= kSkCounters) {
+      a.counters = stream_counters(st);
+      if (!a.counters) {
+        set_error("conv_wgrad: could not allocate the arrival counters");
+        return DADET_ELAUNCH;
+      }
+    }
   }
   const size_t lds = sizeof(float) * 2 * 32 * 128;  // 32 KB: three workgroups per CU
   static bool attr_set = false;
@@ -783,7 +815,7 @@ extern "C" int dadet_conv_wgrad(const dadet_conv_desc* d, const float* x, const 
     rc = check_launch("conv_wgrad");
   }
   if (rc) return rc;
-  if (a.splits > 1) {
+  if (a.splits > 1 && !a.counters) {
     const int64_t total4 = (int64_t)d->Cout * K / 4;
     int64_t blocks = ceil_div64(total4, 256);
     if (blocks > kMaxStreamBlocks) blocks = kMaxStreamBlocks;

@@ -278,30 +278,25 @@ __device__ __forceinline__ void conv_fwd_split_body(const ConvArgs& a, char* sme
   }
 
   if (sk) {
-    // park the partial sums: lane-linear, 16 bytes per lane and store
+    // park the partial sums: lane-linear, 16 bytes per lane and store, written through to memory
     __shared__ int s_ticket;
-    float4* mine = reinterpret_cast<float4*>(sk->tile_ws) + (size_t)sk->part * (BM * BN / 4);
+    const __amdgpu_buffer_rsrc_t pr = make_rsrc(sk->tile_ws, (unsigned)(sk->parts * BM * BN * 4));
+    const unsigned mine = (unsigned)sk->part * (BM * BN * 4) + (unsigned)t * 16u;
 #pragma unroll
     for (int im = 0; im < TM; ++im)
 #pragma unroll
       for (int in = 0; in < TN; ++in)
 #pragma unroll
         for (int g = 0; g < 4; ++g)
-          mine[((im * TN + in) * 4 + g) * 256 + t] = make_float4(acc[im][in][g * 4], acc[im][in][g * 4 + 1],
-                                                                 acc[im][in][g * 4 + 2], acc[im][in][g * 4 + 3]);
-    // hand-off (release by the parking workgroup, acquire by the one that completes the tile), agent scope: the parts
-    // of a tile come from workgroups on different XCDs, whose L2s are only made coherent by these fences
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (t == 0) {
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      s_ticket = __hip_atomic_fetch_add(sk->counter, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
+          buf_store4_wt(pr, mine + ((im * TN + in) * 4 + g) * 4096u,
+                        make_float4(acc[im][in][g * 4], acc[im][in][g * 4 + 1], acc[im][in][g * 4 + 2],
+                                    acc[im][in][g * 4 + 3]));
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // every wave drains its stores ...
+    __syncthreads();                                      // ... before one lane announces the part
+    if (t == 0) s_ticket = __hip_atomic_fetch_add(sk->counter, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __syncthreads();
     if (s_ticket != sk->parts - 1) return;
-    if (t == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-    __syncthreads();
+    if (t == 0) *sk->counter = 0;      // every part has arrived: ready for the next launch (no memset per launch)
     // all parts are in memory: sum them in part order (the same order whichever workgroup arrives last)
 #pragma unroll
     for (int im = 0; im < TM; ++im)
@@ -310,14 +305,14 @@ __device__ __forceinline__ void conv_fwd_split_body(const ConvArgs& a, char* sme
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[im][in][e] = 0.f;
     for (int p = 0; p < sk->parts; ++p) {
-      const float4* src = reinterpret_cast<const float4*>(sk->tile_ws) + (size_t)p * (BM * BN / 4);
+      const unsigned src = (unsigned)p * (BM * BN * 4) + (unsigned)t * 16u;
 #pragma unroll
       for (int im = 0; im < TM; ++im)
 #pragma unroll
         for (int in = 0; in < TN; ++in)
 #pragma unroll
           for (int g = 0; g < 4; ++g) {
-            const float4 v = src[((im * TN + in) * 4 + g) * 256 + t];
+            const float4 v = buf_load4_sc1(pr, src + ((im * TN + in) * 4 + g) * 4096u);
             acc[im][in][g * 4] += v.x; acc[im][in][g * 4 + 1] += v.y;
             acc[im][in][g * 4 + 2] += v.z; acc[im][in][g * 4 + 3] += v.w;
           }
@@ -935,7 +930,52 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_split_kernel(const WgradArg
     }
   }
 
-  float* out = a.direct ? a.out : a.out + (size_t)split * a.Cout * a.K;
+  const bool fused = !a.direct && a.counters;
+  if (fused) {
+    // in-kernel reduction over the splits: every split parks its tile lane-linear (16-byte write-through stores), the
+    // one that draws the last ticket sums the parts in split order and goes on to the final epilogue
+    __shared__ int s_ticket;
+    const size_t tile_bytes = (size_t)a.splits * TILE * TILE * 4;
+    const __amdgpu_buffer_rsrc_t pr = make_rsrc(reinterpret_cast<const char*>(a.out) + (size_t)tile * tile_bytes,
+                                                (unsigned)tile_bytes);
+    const unsigned mine = (unsigned)split * (TILE * TILE * 4) + (unsigned)t * 16u;
+#pragma unroll
+    for (int im = 0; im < 2; ++im)
+#pragma unroll
+      for (int in = 0; in < 2; ++in)
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+          buf_store4_wt(pr, mine + ((im * 2 + in) * 4 + g) * 4096u,
+                        make_float4(acc[im][in][g * 4], acc[im][in][g * 4 + 1], acc[im][in][g * 4 + 2],
+                                    acc[im][in][g * 4 + 3]));
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (t == 0) s_ticket = __hip_atomic_fetch_add(a.counters + tile, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    if (s_ticket != a.splits - 1) return;
+    if (t == 0) a.counters[tile] = 0;      // ready for the next launch
+#pragma unroll
+    for (int im = 0; im < 2; ++im)
+#pragma unroll
+      for (int in = 0; in < 2; ++in)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[im][in][e] = 0.f;
+    for (int p = 0; p < a.splits; ++p) {
+      const unsigned src = (unsigned)p * (TILE * TILE * 4) + (unsigned)t * 16u;
+#pragma unroll
+      for (int im = 0; im < 2; ++im)
+#pragma unroll
+        for (int in = 0; in < 2; ++in)
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            const float4 v = buf_load4_sc1(pr, src + ((im * 2 + in) * 4 + g) * 4096u);
+            acc[im][in][g * 4] += v.x; acc[im][in][g * 4 + 1] += v.y;
+            acc[im][in][g * 4 + 2] += v.z; acc[im][in][g * 4 + 3] += v.w;
+          }
+    }
+  }
+  const bool final_out = a.direct || fused;     // this workgroup writes dw itself (scale / accumulate applied here)
+  float* out = a.direct ? a.out : (fused ? a.final : a.out + (size_t)split * a.Cout * a.K);
   const int col_in = lane & 31, row_hi = 4 * (lane >> 5);
 #pragma unroll
   for (int in = 0; in < 2; ++in) {
@@ -949,7 +989,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_split_kernel(const WgradArg
         if (c >= a.Cout) continue;
         const size_t off = (size_t)c * a.K + kc;
         float v = acc[im][in][reg];
-        if (a.direct) {
+        if (final_out) {
           if (a.out_scale) v = v * a.out_scale[c];
           if (a.accumulate) v = v + out[off];
         }
