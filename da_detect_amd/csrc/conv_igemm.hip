@@ -572,9 +572,10 @@ bool streamk_plan(const ConvArgs& a, int variant, SkPlan* p) {
   if (tiles > 6 * slots && tail > slots / 2) return false;  // many passes: the idle share is small
   p->dp_tiles = tiles - tail;
   p->sk_tiles = tail;
-  p->units = slots;
+  // ranges of at least 8 K-tiles: a short tail (e.g. 32 tiles of 64 K-tiles behind three full passes) is spread over
+  // fewer workgroups rather than cut into slivers
   p->iters = ceil_div(tail * nk, slots);
-  if (p->iters < 8) return false;
+  if (p->iters < 8) p->iters = 8;
   p->units = ceil_div(tail * nk, p->iters);
   p->max_parts = ceil_div(nk, p->iters) + 1;
   return true;
