@@ -83,12 +83,26 @@ class FusedSGD(torch.optim.Optimizer):
             rows.append((p.data_ptr(), g.data_ptr(), st["momentum_buffer"].data_ptr(), p.numel(), lr, wd))
         key = tuple(rows)
         if self._table is None or self._table[0] != key:
+            # The table changes every step under a per-iteration schedule (the cosine schedule of the reference's
+            # trainer rewrites every group's lr): it is staged in one of two pinned host buffers and uploaded on the
+            # compute stream without blocking the host (a pageable `.to(device)` here stalled the host once per step
+            # until the stream had drained); the kernel of step t reads device copy t % 2.
             arr = (SgdEntry * len(rows))()
             for i, r in enumerate(rows):
                 arr[i].p, arr[i].g, arr[i].buf, arr[i].numel, arr[i].lr, arr[i].weight_decay = r
-            raw = bytes(arr)
-            host = torch.frombuffer(bytearray(raw), dtype=torch.uint8)
-            dev = host.to(entries[0][0].device)
+            nbytes = ctypes.sizeof(arr)
+            slot = self._steps % 2
+            stage = getattr(self, "_stage", None)
+            if stage is None or stage[0][0].numel() != nbytes:
+                device = entries[0][0].device
+                stage = self._stage = [(torch.empty(nbytes, dtype=torch.uint8).pin_memory(),
+                                        torch.empty(nbytes, dtype=torch.uint8, device=device),
+                                        torch.cuda.Event()) for _ in range(2)]
+            host, dev, done = stage[slot]
+            done.synchronize()            # the upload issued two steps ago from this buffer (long finished)
+            ctypes.memmove(host.data_ptr(), ctypes.addressof(arr), nbytes)
+            dev.copy_(host, non_blocking=True)
+            done.record()
             self._table = (key, dev, max(r[3] for r in rows), len(rows))
         _, dev, max_numel, n = self._table
         _lib.call("dadet_sgd_step", ctypes.c_void_p(dev.data_ptr()), n, ctypes.c_int64(max_numel),

@@ -126,31 +126,25 @@ def test_gradients_match_cpu_oracle(device):
     losses, _ = _run_with_golden_rpn_selection(model, z, images, targets, seed, device, inject=True)
     sum(losses.values()).backward()
     names = [n for n, p in model.named_parameters() if p.requires_grad]
-    osd = {k: v.clone() for k, v in sd.items()}
+    # the oracle in FLOAT64: against it the HIP path is at rounding level on every tensor that no flipped ReLU touches
+    # (test_default_path_gpu._check_gradients: every tensor < 4e-3, at least 90% of them < 5e-5); the earlier form of
+    # this test compared with the fp32 oracle and had to allow 1e-3 in L2 and 2e-2 in the max norm
+    osd = {k: (v.clone().double() if v.is_floating_point() else v.clone()) for k, v in sd.items()}
     for n in names:
         osd[n].requires_grad_(True)
     cpu_images, cpu_targets = make_batch(c, nimg, H, W, seed=seed, device=torch.device("cpu"))
     torch.manual_seed(seed)
-    olosses = model_ref.training_losses(osd, c, cpu_images.tensors, model_ref.targets_to_dicts(cpu_targets),
+    olosses = model_ref.training_losses(osd, c, cpu_images.tensors.double(), model_ref.targets_to_dicts(cpu_targets),
                                         selection_maps=(torch.from_numpy(z["objectness"]), torch.from_numpy(z["deltas"])))
     for k in olosses:  # same sampled ROIs on both sides -> same losses
-        assert abs(float(olosses[k]) - float(losses[k])) <= 1e-4 * max(abs(float(olosses[k])), 1.0), k
+        assert abs(float(olosses[k].detach()) - float(losses[k].detach())) <= 1e-4 * max(abs(float(olosses[k].detach())), 1.0), k
     sum(olosses.values()).backward()
     params = dict(model.named_parameters())
-    # metric: relative L2 error per tensor (a ReLU whose pre-activation is within fp32 noise of zero may fire on
-    # one device and not on the other; that perturbs a few entries by O(entry) and is not a kernel defect, so the
-    # max-norm gets a looser bound than the L2 norm)
-    worst_l2 = worst_max = 0.0
-    for n in names:
-        want = osd[n].grad
-        got = params[n].grad.detach().cpu()
-        assert want is not None and got is not None, n
-        l2 = float((got - want).norm()) / (float(want.norm()) + 1e-20)
-        mx = float((got - want).abs().max()) / (float(want.abs().max()) + 1e-20)
-        worst_l2, worst_max = max(worst_l2, l2), max(worst_max, mx)
-        assert l2 < 1e-3, "%s: relative L2 gradient error %.3e" % (n, l2)
-        assert mx < 2e-2, "%s: max-norm gradient error %.3e" % (n, mx)
-    print("worst relative L2 / max gradient error: %.3e / %.3e over %d tensors" % (worst_l2, worst_max, len(names)))
+    from test_default_path_gpu import _check_gradients
+
+    worst, above = _check_gradients({n: params[n].grad.detach().cpu() for n in names}, {n: osd[n].grad for n in names})
+    print("worst relative L2 gradient error vs the fp64 oracle: %.3e over %d tensors; above rounding level: %s" % (
+        worst, len(names), above))
 
 
 def test_fused_sgd_matches_torch_sgd(device):
