@@ -107,6 +107,7 @@ inline int fwd_variant(int M, int Cout) {
 int gemm_mode();
 int launch_fwd_split(ConvArgs& a, int variant, int terms, hipStream_t st);
 int launch_fwd_split_sk(ConvArgs& a, int terms, hipStream_t st);
+int launch_fwd_split_db(ConvArgs& a, hipStream_t st);
 int launch_wgrad_split(WgradArgs& a, int terms, hipStream_t st);
 
 }  // namespace dadet

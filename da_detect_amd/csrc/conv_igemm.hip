@@ -633,6 +633,12 @@ extern "C" int dadet_conv_forward(const dadet_conv_desc* d, const float* x, cons
   a.sk_counters = nullptr;
   if (gemm_mode() != 0) {
     const int variant = split_fwd_variant(a.M, a.Cout, a.K);
+    {
+      // experiment (DADET_DB=1): double-buffered K-steps of 16 for the 128x128 variant, whole-K launches only
+      const char* env = getenv("DADET_DB");
+      if (env && env[0] == '1' && variant == 0 && gemm_mode() == 3 && a.Cin % 16 == 0 && !a.ablate)
+        return launch_fwd_split_db(a, st);
+    }
     SkPlan sk;
     if (streamk_plan(a, variant, &sk)) {
       // partial tiles in the per-stream scratch (reused in stream order), arrival counters in their own buffer

@@ -55,6 +55,66 @@ __device__ inline void split4(const float4 v, uint2 (&out)[TERMS]) {
 // AB: stage-ablation mask for profiling experiments (tools/ablate.py).  It is a COMPILE-TIME parameter: as run-time
 // branches the checks cut the K loop into a dozen basic blocks and the scheduler could no longer interleave the
 // MFMAs with the split / LDS traffic across them.  Production launches use AB = 0.
+// fused epilogue of the forward / data-gradient GEMM (same as conv_igemm.hip): y = gate(acc * scale + bias + addend);
+// a split-K launch stores raw partial sums (no scale / bias / addend / gate)
+template <int TM, int TN>
+__device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[TM][TN], const int bm0, const int bn0,
+                                              const int wm, const int wn, const int lane, const unsigned split_y) {
+  const int HoWo = a.Ho * a.Wo;
+  const __amdgpu_buffer_rsrc_t yr = make_rsrc(a.y + (size_t)split_y * a.split_stride, a.y_bytes);
+  const __amdgpu_buffer_rsrc_t ar = make_rsrc(a.addend ? a.addend : a.y, a.addend ? a.y_bytes : 0u);
+  const __amdgpu_buffer_rsrc_t mr = make_rsrc(a.mask_ref ? a.mask_ref : a.y, a.mask_ref ? a.y_bytes : 0u);
+  const int col_in = lane & 31;
+  const int row_hi = 4 * (lane >> 5);
+#pragma unroll
+  for (int in = 0; in < TN; ++in) {
+    const int n = bn0 + wn * TN * 32 + in * 32 + col_in;
+    const bool nvalid = n < a.Cout;
+    const float sc = (a.scale && nvalid) ? a.scale[n] : 1.f;
+    const float bi = (a.bias && nvalid) ? a.bias[n] : 0.f;
+#pragma unroll
+    for (int im = 0; im < TM; ++im) {
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        unsigned offs[4];
+        float add[4], msk[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int m = bm0 + wm * TM * 32 + im * 32 + q + 8 * g + row_hi;
+          unsigned orow = (unsigned)m;
+          if (a.os != 1) {
+            const int img = m / HoWo;
+            const int rem = m - img * HoWo;
+            const int ho = rem / a.Wo;
+            const int wo = rem - ho * a.Wo;
+            orow = (unsigned)((img * a.OutH + ho * a.os) * a.OutW + wo * a.os);
+          }
+          offs[q] = (nvalid && m < a.M) ? (orow * (unsigned)a.Cout + (unsigned)n) * 4u : kOOB;
+        }
+        if (a.addend) {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) add[q] = buf_load1(ar, offs[q]);
+        }
+        if (a.relu_mode == 2) {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) msk[q] = buf_load1(mr, offs[q]);
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          float v = acc[im][in][g * 4 + q];
+          if (a.scale) v = v * sc;
+          if (a.bias) v = v + bi;
+          if (a.addend) v = v + add[q];
+          if (a.relu_mode == 1) v = fmaxf(v, 0.f);
+          else if (a.relu_mode == 2) v = (msk[q] > 0.f) ? v : 0.f;
+          buf_store1(yr, offs[q], v);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+  }
+}
+
 // One output tile over the K range [k_lo, k_hi) (whole K-tiles).  sk = nullptr: the result goes through the epilogue.
 // sk != nullptr (stream-K segment, see conv_fwd_split_sk_kernel): the raw partial sums are parked in the tile's workspace
 // slot; the workgroup that parks a tile's LAST missing part sums all parts in part order and runs the epilogue.
@@ -319,59 +379,7 @@ __device__ __forceinline__ void conv_fwd_split_body(const ConvArgs& a, char* sme
     }
   }
 
-  // epilogue (same as conv_igemm.hip); a split-K launch stores raw partial sums (no scale / bias / addend / gate)
-  const __amdgpu_buffer_rsrc_t yr = make_rsrc(a.y + (size_t)split_y * a.split_stride, a.y_bytes);
-  const __amdgpu_buffer_rsrc_t ar = make_rsrc(a.addend ? a.addend : a.y, a.addend ? a.y_bytes : 0u);
-  const __amdgpu_buffer_rsrc_t mr = make_rsrc(a.mask_ref ? a.mask_ref : a.y, a.mask_ref ? a.y_bytes : 0u);
-  const int col_in = lane & 31;
-  const int row_hi = 4 * (lane >> 5);
-#pragma unroll
-  for (int in = 0; in < TN; ++in) {
-    const int n = bn0 + wn * TN * 32 + in * 32 + col_in;
-    const bool nvalid = n < a.Cout;
-    const float sc = (a.scale && nvalid) ? a.scale[n] : 1.f;
-    const float bi = (a.bias && nvalid) ? a.bias[n] : 0.f;
-#pragma unroll
-    for (int im = 0; im < TM; ++im) {
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        unsigned offs[4];
-        float add[4], msk[4];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const int m = bm0 + wm * TM * 32 + im * 32 + q + 8 * g + row_hi;
-          unsigned orow = (unsigned)m;
-          if (a.os != 1) {
-            const int img = m / HoWo;
-            const int rem = m - img * HoWo;
-            const int ho = rem / a.Wo;
-            const int wo = rem - ho * a.Wo;
-            orow = (unsigned)((img * a.OutH + ho * a.os) * a.OutW + wo * a.os);
-          }
-          offs[q] = (nvalid && m < a.M) ? (orow * (unsigned)a.Cout + (unsigned)n) * 4u : kOOB;
-        }
-        if (a.addend) {
-#pragma unroll
-          for (int q = 0; q < 4; ++q) add[q] = buf_load1(ar, offs[q]);
-        }
-        if (a.relu_mode == 2) {
-#pragma unroll
-          for (int q = 0; q < 4; ++q) msk[q] = buf_load1(mr, offs[q]);
-        }
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          float v = acc[im][in][g * 4 + q];
-          if (a.scale) v = v * sc;
-          if (a.bias) v = v + bi;
-          if (a.addend) v = v + add[q];
-          if (a.relu_mode == 1) v = fmaxf(v, 0.f);
-          else if (a.relu_mode == 2) v = (msk[q] > 0.f) ? v : 0.f;
-          buf_store1(yr, offs[q], v);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-      }
-    }
-  }
+  conv_epilogue<TM, TN>(a, acc, bm0, bn0, wm, wn, lane, split_y);
 }
 
 template <int TM, int TN, int TERMS, int AB = 0>
@@ -423,6 +431,179 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_split_sk_kernel(const ConvArg
     }
     it += k1 - k0;
   }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Double-buffered variant of the 128x128 kernel with K-steps of 16 (experiment, DADET_DB=1).
+// conv_fwd_split_body keeps ONE LDS image of a 32-deep K-tile and pays, per K-tile, "barrier, 12 ds_writes, barrier" with
+// no MFMA in flight for that workgroup (stage ablation: 0.16 of 1.61 ms on the RPN conv).  Here a K-step is 16 deep
+// (one MFMA k-group), the LDS holds TWO steps (2 x 3 planes x 256 rows x 48 B = 72 KB: two workgroups per CU still fit),
+// and the planes of step s + 1 are written into the other buffer WHILE the MFMAs of step s run — one barrier per step
+// and no store phase.  48-byte rows: ds_read_b128 of 16 consecutive rows and ds_write_b64 of 8 same-parity rows each
+// cover all 64 banks exactly once.
+constexpr int DB_STRIDE = 24;   // bf16 per staged row: 16 + 8 pad = 48 bytes
+
+template <int TERMS>
+__global__ __launch_bounds__(256, 2) void conv_fwd_split_db_kernel(const ConvArgs a) {
+  constexpr int TM = 2, TN = 2, BM = 128, BN = 128, KS = 16;
+  constexpr int PLANE = 128 * DB_STRIDE;                 // bf16 elements of one operand plane
+  constexpr int BUF = 2 * TERMS * PLANE;                 // one buffer: A planes then B planes
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  __bf16* lds = reinterpret_cast<__bf16*>(smem);
+  const int tile = xcd_remap(blockIdx.x, a.tiles_m * a.tiles_n);
+  const int bm0 = (tile / a.tiles_n) * BM;
+  const int bn0 = (tile % a.tiles_n) * BN;
+  const int t = threadIdx.x;
+  const int lane = t & 63, wave = t >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int lcol = t & 3;                                // 4 lanes x 4 floats = the 16 k of a row
+  const int slot = lane >> 2;                            // 16 row slots per wave: 8 even rows, then 8 odd rows
+  const int lrow = wave * 16 + (slot < 8 ? 2 * slot : 2 * (slot - 8) + 1);
+
+  const __amdgpu_buffer_rsrc_t xr = make_rsrc(a.x, a.x_bytes);
+  const __amdgpu_buffer_rsrc_t wr = make_rsrc(a.w, a.w_bytes);
+  int pixbase[2], hi0[2], wi0[2];
+  const int HoWo = a.Ho * a.Wo;
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int m = bm0 + lrow + 64 * i;
+    if (m < a.M) {
+      const int img = m / HoWo;
+      const int rem = m - img * HoWo;
+      const int ho = rem / a.Wo;
+      const int wo = rem - ho * a.Wo;
+      pixbase[i] = img * a.H * a.W;
+      hi0[i] = ho * a.stride - a.pad;
+      wi0[i] = wo * a.stride - a.pad;
+    } else {
+      pixbase[i] = 0;
+      hi0[i] = -(1 << 28);
+      wi0[i] = 0;
+    }
+  }
+  unsigned wrow[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int n = bn0 + lrow + 64 * i;
+    wrow[i] = n < a.Cout ? (unsigned)n * (unsigned)a.K * 4u : kOOB;
+  }
+  float4 ra[2], rb[2];
+  int kk = lcol * 4;
+  int tap = kk / a.Cin;
+  int kc = kk - tap * a.Cin;
+  int kr = tap / a.KW;
+  int ks = tap - kr * a.KW;
+  auto load_ab = [&]() {
+    const bool kvalid = kk < a.K;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int hi = hi0[i] + kr, wi = wi0[i] + ks;
+      const bool ok = kvalid && (unsigned)hi < (unsigned)a.H && (unsigned)wi < (unsigned)a.W;
+      const unsigned off = ((unsigned)(pixbase[i] + hi * a.W + wi) * (unsigned)a.Cin + (unsigned)kc) * 4u;
+      ra[i] = buf_load4(xr, ok ? off : kOOB);
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+      rb[i] = buf_load4(wr, (kvalid && wrow[i] != kOOB) ? wrow[i] + (unsigned)kk * 4u : kOOB);
+  };
+  auto advance = [&]() {
+    kk += KS;
+    kc += KS;
+    while (kc >= a.Cin) {
+      kc -= a.Cin;
+      if (++ks == a.KW) {
+        ks = 0;
+        ++kr;
+      }
+    }
+  };
+  uint2 pa_[2][TERMS], pb_[2][TERMS];
+  auto split_ab = [&]() {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) split4<TERMS>(ra[i], pa_[i]);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) split4<TERMS>(rb[i], pb_[i]);
+  };
+  auto store_step = [&](int buf) {
+    __bf16* As = lds + buf * BUF;
+    __bf16* Bs = As + TERMS * PLANE;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int p = 0; p < TERMS; ++p) {
+        *reinterpret_cast<uint2*>(As + p * PLANE + (lrow + 64 * i) * DB_STRIDE + lcol * 4) = pa_[i][p];
+        *reinterpret_cast<uint2*>(Bs + p * PLANE + (lrow + 64 * i) * DB_STRIDE + lcol * 4) = pb_[i][p];
+      }
+  };
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  const int nsteps = (a.K + KS - 1) / KS;
+  load_ab();
+  advance();
+  split_ab();
+  store_step(0);
+  load_ab();       // step 1 is in flight while step 0 is multiplied
+  advance();
+  __syncthreads();
+
+  const int frag_row = lane & 31;
+  const int frag_k = (lane >> 5) * 8;
+  const int a_off = (wm * 64 + frag_row) * DB_STRIDE + frag_k;
+  const int b_off = TERMS * PLANE + (wn * 64 + frag_row) * DB_STRIDE + frag_k;
+  for (int s = 0; s < nsteps; ++s) {
+    const __bf16* cur = lds + (s & 1) * BUF;
+    bf16x8 fa[TERMS][TM], fb[TERMS][TN];
+#pragma unroll
+    for (int p = 0; p < TERMS; ++p) {
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+        fa[p][i] = *reinterpret_cast<const bf16x8*>(cur + a_off + p * PLANE + i * 32 * DB_STRIDE);
+#pragma unroll
+      for (int i = 0; i < TN; ++i)
+        fb[p][i] = *reinterpret_cast<const bf16x8*>(cur + b_off + p * PLANE + i * 32 * DB_STRIDE);
+    }
+    // step s + 1's operands landed a step ago: split them in the shadow of the MFMAs and write them into the OTHER buffer
+    // (every wave finished reading it before the barrier that ended step s - 1)
+    split_ab();
+#pragma unroll
+    for (int order = 2 * (TERMS - 1); order >= 0; --order) {
+#pragma unroll
+      for (int pa = 0; pa < TERMS; ++pa) {
+        const int pb = order - pa;
+        if (pb < 0 || pb >= TERMS) continue;
+        if (pa + pb > TERMS - 1) continue;
+#pragma unroll
+        for (int im = 0; im < TM; ++im)
+#pragma unroll
+          for (int in = 0; in < TN; ++in)
+            acc[im][in] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[pa][im], fb[pb][in], acc[im][in], 0, 0, 0);
+      }
+    }
+    store_step((s + 1) & 1);
+    {
+      constexpr int kMfma = TM * TN * (TERMS == 3 ? 6 : 3);
+      constexpr int kValuPerMfma = 4 * (TERMS == 3 ? 26 : 14) / kMfma + 1;
+      __builtin_amdgcn_sched_group_barrier(0x100, TERMS * (TM + TN), 0);   // DS reads
+#pragma unroll
+      for (int i = 0; i < kMfma; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                 // one MFMA
+        __builtin_amdgcn_sched_group_barrier(0x002, kValuPerMfma, 0);      // VALU in its shadow
+        if (i >= kMfma / 2 && i < kMfma / 2 + 4 * TERMS)
+          __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);               // one DS write per MFMA in the second half
+      }
+    }
+    load_ab();     // step s + 2 (out of range past the end: zeros)
+    advance();
+    __syncthreads();
+  }
+  conv_epilogue<TM, TN>(a, acc, bm0, bn0, wm, wn, lane, 0);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -705,6 +886,24 @@ static int launch_split_sk(ConvArgs& a, hipStream_t st) {
   }
   hipLaunchKernelGGL((conv_fwd_split_sk_kernel<TERMS>), dim3(a.sk_dp_tiles + a.sk_units), dim3(256), lds, st, a);
   return check_launch("conv_forward(split, stream-K)");
+}
+
+int launch_fwd_split_db(ConvArgs& a, hipStream_t st) {
+  a.tiles_m = ceil_div(a.M, 128);
+  a.tiles_n = ceil_div(a.Cout, 128);
+  const size_t lds = sizeof(__bf16) * 2 * 2 * 3 * 128 * DB_STRIDE;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_fwd_split_db_kernel<3>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) {
+      set_error("conv_forward(split, double-buffered): hipFuncSetAttribute: %s", hipGetErrorString(e));
+      return DADET_ELAUNCH;
+    }
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((conv_fwd_split_db_kernel<3>), dim3(a.tiles_m * a.tiles_n), dim3(256), lds, st, a);
+  return check_launch("conv_forward(split, double-buffered)");
 }
 
 int launch_fwd_split_sk(ConvArgs& a, int terms, hipStream_t st) {
