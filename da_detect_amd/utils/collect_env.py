@@ -1,22 +1,36 @@
-"""Environment report logged at start-up (reference: maskrcnn_benchmark/utils/collect_env.py:1-14): torch's own report
-plus the Pillow version; here also the HIP device the kernels were built for."""
-import PIL
-from torch.utils.collect_env import get_pretty_env_info
+"""Environment report logged once at start-up by the entry points (reference: maskrcnn_benchmark/utils/collect_env.py):
+torch's own environment summary, the Pillow version (the host-side image decoding / resizing library whose arithmetic
+the device pipeline reproduces), and the HIP device the kernels run on."""
+
+
+def _pillow_line():
+    import PIL
+
+    return "        Pillow ({})".format(PIL.__version__)
+
+
+def _device_line():
+    import torch
+
+    if not torch.cuda.is_available():
+        return None
+    props = torch.cuda.get_device_properties(0)
+    return "        HIP device 0: {} ({} CUs, {:.0f} GB); libdadet_hip.so is built for gfx950".format(
+        props.name, props.multi_processor_count, props.total_memory / 2 ** 30)
 
 
 def get_pil_version():
-    return "\n        Pillow ({})".format(PIL.__version__)
+    return "\n" + _pillow_line()
 
 
 def collect_env_info():
-    env_str = get_pretty_env_info()
-    env_str += get_pil_version()
+    from torch.utils.collect_env import get_pretty_env_info
+
+    parts = [get_pretty_env_info(), _pillow_line()]
     try:
-        import torch
-        if torch.cuda.is_available():
-            p = torch.cuda.get_device_properties(0)
-            env_str += "\n        HIP device 0: {} ({} CUs, {:.0f} GB); libdadet_hip.so built for gfx950".format(
-                p.name, p.multi_processor_count, p.total_memory / 2 ** 30)
-    except Exception:      # the report is informational
+        dev = _device_line()
+        if dev:
+            parts.append(dev)
+    except Exception:      # informational only
         pass
-    return env_str
+    return "\n".join(parts)

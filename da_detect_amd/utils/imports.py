@@ -1,15 +1,22 @@
-"""Load a python module from an explicit file path (reference: maskrcnn_benchmark/utils/imports.py:12-24).
-Used for `cfg.PATHS_CATALOG` (the site's dataset catalog) and TORCH_DETECTRON_ENV_MODULE."""
-import importlib.util
+"""Load a python module from an explicit file path (reference: maskrcnn_benchmark/utils/imports.py).  Used for
+`cfg.PATHS_CATALOG` (the site's dataset / model catalog) and for TORCH_DETECTRON_ENV_MODULE."""
 import sys
+from importlib import util as _util
 
 
 def import_file(module_name, file_path, make_importable=False):
-    spec = importlib.util.spec_from_file_location(module_name, file_path)
+    """execute `file_path` as module `module_name`; with make_importable it is also registered in sys.modules so that a
+    later `import module_name` finds it"""
+    spec = _util.spec_from_file_location(module_name, file_path)
     if spec is None or spec.loader is None:
         raise ImportError("cannot load %r from %r" % (module_name, file_path))
-    module = importlib.util.module_from_spec(spec)
-    spec.loader.exec_module(module)
+    mod = _util.module_from_spec(spec)
     if make_importable:
-        sys.modules[module_name] = module
-    return module
+        sys.modules[module_name] = mod
+    try:
+        spec.loader.exec_module(mod)
+    except BaseException:
+        if make_importable:
+            sys.modules.pop(module_name, None)
+        raise
+    return mod
