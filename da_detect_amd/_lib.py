@@ -101,6 +101,12 @@ def load():
         raise DadetError(
             "libdadet_hip.so is not built (%s). Run `python -c 'import __graft_entry__ as g; g.build()'` "
             "or `make -C da_detect_amd/csrc`. There is no CPU fallback for the product path." % LIB_PATH)
+    # torch first: its wheel carries its own libamdhip64, and libdadet_hip.so must bind to THAT copy (same SONAME, already
+    # loaded).  Loaded the other way round the process ends up with two HIP runtimes (/opt/rocm's for this library,
+    # torch's for torch) and the second one to initialise reports "no ROCm-capable device is detected" — seen when
+    # __graft_entry__.build() (which loads the library without touching torch) and smoke() ran in one process.
+    import torch  # noqa: F401
+
     lib = ctypes.CDLL(LIB_PATH)
     for name, argtypes in _SIGNATURES.items():
         fn = getattr(lib, name)
