@@ -17,19 +17,26 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _one_step(workload, overlapped, seed, device):
+def _setup(workload, device):
     if ROOT not in sys.path:
         sys.path.insert(0, ROOT)
     import bench
     from da_detect_amd.data.synthetic import make_batch
-    from da_detect_amd.engine.trainer import enable_overlapped_rpn_backward
-    from da_detect_amd.utils import streams
 
     yaml_path, overrides, images_per_gpu, _ = bench.WORKLOADS[workload]
     c, model, opt, reducer = bench.build(yaml_path, device, seed=100, overrides=overrides)
+    images, targets = make_batch(c, images_per_gpu, 1024, 2048, seed=100, device=device)
+    return model, opt, reducer, images, targets
+
+
+def _one_step(ctx, overlapped, seed):
+    """forward + backward (no optimizer step: the parameters stay what they were, so the runs are comparable)"""
+    from da_detect_amd.engine.trainer import enable_overlapped_rpn_backward
+    from da_detect_amd.utils import streams
+
+    model, opt, reducer, images, targets = ctx
     enable_overlapped_rpn_backward(model, overlapped)
     streams.enable_direct_wgrad(overlapped)
-    images, targets = make_batch(c, images_per_gpu, 1024, 2048, seed=100, device=device)
     evaluator = model.roi_heads.box.loss_evaluator
     torch.manual_seed(seed)
     try:
@@ -48,11 +55,12 @@ def _one_step(workload, overlapped, seed, device):
 
 @pytest.mark.parametrize("workload", ["img_only", "da", "triplet", "triplet_aligned"])
 def test_full_size_step_schedules_agree(device, workload):
-    l_ov, s_ov, g_ov = _one_step(workload, True, 7, device)
+    ctx = _setup(workload, device)
+    l_ov, s_ov, g_ov = _one_step(ctx, True, 7)
     assert all(v == v and abs(v) < 1e6 for v in l_ov.values()), l_ov
     assert len(g_ov) > 50 and all(bool(torch.isfinite(g).all()) for g in g_ov.values())
     assert all(len(b) == 256 for b in s_ov), [len(b) for b in s_ov]
-    l_pl, s_pl, g_pl = _one_step(workload, False, 7, device)
+    l_pl, s_pl, g_pl = _one_step(ctx, False, 7)
     assert set(l_ov) == set(l_pl)
     for a, b in zip(s_ov, s_pl):
         assert torch.equal(a, b), "the two schedules sampled different ROIs from the same seed"
@@ -62,7 +70,7 @@ def test_full_size_step_schedules_agree(device, workload):
     for n in g_ov:
         err = float((g_ov[n] - g_pl[n]).norm()) / (float(g_pl[n].norm()) + 1e-30)
         assert err < 1e-4, "%s: overlapped vs plain schedule, relative L2 %.2e" % (n, err)
-    l_again, s_again, _ = _one_step(workload, True, 7, device)
+    l_again, s_again, _ = _one_step(ctx, True, 7)
     for a, b in zip(s_ov, s_again):
         assert torch.equal(a, b)
     for k in l_ov:      # sums with atomics (image-level DA loss) differ in the last bits between runs

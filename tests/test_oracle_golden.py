@@ -179,3 +179,34 @@ def test_model_ref_inference_fpn_reproduces_reference_detections():
         assert np.array_equal(d["labels"].numpy(), z["det/%d/labels" % i])
         np.testing.assert_allclose(d["boxes"].numpy(), z["det/%d/boxes" % i], atol=2e-3)
         np.testing.assert_allclose(d["scores"].numpy(), z["det/%d/scores" % i], atol=1e-6)
+
+
+def test_device_draw_restatement_follows_the_sampler_rule():
+    """oracle/model_ref.sample_pos_neg_device restates the PRODUCT's random draw (csrc/sampling.hip) so that the default
+    GPU path can be compared with the oracle on the same sample (tests/test_default_path_gpu.py).  Here: the key is the
+    scalar splitmix64 finaliser, and the subsets obey the reference sampler's rule
+    (balanced_positive_negative_sampler.py:27-76) — counts per class, ignored rows never taken, smallest keys win, ties
+    to the lower index."""
+    from oracle import model_ref
+
+    def key(seed, i):
+        m = (1 << 64) - 1
+        z = (seed + (i + 1) * 0x9E3779B97F4A7C15) & m
+        z = ((z ^ (z >> 30)) * 0xBF58476D1CE4E5B9) & m
+        z = ((z ^ (z >> 27)) * 0x94D049BB133111EB) & m
+        return (z ^ (z >> 31)) >> 32
+
+    seed = 0xDEADBEEFCAFEBABE
+    keys = model_ref.device_sample_keys(seed, 500)
+    assert all(int(keys[i]) == key(seed, i) for i in range(500))
+    g = torch.Generator().manual_seed(4)
+    labels = torch.randint(-1, 4, (5000,), generator=g)
+    pm, nm = model_ref.sample_pos_neg_device(labels, 256, 0.25, seed)
+    assert int(pm.sum()) == 64 and int(nm.sum()) == 192
+    assert bool((labels[pm] >= 1).all()) and bool((labels[nm] == 0).all()) and not bool((pm & nm).any())
+    all_keys = model_ref.device_sample_keys(seed, 5000).astype(np.int64)
+    pos = torch.nonzero(labels >= 1).squeeze(1).numpy()
+    assert all_keys[pm.numpy()].max() <= np.sort(all_keys[pos])[64 - 1]           # the 64 smallest keys of the class
+    few = torch.tensor([1, 0, -1, 0, 1, 0])                                       # fewer candidates than the quota
+    pm, nm = model_ref.sample_pos_neg_device(few, 256, 0.25, 7)
+    assert pm.tolist() == [True, False, False, False, True, False] and nm.tolist() == [False, True, False, True, False, True]
