@@ -158,7 +158,21 @@ def self_spawn(n):
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
                                       stdout=None if rank == 0 else subprocess.DEVNULL))
-    codes = [p.wait() for p in procs]
+    # a rank that dies leaves the others waiting in a collective: stop them (exact PIDs) instead of hanging
+    codes = [None] * n
+    while any(c is None for c in codes):
+        for i, p in enumerate(procs):
+            if codes[i] is None:
+                codes[i] = p.poll()
+        failed = [c for c in codes if c not in (None, 0)]
+        if failed:
+            time.sleep(5.0)       # let the others fail on their own first (clean error messages)
+            for i, p in enumerate(procs):
+                if p.poll() is None:
+                    p.kill()
+                codes[i] = p.wait()
+            break
+        time.sleep(0.2)
     return max(abs(c) for c in codes)
 
 
