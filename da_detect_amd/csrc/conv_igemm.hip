@@ -626,6 +626,11 @@ extern "C" int dadet_conv_forward(const dadet_conv_desc* d, const float* x, cons
     a.ablate = ablate;
   }
   hipStream_t st = as_stream(stream);
+  {
+    const char* env = getenv("DADET_EPILOGUE_V4");      // 0: the 4-byte epilogue (A/B runs, bit-identity test)
+    a.epi_v4 = !(env && env[0] == '0') && os == 1 && d->Cout % 4 == 0 && al16(y) && (!addend || al16(addend)) &&
+               (!mask_ref || al16(mask_ref)) && (!scale || al16(scale)) && (!bias || al16(bias));
+  }
   a.ksplit = 0;
   a.split_stride = 0;
   a.sk_dp_tiles = a.sk_tiles = a.sk_units = a.sk_iters = a.sk_max_parts = 0;

@@ -55,6 +55,79 @@ __device__ inline void split4(const float4 v, uint2 (&out)[TERMS]) {
 // AB: stage-ablation mask for profiling experiments (tools/ablate.py).  It is a COMPILE-TIME parameter: as run-time
 // branches the checks cut the K loop into a dozen basic blocks and the scheduler could no longer interleave the
 // MFMAs with the split / LDS traffic across them.  Production launches use AB = 0.
+// Vectorised form of the fused epilogue (round 2).  An MFMA 32x32 accumulator gives a lane 16 values of ONE output column
+// (4 x 4 consecutive rows), so the scalar epilogue below moves 4 bytes per lane and instruction: 64 stores plus up to
+// 128 loads (residual, ReLU mask) per lane for a 64 x 64 wave tile.  The short-K layers (res2 / res3 1x1 convs: K = 64 ..
+// 256, two to eight K-tiles) are nothing but prologue and epilogue and ran at 3.6 - 3.9 TB/s.  Here every 32 x 32 block
+// is turned through the wave's slice of the (by then idle) operand LDS — 16 ds_write_b32 into [32][40] floats (rows r
+// and r + 4 of the two half-waves fall on disjoint bank halves), 4 ds_read_b128 back — so that a lane owns 4 consecutive
+// COLUMNS of 4 rows and y / addend / mask move 16 bytes per lane.  Same arithmetic per element, in the same order:
+// results are bit-identical to the scalar epilogue (tests/test_ops_gpu.py).  Needs Cout % 4 == 0, 16-byte aligned
+// tensors, no output stride; otherwise the scalar form runs.
+constexpr int EPI_STRIDE = 40;     // floats per transposed row
+
+template <int TM, int TN>
+__device__ __forceinline__ void conv_epilogue_v4(const ConvArgs& a, f32x16 (&acc)[TM][TN], char* smem, const int bm0,
+                                                 const int bn0, const int wm, const int wn, const int lane,
+                                                 const int wave, const unsigned split_y) {
+  float* tile = reinterpret_cast<float*>(smem) + wave * (32 * EPI_STRIDE);
+  const __amdgpu_buffer_rsrc_t yr = make_rsrc(a.y + (size_t)split_y * a.split_stride, a.y_bytes);
+  const __amdgpu_buffer_rsrc_t ar = make_rsrc(a.addend ? a.addend : a.y, a.addend ? a.y_bytes : 0u);
+  const __amdgpu_buffer_rsrc_t mr = make_rsrc(a.mask_ref ? a.mask_ref : a.y, a.mask_ref ? a.y_bytes : 0u);
+  const int col_in = lane & 31, row_hi = 4 * (lane >> 5);
+  const int rrow = lane >> 3, c4 = (lane & 7) * 4;      // read side: 8 lanes x 16 B = one 32-column row
+  __syncthreads();                                       // every wave is done with the operand planes
+#pragma unroll
+  for (int in = 0; in < TN; ++in) {
+    const int n = bn0 + wn * TN * 32 + in * 32 + c4;
+    const bool nvalid = n < a.Cout;                      // Cout % 4 == 0: the four columns are valid together
+    float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), bi = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (a.scale && nvalid) sc = *reinterpret_cast<const float4*>(a.scale + n);
+    if (a.bias && nvalid) bi = *reinterpret_cast<const float4*>(a.bias + n);
+#pragma unroll
+    for (int im = 0; im < TM; ++im) {
+#pragma unroll
+      for (int g = 0; g < 4; ++g)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) tile[(q + 8 * g + row_hi) * EPI_STRIDE + col_in] = acc[im][in][g * 4 + q];
+      // a wave's own data only: no workgroup barrier, the LDS traffic of one wave is ordered
+      __builtin_amdgcn_s_waitcnt(0xc07f);                // lgkmcnt(0)
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int pass = 0; pass < 4; ++pass) {
+        const int row = pass * 8 + rrow;
+        const float4 v4 = *reinterpret_cast<const float4*>(tile + row * EPI_STRIDE + c4);
+        const int m = bm0 + wm * TM * 32 + im * 32 + row;
+        const unsigned off = (nvalid && m < a.M) ? ((unsigned)m * (unsigned)a.Cout + (unsigned)n) * 4u : kOOB;
+        float v[4] = {v4.x, v4.y, v4.z, v4.w};
+        const float s4[4] = {sc.x, sc.y, sc.z, sc.w}, b4[4] = {bi.x, bi.y, bi.z, bi.w};
+        float ad[4] = {0.f, 0.f, 0.f, 0.f}, mk[4] = {1.f, 1.f, 1.f, 1.f};
+        if (a.addend) {
+          const float4 t = buf_load4(ar, off);
+          ad[0] = t.x; ad[1] = t.y; ad[2] = t.z; ad[3] = t.w;
+        }
+        if (a.relu_mode == 2) {
+          const float4 t = buf_load4(mr, off);
+          mk[0] = t.x; mk[1] = t.y; mk[2] = t.z; mk[3] = t.w;
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          float x = v[e];
+          if (a.scale) x = x * s4[e];
+          if (a.bias) x = x + b4[e];
+          if (a.addend) x = x + ad[e];
+          if (a.relu_mode == 1) x = fmaxf(x, 0.f);
+          else if (a.relu_mode == 2) x = (mk[e] > 0.f) ? x : 0.f;
+          v[e] = x;
+        }
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, make_float4(v[0], v[1], v[2], v[3])), yr,
+                                               (int)off, 0, 0);
+      }
+      __builtin_amdgcn_wave_barrier();                   // the tile is rewritten by the next block
+    }
+  }
+}
+
 // fused epilogue of the forward / data-gradient GEMM (same as conv_igemm.hip): y = gate(acc * scale + bias + addend);
 // a split-K launch stores raw partial sums (no scale / bias / addend / gate)
 template <int TM, int TN>
@@ -379,7 +452,8 @@ __device__ __forceinline__ void conv_fwd_split_body(const ConvArgs& a, char* sme
     }
   }
 
-  conv_epilogue<TM, TN>(a, acc, bm0, bn0, wm, wn, lane, split_y);
+  if (a.epi_v4) conv_epilogue_v4<TM, TN>(a, acc, smem, bm0, bn0, wm, wn, lane, wave, split_y);
+  else conv_epilogue<TM, TN>(a, acc, bm0, bn0, wm, wn, lane, split_y);
 }
 
 template <int TM, int TN, int TERMS, int AB = 0>

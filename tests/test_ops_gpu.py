@@ -919,3 +919,42 @@ def test_hip_ops_against_the_reference_build_itself(device):
         want = ref.roi_align_forward(x, rois, 1 / 16.0, ph, ph, sr)
         got = _C.roi_align_forward(x.to(device), rois.to(device), 1 / 16.0, ph, ph, sr)
         assert torch.equal(got.cpu(), want), "ROIAlign forward differs from the reference build"
+
+
+@pytest.mark.parametrize("shape", [
+    # N, Cin, H, W, Cout, k, stride, pad
+    (2, 64, 64, 96, 256, 1, 1, 0),        # 64x64 tiles (short K), res2-like
+    (2, 128, 40, 60, 512, 1, 1, 0),       # ragged M
+    (2, 256, 40, 64, 256, 3, 1, 1),       # 128x128 tiles
+    (3, 96, 33, 47, 200, 3, 2, 1),        # stride 2, Cout % 128 != 0, 128x64 tiles
+    (512, 512, 7, 7, 512, 3, 1, 1),       # stream-K launch form
+])
+def test_vectorised_epilogue_is_bit_identical(device, shape):
+    """conv_epilogue_v4 (16 bytes per lane through an LDS transpose) against the 4-byte epilogue: every combination of
+    FrozenBN scale / bias, residual addend, ReLU and the data-gradient gate — identical bits"""
+    import os
+
+    from da_detect_amd import _C
+
+    N, Cin, H, W, Cout, k, stride, pad = shape
+    g = torch.Generator().manual_seed(sum(shape))
+    CL = torch.channels_last
+    x = torch.randn((N, Cin, H, W), generator=g).to(device).contiguous(memory_format=CL)
+    w = (torch.randn((Cout, Cin, k, k), generator=g) * 0.05).to(device).contiguous(memory_format=CL)
+    Ho, Wo = (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
+    scale = (torch.rand(Cout, generator=g) + 0.5).to(device)
+    bias = torch.randn(Cout, generator=g).to(device)
+    addend = torch.randn((N, Cout, Ho, Wo), generator=g).to(device).contiguous(memory_format=CL)
+    mask = torch.randn((N, Cout, Ho, Wo), generator=g).to(device).contiguous(memory_format=CL)
+    cases = [dict(), dict(bias=bias), dict(scale=scale, bias=bias, relu_mode=1),
+             dict(scale=scale, bias=bias, addend=addend, relu_mode=1), dict(addend=addend, mask_ref=mask, relu_mode=2),
+             dict(mask_ref=mask, relu_mode=2)]
+    out = {}
+    for flag in ("0", "1"):
+        os.environ["DADET_EPILOGUE_V4"] = flag
+        try:
+            out[flag] = [_C.conv_forward(x, w, stride=stride, pad=pad, **kw) for kw in cases]
+        finally:
+            os.environ.pop("DADET_EPILOGUE_V4")
+    for a, b, kw in zip(out["0"], out["1"], cases):
+        assert torch.equal(a, b), sorted(kw)
