@@ -122,6 +122,11 @@ class DomainAdaptationModule(torch.nn.Module):
     # opt-in (engine.trainer.enable_overlapped_rpn_backward), same contract as RPNModule.early_backward
     early_backward = False
 
+    @property
+    def needs_instance_features(self):
+        """False: no loss reads the instance-level features (the box head may then leave the target-domain ROIs out)"""
+        return self.ins_weight > 0 or self.cst_weight > 0
+
     def _image_level(self, img_features, targets):
         """image head: one fused evaluation serves both the BCE (GRL -w) and the consistency (GRL +w) paths.
         Several levels (FPN): the reference concatenates the per-level logits along dim 0 (loss.py:81-92), which
@@ -161,6 +166,13 @@ class DomainAdaptationModule(torch.nn.Module):
         if not self.training:
             return {}
         early, self._early = getattr(self, "_early", None), None
+        if da_ins_feature is None:
+            # the box head left the instance-level features out because no loss reads them (ROIBoxHead.forward)
+            assert not self.needs_instance_features
+            if early is not None:
+                return {"loss_da_image": early}
+            da_img_loss, _ = self._image_level(img_features, targets)
+            return {"loss_da_image": self.img_weight * da_img_loss} if self.img_weight > 0 else {}
         da_ins_feature = _pool_ins(da_ins_feature, self.resnet_backbone)
         # instance head: adversarial pass then consistency pass, each with its own dropout masks (same program order
         # of the random draws as the reference).  They are independent of the image head: on the GPU they run on a
@@ -233,6 +245,10 @@ class DomainAdaptationModule_triplet(torch.nn.Module):
         loss = current_loss.detach()
         adaptive = -adv_weight * torch.clamp(1.0 / loss, max=float(self.advGRL_threshold))
         return torch.where(loss <= self.adv_gate, adaptive, torch.full_like(loss, -base_weight))
+
+    @property
+    def needs_instance_features(self):
+        return self.ins_weight > 0 or self.cst_weight > 0
 
     def forward(self, img_features, da_ins_feature, da_ins_labels, da_ins_feas_set, img_fea_set, targets=None):
         if not self.training:

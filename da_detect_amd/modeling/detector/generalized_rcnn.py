@@ -64,6 +64,7 @@ class GeneralizedRCNN(nn.Module):
                 assert f.shape[0] == 3, "triplet training expects [source, target, auxiliary] batches"
                 da_img_fea_set = [[f[0:1]], [f[1:2]], [f[2:3]]]
                 ori_features, ori_targets = [f[0:2]], targets[0:2]
+                self.roi_heads.box.ins_features_unused = not self.da_heads_triplet.needs_instance_features
                 x, result, detector_losses, da_ins_feas, da_ins_labels = self.roi_heads(
                     ori_features, proposals[0:2], ori_targets)
                 if self.Aligned:
@@ -77,6 +78,7 @@ class GeneralizedRCNN(nn.Module):
                 da_losses = self.da_heads_triplet(ori_features, da_ins_feas, da_ins_labels, ins_set,
                                                   da_img_fea_set, ori_targets)
             elif self.training and self.da_heads:
+                self.roi_heads.box.ins_features_unused = not self.da_heads.needs_instance_features
                 x, result, detector_losses, da_ins_feas, da_ins_labels = self.roi_heads(features, proposals, targets)
                 da_losses = self.da_heads(features, da_ins_feas, da_ins_labels, targets)
             else:

@@ -195,6 +195,10 @@ class DeviceDraws(object):
         return int(self.seeds[self.taken_seeds - 1])
 
     def mask(self, shape):
+        if not self.masks:
+            # the product drew none: it evaluates the instance-level head only when a loss reads it, the reference (and
+            # this restatement) always (da_heads.py:402-439) — whatever mask is used here reaches no loss
+            return torch.full(tuple(shape), 2.0) * (torch.rand(tuple(shape), generator=torch.Generator().manual_seed(0)) < 0.5)
         self.taken_masks += 1
         m = self.masks[self.taken_masks - 1]
         assert tuple(m.shape) == tuple(shape), (tuple(m.shape), tuple(shape))

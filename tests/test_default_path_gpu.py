@@ -175,19 +175,15 @@ def test_default_path_matches_oracle_small(device, monkeypatch, case, overrides)
     c, sd, rec, nimg = _run_default_path(case, H, W, device, seed, monkeypatch, overrides)
     assert rec["early_rpn"] and rec["loss_prep_rows"], "not the default schedule"
     assert len(rec["anchors"]) == 1 and len(rec["rois"]) >= 2 and len(rec["seeds"]) == 1 + len(rec["rois"])
-    # gradients are checked against the fp64 oracle for two recipes; the third (same kernels, fewer heads) compares
-    # indices and losses with the fp32 oracle only — the CPU backward in fp64 is the slow part of this file
-    with_grads = case != "da_img_only"
-    if with_grads:
-        osd, olosses, inter = _oracle(c, sd, rec, nimg, H, W, seed, dtype=torch.float64)
-    else:
-        with torch.no_grad():
-            osd, olosses, inter = _oracle(c, sd, rec, nimg, H, W, seed)
+    # da_img_only: no loss reads the instance-level features, so the product leaves the target-domain ROIs out of the
+    # box head and does not evaluate the instance head (ROIBoxHead.forward).  The oracle does what the reference does —
+    # all 2 x 256 ROIs through res5, both instance-head passes — so this comparison is the proof that leaving them out
+    # changes no loss and no gradient.
+    assert len(rec["masks"]) == (0 if case == "da_img_only" else (4 if case == "da_plain" else len(rec["masks"])))
+    osd, olosses, inter = _oracle(c, sd, rec, nimg, H, W, seed, dtype=torch.float64)
     n_pos, n_neg = _check_indices(rec, inter)
     assert n_pos + n_neg == c.MODEL.RPN.BATCH_SIZE_PER_IMAGE
     _check_losses(rec, olosses)
-    if not with_grads:
-        return
     # gradients of the whole default schedule (early RPN / DA backward, direct weight-gradient accumulation into the
     # reducer's buckets) against torch autograd on the oracle
     sum(olosses.values()).backward()
@@ -202,6 +198,39 @@ def test_default_path_matches_oracle_small(device, monkeypatch, case, overrides)
         torch.testing.assert_close(got, want, rtol=1e-6, atol=1e-7, msg=lambda m, n=n: "%s: %s" % (n, m))
     print("default path vs fp64 oracle (%s): worst relative L2 gradient error %.2e; above rounding level: %s" % (
         case, worst, above))
+
+
+def test_leaving_out_unread_target_rois_changes_nothing(device, monkeypatch):
+    """img_only recipe (the bench workload) with the target-domain ROIs left out of the box head (default) against the
+    same step with DADET_DEAD_ROI_ROWS=1 semantics (all rows through pooler + res5 + predictor, forward and backward):
+    same sampled ROIs, losses and gradients equal to summation-order rounding"""
+    from da_detect_amd.modeling.roi_heads.box_head import box_head
+
+    seed, H, W = 23, 192, 320
+    rows = []
+    orig = box_head.ROIBoxHead.forward
+
+    def forward(self, features, proposals, targets=None):
+        out = orig(self, features, proposals, targets)
+        rows.append(out[0].shape[0])
+        return out
+
+    monkeypatch.setattr(box_head.ROIBoxHead, "forward", forward)
+    _, _, lean, _ = _run_default_path("da_img_only", H, W, device, seed, monkeypatch)
+    lean = dict(lean, seeds=list(lean["seeds"]), rois=list(lean["rois"]))     # the second run's hooks wrap the first's
+    monkeypatch.setattr(box_head, "_KEEP_DEAD_ROWS", True)
+    _, _, full, _ = _run_default_path("da_img_only", H, W, device, seed, monkeypatch)
+    assert rows[1] == 2 * rows[0] and rows[0] > 0, rows
+    assert lean["seeds"] == full["seeds"]
+    for (a, ca, _), (b, cb, _) in zip(lean["rois"], full["rois"]):
+        assert torch.equal(ca, cb) and torch.equal(a["idx"][: int(ca[0])], b["idx"][: int(cb[0])])
+    # half the GEMM rows: other tile / split-K / stream-K plans, i.e. another summation order — rounding level, and the
+    # occasional ReLU at the edge of zero (the two-tier rule of _check_gradients)
+    assert set(lean["losses"]) == set(full["losses"])
+    for k, v in full["losses"].items():
+        assert abs(lean["losses"][k] - v) <= 2e-6 * max(abs(v), 1.0), (k, lean["losses"][k], v)
+    worst, above = _check_gradients(lean["grads"], full["grads"], rounding_tol=2e-5)
+    print("target ROIs left out vs kept: worst relative L2 gradient difference %.2e; above 2e-5: %s" % (worst, above))
 
 
 def test_default_path_matches_oracle_512x1024(device, monkeypatch):
