@@ -12,6 +12,7 @@ from ...structures.image_list import to_image_list
 from ...utils.streams import record, side_stream
 from ..backbone import build_backbone
 from ..da_heads.da_heads import build_da_heads, build_da_heads_triplet
+from ..elision import elision_enabled, leading_source_images
 from ..roi_heads.roi_heads import build_roi_heads
 from ..rpn.rpn import build_rpn
 
@@ -26,6 +27,19 @@ class GeneralizedRCNN(nn.Module):
         self.triplet_use = cfg.MODEL.DA_HEADS.TRIPLET_USE
         self.da_heads_triplet = build_da_heads_triplet(cfg) if self.triplet_use else False
         self.Aligned = cfg.MODEL.DA_HEADS.ALIGNMENT
+
+    def _images_with_read_proposals(self, targets):
+        """number of leading images whose RPN proposals some loss reads: the source images always (detection losses);
+        a target-domain image only through the instance-level features (or as the ROI set of the aligned triplet
+        passes); the auxiliary image of a triplet batch never (generalized_rcnn.py:100 passes proposals[0:2] on)"""
+        n_src = leading_source_images(targets)
+        if n_src == 0:
+            return None
+        if self.da_heads_triplet:
+            if len(targets) != 3 or n_src != 1:
+                return None
+            return 2 if (self.da_heads_triplet.needs_instance_features or self.Aligned) else 1
+        return len(targets) if self.da_heads.needs_instance_features else n_src
 
     def forward(self, images, targets=None):
         if self.training and targets is None:
@@ -49,6 +63,8 @@ class GeneralizedRCNN(nn.Module):
                 da_stream = None
             else:
                 record(features, da_stream)
+        if self.training and self.roi_heads and (self.da_heads or self.da_heads_triplet) and elision_enabled():
+            self.rpn.live_images = self._images_with_read_proposals(targets)
         proposals, proposal_losses = self.rpn(images, features, targets)
         if self.training:
             if da_stream is not None:

@@ -6,6 +6,7 @@ import torch
 
 from ....structures.bounding_box import is_source_image
 from ....utils import rng
+from ...elision import elision_enabled, leading_source_images
 from ....utils.streams import side_section
 from .inference import make_roi_box_post_processor
 from .loss import make_roi_box_loss_evaluator
@@ -14,8 +15,6 @@ from .roi_box_predictors import make_roi_box_predictor
 
 
 _NO_DEDUP = os.environ.get("DADET_NO_ROI_DEDUP", "0") == "1"
-# DADET_DEAD_ROI_ROWS=1: run the target-domain ROIs through the head even when nothing reads them (see forward)
-_KEEP_DEAD_ROWS = os.environ.get("DADET_DEAD_ROI_ROWS", "0") == "1"
 
 
 class ROIBoxHead(torch.nn.Module):
@@ -33,35 +32,36 @@ class ROIBoxHead(torch.nn.Module):
         """-> (x, proposals | detections, losses, da_ins_feas, da_ins_labels).  Training runs two passes of
         pooler + res5 + predictor: the sampled detection ROIs, then BATCH_SIZE_PER_IMAGE uniformly sampled
         ROIs per image whose features / domain labels feed the instance-level domain classifier."""
-        if self.training:
-            # sampling runs on the side stream: its host round trips then do not wait for the RPN-head backward
-            # queued on the compute stream just before (RPNModule.early_backward)
-            after, self.proposals_ready = self.proposals_ready, None
-            with side_section(proposals[0].bbox.device, after=after) as done, torch.no_grad():
-                proposals = self.loss_evaluator.subsample(proposals, targets)
-                # the reference draws the DA ROI sample after the detection losses (box_head.py:102-104); nothing
-                # between the two draws from the random stream, so drawing it here is the same sample — and it keeps
-                # every host synchronisation of the box head in front of the res5 head instead of behind it
-                da_proposals = self.loss_evaluator.subsample_for_da(proposals, targets)
-                done(proposals, da_proposals, self.loss_evaluator._proposals, self.loss_evaluator._loss_prep)
-        live = proposals
+        burn = 0
         if self.training:
             unused, self.ins_features_unused = self.ins_features_unused, False
             # Rows of target-domain images: the detection losses mask them out (box_head/loss.py:193-198) and their only
             # other reader is the instance-level domain classifier.  When that one has no loss either (instance and
             # consistency weights 0: the reference evaluates it and drops the result, da_heads.py:402-439; SURVEY.md
-            # appendix A "may elide"), pooling them and running res5 + predictor forward and backward over them changes no
-            # loss and no gradient — every one of their gradient rows is exactly 0.  They are sampled as always (the
-            # random draws stay in place) and then left out of the head.  Source images come first in a batch
-            # (engine/trainer.py:215-224), so the live rows are a prefix of the row space the loss targets index.
-            # Not with the reference's random stream (utils.rng.use_cpu_stream): there the instance head's dropout
-            # draws have to keep their sizes.
-            if unused and not _KEEP_DEAD_ROWS and not rng.cpu_stream_enabled():
-                src = [is_source_image(t) for t in targets]
-                n_src = sum(src)
-                if 0 < n_src < len(src) and all(src[:n_src]):
-                    live = proposals[:n_src]
-        x = self.feature_extractor(features, live)
+            # appendix A "may elide"), sampling them, pooling them and running res5 + predictor forward and backward
+            # over them changes no loss and no gradient — every one of their gradient rows is exactly 0.  They are left
+            # out: this call then sees the leading source-domain images only (source images come first in a batch,
+            # engine/trainer.py:215-224; the pooler's batch index is the list position).  One sampler seed per skipped
+            # image is still drawn, so that the images that ARE sampled get the seeds they would get anyway.
+            # Not with the reference's random stream (utils.rng.use_cpu_stream): there every draw keeps its size.
+            if unused and elision_enabled():
+                n_src = leading_source_images(targets)
+                if 0 < n_src < len(targets):
+                    burn = len(targets) - n_src
+                    proposals, targets = proposals[:n_src], targets[:n_src]
+            # sampling runs on the side stream: its host round trips then do not wait for the RPN-head backward
+            # queued on the compute stream just before (RPNModule.early_backward)
+            after, self.proposals_ready = self.proposals_ready, None
+            with side_section(proposals[0].bbox.device, after=after) as done, torch.no_grad():
+                proposals = self.loss_evaluator.subsample(proposals, targets)
+                for _ in range(burn):
+                    rng.next_seed(proposals[0].bbox.device)
+                # the reference draws the DA ROI sample after the detection losses (box_head.py:102-104); nothing
+                # between the two draws from the random stream, so drawing it here is the same sample — and it keeps
+                # every host synchronisation of the box head in front of the res5 head instead of behind it
+                da_proposals = self.loss_evaluator.subsample_for_da(proposals, targets)
+                done(proposals, da_proposals, self.loss_evaluator._proposals, self.loss_evaluator._loss_prep)
+        x = self.feature_extractor(features, proposals)
         class_logits, box_regression = self.predictor(x)
         if not self.training:
             return x, self.post_processor((class_logits, box_regression), proposals), {}, x, None
@@ -73,7 +73,7 @@ class ROIBoxHead(torch.nn.Module):
         # bit.  The identical sub-expression is evaluated once; its two consumers' gradients add up in autograd
         # exactly as the two passes' parameter gradients would.  (subsample_for_da still runs: it draws from the
         # random stream.)  Set DADET_NO_ROI_DEDUP=1 to execute the redundant pass.
-        if len(live) < len(proposals):
+        if burn:
             return (x, proposals, dict(loss_classifier=loss_classifier, loss_box_reg=loss_box_reg), None, None)
         limit = self.loss_evaluator.fg_bg_sampler.batch_size_per_image
         same_set = all(len(p) <= limit for p in proposals) and not _NO_DEDUP

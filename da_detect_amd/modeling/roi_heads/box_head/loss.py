@@ -235,10 +235,8 @@ class FastRCNNLossComputation(object):
             raise RuntimeError("subsample needs to be called before")
         prep = self._loss_prep
         if prep.get("rows"):
-            # fewer rows than sampled: the head was run on the source-domain prefix only (ROIBoxHead.forward)
-            n = class_logits.shape[0]
-            cls_loss, box_loss = fast_rcnn_loss_rows_fused(class_logits, box_regression, prep["loss_labels"][:n],
-                                                           prep["regression_targets"][:n])
+            cls_loss, box_loss = fast_rcnn_loss_rows_fused(class_logits, box_regression, prep["loss_labels"],
+                                                           prep["regression_targets"])
             return cls_loss, box_loss, prep["domain_masks"]
         labels = prep["labels_src"]
         if class_logits.is_cuda and not self.cls_agnostic_bbox_reg:

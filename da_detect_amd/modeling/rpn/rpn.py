@@ -8,6 +8,7 @@ from ..box_coder import BoxCoder
 from .anchor_generator import make_anchor_generator
 from .inference import make_rpn_postprocessor
 from .loss import make_rpn_loss_evaluator
+from ..elision import elision_enabled, leading_source_images
 from ...utils.streams import record, side_section, side_stream
 
 
@@ -36,6 +37,11 @@ class RPNHead(nn.Module):
         return logits, bbox_reg
 
 
+def _add_leading(full, part):
+    full[:part.shape[0]] += part       # `full` is a gradient this step produced for this purpose: updated in place
+    return full
+
+
 class _InjectGrad(torch.autograd.Function):
     """identity whose backward adds a gradient computed earlier (the RPN branch's, see RPNModule.early_backward)"""
 
@@ -47,7 +53,11 @@ class _InjectGrad(torch.autograd.Function):
     @staticmethod
     def backward(ctx, grad_out):
         (g,) = ctx.saved_tensors
-        return grad_out + g, None
+        if g.shape[0] == grad_out.shape[0]:
+            return grad_out + g, None
+        out = grad_out.clone()          # g covers the leading images only (the ones the RPN losses are taken on)
+        out[:g.shape[0]] += g
+        return out, None
 
 
 class RPNModule(torch.nn.Module):
@@ -61,6 +71,11 @@ class RPNModule(torch.nn.Module):
     features."""
 
     early_backward = False
+    # Set by the detector for ONE call (training): the number of leading images whose proposals somebody reads; None =
+    # all.  The images behind them (target-domain images when no loss reads instance-level features, the auxiliary
+    # image of a triplet batch: generalized_rcnn.py:100 passes proposals[0:2] on) get no RPN head pass and no proposal
+    # selection on the overlapped schedule — their entry in the returned list is None.
+    live_images = None
 
     def __init__(self, cfg):
         super(RPNModule, self).__init__()
@@ -81,8 +96,11 @@ class RPNModule(torch.nn.Module):
 
     def forward(self, images, features, targets=None):
         self._feature_grads = None
+        live, self.live_images = self.live_images, None
         early = (self.training and self.early_backward and torch.is_grad_enabled() and not self.cfg.MODEL.RPN_ONLY
                  and all(f.requires_grad for f in features))
+        if early and features[0].is_cuda and len(features) == 1 and elision_enabled():
+            return self._forward_train_overlapped(images, features, targets, live)
         head_in = [f.detach().requires_grad_(True) for f in features] if early else features
         objectness, rpn_box_regression = self.head(head_in)
         anchors = self.anchor_generator(images, features)
@@ -90,6 +108,32 @@ class RPNModule(torch.nn.Module):
             return self._forward_test(anchors, objectness, rpn_box_regression)
         if not (early and objectness[0].is_cuda):
             return self._forward_train(anchors, objectness, rpn_box_regression, targets)
+        return self._finish_overlapped(anchors, head_in, objectness, rpn_box_regression,
+                                       [o.detach() for o in objectness], [r.detach() for r in rpn_box_regression],
+                                       targets, len(targets))
+
+    def _forward_train_overlapped(self, images, features, targets, live):
+        """single-level overlapped schedule with the head's work restricted to the images that need it.  The RPN losses
+        are taken on anchors of source-domain images only (rpn/loss.py:57-98 labels nothing else; they come first in the
+        batch), so the gradient of every other image's objectness / regression map is identically zero: the head runs
+        WITH autograd on the leading source images only — its backward GEMMs then cover those rows and nothing else —
+        without autograd on the other images whose proposals are read, and not at all on the rest (`live_images`)."""
+        f = features[0]
+        n_img = f.shape[0]
+        n_grad = leading_source_images(targets) or n_img      # unusual batch order: no restriction
+        n_live = n_img if live is None else max(n_grad, min(int(live), n_img))
+        head_in = [f[:n_grad].detach().requires_grad_(True)]
+        objectness, rpn_box_regression = self.head(head_in)
+        sel_obj, sel_reg = [objectness[0].detach()], [rpn_box_regression[0].detach()]
+        if n_live > n_grad:
+            with torch.no_grad():
+                o, r = self.head([f[n_grad:n_live]])
+            sel_obj, sel_reg = [torch.cat([sel_obj[0], o[0]], dim=0)], [torch.cat([sel_reg[0], r[0]], dim=0)]
+        anchors = self.anchor_generator(images, features)
+        return self._finish_overlapped(anchors, head_in, objectness, rpn_box_regression, sel_obj, sel_reg, targets,
+                                       n_live)
+
+    def _finish_overlapped(self, anchors, head_in, objectness, rpn_box_regression, sel_obj, sel_reg, targets, n_live):
         # overlapped schedule: losses + the RPN branch's backward go to the compute stream first; proposal selection
         # (sort, decode, single-workgroup NMS sweeps, one host round trip) then runs on the side stream underneath
         # them, and the box head's sampling continues there (ROIBoxHead.forward)
@@ -105,12 +149,12 @@ class RPNModule(torch.nn.Module):
         # the head's maps were allocated on the compute stream and are released when forward() returns: without this the
         # caching allocator may hand their blocks to a later compute-stream allocation while the side stream still reads
         # them
-        record([objectness, rpn_box_regression], side)
+        record([sel_obj, sel_reg], side)
         with torch.cuda.stream(side), torch.no_grad():
-            boxes = self.box_selector_train(anchors, [o.detach() for o in objectness],
-                                            [r.detach() for r in rpn_box_regression], targets)
+            boxes = self.box_selector_train(anchors[:n_live], sel_obj, sel_reg, targets[:n_live])
             self.proposals_ready = side.record_event()
         record(boxes, main)
+        boxes = list(boxes) + [None] * (len(targets) - n_live)
         return boxes, {"loss_objectness": loss_objectness.detach(), "loss_rpn_box_reg": loss_rpn_box_reg.detach()}
 
     def bridge_features(self, features, extra=None):
@@ -120,7 +164,8 @@ class RPNModule(torch.nn.Module):
         if grads is None:
             grads = extra
         elif extra is not None:
-            grads = [g + e for g, e in zip(grads, extra)]
+            # the RPN branch's gradient may cover the leading images only (_forward_train_overlapped)
+            grads = [g + e if g.shape[0] == e.shape[0] else _add_leading(e, g) for g, e in zip(grads, extra)]
         if grads is None:
             return features
         return [_InjectGrad.apply(f, g) for f, g in zip(features, grads)]

@@ -553,7 +553,8 @@ def training_losses(sd, cfg, images, gts, state=None, intermediates=None, select
     """GeneralizedRCNN.forward in training mode (modeling/detector/generalized_rcnn.py:61-153).
     images [N,3,H,W] (already padded), gts: list of dict(boxes [G,4], labels [G], is_source [G] bool).
     selection_maps=(objectness, deltas): tests may feed the proposal SELECTION fixed RPN maps (e.g. the golden
-    reference ones) so index-valued results do not depend on this machine's fp32 GEMM rounding."""
+    reference ones) so index-valued results do not depend on this machine's fp32 GEMM rounding; maps of fewer than N
+    images cover the leading ones."""
     N, _, H, W = images.shape
     image_sizes = [(H, W)] * N
     feat = backbone_c4(images, sd)
@@ -563,6 +564,12 @@ def training_losses(sd, cfg, images, gts, state=None, intermediates=None, select
                            cell_anchors(rpn.ANCHOR_STRIDE[0], rpn.ANCHOR_SIZES, rpn.ASPECT_RATIOS))
     with torch.no_grad():
         sel_obj, sel_del = selection_maps if selection_maps is not None else (objectness, deltas)
+        if sel_obj.shape[0] < N:
+            # maps given for the leading images only (the product evaluates the RPN head on the images whose proposals
+            # are read): the others are selected from this restatement's own maps, as the reference would
+            k = sel_obj.shape[0]
+            sel_obj = torch.cat([sel_obj.to(objectness.dtype), objectness[k:].detach()], dim=0)
+            sel_del = torch.cat([sel_del.to(deltas.dtype), deltas[k:].detach()], dim=0)
         proposals = rpn_proposals(sel_obj, sel_del, anchors, image_sizes, gts, cfg, True)
     obj_loss, rpn_box_loss = rpn_losses(objectness, deltas, anchors, image_sizes, gts, cfg, draws, intermediates)
     img_labels = torch.tensor([1.0 if g["is_source"].any() else 0.0 for g in gts])

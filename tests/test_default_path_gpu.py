@@ -77,8 +77,12 @@ def _run_default_path(case, H, W, device, seed, monkeypatch, overrides=(), steps
     monkeypatch.setattr(rng, "dropout_mask", dropout_mask)
     monkeypatch.setattr(_C, "sample_anchors", sample_anchors)
     monkeypatch.setattr(_C, "sample_rois", sample_rois)
-    model.rpn.head.register_forward_hook(
-        lambda m, i, o: rec.update(objectness=o[0][0].detach(), deltas=o[1][0].detach()))
+    maps = []      # the RPN head runs once per image group (with / without autograd); groups are in batch order
+    model.rpn.head.register_forward_hook(lambda m, i, o: maps.append((o[0][0].detach(), o[1][0].detach())))
+
+    def collect_maps():
+        rec.update(objectness=torch.cat([a for a, _ in maps]), deltas=torch.cat([b for _, b in maps]))
+        del maps[:]
     torch.manual_seed(seed)
     history = []
     for it in range(steps):
@@ -87,6 +91,7 @@ def _run_default_path(case, H, W, device, seed, monkeypatch, overrides=(), steps
             rec.update(seeds=[], masks=[], anchors=[], rois=[])
         losses = train_step(model, opt, images, targets)
         torch.cuda.synchronize()
+        collect_maps()
         rec["losses"] = {k: float(v.detach()) for k, v in losses.items()}
     if steps > 1:
         history.append({k: rec[k] for k in ("seeds", "masks", "anchors", "rois", "objectness", "deltas", "losses")})
@@ -174,7 +179,12 @@ def test_default_path_matches_oracle_small(device, monkeypatch, case, overrides)
     seed, H, W = 11, 192, 320
     c, sd, rec, nimg = _run_default_path(case, H, W, device, seed, monkeypatch, overrides)
     assert rec["early_rpn"] and rec["loss_prep_rows"], "not the default schedule"
-    assert len(rec["anchors"]) == 1 and len(rec["rois"]) >= 2 and len(rec["seeds"]) == 1 + len(rec["rois"])
+    # img_only: the target image is neither sampled nor run through the RPN head (nothing reads its proposals); its
+    # sampler seed is still drawn.  Triplet batches: no RPN head pass for the auxiliary image.
+    read = {"da_plain": 2, "da_img_only": 1, "da_triplet": 2}[case]
+    assert rec["objectness"].shape[0] == read, rec["objectness"].shape
+    assert len(rec["anchors"]) == 1 and len(rec["rois"]) == read and len(rec["seeds"]) == 3, (
+        len(rec["anchors"]), len(rec["rois"]), len(rec["seeds"]))
     # da_img_only: no loss reads the instance-level features, so the product leaves the target-domain ROIs out of the
     # box head and does not evaluate the instance head (ROIBoxHead.forward).  The oracle does what the reference does —
     # all 2 x 256 ROIs through res5, both instance-head passes — so this comparison is the proof that leaving them out
@@ -200,10 +210,13 @@ def test_default_path_matches_oracle_small(device, monkeypatch, case, overrides)
         case, worst, above))
 
 
-def test_leaving_out_unread_target_rois_changes_nothing(device, monkeypatch):
-    """img_only recipe (the bench workload) with the target-domain ROIs left out of the box head (default) against the
-    same step with DADET_DEAD_ROI_ROWS=1 semantics (all rows through pooler + res5 + predictor, forward and backward):
-    same sampled ROIs, losses and gradients equal to summation-order rounding"""
+@pytest.mark.parametrize("case", ["da_img_only", "da_plain"])
+def test_leaving_out_unread_work_changes_nothing(device, monkeypatch, case):
+    """modeling/elision.py on (default) against DADET_DEAD_ROI_ROWS=1 semantics (every head on every image, forward and
+    backward, like the reference): same sampled ROIs, losses and gradients equal to summation-order rounding.
+    img_only (the bench workload): the target image gets no RPN head pass and its ROIs no box-head pass; da_plain: only the
+    RPN head's backward is restricted to the source image."""
+    from da_detect_amd.modeling import elision
     from da_detect_amd.modeling.roi_heads.box_head import box_head
 
     seed, H, W = 23, 192, 320
@@ -216,11 +229,12 @@ def test_leaving_out_unread_target_rois_changes_nothing(device, monkeypatch):
         return out
 
     monkeypatch.setattr(box_head.ROIBoxHead, "forward", forward)
-    _, _, lean, _ = _run_default_path("da_img_only", H, W, device, seed, monkeypatch)
+    _, _, lean, _ = _run_default_path(case, H, W, device, seed, monkeypatch)
     lean = dict(lean, seeds=list(lean["seeds"]), rois=list(lean["rois"]))     # the second run's hooks wrap the first's
-    monkeypatch.setattr(box_head, "_KEEP_DEAD_ROWS", True)
-    _, _, full, _ = _run_default_path("da_img_only", H, W, device, seed, monkeypatch)
-    assert rows[1] == 2 * rows[0] and rows[0] > 0, rows
+    monkeypatch.setattr(elision, "_KEEP_DEAD_ROWS", True)
+    _, _, full, _ = _run_default_path(case, H, W, device, seed, monkeypatch)
+    assert rows[1] == (2 if case == "da_img_only" else 1) * rows[0] and rows[0] > 0, rows
+    assert full["objectness"].shape[0] == 2 and lean["objectness"].shape[0] == (1 if case == "da_img_only" else 2)
     assert lean["seeds"] == full["seeds"]
     for (a, ca, _), (b, cb, _) in zip(lean["rois"], full["rois"]):
         assert torch.equal(ca, cb) and torch.equal(a["idx"][: int(ca[0])], b["idx"][: int(cb[0])])
