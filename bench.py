@@ -217,7 +217,7 @@ def main():
     from da_detect_amd import _C
     from da_detect_amd.data.synthetic import make_batch
     from da_detect_amd.utils import streams
-    from da_detect_amd.engine.trainer import enable_overlapped_rpn_backward, train_step
+    from da_detect_amd.engine.trainer import WgradLaneTuner, enable_overlapped_rpn_backward, train_step
 
     _C.set_gemm_mode(args.gemm_mode)
     yaml_path, overrides, images_per_gpu, workload_desc = WORKLOADS[args.workload]
@@ -232,6 +232,12 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    # schedule choice by measurement, as do_da_train does in its first iterations (untimed, before the warm-up)
+    tuner = WgradLaneTuner(device)
+    while tuner.active:
+        tuner.step_begin()
+        train_step(model, opt, images, targets)
+        tuner.step_end()
     for _ in range(args.warmup):
         loss_dict = train_step(model, opt, images, targets)
     profiler = None
@@ -240,6 +246,7 @@ def main():
         # every event pair between two launches costs dispatch concurrency (measured: ~1 ms / step for all GEMMs)
         profiler = _C.KernelProfiler(pool=2 * 80 * args.steps, only="<2,2")
     barrier()
+    mem0 = torch.cuda.memory_stats(device) if os.environ.get("DADET_BENCH_MEMSTATS") else None
     t0 = time.perf_counter()
     for i in range(args.steps):
         # the brackets are not free (event pairs between launches cost dispatch concurrency: ~3% of the step when every
@@ -249,6 +256,12 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     _C.PROFILER = None
+    if mem0 is not None:       # allocator activity inside the timed region (diagnostics, stderr)
+        mem1 = torch.cuda.memory_stats(device)
+        print("memstats: " + ", ".join("%s %+d" % (k, mem1[k] - mem0[k]) for k in (
+            "num_device_alloc", "num_device_free", "num_alloc_retries", "num_sync_all_streams",
+            "reserved_bytes.all.current")) + ", reserved %.2f GB" % (mem1["reserved_bytes.all.current"] / 1e9),
+            file=sys.stderr)
     exclusive = everything = None
     if profiler is not None and world == 1:
         # two extra UNTIMED passes (single process only: a lone rank must not enter the gradient all-reduce):
@@ -358,7 +371,7 @@ def main():
                                    "box-head pass, fwd+bwd+SGD" % (workload_desc, height, width),
                        "yaml": yaml_path, "overrides": list(overrides), "global_batch": world * images_per_gpu,
                        "image_hw": [height, width],
-                       "parallelism": "dp%d" % world},
+                       "parallelism": "dp%d" % world, "schedule": tuner.report()},
             "roofline": roofline, "cpu_baseline": cpu,
             "kernel_timing": {k: {"launches": v["launches"], "total_ms": round(v["total_ms"], 3),
                                   "tflops": round(v["achieved"] / 1e12, 2)} for k, v in kernels.items()},

@@ -9,11 +9,13 @@ DDP's one-backward-per-forward contract does not admit the overlapped RPN / DA b
 synchronisations of the reference (meters.update -> .item(), the NaN test) are deferred to the logging period."""
 import datetime
 import logging
+import os
 import time
 
 import torch
 import torch.distributed as dist
 
+from ..utils import streams
 from ..utils.comm import get_world_size, synchronize
 from ..utils.metric_logger import MetricLogger
 
@@ -55,6 +57,64 @@ def train_step(model, optimizer, images, targets, scheduler=None, iteration=0):
     if scheduler is not None and hasattr(scheduler, "step_update"):
         scheduler.step_update(iteration)
     return loss_dict
+
+
+class WgradLaneTuner(object):
+    """Picks, by measurement during the first iterations, whether the weight-gradient GEMMs of the narrow layers run on a
+    second stream beside the data-gradient chain (utils.streams.WgradLane, `rows <= WGRAD_LANE_ROWS`).
+
+    The same switch is worth +5% on one recipe and costs 19% on another (one MI355X, 1024x2048: image-level DA only,
+    where the box head and the RPN head see half the rows, 20.9 -> 19.9 ms per step with the lane for GEMMs of up to
+    17 000 rows; image + instance + consistency 29.4 -> 34.9 ms) — small tile grids leave CUs idle that a second GEMM
+    fills, full ones are only slowed down.  So it is not a constant: every candidate runs `settle` untimed and `measure`
+    timed iterations (ordinary training steps — the schedule changes the order of kernels, not a single result), and
+    the fastest stays.  DADET_WGRAD_LANE_ROWS / DADET_WGRAD_STREAM set by hand switch the tuner off."""
+
+    CANDIDATES = (0, 17000)
+
+    def __init__(self, device, settle=2, measure=4):
+        self.device = device
+        self.settle, self.measure = settle, measure
+        self.active = (device.type == "cuda" and "DADET_WGRAD_LANE_ROWS" not in os.environ
+                       and not streams.WGRAD_OVERLAP and os.environ.get("DADET_TUNE_SCHEDULE", "1") == "1")
+        self.times = {}
+        self._cand = self._count = 0
+        self._t0 = None
+
+    def step_begin(self):
+        if not self.active:
+            return
+        if self._count == 0:
+            streams.join_wgrad_lane(self.device)           # nothing of the previous candidate is in flight on the lane
+            streams.WGRAD_LANE_ROWS = self.CANDIDATES[self._cand]
+        if self._count == self.settle:
+            torch.cuda.synchronize(self.device)
+            self._t0 = time.perf_counter()
+
+    def step_end(self):
+        if not self.active:
+            return
+        self._count += 1
+        if self._count < self.settle + self.measure:
+            return
+        torch.cuda.synchronize(self.device)
+        self.times[self.CANDIDATES[self._cand]] = (time.perf_counter() - self._t0) / self.measure
+        self._cand, self._count = self._cand + 1, 0
+        if self._cand == len(self.CANDIDATES):
+            streams.join_wgrad_lane(self.device)
+            streams.WGRAD_LANE_ROWS = min(self.times, key=self.times.get)
+            self.active = False
+
+    def close(self):
+        """a run that ended before the measurement did: back to the default"""
+        if self.active:
+            streams.join_wgrad_lane(self.device)
+            streams.WGRAD_LANE_ROWS = 0
+            self.active = False
+
+    def report(self):
+        return {"wgrad_lane_rows": streams.WGRAD_LANE_ROWS,
+                "tuned_ms_per_step": {str(k): round(v * 1e3, 3) for k, v in self.times.items()}}
 
 
 def _unwrap(model):
@@ -100,6 +160,7 @@ def do_train(model, data_loader, optimizer, scheduler, checkpointer, device, che
     max_iter = len(data_loader)
     start_iter = arguments["iteration"]
     net = _prepare(model, optimizer, get_world_size() > 1)
+    tuner = WgradLaneTuner(torch.device(device))
     start_time = end = time.time()
     for iteration, (images, targets, _) in enumerate(data_loader, start_iter):
         data_time = time.time() - end
@@ -108,7 +169,9 @@ def do_train(model, data_loader, optimizer, scheduler, checkpointer, device, che
         scheduler.step()
         images = images.to(device)
         targets = [t.to(device) for t in targets]
+        tuner.step_begin()
         loss_dict = train_step(net, optimizer, images, targets)
+        tuner.step_end()
         _update_meters(meters, loss_dict)
         meters.update(time=time.time() - end, data=data_time)
         end = time.time()
@@ -118,6 +181,7 @@ def do_train(model, data_loader, optimizer, scheduler, checkpointer, device, che
             checkpointer.save("model_{:07d}".format(iteration), **arguments)
         if iteration == max_iter:
             checkpointer.save("model_final", **arguments)
+    tuner.close()
     total = time.time() - start_time
     logger.info("Total training time: {} ({:.4f} s / it)".format(str(datetime.timedelta(seconds=total)),
                                                                  total / max(max_iter, 1)))
@@ -166,6 +230,7 @@ def do_da_train(model, source_data_loader, positive_target_data_loader, negative
     eval_in_training = bool(cfg.MODEL.EVAL_USE_IN_TRAINING) if cfg is not None else False
     max_iter = len(positive_target_data_loader)
     net = _prepare(model, optimizer, distributed)
+    tuner, tuner_logged = WgradLaneTuner(torch.device(device)), False
     start_time = end = time.time()
     batches = _da_batches(source_data_loader, positive_target_data_loader, negative_target_data_loader,
                           triplet_data_loading, triplet_data_aligned)
@@ -174,7 +239,12 @@ def do_da_train(model, source_data_loader, positive_target_data_loader, negative
         arguments["iteration"] = iteration
         images = images.to(device)
         targets = [t.to(device) for t in targets]
+        tuner.step_begin()
         loss_dict = train_step(net, optimizer, images, targets, scheduler, iteration)
+        tuner.step_end()
+        if tuner.times and not tuner.active and not tuner_logged:
+            tuner_logged = True
+            logger.info("weight-gradient lane: %s" % (tuner.report(),))
         total = _update_meters(meters, loss_dict)
         meters.update(time=time.time() - end, data=data_time)
         end = time.time()
@@ -188,6 +258,7 @@ def do_da_train(model, source_data_loader, positive_target_data_loader, negative
             checkpointer.save("model_final", **arguments)
         if (iteration % 20 == 0 or at_checkpoint or iteration == max_iter - 1) and bool(torch.isnan(total).any()):
             logger.critical("Loss is NaN, exiting...")
+            tuner.close()
             return
         if eval_in_training and at_checkpoint and data_loader_val is not None:
             synchronize()
@@ -198,6 +269,7 @@ def do_da_train(model, source_data_loader, positive_target_data_loader, negative
                           expected_results_sigma_tol=cfg.TEST.EXPECTED_RESULTS_SIGMA_TOL, output_folder=None)
             synchronize()
             net.train()
+    tuner.close()
     total_time = time.time() - start_time
     logger.info("Total training time: {} ({:.4f} s / it)".format(str(datetime.timedelta(seconds=total_time)),
                                                                  total_time / max(max_iter, 1)))

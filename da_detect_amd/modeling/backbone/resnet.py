@@ -70,7 +70,7 @@ class _BottleneckFn(torch.autograd.Function):
         S3 = G.contiguous(memory_format=torch.channels_last) if ctx.out_private else \
             _C.relu_bn_backward(G, out, None)[1]
         dw1 = dw2 = dw3 = dwd = dx = None
-        lane = WgradLane(G.device, defer=ctx.defer_wgrad)
+        lane = WgradLane(G.device, defer=ctx.defer_wgrad, rows=G.shape[0] * G.shape[2] * G.shape[3])
         if n3:
             dw3 = lane.run_into(w3, lambda acc: _C.conv_wgrad(y2, S3, tuple(w3.shape), 1, 0, out_scale=s3, dw=acc,
                                                               accumulate=True),

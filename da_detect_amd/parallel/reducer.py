@@ -89,7 +89,7 @@ class BucketedGradReducer(object):
         on the compute stream: the collective is issued FROM THE LANE after the lane waited for the compute stream's
         current position — the compute stream itself is not held up."""
         dev = flat.device
-        if dev.type == "cuda" and streams.DIRECT_WGRAD and streams.WGRAD_OVERLAP:
+        if dev.type == "cuda" and streams.DIRECT_WGRAD and streams.lane_in_use():
             streams.flush_deferred_wgrads(dev)
             lane = streams.side_stream(dev, 2)
             lane.wait_event(torch.cuda.current_stream(dev).record_event())

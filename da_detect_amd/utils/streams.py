@@ -80,6 +80,13 @@ import os  # noqa: E402
 # 21.0 images/s on one box): two 1000-workgroup GEMMs sharing the CUs run slower than one after the other.  Off by
 # default since then; DADET_WGRAD_STREAM=1 restores the lane.
 WGRAD_OVERLAP = os.environ.get("DADET_WGRAD_STREAM", "0") == "1"
+# GEMMs of at most this many rows (N * H * W of the gradient map) use the lane even when it is off in general
+WGRAD_LANE_ROWS = int(os.environ.get("DADET_WGRAD_LANE_ROWS", "0"))
+
+
+def lane_in_use():
+    """some weight gradients may be accumulated on the lane stream"""
+    return WGRAD_OVERLAP or WGRAD_LANE_ROWS > 0
 
 
 class WgradLane(object):
@@ -88,9 +95,9 @@ class WgradLane(object):
     workgroups.  `run(fn, *tensors)` queues fn() there once the tensors exist on the compute stream; `join()` makes
     the compute stream wait before the gradients are handed to autograd."""
 
-    def __init__(self, device, defer=False):
+    def __init__(self, device, defer=False, rows=None):
         self.defer = defer      # direct accumulations are queued until flush_deferred_wgrads() (see there)
-        self.on = WGRAD_OVERLAP and device.type == "cuda"
+        self.on = device.type == "cuda" and (WGRAD_OVERLAP or (rows is not None and rows <= WGRAD_LANE_ROWS))
         if self.on:
             self.main = torch.cuda.current_stream(device)
             self.lane = side_stream(device, 2)
@@ -174,7 +181,7 @@ def flush_deferred_wgrads(device, after=None):
     if not _DEFERRED:
         return
     items, _DEFERRED = _DEFERRED, []
-    if device.type == "cuda" and WGRAD_OVERLAP:
+    if device.type == "cuda" and lane_in_use():
         main = torch.cuda.current_stream(device)
         lane = side_stream(device, 2)
         lane.wait_event(after if after is not None else main.record_event())
@@ -196,5 +203,5 @@ def deferred_pending():
 def join_wgrad_lane(device):
     """the current stream waits for every weight gradient queued on the lane (call before reading .grad)"""
     flush_deferred_wgrads(device)
-    if device.type == "cuda" and WGRAD_OVERLAP:
+    if device.type == "cuda" and lane_in_use():
         torch.cuda.current_stream(device).wait_stream(side_stream(device, 2))

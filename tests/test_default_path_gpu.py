@@ -243,8 +243,10 @@ def test_leaving_out_unread_work_changes_nothing(device, monkeypatch, case):
     assert set(lean["losses"]) == set(full["losses"])
     for k, v in full["losses"].items():
         assert abs(lean["losses"][k] - v) <= 2e-6 * max(abs(v), 1.0), (k, lean["losses"][k], v)
-    worst, above = _check_gradients(lean["grads"], full["grads"], rounding_tol=2e-5)
-    print("target ROIs left out vs kept: worst relative L2 gradient difference %.2e; above 2e-5: %s" % (worst, above))
+    # each side is within 5e-5 of the fp64 oracle (test_default_path_matches_oracle_small), so within 1e-4 of the other
+    worst, above = _check_gradients(lean["grads"], full["grads"], rounding_tol=1e-4)
+    print("unread work left out vs done (%s): worst relative L2 gradient difference %.2e; above 1e-4: %s" % (
+        case, worst, above))
 
 
 def test_default_path_matches_oracle_512x1024(device, monkeypatch):
@@ -317,3 +319,35 @@ def test_three_step_trajectory_matches_oracle(device, monkeypatch):
     _check_gradients(rec["momentum"], {n: opt.state[osd[n]]["momentum_buffer"] for n in rec["momentum"]},
                      rounding_tol=2e-3, flip_tol=1e-2, flipped_share=0.2)
     assert abs(state["margin_img"] - c.MODEL.DA_HEADS.TRIPLET_MARGIN_IMG) < 1e-9      # never exactly 0 here: no growth
+
+
+def test_wgrad_lane_is_a_schedule_not_a_result(device, monkeypatch):
+    """the weight-gradient lane (utils.streams.WgradLane) only moves kernels to a second stream: the same step with the
+    lane for GEMMs of up to 17 000 rows and without it gives bit-identical losses and gradients; the tuner that picks
+    between them (engine.trainer.WgradLaneTuner) times both and leaves one of its candidates set"""
+    from da_detect_amd.engine.trainer import WgradLaneTuner, train_step
+    from da_detect_amd.utils import streams
+
+    seed, H, W = 31, 192, 320
+    monkeypatch.setattr(streams, "WGRAD_LANE_ROWS", 0)
+    _, _, off, _ = _run_default_path("da_img_only", H, W, device, seed, monkeypatch)
+    monkeypatch.setattr(streams, "WGRAD_LANE_ROWS", 17000)
+    _, _, on, _ = _run_default_path("da_img_only", H, W, device, seed, monkeypatch)
+    assert on["losses"] == off["losses"]
+    for n, g in off["grads"].items():
+        assert torch.equal(on["grads"][n], g), n
+
+    monkeypatch.delenv("DADET_WGRAD_LANE_ROWS", raising=False)
+    monkeypatch.setattr(streams, "WGRAD_LANE_ROWS", 0)
+    calls = []
+    tuner = WgradLaneTuner(torch.device(device), settle=1, measure=2)
+    assert tuner.active
+    while tuner.active:
+        tuner.step_begin()
+        calls.append(streams.WGRAD_LANE_ROWS)
+        torch.cuda.synchronize()
+        tuner.step_end()
+    assert calls == [0, 0, 0, 17000, 17000, 17000]
+    rep = tuner.report()
+    assert rep["wgrad_lane_rows"] in WgradLaneTuner.CANDIDATES and set(rep["tuned_ms_per_step"]) == {"0", "17000"}
+    monkeypatch.setattr(streams, "WGRAD_LANE_ROWS", 0)
