@@ -323,7 +323,7 @@ def test_three_step_trajectory_matches_oracle(device, monkeypatch):
 
 def test_wgrad_lane_is_a_schedule_not_a_result(device, monkeypatch):
     """the weight-gradient lane (utils.streams.WgradLane) only moves kernels to a second stream: the same step with the
-    lane for GEMMs of up to 17 000 rows and without it gives bit-identical losses and gradients; the tuner that picks
+    lane for GEMMs of up to 17 000 rows and without it gives the same losses and gradients; the tuner that picks
     between them (engine.trainer.WgradLaneTuner) times both and leaves one of its candidates set"""
     from da_detect_amd.engine.trainer import WgradLaneTuner, train_step
     from da_detect_amd.utils import streams
@@ -334,8 +334,12 @@ def test_wgrad_lane_is_a_schedule_not_a_result(device, monkeypatch):
     monkeypatch.setattr(streams, "WGRAD_LANE_ROWS", 17000)
     _, _, on, _ = _run_default_path("da_img_only", H, W, device, seed, monkeypatch)
     assert on["losses"] == off["losses"]
+    # not bit for bit even between two identical runs: the image-level DA kernels sum with atomics (order varies), and
+    # the backbone's gradients inherit that rounding
     for n, g in off["grads"].items():
-        assert torch.equal(on["grads"][n], g), n
+        denom = float(g.double().norm())
+        diff = float((on["grads"][n].double() - g.double()).norm())
+        assert diff <= 1e-5 * denom, (n, diff, denom)
 
     monkeypatch.delenv("DADET_WGRAD_LANE_ROWS", raising=False)
     monkeypatch.setattr(streams, "WGRAD_LANE_ROWS", 0)
