@@ -567,6 +567,19 @@ bool streamk_plan(const ConvArgs& a, int variant, SkPlan* p) {
   const int tail = tiles % slots;
   // a grid below one pass is not stream-K'd: cutting 256 tiles into 512 halves measured 7 - 22% SLOWER (the partial-tile
   // round trip costs more than the second workgroup per CU gains; tools/streamk_bench.py)
+  if (tiles > kNumCU && tiles < slots && nk >= 32) {
+    // between one workgroup per CU and two (e.g. the 392 tiles of the res5 GEMMs over 256 ROIs): all workgroups are
+    // resident at once, but 136 CUs run two of them and 120 run one — the launch lasts as long as the pairs.  All tiles
+    // become stream-K tiles: 512 equal ranges, every CU gets two.  DADET_STREAMK_SMALL=0 switches this case off.
+    const char* small = getenv("DADET_STREAMK_SMALL");
+    if (small && small[0] == '0') return false;
+    p->dp_tiles = 0;
+    p->sk_tiles = tiles;
+    p->iters = ceil_div(tiles * nk, slots);
+    p->units = ceil_div(tiles * nk, p->iters);
+    p->max_parts = ceil_div(nk, p->iters) + 1;
+    return true;
+  }
   if (tail == 0 || nk < 16 || tiles < slots || tail > kSkCounters) return false;
   if (tail > slots * 7 / 8) return false;                 // the last pass is full enough
   if (tiles > 6 * slots && tail > slots / 2) return false;  // many passes: the idle share is small

@@ -26,6 +26,12 @@ def timeit(fn, n=20):
 
 
 SHAPES = [  # name, N, Cin, H, W, Cout, k, pad
+    ("res5/256 3x3 512->512 (392 tiles)", 256, 512, 7, 7, 512, 3, 1),
+    ("res5/256 1x1 2048->512 (392 tiles)", 256, 2048, 7, 7, 512, 1, 0),
+    ("res5/256 1x1 1024->512 (392 tiles)", 256, 1024, 7, 7, 512, 1, 0),
+    ("res5/256 1x1 512->2048 (1568 tiles)", 256, 512, 7, 7, 2048, 1, 0),
+    ("res5/256 1x1 1024->2048 (1568 tiles)", 256, 1024, 7, 7, 2048, 1, 0),
+    ("rpn/1 3x3 1024->1024 (512 tiles)", 1, 1024, 64, 128, 1024, 3, 1),
     ("res5 3x3 512->512 (784 tiles)", 512, 512, 7, 7, 512, 3, 1),
     ("res5 1x1 2048->512 (784 tiles)", 512, 2048, 7, 7, 512, 1, 0),
     ("res5 1x1 512->2048 (3136 tiles)", 512, 512, 7, 7, 2048, 1, 0),
