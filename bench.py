@@ -277,14 +277,16 @@ def main():
             train_step(model, opt, images, targets)
         torch.cuda.synchronize()
         extra_elapsed = time.perf_counter() - te
-        if streams.WGRAD_OVERLAP:
-            streams.WGRAD_OVERLAP = False
+        if streams.lane_in_use():
+            saved = (streams.WGRAD_OVERLAP, streams.WGRAD_LANE_ROWS)
+            streams.join_wgrad_lane(device)
+            streams.WGRAD_OVERLAP, streams.WGRAD_LANE_ROWS = False, 0
             exclusive = _C.KernelProfiler()
             _C.PROFILER = exclusive
             for _ in range(extra):
                 train_step(model, opt, images, targets)
             torch.cuda.synchronize()
-            streams.WGRAD_OVERLAP = True
+            streams.WGRAD_OVERLAP, streams.WGRAD_LANE_ROWS = saved
         _C.PROFILER = None
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=device)
@@ -342,6 +344,11 @@ def main():
                     "note": ("forward/data-gradient and weight-gradient GEMMs run on two streams "
                              "(DADET_WGRAD_STREAM=1); `achieved` is per launch WHILE the other stream's kernel shares "
                              "the GPU; " if streams.WGRAD_OVERLAP else
+                             "weight-gradient GEMMs of layers with at most %d rows run on a second stream beside the "
+                             "data-gradient chain (engine.trainer.WgradLaneTuner measured that faster for this recipe): "
+                             "`achieved` is per launch WHILE such a kernel may share the GPU; exclusive_* = the same "
+                             "launches with the second stream off; " % streams.WGRAD_LANE_ROWS
+                             if streams.WGRAD_LANE_ROWS > 0 else
                              "one GEMM stream (default): a bracketed launch has the GPU to itself except for the "
                              "latency-bound side-stream kernels; ") +
                             "this block comes from extra untimed passes with every GEMM bracketed",

@@ -334,12 +334,10 @@ def test_wgrad_lane_is_a_schedule_not_a_result(device, monkeypatch):
     monkeypatch.setattr(streams, "WGRAD_LANE_ROWS", 17000)
     _, _, on, _ = _run_default_path("da_img_only", H, W, device, seed, monkeypatch)
     assert on["losses"] == off["losses"]
-    # not bit for bit even between two identical runs: the image-level DA kernels sum with atomics (order varies), and
-    # the backbone's gradients inherit that rounding
-    for n, g in off["grads"].items():
-        denom = float(g.double().norm())
-        diff = float((on["grads"][n].double() - g.double()).norm())
-        assert diff <= 1e-5 * denom, (n, diff, denom)
+    # not bit for bit even between two identical runs: the image-level DA kernels sum with atomics (order varies), the
+    # backbone's gradients inherit that rounding, and a ReLU at the edge of zero may flip (_check_gradients' two tiers)
+    worst, above = _check_gradients(on["grads"], off["grads"], rounding_tol=1e-5)
+    print("lane on vs off: worst relative L2 gradient difference %.2e; above 1e-5: %s" % (worst, above))
 
     monkeypatch.delenv("DADET_WGRAD_LANE_ROWS", raising=False)
     monkeypatch.setattr(streams, "WGRAD_LANE_ROWS", 0)
