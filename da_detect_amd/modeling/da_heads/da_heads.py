@@ -160,12 +160,17 @@ class DomainAdaptationModule(torch.nn.Module):
         loss = self.img_weight * da_img_loss
         torch.autograd.backward([loss])
         self._early = loss.detach()
+        # the loss value is read on the compute stream later (forward): it waits for this point of the current stream
+        self._early_ready = torch.cuda.current_stream(loss.device).record_event()
         return [f.grad for f in head_in]
 
     def forward(self, img_features, da_ins_feature, da_ins_labels, targets=None):
         if not self.training:
             return {}
         early, self._early = getattr(self, "_early", None), None
+        if early is not None:
+            torch.cuda.current_stream(early.device).wait_event(self._early_ready)
+            early.record_stream(torch.cuda.current_stream(early.device))
         if da_ins_feature is None:
             # the box head left the instance-level features out because no loss reads them (ROIBoxHead.forward)
             assert not self.needs_instance_features

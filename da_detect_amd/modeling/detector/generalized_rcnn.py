@@ -5,6 +5,8 @@ forward(images, targets) -> dict of scalar losses (training) | list[BoxList] det
 Batch layout contracts inherited from the reference trainer (engine/trainer.py:215-224): source images first;
 plain DA = [source, target]; triplet DA = [source, target(positive), auxiliary(negative)].
 """
+import os
+
 import torch
 from torch import nn
 
@@ -15,6 +17,9 @@ from ..da_heads.da_heads import build_da_heads, build_da_heads_triplet
 from ..elision import elision_enabled, leading_source_images
 from ..roi_heads.roi_heads import build_roi_heads
 from ..rpn.rpn import build_rpn
+
+
+_DA_AFTER_RPN = os.environ.get("DADET_DA_AFTER_RPN", "1") == "1"
 
 
 class GeneralizedRCNN(nn.Module):
@@ -49,28 +54,37 @@ class GeneralizedRCNN(nn.Module):
             # lets the RPN prepare its loss targets on a side stream without waiting for the backbone
             self.rpn.inputs_ready = torch.cuda.current_stream(images.tensors.device).record_event()
         features = self.backbone(images.tensors)
-        early_da = da_stream = None
+        holder = {}
         if self.training and self.da_heads and not self.da_heads_triplet and features[0].is_cuda:
             # image-level DA loss + its backward (DomainAdaptationModule.early_image_level) on their own stream, beside
-            # the RPN branch and the box head: they need nothing but the backbone features
+            # the RPN branch and the box head: they need nothing but the backbone features.  _DA_AFTER_RPN: queued behind
+            # the RPN branch's backward instead of beside the RPN head's forward — the compute stream then has GEMM work
+            # while the host waits for the proposals and samples ROIs (tools/gemm_table.py --holes: 0.25 - 0.45 ms)
             dev = features[0].device
-            main = torch.cuda.current_stream(dev)
-            da_stream = side_stream(dev, 3)
-            da_stream.wait_stream(main)
-            with torch.cuda.stream(da_stream):
-                early_da = self.da_heads.early_image_level(features, targets)
-            if early_da is None:
-                da_stream = None
+
+            def run_early_da():
+                main = torch.cuda.current_stream(dev)
+                stream = side_stream(dev, 3)
+                stream.wait_stream(main)
+                with torch.cuda.stream(stream):
+                    holder["grads"] = self.da_heads.early_image_level(features, targets)
+                if holder["grads"] is not None:
+                    holder["ready"] = stream.record_event()
+                    record(features, stream)
+                    record(holder["grads"], main)      # consumed on the compute stream, in the backward pass
+
+            if _DA_AFTER_RPN and self.rpn.early_backward:
+                self.rpn.after_early_backward = run_early_da
             else:
-                record(features, da_stream)
+                run_early_da()
         if self.training and self.roi_heads and (self.da_heads or self.da_heads_triplet) and elision_enabled():
             self.rpn.live_images = self._images_with_read_proposals(targets)
         proposals, proposal_losses = self.rpn(images, features, targets)
         if self.training:
-            if da_stream is not None:
-                torch.cuda.current_stream(features[0].device).wait_stream(da_stream)
-                record(early_da, torch.cuda.current_stream(features[0].device))
-            features = self.rpn.bridge_features(features, early_da)
+            pending, self.rpn.after_early_backward = self.rpn.after_early_backward, None
+            if pending is not None:
+                pending()                    # the RPN took a path without an early backward
+            features = self.rpn.bridge_features(features, holder.get("grads"), holder.get("ready"))
             if self.roi_heads:
                 self.roi_heads.box.proposals_ready, self.rpn.proposals_ready = self.rpn.proposals_ready, None
         da_losses, detector_losses = {}, {}

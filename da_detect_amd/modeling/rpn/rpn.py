@@ -37,27 +37,32 @@ class RPNHead(nn.Module):
         return logits, bbox_reg
 
 
-def _add_leading(full, part):
-    full[:part.shape[0]] += part       # `full` is a gradient this step produced for this purpose: updated in place
-    return full
-
-
 class _InjectGrad(torch.autograd.Function):
-    """identity whose backward adds a gradient computed earlier (the RPN branch's, see RPNModule.early_backward)"""
+    """identity whose backward adds gradients computed earlier: `g` the RPN branch's (RPNModule.early_backward; it may
+    cover the leading images only), `e` another early branch's (the image-level DA head's), ready once `event` fired"""
 
     @staticmethod
-    def forward(ctx, x, g):
-        ctx.save_for_backward(g)
+    def forward(ctx, x, g, e, event):
+        ctx.event = event
+        ctx.save_for_backward(*[t for t in (g, e) if t is not None])
+        ctx.has = (g is not None, e is not None)
         return x.view_as(x)
 
     @staticmethod
     def backward(ctx, grad_out):
-        (g,) = ctx.saved_tensors
-        if g.shape[0] == grad_out.shape[0]:
-            return grad_out + g, None
-        out = grad_out.clone()          # g covers the leading images only (the ones the RPN losses are taken on)
-        out[:g.shape[0]] += g
-        return out, None
+        saved = list(ctx.saved_tensors)
+        g = saved.pop(0) if ctx.has[0] else None
+        e = saved.pop(0) if ctx.has[1] else None
+        if ctx.event is not None:
+            torch.cuda.current_stream(grad_out.device).wait_event(ctx.event)
+        out = grad_out + e if e is not None else None
+        if g is not None:
+            if out is None and g.shape[0] == grad_out.shape[0]:
+                out = grad_out + g
+            else:
+                out = grad_out.clone() if out is None else out
+                out[:g.shape[0]] += g
+        return out, None, None, None
 
 
 class RPNModule(torch.nn.Module):
@@ -76,6 +81,9 @@ class RPNModule(torch.nn.Module):
     # image of a triplet batch: generalized_rcnn.py:100 passes proposals[0:2] on) get no RPN head pass and no proposal
     # selection on the overlapped schedule — their entry in the returned list is None.
     live_images = None
+    # callable run ONCE right after the early backward has been queued (the detector issues the image-level DA branch
+    # there); left in place when the call took a path without an early backward
+    after_early_backward = None
 
     def __init__(self, cfg):
         super(RPNModule, self).__init__()
@@ -144,6 +152,9 @@ class RPNModule(torch.nn.Module):
         loss_objectness, loss_rpn_box_reg = self.loss_evaluator.finish(objectness, rpn_box_regression, prep)
         torch.autograd.backward([loss_objectness + loss_rpn_box_reg])
         self._feature_grads = [f.grad for f in head_in]
+        hook, self.after_early_backward = self.after_early_backward, None
+        if hook is not None:
+            hook()
         side = side_stream(dev)
         side.wait_event(head_done)
         # the head's maps were allocated on the compute stream and are released when forward() returns: without this the
@@ -157,18 +168,16 @@ class RPNModule(torch.nn.Module):
         boxes = list(boxes) + [None] * (len(targets) - n_live)
         return boxes, {"loss_objectness": loss_objectness.detach(), "loss_rpn_box_reg": loss_rpn_box_reg.detach()}
 
-    def bridge_features(self, features, extra=None):
+    def bridge_features(self, features, extra=None, extra_ready=None):
         """features whose backward also delivers the RPN branch's gradient (no-op unless early_backward ran);
-        `extra`: gradients of another branch that ran its backward early (the image-level DA head), same layout"""
+        `extra`: gradients of another branch that ran its backward early (the image-level DA head), same layout, valid
+        on the consuming stream once the event `extra_ready` has fired (the wait is placed in the backward pass)"""
         grads, self._feature_grads = self._feature_grads, None
-        if grads is None:
-            grads = extra
-        elif extra is not None:
-            # the RPN branch's gradient may cover the leading images only (_forward_train_overlapped)
-            grads = [g + e if g.shape[0] == e.shape[0] else _add_leading(e, g) for g, e in zip(grads, extra)]
-        if grads is None:
+        if grads is None and extra is None:
             return features
-        return [_InjectGrad.apply(f, g) for f, g in zip(features, grads)]
+        grads = grads if grads is not None else [None] * len(features)
+        extra = extra if extra is not None else [None] * len(features)
+        return [_InjectGrad.apply(f, g, e, extra_ready) for f, g, e in zip(features, grads, extra)]
 
     def _prepare_loss_targets(self, anchors, targets):
         """RPNLossComputation.prepare on a side stream: its ~150 small launches and host synchronisations overlap
