@@ -333,7 +333,9 @@ def test_wgrad_lane_is_a_schedule_not_a_result(device, monkeypatch):
     _, _, off, _ = _run_default_path("da_img_only", H, W, device, seed, monkeypatch)
     monkeypatch.setattr(streams, "WGRAD_LANE_ROWS", 17000)
     _, _, on, _ = _run_default_path("da_img_only", H, W, device, seed, monkeypatch)
-    assert on["losses"] == off["losses"]
+    assert set(on["losses"]) == set(off["losses"])
+    for k, v in off["losses"].items():
+        assert abs(on["losses"][k] - v) <= 1e-6 * max(abs(v), 1.0), (k, on["losses"][k], v)
     # not bit for bit even between two identical runs: the image-level DA kernels sum with atomics (order varies), the
     # backbone's gradients inherit that rounding, and a ReLU at the edge of zero may flip (_check_gradients' two tiers)
     worst, above = _check_gradients(on["grads"], off["grads"], rounding_tol=1e-5)
