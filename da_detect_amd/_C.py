@@ -170,13 +170,23 @@ def nms(dets, scores, threshold):
     return keep[: int(count.item())]
 
 
-def roi_align_forward(input, rois, spatial_scale, pooled_height, pooled_width, sampling_ratio):
-    """_C.roi_align_forward -> [R,C,ph,pw] (ROIAlign.h:11-25)."""
+def roi_align_forward(input, rois, spatial_scale, pooled_height, pooled_width, sampling_ratio, bin_stride=1):
+    """_C.roi_align_forward -> [R,C,ph,pw] (ROIAlign.h:11-25).  bin_stride s > 1: only the bins (i * s, j * s) of the
+    ph x pw grid, as a compact [R, C, ceil(ph / s), ceil(pw / s)] tensor (dadet_roi_align_forward_sub)."""
     _dev(input, "input"), _dev(rois, "rois")
     B, C, H, W = input.shape
     R = rois.shape[0]
     x = _nhwc(input)
     rois = rois.contiguous()
+    if bin_stride != 1:
+        s = int(bin_stride)
+        out = torch.empty((R, C, -(-pooled_height // s), -(-pooled_width // s)), dtype=torch.float32,
+                          device=input.device, memory_format=CL)
+        ws = _roi_workspace(B, H, W, R, input.device) if ROI_ALIGN_WORKSPACE else None
+        _lib.call("dadet_roi_align_forward_sub", _p(x), _p(rois), _p(out), B, C, H, W, R, pooled_height, pooled_width,
+                  float(spatial_scale), int(sampling_ratio), s, _p(ws) if ws is not None else None,
+                  ctypes.c_size_t(ws.numel() if ws is not None else 0), _stream())
+        return out
     out = torch.empty((R, C, pooled_height, pooled_width), dtype=torch.float32, device=input.device,
                       memory_format=CL)
     if ROI_ALIGN_WORKSPACE:
@@ -200,13 +210,21 @@ def _roi_workspace(B, H, W, R, device):
 
 
 def roi_align_backward(grad, rois, spatial_scale, pooled_height, pooled_width, batch_size, channels,
-                       height, width, sampling_ratio, atomic=False):
-    """_C.roi_align_backward -> [B,C,H,W] (ROIAlign.h:27-45)."""
+                       height, width, sampling_ratio, atomic=False, bin_stride=1):
+    """_C.roi_align_backward -> [B,C,H,W] (ROIAlign.h:27-45).  bin_stride s > 1: `grad` is the compact gradient of the
+    bins (i * s, j * s) (roi_align_forward with the same bin_stride)."""
     _dev(grad, "grad"), _dev(rois, "rois")
     g = _nhwc(grad)
     rois = rois.contiguous()
     gin = torch.empty((batch_size, channels, height, width), dtype=torch.float32, device=grad.device,
                       memory_format=CL)
+    if bin_stride != 1:
+        if atomic:
+            raise ValueError("roi_align_backward: bin_stride needs the gather form")
+        _lib.call("dadet_roi_align_backward_sub", _p(g), _p(rois), _p(gin), batch_size, channels, height, width,
+                  rois.shape[0], pooled_height, pooled_width, float(spatial_scale), int(sampling_ratio),
+                  int(bin_stride), _stream())
+        return gin
     if atomic:
         gin.zero_()
     _lib.call("dadet_roi_align_backward_atomic" if atomic else "dadet_roi_align_backward", _p(g), _p(rois),

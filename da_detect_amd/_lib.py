@@ -40,6 +40,10 @@ _SIGNATURES = {
     "dadet_roi_align_workspace_bytes": [c_int, c_int, c_int, c_int, POINTER(c_size_t)],
     "dadet_roi_align_forward_ws": [_P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_float, c_int, _P, c_size_t, _P],
     "dadet_roi_align_backward_atomic": [_P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_float, c_int, _P],
+    "dadet_roi_align_forward_sub": [_P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_float, c_int, c_int,
+                                    _P, c_size_t, _P],
+    "dadet_roi_align_backward_sub": [_P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_float, c_int, c_int,
+                                     _P],
     "dadet_sigmoid_focal_loss_forward": [_P, _P, _P, c_int, c_int, c_float, c_float, _P],
     "dadet_sigmoid_focal_loss_backward": [_P, _P, _P, _P, c_int, c_int, c_float, c_float, _P],
     "dadet_conv_forward": [POINTER(ConvDesc), _P, _P, _P, _P, _P, _P, _P, _P],

@@ -91,7 +91,8 @@ __device__ inline float sample_coord(float start, int p, float bin, int i, int g
 template <int VEC>
 __global__ __launch_bounds__(256) void roi_align_fwd_kernel(
     const float* __restrict__ input, const float* __restrict__ rois, float* __restrict__ output, int C,
-    int H, int W, int pooled_h, int pooled_w, float scale, int sampling_ratio, const int* __restrict__ order) {
+    int H, int W, int pooled_h, int pooled_w, float scale, int sampling_ratio, const int* __restrict__ order,
+    int bin_stride) {
   // XCD-aware order: the 14 bin rows of one ROI read overlapping feature rows; hardware deals consecutive workgroup
   // ids to the 8 XCDs round-robin, which made every XCD's L2 fetch the same rows again (PMC: 1.95 GB through the
   // fabric for 0.48 GB of algorithmic traffic).  The remap gives each XCD a contiguous range of (roi, ph).
@@ -99,15 +100,20 @@ __global__ __launch_bounds__(256) void roi_align_fwd_kernel(
   // i.e. spatially random: every XCD then pulls the whole feature map through its 4 MB L2 (PMC r01: 1.33 GB fetched +
   // written per launch for 0.48 GB algorithmic).  With spatially sorted ROIs the contiguous range of an XCD covers a
   // compact region and neighbouring ROIs share the rows already in L2.  Outputs stay at their original row r.
+  // bin_stride s > 1: only the bins (ph, pw) with ph % s == 0 and pw % s == 0 of the pooled_h x pooled_w grid are
+  // evaluated, into a compact [R][ceil(pooled_h / s)][ceil(pooled_w / s)][C] output (dadet_roi_align_forward_sub)
+  const int out_h = (pooled_h + bin_stride - 1) / bin_stride, out_w = (pooled_w + bin_stride - 1) / bin_stride;
   const int wg = xcd_remap(blockIdx.x, gridDim.x);
-  const int r = order ? order[wg / pooled_h] : wg / pooled_h;
-  const int ph = wg % pooled_h;
+  const int r = order ? order[wg / out_h] : wg / out_h;
+  const int oph = wg % out_h;
+  const int ph = oph * bin_stride;
   const RoiGeom g = roi_geometry(rois + (size_t)r * 5, scale, pooled_h, pooled_w, sampling_ratio);
   const float* __restrict__ img = input + (size_t)g.batch * H * W * C;
-  float* __restrict__ out_row = output + ((size_t)r * pooled_h + ph) * pooled_w * C;
+  float* __restrict__ out_row = output + ((size_t)r * out_h + oph) * out_w * C;
 
   for (int c = threadIdx.x * VEC; c < C; c += blockDim.x * VEC) {
-    for (int pw = 0; pw < pooled_w; ++pw) {
+    for (int opw = 0; opw < out_w; ++opw) {
+      const int pw = opw * bin_stride;
       float acc[VEC];
 #pragma unroll
       for (int v = 0; v < VEC; ++v) acc[v] = 0.f;
@@ -144,9 +150,9 @@ __global__ __launch_bounds__(256) void roi_align_fwd_kernel(
       if constexpr (VEC == 4) {
         float4 o;
         o.x = acc[0] / g.count; o.y = acc[1] / g.count; o.z = acc[2] / g.count; o.w = acc[3] / g.count;
-        *reinterpret_cast<float4*>(out_row + (size_t)pw * C + c) = o;
+        *reinterpret_cast<float4*>(out_row + (size_t)opw * C + c) = o;
       } else {
-        out_row[(size_t)pw * C + c] = acc[0] / g.count;
+        out_row[(size_t)opw * C + c] = acc[0] / g.count;
       }
     }
   }
@@ -358,8 +364,11 @@ struct Contribution {
 };
 constexpr int kListCap = 1024;   // entries per round (32 KB of LDS)
 
+// bs > 1 (dadet_roi_align_backward_sub): only bins with ph % bs == 0 and pw % bs == 0 carry a gradient; their rows live
+// in a compact [R][ceil(pooled_h / bs)][ceil(pooled_w / bs)] grid
 __device__ inline int roi_contributions(const RoiGeom& g, int r, int H, int W, int pooled_h, int pooled_w, int y0,
-                                        int x0, Contribution* out) {
+                                        int x0, Contribution* out, int bs = 1) {
+  const int out_h = (pooled_h + bs - 1) / bs, out_w = (pooled_w + bs - 1) / bs;
   int sy0, sy1, sx0, sx1, lo, hi, n = 0;
   candidate_range(g.start_h, g.bin_h, g.grid_h, pooled_h, y0, &sy0, &hi);
   candidate_range(g.start_h, g.bin_h, g.grid_h, pooled_h, y0 + 1, &lo, &sy1);
@@ -367,17 +376,19 @@ __device__ inline int roi_contributions(const RoiGeom& g, int r, int H, int W, i
   candidate_range(g.start_w, g.bin_w, g.grid_w, pooled_w, x0 + 1, &lo, &sx1);
   for (int sy = sy0; sy <= sy1; ++sy) {
     const int ph = sy / g.grid_h, iy = sy - ph * g.grid_h;
+    if (bs > 1 && ph % bs) continue;
     const float cy = sample_coord(g.start_h, ph, g.bin_h, iy, g.grid_h);
     const float wy0 = axis_weight(cy, H, y0), wy1 = axis_weight(cy, H, y0 + 1);
     if (wy0 == 0.f && wy1 == 0.f) continue;
     for (int sx = sx0; sx <= sx1; ++sx) {
       const int pw = sx / g.grid_w, ix = sx - pw * g.grid_w;
+      if (bs > 1 && pw % bs) continue;
       const float cx = sample_coord(g.start_w, pw, g.bin_w, ix, g.grid_w);
       const float wx0 = axis_weight(cx, W, x0), wx1 = axis_weight(cx, W, x0 + 1);
       if (wx0 == 0.f && wx1 == 0.f) continue;
       if (out) {
         Contribution c;
-        c.row = (r * pooled_h + ph) * pooled_w + pw;
+        c.row = (r * out_h + ph / bs) * out_w + pw / bs;
         c.count = g.count;
         c.w[0] = wy0 * wx0; c.w[1] = wy0 * wx1; c.w[2] = wy1 * wx0; c.w[3] = wy1 * wx1;
         c.inv = 1.f / g.count;
@@ -394,7 +405,7 @@ __device__ inline int roi_contributions(const RoiGeom& g, int r, int H, int W, i
 template <int VEC, int MAXC>   // MAXC channel groups per lane: C <= 256 * VEC * MAXC
 __global__ __launch_bounds__(256) void roi_align_bwd_list_kernel(
     const float* __restrict__ grad_out, const float* __restrict__ rois, float* __restrict__ grad_in, int B, int C,
-    int H, int W, int R, int pooled_h, int pooled_w, float scale, int sampling_ratio) {
+    int H, int W, int R, int pooled_h, int pooled_w, float scale, int sampling_ratio, int bin_stride) {
   __shared__ Contribution s_list[kListCap];
   __shared__ int s_ids[256];        // touching ROIs of the current range, ascending
   __shared__ int s_wave_n[4];
@@ -484,7 +495,7 @@ __global__ __launch_bounds__(256) void roi_align_bwd_list_kernel(
         if (lane < nround) {
           rr = s_ids[start + lane];
           g = roi_geometry(rois + (size_t)rr * 5, scale, pooled_h, pooled_w, sampling_ratio);
-          my_n = roi_contributions(g, rr, H, W, pooled_h, pooled_w, y0, x0, nullptr);
+          my_n = roi_contributions(g, rr, H, W, pooled_h, pooled_w, y0, x0, nullptr, bin_stride);
         }
         int incl = my_n;   // inclusive wave scan
 #pragma unroll
@@ -495,7 +506,7 @@ __global__ __launch_bounds__(256) void roi_align_bwd_list_kernel(
         const int total = __shfl(incl, 63, 64);
         if (lane == 0) s_total = total;
         if (total <= kListCap && rr >= 0)
-          roi_contributions(g, rr, H, W, pooled_h, pooled_w, y0, x0, s_list + (incl - my_n));
+          roi_contributions(g, rr, H, W, pooled_h, pooled_w, y0, x0, s_list + (incl - my_n), bin_stride);
       }
       __syncthreads();
       const int total = s_total;
@@ -509,8 +520,8 @@ __global__ __launch_bounds__(256) void roi_align_bwd_list_kernel(
           if (threadIdx.x == 0) {
             const int r1 = s_ids[start + i];
             const RoiGeom g1 = roi_geometry(rois + (size_t)r1 * 5, scale, pooled_h, pooled_w, sampling_ratio);
-            const int n1 = roi_contributions(g1, r1, H, W, pooled_h, pooled_w, y0, x0, nullptr);
-            if (n1 <= kListCap) roi_contributions(g1, r1, H, W, pooled_h, pooled_w, y0, x0, s_list);
+            const int n1 = roi_contributions(g1, r1, H, W, pooled_h, pooled_w, y0, x0, nullptr, bin_stride);
+            if (n1 <= kListCap) roi_contributions(g1, r1, H, W, pooled_h, pooled_w, y0, x0, s_list, bin_stride);
             s_total = n1 <= kListCap ? n1 : -1;
           }
           __syncthreads();
@@ -559,9 +570,11 @@ extern "C" int dadet_roi_align_workspace_bytes(int B, int H, int W, int R, size_
 
 static int roi_align_forward_impl(const float* input, const float* rois, float* output, int B, int C, int H, int W, int R,
                                   int pooled_h, int pooled_w, float spatial_scale, int sampling_ratio, void* workspace,
-                                  size_t workspace_bytes, void* stream) {
+                                  size_t workspace_bytes, void* stream, int bin_stride = 1) {
   int rc = roi_args_ok(input, rois, output, B, C, H, W, R, pooled_h, pooled_w);
   if (rc) return rc;
+  DADET_REQUIRE(bin_stride >= 1 && bin_stride <= pooled_h && bin_stride <= pooled_w, "roi_align_forward: bin_stride=%d",
+                bin_stride);
   if (R == 0) return DADET_OK;
   int* order = nullptr;
   if (workspace && R > 64 && R <= 4096) {     // spatial processing order (see roi_align_fwd_kernel)
@@ -573,19 +586,27 @@ static int roi_align_forward_impl(const float* input, const float* rois, float* 
     hipLaunchKernelGGL(roi_order_kernel, dim3(1), dim3(1024), sizeof(unsigned long long) * (size_t)N, as_stream(stream),
                        rois, R, N, spatial_scale, H, W, order);
   }
-  const dim3 grid((unsigned)(R * pooled_h));
+  const dim3 grid((unsigned)(R * ((pooled_h + bin_stride - 1) / bin_stride)));
   const bool vec = (C % 4 == 0) && ((reinterpret_cast<uintptr_t>(input) & 15) == 0) &&
                    ((reinterpret_cast<uintptr_t>(output) & 15) == 0);
   if (vec) {
     const int threads = (C / 4 >= 256) ? 256 : ((C / 4 + 63) / 64) * 64;
     hipLaunchKernelGGL(roi_align_fwd_kernel<4>, grid, dim3(threads), 0, as_stream(stream), input, rois,
-                       output, C, H, W, pooled_h, pooled_w, spatial_scale, sampling_ratio, order);
+                       output, C, H, W, pooled_h, pooled_w, spatial_scale, sampling_ratio, order, bin_stride);
   } else {
     const int threads = (C >= 256) ? 256 : ((C + 63) / 64) * 64;
     hipLaunchKernelGGL(roi_align_fwd_kernel<1>, grid, dim3(threads), 0, as_stream(stream), input, rois,
-                       output, C, H, W, pooled_h, pooled_w, spatial_scale, sampling_ratio, order);
+                       output, C, H, W, pooled_h, pooled_w, spatial_scale, sampling_ratio, order, bin_stride);
   }
   return check_launch("roi_align_forward");
+}
+
+extern "C" int dadet_roi_align_forward_sub(const float* input, const float* rois, float* output, int B, int C, int H,
+                                           int W, int R, int pooled_h, int pooled_w, float spatial_scale,
+                                           int sampling_ratio, int bin_stride, void* workspace, size_t workspace_bytes,
+                                           void* stream) {
+  return roi_align_forward_impl(input, rois, output, B, C, H, W, R, pooled_h, pooled_w, spatial_scale, sampling_ratio,
+                                workspace, workspace_bytes, stream, bin_stride);
 }
 
 extern "C" int dadet_roi_align_forward(const float* input, const float* rois, float* output, int B, int C, int H, int W,
@@ -622,11 +643,13 @@ extern "C" int dadet_roi_align_backward_atomic(const float* grad_output, const f
   return check_launch("roi_align_backward_atomic");
 }
 
-extern "C" int dadet_roi_align_backward(const float* grad_output, const float* rois, float* grad_input, int B, int C,
-                                        int H, int W, int R, int pooled_h, int pooled_w, float spatial_scale,
-                                        int sampling_ratio, void* stream) {
+static int roi_align_backward_impl(const float* grad_output, const float* rois, float* grad_input, int B, int C, int H,
+                                   int W, int R, int pooled_h, int pooled_w, float spatial_scale, int sampling_ratio,
+                                   int bin_stride, void* stream) {
   int rc = roi_args_ok(grad_output, rois, grad_input, B, C, H, W, R, pooled_h, pooled_w);
   if (rc) return rc;
+  DADET_REQUIRE(bin_stride >= 1 && bin_stride <= pooled_h && bin_stride <= pooled_w, "roi_align_backward: bin_stride=%d",
+                bin_stride);
   hipStream_t st = as_stream(stream);
   if (R == 0) {
     (void)hipMemsetAsync(grad_input, 0, sizeof(float) * (size_t)B * C * H * W, st);
@@ -644,10 +667,14 @@ extern "C" int dadet_roi_align_backward(const float* grad_output, const float* r
     const dim3 tgrid((unsigned)(((supers + kNumXCD - 1) / kNumXCD) * kNumXCD * 4), 1, 1);
     if (C <= 1024)
       hipLaunchKernelGGL((roi_align_bwd_list_kernel<4, 1>), tgrid, dim3(256), 0, st, grad_output, rois, grad_input, B, C,
-                         H, W, R, pooled_h, pooled_w, spatial_scale, sampling_ratio);
+                         H, W, R, pooled_h, pooled_w, spatial_scale, sampling_ratio, bin_stride);
     else
       hipLaunchKernelGGL((roi_align_bwd_list_kernel<4, 4>), tgrid, dim3(256), 0, st, grad_output, rois, grad_input, B, C,
-                         H, W, R, pooled_h, pooled_w, spatial_scale, sampling_ratio);
+                         H, W, R, pooled_h, pooled_w, spatial_scale, sampling_ratio, bin_stride);
+  } else if (bin_stride != 1) {
+    set_error("roi_align_backward_sub: needs C %% 4 == 0 (C=%d), 16-byte aligned buffers and a pooled grid of at most "
+              "14 x 14 (%d x %d)", C, pooled_h, pooled_w);
+    return DADET_EUNSUPPORTED;
   } else if (vec) {
     const int threads = (C / 4 >= 256) ? 256 : ((C / 4 + 63) / 64) * 64;
     hipLaunchKernelGGL(roi_align_bwd_gather_kernel<4>, grid, dim3(threads), lds, st, grad_output, rois,
@@ -658,4 +685,18 @@ extern "C" int dadet_roi_align_backward(const float* grad_output, const float* r
                        grad_input, C, H, W, R, pooled_h, pooled_w, spatial_scale, sampling_ratio);
   }
   return check_launch("roi_align_backward");
+}
+
+extern "C" int dadet_roi_align_backward(const float* grad_output, const float* rois, float* grad_input, int B, int C,
+                                        int H, int W, int R, int pooled_h, int pooled_w, float spatial_scale,
+                                        int sampling_ratio, void* stream) {
+  return roi_align_backward_impl(grad_output, rois, grad_input, B, C, H, W, R, pooled_h, pooled_w, spatial_scale,
+                                 sampling_ratio, 1, stream);
+}
+
+extern "C" int dadet_roi_align_backward_sub(const float* grad_output, const float* rois, float* grad_input, int B, int C,
+                                            int H, int W, int R, int pooled_h, int pooled_w, float spatial_scale,
+                                            int sampling_ratio, int bin_stride, void* stream) {
+  return roi_align_backward_impl(grad_output, rois, grad_input, B, C, H, W, R, pooled_h, pooled_w, spatial_scale,
+                                 sampling_ratio, bin_stride, stream);
 }

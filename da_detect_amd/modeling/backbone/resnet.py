@@ -146,20 +146,33 @@ class Bottleneck(nn.Module):
     # this block's weight gradients are then queued for utils.streams.flush_deferred_wgrads
     defer_wgrad = False
 
-    def forward(self, x, in_relu=False, out_private=False):
-        """in_relu / out_private: structural promises made by _Stage (see _BottleneckFn); a direct call makes none"""
+    def forward(self, x, in_relu=False, out_private=False, stride=None):
+        """in_relu / out_private: structural promises made by _Stage (see _BottleneckFn); a direct call makes none.
+        stride: overrides the stride of conv1 and the shortcut (see input_is_strided_1x1) — fused path only"""
         if self.with_dcn:
+            assert stride is None
             return self._forward_dcn(x)
         if self.conv2.stride[0] == 1:   # STRIDE_IN_1X1: the stride (if any) sits in conv1 and the shortcut
-            if x.shape[0] == 0:
+            if x.shape[0] == 0 and stride is None:
                 return self._forward_per_conv(x)
             wd = sd = bd = None
             if self.downsample is not None:
                 wd, (sd, bd) = self.downsample[0].weight, self.downsample[1].folded()
             return _BottleneckFn.apply(x, self.conv1.weight, self.conv2.weight, self.conv3.weight, wd,
                                        *self.bn1.folded(), *self.bn2.folded(), *self.bn3.folded(), sd, bd,
-                                       self.conv1.stride[0], in_relu, out_private, self.defer_wgrad)
+                                       self.conv1.stride[0] if stride is None else stride, in_relu, out_private,
+                                       self.defer_wgrad)
+        assert stride is None
         return self._forward_per_conv(x)
+
+    def input_is_strided_1x1(self):
+        """the block reads its input ONLY through stride-s 1x1 convolutions (conv1 and a projection shortcut), i.e. only
+        the pixels (i * s, j * s): -> s, else 1"""
+        s = self.conv1.stride[0]
+        if (self.uses_fused_path() and s > 1 and self.downsample is not None and self.conv1.kernel_size == (1, 1)
+                and self.downsample[0].kernel_size == (1, 1) and self.downsample[0].stride[0] == s):
+            return s
+        return 1
 
     def uses_fused_path(self):
         return (not self.with_dcn) and self.conv2.stride[0] == 1
@@ -244,13 +257,16 @@ class _Stage(nn.Sequential):
 
     input_is_relu = False   # set by the owner when the stage input is itself a ReLU output (ResNet.layer2..4)
 
-    def forward(self, x):
+    def forward(self, x, first_stride=None):
         n = len(self)
         blocks = list(self)
         for i, block in enumerate(blocks):
             # "private" only if the consumer really is a fused block that gates what it returns
             private = i < n - 1 and blocks[i + 1].uses_fused_path()
-            x = block(x, in_relu=(i > 0 or self.input_is_relu), out_private=private)
+            if i == 0 and first_stride is not None:
+                x = block(x, in_relu=self.input_is_relu, out_private=private, stride=first_stride)
+            else:
+                x = block(x, in_relu=(i > 0 or self.input_is_relu), out_private=private)
         return x
 
 
@@ -326,10 +342,15 @@ class ResNetHead(nn.Module):
         first = getattr(self, self.stages[0])[0]
         first.defer_wgrad = True   # last node of the head's backward, in front of the pooler's backward
 
-    def forward(self, x):
-        for stage in self.stages:
-            x = getattr(self, stage)(x)
+    def forward(self, x, first_stride=None):
+        for i, stage in enumerate(self.stages):
+            x = getattr(self, stage)(x, first_stride=first_stride) if (i == 0 and first_stride is not None) \
+                else getattr(self, stage)(x)
         return x
+
+    def input_bin_stride(self):
+        """s > 1: the head reads only the pixels (i * s, j * s) of its input (Bottleneck.input_is_strided_1x1)"""
+        return getattr(self, self.stages[0])[0].input_is_strided_1x1()
 
 
 _TRANSFORMATION_MODULES = Registry({"BottleneckWithFixedBatchNorm": BottleneckWithFixedBatchNorm})

@@ -36,10 +36,12 @@ class Pooler(nn.Module):
                    for i, b in enumerate(boxes)], dim=0)
         return torch.cat([ids, concat], dim=1)
 
-    def forward(self, x, boxes):
+    def forward(self, x, boxes, bin_stride=1):
         rois = self.convert_to_roi_format(boxes)
         if len(self.poolers) == 1:
-            return self.poolers[0](x[0], rois)
+            return self.poolers[0](x[0], rois, bin_stride)
+        if bin_stride != 1:
+            raise NotImplementedError("bin_stride over several pyramid levels")
         levels = self.map_levels(boxes)
         out_size = self.output_size[0]
         result = torch.zeros((len(rois), x[0].shape[1], out_size, out_size), dtype=x[0].dtype,

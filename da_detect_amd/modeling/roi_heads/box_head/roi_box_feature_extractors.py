@@ -1,4 +1,6 @@
 """ROI feature extractors (reference: maskrcnn_benchmark/modeling/roi_heads/box_head/roi_box_feature_extractors.py)."""
+import os
+
 from torch import nn
 
 from ....layers import conv2d_affine_act
@@ -6,6 +8,9 @@ from ... import registry
 from ...backbone import resnet
 from ...make_layers import make_fc
 from ...poolers import Pooler
+
+
+_SUBGRID = os.environ.get("DADET_ROI_SUBGRID", "1") == "1"
 
 
 @registry.ROI_BOX_FEATURE_EXTRACTORS.register("ResNet50Conv5ROIFeatureExtractor")
@@ -26,6 +31,15 @@ class ResNet50Conv5ROIFeatureExtractor(nn.Module):
             res2_out_channels=config.MODEL.RESNETS.RES2_OUT_CHANNELS, dilation=config.MODEL.RESNETS.RES5_DILATION)
 
     def forward(self, x, proposals):
+        # With STRIDE_IN_1X1 the head's first block reads the pooled 14 x 14 grid through two stride-2 1x1 convolutions
+        # (conv1 and the shortcut, resnet.py:236-262): bins (2i, 2j) only, and zeros flow back into the other three
+        # quarters.  Those bins are pooled alone, into a 7 x 7 grid, and the block runs with stride 1 on it: the same
+        # values (bit for bit) from a quarter of the ROIAlign work, forward and backward.  DADET_ROI_SUBGRID=0: the
+        # reference's full grid.
+        stride = self.head.input_bin_stride() if (_SUBGRID and x[0].is_cuda and len(self.pooler.poolers) == 1
+                                                  and sum(len(p) for p in proposals) > 0) else 1
+        if stride > 1:
+            return self.head(self.pooler(x, proposals, bin_stride=stride), first_stride=1)
         return self.head(self.pooler(x, proposals))
 
 

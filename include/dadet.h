@@ -93,6 +93,19 @@ int dadet_roi_align_forward_ws(const float* input, const float* rois, float* out
 int dadet_roi_align_backward_atomic(const float* grad_output, const float* rois, float* grad_input, int B,
                                     int C, int H, int W, int R, int pooled_h, int pooled_w,
                                     float spatial_scale, int sampling_ratio, void* stream);
+/* Every bin_stride-th bin of the pooled_h x pooled_w grid only: output / grad_output are the COMPACT
+ * [R][ceil(pooled_h / s)][ceil(pooled_w / s)][C] tensors of the bins (ph, pw) with ph % s == 0 and pw % s == 0, each bin
+ * evaluated exactly as in the full grid.  For the reference's res5 ROI head with STRIDE_IN_1X1 (modeling/backbone/
+ * resnet.py:236-262: the first block's 1x1 conv and its shortcut carry stride 2), which reads one of four bins of
+ * roi_align's 14 x 14 output and back-propagates zeros into the other three: the same 7 x 7 values, a quarter of the
+ * work and of the pooled tensor.  workspace as in dadet_roi_align_forward_ws (may be NULL).  The backward needs C % 4 ==
+ * 0, 16-byte aligned buffers and a pooled grid of at most 14 x 14 (DADET_EUNSUPPORTED otherwise). */
+int dadet_roi_align_forward_sub(const float* input, const float* rois, float* output, int B, int C, int H, int W, int R,
+                                int pooled_h, int pooled_w, float spatial_scale, int sampling_ratio, int bin_stride,
+                                void* workspace, size_t workspace_bytes, void* stream);
+int dadet_roi_align_backward_sub(const float* grad_output, const float* rois, float* grad_input, int B, int C, int H,
+                                 int W, int R, int pooled_h, int pooled_w, float spatial_scale, int sampling_ratio,
+                                 int bin_stride, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * SigmoidFocalLoss — replaces `_C.sigmoid_focalloss_forward/backward`

@@ -3,12 +3,15 @@
 Bars: integer / index results bit-exact; ROIAlign forward bit-exact (same operation order, contraction off);
 atomically-accumulated and MFMA results within the fp32 tolerances stated per test.
 """
+import os
+
 import numpy as np
 import pytest
 import torch
 import torch.nn.functional as F
 
 pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 CL = torch.channels_last
 
@@ -958,3 +961,65 @@ def test_vectorised_epilogue_is_bit_identical(device, shape):
             os.environ.pop("DADET_EPILOGUE_V4")
     for a, b, kw in zip(out["0"], out["1"], cases):
         assert torch.equal(a, b), sorted(kw)
+
+
+@pytest.mark.parametrize("sampling_ratio", [0, 2])
+def test_roi_align_every_other_bin(device, sampling_ratio):
+    """dadet_roi_align_forward_sub / _backward_sub (bin_stride 2): the compact 7 x 7 result IS the (2i, 2j) sub-grid of
+    the full 14 x 14 one, bit for bit; the gradient equals the full backward fed with zeros in the other bins"""
+    from da_detect_amd import _C
+
+    g = torch.Generator().manual_seed(77 + sampling_ratio)
+    B, C, H, W, R = 2, 256, 38, 50, 300
+    feat = torch.randn((B, C, H, W), generator=g).to(device).contiguous(memory_format=torch.channels_last)
+    xy = torch.rand((R, 2), generator=g) * torch.tensor([W * 16.0 - 40, H * 16.0 - 40])
+    wh = torch.rand((R, 2), generator=g) * 400 + 4
+    rois = torch.cat([torch.randint(0, B, (R, 1), generator=g).float(), xy, xy + wh], dim=1).to(device)
+    rois[:5, 1:] = torch.tensor([-30.0, -20.0, 10.0, 12.0])       # partly outside the image
+    full = _C.roi_align_forward(feat, rois, 1 / 16, 14, 14, sampling_ratio)
+    sub = _C.roi_align_forward(feat, rois, 1 / 16, 14, 14, sampling_ratio, bin_stride=2)
+    assert tuple(sub.shape) == (R, C, 7, 7)
+    assert torch.equal(sub, full[:, :, ::2, ::2])
+    go = torch.randn((R, C, 7, 7), generator=g).to(device).contiguous(memory_format=torch.channels_last)
+    spread = torch.zeros((R, C, 14, 14), device=device).contiguous(memory_format=torch.channels_last)
+    spread[:, :, ::2, ::2] = go
+    want = _C.roi_align_backward(spread, rois, 1 / 16, 14, 14, B, C, H, W, sampling_ratio)
+    got = _C.roi_align_backward(go, rois, 1 / 16, 14, 14, B, C, H, W, sampling_ratio, bin_stride=2)
+    assert torch.equal(got, want)
+    # odd grids: ceil(5 / 2) = 3 bins per side
+    full5 = _C.roi_align_forward(feat, rois, 1 / 16, 5, 5, sampling_ratio)
+    assert torch.equal(_C.roi_align_forward(feat, rois, 1 / 16, 5, 5, sampling_ratio, bin_stride=2), full5[:, :, ::2, ::2])
+
+
+def test_res5_head_on_the_sub_grid_is_the_same_head(device, monkeypatch):
+    """ResNet50Conv5ROIFeatureExtractor: pooling only the bins its stride-2 1x1 convolutions read (default) against the
+    reference's full 14 x 14 grid (DADET_ROI_SUBGRID=0): identical features, identical gradients"""
+    from da_detect_amd.config import cfg as base
+    from da_detect_amd.modeling.roi_heads.box_head import roi_box_feature_extractors as fe
+    from da_detect_amd.structures.bounding_box import BoxList
+
+    c = base.clone()
+    c.merge_from_file(os.path.join(ROOT, "configs/da_faster_rcnn/e2e_da_faster_rcnn_R_50_C4_img_only.yaml"))
+    torch.manual_seed(3)
+    ext = fe.make_roi_box_feature_extractor(c).to(device)
+    g = torch.Generator().manual_seed(5)
+    feat = torch.randn((2, 1024, 24, 40), generator=g).to(device).contiguous(memory_format=torch.channels_last)
+    boxes = []
+    for _ in range(2):
+        xy = torch.rand((40, 2), generator=g) * torch.tensor([500.0, 300.0])
+        boxes.append(BoxList(torch.cat([xy, xy + torch.rand((40, 2), generator=g) * 200 + 8], dim=1).to(device),
+                             (640, 384), "xyxy"))
+    out = {}
+    for flag in (True, False):
+        monkeypatch.setattr(fe, "_SUBGRID", flag)
+        f = feat.clone().requires_grad_(True)
+        for p in ext.parameters():
+            p.grad = None
+        y = ext([f], boxes)
+        (y * torch.linspace(-1, 1, y.numel(), device=device).view_as(y)).sum().backward()
+        out[flag] = (y.detach(), f.grad, {n: p.grad.clone() for n, p in ext.named_parameters() if p.grad is not None})
+    assert tuple(out[True][0].shape) == (80, 2048, 7, 7)
+    assert torch.equal(out[True][0], out[False][0])
+    torch.testing.assert_close(out[True][1], out[False][1], rtol=1e-5, atol=1e-6)
+    for n, gfull in out[False][2].items():
+        torch.testing.assert_close(out[True][2][n], gfull, rtol=1e-4, atol=1e-6, msg=lambda m, n=n: "%s: %s" % (n, m))
