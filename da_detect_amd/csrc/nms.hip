@@ -236,34 +236,31 @@ __global__ void nms_flag_kernel(const unsigned long long* __restrict__ keep_bits
   flag[order ? order[i] : i] = kept ? 1 : 0;
 }
 
-__global__ __launch_bounds__(1024) void nms_compact_kernel(const unsigned char* __restrict__ flag, int n,
-                                                           int64_t* __restrict__ keep_out,
-                                                           int* __restrict__ num_out) {
-  __shared__ int wave_sums[16];
-  __shared__ int s_base;
-  if (threadIdx.x == 0) s_base = 0;
-  __syncthreads();
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  for (int start = 0; start < n; start += blockDim.x) {
-    const int i = start + threadIdx.x;
-    const int f = (i < n) ? (int)flag[i] : 0;
-    const unsigned long long ballot = __ballot(f);
-    const int prefix = __popcll(ballot & ((1ULL << lane) - 1ULL));
-    if (lane == 0) wave_sums[wave] = __popcll(ballot);
-    __syncthreads();
-    int wave_off = 0, total = 0;
-    for (int k = 0; k < (int)(blockDim.x >> 6); ++k) {
-      const int s = wave_sums[k];
-      if (k < wave) wave_off += s;
-      total += s;
+// One WAVE: the kernel runs on a side stream beside GEMM workgroups that fill the SIMDs' register files (two waves of
+// 204 - 237 VGPRs each), and a 1024-thread workgroup (16 waves on one CU) was only placed when a GEMM workgroup retired —
+// 0.2 - 0.45 ms for ~10 us of work, on the path between the NMS sweep and the box head.  A single wave with a few
+// registers is placed at once; 12 000 flags are 188 ballots.
+__global__ __launch_bounds__(64) void nms_compact_kernel(const unsigned char* __restrict__ flag, int n,
+                                                         int64_t* __restrict__ keep_out,
+                                                         int* __restrict__ num_out) {
+  const int lane = threadIdx.x;
+  int base = 0;
+  for (int start = 0; start < n; start += 4 * 64) {
+    // four ballots per round: the byte loads of a round are independent and issue back to back
+    int f[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int i = start + u * 64 + lane;
+      f[u] = (i < n) ? (int)flag[i] : 0;
     }
-    const int base = s_base;
-    if (f) keep_out[base + wave_off + prefix] = (int64_t)i;
-    __syncthreads();
-    if (threadIdx.x == 0) s_base = base + total;
-    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const unsigned long long ballot = __ballot(f[u]);
+      if (f[u]) keep_out[base + __popcll(ballot & ((1ULL << lane) - 1ULL))] = (int64_t)(start + u * 64 + lane);
+      base += __popcll(ballot);
+    }
   }
-  if (threadIdx.x == 0) *num_out = s_base;
+  if (lane == 0) *num_out = base;
 }
 
 static int next_pow2(int n) {
@@ -369,6 +366,6 @@ extern "C" int dadet_nms(const float* boxes_xyxy, const float* scores, int n, fl
   hipLaunchKernelGGL(nms_sweep_kernel, dim3(1), dim3(sweep_threads), 0, st, mask, n, col_blocks, max_keep,
                      keep_bits);
   hipLaunchKernelGGL(nms_flag_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, st, keep_bits, order, n, flag);
-  hipLaunchKernelGGL(nms_compact_kernel, dim3(1), dim3(1024), 0, st, flag, n, keep_out, num_keep_out);
+  hipLaunchKernelGGL(nms_compact_kernel, dim3(1), dim3(64), 0, st, flag, n, keep_out, num_keep_out);
   return check_launch("nms");
 }
