@@ -538,6 +538,46 @@ def rpn_loss(objectness, box_regression, sampled_inds, labels_sampled, pos_inds,
     return losses, g_obj, g_reg
 
 
+def rpn_loss_rows(objectness, box_regression, sampled_inds, labels_sampled, num_pos, targets_pos, beta):
+    """RPN losses with the gradient in row form (dadet_rpn_loss_rows): -> (losses [2], grad rows [S, ldg] with ldg = 5A
+    rounded up to a multiple of 4, pixel index of every row int32 [S])"""
+    _dev(objectness, "objectness"), _dev(box_regression, "box_regression")
+    obj, reg = _nhwc(objectness), _nhwc(box_regression)
+    A = obj.shape[1]
+    S = int(sampled_inds.numel())
+    ldg = (5 * A + 3) // 4 * 4
+    losses = torch.empty(2, dtype=torch.float32, device=obj.device)
+    rows = torch.empty((S, ldg), dtype=torch.float32, device=obj.device)
+    pixels = torch.empty(S, dtype=torch.int32, device=obj.device)
+    _lib.call("dadet_rpn_loss_rows", _p(obj), _p(reg), _p(sampled_inds.contiguous()), _p(labels_sampled.contiguous()),
+              S, int(num_pos), _p(targets_pos.contiguous()), A, float(beta), _p(losses), _p(rows), ldg, _p(pixels),
+              _stream())
+    return losses, rows, pixels
+
+
+def gather_pixel_taps(x, pixels, ksize=1, pad=0):
+    """x [N,C,H,W] channels_last, pixels int32 [S] -> [S, ksize*ksize, C]: the rows x[pixel + tap offset] (zero outside)"""
+    _dev(x, "x")
+    assert pixels.is_cuda and pixels.dtype == torch.int32
+    N, C, H, W = x.shape
+    x = _nhwc(x)
+    S = int(pixels.numel())
+    out = torch.empty((S, ksize * ksize, C), dtype=torch.float32, device=x.device)
+    _lib.call("dadet_gather_pixel_taps", _p(x), _p(pixels), S, N, H, W, C, ksize, ksize, pad, _p(out), _stream())
+    return out
+
+
+def scatter_pixel_taps_add(y, pixels, shape, ksize=1, pad=0):
+    """y [S, ksize*ksize, C] -> zero [N,C,H,W] channels_last map with y[r, tap] added at pixel_r + tap offset"""
+    _dev(y, "y")
+    assert pixels.is_cuda and pixels.dtype == torch.int32
+    N, C, H, W = shape
+    dx = torch.zeros((N, C, H, W), dtype=torch.float32, device=y.device).contiguous(memory_format=CL)
+    _lib.call("dadet_scatter_pixel_taps_add", _p(y.contiguous()), _p(pixels), int(pixels.numel()), N, H, W, C, ksize,
+              ksize, pad, _p(dx), _stream())
+    return dx
+
+
 def fast_rcnn_loss(class_logits, box_regression, src, labels_src, rows_pos, map_inds, targets_pos):
     """Fast R-CNN losses + gradients in one launch (dadet_fast_rcnn_loss) -> (losses [2], g_cls, g_reg)"""
     _dev(class_logits, "class_logits"), _dev(box_regression, "box_regression")

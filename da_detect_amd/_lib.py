@@ -59,6 +59,9 @@ _SIGNATURES = {
     "dadet_image_resample_v_normalize": [_P, c_int, c_int, _P, _P, c_int, c_int, c_int, c_int, POINTER(c_float),
                                          POINTER(c_float), _P, c_int, _P],
     "dadet_rpn_loss": [_P, _P, _P, _P, c_int, _P, _P, c_int, c_float, _P, _P, _P, _P],
+    "dadet_rpn_loss_rows": [_P, _P, _P, _P, c_int, c_int, _P, c_int, c_float, _P, _P, c_int, _P, _P],
+    "dadet_gather_pixel_taps": [_P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P, _P],
+    "dadet_scatter_pixel_taps_add": [_P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P, _P],
     "dadet_fast_rcnn_loss": [_P, _P, c_int, c_int, _P, _P, c_int, _P, _P, _P, c_int, _P, _P, _P, _P],
     "dadet_fast_rcnn_loss_rows": [_P, _P, c_int, c_int, c_int, _P, _P, _P, _P, _P, _P],
     "dadet_sample_rois": [_P, _P, _P, c_int, c_int, c_int, c_uint64, c_int, _P, _P, _P, _P, _P, _P, _P, _P],

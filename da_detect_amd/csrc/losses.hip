@@ -153,6 +153,81 @@ __global__ __launch_bounds__(256) void frcnn_loss_rows_kernel(const float* __res
   }
 }
 
+// ---- RPN losses in ROW form -------------------------------------------------------------------------------------
+// The RPN losses read the head's maps at the S sampled anchors only (<= 256 per labelled image), so the gradient of the
+// maps is zero everywhere else: at most S of the N*H*W pixel rows of the head's backward GEMMs carry anything.  This
+// kernel returns the gradient as S rows instead of two dense maps — row r belongs to anchor sampled_inds[r] = pixel * A + a
+// and holds d loss / d (that pixel's A objectness + 4A regression outputs) restricted to anchor a — plus each row's pixel.
+// Rows of the same pixel (two sampled anchors at one location) stay separate: everything downstream is linear in the
+// rows.  The positives are the first Pn sampled rows (rpn/loss.py:116-118: cat([pos, neg])).  Loss values: the same
+// arithmetic and reduction order as rpn_loss_kernel.
+__global__ __launch_bounds__(256) void rpn_loss_rows_kernel(const float* __restrict__ objectness,
+                                                            const float* __restrict__ box_regression,
+                                                            const int64_t* __restrict__ sampled_inds,
+                                                            const float* __restrict__ labels_sampled, int S, int Pn,
+                                                            const float* __restrict__ targets_pos, int A, float beta,
+                                                            float* __restrict__ losses, float* __restrict__ G, int ldg,
+                                                            int* __restrict__ pixels) {
+  __shared__ float red[4];
+  const float inv = S > 0 ? 1.f / (float)S : 0.f;
+  for (int i = threadIdx.x; i < S * ldg; i += 256) G[i] = 0.f;
+  __syncthreads();
+  float bce = 0.f;
+  for (int i = threadIdx.x; i < S; i += 256) {
+    const int64_t idx = sampled_inds[i];
+    const int a = (int)(idx % A);
+    const float x = objectness[idx], y = labels_sampled[i];
+    bce += fmaxf(x, 0.f) - x * y + log1pf(expf(-fabsf(x)));
+    G[(size_t)i * ldg + a] = (1.f / (1.f + expf(-x)) - y) * inv;
+    pixels[i] = (int)(idx / A);
+  }
+  float box = 0.f;
+  for (int i = threadIdx.x; i < Pn * 4; i += 256) {
+    const int r = i >> 2, j = i & 3;
+    const int64_t idx = sampled_inds[r];
+    const int a = (int)(idx % A);
+    float g;
+    box += smooth_l1_term(box_regression[idx * 4 + j], targets_pos[i], beta, &g);
+    G[(size_t)r * ldg + A + 4 * a + j] = g * inv;
+  }
+  bce = block_sum_256(bce, red);
+  box = block_sum_256(box, red);
+  if (threadIdx.x == 0) {
+    losses[0] = bce * inv;
+    losses[1] = box * inv;
+  }
+}
+
+// out[r][tap][c] = x[pixel_r + offset(tap)][c], 0 outside the image: the K-contiguous operand rows ("im2col" of S pixels)
+// of a KH x KW stride-1 convolution's weight gradient; KH = KW = 1: plain row gather
+__global__ __launch_bounds__(256) void gather_pixel_taps_kernel(const float4* __restrict__ x, const int* __restrict__ pixels,
+                                                                int H, int W, int C4, int KH, int KW, int pad,
+                                                                float4* __restrict__ out) {
+  const int r = blockIdx.x / (KH * KW), tap = blockIdx.x % (KH * KW);
+  const int p = pixels[r];
+  const int n = p / (H * W), rem = p - n * H * W;
+  const int h = rem / W + tap / KW - pad, w = rem % W + tap % KW - pad;
+  const bool inside = h >= 0 && h < H && w >= 0 && w < W;
+  const float4* src = x + ((size_t)(n * H + h) * W + w) * C4;
+  float4* dst = out + (size_t)blockIdx.x * C4;
+  for (int c = threadIdx.x; c < C4; c += 256) dst[c] = inside ? src[c] : make_float4(0.f, 0.f, 0.f, 0.f);
+}
+
+// dx[pixel_r + offset(tap)][c] += y[r][tap][c]: the data gradient of the same convolution from its S non-zero output rows
+// (dx zero-filled by the caller; rows of neighbouring or equal pixels meet on the same dx row: hardware fp32 atomics)
+__global__ __launch_bounds__(256) void scatter_pixel_taps_add_kernel(const float* __restrict__ y,
+                                                                     const int* __restrict__ pixels, int H, int W, int C,
+                                                                     int KH, int KW, int pad, float* __restrict__ dx) {
+  const int r = blockIdx.x / (KH * KW), tap = blockIdx.x % (KH * KW);
+  const int p = pixels[r];
+  const int n = p / (H * W), rem = p - n * H * W;
+  const int h = rem / W + tap / KW - pad, w = rem % W + tap % KW - pad;
+  if (h < 0 || h >= H || w < 0 || w >= W) return;
+  const float* src = y + (size_t)blockIdx.x * C;
+  float* dst = dx + ((size_t)(n * H + h) * W + w) * C;
+  for (int c = threadIdx.x; c < C; c += 256) atomicAdd(dst + c, src[c]);
+}
+
 }  // namespace dadet
 
 using namespace dadet;
@@ -202,4 +277,43 @@ extern "C" int dadet_fast_rcnn_loss_rows(const float* class_logits, const float*
                      num_rows, num_classes, reg_cols, loss_labels, regression_targets, losses_out, grad_class_logits,
                      grad_box_regression);
   return check_launch("fast_rcnn_loss_rows");
+}
+
+extern "C" int dadet_rpn_loss_rows(const float* objectness, const float* box_regression, const int64_t* sampled_inds,
+                                   const float* labels_sampled, int num_sampled, int num_pos,
+                                   const float* regression_targets_pos, int anchors_per_location, float beta,
+                                   float* losses_out, float* grad_rows, int ldg, int* pixels_out, void* stream) {
+  DADET_REQUIRE(num_sampled > 0 && num_pos >= 0 && num_pos <= num_sampled && anchors_per_location > 0,
+                "rpn_loss_rows: bad counts (%d sampled, %d positive)", num_sampled, num_pos);
+  DADET_REQUIRE(ldg >= 5 * anchors_per_location, "rpn_loss_rows: ldg=%d < 5 * %d", ldg, anchors_per_location);
+  DADET_REQUIRE(objectness && box_regression && sampled_inds && labels_sampled && losses_out && grad_rows && pixels_out,
+                "rpn_loss_rows: null pointer");
+  DADET_REQUIRE(num_pos == 0 || regression_targets_pos, "rpn_loss_rows: null regression targets");
+  hipLaunchKernelGGL(rpn_loss_rows_kernel, dim3(1), dim3(256), 0, as_stream(stream), objectness, box_regression,
+                     sampled_inds, labels_sampled, num_sampled, num_pos, regression_targets_pos, anchors_per_location,
+                     beta, losses_out, grad_rows, ldg, pixels_out);
+  return check_launch("rpn_loss_rows");
+}
+
+extern "C" int dadet_gather_pixel_taps(const float* x, const int* pixels, int num_rows, int N, int H, int W, int C, int KH,
+                                       int KW, int pad, float* out, void* stream) {
+  DADET_REQUIRE(num_rows >= 0 && N > 0 && H > 0 && W > 0 && C > 0 && C % 4 == 0 && KH > 0 && KW > 0 && pad >= 0,
+                "gather_pixel_taps: bad dims (C=%d must be a multiple of 4)", C);
+  if (num_rows == 0) return DADET_OK;
+  DADET_REQUIRE(x && pixels && out && (reinterpret_cast<uintptr_t>(x) & 15) == 0 && (reinterpret_cast<uintptr_t>(out) & 15) == 0,
+                "gather_pixel_taps: null or unaligned pointer");
+  hipLaunchKernelGGL(gather_pixel_taps_kernel, dim3(num_rows * KH * KW), dim3(256), 0, as_stream(stream),
+                     reinterpret_cast<const float4*>(x), pixels, H, W, C / 4, KH, KW, pad, reinterpret_cast<float4*>(out));
+  return check_launch("gather_pixel_taps");
+}
+
+extern "C" int dadet_scatter_pixel_taps_add(const float* y, const int* pixels, int num_rows, int N, int H, int W, int C,
+                                            int KH, int KW, int pad, float* dx, void* stream) {
+  DADET_REQUIRE(num_rows >= 0 && N > 0 && H > 0 && W > 0 && C > 0 && KH > 0 && KW > 0 && pad >= 0,
+                "scatter_pixel_taps_add: bad dims");
+  if (num_rows == 0) return DADET_OK;
+  DADET_REQUIRE(y && pixels && dx, "scatter_pixel_taps_add: null pointer");
+  hipLaunchKernelGGL(scatter_pixel_taps_add_kernel, dim3(num_rows * KH * KW), dim3(256), 0, as_stream(stream), y, pixels,
+                     H, W, C, KH, KW, pad, dx);
+  return check_launch("scatter_pixel_taps_add");
 }

@@ -126,6 +126,58 @@ class _RPNLoss(Function):
         return g_obj * g0, g_reg * g1, None, None, None, None, None
 
 
+class _RPNHeadLossRows(Function):
+    """RPN losses of one level AND the single-conv RPN head's whole backward, on the sampled rows only.
+
+    The losses read the head's maps at the S sampled anchors (<= 256 per labelled image; rpn/loss.py:125-143), so
+    d loss / d maps is zero at every other pixel and every GEMM of the head's backward (modeling/rpn/rpn.py:39-46 under
+    autograd: two 1x1 convolutions, the ReLU, the 3x3 convolution) has at most S non-zero rows out of N*H*W.  Here they
+    run on those rows: G [S, 5A] from the loss kernel (row form), the hidden activations t and the 3x3 operand rows of x
+    gathered at the rows' pixels, four small GEMMs (through the same conv entry points, as 1x1 convolutions over S "pixels")
+    and one scatter for the data gradient.  Same sums as the dense backward — zero rows contribute nothing — in another
+    order.  Inputs: x [n,C,H,W] (the head's input), conv / cls_logits / bbox_pred parameters, t = relu(conv(x)), the
+    head's output maps, the sample."""
+
+    @staticmethod
+    def forward(ctx, x, w3, b3, wc, bc, wb, bb, t, objectness, box_regression, sampled_inds, labels_sampled, n_pos,
+                targets_pos, beta):
+        losses, rows, pixels = _C.rpn_loss_rows(objectness, box_regression, sampled_inds, labels_sampled, n_pos,
+                                                targets_pos, beta)
+        ctx.save_for_backward(x, w3, wc, wb, t, rows, pixels)
+        ctx.A = objectness.shape[1]
+        return losses[0], losses[1]
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g0, g1):
+        x, w3, wc, wb, t, rows, pixels = ctx.saved_tensors
+        A, S, ldg = ctx.A, rows.shape[0], rows.shape[1]
+        C = x.shape[1]
+        k = w3.shape[2]
+        # upstream factors of the two losses (1 and 1 when they enter the total loss unweighted)
+        scale = torch.cat([g0.reshape(1).expand(A), g1.reshape(1).expand(4 * A), rows.new_zeros(ldg - 5 * A)])
+        G = (rows * scale).view(S, ldg, 1, 1)
+        t_rows = _C.gather_pixel_taps(t, pixels).view(S, C, 1, 1)
+        x_cols = _C.gather_pixel_taps(x, pixels, k, k // 2).view(S, k * k * C, 1, 1)
+        # the two 1x1 heads as one [5A (+pad), C] matrix, like the forward pass (layers.conv1x1_multi)
+        w_head = torch.cat([wc.reshape(A, C), wb.reshape(4 * A, C), rows.new_zeros(ldg - 5 * A, C)], 0)
+        d_head = _C.conv_wgrad(t_rows, G, (ldg, C, 1, 1))
+        b_head = G.view(S, ldg).sum(0)
+        # gradient of the hidden activations at the rows' pixels, gated by the ReLU (relu_mode 2: mask_ref > 0)
+        gt = _C.conv_forward(G, w_head.t().contiguous().view(C, ldg, 1, 1), relu_mode=2, mask_ref=t_rows)
+        dw3 = _C.conv_wgrad(x_cols, gt, (w3.shape[0], k * k * C, 1, 1))
+        dw3 = dw3.view(w3.shape[0], k, k, C).permute(0, 3, 1, 2)          # the parameter's channels_last layout
+        db3 = gt.view(S, -1).sum(0)
+        # data gradient: y[r][tap][ci] = sum_co gt[r][co] * w3[co][tap][ci], added at pixel_r + tap offset
+        w_mat = w3.permute(0, 2, 3, 1).reshape(w3.shape[0], k * k * C)
+        y = _C.conv_forward(gt, w_mat.t().contiguous().view(k * k * C, w3.shape[0], 1, 1))
+        dx = _C.scatter_pixel_taps_add(y.view(S, k * k, C), pixels, tuple(x.shape), k, k // 2)
+        return (dx, dw3, db3, d_head[:A], b_head[:A], d_head[A:5 * A], b_head[A:5 * A]) + (None,) * 8
+
+
+rpn_head_loss_rows = _RPNHeadLossRows.apply
+
+
 class _FastRCNNLoss(Function):
     """(classification_loss, box_loss) with the gradients produced by the same launch"""
 

@@ -3,6 +3,7 @@ import torch
 from torch import nn
 
 from ...layers import Conv2d, conv1x1_multi
+from ...layers.misc import rpn_head_loss_rows
 from .. import registry
 from ..box_coder import BoxCoder
 from .anchor_generator import make_anchor_generator
@@ -26,15 +27,24 @@ class RPNHead(nn.Module):
             torch.nn.init.normal_(l.weight, std=0.01)
             torch.nn.init.constant_(l.bias, 0)
 
+    keep_hidden = False     # True: forward also leaves the 3x3 conv's ReLU output of every level in self.hidden
+
     def forward(self, x):
         logits, bbox_reg = [], []
+        self.hidden = []
         for feature in x:
             t = self.conv(feature, relu=True)
+            if self.keep_hidden:
+                self.hidden.append(t)
             cls, box = conv1x1_multi(t, [self.cls_logits.weight, self.bbox_pred.weight],
                                      [self.cls_logits.bias, self.bbox_pred.bias])
             logits.append(cls)
             bbox_reg.append(box)
         return logits, bbox_reg
+
+
+# the single-conv head's backward over the sampled anchors' rows only (layers.misc._RPNHeadLossRows); 0: autograd's dense one
+_ROW_BACKWARD = __import__("os").environ.get("DADET_RPN_ROW_BACKWARD", "1") == "1"
 
 
 class _InjectGrad(torch.autograd.Function):
@@ -131,7 +141,15 @@ class RPNModule(torch.nn.Module):
         n_grad = leading_source_images(targets) or n_img      # unusual batch order: no restriction
         n_live = n_img if live is None else max(n_grad, min(int(live), n_img))
         head_in = [f[:n_grad].detach().requires_grad_(True)]
-        objectness, rpn_box_regression = self.head(head_in)
+        hidden = None
+        if _ROW_BACKWARD and isinstance(self.head, RPNHead):
+            # the head's backward is hand-written over the sampled rows (layers.misc._RPNHeadLossRows): no autograd graph
+            with torch.no_grad():
+                self.head.keep_hidden = True
+                objectness, rpn_box_regression = self.head(head_in)
+                hidden, self.head.hidden, self.head.keep_hidden = self.head.hidden[0], [], False
+        else:
+            objectness, rpn_box_regression = self.head(head_in)
         sel_obj, sel_reg = [objectness[0].detach()], [rpn_box_regression[0].detach()]
         if n_live > n_grad:
             with torch.no_grad():
@@ -139,9 +157,10 @@ class RPNModule(torch.nn.Module):
             sel_obj, sel_reg = [torch.cat([sel_obj[0], o[0]], dim=0)], [torch.cat([sel_reg[0], r[0]], dim=0)]
         anchors = self.anchor_generator(images, features)
         return self._finish_overlapped(anchors, head_in, objectness, rpn_box_regression, sel_obj, sel_reg, targets,
-                                       n_live)
+                                       n_live, hidden)
 
-    def _finish_overlapped(self, anchors, head_in, objectness, rpn_box_regression, sel_obj, sel_reg, targets, n_live):
+    def _finish_overlapped(self, anchors, head_in, objectness, rpn_box_regression, sel_obj, sel_reg, targets, n_live,
+                           hidden=None):
         # overlapped schedule: losses + the RPN branch's backward go to the compute stream first; proposal selection
         # (sort, decode, single-workgroup NMS sweeps, one host round trip) then runs on the side stream underneath
         # them, and the box head's sampling continues there (ROIBoxHead.forward)
@@ -149,7 +168,16 @@ class RPNModule(torch.nn.Module):
         prep = self._prepare_loss_targets(anchors, targets)
         main = torch.cuda.current_stream(dev)
         head_done = main.record_event()
-        loss_objectness, loss_rpn_box_reg = self.loss_evaluator.finish(objectness, rpn_box_regression, prep)
+        if hidden is not None and prep["sampled_inds"].numel() > 0:
+            h = self.head
+            loss_objectness, loss_rpn_box_reg = rpn_head_loss_rows(
+                head_in[0], h.conv.weight, h.conv.bias, h.cls_logits.weight, h.cls_logits.bias, h.bbox_pred.weight,
+                h.bbox_pred.bias, hidden, objectness[0], rpn_box_regression[0], prep["sampled_inds"],
+                prep["labels_sampled"], int(prep["pos_inds"].numel()), prep["regression_targets_pos"], 1.0 / 9)
+        else:
+            if hidden is not None:      # nothing sampled: the dense path's autograd graph does not exist — build it
+                objectness, rpn_box_regression = self.head(head_in)
+            loss_objectness, loss_rpn_box_reg = self.loss_evaluator.finish(objectness, rpn_box_regression, prep)
         torch.autograd.backward([loss_objectness + loss_rpn_box_reg])
         self._feature_grads = [f.grad for f in head_in]
         hook, self.after_early_backward = self.after_early_backward, None

@@ -226,6 +226,23 @@ int dadet_rpn_loss(const float* objectness, const float* box_regression, const i
                    const float* labels_sampled, int num_sampled, const int64_t* pos_inds,
                    const float* regression_targets_pos, int num_pos, float beta, float* losses_out,
                    float* grad_objectness, float* grad_box_regression, void* stream);
+/* The RPN losses in ROW form (losses.hip): the gradient of the head's maps is zero outside the num_sampled sampled anchors,
+ * so it is returned as num_sampled rows — row r = anchor sampled_inds[r] = pixel * A + a, holding d loss / d (objectness
+ * | box regression of that pixel) for anchor a in the columns [a] and [A + 4a .. A + 4a + 3] of a zero row of ldg >= 5A
+ * floats — with the row's pixel index n*H*W + h*W + w in pixels_out.  The positives are the first num_pos sampled rows
+ * (rpn/loss.py:116-118).  Same loss values as dadet_rpn_loss.  dadet_gather_pixel_taps builds the operand rows of a
+ * stride-1 KH x KW convolution's backward at those pixels (out [rows][KH*KW][C], zero outside the image; KH = KW = 1: a
+ * row gather); dadet_scatter_pixel_taps_add adds y [rows][KH*KW][C] to dx [N][H][W][C] at pixel + tap offset (the caller
+ * zero-fills dx; fp32 atomics).  With these the RPN head's backward (modeling/rpn/rpn.py:39-46 under autograd) runs on
+ * num_sampled rows instead of N*H*W. */
+int dadet_rpn_loss_rows(const float* objectness, const float* box_regression, const int64_t* sampled_inds,
+                        const float* labels_sampled, int num_sampled, int num_pos, const float* regression_targets_pos,
+                        int anchors_per_location, float beta, float* losses_out, float* grad_rows, int ldg,
+                        int* pixels_out, void* stream);
+int dadet_gather_pixel_taps(const float* x, const int* pixels, int num_rows, int N, int H, int W, int C, int KH, int KW,
+                            int pad, float* out, void* stream);
+int dadet_scatter_pixel_taps_add(const float* y, const int* pixels, int num_rows, int N, int H, int W, int C, int KH,
+                                 int KW, int pad, float* dx, void* stream);
 int dadet_fast_rcnn_loss(const float* class_logits, const float* box_regression, int num_classes, int reg_cols,
                          const int64_t* src_rows, const int64_t* labels_src, int num_src, const int64_t* rows_pos,
                          const int64_t* map_inds, const float* regression_targets_pos, int num_pos,

@@ -355,3 +355,27 @@ def test_wgrad_lane_is_a_schedule_not_a_result(device, monkeypatch):
     rep = tuner.report()
     assert rep["wgrad_lane_rows"] in WgradLaneTuner.CANDIDATES and set(rep["tuned_ms_per_step"]) == {"0", "17000"}
     monkeypatch.setattr(streams, "WGRAD_LANE_ROWS", 0)
+
+
+def test_rpn_backward_over_sampled_rows_equals_the_dense_one(device, monkeypatch):
+    """layers.misc._RPNHeadLossRows (the RPN head's backward on the <= 256 sampled anchors' rows: row-form loss gradient,
+    gathered operand rows, four small GEMMs, one scatter) against autograd's dense backward of the same head: identical
+    RPN loss values, every gradient at rounding level"""
+    from da_detect_amd.modeling.rpn import rpn as rpn_mod
+
+    seed, H, W = 41, 192, 320
+    monkeypatch.setattr(rpn_mod, "_ROW_BACKWARD", True)
+    _, _, rows, _ = _run_default_path("da_plain", H, W, device, seed, monkeypatch)
+    monkeypatch.setattr(rpn_mod, "_ROW_BACKWARD", False)
+    _, _, dense, _ = _run_default_path("da_plain", H, W, device, seed, monkeypatch)
+    for k in ("loss_objectness", "loss_rpn_box_reg"):
+        assert rows["losses"][k] == dense["losses"][k], (k, rows["losses"][k], dense["losses"][k])
+    for k, v in dense["losses"].items():
+        assert abs(rows["losses"][k] - v) <= 1e-6 * max(abs(v), 1.0), (k, rows["losses"][k], v)
+    head = {n: g for n, g in dense["grads"].items() if n.startswith("rpn.head.")}
+    assert len(head) == 6
+    for n, g in head.items():        # the six tensors the row form computes itself
+        err = float((rows["grads"][n].double() - g.double()).norm()) / float(g.double().norm())
+        assert err < 2e-5, (n, err)
+    worst, above = _check_gradients(rows["grads"], dense["grads"], rounding_tol=2e-5)
+    print("RPN backward over rows vs dense: worst relative L2 gradient difference %.2e; above 2e-5: %s" % (worst, above))
