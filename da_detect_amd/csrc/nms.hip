@@ -159,15 +159,20 @@ __global__ __launch_bounds__(1024) void nms_sweep_kernel(const unsigned long lon
   const int w = threadIdx.x;
   unsigned long long removed = 0;  // word w of the removed set (valid for w < col_blocks)
   if (threadIdx.x == 0) s_kept_total = 0;
+  // The chunk loop is a dependent chain, so the latency of one iteration is what counts.  The diagonal words do not
+  // depend on anything computed here: those of chunk c + 1 are fetched while chunk c is resolved (measured: no change —
+  // the kept rows' loads below are what an iteration waits for).
+  unsigned long long diag_next = 0;   // wave 0: this lane's diagonal word of the next chunk
+  if (threadIdx.x < 64 && (int)threadIdx.x < n) diag_next = mask[(size_t)threadIdx.x * col_blocks];
   __syncthreads();
   for (int c = 0; c < col_blocks; ++c) {
     if (w == c) s_removed_c = removed;
     __syncthreads();
     if (threadIdx.x < 64) {
       const int lane = threadIdx.x;
-      const int box = c * 64 + lane;
-      unsigned long long diag = 0;
-      if (box < n) diag = mask[(size_t)box * col_blocks + c];
+      const unsigned long long diag = diag_next;
+      const int nbox = (c + 1) * 64 + lane;
+      diag_next = (c + 1 < col_blocks && nbox < n) ? mask[(size_t)nbox * col_blocks + c + 1] : 0ULL;
       const unsigned lo = (unsigned)diag, hi = (unsigned)(diag >> 32);
       // the whole resolution is wavefront-uniform: keep it on the scalar unit (SGPR state, v_readlane of the
       // diagonal rows) and visit only the boxes that are still alive instead of all 64 positions
@@ -201,21 +206,26 @@ __global__ __launch_bounds__(1024) void nms_sweep_kernel(const unsigned long lon
     __syncthreads();
     const unsigned long long keep = s_keep;
     if (w > c && w < col_blocks) {
-      // the keep word is wavefront-uniform: peel eight kept rows per step so eight independent
-      // loads are in flight instead of one dependent round trip per kept box
+      // the keep word is wavefront-uniform: peel kPeel kept rows per step so that many independent loads are in
+      // flight instead of one dependent round trip per kept box (a chunk of a fresh region keeps most of its 64 boxes:
+      // with 8 per step that was 8 round trips in series per chunk; 32 make it 2)
+      constexpr int kPeel = 32;
       unsigned long long k = keep;
       const unsigned long long* mrow = mask + (size_t)c * 64 * col_blocks + w;
       while (k) {
-        int j[8];
+        int j[kPeel];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
+        for (int u = 0; u < kPeel; ++u) {
           j[u] = k ? (__ffsll((long long)k) - 1) : -1;
           k &= (k - 1);
         }
-        unsigned long long v[8];
+        unsigned long long v[kPeel];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) v[u] = (j[u] >= 0) ? mrow[(size_t)j[u] * col_blocks] : 0ULL;
-        removed |= ((v[0] | v[1]) | (v[2] | v[3])) | ((v[4] | v[5]) | (v[6] | v[7]));
+        for (int u = 0; u < kPeel; ++u) v[u] = (j[u] >= 0) ? mrow[(size_t)j[u] * col_blocks] : 0ULL;
+        unsigned long long acc = 0;
+#pragma unroll
+        for (int u = 0; u < kPeel; ++u) acc |= v[u];
+        removed |= acc;
       }
     }
     // early out once the quota is filled: later chunks keep nothing
