@@ -75,8 +75,13 @@ class WgradLaneTuner(object):
     def __init__(self, device, settle=2, measure=4):
         self.device = device
         self.settle, self.measure = settle, measure
+        # single process only: with several ranks the bucket collectives are issued from the lane stream while it is in
+        # use (parallel/reducer.py), a combination only ever exercised over gloo on one GPU — where 6 steps with the lane
+        # left the process 10x slower for good — and never over RCCL.  Multi-rank runs keep the one-stream schedule
+        # they were tested with unless DADET_WGRAD_LANE_ROWS is set by hand.
         self.active = (device.type == "cuda" and "DADET_WGRAD_LANE_ROWS" not in os.environ
-                       and not streams.WGRAD_OVERLAP and os.environ.get("DADET_TUNE_SCHEDULE", "1") == "1")
+                       and not streams.WGRAD_OVERLAP and os.environ.get("DADET_TUNE_SCHEDULE", "1") == "1"
+                       and get_world_size() == 1)
         self.times = {}
         self._cand = self._count = 0
         self._t0 = None
