@@ -15,7 +15,13 @@ This module is the MI355X-side equivalent, built around the fused optimizer inst
     latency, 25 MB by default like the reference's DDP);
   * parameters that receive no gradient in a step (e.g. the instance head when its loss weight is 0) are
     handled in `finalize()`: incomplete buckets are reduced there with their zero gradients, which is what
-    DDP's find_unused_parameters achieves with a graph walk.
+    DDP's find_unused_parameters achieves with a graph walk.  Collectives are issued in bucket order, so ONE
+    bucket that never completes would push every later bucket's all-reduce to the end of backward — and the first
+    bucket holds the DA heads, of which the image-level-only recipe never uses the instance head, and the triplet
+    recipes never use the plain DA module.  After the first step the ranks therefore agree (one small all-reduce of a
+    0/1 mask) on the parameters NO rank touched; from then on those are not waited for, their bucket goes out as soon
+    as the used ones have arrived, and the overlap with backward is back.  A parameter classified unused that later
+    does receive a gradient raises (the collective may already be on its way).
 World size 1 keeps the flat views and skips communication.
 """
 import torch
@@ -25,8 +31,9 @@ from ..utils import streams
 
 
 class BucketedGradReducer(object):
-    def __init__(self, params, bucket_bytes=25 * 1024 * 1024, process_group=None):
+    def __init__(self, params, bucket_bytes=25 * 1024 * 1024, process_group=None, learn_unused=True):
         self.params = [p for p in params if p.requires_grad]
+        self.learn_unused = learn_unused
         self.group = process_group
         self.world_size = dist.get_world_size(process_group) if dist.is_available() and dist.is_initialized() else 1
         self.buckets = []          # list of dict(flat=tensor, params=[...], pending=int, work=None)
@@ -36,6 +43,7 @@ class BucketedGradReducer(object):
         self._next = 0
         self._finalized = True
         self.touched = set()       # ids of the parameters that received a gradient since zero_grad()
+        self.static_unused = None  # ids of the parameters no rank touched in the first step (None: not learned yet)
 
     def _build(self, bucket_bytes):
         cur, cur_bytes = [], 0
@@ -64,9 +72,10 @@ class BucketedGradReducer(object):
 
     # -- per-step protocol: zero_grad() -> backward (hooks fire) -> finalize() -> optimizer.step() --------
     def zero_grad(self):
+        unused = self.static_unused or ()
         for b in self.buckets:
             b["flat"].zero_()
-            b["pending"] = len(b["params"])
+            b["pending"] = sum(1 for p in b["params"] if id(p) not in unused)
             b["work"] = None
         self._next = 0
         self._finalized = False
@@ -100,6 +109,11 @@ class BucketedGradReducer(object):
     def _on_grad(self, p):
         b = self._bucket_of[id(p)]
         self.touched.add(id(p))
+        if self.static_unused and id(p) in self.static_unused:
+            raise RuntimeError("BucketedGradReducer: a parameter of shape %s received a gradient after no rank had "
+                               "touched it in the first step; its bucket is no longer waiting for it.  Build the "
+                               "reducer with learn_unused=False for graphs that change between steps" %
+                               (tuple(p.shape),))
         b["pending"] -= 1
         if b["pending"] == 0 and not self._finalized:
             self._launch_ready()
@@ -117,6 +131,16 @@ class BucketedGradReducer(object):
                     b["work"].wait()
                 b["flat"].mul_(1.0 / self.world_size)
         self._finalized = True
+        if self.static_unused is None and self.learn_unused and self.world_size > 1:
+            self._learn_unused()
+
+    def _learn_unused(self):
+        """end of the first step: the parameters that NO rank touched (agreed on through one all-reduce of a mask)"""
+        dev = self.buckets[0]["flat"].device if self.buckets else torch.device("cpu")
+        mask = torch.tensor([0.0 if id(p) in self.touched else 1.0 for p in self.params], dtype=torch.float32, device=dev)
+        if self.world_size > 1 and mask.numel():
+            dist.all_reduce(mask, op=dist.ReduceOp.MIN, group=self.group)
+        self.static_unused = frozenset(id(p) for p, m in zip(self.params, mask.tolist()) if m > 0.5)
 
     def broadcast_parameters(self, src=0):
         """rank-0 parameters to every rank at start-up (what DDP's constructor does; buffers are not
