@@ -330,8 +330,24 @@ def conv_weight_transpose(w, scale=None):
     return wt
 
 
-def conv_wgrad(x, gy, weight_shape, stride=1, pad=0, out_scale=None, dw=None, accumulate=False):
-    """dw[co,ci,r,s] = out_scale[co] * sum_m gy[m,co] * x[gather(m,r,s),ci]  (channels_last weight layout)."""
+class WgradBatch(list):
+    """weight gradients whose reduction pass over the split partial results is still to come
+    (conv_wgrad(..., pending=batch) ... conv_wgrad_reduce_batch(batch)); keeps their workspaces alive until then"""
+
+
+def conv_wgrad_reduce_batch(batch):
+    """one launch for the reduction passes collected in `batch` (dadet_conv_wgrad_reduce_batch); same stream as the GEMMs"""
+    if not batch:
+        return
+    arr = (_lib.WgradPending * len(batch))(*[item[0] for item in batch])
+    _lib.call("dadet_conv_wgrad_reduce_batch", arr, len(batch), _stream())
+    del batch[:]
+
+
+def conv_wgrad(x, gy, weight_shape, stride=1, pad=0, out_scale=None, dw=None, accumulate=False, pending=None):
+    """dw[co,ci,r,s] = out_scale[co] * sum_m gy[m,co] * x[gather(m,r,s),ci]  (channels_last weight layout).
+    pending (a WgradBatch): the reduction over split partial results is left to conv_wgrad_reduce_batch(pending) — dw is
+    complete only after that call."""
     _dev(x, "x"), _dev(gy, "gy")
     N, Cin, H, W = x.shape
     Cout, Cin_w, KH, KW = weight_shape
@@ -345,6 +361,28 @@ def conv_wgrad(x, gy, weight_shape, stride=1, pad=0, out_scale=None, dw=None, ac
     d = _desc(N, H, W, Cin, Cout, KH, KW, stride, pad, Ho, Wo)
     nbytes = ctypes.c_size_t(0)
     _lib.call("dadet_conv_wgrad_workspace_bytes", ctypes.byref(d), ctypes.byref(nbytes))
+    if pending is not None:
+        # own workspace (the shared one is overwritten by the next weight gradient), alive until the batched pass
+        ws = torch.empty(max(nbytes.value, 16), dtype=torch.uint8, device=x.device)
+        item = _lib.WgradPending()
+
+        def launch():
+            _lib.call("dadet_conv_wgrad_partials", ctypes.byref(d), _p(x), _p(gy), _p(out_scale), _p(dw),
+                      1 if accumulate else 0, _p(ws), ctypes.c_size_t(ws.numel()), ctypes.byref(item), _stream())
+
+        if PROFILER is not None:
+            mode = get_gemm_mode()
+            kname = "conv_wgrad_kernel" if mode == 0 else "conv_wgrad_split_kernel<%d>" % mode
+            if getattr(PROFILER, "detail", False):
+                kname = "%s|M=%d N=%d K=%d k%dx%d s%d" % (kname, N * Ho * Wo, Cout, Cin * KH * KW, KH, KW, stride)
+            with PROFILER.span(kname, 2.0 * N * Ho * Wo * Cout * Cin * KH * KW,
+                               4.0 * (x.numel() + gy.numel() + dw.numel())):
+                launch()
+        else:
+            launch()
+        if item.splits > 1:
+            pending.append((item, ws, dw, out_scale))
+        return dw
     ws = _workspace(nbytes.value, x.device)
     if PROFILER is not None:
         mode = get_gemm_mode()

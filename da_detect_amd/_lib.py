@@ -21,6 +21,13 @@ class ConvDesc(ctypes.Structure):
         "out_spatial_stride", "relu_mode")]
 
 
+class WgradPending(ctypes.Structure):
+    """mirror of dadet_wgrad_pending (include/dadet.h)"""
+
+    _fields_ = [("partials", c_void_p), ("out_scale", c_void_p), ("dw", c_void_p), ("count", ctypes.c_longlong),
+                ("K", c_int), ("splits", c_int), ("accumulate", c_int)]
+
+
 class SgdEntry(ctypes.Structure):
     """mirror of dadet_sgd_entry (include/dadet.h)"""
 
@@ -52,6 +59,8 @@ _SIGNATURES = {
     "dadet_get_gemm_mode": [],
     "dadet_conv_wgrad_workspace_bytes": [POINTER(ConvDesc), POINTER(c_size_t)],
     "dadet_conv_wgrad": [POINTER(ConvDesc), _P, _P, _P, _P, c_int, _P, c_size_t, _P],
+    "dadet_conv_wgrad_partials": [POINTER(ConvDesc), _P, _P, _P, _P, c_int, _P, c_size_t, POINTER(WgradPending), _P],
+    "dadet_conv_wgrad_reduce_batch": [POINTER(WgradPending), c_int, _P],
     "dadet_conv_weight_transpose": [_P, _P, _P, c_int, c_int, c_int, c_int, _P],
     "dadet_deform_sample_forward": [_P, _P, _P, _P] + [c_int] * 12 + [_P],
     "dadet_deform_sample_backward": [_P, _P, _P, _P, _P, _P, _P] + [c_int] * 12 + [_P],

@@ -397,6 +397,49 @@ __global__ void wgrad_reduce_kernel(const float4* __restrict__ part, const float
   }
 }
 
+// The same reduction for up to kReduceBatch weight gradients in ONE launch (dadet_conv_wgrad_reduce_batch): a residual
+// block's backward produces 3 - 4 split weight gradients of 0.3 - 9 MB each; one reduction pass per tensor is a
+// 10 - 40 us launch that runs at ~1.5 TB/s because it is over before it fills the chip (45 launches, 1.2 ms per step).
+// Block b belongs to the item whose block range contains it; within an item the arithmetic is wgrad_reduce_kernel's.
+constexpr int kReduceBatch = 8;
+struct ReduceItem {
+  const float4* part;
+  const float* out_scale;
+  float4* dw;
+  long long total4;
+  int K4, splits, accumulate, first_block;
+};
+struct ReduceBatch {
+  ReduceItem item[kReduceBatch];
+  int n;
+};
+
+__global__ __launch_bounds__(256) void wgrad_reduce_batch_kernel(const ReduceBatch batch) {
+  int k = 0;
+#pragma unroll
+  for (int i = 1; i < kReduceBatch; ++i)
+    if (i < batch.n && (int)blockIdx.x >= batch.item[i].first_block) k = i;
+  const ReduceItem& it = batch.item[k];
+  const int nblocks = (k + 1 < batch.n ? batch.item[k + 1].first_block : (int)gridDim.x) - it.first_block;
+  for (int64_t i = (int64_t)((int)blockIdx.x - it.first_block) * 256 + threadIdx.x; i < it.total4;
+       i += (int64_t)nblocks * 256) {
+    float4 s = it.part[i];
+    for (int p = 1; p < it.splits; ++p) {
+      const float4 v = it.part[(int64_t)p * it.total4 + i];
+      s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+    }
+    if (it.out_scale) {
+      const float sc = it.out_scale[i / it.K4];
+      s.x *= sc; s.y *= sc; s.z *= sc; s.w *= sc;
+    }
+    if (it.accumulate) {
+      const float4 o = it.dw[i];
+      s.x += o.x; s.y += o.y; s.z += o.z; s.w += o.w;
+    }
+    it.dw[i] = s;
+  }
+}
+
 // wt[ci][KH-1-r][KW-1-s][co] = w[co][r][s][ci] * scale[co]
 // 32x32 LDS tile transpose between the co axis and the ci axis for one (r,s) tap.
 __global__ __launch_bounds__(256) void weight_transpose_kernel(const float* __restrict__ w,
@@ -766,9 +809,10 @@ extern "C" int dadet_conv_wgrad_workspace_bytes(const dadet_conv_desc* d, size_t
   return DADET_OK;
 }
 
-extern "C" int dadet_conv_wgrad(const dadet_conv_desc* d, const float* x, const float* gy,
-                                const float* out_scale, float* dw, int accumulate, void* workspace,
-                                size_t workspace_bytes, void* stream) {
+static int conv_wgrad_impl(const dadet_conv_desc* d, const float* x, const float* gy, const float* out_scale, float* dw,
+                           int accumulate, void* workspace, size_t workspace_bytes, dadet_wgrad_pending* pending,
+                           void* stream) {
+  if (pending) pending->splits = 0;
   int rc = conv_desc_check(d, "conv_wgrad");
   if (rc) return rc;
   DADET_REQUIRE(dw, "conv_wgrad: null dw");
@@ -840,6 +884,16 @@ extern "C" int dadet_conv_wgrad(const dadet_conv_desc* d, const float* x, const 
     rc = check_launch("conv_wgrad");
   }
   if (rc) return rc;
+  if (a.splits > 1 && !a.counters && pending) {      // the caller batches the reduction passes
+    pending->partials = static_cast<const float*>(workspace);
+    pending->out_scale = out_scale;
+    pending->dw = dw;
+    pending->count = (long long)d->Cout * K;
+    pending->K = K;
+    pending->splits = a.splits;
+    pending->accumulate = accumulate;
+    return DADET_OK;
+  }
   if (a.splits > 1 && !a.counters) {
     const int64_t total4 = (int64_t)d->Cout * K / 4;
     int64_t blocks = ceil_div64(total4, 256);
@@ -850,6 +904,52 @@ extern "C" int dadet_conv_wgrad(const dadet_conv_desc* d, const float* x, const 
     rc = check_launch("conv_wgrad(reduce)");
   }
   return rc;
+}
+
+extern "C" int dadet_conv_wgrad(const dadet_conv_desc* d, const float* x, const float* gy,
+                                const float* out_scale, float* dw, int accumulate, void* workspace,
+                                size_t workspace_bytes, void* stream) {
+  return conv_wgrad_impl(d, x, gy, out_scale, dw, accumulate, workspace, workspace_bytes, nullptr, stream);
+}
+
+extern "C" int dadet_conv_wgrad_partials(const dadet_conv_desc* d, const float* x, const float* gy,
+                                         const float* out_scale, float* dw, int accumulate, void* workspace,
+                                         size_t workspace_bytes, dadet_wgrad_pending* pending_out, void* stream) {
+  DADET_REQUIRE(pending_out, "conv_wgrad_partials: null pending_out");
+  return conv_wgrad_impl(d, x, gy, out_scale, dw, accumulate, workspace, workspace_bytes, pending_out, stream);
+}
+
+extern "C" int dadet_conv_wgrad_reduce_batch(const dadet_wgrad_pending* items, int n, void* stream) {
+  DADET_REQUIRE(n >= 0 && (n == 0 || items), "conv_wgrad_reduce_batch: bad arguments");
+  hipStream_t st = as_stream(stream);
+  for (int base = 0; base < n; base += kReduceBatch) {
+    ReduceBatch b;
+    b.n = 0;
+    int blocks_total = 0;
+    for (int i = base; i < n && b.n < kReduceBatch; ++i) {
+      const dadet_wgrad_pending& p = items[i];
+      if (p.splits <= 1) continue;       // nothing pending for this one (splits == 1 wrote dw itself)
+      DADET_REQUIRE(p.partials && p.dw && p.count > 0 && p.count % 4 == 0 && p.K > 0 && p.K % 4 == 0,
+                    "conv_wgrad_reduce_batch: item %d is malformed", i);
+      ReduceItem& it = b.item[b.n++];
+      it.part = reinterpret_cast<const float4*>(p.partials);
+      it.out_scale = p.out_scale;
+      it.dw = reinterpret_cast<float4*>(p.dw);
+      it.total4 = p.count / 4;
+      it.K4 = p.K / 4;
+      it.splits = p.splits;
+      it.accumulate = p.accumulate;
+      it.first_block = blocks_total;
+      int64_t blocks = ceil_div64(it.total4, 256);
+      if (blocks > kMaxStreamBlocks) blocks = kMaxStreamBlocks;
+      blocks_total += (int)blocks;
+    }
+    if (b.n == 0) continue;
+    hipLaunchKernelGGL(wgrad_reduce_batch_kernel, dim3(blocks_total), dim3(256), 0, st, b);
+    int rc = check_launch("conv_wgrad_reduce_batch");
+    if (rc) return rc;
+  }
+  return DADET_OK;
 }
 
 extern "C" int dadet_conv_weight_transpose(const float* w, const float* scale, float* wt, int Cout, int KH,

@@ -16,6 +16,7 @@ from torch import nn
 from ... import _C
 from ...layers import Conv2d, FrozenBatchNorm2d, conv2d_affine_act
 from ...utils.registry import Registry
+from ...utils import streams
 from ...utils.streams import WgradLane
 
 StageSpec = namedtuple("StageSpec", ["index", "block_count", "return_features"])
@@ -33,6 +34,10 @@ ResNet101StagesTo4 = _specs((1, 3, False), (2, 4, False), (3, 23, True))
 ResNet50FPNStagesTo5 = _specs((1, 3, True), (2, 4, True), (3, 6, True), (4, 3, True))
 ResNet101FPNStagesTo5 = _specs((1, 3, True), (2, 4, True), (3, 23, True), (4, 3, True))
 ResNet152FPNStagesTo5 = _specs((1, 3, True), (2, 8, True), (3, 36, True), (4, 3, True))
+
+
+# one reduction launch per block for its split weight gradients (dadet_conv_wgrad_reduce_batch); 0: one pass per tensor
+_WGRAD_BATCH = __import__("os").environ.get("DADET_WGRAD_BATCH", "1") == "1"
 
 
 class _BottleneckFn(torch.autograd.Function):
@@ -71,25 +76,27 @@ class _BottleneckFn(torch.autograd.Function):
             _C.relu_bn_backward(G, out, None)[1]
         dw1 = dw2 = dw3 = dwd = dx = None
         lane = WgradLane(G.device, defer=ctx.defer_wgrad, rows=G.shape[0] * G.shape[2] * G.shape[3])
+        # the block's 3 - 4 weight gradients share ONE reduction launch over their split partial results (_WGRAD_BATCH)
+        batch = _C.WgradBatch() if (_WGRAD_BATCH and not (ctx.defer_wgrad and streams._DEFER_ENABLED)) else None
+
+        def wgrad(w, xin, gout, st, pd, sc):
+            return lane.run_into(w, lambda acc: _C.conv_wgrad(xin, gout, tuple(w.shape), st, pd, out_scale=sc, dw=acc,
+                                                              accumulate=True, pending=batch),
+                                 lambda: _C.conv_wgrad(xin, gout, tuple(w.shape), st, pd, out_scale=sc, pending=batch),
+                                 xin, gout)
+
         if n3:
-            dw3 = lane.run_into(w3, lambda acc: _C.conv_wgrad(y2, S3, tuple(w3.shape), 1, 0, out_scale=s3, dw=acc,
-                                                              accumulate=True),
-                                lambda: _C.conv_wgrad(y2, S3, tuple(w3.shape), 1, 0, out_scale=s3), y2, S3)
+            dw3 = wgrad(w3, y2, S3, 1, 0, s3)
         S2 = _C.conv_forward(S3, _C.conv_weight_transpose(w3, s3), relu_mode=2, mask_ref=y2)
         if n2:
-            dw2 = lane.run_into(w2, lambda acc: _C.conv_wgrad(y1, S2, tuple(w2.shape), 1, 1, out_scale=s2, dw=acc,
-                                                              accumulate=True),
-                                lambda: _C.conv_wgrad(y1, S2, tuple(w2.shape), 1, 1, out_scale=s2), y1, S2)
+            dw2 = wgrad(w2, y1, S2, 1, 1, s2)
         if n1 or need_x:
             S1 = _C.conv_forward(S2, _C.conv_weight_transpose(w2, s2), pad=1, relu_mode=2, mask_ref=y1)
         if n1:
-            dw1 = lane.run_into(w1, lambda acc: _C.conv_wgrad(x, S1, tuple(w1.shape), stride, 0, out_scale=s1,
-                                                              dw=acc, accumulate=True),
-                                lambda: _C.conv_wgrad(x, S1, tuple(w1.shape), stride, 0, out_scale=s1), x, S1)
+            dw1 = wgrad(w1, x, S1, stride, 0, s1)
         if nd and wd is not None:
-            dwd = lane.run_into(wd, lambda acc: _C.conv_wgrad(x, S3, tuple(wd.shape), stride, 0, out_scale=sd,
-                                                              dw=acc, accumulate=True),
-                                lambda: _C.conv_wgrad(x, S3, tuple(wd.shape), stride, 0, out_scale=sd), x, S3)
+            dwd = wgrad(wd, x, S3, stride, 0, sd)
+        lane.reduce_batch(batch)
         if need_x:
             gate = dict(relu_mode=2, mask_ref=x) if ctx.in_relu else {}
             hw = tuple(x.shape[2:])

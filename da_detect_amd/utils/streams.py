@@ -135,6 +135,19 @@ class WgradLane(object):
             t.record_stream(self.lane)
         return None
 
+    def reduce_batch(self, batch):
+        """the batched reduction pass of the weight gradients queued through this lane object (same stream as their
+        GEMMs: the lane when it is on, else the current stream)"""
+        if not batch:
+            return
+        from .. import _C
+
+        if self.on:
+            with torch.cuda.stream(self.lane):
+                _C.conv_wgrad_reduce_batch(batch)
+        else:
+            _C.conv_wgrad_reduce_batch(batch)
+
     def join(self):
         if self.on and self.out:
             record(self.out, self.main)

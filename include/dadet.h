@@ -163,6 +163,22 @@ int dadet_conv_forward_variant(const dadet_conv_desc* d);
 int dadet_conv_wgrad_workspace_bytes(const dadet_conv_desc* d, size_t* bytes_out);
 int dadet_conv_wgrad(const dadet_conv_desc* d, const float* x, const float* gy, const float* out_scale,
                      float* dw, int accumulate, void* workspace, size_t workspace_bytes, void* stream);
+/* The same with the reduction over the split partial results left to the caller: when the plan splits the reduction,
+ * *pending_out describes the missing pass (splits > 1) and `workspace` must stay untouched until
+ * dadet_conv_wgrad_reduce_batch has run on the same stream; otherwise pending_out->splits == 0 and dw is complete.
+ * dadet_conv_wgrad_reduce_batch performs up to 8 such passes per launch — one launch for the 3 - 4 weight gradients of a
+ * residual block instead of one 10 - 40 us launch each — with dadet_conv_wgrad's arithmetic (identical bits). */
+typedef struct dadet_wgrad_pending {
+  const float* partials;   /* [splits][Cout][K] */
+  const float* out_scale;  /* [Cout] or NULL */
+  float* dw;               /* [Cout][K] */
+  long long count;         /* Cout * K */
+  int K, splits, accumulate;
+} dadet_wgrad_pending;
+int dadet_conv_wgrad_partials(const dadet_conv_desc* d, const float* x, const float* gy, const float* out_scale,
+                              float* dw, int accumulate, void* workspace, size_t workspace_bytes,
+                              dadet_wgrad_pending* pending_out, void* stream);
+int dadet_conv_wgrad_reduce_batch(const dadet_wgrad_pending* items, int n, void* stream);
 
 /* weight re-layout for the data gradient: wt[ci][KH-1-r][KW-1-s][co] = w[co][r][s][ci] * scale[co].
  * dgrad of a stride-1 conv is then dadet_conv_forward(gy, wt) with pad' = K-1-pad. */

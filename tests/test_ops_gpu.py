@@ -1023,3 +1023,31 @@ def test_res5_head_on_the_sub_grid_is_the_same_head(device, monkeypatch):
     torch.testing.assert_close(out[True][1], out[False][1], rtol=1e-5, atol=1e-6)
     for n, gfull in out[False][2].items():
         torch.testing.assert_close(out[True][2][n], gfull, rtol=1e-4, atol=1e-6, msg=lambda m, n=n: "%s: %s" % (n, m))
+
+
+def test_batched_wgrad_reduction_is_bit_identical(device):
+    """dadet_conv_wgrad_partials + ONE dadet_conv_wgrad_reduce_batch for several weight gradients against
+    dadet_conv_wgrad's own reduction pass per tensor: identical bits, with / without FrozenBN scale and accumulation"""
+    from da_detect_amd import _C
+
+    g = torch.Generator().manual_seed(9)
+    shapes = [(2, 256, 40, 64, 256, 3, 1, 1), (2, 256, 40, 64, 1024, 1, 1, 0), (2, 1024, 40, 64, 256, 1, 1, 0),
+              (2, 512, 80, 128, 256, 1, 2, 0), (64, 512, 7, 7, 512, 3, 1, 1)]
+    batch = _C.WgradBatch()
+    want, got = [], []
+    for i, (N, Cin, H, W, Cout, k, stride, pad) in enumerate(shapes):
+        x = torch.randn((N, Cin, H, W), generator=g).to(device).contiguous(memory_format=CL)
+        Ho, Wo = (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
+        gy = torch.randn((N, Cout, Ho, Wo), generator=g).to(device).contiguous(memory_format=CL)
+        scale = (torch.rand(Cout, generator=g) + 0.5).to(device) if i % 2 == 0 else None
+        base = torch.randn((Cout, Cin, k, k), generator=g).to(device).contiguous(memory_format=CL)
+        acc = i % 3 == 0
+        want.append(_C.conv_wgrad(x, gy, (Cout, Cin, k, k), stride, pad, out_scale=scale,
+                                  dw=base.clone(memory_format=torch.preserve_format), accumulate=acc))
+        got.append(_C.conv_wgrad(x, gy, (Cout, Cin, k, k), stride, pad, out_scale=scale,
+                                 dw=base.clone(memory_format=torch.preserve_format), accumulate=acc, pending=batch))
+    assert len(batch) >= 3, "the plan split fewer reductions than this test means to batch: %d" % len(batch)
+    _C.conv_wgrad_reduce_batch(batch)
+    assert len(batch) == 0
+    for a, b in zip(want, got):
+        assert torch.equal(a, b)
