@@ -210,7 +210,7 @@ def _roi_workspace(B, H, W, R, device):
 
 
 def roi_align_backward(grad, rois, spatial_scale, pooled_height, pooled_width, batch_size, channels,
-                       height, width, sampling_ratio, atomic=False, bin_stride=1):
+                       height, width, sampling_ratio, atomic=False, bin_stride=1, live_images=None):
     """_C.roi_align_backward -> [B,C,H,W] (ROIAlign.h:27-45).  bin_stride s > 1: `grad` is the compact gradient of the
     bins (i * s, j * s) (roi_align_forward with the same bin_stride)."""
     _dev(grad, "grad"), _dev(rois, "rois")
@@ -218,13 +218,20 @@ def roi_align_backward(grad, rois, spatial_scale, pooled_height, pooled_width, b
     rois = rois.contiguous()
     gin = torch.empty((batch_size, channels, height, width), dtype=torch.float32, device=grad.device,
                       memory_format=CL)
+    # live_images: only the leading images are referenced by any ROI (the caller knows: it built the batch indices); the
+    # gather kernel then sweeps those images' pixel tiles only and the others' gradient is a plain zero fill
+    B = batch_size
+    if live_images is not None and 0 < live_images < batch_size and not atomic and rois.shape[0] > 0:
+        B = int(live_images)
+        gin[B:].zero_()
     if bin_stride != 1:
         if atomic:
             raise ValueError("roi_align_backward: bin_stride needs the gather form")
-        _lib.call("dadet_roi_align_backward_sub", _p(g), _p(rois), _p(gin), batch_size, channels, height, width,
+        _lib.call("dadet_roi_align_backward_sub", _p(g), _p(rois), _p(gin), B, channels, height, width,
                   rois.shape[0], pooled_height, pooled_width, float(spatial_scale), int(sampling_ratio),
                   int(bin_stride), _stream())
         return gin
+    batch_size = B
     if atomic:
         gin.zero_()
     _lib.call("dadet_roi_align_backward_atomic" if atomic else "dadet_roi_align_backward", _p(g), _p(rois),

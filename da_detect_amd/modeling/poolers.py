@@ -39,7 +39,8 @@ class Pooler(nn.Module):
     def forward(self, x, boxes, bin_stride=1):
         rois = self.convert_to_roi_format(boxes)
         if len(self.poolers) == 1:
-            return self.poolers[0](x[0], rois, bin_stride)
+            # the batch index of a ROI is its BoxList's position: images behind the last BoxList have no ROI
+            return self.poolers[0](x[0], rois, bin_stride, live_images=len(boxes))
         if bin_stride != 1:
             raise NotImplementedError("bin_stride over several pyramid levels")
         levels = self.map_levels(boxes)

@@ -1051,3 +1051,20 @@ def test_batched_wgrad_reduction_is_bit_identical(device):
     assert len(batch) == 0
     for a, b in zip(want, got):
         assert torch.equal(a, b)
+
+
+def test_roi_align_backward_skips_images_without_rois(device):
+    """live_images: the gather backward sweeps the leading images only and zero-fills the rest — same result as the full
+    sweep when no ROI points at the other images"""
+    from da_detect_amd import _C
+
+    g = torch.Generator().manual_seed(123)
+    B, C, H, W, R = 3, 128, 30, 44, 90
+    xy = torch.rand((R, 2), generator=g) * torch.tensor([W * 16.0 - 60, H * 16.0 - 60])
+    rois = torch.cat([torch.zeros((R, 1)), xy, xy + torch.rand((R, 2), generator=g) * 300 + 6], dim=1).to(device)
+    go = torch.randn((R, C, 7, 7), generator=g).to(device).contiguous(memory_format=torch.channels_last)
+    for stride in (1, 2):
+        gg = go if stride == 2 else torch.randn((R, C, 14, 14), generator=g).to(device).contiguous(memory_format=CL)
+        full = _C.roi_align_backward(gg, rois, 1 / 16, 14, 14, B, C, H, W, 0, bin_stride=stride)
+        lean = _C.roi_align_backward(gg, rois, 1 / 16, 14, 14, B, C, H, W, 0, bin_stride=stride, live_images=1)
+        assert torch.equal(full, lean) and float(full[1:].abs().max()) == 0.0
