@@ -391,35 +391,52 @@ __global__ void focal_bwd_kernel(const float* __restrict__ logits, const int* __
 
 // ---- fused multi-tensor SGD -------------------------------------------------------------------
 // reference: torch.optim.SGD.step over solver/build.py:7-20's one-group-per-tensor list.
-// grid.y = tensor, grid.x strides over that tensor's elements.
-__global__ void sgd_kernel(const dadet_sgd_entry* __restrict__ table, float momentum, int first_step,
-                           float grad_scale) {
+// grid.y = tensor, grid.x strides over that tensor's elements in units of 1024 float4 per workgroup (4 per lane, their
+// 12 loads issued before the first store).  grid.x is sized for the LARGEST tensor (up to 512): the workgroups a smaller
+// tensor does not need leave at once.  (It was capped at 64 per tensor: the RPN conv's 9.4 M weights — 190 MB of the
+// step's 730 — were then walked by 64 workgroups, an eighth of the chip's slots, one float4 per lane in flight.)
+__global__ __launch_bounds__(256) void sgd_kernel(const dadet_sgd_entry* __restrict__ table, float momentum, int first_step,
+                                                  float grad_scale) {
   const dadet_sgd_entry e = table[blockIdx.y];
   const int64_t n = e.numel;
-  const float lr = e.lr, wd = e.weight_decay;
   const bool vec = ((reinterpret_cast<uintptr_t>(e.p) | reinterpret_cast<uintptr_t>(e.g) |
                      reinterpret_cast<uintptr_t>(e.buf)) & 15) == 0;
   const int64_t n4 = vec ? n / 4 : 0;
+  if ((int64_t)blockIdx.x * 1024 >= n4 && ((int64_t)blockIdx.x * 256 >= n - n4 * 4)) return;
+  const float lr = e.lr, wd = e.weight_decay;
   float4* p4 = reinterpret_cast<float4*>(e.p);
   const float4* g4 = reinterpret_cast<const float4*>(e.g);
   float4* b4 = reinterpret_cast<float4*>(e.buf);
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4;
-       i += (int64_t)gridDim.x * blockDim.x) {
-    float4 p = p4[i];
-    const float4 g = g4[i];
-    float4 d, b;
-    d.x = g.x * grad_scale + wd * p.x; d.y = g.y * grad_scale + wd * p.y;
-    d.z = g.z * grad_scale + wd * p.z; d.w = g.w * grad_scale + wd * p.w;
-    if (first_step) {
-      b = d;
-    } else {
-      b = b4[i];
-      b.x = momentum * b.x + d.x; b.y = momentum * b.y + d.y;
-      b.z = momentum * b.z + d.z; b.w = momentum * b.w + d.w;
+  for (int64_t base = (int64_t)blockIdx.x * 1024; base < n4; base += (int64_t)gridDim.x * 1024) {
+    float4 p[4], g[4], b[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int64_t i = base + u * 256 + threadIdx.x;
+      if (i < n4) {
+        p[u] = p4[i];
+        g[u] = g4[i];
+        if (!first_step) b[u] = b4[i];
+      }
     }
-    b4[i] = b;
-    p.x -= lr * b.x; p.y -= lr * b.y; p.z -= lr * b.z; p.w -= lr * b.w;
-    p4[i] = p;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int64_t i = base + u * 256 + threadIdx.x;
+      if (i >= n4) continue;
+      float4 d;
+      d.x = g[u].x * grad_scale + wd * p[u].x; d.y = g[u].y * grad_scale + wd * p[u].y;
+      d.z = g[u].z * grad_scale + wd * p[u].z; d.w = g[u].w * grad_scale + wd * p[u].w;
+      float4 nb;
+      if (first_step) {
+        nb = d;
+      } else {
+        nb.x = momentum * b[u].x + d.x; nb.y = momentum * b[u].y + d.y;
+        nb.z = momentum * b[u].z + d.z; nb.w = momentum * b[u].w + d.w;
+      }
+      b4[i] = nb;
+      float4 q = p[u];
+      q.x -= lr * nb.x; q.y -= lr * nb.y; q.z -= lr * nb.z; q.w -= lr * nb.w;
+      p4[i] = q;
+    }
   }
   for (int64_t i = n4 * 4 + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
        i += (int64_t)gridDim.x * blockDim.x) {
@@ -622,8 +639,9 @@ extern "C" int dadet_sgd_step(const dadet_sgd_entry* table_dev, int num_tensors,
   if (num_tensors == 0 || max_numel == 0) return DADET_OK;
   DADET_REQUIRE(table_dev, "sgd_step: null table");
   DADET_REQUIRE(num_tensors <= 65535, "sgd_step: too many tensors for one launch");
-  int bx = (int)ceil_div64(ceil_div64(max_numel, 4), 256);
-  if (bx > 64) bx = 64;  // <= 64 x num_tensors workgroups, grid-stride inside
+  int bx = (int)ceil_div64(ceil_div64(max_numel, 4), 1024);
+  if (bx > 512) bx = 512;  // sized for the largest tensor; smaller tensors' surplus workgroups exit at once
+  if (bx < 1) bx = 1;
   hipLaunchKernelGGL(sgd_kernel, dim3(bx, num_tensors), dim3(256), 0, as_stream(stream), table_dev,
                      momentum, first_step, grad_scale);
   return check_launch("sgd_step");
