@@ -549,12 +549,12 @@ def box_head_pass(feat, proposals, gts, sd, cfg, with_losses=True, draws=None):
 
 
 def training_losses(sd, cfg, images, gts, state=None, intermediates=None, selection_maps=None, draws=None,
-                    grad_probe=False):
+                    grad_probe=False, selection_proposals=None):
     """GeneralizedRCNN.forward in training mode (modeling/detector/generalized_rcnn.py:61-153).
     images [N,3,H,W] (already padded), gts: list of dict(boxes [G,4], labels [G], is_source [G] bool).
     selection_maps=(objectness, deltas): tests may feed the proposal SELECTION fixed RPN maps (e.g. the golden
     reference ones) so index-valued results do not depend on this machine's fp32 GEMM rounding; maps of fewer than N
-    images cover the leading ones."""
+    images cover the leading ones.  selection_proposals: the proposal lists themselves (see below)."""
     N, _, H, W = images.shape
     image_sizes = [(H, W)] * N
     feat = backbone_c4(images, sd)
@@ -571,6 +571,14 @@ def training_losses(sd, cfg, images, gts, state=None, intermediates=None, select
             sel_obj = torch.cat([sel_obj.to(objectness.dtype), objectness[k:].detach()], dim=0)
             sel_del = torch.cat([sel_del.to(deltas.dtype), deltas[k:].detach()], dim=0)
         proposals = rpn_proposals(sel_obj, sel_del, anchors, image_sizes, gts, cfg, True)
+        if selection_proposals is not None:
+            # proposal lists handed in (boxes [P,4], objectness [P]) per image, None = keep this restatement's own.  The
+            # ranking behind them sorts SIGMOID scores: thousands of anchors share a saturated fp32 value and are ordered
+            # by index, and which logits collapse onto one value differs by an ulp between two sigmoid implementations
+            # (and entirely between float32 and float64) — two devices then agree on the proposal SET but may swap
+            # neighbours, and an index into the list means another box ("near-tied scores")
+            proposals = [p if q is None else (q[0].to(p[0].dtype), q[1].to(p[1].dtype))
+                         for p, q in zip(proposals, list(selection_proposals) + [None] * (N - len(selection_proposals)))]
     obj_loss, rpn_box_loss = rpn_losses(objectness, deltas, anchors, image_sizes, gts, cfg, draws, intermediates)
     img_labels = torch.tensor([1.0 if g["is_source"].any() else 0.0 for g in gts])
     losses = {}

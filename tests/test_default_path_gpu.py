@@ -77,6 +77,18 @@ def _run_default_path(case, H, W, device, seed, monkeypatch, overrides=(), steps
     monkeypatch.setattr(rng, "dropout_mask", dropout_mask)
     monkeypatch.setattr(_C, "sample_anchors", sample_anchors)
     monkeypatch.setattr(_C, "sample_rois", sample_rois)
+    # the proposal lists the RPN hands to the box head (None for images nothing reads): the oracle samples from THESE —
+    # its own selection on the same maps yields the same set, but sigmoid-tied neighbours may come out swapped
+    # (oracle/model_ref.py training_losses) and an equal sampled index would then name another box
+    sel = model.rpn.box_selector_train
+    orig_sel = sel.forward
+
+    def sel_forward(*a, **k):
+        boxes = orig_sel(*a, **k)
+        rec["proposals"] = [(b.bbox.detach().cpu(), b.get_field("objectness").detach().cpu()) for b in boxes]
+        return boxes
+
+    monkeypatch.setattr(sel, "forward", sel_forward)
     maps = []      # the RPN head runs once per image group (with / without autograd); groups are in batch order
     model.rpn.head.register_forward_hook(lambda m, i, o: maps.append((o[0][0].detach(), o[1][0].detach())))
 
@@ -87,14 +99,16 @@ def _run_default_path(case, H, W, device, seed, monkeypatch, overrides=(), steps
     history = []
     for it in range(steps):
         if it:
-            history.append({k: rec[k] for k in ("seeds", "masks", "anchors", "rois", "objectness", "deltas", "losses")})
+            history.append({k: rec[k] for k in ("seeds", "masks", "anchors", "rois", "objectness", "deltas", "losses",
+                                                "proposals")})
             rec.update(seeds=[], masks=[], anchors=[], rois=[])
         losses = train_step(model, opt, images, targets)
         torch.cuda.synchronize()
         collect_maps()
         rec["losses"] = {k: float(v.detach()) for k, v in losses.items()}
     if steps > 1:
-        history.append({k: rec[k] for k in ("seeds", "masks", "anchors", "rois", "objectness", "deltas", "losses")})
+        history.append({k: rec[k] for k in ("seeds", "masks", "anchors", "rois", "objectness", "deltas", "losses",
+                                            "proposals")})
         rec["history"] = history
         rec["momentum"] = {n: opt.state[p]["momentum_buffer"].detach().cpu().clone()
                            for n, p in model.named_parameters() if p.requires_grad and p in opt.state}
@@ -118,7 +132,8 @@ def _oracle(c, sd, rec, nimg, H, W, seed, dtype=torch.float32):
     inter = {}
     olosses = model_ref.training_losses(osd, c, cpu_images.tensors.to(dtype), model_ref.targets_to_dicts(cpu_targets),
                                         intermediates=inter, draws=draws,
-                                        selection_maps=(rec["objectness"].cpu(), rec["deltas"].cpu()))
+                                        selection_maps=(rec["objectness"].cpu(), rec["deltas"].cpu()),
+                                        selection_proposals=rec["proposals"])
     assert draws.exhausted(), "the oracle consumed %d/%d seeds and %d/%d dropout masks" % (
         draws.taken_seeds, len(draws.seeds), draws.taken_masks, len(draws.masks))
     return osd, olosses, inter
@@ -174,6 +189,7 @@ def _check_losses(rec, olosses, tol=1e-4):
     ("da_plain", ()),                                       # image + instance + consistency (BASELINE configs[2])
     ("da_img_only", ()),                                    # the bench workload's recipe (configs[1]): early DA backward
     ("da_triplet", ()),                                     # AdvGRL + image triplet (configs[3])
+    ("da_triplet_aligned", ()),                             # + 3 aligned box-head passes on the target's proposals
 ])
 def test_default_path_matches_oracle_small(device, monkeypatch, case, overrides):
     seed, H, W = 11, 192, 320
@@ -181,9 +197,11 @@ def test_default_path_matches_oracle_small(device, monkeypatch, case, overrides)
     assert rec["early_rpn"] and rec["loss_prep_rows"], "not the default schedule"
     # img_only: the target image is neither sampled nor run through the RPN head (nothing reads its proposals); its
     # sampler seed is still drawn.  Triplet batches: no RPN head pass for the auxiliary image.
-    read = {"da_plain": 2, "da_img_only": 1, "da_triplet": 2}[case]
-    assert rec["objectness"].shape[0] == read, rec["objectness"].shape
-    assert len(rec["anchors"]) == 1 and len(rec["rois"]) == read and len(rec["seeds"]) == 3, (
+    read = {"da_plain": 2, "da_img_only": 1, "da_triplet": 2, "da_triplet_aligned": 2}[case]
+    assert rec["objectness"].shape[0] == read and len(rec["proposals"]) == read, rec["objectness"].shape
+    # aligned: three more box-head calls on one image each, each with its own ROI sample (and seed)
+    extra = 3 if case == "da_triplet_aligned" else 0
+    assert len(rec["anchors"]) == 1 and len(rec["rois"]) == read + extra and len(rec["seeds"]) == 3 + extra, (
         len(rec["anchors"]), len(rec["rois"]), len(rec["seeds"]))
     # da_img_only: no loss reads the instance-level features, so the product leaves the target-domain ROIs out of the
     # box head and does not evaluate the instance head (ROIBoxHead.forward).  The oracle does what the reference does —
@@ -293,7 +311,8 @@ def test_three_step_trajectory_matches_oracle(device, monkeypatch):
     for it, h in enumerate(rec["history"]):
         draws = model_ref.DeviceDraws(h["seeds"], h["masks"])
         olosses = model_ref.training_losses(osd, c, cpu_images.tensors, gts, state=state, draws=draws,
-                                            selection_maps=(h["objectness"].cpu(), h["deltas"].cpu()))
+                                            selection_maps=(h["objectness"].cpu(), h["deltas"].cpu()),
+                                            selection_proposals=h["proposals"])
         assert draws.exhausted()
         for k, v in olosses.items():
             v = float(v.detach())
