@@ -250,3 +250,65 @@ def test_weight_gradient_split_plan_respects_the_workgroup_slots():
     assert splits(512, 7, 7, 512, 512, 3, 1)[0] == 7           # 144 tiles -> 1008 workgroups
     assert splits(512, 7, 7, 512, 2048, 1, 1)[0] == 8          # 64 tiles  -> 512 workgroups
     assert splits(2, 64, 128, 256, 1024, 1, 1)[0] == 32        # 16 tiles  -> 512 workgroups
+
+
+def test_unread_work_rules():
+    """modeling/elision.py + GeneralizedRCNN._images_with_read_proposals: which images' RPN proposals some loss reads
+    (source images always; a target image only through instance-level features or aligned passes; a triplet batch's
+    auxiliary image never) — host logic, no kernels"""
+    from da_detect_amd.config import cfg as base
+    from da_detect_amd.modeling import elision
+    from da_detect_amd.modeling.detector import build_detection_model
+    from da_detect_amd.structures.bounding_box import BoxList
+
+    def tgt(source):
+        b = BoxList(torch.tensor([[1.0, 2.0, 30.0, 40.0]]), (64, 64), "xyxy")
+        b.add_field("labels", torch.tensor([1]))
+        b.add_field("is_source", torch.tensor([source]))
+        return b
+
+    assert elision.leading_source_images([tgt(True), tgt(False)]) == 1
+    assert elision.leading_source_images([tgt(True), tgt(True), tgt(False)]) == 2
+    assert elision.leading_source_images([tgt(False), tgt(True)]) == 0          # not a prefix: no rule applies
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+    def model_for(yaml, *overrides):
+        c = base.clone()
+        c.merge_from_file(os.path.join(root, "configs/da_faster_rcnn", yaml))
+        c.merge_from_list(list(overrides))
+        return build_detection_model(c)
+
+    pair, triple = [tgt(True), tgt(False)], [tgt(True), tgt(False), tgt(False)]
+    m = model_for("e2e_da_faster_rcnn_R_50_C4_img_only.yaml")
+    assert not m.da_heads.needs_instance_features and m._images_with_read_proposals(pair) == 1
+    m = model_for("e2e_da_faster_rcnn_R_50_C4_cityscapes_to_foggy_cityscapes.yaml")
+    assert m.da_heads.needs_instance_features and m._images_with_read_proposals(pair) == 2
+    tri = [f for f in os.listdir(os.path.join(root, "configs/da_faster_rcnn")) if "triplet" in f][0]
+    m = model_for(tri, "MODEL.DA_HEADS.ALIGNMENT", False)
+    need = m.da_heads_triplet.needs_instance_features
+    assert m._images_with_read_proposals(triple) == (2 if need else 1)
+    m = model_for(tri, "MODEL.DA_HEADS.ALIGNMENT", True)
+    assert m._images_with_read_proposals(triple) == 2                          # aligned passes pool the target's proposals
+    assert m._images_with_read_proposals(pair) is None                         # not a triplet batch: no rule
+
+
+def test_lane_tuner_keeps_one_stream_unless_clearly_faster(monkeypatch):
+    """engine.trainer.WgradLaneTuner's decision rule (the timing itself needs a GPU: tests/test_default_path_gpu.py)"""
+    from da_detect_amd.engine.trainer import WgradLaneTuner
+    from da_detect_amd.utils import streams
+
+    monkeypatch.setattr(streams, "WGRAD_LANE_ROWS", 0)
+    t = WgradLaneTuner(torch.device("cpu"))
+    assert not t.active                                                         # CPU: nothing to tune
+    for times, want in (({0: 20.0, 17000: 19.7}, 0), ({0: 20.0, 17000: 19.3}, 17000), ({0: 20.0, 17000: 21.0}, 0)):
+        t = WgradLaneTuner(torch.device("cpu"))
+        t.active, t.times = True, {}
+        t._cand, t._count = len(t.CANDIDATES) - 1, t.settle + t.measure - 1
+        t.times = {k: v for k, v in times.items() if k != t.CANDIDATES[-1]}
+        monkeypatch.setattr(torch.cuda, "synchronize", lambda *a, **k: None)
+        monkeypatch.setattr(streams, "join_wgrad_lane", lambda *a, **k: None)
+        import time as _time
+        t._t0 = _time.perf_counter() - times[t.CANDIDATES[-1]] * t.measure
+        t.step_end()
+        assert not t.active and streams.WGRAD_LANE_ROWS == want, (times, streams.WGRAD_LANE_ROWS)
+    monkeypatch.setattr(streams, "WGRAD_LANE_ROWS", 0)

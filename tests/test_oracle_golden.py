@@ -210,3 +210,46 @@ def test_device_draw_restatement_follows_the_sampler_rule():
     few = torch.tensor([1, 0, -1, 0, 1, 0])                                       # fewer candidates than the quota
     pm, nm = model_ref.sample_pos_neg_device(few, 256, 0.25, 7)
     assert pm.tolist() == [True, False, False, False, True, False] and nm.tolist() == [False, True, False, True, False, True]
+
+
+def test_model_ref_accepts_proposal_lists():
+    """training_losses(selection_proposals=...): the proposal lists handed in replace the restatement's own selection (what
+    tests/test_default_path_gpu.py uses to compare the GPU path on IDENTICAL lists: sigmoid-tied neighbours may swap
+    between devices).  Own lists handed back in -> same losses; two neighbours swapped -> still the same SET, another
+    order, and the sampled boxes follow the list."""
+    from da_detect_amd.data.synthetic import make_batch
+    from da_detect_amd.modeling.detector import build_detection_model
+    from golden.cases import case_cfg
+    from golden.fill import fill_state_dict
+    from oracle import model_ref
+
+    case = "da_plain"
+    z = np.load(os.path.join(GOLD, case + ".npz"))
+    c = case_cfg(case)
+    seed, H, W, nimg = int(z["seed"]), int(z["H"]), int(z["W"]), int(z["nimg"])
+    sd = fill_state_dict(build_detection_model(c).state_dict(), seed)
+    images, targets = make_batch(c, nimg, H, W, seed=seed, device=torch.device("cpu"))
+    gts = model_ref.targets_to_dicts(targets)
+    maps = (torch.from_numpy(z["objectness"]), torch.from_numpy(z["deltas"]))
+
+    def run(props):
+        inter = {}
+        torch.manual_seed(seed)
+        with torch.no_grad():
+            losses = model_ref.training_losses(sd, c, images.tensors, gts, state={}, intermediates=inter,
+                                               selection_maps=maps, selection_proposals=props)
+        return {k: float(v) for k, v in losses.items()}, inter
+
+    base, inter = run(None)
+    own = [(b.clone(), s.clone()) for b, s in inter["proposals"]]
+    again, _ = run(own)
+    assert again == base
+    only_first, _ = run(own[:1])                       # a shorter list covers the leading images
+    assert only_first == base
+    swapped = [(b.clone(), s.clone()) for b, s in own]
+    b1, s1 = swapped[1]
+    b1[[3, 4]] = b1[[4, 3]]
+    s1[[3, 4]] = s1[[4, 3]]
+    other, inter2 = run(swapped)
+    assert torch.equal(inter2["proposals"][1][0][3], own[1][0][4]) and torch.equal(inter2["proposals"][0][0], own[0][0])
+    assert set(other) == set(base)
