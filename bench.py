@@ -3,9 +3,13 @@
 
 Workload (BASELINE.json configs[1]): configs/da_faster_rcnn/e2e_da_faster_rcnn_R_50_C4_img_only.yaml — image-level
 DA head only, 1 source + 1 target image of 1024 x 2048 per GPU per step (SOLVER.IMS_PER_BATCH = 2 * n_gpus),
-256 ROIs per image and per box-head pass, SGD(momentum) step included.  One "step" = forward + backward
-(+ bucketed gradient all-reduce when n_gpus > 1) + fused SGD over one such batch; inputs are resident in HBM
-before the timed region.  Weak scaling: every rank processes its own (source, target) pair.
+256 ROIs sampled per image, SGD(momentum) step included.  One "step" = forward + backward (+ bucketed gradient
+all-reduce when n_gpus > 1) + fused SGD over one such batch; inputs are resident in HBM before the timed region.
+Weak scaling: every rank processes its own (source, target) pair.
+Work the recipe never reads is not evaluated (DESIGN.md section 4 "Unread work"; the line's `elided` list says what,
+`flop_per_step` says how many algorithmic FLOPs a step executes, `step_frac` = flop_per_step / time / ceiling).  After
+the headline loop the paper's own recipes (BASELINE configs[2] `da`, configs[3] `triplet`) are timed for a few steps
+each and reported under `other_workloads`.
 
 Launch:  python bench.py --gpus 1 --steps K --warmup W
          python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
@@ -176,6 +180,145 @@ def self_spawn(n):
     return max(abs(c) for c in codes)
 
 
+def elided_work(c, model, targets):
+    """what this build leaves out of a step of `model` on this batch because no loss reads it (same losses, same
+    gradients: tests/test_default_path_gpu.py) — strings for the bench line"""
+    import os as _os
+
+    from da_detect_amd.modeling.elision import elision_enabled
+
+    single_level = not c.MODEL.RPN.USE_FPN
+    out = ["second pooler + box-head pass over the DA ROIs (the reference recomputes the first pass bit for bit)"]
+    fx = getattr(getattr(model.roi_heads, "box", None), "feature_extractor", None)
+    head = getattr(fx, "head", None)
+    if head is not None and hasattr(head, "input_bin_stride") and head.input_bin_stride() > 1 \
+            and _os.environ.get("DADET_ROI_SUBGRID", "1") == "1":
+        out.append("3 of 4 ROIAlign bins in front of the stride-2 res5 head (never read)")
+    if not elision_enabled():
+        return out
+    da = model.da_heads_triplet if getattr(model, "da_heads_triplet", False) else getattr(model, "da_heads", None)
+    if da and not getattr(da, "needs_instance_features", True):
+        out.append("box head (ROIAlign, res5, predictor; forward and backward) on the 256 target-domain ROIs: instance-level "
+                   "loss weights are 0, every one of their gradient rows is zero")
+    if single_level and model.rpn.early_backward:
+        live = model._images_with_read_proposals(targets)
+        n = len(targets)
+        if live is not None and live < n:
+            out.append("RPN head + proposal selection on %d of %d images (their proposals reach no loss)" % (n - live, n))
+        out.append("RPN head backward on images without labelled anchors (target / auxiliary: identically zero)")
+        if _os.environ.get("DADET_RPN_ROW_BACKWARD", "1") == "1":
+            out.append("RPN head backward as dense GEMMs: run on the <= 256 sampled anchors' rows of the source image")
+    return out
+
+
+def run_workload(args, name, device, rank, world, steps, warmup, headline):
+    """build the recipe, tune the schedule, warm up, time `steps` steps between barriers.  headline: with the dominant
+    kernel bracketed in the timed region; always followed by an UNTIMED pass with every GEMM bracketed (single process
+    only), from which flop_per_step and the all-GEMM rate come."""
+    from da_detect_amd import _C
+    from da_detect_amd.data.synthetic import make_batch
+    from da_detect_amd.utils import streams
+    from da_detect_amd.engine.trainer import WgradLaneTuner, enable_overlapped_rpn_backward, train_step
+
+    yaml_path, overrides, images_per_gpu, workload_desc = WORKLOADS[name]
+    height, width = (HEIGHT, WIDTH) if args.image_hw is None else [int(v) for v in args.image_hw.lower().split("x")]
+    c, model, opt, reducer = build(yaml_path, device, seed=100, overrides=overrides)
+    enable_overlapped_rpn_backward(model, not args.no_overlap)
+    images, targets = make_batch(c, images_per_gpu, height, width, seed=100 + rank, device=device)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    # schedule choice by measurement, as do_da_train does in its first iterations (untimed, before the warm-up)
+    streams.join_wgrad_lane(device)
+    streams.WGRAD_LANE_ROWS = int(os.environ.get("DADET_WGRAD_LANE_ROWS", "0"))
+    tuner = WgradLaneTuner(device)
+    while tuner.active:
+        tuner.step_begin()
+        train_step(model, opt, images, targets)
+        tuner.step_end()
+    for _ in range(warmup):
+        loss_dict = train_step(model, opt, images, targets)
+    profiler = None
+    if headline and not args.no_kernel_timing and rank == 0:
+        # timed region: only the dominant kernel family (128x128-tile forward / data-gradient GEMM) is bracketed —
+        # every event pair between two launches costs dispatch concurrency (measured: ~1 ms / step for all GEMMs)
+        profiler = _C.KernelProfiler(pool=2 * 80 * steps, only="<2,2")
+    barrier()
+    mem0 = torch.cuda.memory_stats(device) if os.environ.get("DADET_BENCH_MEMSTATS") else None
+    t0 = time.perf_counter()
+    for i in range(steps):
+        # the brackets are not free (event pairs between launches cost dispatch concurrency: ~3% of the step when every
+        # step is bracketed), so only every `--kernel-timing-every`-th timed step carries them
+        _C.PROFILER = profiler if (profiler is not None and i % args.kernel_timing_every == 0) else None
+        loss_dict = train_step(model, opt, images, targets)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    _C.PROFILER = None
+    if mem0 is not None:       # allocator activity inside the timed region (diagnostics, stderr)
+        mem1 = torch.cuda.memory_stats(device)
+        print("memstats: " + ", ".join("%s %+d" % (k, mem1[k] - mem0[k]) for k in (
+            "num_device_alloc", "num_device_free", "num_alloc_retries", "num_sync_all_streams",
+            "reserved_bytes.all.current")) + ", reserved %.2f GB" % (mem1["reserved_bytes.all.current"] / 1e9),
+            file=sys.stderr)
+    exclusive = everything = None
+    extra = extra_elapsed = 0
+    if not args.no_kernel_timing and rank == 0 and world == 1:
+        # extra UNTIMED passes (single process only: a lone rank must not enter the gradient all-reduce):
+        # (1) all GEMM kernels bracketed, same schedule -> which kernel dominates, union-of-busy rate, FLOPs per step;
+        # (2) headline only: the same kernels without a second GEMM stream beside them -> per-kernel durations that do
+        #     not include a co-running weight-gradient / data-gradient kernel
+        extra = max(2, min(steps, 5)) if headline else 2
+        everything = _C.KernelProfiler()
+        _C.PROFILER = everything
+        torch.cuda.synchronize()
+        te = time.perf_counter()
+        for _ in range(extra):
+            train_step(model, opt, images, targets)
+        torch.cuda.synchronize()
+        extra_elapsed = time.perf_counter() - te
+        if headline and streams.lane_in_use():
+            saved = (streams.WGRAD_OVERLAP, streams.WGRAD_LANE_ROWS)
+            streams.join_wgrad_lane(device)
+            streams.WGRAD_OVERLAP, streams.WGRAD_LANE_ROWS = False, 0
+            exclusive = _C.KernelProfiler()
+            _C.PROFILER = exclusive
+            for _ in range(extra):
+                train_step(model, opt, images, targets)
+            torch.cuda.synchronize()
+            streams.WGRAD_OVERLAP, streams.WGRAD_LANE_ROWS = saved
+        _C.PROFILER = None
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    ranks_in_sync = None
+    if world > 1:
+        # data-parallel invariant, checked after the timed region: every rank applied the same averaged gradients to
+        # the same parameters, so the parameters are still identical bit for bit
+        chk = torch.stack([p.detach().double().sum() for p in model.parameters()])
+        lo, hi = chk.clone(), chk.clone()
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+        dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+        ranks_in_sync = bool((lo == hi).all().item())
+        if not ranks_in_sync and rank == 0:
+            print("WARNING: parameters differ between ranks after %d steps (max checksum spread %.3e)" % (
+                steps + warmup, float((hi - lo).abs().max())), file=sys.stderr, flush=True)
+    streams.join_wgrad_lane(device)
+    flop_per_step = None
+    if everything is not None:
+        flop_per_step = everything.union()[0] / extra
+    return dict(name=name, yaml=yaml_path, overrides=list(overrides), images_per_gpu=images_per_gpu, desc=workload_desc,
+                hw=(height, width), elapsed=elapsed, steps=steps, losses={k: float(v.detach()) for k, v in loss_dict.items()},
+                schedule=tuner.report(), profiler=profiler, everything=everything, exclusive=exclusive, extra=extra,
+                extra_elapsed=extra_elapsed, ranks_in_sync=ranks_in_sync, flop_per_step=flop_per_step,
+                lane_overlap=streams.WGRAD_OVERLAP, lane_rows=streams.WGRAD_LANE_ROWS,
+                elided=elided_work(c, model, targets))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -188,6 +331,10 @@ def main():
     ap.add_argument("--workload", default="img_only", choices=sorted(WORKLOADS),
                     help="img_only (default, BASELINE configs[1]) | da (configs[2]) | triplet (configs[3]) | "
                          "triplet_aligned | fpn_dcn_da (configs[4]); non-default workloads are extra measurements")
+    ap.add_argument("--others", default=None,
+                    help="comma-separated workloads timed after the headline loop and reported under other_workloads "
+                         "(default: da,triplet next to the default headline, none otherwise; 'none' switches it off)")
+    ap.add_argument("--other-steps", type=int, default=10)
     ap.add_argument("--image-hw", default=None, help="HxW of the synthetic images (default 1024x2048)")
     ap.add_argument("--no-overlap", action="store_true", help="keep the RPN backward inside the main backward pass")
     ap.add_argument("--gemm-mode", type=int, default=int(os.environ.get("DADET_GEMM_MODE", "3")),
@@ -215,111 +362,54 @@ def main():
     assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
 
     from da_detect_amd import _C
-    from da_detect_amd.data.synthetic import make_batch
-    from da_detect_amd.utils import streams
-    from da_detect_amd.engine.trainer import WgradLaneTuner, enable_overlapped_rpn_backward, train_step
 
     _C.set_gemm_mode(args.gemm_mode)
-    yaml_path, overrides, images_per_gpu, workload_desc = WORKLOADS[args.workload]
-    height, width = (HEIGHT, WIDTH) if args.image_hw is None else [int(v) for v in args.image_hw.lower().split("x")]
-    c, model, opt, reducer = build(yaml_path, device, seed=100, overrides=overrides)
-    enable_overlapped_rpn_backward(model, not args.no_overlap)
-    images, targets = make_batch(c, images_per_gpu, height, width, seed=100 + rank, device=device)
+    desc, mfma_per_product = GEMM_MODES[args.gemm_mode]
+    # peak for ALGORITHMIC flops: the fp32 pipe's peak in mode 0; in the split modes every fp32 product
+    # costs `mfma_per_product` bf16 MFMAs, so the algorithmic ceiling is the bf16 dense peak divided by it
+    peak = FP32_MFMA_PEAK_TFLOPS if args.gemm_mode == 0 else BF16_MFMA_PEAK_TFLOPS / mfma_per_product
 
-    def barrier():
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    # schedule choice by measurement, as do_da_train does in its first iterations (untimed, before the warm-up)
-    tuner = WgradLaneTuner(device)
-    while tuner.active:
-        tuner.step_begin()
-        train_step(model, opt, images, targets)
-        tuner.step_end()
-    for _ in range(args.warmup):
-        loss_dict = train_step(model, opt, images, targets)
-    profiler = None
-    if not args.no_kernel_timing and rank == 0:
-        # timed region: only the dominant kernel family (128x128-tile forward / data-gradient GEMM) is bracketed —
-        # every event pair between two launches costs dispatch concurrency (measured: ~1 ms / step for all GEMMs)
-        profiler = _C.KernelProfiler(pool=2 * 80 * args.steps, only="<2,2")
-    barrier()
-    mem0 = torch.cuda.memory_stats(device) if os.environ.get("DADET_BENCH_MEMSTATS") else None
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        # the brackets are not free (event pairs between launches cost dispatch concurrency: ~3% of the step when every
-        # step is bracketed), so only every `--kernel-timing-every`-th timed step carries them
-        _C.PROFILER = profiler if (profiler is not None and i % args.kernel_timing_every == 0) else None
-        loss_dict = train_step(model, opt, images, targets)
-    barrier()
-    elapsed = time.perf_counter() - t0
-    _C.PROFILER = None
-    if mem0 is not None:       # allocator activity inside the timed region (diagnostics, stderr)
-        mem1 = torch.cuda.memory_stats(device)
-        print("memstats: " + ", ".join("%s %+d" % (k, mem1[k] - mem0[k]) for k in (
-            "num_device_alloc", "num_device_free", "num_alloc_retries", "num_sync_all_streams",
-            "reserved_bytes.all.current")) + ", reserved %.2f GB" % (mem1["reserved_bytes.all.current"] / 1e9),
-            file=sys.stderr)
-    exclusive = everything = None
-    if profiler is not None and world == 1:
-        # two extra UNTIMED passes (single process only: a lone rank must not enter the gradient all-reduce):
-        # (1) all GEMM kernels bracketed, same schedule -> which kernel dominates, union-of-busy rate;
-        # (2) the same kernels without a second GEMM stream beside them -> per-kernel durations that do not include a
-        #     co-running weight-gradient / data-gradient kernel
-        extra = max(2, min(args.steps, 5))
-        everything = _C.KernelProfiler()
-        _C.PROFILER = everything
-        torch.cuda.synchronize()
-        te = time.perf_counter()
-        for _ in range(extra):
-            train_step(model, opt, images, targets)
-        torch.cuda.synchronize()
-        extra_elapsed = time.perf_counter() - te
-        if streams.lane_in_use():
-            saved = (streams.WGRAD_OVERLAP, streams.WGRAD_LANE_ROWS)
-            streams.join_wgrad_lane(device)
-            streams.WGRAD_OVERLAP, streams.WGRAD_LANE_ROWS = False, 0
-            exclusive = _C.KernelProfiler()
-            _C.PROFILER = exclusive
-            for _ in range(extra):
-                train_step(model, opt, images, targets)
-            torch.cuda.synchronize()
-            streams.WGRAD_OVERLAP, streams.WGRAD_LANE_ROWS = saved
-        _C.PROFILER = None
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-    losses = {k: float(v.detach()) for k, v in loss_dict.items()}
-    ranks_in_sync = None
-    if world > 1:
-        # data-parallel invariant, checked after the timed region: every rank applied the same averaged gradients to
-        # the same parameters, so the parameters are still identical bit for bit
-        chk = torch.stack([p.detach().double().sum() for p in model.parameters()])
-        lo, hi = chk.clone(), chk.clone()
-        dist.all_reduce(lo, op=dist.ReduceOp.MIN)
-        dist.all_reduce(hi, op=dist.ReduceOp.MAX)
-        ranks_in_sync = bool((lo == hi).all().item())
-        if not ranks_in_sync and rank == 0:
-            print("WARNING: parameters differ between ranks after %d steps (max checksum spread %.3e)" % (
-                args.steps + args.warmup, float((hi - lo).abs().max())), file=sys.stderr, flush=True)
+    r = run_workload(args, args.workload, device, rank, world, args.steps, args.warmup, headline=True)
+    if args.others is None:
+        others = ["da", "triplet"] if (args.workload == "img_only" and args.image_hw is None) else []
+    else:
+        others = [w for w in args.others.split(",") if w and w != "none"]
+    other_results = {}
+    for name in others:
+        # the paper's own recipes on the same GPU(s), same sizes, a few steps each: the headline recipe is the one that
+        # loses the most work to `elided`, these two lose the least
+        torch.cuda.empty_cache()
+        o = run_workload(args, name, device, rank, world, args.other_steps, max(3, args.warmup // 2), headline=False)
+        ms = o["elapsed"] / o["steps"] * 1e3
+        rec = {"workload": o["desc"], "yaml": o["yaml"], "images_per_step": world * o["images_per_gpu"],
+               "steps": o["steps"], "ms_per_step": round(ms, 3),
+               "images_per_s": round(world * o["images_per_gpu"] * o["steps"] / o["elapsed"], 3),
+               "schedule": o["schedule"], "elided": o["elided"]}
+        if o["flop_per_step"] is not None:
+            rec["flop_per_step"] = round(o["flop_per_step"] / 1e12, 4)
+            rec["flop_unit"] = "TFLOP (algorithmic fp32, 2*MAC, all GEMM launches of one step per GPU)"
+            rec["step_frac"] = round(o["flop_per_step"] / 1e12 / (ms * 1e-3) / peak, 4)
+            work, busy_ms = o["everything"].union()
+            rec["all_gemm_frac"] = round(work / (busy_ms * 1e-3) / 1e12 / peak, 4)
+        if o["ranks_in_sync"] is not None:
+            rec["ranks_in_sync_after_run"] = o["ranks_in_sync"]
+        other_results[name] = rec
 
     if rank == 0:
-        value = world * images_per_gpu * args.steps / elapsed
+        elapsed, steps = r["elapsed"], r["steps"]
+        images_per_gpu = r["images_per_gpu"]
+        height, width = r["hw"]
+        profiler, everything, exclusive = r["profiler"], r["everything"], r["exclusive"]
+        value = world * images_per_gpu * steps / elapsed
+        ms_per_step = elapsed / steps * 1e3
         roofline = None
         kernels = {}
         if profiler is not None:
             kernels = profiler.summary()
-            bracketed_steps = len(range(0, args.steps, args.kernel_timing_every))
+            bracketed_steps = len(range(0, steps, args.kernel_timing_every))
             name = max(kernels, key=lambda k: kernels[k]["total_ms"])
             k = kernels[name]
             achieved = k["achieved"] / 1e12
-            desc, mfma_per_product = GEMM_MODES[args.gemm_mode]
-            # peak for ALGORITHMIC flops: the fp32 pipe's peak in mode 0; in the split modes every fp32 product
-            # costs `mfma_per_product` bf16 MFMAs, so the algorithmic ceiling is the bf16 dense peak divided by it
-            peak = FP32_MFMA_PEAK_TFLOPS if args.gemm_mode == 0 else BF16_MFMA_PEAK_TFLOPS / mfma_per_product
             traffic, traffic_src = pmc_traffic(name, args.gemm_mode)
             shown = name + (" (+ its stream-K launch form conv_fwd_split_sk_kernel<3>, same tile body)"
                             if name.endswith("<2,2,3>") else "")
@@ -335,7 +425,7 @@ def main():
                         "bracketed_steps": bracketed_steps,
                         "avg_launch_ms": round(k["avg_ms"], 4),
                         "gflop_per_launch": round(k["work_per_launch"] / 1e9, 3),
-                        "share_of_step": round(k["total_ms"] / bracketed_steps / (elapsed / args.steps * 1e3), 4)}
+                        "share_of_step": round(k["total_ms"] / bracketed_steps / ms_per_step, 4)}
             if everything is not None:
                 work, busy_ms = everything.union()
                 kernels = everything.summary()      # table of all GEMM kernels (extra pass, `extra` steps)
@@ -343,19 +433,19 @@ def main():
                 roofline["gemm_streams"] = {
                     "note": ("forward/data-gradient and weight-gradient GEMMs run on two streams "
                              "(DADET_WGRAD_STREAM=1); `achieved` is per launch WHILE the other stream's kernel shares "
-                             "the GPU; " if streams.WGRAD_OVERLAP else
+                             "the GPU; " if r["lane_overlap"] else
                              "weight-gradient GEMMs of layers with at most %d rows run on a second stream beside the "
                              "data-gradient chain (engine.trainer.WgradLaneTuner measured that faster for this recipe): "
                              "`achieved` is per launch WHILE such a kernel may share the GPU; exclusive_* = the same "
-                             "launches with the second stream off; " % streams.WGRAD_LANE_ROWS
-                             if streams.WGRAD_LANE_ROWS > 0 else
+                             "launches with the second stream off; " % r["lane_rows"]
+                             if r["lane_rows"] > 0 else
                              "one GEMM stream (default): a bracketed launch has the GPU to itself except for the "
                              "latency-bound side-stream kernels; ") +
                             "this block comes from extra untimed passes with every GEMM bracketed",
                     "dominant_kernel_all_bracketed": dominant,
                     "all_gemm_tflops_while_any_runs": round(work / (busy_ms * 1e-3) / 1e12, 2),
                     "all_gemm_frac": round(work / (busy_ms * 1e-3) / 1e12 / peak, 4),
-                    "gemm_busy_share_of_step": round(busy_ms / (extra_elapsed * 1e3), 4)}
+                    "gemm_busy_share_of_step": round(busy_ms / (r["extra_elapsed"] * 1e3), 4)}
             if exclusive is not None:
                 ek = exclusive.summary().get(name)
                 if ek:
@@ -365,27 +455,46 @@ def main():
         if not args.no_cpu_baseline and world == 1:
             try:
                 cpu = cpu_baseline(YAML, seed=100) if args.workload == "img_only" and args.image_hw is None else None
+                if cpu is not None:
+                    cpu["sample"] = str(cpu.get("sample", "")) + (
+                        "; ALL rows evaluated as the reference does (every head on every image, both box-head passes): "
+                        "the GPU step leaves out the work listed under `elided`, so the ratio of the two values is not a "
+                        "kernel-quality figure")
             except Exception as e:  # the baseline is reported, never required for the GPU number
                 cpu = {"value": None, "unit": "images/s", "cores": min(os.cpu_count() or 1, 64), "kind": "port",
                        "sample": "failed: %r" % (e,)}
+        rois = ("box head on the 256 source-domain ROIs (the target image's ROIs reach no loss), RPN head on the source "
+                "image, RPN backward on <= 256 sampled anchor rows" if any("target-domain ROIs" in e for e in r["elided"])
+                else "256 ROIs sampled per image, one box-head pass over all of them")
         line = {
             "metric": "train images/sec, DA-Faster-RCNN R-50 Cityscapes->Foggy",
-            "value": round(value, 3), "unit": "images/s", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3),
+            "value": round(value, 3), "unit": "images/s", "n_gpus": world, "steps": steps,
+            "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
             "data": "synthetic (seeded rand*255 - PIXEL_MEAN images, 8-20 seeded boxes/image, seeded random-init weights)",
-            "config": {"workload": "configs/da_faster_rcnn %s %dx%d image per GPU per step, 256 ROIs per image and "
-                                   "box-head pass, fwd+bwd+SGD" % (workload_desc, height, width),
-                       "yaml": yaml_path, "overrides": list(overrides), "global_batch": world * images_per_gpu,
+            "config": {"workload": "configs/da_faster_rcnn %s %dx%d image per GPU per step, %s, fwd+bwd+SGD; work no loss "
+                                   "reads is not evaluated (see `elided`, `flop_per_step`)"
+                                   % (r["desc"], height, width, rois),
+                       "yaml": r["yaml"], "overrides": r["overrides"], "global_batch": world * images_per_gpu,
                        "image_hw": [height, width],
-                       "parallelism": "dp%d" % world, "schedule": tuner.report()},
+                       "parallelism": "dp%d" % world, "schedule": r["schedule"]},
+            "elided": r["elided"],
             "roofline": roofline, "cpu_baseline": cpu,
+            "other_workloads": other_results,
             "kernel_timing": {k: {"launches": v["launches"], "total_ms": round(v["total_ms"], 3),
                                   "tflops": round(v["achieved"] / 1e12, 2)} for k, v in kernels.items()},
-            "final_losses": {k: round(v, 5) for k, v in losses.items()},
+            "final_losses": {k: round(v, 5) for k, v in r["losses"].items()},
         }
-        if ranks_in_sync is not None:
-            line["config"]["ranks_in_sync_after_run"] = ranks_in_sync
+        if r["flop_per_step"] is not None:
+            # images/s counts images, not work: the FLOPs one step executes on one GPU (all GEMM launches, algorithmic
+            # 2*MAC in fp32 terms) and the fraction of the contraction's ceiling the WHOLE step reaches with them
+            line["flop_per_step"] = round(r["flop_per_step"] / 1e12, 4)
+            line["flop_unit"] = "TFLOP per step per GPU (algorithmic fp32, 2*MAC, all GEMM launches; measured in an extra pass)"
+            line["step_frac"] = round(r["flop_per_step"] / 1e12 / (ms_per_step * 1e-3) / peak, 4)
+            line["reference_flop_per_step"] = {"value": 6.9, "unit": "TFLOP", "note": "the reference's dense evaluation "
+                                               "of the same batch incl. its redundant second box-head pass (SURVEY.md 8d)"}
+        if r["ranks_in_sync"] is not None:
+            line["config"]["ranks_in_sync_after_run"] = r["ranks_in_sync"]
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()

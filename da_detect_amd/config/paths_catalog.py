@@ -1,7 +1,7 @@
 """Dataset / pretrained-model catalog (reference: maskrcnn_benchmark/config/paths_catalog.py:7-300).
 
-`cfg.PATHS_CATALOG` names a python file that defines `DatasetCatalog` (and `ModelCatalog`); data/build.py loads it
-with utils.imports.import_file and calls `DatasetCatalog.get(name)` -> dict(factory=<class name in data.datasets>,
+`cfg.PATHS_CATALOG` names a python file that defines `DatasetCatalog` (and `ModelCatalog`); data/build.py loads it ONCE
+per file (utils.imports.load_paths_catalog: run-time `register` calls and edits of the tables stay visible) and calls `DatasetCatalog.get(name)` -> dict(factory=<class name in data.datasets>,
 args=dict(root=..., ann_file=...)).  The reference's own file hard-codes its author's directories; a site keeps
 pointing PATHS_CATALOG at its copy of that file (it is plain data and loads unchanged), or fills this one:
 
@@ -62,7 +62,7 @@ class DatasetCatalog(object):
             if name not in DatasetCatalog.DATASETS:
                 raise RuntimeError("Dataset not available: {}".format(name))
             attrs = DatasetCatalog.DATASETS[name]
-            data_dir = DatasetCatalog.DATA_DIR
+            data_dir = os.environ.get("DADET_DATA_DIR", DatasetCatalog.DATA_DIR)     # the environment wins, at call time
             return dict(factory="COCODataset", args=dict(root=os.path.join(data_dir, attrs["img_dir"]),
                                                          ann_file=os.path.join(data_dir, attrs["ann_file"])))
         raise RuntimeError("Dataset not available: {}".format(name))
@@ -80,5 +80,6 @@ class ModelCatalog(object):
         if name.startswith("ImageNetPretrained/"):
             key = name[len("ImageNetPretrained/"):]
             if key in ModelCatalog.C2_IMAGENET_MODELS:
-                return os.path.join(ModelCatalog.MODEL_DIR, ModelCatalog.C2_IMAGENET_MODELS[key])
+                return os.path.join(os.environ.get("DADET_MODEL_DIR", ModelCatalog.MODEL_DIR),
+                                    ModelCatalog.C2_IMAGENET_MODELS[key])
         raise RuntimeError("model not present in the catalog {}".format(name))

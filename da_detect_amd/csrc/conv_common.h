@@ -104,7 +104,7 @@ inline int fwd_variant(int M, int Cout) {
   return 1;
 }
 
-// 0 = exact fp32 MFMA (default); 2 / 3 = products from a 2- / 3-term bf16 split of both operands
+// 3 (default) / 2 = products from a 3- / 2-term bf16 split of both operands; 0 = exact fp32 MFMA
 int gemm_mode();
 int launch_fwd_split(ConvArgs& a, int variant, int terms, hipStream_t st);
 int launch_fwd_split_sk(ConvArgs& a, int terms, hipStream_t st);

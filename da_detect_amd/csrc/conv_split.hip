@@ -12,7 +12,8 @@
 // over the 128-wide reuse of the tile; the LDS image is one [rows][32 + 8 pad] bf16 plane per term (80-byte
 // rows: ds_read_b128 fragment reads and ds_write_b64 staging writes are both bank-conflict free).
 // Everything else — buffer-descriptor loads, tap/channel indexing, XCD-aware tile order, fused epilogue — is the
-// fp32 kernel's (conv_igemm.hip).  Selected with dadet_set_gemm_mode(); the default stays exact fp32.
+// fp32 kernel's (conv_igemm.hip).  The 3-term split is the library's DEFAULT contraction (a C-ABI consumer gets it
+// without any call); dadet_set_gemm_mode(0) selects the exact-fp32 MFMA kernels instead.
 #include "conv_common.h"
 #include <stdlib.h>
 
@@ -26,7 +27,7 @@ constexpr int PLANE_STRIDE = 40;  // bf16 per staged row: 32 + 8 pad = 80 bytes
 #endif
 constexpr bool PRIO_SPLIT = DADET_PRIO_SPLIT != 0;
 
-static int g_gemm_mode = 0;
+static int g_gemm_mode = 3;
 int gemm_mode() { return g_gemm_mode; }
 
 __device__ inline unsigned pack_bf16(float lo, float hi) {
@@ -1300,7 +1301,7 @@ int launch_wgrad_split(WgradArgs& a, int terms, hipStream_t st) {
 
 }  // namespace dadet
 
-// 0 = exact fp32 MFMA (default); 2 = 2-term bf16 split (3 MFMAs / K=16); 3 = 3-term split (6 MFMAs / K=16)
+// 3 = 3-term bf16 split (6 MFMAs / K=16, fp32-class accuracy; default); 0 = exact fp32 MFMA; 2 = 2-term split (3 MFMAs / K=16)
 extern "C" int dadet_set_gemm_mode(int mode) {
   if (mode != 0 && mode != 2 && mode != 3) {
     dadet::set_error("set_gemm_mode: mode must be 0, 2 or 3");

@@ -15,7 +15,7 @@ import logging
 import torch
 
 from ..utils.comm import get_world_size
-from ..utils.imports import import_file
+from ..utils.imports import load_paths_catalog
 from . import datasets as D
 from . import samplers
 from .collate_batch import BatchCollator, BatchCollator_triplet
@@ -78,7 +78,7 @@ def _loader_for(cfg, dataset, per_gpu, shuffle, is_distributed, num_iters, start
 
 # ------------------------------------------------------------------------------------ the reference's entry points
 def _catalog(cfg):
-    return import_file("maskrcnn_benchmark.config.paths_catalog", cfg.PATHS_CATALOG, True).DatasetCatalog
+    return load_paths_catalog(cfg.PATHS_CATALOG).DatasetCatalog
 
 
 def _from_catalog(name, catalog, transforms, is_train, is_source):

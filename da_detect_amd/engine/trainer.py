@@ -134,15 +134,30 @@ def _unwrap(model):
 
 
 def _prepare(model, optimizer, distributed):
-    """the network that is actually stepped + its gradient reducer (see the module docstring)"""
+    """the network that is actually stepped + its gradient reducer (see the module docstring).
+
+    A DistributedDataParallel wrapper is taken off ONLY when this module's own reducer does (or will do) the gradient
+    exchange, i.e. the optimizer is the fused one (`attach_reducer`).  With any other optimizer (the reference's
+    signature allows torch.optim.SGD) the wrapper is the only gradient synchronisation there is: it stays, and the
+    overlapped RPN / DA backward — several backward passes per forward, which DDP's contract does not admit — stays off."""
+    wrapped = isinstance(model, torch.nn.parallel.DistributedDataParallel)
+    own_reducer = hasattr(optimizer, "attach_reducer")
+    if wrapped and not own_reducer:
+        model.train()
+        enable_overlapped_rpn_backward(model.module, False)
+        return model
     net = _unwrap(model)
-    if hasattr(optimizer, "attach_reducer") and getattr(optimizer, "reducer", None) is None \
+    if own_reducer and getattr(optimizer, "reducer", None) is None \
             and (distributed or get_world_size() > 1 or next(net.parameters()).is_cuda):
         from ..parallel.reducer import BucketedGradReducer
 
         reducer = BucketedGradReducer([p for p in net.parameters() if p.requires_grad])
         reducer.broadcast_parameters(0)
         optimizer.attach_reducer(reducer)
+    if get_world_size() > 1 and getattr(optimizer, "reducer", None) is None:
+        raise RuntimeError("world size %d without gradient synchronisation: pass the model wrapped in "
+                           "DistributedDataParallel or use solver.make_optimizer (fused SGD + bucketed reducer)"
+                           % get_world_size())
     net.train()
     enable_overlapped_rpn_backward(net)
     return net
@@ -161,6 +176,16 @@ def _update_meters(meters, loss_dict):
     total = torch.stack([v.reshape(()) for v in vals]).sum() if vals else torch.zeros(())
     meters.update(loss=total, **{k: v.detach() for k, v in reduced.items()})
     return total
+
+
+def _loss_is_nan(net, total):
+    """NaN in this step's summed loss, or — between two tests — in the parameters an earlier NaN step has since
+    poisoned (SGD carries a NaN gradient into the weights for good; one small tensor is enough to see it)"""
+    bad = torch.isnan(total).any()
+    probe = next((p for p in net.parameters() if p.requires_grad), None)
+    if probe is not None:
+        bad = bad | torch.isnan(probe.detach().sum())
+    return bool(bad)
 
 
 def do_train(model, data_loader, optimizer, scheduler, checkpointer, device, checkpoint_period, arguments):
@@ -263,15 +288,17 @@ def do_da_train(model, source_data_loader, positive_target_data_loader, negative
         at_checkpoint = checkpoint_period > 0 and iteration % checkpoint_period == 0 and iteration != 0
         if iteration % 20 == 0 or iteration == max_iter:
             _log_line(logger, meters, iteration, max_iter, optimizer)
+        # the NaN test is a host synchronisation: it runs at the logging period and BEFORE anything is written — a
+        # checkpoint of poisoned weights would also retag `last_checkpoint` (the reference tests every iteration)
+        if (iteration % 20 == 0 or at_checkpoint or iteration == max_iter - 1) and _loss_is_nan(net, total):
+            logger.critical("Loss is NaN, exiting...")
+            tuner.close()
+            return
         if at_checkpoint:
             checkpointer.save("model_{:07d}".format(iteration), **arguments)
             scheduler.step(int(iteration / checkpoint_period))
         if iteration == max_iter - 1:
             checkpointer.save("model_final", **arguments)
-        if (iteration % 20 == 0 or at_checkpoint or iteration == max_iter - 1) and bool(torch.isnan(total).any()):
-            logger.critical("Loss is NaN, exiting...")
-            tuner.close()
-            return
         if eval_in_training and at_checkpoint and data_loader_val is not None:
             synchronize()
             with torch.no_grad():

@@ -11,6 +11,7 @@ from ...poolers import Pooler
 
 
 _SUBGRID = os.environ.get("DADET_ROI_SUBGRID", "1") == "1"
+_BWD_LIST = os.environ.get("DADET_ROI_BWD_LIST", "1")[:1] != "0"      # csrc/roi_align.hip reads the same switch
 
 
 @registry.ROI_BOX_FEATURE_EXTRACTORS.register("ResNet50Conv5ROIFeatureExtractor")
@@ -36,8 +37,12 @@ class ResNet50Conv5ROIFeatureExtractor(nn.Module):
         # quarters.  Those bins are pooled alone, into a 7 x 7 grid, and the block runs with stride 1 on it: the same
         # values (bit for bit) from a quarter of the ROIAlign work, forward and backward.  DADET_ROI_SUBGRID=0: the
         # reference's full grid.
+        # (the sub-grid backward is the list kernel's: channels in 16-byte groups, pooled grid of at most 14 x 14,
+        # DADET_ROI_BWD_LIST on — a configuration it does not cover pools the full grid instead of failing mid-backward)
         stride = self.head.input_bin_stride() if (_SUBGRID and x[0].is_cuda and len(self.pooler.poolers) == 1
-                                                  and sum(len(p) for p in proposals) > 0) else 1
+                                                  and sum(len(p) for p in proposals) > 0
+                                                  and x[0].shape[1] % 4 == 0 and max(self.pooler.output_size) <= 14
+                                                  and _BWD_LIST) else 1
         if stride > 1:
             return self.head(self.pooler(x, proposals, bin_stride=stride), first_stride=1)
         return self.head(self.pooler(x, proposals))

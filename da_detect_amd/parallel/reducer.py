@@ -31,11 +31,16 @@ from ..utils import streams
 
 
 class BucketedGradReducer(object):
-    def __init__(self, params, bucket_bytes=25 * 1024 * 1024, process_group=None, learn_unused=True):
+    def __init__(self, params, bucket_bytes=25 * 1024 * 1024, process_group=None, learn_unused=True,
+                 always_communicate=False):
         self.params = [p for p in params if p.requires_grad]
         self.learn_unused = learn_unused
         self.group = process_group
         self.world_size = dist.get_world_size(process_group) if dist.is_available() and dist.is_initialized() else 1
+        # always_communicate: issue the bucket collectives also in a ONE-rank process group (a single-GPU box can then
+        # drive RCCL itself — communicator set-up, stream ordering against the compute stream and the weight-gradient
+        # lane, async work handles — through exactly the code path of N ranks; tests/test_multirank_gpu.py)
+        self.communicate = self.world_size > 1 or (always_communicate and dist.is_available() and dist.is_initialized())
         self.buckets = []          # list of dict(flat=tensor, params=[...], pending=int, work=None)
         self._bucket_of = {}
         self._build(bucket_bytes)
@@ -44,6 +49,8 @@ class BucketedGradReducer(object):
         self._finalized = True
         self.touched = set()       # ids of the parameters that received a gradient since zero_grad()
         self.static_unused = None  # ids of the parameters no rank touched in the first step (None: not learned yet)
+        self.mean_scale = 1.0      # what the buckets must still be multiplied by after finalize(mean=False)
+        self._touched_any = frozenset()
 
     def _build(self, bucket_bytes):
         cur, cur_bytes = [], 0
@@ -88,7 +95,7 @@ class BucketedGradReducer(object):
             b = self.buckets[self._next]
             if b["pending"] > 0 and not force:
                 return
-            if self.world_size > 1:
+            if self.communicate:
                 b["work"] = self._all_reduce(b["flat"])
             self._next += 1
 
@@ -118,21 +125,49 @@ class BucketedGradReducer(object):
         if b["pending"] == 0 and not self._finalized:
             self._launch_ready()
 
-    def finalize(self):
-        """reduce buckets that never completed, wait for every collective, turn sums into means"""
+    def finalize(self, mean=True):
+        """reduce buckets that never completed and wait for every collective.  mean=True turns the sums into means here
+        (one multiply per bucket); mean=False leaves the SUMS in the buckets and the caller applies `mean_scale` itself —
+        the fused optimizer folds it into the SGD kernel's gradient read (solver/fused_sgd.py), six launches fewer"""
         if self._finalized:
             return
         if self.buckets:
             streams.join_wgrad_lane(self.buckets[0]["flat"].device)
         self._launch_ready(force=True)
-        if self.world_size > 1:
+        if self.communicate:
             for b in self.buckets:
                 if b["work"] is not None:
                     b["work"].wait()
-                b["flat"].mul_(1.0 / self.world_size)
+                if mean and self.world_size > 1:
+                    b["flat"].mul_(1.0 / self.world_size)
+        self.mean_scale = 1.0 if (mean or self.world_size == 1) else 1.0 / self.world_size
         self._finalized = True
-        if self.static_unused is None and self.learn_unused and self.world_size > 1:
-            self._learn_unused()
+        if self.world_size > 1:
+            if self.static_unused is None and self.learn_unused:
+                self._learn_unused()
+            elif self.static_unused is None:
+                self._agree_touched()
+
+    def _agree_touched(self):
+        """graphs that change between steps (learn_unused=False): the parameters ANY rank touched in this step, agreed on
+        through one small all-reduce per step — what `update_ids` then reports on every rank alike"""
+        dev = self.buckets[0]["flat"].device if self.buckets else torch.device("cpu")
+        mask = torch.tensor([1.0 if id(p) in self.touched else 0.0 for p in self.params], dtype=torch.float32, device=dev)
+        if mask.numel():
+            dist.all_reduce(mask, op=dist.ReduceOp.MAX, group=self.group)
+        self._touched_any = frozenset(id(p) for p, m in zip(self.params, mask.tolist()) if m > 0.5)
+
+    def update_ids(self):
+        """ids of the parameters the optimizer must update after finalize().  One rank: those that received a gradient
+        (torch.optim.SGD skips `grad is None`: no weight decay, no momentum step).  Several ranks: every parameter ANY
+        rank touched — its averaged gradient is the same everywhere, so is its update (DDP with find_unused_parameters
+        behaves the same); deciding by the LOCAL touched set would let weights, momentum and weight decay of a
+        parameter used on rank A only drift apart between the ranks"""
+        if self.world_size == 1:
+            return self.touched
+        if self.static_unused is not None:
+            return frozenset(id(p) for p in self.params) - self.static_unused
+        return self._touched_any
 
     def _learn_unused(self):
         """end of the first step: the parameters that NO rank touched (agreed on through one all-reduce of a mask)"""

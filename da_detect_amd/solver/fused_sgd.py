@@ -45,7 +45,8 @@ class FusedSGD(torch.optim.Optimizer):
                 # with the reducer every .grad is a persistent (zeroed) bucket view: a parameter that received no
                 # gradient this step must still be SKIPPED, as torch.optim.SGD skips `grad is None` (no weight decay,
                 # no momentum update) — e.g. the instance head when its loss weight is 0
-                if self.reducer is not None and id(p) not in self.reducer.touched:
+                # (with several ranks: no gradient on ANY rank — reducer.update_ids)
+                if self.reducer is not None and id(p) not in self._update_ids:
                     continue
                 out.append((p, group["lr"], group["weight_decay"], group["momentum"]))
         return out
@@ -57,7 +58,11 @@ class FusedSGD(torch.optim.Optimizer):
             with torch.enable_grad():
                 loss = closure()
         if self.reducer is not None:
-            self.reducer.finalize()
+            # the 1 / world of the gradient mean rides in the kernel's gradient read (g * grad_scale: exact for the
+            # power-of-two worlds of one node) instead of one multiply launch per bucket
+            self.reducer.finalize(mean=False)
+            grad_scale = grad_scale * self.reducer.mean_scale
+            self._update_ids = self.reducer.update_ids()
         entries = self._entries()
         if not entries:
             return loss

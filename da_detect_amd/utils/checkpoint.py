@@ -16,7 +16,7 @@ import os
 import torch
 
 from .c2_model_loading import load_c2_format
-from .imports import import_file
+from .imports import load_paths_catalog
 from .model_serialization import load_state_dict
 
 _TAG = "last_checkpoint"
@@ -96,7 +96,7 @@ class DetectronCheckpointer(Checkpointer):
 
     def _resolve(self, f):
         if f.startswith("catalog://"):
-            catalog = import_file("maskrcnn_benchmark.config.paths_catalog", self.cfg.PATHS_CATALOG, True)
+            catalog = load_paths_catalog(self.cfg.PATHS_CATALOG)
             target = catalog.ModelCatalog.get(f[len("catalog://"):])
             self.logger.info("{} points to {}".format(f, target))
             f = target

@@ -20,3 +20,18 @@ def import_file(module_name, file_path, make_importable=False):
             sys.modules.pop(module_name, None)
         raise
     return mod
+
+
+def load_paths_catalog(file_path):
+    """the PATHS_CATALOG module, executed ONCE per file: a `DatasetCatalog.register(...)` or an edit of
+    `ModelCatalog`'s tables made at run time is then seen by every later make_data_loader / catalog:// lookup (a fresh
+    execution per call handed each caller its own pristine classes).  An already imported
+    `maskrcnn_benchmark.config.paths_catalog` backed by the same file is reused."""
+    import os
+
+    name = "maskrcnn_benchmark.config.paths_catalog"
+    want = os.path.abspath(file_path)
+    mod = sys.modules.get(name)
+    if mod is not None and os.path.abspath(getattr(mod, "__file__", "") or "") == want:
+        return mod
+    return import_file(name, want, True)

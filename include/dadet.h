@@ -146,10 +146,10 @@ int dadet_conv_forward(const dadet_conv_desc* d, const float* x, const float* w,
                        const float* bias, const float* addend, const float* mask_ref, float* y,
                        void* stream);
 
-/* Contraction mode of dadet_conv_forward (process-wide): 0 = exact fp32 MFMA (v_mfma_f32_32x32x2_f32, default);
- * 3 = fp32 operands split into three bf16 terms, six v_mfma_f32_32x32x16_bf16 per K=16 (error ~2^-24 |ab|, fp32
- * class); 2 = two-term split, three MFMAs per K=16 (error ~2^-16 |ab|).  Inputs, outputs and accumulation are
- * fp32 in every mode. */
+/* Contraction mode of dadet_conv_forward / dadet_conv_wgrad (process-wide): 3 (DEFAULT, also for a consumer that never
+ * calls this) = fp32 operands split into three bf16 terms, six v_mfma_f32_32x32x16_bf16 per K=16 (error ~2^-24 |ab|,
+ * fp32 class, 2.6x the rate of mode 0); 0 = exact fp32 MFMA (v_mfma_f32_32x32x2_f32); 2 = two-term split, three
+ * MFMAs per K=16 (error ~2^-16 |ab|, experiments only).  Inputs, outputs and accumulation are fp32 in every mode. */
 int dadet_set_gemm_mode(int mode);
 int dadet_get_gemm_mode(void);
 

@@ -102,7 +102,7 @@ def test_checkpointer_round_trip_and_c2_pickle(tmp_path):
     os.replace(str(tmp_path / "R-50.pkl"), str(tmp_path / "ImageNetPretrained" / "MSRA" / "R-50.pkl"))
     catalog = importlib.import_module("da_detect_amd.config.paths_catalog")
     old = catalog.ModelCatalog.MODEL_DIR
-    os.environ["DADET_MODEL_DIR"] = str(tmp_path)      # read when the catalog FILE is executed by import_file
+    os.environ["DADET_MODEL_DIR"] = str(tmp_path)      # read by ModelCatalog.get at call time
     try:
         with torch.no_grad():
             model.backbone.body.stem.conv1.weight.zero_()
@@ -111,6 +111,24 @@ def test_checkpointer_round_trip_and_c2_pickle(tmp_path):
     finally:
         os.environ.pop("DADET_MODEL_DIR")
         catalog.ModelCatalog.MODEL_DIR = old
+
+
+def test_catalog_module_is_loaded_once_so_run_time_registrations_are_seen():
+    """ADVICE r2: DatasetCatalog.register(...) / an edited ModelCatalog table must reach make_data_loader and catalog://
+    loading — the PATHS_CATALOG file is executed once, not once per call"""
+    from da_detect_amd.config import cfg
+    from da_detect_amd.data import build as B
+    from da_detect_amd.utils.imports import load_paths_catalog
+
+    cat = B._catalog(cfg)
+    cat.register("unit_test_cocostyle", "/abs/images", "/abs/ann.json")
+    try:
+        again = B._catalog(cfg)
+        assert again is cat
+        assert again.get("unit_test_cocostyle")["args"] == {"root": "/abs/images", "ann_file": "/abs/ann.json"}
+        assert load_paths_catalog(cfg.PATHS_CATALOG).DatasetCatalog is cat
+    finally:
+        cat.DATASETS.pop("unit_test_cocostyle", None)
 
 
 def test_saved_state_is_the_live_state_not_the_loaded_one(tmp_path):

@@ -48,14 +48,18 @@ def _worker(rank, world, port, case, out):
 
     torch.cuda.set_device(0)
     dev = torch.device("cuda", 0)
+    rccl_alone = world == 1 and os.environ.get("DADET_TEST_RCCL_ONE_RANK") == "1"
     if world > 1:
         dist.init_process_group("gloo", rank=rank, world_size=world)
+    elif rccl_alone:
+        dist.init_process_group("nccl", rank=0, world_size=1)       # "nccl" is RCCL on ROCm
     from da_detect_amd.data.synthetic import make_batch
     from da_detect_amd.engine.trainer import enable_overlapped_rpn_backward, train_step
     from da_detect_amd.parallel.reducer import BucketedGradReducer
 
     c, model, opt = _build(case, 3, dev)
-    reducer = BucketedGradReducer([p for p in model.parameters() if p.requires_grad], bucket_bytes=8 << 20)
+    reducer = BucketedGradReducer([p for p in model.parameters() if p.requires_grad], bucket_bytes=8 << 20,
+                                  always_communicate=rccl_alone)
     reducer.broadcast_parameters(0)
     opt.attach_reducer(reducer)
     enable_overlapped_rpn_backward(model)
@@ -74,8 +78,9 @@ def _worker(rank, world, port, case, out):
     torch.manual_seed(50 + batch_rank)                      # device sampler seeds: per-rank stream
     train_step(model, opt, images, targets)
     torch.cuda.synchronize()
-    after = [b["flat"].detach().clone().cpu() for b in reducer.buckets]
-    if world > 1:
+    # the fused optimizer leaves the SUMS in the buckets and folds 1 / world into the SGD kernel (reducer.mean_scale)
+    after = [b["flat"].detach().clone().cpu() * reducer.mean_scale for b in reducer.buckets]
+    if world > 1 or rccl_alone:
         snaps = [local[b["flat"].data_ptr()].cpu() for b in reducer.buckets]
     else:
         snaps = after                                        # single process: nothing is reduced
@@ -83,11 +88,11 @@ def _worker(rank, world, port, case, out):
     early = []
     orig_finalize = reducer.finalize
 
-    def finalize():
+    def finalize(**kw):
         # collectives already issued when backward is over: from the second step on the reducer no longer waits for the
         # parameters no rank used in the first (the instance head of the image-level-only recipe sits in bucket 0)
         early.append(sum(1 for b in reducer.buckets if b["work"] is not None))
-        return orig_finalize()
+        return orig_finalize(**kw)
 
     reducer.finalize = finalize
     for it in range(1, 3):
@@ -97,22 +102,27 @@ def _worker(rank, world, port, case, out):
     if world > 1:
         assert reducer.static_unused is not None
         assert all(e == len(reducer.buckets) for e in early), (early, len(reducer.buckets), len(reducer.static_unused))
+    if rccl_alone:
+        # one rank has no "unused on every rank" agreement: buckets that hold a parameter outside the recipe's graph go
+        # out in finalize(), the others during backward — at least one collective must have overlapped backward
+        assert all(e >= 1 for e in early), early
     moved = sum(int(not torch.equal(a, p.detach())) for a, p in zip(p0, reducer.params))
     params = torch.cat([p.detach().reshape(-1).cpu() for p in reducer.params])
     out.put((rank, [s.numpy() for s in snaps], [a.numpy() for a in after], params.numpy(), moved,
              len(reducer.buckets), len(reducer.touched)))
-    if world > 1:
+    if world > 1 or rccl_alone:
         dist.barrier()
         dist.destroy_process_group()
 
 
-def _run(world, case, batch_rank=0):
+def _run(world, case, batch_rank=0, rccl_one_rank=False):
     import torch.multiprocessing as mp
 
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
     os.environ["DADET_TEST_BATCH_RANK"] = str(batch_rank)
+    os.environ["DADET_TEST_RCCL_ONE_RANK"] = "1" if rccl_one_rank else "0"
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     procs = [ctx.Process(target=_worker, args=(r, world, port, case, q)) for r in range(world)]
     for p in procs:
@@ -148,3 +158,22 @@ def test_two_ranks_real_model_bucket_means_and_sync(device, case):
     for b in range(n_buckets):
         scale = float(np.abs(solo[2][b]).max())
         np.testing.assert_allclose(r1[1][b], solo[2][b], rtol=1e-4, atol=1e-6 * scale + 1e-12)
+
+
+def test_one_rank_over_rccl_takes_the_n_rank_path_and_changes_nothing(device):
+    """RCCL first contact on a one-GPU box: a ONE-rank "nccl" process group with the reducer forced to communicate —
+    communicator set-up, every bucket through ncclAllReduce on RCCL's stream with an async work handle, the optimizer
+    waiting for the handles — must leave exactly the single-process result: same bucket contents, same parameters after
+    3 steps (an all-reduce over one rank is the identity, the mean factor is 1)."""
+    import numpy as np
+
+    alone, = _run(1, "da_plain")
+    rccl, = _run(1, "da_plain", rccl_one_rank=True)
+    assert rccl[5] == alone[5] and rccl[6] == alone[6]
+    # (two processes: the fp32 atomics of the image-level DA sums and of the RPN row scatter may differ in the last bit)
+    for b in range(rccl[5]):
+        scale = float(np.abs(alone[2][b]).max())
+        tol = dict(rtol=1e-5, atol=1e-6 * scale + 1e-12)
+        np.testing.assert_allclose(rccl[1][b], alone[2][b], err_msg="what went into bucket %d's collective" % b, **tol)
+        assert np.array_equal(rccl[2][b], rccl[1][b]), "bucket %d changed in a one-rank all-reduce" % b
+    np.testing.assert_allclose(rccl[3], alone[3], rtol=1e-5, atol=1e-7, err_msg="parameters after 3 steps")

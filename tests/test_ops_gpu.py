@@ -280,6 +280,68 @@ def test_conv_forward_split_bf16_modes(device, case, mode, tol):
         assert err_split < max(4 * err_exact, 1e-6)
 
 
+# the two longest reductions of the BASELINE step: res5 3x3 512 -> 512 on the 7 x 7 maps of 256 ROIs (M = 12544, K = 4608)
+# and the RPN 3x3 1024 -> 1024 on a 64 x 128 map (M = 8192, K = 9216)
+PRODUCTION_K = [(256, 512, 7, 7, 512, 3, 1, 1), (1, 1024, 64, 128, 1024, 3, 1, 1)]
+
+
+@pytest.mark.parametrize("case", PRODUCTION_K)
+def test_split_bf16_accuracy_at_production_k(device, case):
+    """the claim "the split contraction's error is not larger than the exact-fp32 MFMA kernel's", at the production
+    reduction lengths: forward outputs and weight gradients of both kernels against float64 dot products of the same
+    operands, on 96 sampled output pixels x all channels (forward) and 8 sampled taps x all channel pairs (weight
+    gradient: float64 GEMM over all M rows on the device).  Asserted on the RMS error (the maximum over 5e4 samples of
+    two error populations of the same size is a coin flip) with 10% slack for that comparison's own noise, and on the
+    maximum within 1.5x."""
+    from da_detect_amd import _C
+
+    N, Cin, H, W, Cout, k, stride, pad = case
+    rng = np.random.default_rng(sum(case) + 77)
+    x, w = _conv_case(rng, *case)
+    xd, wd = x.to(device).contiguous(memory_format=CL), w.to(device).contiguous(memory_format=CL)
+    gy = torch.from_numpy(rng.standard_normal((N, Cout, H, W)).astype(np.float32))
+    gyd = gy.to(device).contiguous(memory_format=CL)
+    prev = _C.get_gemm_mode()
+    out = {}
+    try:
+        for mode in (0, 3):
+            _C.set_gemm_mode(mode)
+            out[mode] = (_C.conv_forward(xd, wd, stride=stride, pad=pad), _C.conv_wgrad(xd, gyd, tuple(w.shape), stride, pad))
+    finally:
+        _C.set_gemm_mode(prev)
+    # forward: sampled pixels (corners and edges included: padding taps), float64 patches x float64 weights
+    pix = [(0, 0, 0), (N - 1, H - 1, W - 1), (0, 0, W - 1), (N - 1, H - 1, 0)]
+    pix += [(int(rng.integers(N)), int(rng.integers(H)), int(rng.integers(W))) for _ in range(92)]
+    xp = F.pad(x.double(), (pad, pad, pad, pad))
+    patches = torch.stack([xp[n, :, h:h + k, w_:w_ + k].reshape(-1) for n, h, w_ in pix])        # [96, Cin*k*k]
+    ref = patches @ w.double().reshape(Cout, -1).t()                                               # [96, Cout]
+    stats = {}
+    for mode in (0, 3):
+        y = out[mode][0].cpu().double()
+        got = torch.stack([y[n, :, h, w_] for n, h, w_ in pix])
+        e = (got - ref) / ref.abs().mean()
+        stats[mode] = (float(e.pow(2).mean().sqrt()), float(e.abs().max()))
+    print("forward %s: rel. error rms / max  exact-fp32 %.3e / %.3e   split %.3e / %.3e" % ((case,) + stats[0] + stats[3]))
+    assert stats[3][0] <= 1.1 * stats[0][0] and stats[3][1] <= 1.5 * stats[0][1], stats
+    # weight gradient: taps (r, s) sampled, dW[:, :, r, s] = gy^T [Cout, M] @ x_shifted [M, Cin] in float64 on the device
+    taps = [(0, 0), (1, 1), (2, 2), (0, 2), (2, 0), (1, 0), (0, 1), (2, 1)]
+    xpd = F.pad(xd.double(), (pad, pad, pad, pad))
+    g2 = gyd.double().permute(1, 0, 2, 3).reshape(Cout, -1)
+    stats = {0: [0.0, 0.0, 0], 3: [0.0, 0.0, 0]}
+    for r, s_ in taps:
+        xs = xpd[:, :, r:r + H, s_:s_ + W].permute(0, 2, 3, 1).reshape(-1, Cin)
+        refw = (g2 @ xs).cpu()
+        for mode in (0, 3):
+            e = (out[mode][1][:, :, r, s_].cpu().double() - refw) / refw.abs().mean()
+            stats[mode][0] += float(e.pow(2).sum())
+            stats[mode][1] = max(stats[mode][1], float(e.abs().max()))
+            stats[mode][2] += e.numel()
+    rms = {m: (stats[m][0] / stats[m][2]) ** 0.5 for m in stats}
+    print("wgrad   %s: rel. error rms / max  exact-fp32 %.3e / %.3e   split %.3e / %.3e"
+          % (case, rms[0], stats[0][1], rms[3], stats[3][1]))
+    assert rms[3] <= 1.1 * rms[0] and stats[3][1] <= 1.5 * stats[0][1], (rms, stats)
+
+
 @pytest.mark.parametrize("mode,tol", [(3, 1e-4), (2, 2e-3)])
 @pytest.mark.parametrize("case", [CONV_CASES[1], CONV_CASES[2], CONV_CASES[3], CONV_CASES[6], CONV_CASES[7], CONV_CASES[9]])
 def test_conv_wgrad_split_bf16_modes(device, case, mode, tol):

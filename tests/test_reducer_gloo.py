@@ -47,6 +47,25 @@ def _worker(rank, world, port, out):
     assert red.static_unused == frozenset([id(never)]), red.static_unused
     assert early[0] == 0 and early[1] == early[2]
     assert early[1] == (len(red.buckets) if rank == 0 else red.buckets.index(red._bucket_of[id(unused)])), early
+    # which parameters the optimizer updates: everything some rank touched — `unused` also on rank 1, which never
+    # touched it (its averaged gradient is the same on both ranks, so must be its update); `never` on neither
+    assert red.update_ids() == frozenset(id(p) for p in params[:-1]), "update set differs from 'touched by any rank'"
+    assert (id(unused) in red.touched) == (rank == 0)
+    # finalize(mean=False) leaves the sums and reports the factor the optimizer folds into its gradient read
+    means = [b["flat"].clone() for b in red.buckets]
+    red.zero_grad()
+    loss = model(torch.full((5, 8), float(rank + 2))).pow(2).sum()
+    if rank == 0:
+        loss = loss + (unused * 2).sum()
+    loss.backward()
+    red.finalize(mean=False)
+    assert red.mean_scale == 0.5
+    for b, m in zip(red.buckets, means):
+        torch.testing.assert_close(b["flat"] * red.mean_scale, m, rtol=0, atol=0)
+    red.finalize()                      # a second call in the same step is a no-op
+    assert red.mean_scale == 0.5
+    for b in red.buckets:
+        b["flat"].mul_(red.mean_scale)
     params = params[:-1]
     flat = torch.cat([p.grad.reshape(-1) for p in params])
     gathered = [torch.zeros_like(flat) for _ in range(world)]
@@ -80,3 +99,41 @@ def test_bucketed_allreduce_two_ranks():
         grads.append(torch.cat([p.grad.reshape(-1) for p in model.parameters()]))
     want = torch.cat([(grads[0] + grads[1]) / 2, torch.full((3,), 1.0)])  # unused: (2 + 0) / 2; `never` is not compared
     torch.testing.assert_close(g0, want, rtol=1e-5, atol=1e-6)
+
+
+def _worker_dynamic(rank, world, port, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from da_detect_amd.parallel.reducer import BucketedGradReducer
+
+    a, b, c = (torch.nn.Parameter(torch.ones(4)) for _ in range(3))
+    red = BucketedGradReducer([a, b, c], bucket_bytes=16, learn_unused=False)
+    seen = []
+    for step in range(2):
+        red.zero_grad()
+        loss = (a * 2).sum()
+        if rank == step:                  # `b` is used by a different rank in each step, `c` by none
+            loss = loss + (b * 3).sum()
+        loss.backward()
+        red.finalize()
+        seen.append((sorted(i for i, p in enumerate((a, b, c)) if id(p) in red.update_ids()), b.grad.tolist()))
+    out.put((rank, seen))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_update_set_is_agreed_per_step_when_graphs_change():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_dynamic, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = dict(q.get(timeout=120) for _ in range(2))
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    assert got[0] == got[1], "ranks disagree on which parameters to update"
+    for ids, gb in got[0]:
+        assert ids == [0, 1] and gb == [1.5] * 4
