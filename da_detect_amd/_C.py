@@ -487,6 +487,51 @@ def nchw3_to_nhwc4(x):
     return y
 
 
+def da_ins_tail_forward(h, w3, b3, labels, means, r_bce, r_cst, n_src):
+    """h [r_bce + r_cst, C], w3 [C], b3 [1], labels float [r_bce] | None, means [L, 2] | None
+    -> (logits [rows], sums [2] = (BCE sum, consistency sum))"""
+    _dev(h, "h")
+    rows, C = h.shape
+    assert rows == r_bce + r_cst
+    L = int(means.shape[0]) if means is not None else 0
+    logits = torch.empty(rows, dtype=torch.float32, device=h.device)
+    sums = torch.zeros(2, dtype=torch.float32, device=h.device)
+    _lib.call("dadet_da_ins_tail_forward", _p(h), _p(w3), _p(b3), _p(labels), _p(means), _p(logits), _p(sums),
+              int(r_bce), int(r_cst), int(n_src), L, C, _stream())
+    return logits, sums
+
+
+def da_ins_tail_backward(h, w3, logits, labels, means, coef, inv_keep, r_bce, r_cst, n_src):
+    """-> (g_z [rows, C] gradient w.r.t. the last hidden layer's PRE-activation, g_w3 [C], g_b3 [1], g_means [L, 2] | None)"""
+    rows, C = h.shape
+    L = int(means.shape[0]) if means is not None else 0
+    g_z = torch.empty_like(h)
+    acc = torch.zeros(C + 1 + 2 * L, dtype=torch.float32, device=h.device)      # one zero-fill for the three sums
+    g_w3, g_b3 = acc[:C], acc[C:C + 1]
+    g_means = acc[C + 1:].view(L, 2) if L else None
+    _lib.call("dadet_da_ins_tail_backward", _p(h), _p(w3), _p(logits), _p(labels), _p(means), _p(coef), float(inv_keep),
+              _p(g_z), _p(g_w3), _p(g_b3), _p(g_means), int(r_bce), int(r_cst), int(n_src), L, C, _stream())
+    return g_z, g_w3, g_b3, g_means
+
+
+def da_ins_dropout_rows(h1, masks):
+    """h1 [R, C], masks [P, R, C] -> [P * R, C]: the passes' dropped copies of the shared hidden layer"""
+    P = masks.shape[0]
+    out = torch.empty((P * h1.shape[0], h1.shape[1]), dtype=torch.float32, device=h1.device)
+    _lib.call("dadet_da_ins_dropout_rows", _p(h1), _p(masks), _p(out), ctypes.c_int64(h1.numel()), int(P), _stream())
+    return out
+
+
+def da_ins_merge(g, masks, h1, grl, need_x=True):
+    """g [P * R, C], masks [P, R, C], h1 [R, C], grl float [P] (device) -> (g_w [R, C], g_x [R, C] | None)"""
+    P = masks.shape[0]
+    g_w = torch.empty_like(h1)
+    g_x = torch.empty_like(h1) if need_x else None
+    _lib.call("dadet_da_ins_merge", _p(g), _p(masks), _p(h1), _p(grl), _p(g_w), _p(g_x), ctypes.c_int64(h1.numel()),
+              int(P), _stream())
+    return g_w, g_x
+
+
 def rpn_decode_clip(deltas_nhwc, anchors, topk_idx, weights, xform_clip, im_w, im_h):
     """decode + clip the top-k anchors of ONE image.  deltas_nhwc: [H,W,A*4] (any view whose storage is
     that order), anchors [H*W*A,4], topk_idx int64[K] -> boxes [K,4]."""
@@ -567,6 +612,41 @@ def deform_sample_backward(x, offset, mask, gcols, kh, kw, stride, pad, dil, dg,
     _lib.call("dadet_deform_sample_backward", _p(x), _p(offset), _p(mask), _p(gcols), _p(gx), _p(goffset), _p(gmask),
               N, H, W, C, kh, kw, stride, pad, dil, dg, Ho, Wo, _stream())
     return gx, goffset, gmask
+
+
+def _off_ptr(t, floats):
+    return ctypes.c_void_p(t.data_ptr() + 4 * int(floats))
+
+
+def deform_sample_forward_om(x, om, kh, kw, stride, pad, dil, dg, modulated):
+    """deformable sampling that reads offsets (channels [0, 2T*dg)) and modulation LOGITS (channels [2T*dg, 3T*dg),
+    sigmoid applied in the kernel) straight out of `om` [N, ld, Ho, Wo] channels_last — the offset-predicting conv's
+    output, ld >= the channels used (padded to a multiple of 4).  -> cols [N, kh*kw*C, Ho, Wo]"""
+    _dev(x, "x"), _dev(om, "om")
+    x, om = _nhwc(x), _nhwc(om)
+    N, C, H, W = x.shape
+    ld, Ho, Wo = om.shape[1], om.shape[2], om.shape[3]
+    T = kh * kw
+    assert ld >= dg * T * (3 if modulated else 2)
+    cols = torch.empty((N, T * C, Ho, Wo), dtype=torch.float32, device=x.device, memory_format=CL)
+    _lib.call("dadet_deform_sample_forward_ld", _p(x), _p(om), ld, _off_ptr(om, 2 * T * dg) if modulated else None, ld,
+              1, _p(cols), N, H, W, C, kh, kw, stride, pad, dil, dg, Ho, Wo, _stream())
+    return cols
+
+
+def deform_sample_backward_om(x, om, gcols, kh, kw, stride, pad, dil, dg, modulated):
+    """-> (gx [N,C,H,W], gom [N, ld, Ho, Wo]): gradients w.r.t. the sampled map and w.r.t. the offset conv's output
+    (offset channels, modulation logits; the padding channels stay zero)"""
+    x, om, gcols = _nhwc(x), _nhwc(om), _nhwc(gcols)
+    N, C, H, W = x.shape
+    ld, Ho, Wo = om.shape[1], om.shape[2], om.shape[3]
+    T = kh * kw
+    gx = torch.empty_like(x).zero_()
+    gom = torch.empty_like(om).zero_()
+    _lib.call("dadet_deform_sample_backward_ld", _p(x), _p(om), ld, _off_ptr(om, 2 * T * dg) if modulated else None, ld,
+              1, _p(gcols), _p(gx), _p(gom), ld, _off_ptr(gom, 2 * T * dg) if modulated else None, ld,
+              N, H, W, C, kh, kw, stride, pad, dil, dg, Ho, Wo, _stream())
+    return gx, gom
 
 
 def rpn_loss(objectness, box_regression, sampled_inds, labels_sampled, pos_inds, targets_pos, beta):

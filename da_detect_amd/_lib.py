@@ -64,6 +64,8 @@ _SIGNATURES = {
     "dadet_conv_weight_transpose": [_P, _P, _P, c_int, c_int, c_int, c_int, _P],
     "dadet_deform_sample_forward": [_P, _P, _P, _P] + [c_int] * 12 + [_P],
     "dadet_deform_sample_backward": [_P, _P, _P, _P, _P, _P, _P] + [c_int] * 12 + [_P],
+    "dadet_deform_sample_forward_ld": [_P, _P, c_int, _P, c_int, c_int, _P] + [c_int] * 12 + [_P],
+    "dadet_deform_sample_backward_ld": [_P, _P, c_int, _P, c_int, c_int, _P, _P, _P, c_int, _P, c_int] + [c_int] * 12 + [_P],
     "dadet_image_resample_h": [_P, c_int, c_int, _P, _P, c_int, c_int, _P, _P],
     "dadet_image_resample_v_normalize": [_P, c_int, c_int, _P, _P, c_int, c_int, c_int, c_int, POINTER(c_float),
                                          POINTER(c_float), _P, c_int, _P],
@@ -96,6 +98,10 @@ _SIGNATURES = {
     "dadet_rpn_decode_clip": [_P, _P, _P, c_int, c_float, c_float, c_float, c_float, c_float, c_float, c_float, _P, _P],
     "dadet_da_img_head_loss_forward": [_P, _P, _P, _P, _P, _P, c_int, c_int, c_int, _P],
     "dadet_da_img_head_loss_backward": [_P, _P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, _P],
+    "dadet_da_ins_tail_forward": [_P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P],
+    "dadet_da_ins_tail_backward": [_P, _P, _P, _P, _P, _P, c_float, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P],
+    "dadet_da_ins_dropout_rows": [_P, _P, _P, c_int64, c_int, _P],
+    "dadet_da_ins_merge": [_P, _P, _P, _P, _P, _P, c_int64, c_int, _P],
     "dadet_triplet_w_forward": [_P, _P, _P, c_int, c_int, c_int, c_float, c_float, _P, _P, _P],
     "dadet_triplet_w_backward": [_P, _P, _P, _P, _P, c_int, c_int, c_int, c_float, c_float, _P, _P, _P, _P],
     "dadet_sgd_step": [_P, c_int, c_int64, c_float, c_int, c_float, _P],

@@ -165,6 +165,178 @@ __global__ __launch_bounds__(256) void da_img_bwd_kernel(
   if (lane == 0) atomicAdd(g_b2, bacc);  // bacc is wavefront-uniform
 }
 
+// ---- instance-level domain classifier tail -------------------------------------------------------
+// Reference: DAInsHead.forward's last layer (modeling/da_heads/da_heads.py:61-68: fc3_da 1024 -> 1), the instance BCE
+// (da_heads/loss.py:95-97: BCE-with-logits against the ROI's domain label, mean over the ROIs) and the consistency
+// regulariser (layers/consistency_loss.py:3-27: |mean_hw sigmoid(image logits of the ROI's image) - sigmoid(instance
+// logit)|, one column per feature level, mean over ROIs x levels; ROIs of the source image come first, batch of 2).
+// The reference evaluates the head twice per iteration — behind GRL(-w) for the BCE, behind GRL(+w) for the consistency
+// term, each pass with its own dropout masks (da_heads.py:421-424) — and runs fc3, squeeze, BCE, sigmoid, repeat / cat /
+// abs / mean as ~25 ATen launches forward and backward.  Here the rows of both passes are stacked ([R_bce] adversarial
+// rows, then [R_cst] consistency rows) and ONE launch evaluates fc3 and both loss sums, one wavefront per row (64 lanes x
+// float4 along the 1024 hidden units, wave reduction), and ONE launch does the whole backward of the tail: the gradient
+// w.r.t. fc2's pre-activation (dropout scale and ReLU gate folded in: h = relu(z) * mask with mask in {0, 1 / keep}, so
+// h != 0 <=> gate open and mask = 1 / keep), fc3's weight / bias gradients and the gradient of the per-image means.
+// The two reversal weights act where the passes merge again, in da_ins_merge_kernel below.
+//   h       [R_bce + R_cst][C]   second hidden layer AFTER dropout
+//   means   [L][2]               per level: mean sigmoid of image 0 (source) and image 1 (target); null when R_cst == 0
+//   sums    [2]                  += sum of BCE terms, += sum over consistency rows and levels of |mean - sigmoid|
+__global__ __launch_bounds__(256) void da_ins_fwd_kernel(const float* __restrict__ h, const float* __restrict__ w3,
+                                                         const float* __restrict__ b3,
+                                                         const float* __restrict__ labels,
+                                                         const float* __restrict__ means, float* __restrict__ logits,
+                                                         float* __restrict__ sums, int R_bce, int R_cst, int n_src,
+                                                         int L, int C) {
+  __shared__ float s_acc[2];
+  if (threadIdx.x < 2) s_acc[threadIdx.x] = 0.f;
+  __syncthreads();
+  const int lane = threadIdx.x & 63;
+  const int wave_global = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int nwaves = (gridDim.x * blockDim.x) >> 6;
+  const int R = R_bce + R_cst;
+  const float bias = b3[0];
+  float bce = 0.f, cst = 0.f;
+  for (int r = wave_global; r < R; r += nwaves) {
+    const float* row = h + (size_t)r * C;
+    float dot = 0.f;
+    for (int c = lane * 4; c < C; c += 256) {
+      const float4 hv = *reinterpret_cast<const float4*>(row + c);
+      const float4 wv = *reinterpret_cast<const float4*>(w3 + c);
+      dot += hv.x * wv.x + hv.y * wv.y + hv.z * wv.z + hv.w * wv.w;
+    }
+    const float logit = wave_sum(dot) + bias;
+    if (lane == 0) {
+      logits[r] = logit;
+      if (r < R_bce) {
+        bce += bce_with_logits(logit, labels[r]);
+      } else {
+        const int img = (r - R_bce) < n_src ? 0 : 1;
+        const float sg = sigmoidf(logit);
+        for (int l = 0; l < L; ++l) cst += fabsf(means[l * 2 + img] - sg);
+      }
+    }
+  }
+  if (lane == 0) {
+    if (bce != 0.f) atomicAdd(&s_acc[0], bce);
+    if (cst != 0.f) atomicAdd(&s_acc[1], cst);
+  }
+  __syncthreads();
+  if (threadIdx.x < 2 && s_acc[threadIdx.x] != 0.f) atomicAdd(&sums[threadIdx.x], s_acc[threadIdx.x]);
+}
+
+// coef[0] = d loss / d (BCE sum), coef[1] = d loss / d (consistency sum) (device scalars: upstream gradients x the
+// mean factors).  g_z[r][c] = dlogit_r * w3[c] * inv_keep * [h[r][c] != 0];  g_w3[c] += sum_r dlogit_r * h[r][c];
+// g_b3 += sum_r dlogit_r;  g_means[l][img] += coef[1] * sign(mean - sigmoid).
+__global__ __launch_bounds__(256) void da_ins_bwd_kernel(const float* __restrict__ h, const float* __restrict__ w3,
+                                                         const float* __restrict__ logits,
+                                                         const float* __restrict__ labels,
+                                                         const float* __restrict__ means,
+                                                         const float* __restrict__ coef, float inv_keep,
+                                                         float* __restrict__ g_z, float* __restrict__ g_w3,
+                                                         float* __restrict__ g_b3, float* __restrict__ g_means,
+                                                         int R_bce, int R_cst, int n_src, int L, int C) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* s_w = reinterpret_cast<float*>(smem);   // [C] workgroup partial of g_w3, then [L * 2] of g_means, [1] g_b3
+  float* s_m = s_w + C;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int nw_block = blockDim.x >> 6;
+  for (int c = threadIdx.x; c < C + 2 * L + 1; c += blockDim.x) s_w[c] = 0.f;
+  __syncthreads();
+  const int R = R_bce + R_cst;
+  const float a_bce = coef[0], a_cst = coef[1];
+  float4 wacc[4];     // C <= 1024: lane owns float4 slots c = lane*4 + 256*k
+#pragma unroll
+  for (int k = 0; k < 4; ++k) wacc[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+  float bacc = 0.f;
+  for (int r = blockIdx.x * nw_block + wave; r < R; r += gridDim.x * nw_block) {
+    const float sg = sigmoidf(logits[r]);
+    float dl;
+    if (r < R_bce) {
+      dl = a_bce * (sg - labels[r]);
+    } else {
+      const int img = (r - R_bce) < n_src ? 0 : 1;
+      float sgn = 0.f;    // d |m - s| / d s summed over levels
+      for (int l = 0; l < L; ++l) {
+        const float d = means[l * 2 + img] - sg;
+        const float sd = d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f);
+        sgn -= sd;
+        if (lane == 0 && sd != 0.f) atomicAdd(&s_m[l * 2 + img], a_cst * sd);
+      }
+      dl = a_cst * sgn * sg * (1.f - sg);
+    }
+    bacc += dl;
+    const float* row = h + (size_t)r * C;
+    const float gk = dl * inv_keep;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int c = lane * 4 + 256 * k;
+      if (c < C) {
+        const float4 hv = *reinterpret_cast<const float4*>(row + c);
+        const float4 wv = *reinterpret_cast<const float4*>(w3 + c);
+        float4 o;
+        o.x = hv.x != 0.f ? gk * wv.x : 0.f; o.y = hv.y != 0.f ? gk * wv.y : 0.f;
+        o.z = hv.z != 0.f ? gk * wv.z : 0.f; o.w = hv.w != 0.f ? gk * wv.w : 0.f;
+        *reinterpret_cast<float4*>(g_z + (size_t)r * C + c) = o;
+        wacc[k].x += dl * hv.x; wacc[k].y += dl * hv.y; wacc[k].z += dl * hv.z; wacc[k].w += dl * hv.w;
+      }
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int c = lane * 4 + 256 * k;
+    if (c < C) {
+      atomicAdd(&s_w[c + 0], wacc[k].x);
+      atomicAdd(&s_w[c + 1], wacc[k].y);
+      atomicAdd(&s_w[c + 2], wacc[k].z);
+      atomicAdd(&s_w[c + 3], wacc[k].w);
+    }
+  }
+  if (lane == 0 && bacc != 0.f) atomicAdd(&s_m[2 * L], bacc);   // bacc is wavefront-uniform
+  __syncthreads();
+  for (int c = threadIdx.x; c < C; c += blockDim.x)
+    if (s_w[c] != 0.f) atomicAdd(&g_w3[c], s_w[c]);
+  if (g_means && threadIdx.x < 2 * L && s_m[threadIdx.x] != 0.f) atomicAdd(&g_means[threadIdx.x], s_m[threadIdx.x]);
+  if (threadIdx.x == 0 && s_m[2 * L] != 0.f) atomicAdd(g_b3, s_m[2 * L]);
+}
+
+// the two passes share the head's first layer up to its dropout mask: h1s = [h1 * mask_a; h1 * mask_b]
+__global__ __launch_bounds__(256) void da_ins_dropout_rows_kernel(const float4* __restrict__ h1,
+                                                                  const float4* __restrict__ masks,
+                                                                  float4* __restrict__ out, int64_t n4_per_pass,
+                                                                  int passes) {
+  const int64_t total = n4_per_pass * passes;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const float4 v = h1[i % n4_per_pass], m = masks[i];
+    out[i] = make_float4(v.x * m.x, v.y * m.y, v.z * m.z, v.w * m.w);
+  }
+}
+
+// where the passes merge again (backward through the shared first layer).  g [P][R][C] = gradient w.r.t. the dropped
+// hidden layer of each pass; the gradient w.r.t. fc1's pre-activation is summed over the passes ONCE unweighted (the
+// head's own parameter gradients) and ONCE with each pass's gradient-reversal weight (what flows on into the ROI
+// features: layers/gradient_scalar_layer.py:4-13 sits in front of fc1, and everything in between is linear in the
+// gradient), both gated by h1's ReLU:   g_w = [h1 > 0] * sum_p mask_p * g_p,   g_x = [h1 > 0] * sum_p grl[p] * mask_p * g_p
+__global__ __launch_bounds__(256) void da_ins_merge_kernel(const float4* __restrict__ g, const float4* __restrict__ masks,
+                                                           const float4* __restrict__ h1, const float* __restrict__ grl,
+                                                           float4* __restrict__ g_w, float4* __restrict__ g_x,
+                                                           int64_t n4_per_pass, int passes) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4_per_pass;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    const float4 hv = h1[i];
+    float4 aw = make_float4(0.f, 0.f, 0.f, 0.f), ax = aw;
+    for (int p = 0; p < passes; ++p) {
+      const float4 gv = g[p * n4_per_pass + i], mv = masks[p * n4_per_pass + i];
+      const float w = grl[p];
+      const float4 t = make_float4(gv.x * mv.x, gv.y * mv.y, gv.z * mv.z, gv.w * mv.w);
+      aw.x += t.x; aw.y += t.y; aw.z += t.z; aw.w += t.w;
+      ax.x += w * t.x; ax.y += w * t.y; ax.z += w * t.z; ax.w += w * t.w;
+    }
+    g_w[i] = make_float4(hv.x > 0.f ? aw.x : 0.f, hv.y > 0.f ? aw.y : 0.f, hv.z > 0.f ? aw.z : 0.f, hv.w > 0.f ? aw.w : 0.f);
+    if (g_x) g_x[i] = make_float4(hv.x > 0.f ? ax.x : 0.f, hv.y > 0.f ? ax.y : 0.f, hv.z > 0.f ? ax.z : 0.f,
+                                  hv.w > 0.f ? ax.w : 0.f);
+  }
+}
+
 // ---- triplet loss over the W axis of NHWC maps ------------------------------------------------
 // a, p, n: [H][W][C] (one image each).  For every (h, c): d_ap = ||a - p + eps||_2 over w, d_an likewise;
 // loss_sum += max(d_ap - d_an + margin, 0).  A lane owns one (h, c) pair — lanes run along c, so every
@@ -294,4 +466,66 @@ extern "C" int dadet_triplet_w_backward(const float* anchor, const float* positi
                      positive, negative, dist, g_scale, H, W, C, margin, eps, g_anchor, g_positive,
                      g_negative);
   return check_launch("triplet_w_backward");
+}
+
+extern "C" int dadet_da_ins_tail_forward(const float* h, const float* w3, const float* b3, const float* labels,
+                                         const float* means, float* logits, float* sums, int R_bce, int R_cst,
+                                         int n_src, int levels, int C, void* stream) {
+  DADET_REQUIRE(R_bce >= 0 && R_cst >= 0 && C > 0 && C % 4 == 0 && levels >= 0, "da_ins_tail_forward: bad dims");
+  if (R_bce + R_cst == 0) return DADET_OK;
+  DADET_REQUIRE(h && w3 && b3 && logits && sums && a16(h) && a16(w3) && (R_bce == 0 || labels) &&
+                    (R_cst == 0 || (means && levels > 0)),
+                "da_ins_tail_forward: bad pointers");
+  int blocks = ceil_div(R_bce + R_cst, 4);
+  if (blocks > kNumCU * 2) blocks = kNumCU * 2;
+  hipLaunchKernelGGL(da_ins_fwd_kernel, dim3(blocks), dim3(256), 0, as_stream(stream), h, w3, b3, labels, means,
+                     logits, sums, R_bce, R_cst, n_src, levels, C);
+  return check_launch("da_ins_tail_forward");
+}
+
+extern "C" int dadet_da_ins_tail_backward(const float* h, const float* w3, const float* logits, const float* labels,
+                                          const float* means, const float* coef, float inv_keep, float* g_z,
+                                          float* g_w3, float* g_b3, float* g_means, int R_bce, int R_cst, int n_src,
+                                          int levels, int C, void* stream) {
+  DADET_REQUIRE(R_bce >= 0 && R_cst >= 0 && C > 0 && C % 4 == 0 && C <= 1024 && levels >= 0 && levels <= 16,
+                "da_ins_tail_backward: C must be a multiple of 4 and <= 1024");
+  if (R_bce + R_cst == 0) return DADET_OK;
+  DADET_REQUIRE(h && w3 && logits && coef && g_z && g_w3 && g_b3 && a16(h) && a16(w3) && a16(g_z) &&
+                    (R_bce == 0 || labels) && (R_cst == 0 || (means && levels > 0)),
+                "da_ins_tail_backward: bad pointers");
+  int blocks = ceil_div(R_bce + R_cst, 4 * 4);
+  if (blocks > kNumCU) blocks = kNumCU;
+  if (blocks < 1) blocks = 1;
+  hipLaunchKernelGGL(da_ins_bwd_kernel, dim3(blocks), dim3(256), sizeof(float) * (C + 2 * levels + 1), as_stream(stream),
+                     h, w3, logits, labels, means, coef, inv_keep, g_z, g_w3, g_b3, g_means, R_bce, R_cst, n_src, levels,
+                     C);
+  return check_launch("da_ins_tail_backward");
+}
+
+extern "C" int dadet_da_ins_dropout_rows(const float* h1, const float* masks, float* out, int64_t numel_per_pass,
+                                         int passes, void* stream) {
+  DADET_REQUIRE(numel_per_pass >= 0 && numel_per_pass % 4 == 0 && passes > 0, "da_ins_dropout_rows: bad dims");
+  if (numel_per_pass == 0) return DADET_OK;
+  DADET_REQUIRE(h1 && masks && out && a16(h1) && a16(masks) && a16(out), "da_ins_dropout_rows: bad pointers");
+  int64_t blocks = ceil_div64(numel_per_pass / 4 * passes, 256);
+  if (blocks > kMaxStreamBlocks) blocks = kMaxStreamBlocks;
+  hipLaunchKernelGGL(da_ins_dropout_rows_kernel, dim3((int)blocks), dim3(256), 0, as_stream(stream),
+                     reinterpret_cast<const float4*>(h1), reinterpret_cast<const float4*>(masks),
+                     reinterpret_cast<float4*>(out), numel_per_pass / 4, passes);
+  return check_launch("da_ins_dropout_rows");
+}
+
+extern "C" int dadet_da_ins_merge(const float* g, const float* masks, const float* h1, const float* grl, float* g_w,
+                                  float* g_x, int64_t numel_per_pass, int passes, void* stream) {
+  DADET_REQUIRE(numel_per_pass >= 0 && numel_per_pass % 4 == 0 && passes > 0, "da_ins_merge: bad dims");
+  if (numel_per_pass == 0) return DADET_OK;
+  DADET_REQUIRE(g && masks && h1 && grl && g_w && a16(g) && a16(masks) && a16(h1) && a16(g_w) && a16(g_x),
+                "da_ins_merge: bad pointers");
+  int64_t blocks = ceil_div64(numel_per_pass / 4, 256);
+  if (blocks > kMaxStreamBlocks) blocks = kMaxStreamBlocks;
+  hipLaunchKernelGGL(da_ins_merge_kernel, dim3((int)blocks), dim3(256), 0, as_stream(stream),
+                     reinterpret_cast<const float4*>(g), reinterpret_cast<const float4*>(masks),
+                     reinterpret_cast<const float4*>(h1), grl, reinterpret_cast<float4*>(g_w),
+                     reinterpret_cast<float4*>(g_x), numel_per_pass / 4, passes);
+  return check_launch("da_ins_merge");
 }

@@ -24,7 +24,18 @@ namespace dadet {
 
 struct DeformGeom {
   int N, H, W, C, KH, KW, stride, pad, dil, dg, Ho, Wo;
+  // floats per output pixel of the offset / mask / offset-gradient / mask-gradient tensors (dense: dg*2*T and dg*T).
+  // Larger strides let the kernels read offsets and modulation logits straight out of the offset-predicting conv's
+  // (channel-padded) output and write their gradients straight into that conv's output-gradient tensor — no slices,
+  // no concatenation (DFConv2d, layers/misc.py:187-188 of the vendored tree slices [:, :18] and [:, -9:])
+  int off_ld, mask_ld, goff_ld, gmask_ld;
+  int mask_sigmoid;   // the mask tensor holds LOGITS: modulation = sigmoid(logit), gmask is the gradient w.r.t. the logit
 };
+
+__device__ inline float modulation(const float* __restrict__ msk_m, int idx, int sig) {
+  const float v = msk_m[idx];
+  return sig ? 1.f / (1.f + expf(-v)) : v;
+}
 
 struct Corner {
   bool valid;           // sample inside (-1,H) x (-1,W)
@@ -70,15 +81,15 @@ __global__ __launch_bounds__(256) void deform_sample_fwd_kernel(const float* __r
   const int T = g.KH * g.KW;
   const int cpg = g.C / g.dg;
   const float* __restrict__ img = x + (size_t)n * g.H * g.W * g.C;
-  const float* __restrict__ off_m = offset + (size_t)m * g.dg * 2 * T;
-  const float* __restrict__ msk_m = mask ? mask + (size_t)m * g.dg * T : nullptr;
+  const float* __restrict__ off_m = offset + (size_t)m * g.off_ld;
+  const float* __restrict__ msk_m = mask ? mask + (size_t)m * g.mask_ld : nullptr;
   float* __restrict__ col_m = cols + (size_t)m * T * g.C;
   for (int tap = 0; tap < T; ++tap) {
     const int i = tap / g.KW, j = tap - i * g.KW;
     for (int c = threadIdx.x * 4; c < g.C; c += blockDim.x * 4) {
       const int grp = c / cpg;
       const float oh = off_m[grp * 2 * T + 2 * tap], ow = off_m[grp * 2 * T + 2 * tap + 1];
-      const float mk = msk_m ? msk_m[grp * T + tap] : 1.f;
+      const float mk = msk_m ? modulation(msk_m, grp * T + tap, g.mask_sigmoid) : 1.f;
       const float h_im = (float)(ho * g.stride - g.pad + i * g.dil) + oh;
       const float w_im = (float)(wo * g.stride - g.pad + j * g.dil) + ow;
       const Corner k = corner_of(h_im, w_im, g.H, g.W);
@@ -115,11 +126,11 @@ __global__ __launch_bounds__(256) void deform_sample_bwd_kernel(const float* __r
   const int cpg = g.C / g.dg;
   const float* __restrict__ img = x + (size_t)n * g.H * g.W * g.C;
   float* __restrict__ gimg = gx ? gx + (size_t)n * g.H * g.W * g.C : nullptr;
-  const float* __restrict__ off_m = offset + (size_t)m * g.dg * 2 * T;
-  const float* __restrict__ msk_m = mask ? mask + (size_t)m * g.dg * T : nullptr;
+  const float* __restrict__ off_m = offset + (size_t)m * g.off_ld;
+  const float* __restrict__ msk_m = mask ? mask + (size_t)m * g.mask_ld : nullptr;
   const float* __restrict__ gcol_m = gcols + (size_t)m * T * g.C;
-  float* __restrict__ goff_m = goffset + (size_t)m * g.dg * 2 * T;
-  float* __restrict__ gmsk_m = gmask ? gmask + (size_t)m * g.dg * T : nullptr;
+  float* __restrict__ goff_m = goffset + (size_t)m * g.goff_ld;
+  float* __restrict__ gmsk_m = gmask ? gmask + (size_t)m * g.gmask_ld : nullptr;
   const bool wave_uniform_group = (cpg % 256) == 0 || g.dg == 1;  // all 64 lanes of a wave in one group
   for (int tap = 0; tap < T; ++tap) {
     const int i = tap / g.KW, j = tap - i * g.KW;
@@ -129,7 +140,7 @@ __global__ __launch_bounds__(256) void deform_sample_bwd_kernel(const float* __r
       const int cc = active ? c : 0;
       const int grp = cc / cpg;
       const float oh = off_m[grp * 2 * T + 2 * tap], ow = off_m[grp * 2 * T + 2 * tap + 1];
-      const float mk = msk_m ? msk_m[grp * T + tap] : 1.f;
+      const float mk = msk_m ? modulation(msk_m, grp * T + tap, g.mask_sigmoid) : 1.f;
       const float h_im = (float)(ho * g.stride - g.pad + i * g.dil) + oh;
       const float w_im = (float)(wo * g.stride - g.pad + j * g.dil) + ow;
       const Corner k = corner_of(h_im, w_im, g.H, g.W);
@@ -162,6 +173,7 @@ __global__ __launch_bounds__(256) void deform_sample_bwd_kernel(const float* __r
           d_m += gv[e] * (w1 * a1[e] + w2 * a2[e] + w3 * a3[e] + w4 * a4[e]);
         }
         if (!k.valid) d_h = d_w = 0.f;
+        if (g.mask_sigmoid) d_m = d_m * mk * (1.f - mk);
       }
       if (wave_uniform_group) {
         d_h = wave_sum_f(d_h);
@@ -218,15 +230,15 @@ __global__ __launch_bounds__(256) void deform_sample_bwd_lds_kernel(const float*
     const int ho = y0 + p / kDTile, wo = x0 + p % kDTile;
     if (ho >= g.Ho || wo >= g.Wo) continue;      // wave-uniform
     const size_t m = ((size_t)n * g.Ho + ho) * g.Wo + wo;
-    const float* __restrict__ off_m = offset + m * g.dg * 2 * T;
-    const float* __restrict__ msk_m = mask ? mask + m * g.dg * T : nullptr;
+    const float* __restrict__ off_m = offset + m * g.off_ld;
+    const float* __restrict__ msk_m = mask ? mask + m * g.mask_ld : nullptr;
     const float* __restrict__ gcol_m = gcols + m * T * g.C;
-    float* __restrict__ goff_m = goffset + m * g.dg * 2 * T;
-    float* __restrict__ gmsk_m = gmask ? gmask + m * g.dg * T : nullptr;
+    float* __restrict__ goff_m = goffset + m * g.goff_ld;
+    float* __restrict__ gmsk_m = gmask ? gmask + m * g.gmask_ld : nullptr;
     for (int tap = 0; tap < T; ++tap) {
       const int i = tap / g.KW, j = tap - i * g.KW;
       const float oh = off_m[grp * 2 * T + 2 * tap], ow = off_m[grp * 2 * T + 2 * tap + 1];
-      const float mk = msk_m ? msk_m[grp * T + tap] : 1.f;
+      const float mk = msk_m ? modulation(msk_m, grp * T + tap, g.mask_sigmoid) : 1.f;
       const float h_im = (float)(ho - g.pad + i * g.dil) + oh;
       const float w_im = (float)(wo - g.pad + j * g.dil) + ow;
       const Corner k = corner_of(h_im, w_im, g.H, g.W);
@@ -253,6 +265,7 @@ __global__ __launch_bounds__(256) void deform_sample_bwd_lds_kernel(const float*
       float d_w = ge * (hh * (a2 - a1) + k.lh * (a4 - a3));
       float d_m = gv * (w1 * a1 + w2 * a2 + w3 * a3 + w4 * a4);
       if (!k.valid) d_h = d_w = 0.f;
+      if (g.mask_sigmoid) d_m = d_m * mk * (1.f - mk);
       if (uniform_group) {
         d_h = wave_sum_f(d_h);
         d_w = wave_sum_f(d_w);
@@ -297,33 +310,50 @@ using namespace dadet;
 
 static bool al16d(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
-extern "C" int dadet_deform_sample_forward(const float* x, const float* offset, const float* mask, float* cols,
-                                           int N, int H, int W, int C, int KH, int KW, int stride, int pad,
-                                           int dil, int deformable_groups, int Ho, int Wo, void* stream) {
-  int rc = deform_check("deform_sample_forward", N, H, W, C, KH, KW, stride, pad, dil, deformable_groups, Ho, Wo);
+static int deform_sample_forward_impl(const float* x, const float* offset, const float* mask, float* cols, DeformGeom g,
+                                      void* stream) {
+  int rc = deform_check("deform_sample_forward", g.N, g.H, g.W, g.C, g.KH, g.KW, g.stride, g.pad, g.dil, g.dg, g.Ho, g.Wo);
   if (rc) return rc;
-  if (N == 0) return DADET_OK;
+  if (g.N == 0) return DADET_OK;
   DADET_REQUIRE(x && offset && cols && al16d(x) && al16d(cols), "deform_sample_forward: bad pointers");
-  DeformGeom g{N, H, W, C, KH, KW, stride, pad, dil, deformable_groups, Ho, Wo};
-  const int threads = (C / 4 >= 256) ? 256 : ((C / 4 + 63) / 64) * 64;
-  hipLaunchKernelGGL(deform_sample_fwd_kernel, dim3((unsigned)(N * Ho * Wo)), dim3(threads), 0,
+  const int T = g.KH * g.KW;
+  DADET_REQUIRE(g.off_ld >= g.dg * 2 * T && (!mask || g.mask_ld >= g.dg * T), "deform_sample_forward: row stride too small");
+  const int threads = (g.C / 4 >= 256) ? 256 : ((g.C / 4 + 63) / 64) * 64;
+  hipLaunchKernelGGL(deform_sample_fwd_kernel, dim3((unsigned)(g.N * g.Ho * g.Wo)), dim3(threads), 0,
                      as_stream(stream), x, offset, mask, cols, g);
   return check_launch("deform_sample_forward");
 }
 
-extern "C" int dadet_deform_sample_backward(const float* x, const float* offset, const float* mask,
-                                            const float* gcols, float* gx, float* goffset, float* gmask, int N,
-                                            int H, int W, int C, int KH, int KW, int stride, int pad, int dil,
-                                            int deformable_groups, int Ho, int Wo, void* stream) {
-  int rc = deform_check("deform_sample_backward", N, H, W, C, KH, KW, stride, pad, dil, deformable_groups, Ho, Wo);
+extern "C" int dadet_deform_sample_forward(const float* x, const float* offset, const float* mask, float* cols,
+                                           int N, int H, int W, int C, int KH, int KW, int stride, int pad,
+                                           int dil, int deformable_groups, int Ho, int Wo, void* stream) {
+  const int T = KH * KW, dg = deformable_groups;
+  DeformGeom g{N, H, W, C, KH, KW, stride, pad, dil, dg, Ho, Wo, dg * 2 * T, dg * T, dg * 2 * T, dg * T, 0};
+  return deform_sample_forward_impl(x, offset, mask, cols, g, stream);
+}
+
+extern "C" int dadet_deform_sample_forward_ld(const float* x, const float* offset, int offset_ld, const float* mask,
+                                              int mask_ld, int mask_is_logit, float* cols, int N, int H, int W, int C,
+                                              int KH, int KW, int stride, int pad, int dil, int deformable_groups,
+                                              int Ho, int Wo, void* stream) {
+  DeformGeom g{N, H, W, C, KH, KW, stride, pad, dil, deformable_groups, Ho, Wo, offset_ld, mask_ld, 0, 0, mask_is_logit};
+  return deform_sample_forward_impl(x, offset, mask, cols, g, stream);
+}
+
+static int deform_sample_backward_impl(const float* x, const float* offset, const float* mask, const float* gcols,
+                                       float* gx, float* goffset, float* gmask, DeformGeom g, void* stream) {
+  int rc = deform_check("deform_sample_backward", g.N, g.H, g.W, g.C, g.KH, g.KW, g.stride, g.pad, g.dil, g.dg, g.Ho, g.Wo);
   if (rc) return rc;
-  if (N == 0) return DADET_OK;
+  if (g.N == 0) return DADET_OK;
   DADET_REQUIRE(x && offset && gcols && goffset && al16d(x) && al16d(gcols), "deform_sample_backward: bad pointers");
   DADET_REQUIRE(!mask == !gmask || !gmask, "deform_sample_backward: gmask needs mask");
-  DeformGeom g{N, H, W, C, KH, KW, stride, pad, dil, deformable_groups, Ho, Wo};
+  const int T = g.KH * g.KW;
+  DADET_REQUIRE(g.off_ld >= g.dg * 2 * T && g.goff_ld >= g.dg * 2 * T && (!mask || g.mask_ld >= g.dg * T) &&
+                    (!gmask || g.gmask_ld >= g.dg * T),
+                "deform_sample_backward: row stride too small");
   static const bool allow_lds = !(getenv("DADET_DEFORM_BWD_LDS") && getenv("DADET_DEFORM_BWD_LDS")[0] == '0');
-  if (allow_lds && stride == 1 && dil * (KH - 1) <= 2 && dil * (KW - 1) <= 2 && C % kDChunk == 0) {
-    const int tiles_x = ceil_div(Wo, kDTile), tiles_y = ceil_div(Ho, kDTile);
+  if (allow_lds && g.stride == 1 && g.dil * (g.KH - 1) <= 2 && g.dil * (g.KW - 1) <= 2 && g.C % kDChunk == 0) {
+    const int tiles_x = ceil_div(g.Wo, kDTile), tiles_y = ceil_div(g.Ho, kDTile);
     const size_t lds = sizeof(float) * kDWin * kDWin * kDChunk;
     static bool attr_set = false;
     if (!attr_set) {
@@ -335,15 +365,34 @@ extern "C" int dadet_deform_sample_backward(const float* x, const float* offset,
       }
       attr_set = true;
     }
-    hipLaunchKernelGGL(deform_sample_bwd_lds_kernel, dim3((unsigned)(N * tiles_x * tiles_y), (unsigned)(C / kDChunk)),
+    hipLaunchKernelGGL(deform_sample_bwd_lds_kernel, dim3((unsigned)(g.N * tiles_x * tiles_y), (unsigned)(g.C / kDChunk)),
                        dim3(256), lds, as_stream(stream), x, offset, mask, gcols, gx, goffset, gmask, g, tiles_x,
                        tiles_y);
     return check_launch("deform_sample_backward(lds)");
   }
-  const int threads = (C / 4 >= 256) ? 256 : ((C / 4 + 63) / 64) * 64;
-  hipLaunchKernelGGL(deform_sample_bwd_kernel, dim3((unsigned)(N * Ho * Wo)), dim3(threads), 0,
+  const int threads = (g.C / 4 >= 256) ? 256 : ((g.C / 4 + 63) / 64) * 64;
+  hipLaunchKernelGGL(deform_sample_bwd_kernel, dim3((unsigned)(g.N * g.Ho * g.Wo)), dim3(threads), 0,
                      as_stream(stream), x, offset, mask, gcols, gx, goffset, gmask, g);
   return check_launch("deform_sample_backward");
+}
+
+extern "C" int dadet_deform_sample_backward(const float* x, const float* offset, const float* mask,
+                                            const float* gcols, float* gx, float* goffset, float* gmask, int N,
+                                            int H, int W, int C, int KH, int KW, int stride, int pad, int dil,
+                                            int deformable_groups, int Ho, int Wo, void* stream) {
+  const int T = KH * KW, dg = deformable_groups;
+  DeformGeom g{N, H, W, C, KH, KW, stride, pad, dil, dg, Ho, Wo, dg * 2 * T, dg * T, dg * 2 * T, dg * T, 0};
+  return deform_sample_backward_impl(x, offset, mask, gcols, gx, goffset, gmask, g, stream);
+}
+
+extern "C" int dadet_deform_sample_backward_ld(const float* x, const float* offset, int offset_ld, const float* mask,
+                                               int mask_ld, int mask_is_logit, const float* gcols, float* gx,
+                                               float* goffset, int goffset_ld, float* gmask, int gmask_ld, int N, int H,
+                                               int W, int C, int KH, int KW, int stride, int pad, int dil,
+                                               int deformable_groups, int Ho, int Wo, void* stream) {
+  DeformGeom g{N, H, W, C, KH, KW, stride, pad, dil, deformable_groups, Ho, Wo, offset_ld, mask_ld, goffset_ld, gmask_ld,
+               mask_is_logit};
+  return deform_sample_backward_impl(x, offset, mask, gcols, gx, goffset, gmask, g, stream);
 }
 
 // ------------------------------------------------------------------------------------------------

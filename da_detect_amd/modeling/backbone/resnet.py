@@ -113,6 +113,116 @@ class _BottleneckFn(torch.autograd.Function):
         return (dx, dw1, dw2, dw3, dwd) + (None,) * 12
 
 
+class _DCNBottleneckFn(torch.autograd.Function):
+    """A bottleneck whose 3x3 is a deformable convolution (vendored tree: modeling/backbone/resnet.py:286-312 with
+    layers/misc.py:114-203 `DFConv2d` as conv2) as ONE autograd node, with the plain block's epilogue fusions:
+
+    forward : y1 = relu(bn1(conv1(x)))                                          1 GEMM launch
+              om = offset_conv(y1)          (3x3, bias; 18 | 27 channels padded to 20 | 28)   1 GEMM launch
+              cols = deform_sample(y1, om)  (offsets / modulation logits read in place, sigmoid inside)   1 launch
+              y2 = relu(bn2(cols (*) W2))   (1x1 GEMM over K = 9 * C, affine + ReLU in its epilogue)      1 GEMM launch
+              out = relu(bn3(conv3(y2)) + identity)                              1 - 2 GEMM launches
+    backward: S3, S2 as in _BottleneckFn (gates in the dgrad epilogues); gcols = S2 (*) (s2 W2)^T; the sampling backward
+              gives d y1 (sampled path) and d om (written into the offset conv's padded output gradient in place); the
+              offset conv's data gradient ADDS d y1 of the sampled path and applies y1's ReLU gate in its epilogue:
+              S1 = [y1 > 0] * (dgrad_off(d om) + d y1).  No standalone affine / ReLU / ReLU-backward / concatenation
+              kernel runs (the per-conv path used ~14 of them per block).
+    The reference runs bn2 and the ReLU as separate modules after DFConv2d and materialises offset / mask slices."""
+
+    @staticmethod
+    def forward(ctx, x, w1, w2, w3, wd, w_off, b_off, s1, b1, s2, b2, s3, b3, sd, bd, stride, in_relu, out_private,
+                modulated, dg):
+        cout2, cin2, kh, kw = w2.shape
+        y1 = _C.conv_forward(x, w1, s1, b1, stride=stride, relu_mode=1)
+        wo4, bo4 = _pad_out_channels(w_off, b_off)
+        om = _C.conv_forward(y1, wo4, None, bo4, pad=kh // 2)
+        cols = _C.deform_sample_forward_om(y1, om, kh, kw, 1, kh // 2, 1, dg, modulated)
+        y2 = _C.conv_forward(cols, _as_1x1(w2), s2, b2, relu_mode=1)
+        idn = x if wd is None else _C.conv_forward(x, wd, sd, bd, stride=stride)
+        out = _C.conv_forward(y2, w3, s3, b3, addend=idn, relu_mode=1)
+        ctx.conf = (stride, in_relu, out_private, modulated, dg, kh, kw, w_off.shape[0])
+        ctx.save_for_backward(x, y1, om, cols, y2, out, w1, w2, w3, wd, wo4, s1, s2, s3, sd)
+        return out
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, G):
+        x, y1, om, cols, y2, out, w1, w2, w3, wd, wo4, s1, s2, s3, sd = ctx.saved_tensors
+        stride, in_relu, out_private, modulated, dg, kh, kw, n_offch = ctx.conf
+        need_x, n1, n2, n3, nd, n_off, n_boff = ctx.needs_input_grad[:7]
+        cout2, cin2 = w2.shape[0], w2.shape[1]
+        S3 = G.contiguous(memory_format=torch.channels_last) if out_private else _C.relu_bn_backward(G, out, None)[1]
+        dw1 = dw2 = dw3 = dwd = dx = dwo = dbo = None
+        lane = WgradLane(G.device, rows=G.shape[0] * G.shape[2] * G.shape[3])
+        batch = _C.WgradBatch() if _WGRAD_BATCH else None
+
+        def wgrad(w, xin, gout, st, pd, sc, shape=None):
+            shape = tuple(w.shape) if shape is None else shape
+            return lane.run_into(w, lambda acc: _C.conv_wgrad(xin, gout, shape, st, pd, out_scale=sc, dw=acc,
+                                                              accumulate=True, pending=batch),
+                                 lambda: _C.conv_wgrad(xin, gout, shape, st, pd, out_scale=sc, pending=batch),
+                                 xin, gout)
+
+        if n3:
+            dw3 = wgrad(w3, y2, S3, 1, 0, s3)
+        S2 = _C.conv_forward(S3, _C.conv_weight_transpose(w3, s3), relu_mode=2, mask_ref=y2)
+        w2_1x1 = _as_1x1(w2)
+        if n2:
+            # [Cout][kh][kw][Cin] IS the 1x1 weight [Cout][K = (tap, ci)]: the gradient lands in w2's own layout
+            dw2 = wgrad(w2, cols, S2, 1, 0, s2, shape=(cout2, kh * kw * cin2, 1, 1))
+        gcols = _C.conv_forward(S2, _C.conv_weight_transpose(w2_1x1, s2))
+        gy1, gom = _C.deform_sample_backward_om(y1, om, gcols, kh, kw, 1, kh // 2, 1, dg, modulated)
+        if n_off:    # with the block's other weight gradients (same stream, same batched reduction pass)
+            dwo = lane.run(lambda: _C.conv_wgrad(y1, gom, tuple(wo4.shape), 1, kh // 2, pending=batch), y1, gom)
+        if n_boff:
+            dbo = _C.colsum(gom)[:n_offch]
+        # d y1 = [y1 > 0] * (sampled path + offset-conv path)
+        S1 = _C.conv_forward(gom, _C.conv_weight_transpose(wo4), pad=kh // 2, addend=gy1, out=gy1, relu_mode=2,
+                             mask_ref=y1)
+        if n1:
+            dw1 = wgrad(w1, x, S1, stride, 0, s1)
+        if nd and wd is not None:
+            dwd = wgrad(wd, x, S3, stride, 0, sd)
+        lane.reduce_batch(batch)
+        if need_x:
+            gate = dict(relu_mode=2, mask_ref=x) if in_relu else {}
+            hw = tuple(x.shape[2:])
+            if wd is None:
+                dx = _C.conv_forward(S1, _C.conv_weight_transpose(w1, s1), addend=S3, **gate)
+            elif stride == 1:
+                t = _C.conv_forward(S3, _C.conv_weight_transpose(wd, sd))
+                dx = _C.conv_forward(S1, _C.conv_weight_transpose(w1, s1), addend=t, out=t, **gate)
+            else:
+                t = _C.conv_forward(S3, _C.conv_weight_transpose(wd, sd), out_spatial_stride=stride, out_hw=hw)
+                dx = _C.conv_forward(S1, _C.conv_weight_transpose(w1, s1), addend=t, out=t,
+                                     out_spatial_stride=stride, out_hw=hw, **gate)
+        lane.join()
+        if dwo is not None:
+            dwo = dwo[:n_offch]
+        if dw2 is not None:     # returned to autograd (no persistent gradient buffer): back in w2's logical shape
+            dw2 = torch.as_strided(dw2, (cout2, cin2, kh, kw), (kh * kw * cin2, 1, kw * cin2, cin2))
+        return (dx, dw1, dw2, dw3, dwd, dwo, dbo) + (None,) * 13
+
+
+def _as_1x1(weight):
+    """[Cout,Cin,kh,kw] (physically [Cout][kh][kw][Cin]) -> the same bytes as [Cout, kh*kw*Cin, 1, 1], K = (tap, ci)"""
+    cout, cin, kh, kw = weight.shape
+    return weight.contiguous(memory_format=torch.channels_last).permute(0, 2, 3, 1).reshape(cout, kh * kw * cin, 1, 1)
+
+
+def _pad_out_channels(weight, bias):
+    """zero output channels appended up to a multiple of 4 (16-byte rows for the kernels that contract over them)"""
+    pad = (-weight.shape[0]) % 4
+    if pad == 0:
+        return weight, bias
+    w = F.pad(weight, (0, 0, 0, 0, 0, 0, 0, pad)).contiguous(memory_format=torch.channels_last)
+    return w, (F.pad(bias, (0, pad)) if bias is not None else None)
+
+
+# DADET_DCN_FUSED=0: DCN bottlenecks on the per-conv autograd path (DFConv2d module + standalone bn2 / ReLU kernels)
+_DCN_FUSED = __import__("os").environ.get("DADET_DCN_FUSED", "1") == "1"
+
+
 class Bottleneck(nn.Module):
     """1x1 (carries the stride when stride_in_1x1) -> 3x3 -> 1x1, FrozenBN after each, projection shortcut
     when the channel count changes (resnet.py:227-314)."""
@@ -158,6 +268,15 @@ class Bottleneck(nn.Module):
         stride: overrides the stride of conv1 and the shortcut (see input_is_strided_1x1) — fused path only"""
         if self.with_dcn:
             assert stride is None
+            if self._dcn_fusable(x):
+                c2 = self.conv2
+                wd = sd = bd = None
+                if self.downsample is not None:
+                    wd, (sd, bd) = self.downsample[0].weight, self.downsample[1].folded()
+                return _DCNBottleneckFn.apply(x, self.conv1.weight, c2.conv.weight, self.conv3.weight, wd,
+                                              c2.offset.weight, c2.offset.bias, *self.bn1.folded(), *self.bn2.folded(),
+                                              *self.bn3.folded(), sd, bd, self.conv1.stride[0], in_relu, out_private,
+                                              c2.with_modulated_dcn, c2.conv.deformable_groups)
             return self._forward_dcn(x)
         if self.conv2.stride[0] == 1:   # STRIDE_IN_1X1: the stride (if any) sits in conv1 and the shortcut
             if x.shape[0] == 0 and stride is None:
@@ -182,7 +301,17 @@ class Bottleneck(nn.Module):
         return 1
 
     def uses_fused_path(self):
-        return (not self.with_dcn) and self.conv2.stride[0] == 1
+        if self.with_dcn:
+            return self._dcn_fusable(None)
+        return self.conv2.stride[0] == 1
+
+    def _dcn_fusable(self, x):
+        """the fused node covers what the DA configurations use: 3x3 deformable conv of stride 1 (STRIDE_IN_1X1) without
+        bias, one group; anything else takes the per-conv path"""
+        c = self.conv2.conv
+        ok = (_DCN_FUSED and c.stride == 1 and c.dilation == 1 and c.groups == 1 and c.bias is None
+              and c.kernel_size == (3, 3) and c.in_channels % (4 * c.deformable_groups) == 0)
+        return ok and (x is None or (x.is_cuda and x.shape[0] > 0))
 
     def _forward_dcn(self, x):
         """conv2 is a DFConv2d (offset conv + deformable conv): bn2 + ReLU run as the standalone affine kernel"""

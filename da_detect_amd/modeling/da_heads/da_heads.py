@@ -15,7 +15,7 @@ from ...layers import Conv2d, GradientScalarLayer, global_avg_pool, linear
 from ...layers.misc import gradient_scalar
 from ...utils import rng
 from ...utils.streams import other_stream
-from .fused import da_image_head
+from .fused import INS_DROPOUT_P, da_image_head, da_instance_head
 from .loss import TripletMargins, da_consist_loss, da_ins_loss, image_domain_labels
 
 
@@ -77,6 +77,38 @@ class DAInsHead(nn.Module):
         if self.training:
             x = x * rng.dropout_mask(tuple(x.shape), 0.5, x.device)
         return linear(x, self.fc3_da.weight, self.fc3_da.bias)
+
+
+_FUSED_INS = __import__("os").environ.get("DADET_FUSED_INS_HEAD", "1") == "1"   # 0: one DAInsHead.forward per pass + ATen losses
+_GRL_CACHE = {}
+
+
+def _grl_vector(weights, device):
+    """float [P] device tensor of the passes' gradient-reversal weights.  Plain floats come from a cache (a
+    torch.tensor(list, device=...) per step is a blocking host->device copy); 0-d device tensors (AdvGRL) are stacked"""
+    if all(not isinstance(w, torch.Tensor) for w in weights):
+        key = (tuple(float(w) for w in weights), str(device))
+        v = _GRL_CACHE.get(key)
+        if v is None:
+            v = _GRL_CACHE[key] = torch.tensor(key[0], dtype=torch.float32, device=device)
+        return v
+    return torch.stack([w.reshape(()).to(torch.float32) if isinstance(w, torch.Tensor)
+                        else _grl_vector([w], device)[0] for w in weights])
+
+
+def _draw_pass_masks(passes, rows, device):
+    """dropout masks of `passes` head passes in the reference's order of draws (pass by pass: after fc1, after fc2;
+    da_heads.py:63,65) -> (masks1 [P, R, 1024], masks2 [P, R, 1024])"""
+    m1, m2 = [], []
+    for _ in range(passes):
+        m1.append(rng.dropout_mask((rows, 1024), INS_DROPOUT_P, device))
+        m2.append(rng.dropout_mask((rows, 1024), INS_DROPOUT_P, device))
+    return torch.stack(m1), torch.stack(m2)
+
+
+def _n_source_rows(da_ins_labels):
+    n_src = getattr(da_ins_labels, "_n_src_host", None)   # set by the box head, which knows it without a round trip
+    return int(torch.nonzero(da_ins_labels).size(0)) if n_src is None else int(n_src)
 
 
 def _vector_ins_features(cfg):
@@ -179,6 +211,9 @@ class DomainAdaptationModule(torch.nn.Module):
             da_img_loss, _ = self._image_level(img_features, targets)
             return {"loss_da_image": self.img_weight * da_img_loss} if self.img_weight > 0 else {}
         da_ins_feature = _pool_ins(da_ins_feature, self.resnet_backbone)
+        if _FUSED_INS and da_ins_feature.is_cuda and da_ins_feature.shape[0] > 0 \
+                and self.inshead.fc1_da.out_features == 1024 and self.inshead.fc2_da.out_features == 1024:
+            return self._forward_fused_instance(img_features, da_ins_feature, da_ins_labels, targets, early)
         # instance head: adversarial pass then consistency pass, each with its own dropout masks (same program order
         # of the random draws as the reference).  They are independent of the image head: on the GPU they run on a
         # side stream beside it, and the compute stream only waits for them if a loss uses them.
@@ -209,6 +244,41 @@ class DomainAdaptationModule(torch.nn.Module):
         if self.cst_weight > 0:
             losses["loss_da_consistency"] = self.cst_weight * da_consist_loss(img_mean_sig, da_ins_consist,
                                                                               da_ins_labels)
+        return losses
+
+    def _forward_fused_instance(self, img_features, feat, da_ins_labels, targets, early):
+        """image head first (the consistency rows read its per-image means), then BOTH instance-head passes and both
+        instance-level losses as one autograd node (fused.da_instance_head).  The dropout masks of both passes are drawn
+        in the reference's order even when a pass's loss weight is 0 (its draws still advance the random stream)."""
+        losses = {}
+        img_mean_sig = None
+        if early is not None:
+            losses["loss_da_image"] = early
+        else:
+            da_img_loss, img_mean_sig = self._image_level(img_features, targets)
+            if self.img_weight > 0:
+                losses["loss_da_image"] = self.img_weight * da_img_loss
+        R = feat.shape[0]
+        masks1, masks2 = _draw_pass_masks(2, R, feat.device)       # adversarial pass, then consistency pass
+        kinds, grl, sel = [], [], []
+        if self.ins_weight > 0:
+            kinds.append("bce"), grl.append(self.grl_ins.weight), sel.append(0)
+        if self.cst_weight > 0:
+            kinds.append("cst"), grl.append(self.grl_ins_consist.weight), sel.append(1)
+        if not kinds:
+            return losses
+        if len(sel) == 1:
+            masks1, masks2 = masks1[sel[0]:sel[0] + 1], masks2[sel[0]:sel[0] + 1]
+        means = torch.stack(list(img_mean_sig)) if self.cst_weight > 0 else None        # [levels, 2]
+        if means is not None:
+            assert means.shape[1] == 2, \
+                "only batch size=2 is supported for consistency loss now, received batch size: {}".format(means.shape[1])
+        bce, cst, _ = da_instance_head(feat, self.inshead, da_ins_labels, means, masks1, masks2,
+                                       _grl_vector(grl, feat.device), kinds, _n_source_rows(da_ins_labels))
+        if self.ins_weight > 0:
+            losses["loss_da_instance"] = self.ins_weight * bce
+        if self.cst_weight > 0:
+            losses["loss_da_consistency"] = self.cst_weight * cst
         return losses
 
 
@@ -286,6 +356,12 @@ class DomainAdaptationModule_triplet(torch.nn.Module):
                                                              self.grl_img_consist.weight)
             if self.img_weight > 0:
                 losses["loss_da_image"] = self.img_weight * da_img_loss
+        fused_ins = (_FUSED_INS and (self.ins_weight > 0 or self.cst_weight > 0) and da_ins_feature is not None
+                     and da_ins_feature.is_cuda and da_ins_feature.shape[0] > 0)
+        if fused_ins:
+            losses.update(self._fused_instance_losses(_pool_ins(da_ins_feature, self.resnet_backbone), da_ins_labels,
+                                                      img_mean_sig if self.cst_weight > 0 else None))
+            return losses
         if self.ins_weight > 0:
             feat = _pool_ins(da_ins_feature, self.resnet_backbone)
             cur = da_ins_loss(self.inshead(feat.detach()), da_ins_labels)  # own dropout draws, as the reference
@@ -301,6 +377,43 @@ class DomainAdaptationModule_triplet(torch.nn.Module):
             losses["loss_da_consistency"] = self.cst_weight * da_consist_loss(img_mean_sig, ins_consist,
                                                                               da_ins_labels)
         return losses
+
+
+def _triplet_fused_instance_losses(self, feat, da_ins_labels, img_mean_sig):
+    """instance-level BCE (da_heads.py:147-169, with the AdvGRL weight of :173-195) and consistency (:276-291) of the
+    component-wise module through fused.da_instance_head.  Order of the dropout draws as in the reference: the detached
+    "current loss" pass, the adversarial pass, the consistency pass."""
+    R, dev = feat.shape[0], feat.device
+    n_src = _n_source_rows(da_ins_labels)
+    kinds, grl = [], []
+    if self.ins_weight > 0:
+        m1, m2 = _draw_pass_masks(1, R, dev)
+        w = self.grl_ins.weight
+        if self.advGRL:
+            with torch.no_grad():     # the value the reference detaches (da_heads.py:150-152): forward only
+                cur, _, _ = da_instance_head(feat.detach(), self.inshead, da_ins_labels, None, m1, m2,
+                                             _grl_vector([0.0], dev), ("bce",), n_src)
+            w = self.adv_grl_weight(cur, -self.grl_ins.weight, self.adv_ins_weight)
+        kinds.append("bce"), grl.append(w)
+    if self.cst_weight > 0:
+        kinds.append("cst"), grl.append(self.grl_ins_consist.weight)
+    masks1, masks2 = _draw_pass_masks(len(kinds), R, dev)
+    means = None
+    if self.cst_weight > 0:
+        means = torch.stack(list(img_mean_sig) if isinstance(img_mean_sig, (list, tuple)) else [img_mean_sig])
+        assert means.shape[1] == 2, \
+            "only batch size=2 is supported for consistency loss now, received batch size: {}".format(means.shape[1])
+    bce, cst, _ = da_instance_head(feat, self.inshead, da_ins_labels, means, masks1, masks2, _grl_vector(grl, dev), kinds,
+                                   n_src)
+    out = {}
+    if self.ins_weight > 0:
+        out["loss_da_instance"] = self.ins_weight * bce
+    if self.cst_weight > 0:
+        out["loss_da_consistency"] = self.cst_weight * cst
+    return out
+
+
+DomainAdaptationModule_triplet._fused_instance_losses = _triplet_fused_instance_losses
 
 
 def build_da_heads(cfg):

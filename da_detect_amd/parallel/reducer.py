@@ -142,10 +142,10 @@ class BucketedGradReducer(object):
                     b["flat"].mul_(1.0 / self.world_size)
         self.mean_scale = 1.0 if (mean or self.world_size == 1) else 1.0 / self.world_size
         self._finalized = True
-        if self.world_size > 1:
+        if self.communicate:
             if self.static_unused is None and self.learn_unused:
                 self._learn_unused()
-            elif self.static_unused is None:
+            elif self.static_unused is None and self.world_size > 1:
                 self._agree_touched()
 
     def _agree_touched(self):
@@ -173,7 +173,7 @@ class BucketedGradReducer(object):
         """end of the first step: the parameters that NO rank touched (agreed on through one all-reduce of a mask)"""
         dev = self.buckets[0]["flat"].device if self.buckets else torch.device("cpu")
         mask = torch.tensor([0.0 if id(p) in self.touched else 1.0 for p in self.params], dtype=torch.float32, device=dev)
-        if self.world_size > 1 and mask.numel():
+        if self.communicate and mask.numel():
             dist.all_reduce(mask, op=dist.ReduceOp.MIN, group=self.group)
         self.static_unused = frozenset(id(p) for p, m in zip(self.params, mask.tolist()) if m > 0.5)
 

@@ -205,6 +205,19 @@ int dadet_deform_sample_backward(const float* x, const float* offset, const floa
                                  float* gx, float* goffset, float* gmask, int N, int H, int W, int C, int KH,
                                  int KW, int stride, int pad, int dil, int deformable_groups, int Ho, int Wo,
                                  void* stream);
+/* The same two operators reading offsets / modulation straight out of the offset-predicting convolution's output and
+ * writing their gradients straight into that convolution's output gradient (DFConv2d: vendored layers/misc.py:114-203
+ * slices `[:, :18]` / `[:, -9:]` out of one conv output and autograd concatenates the slice gradients back).  `*_ld` =
+ * floats per output pixel of the tensor the pointer points into (>= dg*2*KH*KW resp. dg*KH*KW); mask_is_logit != 0: the
+ * mask tensor holds the conv's raw output, modulation = sigmoid(logit) is applied here and gmask is the gradient w.r.t.
+ * the logit (misc.py:188 `.sigmoid()` folded in). */
+int dadet_deform_sample_forward_ld(const float* x, const float* offset, int offset_ld, const float* mask, int mask_ld,
+                                   int mask_is_logit, float* cols, int N, int H, int W, int C, int KH, int KW, int stride,
+                                   int pad, int dil, int deformable_groups, int Ho, int Wo, void* stream);
+int dadet_deform_sample_backward_ld(const float* x, const float* offset, int offset_ld, const float* mask, int mask_ld,
+                                    int mask_is_logit, const float* gcols, float* gx, float* goffset, int goffset_ld,
+                                    float* gmask, int gmask_ld, int N, int H, int W, int C, int KH, int KW, int stride,
+                                    int pad, int dil, int deformable_groups, int Ho, int Wo, void* stream);
 
 /* ROIPool — replaces `_C.roi_pool_forward / roi_pool_backward` (csrc/vision.cpp:11-12, ROIPool.h:11-46,
  * cuda/ROIPool_cuda.cu:16-108).  input [B][H][W][C] NHWC, rois [R][5] = (batch, x1, y1, x2, y2), output and
@@ -402,6 +415,32 @@ int dadet_da_img_head_loss_backward(const float* t, const float* w2, const float
  * eps, hinge with margin, loss_sum[0] += sum over (h,c) (the caller zeroes it and divides by H*C).
  * dist_out [H*C][2] keeps (d_ap, d_an) for the backward; g_scale[0] = upstream grad / (H*C).
  * reference: da_heads/loss.py:180-200 (nn.TripletMarginLoss(margin, p=2) on [1,C,H,W]). */
+/* Instance-level domain classifier tail — replaces, per iteration, the last layer of `DAInsHead.forward`
+ * (modeling/da_heads/da_heads.py:61-68), `F.binary_cross_entropy_with_logits` of the instance logits
+ * (da_heads/loss.py:95-97) and `consistency_loss` (layers/consistency_loss.py:3-27) of the reference's TWO head passes
+ * (behind GRL(-w) and GRL(+w), da_heads.py:421-424), forward and backward.  Rows of the adversarial pass ([R_bce]) and of
+ * the consistency pass ([R_cst]) are stacked in h [R_bce + R_cst][C] (second hidden layer after dropout).
+ *   forward : logits[r] = h[r] . w3 + b3;  sums[0] += sum_r<R_bce BCE(logits[r], labels[r]);
+ *             sums[1] += sum over consistency rows j and levels l of |means[l][j < n_src ? 0 : 1] - sigmoid(logit)|
+ *             (caller zero-fills sums; means [levels][2] = per-level mean sigmoid of the image head on image 0 / 1)
+ *   backward: coef[0] / coef[1] (device) = d loss / d sums[0] / d sums[1];  g_z = gradient w.r.t. fc2's PRE-activation
+ *             (dropout scale inv_keep and ReLU gate folded in); g_w3 / g_b3 / g_means are accumulated (caller zero-fills).
+ * dadet_da_ins_dropout_rows: out[p][r] = h1[r] * masks[p][r] (the passes share the first layer up to its dropout mask).
+ * dadet_da_ins_merge: backward through that shared layer — g_w = [h1 > 0] * sum_p masks[p] * g[p] (parameter gradients),
+ *   g_x = [h1 > 0] * sum_p grl[p] * masks[p] * g[p] (towards the ROI features: the passes' gradient-reversal weights,
+ *   layers/gradient_scalar_layer.py:4-13, device array grl[passes]). */
+int dadet_da_ins_tail_forward(const float* h, const float* w3, const float* b3, const float* labels,
+                              const float* means, float* logits, float* sums, int R_bce, int R_cst, int n_src,
+                              int levels, int C, void* stream);
+int dadet_da_ins_tail_backward(const float* h, const float* w3, const float* logits, const float* labels,
+                               const float* means, const float* coef, float inv_keep, float* g_z, float* g_w3,
+                               float* g_b3, float* g_means, int R_bce, int R_cst, int n_src, int levels, int C,
+                               void* stream);
+int dadet_da_ins_dropout_rows(const float* h1, const float* masks, float* out, int64_t numel_per_pass, int passes,
+                              void* stream);
+int dadet_da_ins_merge(const float* g, const float* masks, const float* h1, const float* grl, float* g_w, float* g_x,
+                       int64_t numel_per_pass, int passes, void* stream);
+
 int dadet_triplet_w_forward(const float* anchor, const float* positive, const float* negative, int H,
                             int W, int C, float margin, float eps, float* dist_out, float* loss_sum,
                             void* stream);

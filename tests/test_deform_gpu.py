@@ -38,6 +38,119 @@ def test_oracle_identities_cpu():
                                F.conv2d(xs, w, None, 1, pad)[:, :, 1:], rtol=1e-5, atol=1e-5)
 
 
+def _border_case(seed, N, C, H, W, Cout, k, stride, dg, modulated):
+    """offsets that put samples at non-integer positions everywhere, inside the border bands (-1, 0) and (H-1, H) /
+    (W-1, W) where only one corner row / column exists, exactly ON the band limits (-1, H: the reference returns 0
+    there), and far outside the map"""
+    x, off, mask, w, b, pad = _case(seed, N, C, H, W, Cout, k, stride, dg, modulated, scale=1.3)
+    T = k * k
+    Ho, Wo = off.shape[2], off.shape[3]
+    g = torch.Generator().manual_seed(seed + 1)
+    off = off.double()
+    ys = (torch.arange(Ho, dtype=torch.float64) * stride - pad).view(Ho, 1)
+    xs = (torch.arange(Wo, dtype=torch.float64) * stride - pad).view(1, Wo)
+    for n in range(N):
+        for grp in range(dg):
+            for tap in range(T):
+                i, j = tap // k, tap % k
+                kind = int(torch.randint(0, 6, (1,), generator=g))
+                cy, cx = grp * 2 * T + 2 * tap, grp * 2 * T + 2 * tap + 1
+                frac = torch.rand((Ho, Wo), generator=g, dtype=torch.float64) * 0.98 + 0.01
+                if kind == 0:      # rows in (-1, 0)
+                    off[n, cy] = -frac - (ys + i)
+                elif kind == 1:    # rows in (H-1, H)
+                    off[n, cy] = (H - 1) + frac - (ys + i)
+                elif kind == 2:    # columns in (W-1, W), rows anywhere
+                    off[n, cx] = (W - 1) + frac - (xs + j)
+                elif kind == 3:    # exactly on the limits: h = -1 on the upper half, w = W on the lower half
+                    off[n, cy, : Ho // 2] = (-1.0 - (ys + i))[: Ho // 2]
+                    off[n, cx, Ho // 2:] = (float(W) - (xs + j)).expand(Ho, Wo)[Ho // 2:]
+                elif kind == 4:    # far outside
+                    off[n, cy] = off[n, cy] + 3.0 * H
+                # kind 5: the random non-integer offsets stay
+    return x, off.float(), mask, w, b, pad
+
+
+BORDER_CASES = [(2, 8, 9, 11, 12, 3, 1, 1, False), (2, 16, 10, 12, 8, 3, 1, 2, True), (1, 64, 12, 9, 16, 3, 1, 1, True),
+                (1, 16, 11, 13, 8, 3, 2, 1, True), (1, 128, 8, 8, 8, 3, 1, 4, False)]
+
+
+@pytest.mark.parametrize("cfg", BORDER_CASES)
+def test_two_independent_oracles_agree_cpu(cfg):
+    """oracle/deform_ref.py (hand-written floor / gather / validity masks) and oracle/deform_ref2.py (grid_sample on a
+    normalised grid, per-tap matmul) were written independently from the CUDA kernels: they must agree in float64 on the
+    forward and on every gradient, on the border-band / on-the-limit / far-outside / modulated / grouped cases"""
+    from oracle import deform_ref as R1
+    from oracle import deform_ref2 as R2
+
+    N, C, H, W, Cout, k, stride, dg, modulated = cfg
+    x, off, mask, w, b, pad = _border_case(sum(cfg[:7]) + 3, *cfg)
+    outs = []
+    for R in (R1, R2):
+        leaves = [t.double().clone().requires_grad_(True) for t in (x, off, w)] + \
+            ([mask.double().clone().requires_grad_(True), b.double().clone().requires_grad_(True)] if modulated else [])
+        y = R.deform_conv2d(leaves[0], leaves[1], leaves[3] if modulated else None, leaves[2],
+                            leaves[4] if modulated else None, stride, pad, 1, dg)
+        gy = torch.randn(y.shape, generator=torch.Generator().manual_seed(1), dtype=torch.float64)
+        y.backward(gy)
+        outs.append((y.detach(), [t.grad for t in leaves]))
+    torch.testing.assert_close(outs[0][0], outs[1][0], rtol=1e-10, atol=1e-10)
+    for name, a, r in zip(["x", "offset", "weight", "mask", "bias"], outs[0][1], outs[1][1]):
+        # on an exact limit / an exact integer position the two formulations may pick different one-sided derivatives
+        # of the (there non-differentiable) bilinear kernel for the OFFSET gradient; everything else is smooth
+        if name == "offset":
+            bad = (a - r).abs() > 1e-8 * (1 + r.abs())
+            assert float(bad.double().mean()) < 0.06, "offset gradients differ on %.1f%% of the entries" % (
+                100 * float(bad.double().mean()))
+        else:
+            torch.testing.assert_close(a, r, rtol=1e-9, atol=1e-9, msg="grad " + name)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cfg", BORDER_CASES)
+def test_deform_conv_matches_second_oracle_on_border_cases(device, cfg):
+    """the HIP kernels against the float64 grid_sample oracle on the same border cases (the offset gradient is compared
+    where the two oracles agree with each other, see above)"""
+    from da_detect_amd.layers.dcn import deform_conv, modulated_deform_conv
+    from oracle import deform_ref as R1
+    from oracle import deform_ref2 as R2
+
+    N, C, H, W, Cout, k, stride, dg, modulated = cfg
+    x, off, mask, w, b, pad = _border_case(sum(cfg[:7]) + 3, *cfg)
+    ref = {}
+    for key, R in (("a", R1), ("b", R2)):
+        leaves = [t.double().clone().requires_grad_(True) for t in (x, off, w)] + \
+            ([mask.double().clone().requires_grad_(True), b.double().clone().requires_grad_(True)] if modulated else [])
+        y = R.deform_conv2d(leaves[0], leaves[1], leaves[3] if modulated else None, leaves[2],
+                            leaves[4] if modulated else None, stride, pad, 1, dg)
+        gy = torch.randn(y.shape, generator=torch.Generator().manual_seed(1), dtype=torch.float64)
+        y.backward(gy)
+        ref[key] = (y.detach(), [t.grad for t in leaves])
+    src = [x, off, w] + ([mask, b] if modulated else [])
+    dl = [t.to(device).contiguous(memory_format=CL) if t.dim() == 4 else t.to(device) for t in src]
+    for t in dl:
+        t.requires_grad_(True)
+    if modulated:
+        got = modulated_deform_conv(dl[0], dl[1], dl[3], dl[2], dl[4], stride, pad, 1, 1, dg)
+    else:
+        got = deform_conv(dl[0], dl[1], dl[2], stride, pad, 1, 1, dg)
+    want = ref["b"][0]
+    torch.testing.assert_close(got.detach().cpu().double(), want, rtol=1e-4, atol=1e-4 * float(want.abs().max()))
+    got.backward(gy.float().to(device))
+    for name, a, r1, r2 in zip(["x", "offset", "weight", "mask", "bias"], dl, ref["a"][1], ref["b"][1]):
+        g = a.grad.cpu().double()
+        scale = float(r2.abs().max()) + 1e-12
+        if name == "offset":
+            agree = (r1 - r2).abs() <= 1e-8 * (1 + r2.abs())
+            err = float(((g - r2).abs() * agree).max()) / scale
+            # where the oracles pick different one-sided derivatives the kernel must equal one of them
+            side = torch.minimum((g - r1).abs(), (g - r2).abs())
+            assert float((side * (~agree)).max()) / scale < 2e-4
+        else:
+            err = float((g - r2).abs().max()) / scale
+        assert err < 2e-4, "grad %s: %.3e" % (name, err)
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("cfg", [(2, 16, 9, 11, 24, 3, 1, 1, False), (2, 32, 12, 10, 16, 3, 1, 1, True),
                                  (1, 64, 15, 13, 32, 3, 2, 2, True), (1, 1024, 6, 7, 8, 3, 1, 4, True),
@@ -194,3 +307,73 @@ def test_dcn_bottleneck_stage_matches_plain_stage_at_zero_offsets(modulated):
         torch.testing.assert_close(pb[k].grad, pa[k].grad, rtol=1e-3, atol=1e-4)
     scale = 0.5 if modulated else 1.0
     torch.testing.assert_close(pb["1.conv2.conv.weight"].grad, pa["1.conv2.weight"].grad * scale, rtol=1e-3, atol=1e-4)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("modulated,stride,dg", [(False, 1, 1), (True, 1, 1), (False, 2, 1), (True, 1, 2)])
+def test_fused_dcn_bottleneck_matches_per_conv_path_and_float64_oracle(modulated, stride, dg):
+    """the one-node DCN bottleneck (_DCNBottleneckFn: offsets / modulation logits read in place, bn2 + ReLU in the GEMM
+    epilogue, y1's ReLU gate and the two gradient paths into y1 merged in the offset conv's data-gradient epilogue)
+    against (a) the per-conv path it replaces (DFConv2d module + standalone kernels, DADET_DCN_FUSED=0's route) and
+    (b) the block written in float64 torch ops around the grid_sample oracle: output, input gradient, every parameter
+    gradient — with NON-zero offsets of a pixel or two."""
+    from da_detect_amd.modeling.backbone import resnet as RN
+    from oracle import deform_ref2 as R2
+
+    torch.manual_seed(3 + int(modulated) + stride)
+    dcn = {"stage_with_dcn": True, "with_modulated_dcn": modulated, "deformable_groups": dg}
+    blk = RN.BottleneckWithFixedBatchNorm(64, 32, 128, stride=stride, dcn_config=dcn).cuda()
+    with torch.no_grad():
+        blk.conv2.offset.weight.normal_(0, 0.08)
+        blk.conv2.offset.bias.normal_(0, 0.5)
+        for bn in (blk.bn1, blk.bn2, blk.bn3, blk.downsample[1]):
+            bn.weight.uniform_(0.5, 1.5)
+            bn.bias.normal_(0, 0.2)
+            bn.running_mean.normal_(0, 0.2)
+            bn.running_var.uniform_(0.5, 2.0)
+            bn._cache = None
+    params = dict(blk.named_parameters())
+    x = torch.randn(2, 64, 14, 18, device="cuda").contiguous(memory_format=CL)
+    g = None
+    res = {}
+    for name, fused in (("fused", True), ("per_conv", False)):
+        RN._DCN_FUSED = fused
+        try:
+            for p in params.values():
+                p.grad = None
+            xi = x.clone().requires_grad_(True)
+            assert blk.uses_fused_path() == fused
+            y = blk(xi, in_relu=False, out_private=False)
+            if g is None:
+                g = torch.randn_like(y)
+            y.backward(g)
+            res[name] = (y.detach().cpu(), xi.grad.cpu(), {k: p.grad.detach().cpu().clone() for k, p in params.items()})
+        finally:
+            RN._DCN_FUSED = True
+    assert float(res["fused"][2]["conv2.offset.weight"].abs().max()) > 0
+    # (b) float64
+    dd = lambda t: t.detach().cpu().double()
+    P = {k: dd(v).requires_grad_(True) for k, v in params.items()}
+    fold = lambda bn: tuple(dd(t).view(1, -1, 1, 1) for t in bn.folded())
+    xr = dd(x).requires_grad_(True)
+    s1, b1 = fold(blk.bn1)
+    s2, b2 = fold(blk.bn2)
+    s3, b3 = fold(blk.bn3)
+    sd, bd = fold(blk.downsample[1])
+    y1 = F.relu(F.conv2d(xr, P["conv1.weight"], None, stride) * s1 + b1)
+    y2 = F.relu(R2.dfconv2d(y1, P["conv2.offset.weight"], P["conv2.offset.bias"], P["conv2.conv.weight"], modulated, dg)
+                * s2 + b2)
+    idn = F.conv2d(xr, P["downsample.0.weight"], None, stride) * sd + bd
+    yr = F.relu(F.conv2d(y2, P["conv3.weight"]) * s3 + b3 + idn)
+    yr.backward(dd(g))
+    for name in ("fused", "per_conv"):
+        y, gx, gp = res[name]
+        torch.testing.assert_close(y.double(), yr.detach(), rtol=1e-4, atol=1e-4, msg=name + ": output")
+        scale = float(xr.grad.abs().max())
+        assert float((gx.double() - xr.grad).abs().max()) / scale < 2e-4, name + ": input gradient"
+        for k, v in gp.items():
+            ref = P[k].grad
+            err = float((v.double() - ref).abs().max()) / (float(ref.abs().max()) + 1e-12)
+            assert err < 3e-4, "%s: gradient of %s off by %.2e" % (name, k, err)
+    # and the two HIP routes against each other
+    torch.testing.assert_close(res["fused"][0], res["per_conv"][0], rtol=1e-5, atol=1e-5)

@@ -1,5 +1,6 @@
 """Full-size sanity (2 or 3 images of 1024 x 2048 per step, the BASELINE.json shapes) of the recipes behind
-BASELINE configs[1]-[3], on the schedule bench.py times.  No CPU oracle finishes at this size in seconds, so the checks
+BASELINE configs[1]-[4] (the last one: R-101-FPN with deformable 3x3 convolutions in res3-5 under DA, every DCN bottleneck
+on the fused one-node path), on the schedule bench.py times.  No CPU oracle finishes at this size in seconds, so the checks
 are size-independent properties aimed at what only shows at size — a cross-stream race between the side streams
 (RPN target preparation, proposal selection + sampling, early RPN / DA backward, instance-head passes) and the compute
 stream:
@@ -53,7 +54,7 @@ def _one_step(ctx, overlapped, seed):
     return {k: float(v.detach()) for k, v in losses.items()}, sampled, grads
 
 
-@pytest.mark.parametrize("workload", ["img_only", "da", "triplet", "triplet_aligned"])
+@pytest.mark.parametrize("workload", ["img_only", "da", "triplet", "triplet_aligned", "fpn_dcn_da"])
 def test_full_size_step_schedules_agree(device, workload):
     ctx = _setup(workload, device)
     l_ov, s_ov, g_ov = _one_step(ctx, True, 7)
