@@ -302,16 +302,23 @@ def test_default_path_matches_oracle_512x1024(device, monkeypatch):
     swapped = 0
     for i, ((bo, so), (bg, sg)) in enumerate(zip(own, rec["proposals"])):
         assert len(bo) == len(bg), "image %d: %d proposals in the oracle's own selection, %d on the GPU" % (i, len(bo), len(bg))
-        rows_o = sorted(tuple(r) for r in torch.cat([bo, so.view(-1, 1)], 1).tolist())
-        rows_g = sorted(tuple(r) for r in torch.cat([bg, sg.view(-1, 1).to(bo.dtype)], 1).tolist())
-        assert rows_o == rows_g, "image %d: the two selections kept different boxes" % i
-        same = (bo == bg).all(dim=1)
+        # the device's decode (expf) and sigmoid differ from the host's in the last bit: boxes are matched to 1e-3 px and
+        # scores to 1e-6 instead of bit for bit.  Same SET: nearest-box matching is a bijection with every distance ~0.
+        bg, sg = bg.to(bo.dtype), sg.to(so.dtype)
+        dist = torch.cdist(bo.double(), bg.double(), p=float("inf"))
+        near = dist.argmin(dim=1)
+        assert float(dist.gather(1, near.view(-1, 1)).max()) < 1e-3, "image %d: a box of the oracle's selection is missing" % i
+        assert len(set(near.tolist())) == len(bo), "image %d: two boxes of the oracle's selection map to one GPU box" % i
+        assert float((so - sg[near]).abs().max()) < 1e-6, "image %d: scores of matched boxes differ" % i
+        # same ORDER, except inside runs of (near-)tied scores
+        pos = torch.arange(len(bo))
         tied = torch.zeros(len(so), dtype=torch.bool)
-        eq = so[1:] == so[:-1]
+        eq = (so[1:] - so[:-1]).abs() <= 2e-7 * so[1:].abs().clamp(min=1e-30)
         tied[1:] |= eq
         tied[:-1] |= eq
-        assert bool(same[~tied].all()), "image %d: order differs at a position whose score is not tied" % i
-        swapped += int((~same).sum())
+        moved = near != pos
+        assert not bool((moved & ~tied).any()), "image %d: order differs at a position whose score is not tied" % i
+        swapped += int(moved.sum())
     print("own selection vs the GPU's at %dx%d: identical sets; %d positions differ inside tied-score runs" % (H, W, swapped))
     _check_losses(rec, olosses)
 
@@ -327,8 +334,7 @@ def test_three_step_trajectory_matches_oracle(device, monkeypatch):
     seed, H, W, steps = 11, 160, 288, 3
     # a rate at which the losses visibly move in three steps without the run becoming chaotic (at 0.01 this random-init
     # model diverges: loss_da_image 0.7 -> 3.5 by the third step, and rounding-level parameter differences are amplified)
-    overrides = ("SOLVER.BASE_LR", 0.002, "MODEL.DA_HEADS.TRIPLET_MAX_MARGIN", 3.0,
-                 "MODEL.ROI_HEADS.BATCH_SIZE_PER_IMAGE", 128)      # 128 ROIs per image: half the oracle's res5 work
+    overrides = ("SOLVER.BASE_LR", 0.002, "MODEL.DA_HEADS.TRIPLET_MAX_MARGIN", 3.0)
     c, sd, rec, nimg = _run_default_path("da_triplet", H, W, device, seed, monkeypatch, overrides, steps=steps)
     names = list(rec["grads"])
     # fp32 oracle here (its three backward passes in fp64 took 140 s): the trajectory's tolerances are set by the

@@ -154,9 +154,12 @@ def test_two_ranks_real_model_bucket_means_and_sync(device, case):
     assert r0[4] == r1[4] and r0[4] > 50
     # (2) nothing was reduced too early: rank 1's local snapshot == the same step run alone on rank 1's batch
     solo, = _run(1, case, batch_rank=1)
+    # (the deformable sampling's backward sums its scatter with fp32 atomics: two PROCESSES differ in the last bits of
+    # those sums, and downstream of 30 DCN blocks in the order of 1e-6 of a bucket's largest gradient)
+    floor = 4e-6 if case == "fpn_dcn_da" else 1e-6
     for b in range(n_buckets):
         scale = float(np.abs(solo[2][b]).max())
-        np.testing.assert_allclose(r1[1][b], solo[2][b], rtol=1e-4, atol=1e-6 * scale + 1e-12)
+        np.testing.assert_allclose(r1[1][b], solo[2][b], rtol=1e-4, atol=floor * scale + 1e-12)
 
 
 def test_one_rank_over_rccl_takes_the_n_rank_path_and_changes_nothing(device):
