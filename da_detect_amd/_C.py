@@ -274,18 +274,8 @@ def conv_out_size(H, W, KH, KW, stride, pad):
     return (H + 2 * pad - KH) // stride + 1, (W + 2 * pad - KW) // stride + 1
 
 
-def weight_planes(w):
-    """fp32 weights (any shape, numel % 4 == 0, physical order = the GEMM's [Cout][K]) -> uint8 tensor holding the three
-    bf16 term planes [3][numel] the split contraction would form on the fly (dadet_weight_planes)"""
-    _dev(w, "w")
-    w = _nhwc(w) if w.dim() == 4 else w.contiguous()
-    planes = torch.empty(6 * w.numel(), dtype=torch.uint8, device=w.device)
-    _lib.call("dadet_weight_planes", _p(w), _p(planes), ctypes.c_int64(w.numel()), _stream())
-    return planes
-
-
 def conv_forward(x, w, scale=None, bias=None, addend=None, mask_ref=None, stride=1, pad=0, relu_mode=0,
-                 out=None, out_spatial_stride=1, out_hw=None, out_size=None, w_planes=None):
+                 out=None, out_spatial_stride=1, out_hw=None, out_size=None):
     """y = act(conv(x, w) * scale + bias + addend); see dadet_conv_forward in include/dadet.h.
 
     x [N,Cin,H,W] channels_last, w [Cout,Cin,KH,KW] channels_last.  `out_size` overrides (Ho, Wo) (used
@@ -329,10 +319,10 @@ def conv_forward(x, w, scale=None, bias=None, addend=None, mask_ref=None, stride
                            2.0 * N * Ho * Wo * Cout * Cin * KH * KW,
                            4.0 * (x.numel() + w.numel() + out.numel() + (addend.numel() if addend is not None else 0)
                                   + (mask_ref.numel() if mask_ref is not None else 0))):
-            _lib.call("dadet_conv_forward_wp", ctypes.byref(d), _p(x), _p(w), _p(w_planes), _p(scale), _p(bias),
-                      _p(addend), _p(mask_ref), _p(out), _stream())
+            _lib.call("dadet_conv_forward", ctypes.byref(d), _p(x), _p(w), _p(scale), _p(bias), _p(addend),
+                      _p(mask_ref), _p(out), _stream())
         return out
-    _lib.call("dadet_conv_forward_wp", ctypes.byref(d), _p(x), _p(w), _p(w_planes), _p(scale), _p(bias), _p(addend),
+    _lib.call("dadet_conv_forward", ctypes.byref(d), _p(x), _p(w), _p(scale), _p(bias), _p(addend),
               _p(mask_ref), _p(out), _stream())
     return out
 

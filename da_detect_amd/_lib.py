@@ -54,8 +54,6 @@ _SIGNATURES = {
     "dadet_sigmoid_focal_loss_forward": [_P, _P, _P, c_int, c_int, c_float, c_float, _P],
     "dadet_sigmoid_focal_loss_backward": [_P, _P, _P, _P, c_int, c_int, c_float, c_float, _P],
     "dadet_conv_forward": [POINTER(ConvDesc), _P, _P, _P, _P, _P, _P, _P, _P],
-    "dadet_conv_forward_wp": [POINTER(ConvDesc), _P, _P, _P, _P, _P, _P, _P, _P, _P],
-    "dadet_weight_planes": [_P, _P, c_int64, _P],
     "dadet_conv_forward_variant": [POINTER(ConvDesc)],
     "dadet_set_gemm_mode": [c_int],
     "dadet_get_gemm_mode": [],

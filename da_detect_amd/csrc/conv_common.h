@@ -68,9 +68,6 @@ struct ConvArgs {
   int sk_dp_tiles, sk_tiles, sk_units, sk_iters, sk_max_parts;
   float* sk_ws;
   int* sk_counters;
-  // weights pre-split into bf16 term planes [3][Cout][K] (conv_split.hip "BP"): nullptr = split while staging
-  const void* wp;
-  unsigned wp_plane_bytes;             // Cout * K * 2
 };
 
 struct WgradArgs {
@@ -113,6 +110,5 @@ int launch_fwd_split(ConvArgs& a, int variant, int terms, hipStream_t st);
 int launch_fwd_split_sk(ConvArgs& a, int terms, hipStream_t st);
 int launch_fwd_split_db(ConvArgs& a, hipStream_t st);
 int launch_wgrad_split(WgradArgs& a, int terms, hipStream_t st);
-int launch_weight_planes(const float* w, void* planes, int64_t numel, hipStream_t st);
 
 }  // namespace dadet

@@ -652,32 +652,9 @@ int splitk_plan(const ConvArgs& a, int variant) {
 }
 }  // namespace
 
-static int conv_forward_impl(const dadet_conv_desc* d, const float* x, const float* w, const void* wp,
-                             const float* scale, const float* bias, const float* addend, const float* mask_ref,
-                             float* y, void* stream);
-
 extern "C" int dadet_conv_forward(const dadet_conv_desc* d, const float* x, const float* w,
                                   const float* scale, const float* bias, const float* addend,
                                   const float* mask_ref, float* y, void* stream) {
-  return conv_forward_impl(d, x, w, nullptr, scale, bias, addend, mask_ref, y, stream);
-}
-
-extern "C" int dadet_conv_forward_wp(const dadet_conv_desc* d, const float* x, const float* w, const void* w_planes,
-                                     const float* scale, const float* bias, const float* addend,
-                                     const float* mask_ref, float* y, void* stream) {
-  return conv_forward_impl(d, x, w, w_planes, scale, bias, addend, mask_ref, y, stream);
-}
-
-extern "C" int dadet_weight_planes(const float* w, void* planes, int64_t numel, void* stream) {
-  DADET_REQUIRE(numel >= 0 && numel % 4 == 0, "weight_planes: the element count must be a multiple of 4");
-  if (numel == 0) return DADET_OK;
-  DADET_REQUIRE(w && planes && al16(w) && al16(planes), "weight_planes: pointers must be non-null and 16-byte aligned");
-  return launch_weight_planes(w, planes, numel, as_stream(stream));
-}
-
-static int conv_forward_impl(const dadet_conv_desc* d, const float* x, const float* w, const void* wp,
-                             const float* scale, const float* bias, const float* addend, const float* mask_ref,
-                             float* y, void* stream) {
   int rc = conv_desc_check(d, "conv_forward");
   if (rc) return rc;
   if (d->N == 0) return DADET_OK;
@@ -715,19 +692,12 @@ static int conv_forward_impl(const dadet_conv_desc* d, const float* x, const flo
   a.sk_dp_tiles = a.sk_tiles = a.sk_units = a.sk_iters = a.sk_max_parts = 0;
   a.sk_ws = nullptr;
   a.sk_counters = nullptr;
-  // pre-split weight planes: 3-term mode, rows of whole 16-byte chunks (K % 8 == 0), three planes under one descriptor
-  a.wp = nullptr;
-  a.wp_plane_bytes = 0;
-  if (wp && gemm_mode() == 3 && a.K % 8 == 0 && !a.ablate && 3ull * d->Cout * a.K * 2 < 0xFFFFFFF0ull && al16(wp)) {
-    a.wp = wp;
-    a.wp_plane_bytes = (unsigned)((uint64_t)d->Cout * a.K * 2);
-  }
   if (gemm_mode() != 0) {
     const int variant = split_fwd_variant(a.M, a.Cout, a.K);
     {
       // experiment (DADET_DB=1): double-buffered K-steps of 16 for the 128x128 variant, whole-K launches only
       const char* env = getenv("DADET_DB");
-      if (env && env[0] == '1' && variant == 0 && gemm_mode() == 3 && a.Cin % 16 == 0 && !a.ablate && !a.wp)
+      if (env && env[0] == '1' && variant == 0 && gemm_mode() == 3 && a.Cin % 16 == 0 && !a.ablate)
         return launch_fwd_split_db(a, st);
     }
     SkPlan sk;

@@ -53,53 +53,6 @@ __device__ inline void split4(const float4 v, uint2 (&out)[TERMS]) {
   }
 }
 
-// ---- weights as pre-split bf16 planes, streamed into LDS by the DMA path (BP = "B planes") ------------------------
-// The B operand of every forward / data-gradient GEMM is a WEIGHT matrix: the same [Cout][K] panel is staged by every
-// M-tile of the launch (64 times for the RPN conv) and, with the on-the-fly split, converted 64 times.  With BP the three
-// bf16 terms of the weights exist in HBM ([3][Cout][K] bf16, produced once per optimizer step by dadet_weight_planes /
-// the transposing variant / the SGD kernel) and a K-tile of them goes global -> LDS with `buffer_load_dwordx4 ... lds`:
-// no VGPRs, no v_cvt / v_sub, no ds_write for half of the staged bytes.  The DMA writes a wavefront's 64 x 16 bytes
-// lane-linearly, so a B plane tile is [rows][32 bf16] WITHOUT row padding (64-byte rows); bank conflicts of the
-// ds_read_b128 fragment reads are avoided by an XOR swizzle of the 16-byte chunk index with bits 2..3 of the row, applied
-// on the SOURCE address of the DMA and on the read address (guide rule 21).  The planes hold exactly the values split4()
-// produces, and the MFMA order is unchanged: results are bit-identical to the register-staged kernel.
-// B is double buffered in LDS (the DMA of tile t+1 runs while tile t is multiplied); hipcc does not see the asm loads, so
-// the kernel waits for them itself (s_waitcnt vmcnt(0) in front of the barrier that publishes the tile).
-__device__ inline u32x4 raw_rsrc_words(const void* p, unsigned bytes) {
-  const unsigned long long a = reinterpret_cast<unsigned long long>(p);
-  u32x4 r;
-  r.x = __builtin_amdgcn_readfirstlane((unsigned)a);
-  r.y = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32) & 0xFFFFu);
-  r.z = __builtin_amdgcn_readfirstlane(bytes);
-  r.w = __builtin_amdgcn_readfirstlane(0x00020000u);
-  return r;
-}
-// one wavefront-wide 1 KB piece: lane l's 16 bytes at byte offset `voff` of the buffer land at LDS byte lds_off + 16 * l
-__device__ inline void glds16(const u32x4 rsrc, const unsigned voff, const unsigned lds_off) {
-  unsigned keep;
-  asm volatile(
-      "s_mov_b32 %0, m0\n\t"
-      "s_mov_b32 m0, %3\n\t"
-      "s_nop 4\n\t"
-      "buffer_load_dwordx4 %1, %2, 0 offen lds\n\t"
-      "s_mov_b32 m0, %0"
-      : "=&s"(keep)
-      : "v"(voff), "s"(rsrc), "s"(lds_off)
-      : "memory");
-}
-
-// [Cout][K] fp32 -> [3][Cout][K] bf16 term planes (the values split4 produces); K % 4 == 0
-__global__ __launch_bounds__(256) void weight_planes_kernel(const float4* __restrict__ w, uint2* __restrict__ planes,
-                                                            int64_t n4) {
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
-    uint2 t[3];
-    split4<3>(w[i], t);
-    planes[i] = t[0];
-    planes[n4 + i] = t[1];
-    planes[2 * n4 + i] = t[2];
-  }
-}
-
 // AB: stage-ablation mask for profiling experiments (tools/ablate.py).  It is a COMPILE-TIME parameter: as run-time
 // branches the checks cut the K loop into a dozen basic blocks and the scheduler could no longer interleave the
 // MFMAs with the split / LDS traffic across them.  Production launches use AB = 0.
@@ -245,16 +198,14 @@ struct SkPart {
   int part, parts;
 };
 
-template <int TM, int TN, int TERMS, int AB, bool BP = false>
+template <int TM, int TN, int TERMS, int AB>
 __device__ __forceinline__ void conv_fwd_split_body(const ConvArgs& a, char* smem, const int tile, const int k_lo,
                                                     const int k_hi, const unsigned split_y, const SkPart* sk) {
   constexpr int BM = 2 * TM * 32, BN = 2 * TN * 32;
   constexpr int A_LOADS = BM / 32, B_LOADS = BN / 32;
-  constexpr int A_PLANE = BM * PLANE_STRIDE, B_PLANE = BP ? BN * 32 : BN * PLANE_STRIDE;  // bf16 elements
-  // BP: [2 buffers][TERMS][BN][32] B planes first (DMA destinations below 64 KB), then the A planes
-  constexpr int BP_BUF = TERMS * BN * 32;         // bf16 elements of one B buffer
-  __bf16* As = reinterpret_cast<__bf16*>(smem) + (BP ? 2 * BP_BUF : 0);   // [TERMS][BM][PLANE_STRIDE]
-  __bf16* Bs = BP ? reinterpret_cast<__bf16*>(smem) : As + TERMS * A_PLANE;   // [TERMS][BN][PLANE_STRIDE] | BP layout
+  constexpr int A_PLANE = BM * PLANE_STRIDE, B_PLANE = BN * PLANE_STRIDE;  // bf16 elements
+  __bf16* As = reinterpret_cast<__bf16*>(smem);   // [TERMS][BM][PLANE_STRIDE]
+  __bf16* Bs = As + TERMS * A_PLANE;              // [TERMS][BN][PLANE_STRIDE]
 
   const int bm0 = (tile / a.tiles_n) * BM;
   const int bn0 = (tile % a.tiles_n) * BN;
@@ -303,32 +254,6 @@ __device__ __forceinline__ void conv_fwd_split_body(const ConvArgs& a, char* sme
     const int n = bn0 + lrow + 32 * i;
     wrow[i] = n < a.Cout ? (unsigned)n * (unsigned)a.K * 4u : kOOB;
   }
-  // BP: this wave issues BP_PIECES of the TERMS * BN / 16 one-KB pieces of a B K-tile.  Piece j = plane j / (BN / 16),
-  // row block j % (BN / 16); lane l carries row (l >> 2) of the block and the 16-byte chunk (l & 3) ^ ((l >> 4) & 3)
-  // (the swizzle: bits 2..3 of the row — the row block contributes a multiple of 4 to row >> 2)
-  constexpr int BP_PIECES = TERMS * BN / 16 / 4;
-  const u32x4 wpr = BP ? raw_rsrc_words(a.wp, (unsigned)(TERMS * a.wp_plane_bytes)) : u32x4{0, 0, 0, 0};
-  const int bp_row = lane >> 2;
-  const unsigned bp_chunk = (unsigned)((lane & 3) ^ ((lane >> 4) & 3));
-  int kb = k_lo;       // first k of the B tile the next DMA fetches
-  auto dma_b = [&](const int buf) {
-    if constexpr (BP) {
-      const unsigned kcol = (unsigned)kb + bp_chunk * 8u;
-      const bool kvalid = (int)kcol < k_hi;
-#pragma unroll
-      for (int q = 0; q < BP_PIECES; ++q) {
-        const int j = wave * BP_PIECES + q;
-        const int plane = j / (BN / 16), rb = j % (BN / 16);
-        const int n = bn0 + rb * 16 + bp_row;
-        const unsigned off = (kvalid && n < a.Cout)
-                                 ? (unsigned)plane * a.wp_plane_bytes + ((unsigned)n * (unsigned)a.K + kcol) * 2u
-                                 : kOOB;
-        const unsigned dst = (unsigned)((buf * BP_BUF + plane * BN * 32 + rb * 16 * 32) * 2);
-        glds16(wpr, off, __builtin_amdgcn_readfirstlane(dst));
-      }
-      kb += BK;
-    }
-  };
   float4 ra[A_LOADS], rb[B_LOADS];
   int kk = k_lo + lcol * 4;
   int tap = kk / a.Cin;
@@ -350,12 +275,10 @@ __device__ __forceinline__ void conv_fwd_split_body(const ConvArgs& a, char* sme
     }
   };
   auto load_b = [&]() {
-    if constexpr (!BP) {
-      const bool kvalid = kk < k_hi;
+    const bool kvalid = kk < k_hi;
 #pragma unroll
-      for (int i = 0; i < B_LOADS; ++i)
-        rb[i] = buf_load4(wr, (kvalid && wrow[i] != kOOB) ? wrow[i] + (unsigned)kk * 4u : kOOB);
-    }
+    for (int i = 0; i < B_LOADS; ++i)
+      rb[i] = buf_load4(wr, (kvalid && wrow[i] != kOOB) ? wrow[i] + (unsigned)kk * 4u : kOOB);
   };
   auto advance = [&]() {
     kk += BK;
@@ -377,10 +300,8 @@ __device__ __forceinline__ void conv_fwd_split_body(const ConvArgs& a, char* sme
     for (int i = 0; i < A_LOADS; ++i) split4<TERMS>(ra[i], pa_[i]);
   };
   auto split_b = [&]() {
-    if constexpr (!BP) {
 #pragma unroll
-      for (int i = 0; i < B_LOADS; ++i) split4<TERMS>(rb[i], pb_[i]);
-    }
+    for (int i = 0; i < B_LOADS; ++i) split4<TERMS>(rb[i], pb_[i]);
   };
   auto store_tile = [&]() {
 #pragma unroll
@@ -388,13 +309,11 @@ __device__ __forceinline__ void conv_fwd_split_body(const ConvArgs& a, char* sme
 #pragma unroll
       for (int p = 0; p < TERMS; ++p)
         *reinterpret_cast<uint2*>(As + p * A_PLANE + (lrow + 32 * i) * PLANE_STRIDE + lcol * 4) = pa_[i][p];
-    if constexpr (!BP) {
 #pragma unroll
-      for (int i = 0; i < B_LOADS; ++i)
+    for (int i = 0; i < B_LOADS; ++i)
 #pragma unroll
-        for (int p = 0; p < TERMS; ++p)
-          *reinterpret_cast<uint2*>(Bs + p * B_PLANE + (lrow + 32 * i) * PLANE_STRIDE + lcol * 4) = pb_[i][p];
-    }
+      for (int p = 0; p < TERMS; ++p)
+        *reinterpret_cast<uint2*>(Bs + p * B_PLANE + (lrow + 32 * i) * PLANE_STRIDE + lcol * 4) = pb_[i][p];
   };
 
   f32x16 acc[TM][TN];
@@ -406,14 +325,12 @@ __device__ __forceinline__ void conv_fwd_split_body(const ConvArgs& a, char* sme
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
   const int nk = (k_hi - k_lo + BK - 1) / BK;
-  dma_b(0);          // BP: tile 0 of the weights straight into LDS buffer 0
   load_a();
   load_b();
   advance();
   split_a();
   split_b();
   store_tile();
-  if constexpr (BP) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   if (!(AB & 4)) {   // tile 1 is in flight while tile 0 is multiplied
     load_a();
@@ -426,16 +343,9 @@ __device__ __forceinline__ void conv_fwd_split_body(const ConvArgs& a, char* sme
   const int frag_k = (lane >> 5) * 8;
   const __bf16* Ab = As + (wm * TM * 32 + frag_row) * PLANE_STRIDE + frag_k;
   const __bf16* Bb = Bs + (wn * TN * 32 + frag_row) * PLANE_STRIDE + frag_k;
-  // BP: row r's k-chunk c (8 bf16) sits at chunk c ^ ((r >> 2) & 3) of its 64-byte row
-  const int bp_frow = wn * TN * 32 + frag_row;
-  const int bp_sw = (bp_frow >> 2) & 3;        // the same for the wave's other 32-row blocks (multiples of 32 rows apart)
   constexpr int ab = AB;
   for (int kt = 0; kt < nk; ++kt) {
     const bool more = kt + 1 < nk;
-    // BP: the weights of tile kt + 1 go into the other LDS buffer while tile kt is multiplied (every wave finished
-    // reading that buffer before the barriers that ended iteration kt - 1); past the last tile the offsets are out of range
-    if (more) dma_b((kt + 1) & 1);
-    const __bf16* Bcur = Bs + (BP ? (kt & 1) * BP_BUF : 0);
     // LDS holds tile kt, the registers hold tile kt + 1 (fetched one iteration ago).  Per k16 group: split one
     // operand of tile kt + 1 in the shadow of the MFMAs (each 32x32x16 occupies the matrix pipe for 32 cycles = 8 issue
     // slots), then fetch that operand of tile kt + 2 into the registers just freed.  Everything is unconditional on
@@ -451,13 +361,8 @@ __device__ __forceinline__ void conv_fwd_split_body(const ConvArgs& a, char* sme
         for (int i = 0; i < TM; ++i)
           fa[p][i] = *reinterpret_cast<const bf16x8*>(Ab + p * A_PLANE + i * 32 * PLANE_STRIDE + step * 16);
 #pragma unroll
-        for (int i = 0; i < TN; ++i) {
-          if constexpr (BP)
-            fb[p][i] = *reinterpret_cast<const bf16x8*>(Bcur + p * B_PLANE + (bp_frow + i * 32) * 32 +
-                                                        (((step * 2 + (lane >> 5)) ^ bp_sw) * 8));
-          else
-            fb[p][i] = *reinterpret_cast<const bf16x8*>(Bb + p * B_PLANE + i * 32 * PLANE_STRIDE + step * 16);
-        }
+        for (int i = 0; i < TN; ++i)
+          fb[p][i] = *reinterpret_cast<const bf16x8*>(Bb + p * B_PLANE + i * 32 * PLANE_STRIDE + step * 16);
       }
       // the next tile's operands have landed by now: split one operand per k16 group of MFMAs
       if (!(ab & 1)) {
@@ -484,9 +389,7 @@ __device__ __forceinline__ void conv_fwd_split_body(const ConvArgs& a, char* sme
         // desired issue order for this k16 group: fragment reads up front, then every MFMA followed by the VALU
         // instructions that fit in its shadow
         constexpr int kMfma = TM * TN * (TERMS == 3 ? 6 : 3);
-        // BP: only the A operand is split (in the first k16 group); spread it over both groups' MFMAs
-        constexpr int kValuPerMfma = BP ? A_LOADS * (TERMS == 3 ? 26 : 14) / (2 * kMfma) + 2
-                                        : (TM == 2 ? A_LOADS : B_LOADS) * (TERMS == 3 ? 26 : 14) / kMfma + 1;
+        constexpr int kValuPerMfma = (TM == 2 ? A_LOADS : B_LOADS) * (TERMS == 3 ? 26 : 14) / kMfma + 1;
         __builtin_amdgcn_sched_group_barrier(0x100, TERMS * (TM + TN), 0);   // DS reads
 #pragma unroll
         for (int i = 0; i < kMfma; ++i) {
@@ -504,7 +407,6 @@ __device__ __forceinline__ void conv_fwd_split_body(const ConvArgs& a, char* sme
     if (more) {
       if (!(ab & 64)) __syncthreads();
       if (!(ab & 2)) store_tile();
-      if constexpr (BP) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's DMA pieces of tile kt + 1 landed
       if (!(ab & 64)) __syncthreads();
     }
   }
@@ -555,13 +457,13 @@ __device__ __forceinline__ void conv_fwd_split_body(const ConvArgs& a, char* sme
   else conv_epilogue<TM, TN>(a, acc, bm0, bn0, wm, wn, lane, split_y);
 }
 
-template <int TM, int TN, int TERMS, int AB = 0, bool BP = false>
+template <int TM, int TN, int TERMS, int AB = 0>
 __global__ __launch_bounds__(256, 2) void conv_fwd_split_kernel(const ConvArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int k_lo = a.ksplit ? (int)blockIdx.y * a.ksplit : 0;
   const int k_hi = a.ksplit ? min(a.K, k_lo + a.ksplit) : a.K;
-  conv_fwd_split_body<TM, TN, TERMS, AB, BP>(a, smem, xcd_remap(blockIdx.x, a.tiles_m * a.tiles_n), k_lo, k_hi,
-                                             blockIdx.y, nullptr);
+  conv_fwd_split_body<TM, TN, TERMS, AB>(a, smem, xcd_remap(blockIdx.x, a.tiles_m * a.tiles_n), k_lo, k_hi, blockIdx.y,
+                                         nullptr);
 }
 
 // Stream-K tail.  A grid of T output tiles runs on 512 workgroup slots (2 per CU) in ceil(T / 512) passes; the last pass
@@ -570,11 +472,11 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_split_kernel(const ConvArgs a
 // as before; the remaining sk_tiles * nk K-tile iterations are cut into `sk_units` equal contiguous ranges, one per
 // extra workgroup, so the tail ends (T mod 512) / 512 of a pass after the full passes instead of a whole one.  A range
 // covers the end of one tile and the start of the next; the parts of a tile meet in the workspace (conv_fwd_split_body).
-template <int TERMS, bool BP = false>
+template <int TERMS>
 __global__ __launch_bounds__(256, 2) void conv_fwd_split_sk_kernel(const ConvArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   if ((int)blockIdx.x < a.sk_dp_tiles) {
-    conv_fwd_split_body<2, 2, TERMS, 0, BP>(a, smem, xcd_remap(blockIdx.x, a.sk_dp_tiles), 0, a.K, 0, nullptr);
+    conv_fwd_split_body<2, 2, TERMS, 0>(a, smem, xcd_remap(blockIdx.x, a.sk_dp_tiles), 0, a.K, 0, nullptr);
     return;
   }
   const int nk = (a.K + BK - 1) / BK;
@@ -592,7 +494,7 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_split_sk_kernel(const ConvArg
     first = false;
     const int k_lo = k0 * BK, k_hi = min(a.K, k1 * BK);
     if (k0 == 0 && k1 == nk) {
-      conv_fwd_split_body<2, 2, TERMS, 0, BP>(a, smem, a.sk_dp_tiles + tl, k_lo, k_hi, 0, nullptr);
+      conv_fwd_split_body<2, 2, TERMS, 0>(a, smem, a.sk_dp_tiles + tl, k_lo, k_hi, 0, nullptr);
     } else {
       const int first_unit = (tl * nk) / a.sk_iters, last_unit = ((tl + 1) * nk - 1) / a.sk_iters;
       SkPart part;
@@ -600,7 +502,7 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_split_sk_kernel(const ConvArg
       part.counter = a.sk_counters + tl;
       part.part = unit - first_unit;
       part.parts = last_unit - first_unit + 1;
-      conv_fwd_split_body<2, 2, TERMS, 0, BP>(a, smem, a.sk_dp_tiles + tl, k_lo, k_hi, 0, &part);
+      conv_fwd_split_body<2, 2, TERMS, 0>(a, smem, a.sk_dp_tiles + tl, k_lo, k_hi, 0, &part);
     }
     it += k1 - k0;
   }
@@ -1022,16 +924,15 @@ static int launch_split_ws(ConvArgs& a, hipStream_t st) {
   return check_launch("conv_forward(split, wave-specialised)");
 }
 
-template <int TM, int TN, int TERMS, int AB = 0, bool BP = false>
+template <int TM, int TN, int TERMS, int AB = 0>
 static int launch_split(ConvArgs& a, hipStream_t st) {
   constexpr int BM = 2 * TM * 32, BN = 2 * TN * 32;
   a.tiles_m = ceil_div(a.M, BM);
   a.tiles_n = ceil_div(a.Cout, BN);
-  const size_t lds = BP ? sizeof(__bf16) * TERMS * (BM * PLANE_STRIDE + 2 * BN * 32)
-                        : sizeof(__bf16) * TERMS * (BM + BN) * PLANE_STRIDE;
+  const size_t lds = sizeof(__bf16) * TERMS * (BM + BN) * PLANE_STRIDE;
   static bool attr_set = false;
   if (!attr_set && lds > 48 * 1024) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_fwd_split_kernel<TM, TN, TERMS, AB, BP>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_fwd_split_kernel<TM, TN, TERMS, AB>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) {
       set_error("conv_forward(split): hipFuncSetAttribute: %s", hipGetErrorString(e));
@@ -1040,18 +941,17 @@ static int launch_split(ConvArgs& a, hipStream_t st) {
     attr_set = true;
   }
   const int ksplits = a.ksplit ? ceil_div(a.K, a.ksplit) : 1;
-  hipLaunchKernelGGL((conv_fwd_split_kernel<TM, TN, TERMS, AB, BP>), dim3(a.tiles_m * a.tiles_n, ksplits), dim3(256),
-                     lds, st, a);
+  hipLaunchKernelGGL((conv_fwd_split_kernel<TM, TN, TERMS, AB>), dim3(a.tiles_m * a.tiles_n, ksplits), dim3(256), lds,
+                     st, a);
   return check_launch("conv_forward(split)");
 }
 
-template <int TERMS, bool BP = false>
+template <int TERMS>
 static int launch_split_sk(ConvArgs& a, hipStream_t st) {
-  const size_t lds = BP ? sizeof(__bf16) * TERMS * (128 * PLANE_STRIDE + 2 * 128 * 32)
-                        : sizeof(__bf16) * TERMS * 256 * PLANE_STRIDE;
+  const size_t lds = sizeof(__bf16) * TERMS * 256 * PLANE_STRIDE;
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_fwd_split_sk_kernel<TERMS, BP>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_fwd_split_sk_kernel<TERMS>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) {
       set_error("conv_forward(split, stream-K): hipFuncSetAttribute: %s", hipGetErrorString(e));
@@ -1059,7 +959,7 @@ static int launch_split_sk(ConvArgs& a, hipStream_t st) {
     }
     attr_set = true;
   }
-  hipLaunchKernelGGL((conv_fwd_split_sk_kernel<TERMS, BP>), dim3(a.sk_dp_tiles + a.sk_units), dim3(256), lds, st, a);
+  hipLaunchKernelGGL((conv_fwd_split_sk_kernel<TERMS>), dim3(a.sk_dp_tiles + a.sk_units), dim3(256), lds, st, a);
   return check_launch("conv_forward(split, stream-K)");
 }
 
@@ -1084,7 +984,6 @@ int launch_fwd_split_db(ConvArgs& a, hipStream_t st) {
 int launch_fwd_split_sk(ConvArgs& a, int terms, hipStream_t st) {
   a.tiles_m = ceil_div(a.M, 128);
   a.tiles_n = ceil_div(a.Cout, 128);
-  if (terms == 3 && a.wp) return launch_split_sk<3, true>(a, st);
   return terms == 2 ? launch_split_sk<2>(a, st) : launch_split_sk<3>(a, st);
 }
 
@@ -1113,28 +1012,11 @@ int launch_fwd_split(ConvArgs& a, int variant, int terms, hipStream_t st) {
       default: return launch_split<1, 1, 2>(a, st);
     }
   }
-  if (a.wp) {     // weights as pre-split bf16 planes, DMA-staged (see glds16)
-    switch (variant) {
-      case 0: return launch_split<2, 2, 3, 0, true>(a, st);
-      case 1: return launch_split<2, 1, 3, 0, true>(a, st);
-      default: return launch_split<1, 1, 3, 0, true>(a, st);
-    }
-  }
   switch (variant) {
     case 0: return launch_split<2, 2, 3>(a, st);
     case 1: return launch_split<2, 1, 3>(a, st);
     default: return launch_split<1, 1, 3>(a, st);
   }
-}
-
-int launch_weight_planes(const float* w, void* planes, int64_t numel, hipStream_t st) {
-  const int64_t n4 = numel / 4;
-  int64_t blocks = ceil_div64(n4, 256);
-  if (blocks > kMaxStreamBlocks) blocks = kMaxStreamBlocks;
-  if (blocks < 1) blocks = 1;
-  hipLaunchKernelGGL(weight_planes_kernel, dim3((int)blocks), dim3(256), 0, st, reinterpret_cast<const float4*>(w),
-                     reinterpret_cast<uint2*>(planes), n4);
-  return check_launch("weight_planes");
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -18,7 +18,7 @@
 // (pixel, tap) instead of once per (pixel, tap, channel).
 #include <cstdlib>
 
-#include "common.h"
+#include "conv_common.h"
 
 namespace dadet {
 
@@ -293,6 +293,153 @@ __global__ __launch_bounds__(256) void deform_sample_bwd_lds_kernel(const float*
   }
 }
 
+// Second form of the LDS-window backward (round 3).  The kernel above walks ONE (pixel, tap) per wavefront and
+// iteration — 4-byte loads, two 6-step wave reductions and a dependent chain of load -> weight -> ds_add -> reduce per
+// step, 144 steps per wavefront: latency bound (rocprofv3: 0.72 ms per call, 30 calls = 21.7 ms of the 85 ms
+// R-101-FPN-DCN step, its largest kernel).  Here a wavefront works on FOUR output pixels at once — 16 lanes x 4 channels
+// (16 bytes) per pixel, the 64 channels of the chunk — and on THREE taps per iteration with all 15 of their 16-byte loads
+// (gradient + four corners each) issued before the first use; the offset / mask gradients need 4-step reductions over 16
+// lanes instead of 6-step ones over 64.  12 iterations per wavefront instead of 144.  The window keeps its [cell][64]
+// float layout with the channel index rotated by the cell's column (channel c of cell (cy, cx) sits at (c + cx) & 63): the
+// four pixels of a wavefront hit neighbouring columns, and unrotated their lanes' ds_add_f32 would pile onto the same 16
+// banks (4-way conflicts).
+__global__ __launch_bounds__(256) void deform_sample_bwd_lds4_kernel(const float* __restrict__ x,
+                                                                     const float* __restrict__ offset,
+                                                                     const float* __restrict__ mask,
+                                                                     const float* __restrict__ gcols,
+                                                                     float* __restrict__ gx,
+                                                                     float* __restrict__ goffset,
+                                                                     float* __restrict__ gmask, DeformGeom g,
+                                                                     int tiles_x, int tiles_y) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* win = reinterpret_cast<float*>(smem);   // [kDWin * kDWin][kDChunk], channel index rotated by the column
+  const int tile = blockIdx.x;
+  const int n = tile / (tiles_x * tiles_y);
+  const int ty = (tile / tiles_x) % tiles_y, tx = tile % tiles_x;
+  const int y0 = ty * kDTile, x0 = tx * kDTile;
+  const int oy = y0 - g.pad - kDHalo, ox = x0 - g.pad - kDHalo;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int sub = lane >> 4, l16 = lane & 15;           // pixel of the wavefront's group of four, channel quad
+  const int c = blockIdx.y * kDChunk + l16 * 4;          // first of this lane's 4 channels
+  const int T = g.KH * g.KW;
+  const int cpg = g.C / g.dg;
+  const int grp = c / cpg;                               // (C / dg) % 4 == 0: a lane's 4 channels share the group
+  const bool uniform16 = (cpg % kDChunk) == 0;           // the 16 lanes of a pixel share one deformable group
+  {
+    float4* w4 = reinterpret_cast<float4*>(win);
+    for (int i = threadIdx.x; i < kDWin * kDWin * kDChunk / 4; i += 256) w4[i] = zero4();
+  }
+  __syncthreads();
+  const float* __restrict__ img = x + (size_t)n * g.H * g.W * g.C;
+  float* __restrict__ gimg = gx ? gx + (size_t)n * g.H * g.W * g.C : nullptr;
+  const __amdgpu_buffer_rsrc_t xr = make_rsrc(img, (unsigned)((size_t)g.H * g.W * g.C * 4));
+  const __amdgpu_buffer_rsrc_t gr = make_rsrc(gcols, (unsigned)((size_t)g.N * g.Ho * g.Wo * T * g.C * 4));
+  // a wavefront takes half a row of the 8 x 8 tile (4 consecutive pixels) per step
+  for (int p4 = wave; p4 < kDTile * kDTile / 4; p4 += 4) {
+    const int py = p4 / 2, px = (p4 & 1) * 4 + sub;
+    const int ho = y0 + py, wo = x0 + px;
+    const bool live = ho < g.Ho && wo < g.Wo;
+    const size_t m = ((size_t)n * g.Ho + (live ? ho : 0)) * g.Wo + (live ? wo : 0);
+    const float* __restrict__ off_m = offset + m * g.off_ld;
+    const float* __restrict__ msk_m = mask ? mask + m * g.mask_ld : nullptr;
+    float* __restrict__ goff_m = goffset + m * g.goff_ld;
+    float* __restrict__ gmsk_m = gmask ? gmask + m * g.gmask_ld : nullptr;
+    for (int tap0 = 0; tap0 < T; tap0 += 3) {
+      Corner k[3];
+      float mk[3];
+      float4 gv[3], a1[3], a2[3], a3[3], a4[3];
+      size_t p1[3];
+#pragma unroll
+      for (int u = 0; u < 3; ++u) {
+        const int tap = tap0 + u;
+        const bool on = live && tap < T;
+        const int tt = on ? tap : 0;
+        const int i = tt / g.KW, j = tt - i * g.KW;
+        const float oh = off_m[grp * 2 * T + 2 * tt], ow = off_m[grp * 2 * T + 2 * tt + 1];
+        mk[u] = msk_m ? modulation(msk_m, grp * T + tt, g.mask_sigmoid) : 1.f;
+        const float h_im = (float)(ho - g.pad + i * g.dil) + oh;
+        const float w_im = (float)(wo - g.pad + j * g.dil) + ow;
+        k[u] = corner_of(h_im, w_im, g.H, g.W);
+        if (!on) k[u].valid = k[u].in1 = k[u].in2 = k[u].in3 = k[u].in4 = false;
+        p1[u] = ((size_t)k[u].hl * g.W + k[u].wl) * g.C + c;
+        // buffer loads: a corner outside the map / a tap beyond the last one is an out-of-range offset that returns 0 —
+        // no branches, all 15 loads of the three taps are in flight together (conv_common.h)
+        const unsigned b1o = (unsigned)p1[u] * 4u, rowb = (unsigned)(g.W * g.C) * 4u, pixb = (unsigned)g.C * 4u;
+        gv[u] = buf_load4(gr, on ? (unsigned)((m * T + tt) * g.C + c) * 4u : kOOB);
+        a1[u] = buf_load4(xr, k[u].in1 ? b1o : kOOB);
+        a2[u] = buf_load4(xr, k[u].in2 ? b1o + pixb : kOOB);
+        a3[u] = buf_load4(xr, k[u].in3 ? b1o + rowb : kOOB);
+        a4[u] = buf_load4(xr, k[u].in4 ? b1o + rowb + pixb : kOOB);
+      }
+#pragma unroll
+      for (int u = 0; u < 3; ++u) {
+        const int tap = tap0 + u;
+        const bool on = live && tap < T;
+        const float hh = 1.f - k[u].lh, hw = 1.f - k[u].lw;
+        const float w1 = hh * hw, w2 = hh * k[u].lw, w3 = k[u].lh * hw, w4 = k[u].lh * k[u].lw;
+        const float g4[4] = {gv[u].x, gv[u].y, gv[u].z, gv[u].w};
+        const float b1[4] = {a1[u].x, a1[u].y, a1[u].z, a1[u].w}, b2[4] = {a2[u].x, a2[u].y, a2[u].z, a2[u].w};
+        const float b3[4] = {a3[u].x, a3[u].y, a3[u].z, a3[u].w}, b4[4] = {a4[u].x, a4[u].y, a4[u].z, a4[u].w};
+        const int cy = k[u].hl - oy, cx = k[u].wl - ox;   // window cell of the top-left corner
+        const bool r0 = (unsigned)cy < (unsigned)kDWin, r1 = (unsigned)(cy + 1) < (unsigned)kDWin;
+        const bool q0 = (unsigned)cx < (unsigned)kDWin, q1 = (unsigned)(cx + 1) < (unsigned)kDWin;
+        float* cell = win + ((size_t)cy * kDWin + cx) * kDChunk;
+        float d_h = 0.f, d_w = 0.f, d_m = 0.f;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float ge = g4[e] * mk[u];   // gradient wrt the unmasked sample
+          if (gimg) {
+            const int ch = l16 * 4 + e;
+            const int s0 = (ch + cx) & (kDChunk - 1), s1 = (ch + cx + 1) & (kDChunk - 1);   // rotation by the column
+            if (k[u].in1) { if (r0 && q0) unsafeAtomicAdd(cell + s0, w1 * ge); else unsafeAtomicAdd(gimg + p1[u] + e, w1 * ge); }
+            if (k[u].in2) { if (r0 && q1) unsafeAtomicAdd(cell + kDChunk + s1, w2 * ge); else unsafeAtomicAdd(gimg + p1[u] + g.C + e, w2 * ge); }
+            if (k[u].in3) { if (r1 && q0) unsafeAtomicAdd(cell + kDWin * kDChunk + s0, w3 * ge); else unsafeAtomicAdd(gimg + p1[u] + (size_t)g.W * g.C + e, w3 * ge); }
+            if (k[u].in4) { if (r1 && q1) unsafeAtomicAdd(cell + (kDWin + 1) * kDChunk + s1, w4 * ge); else unsafeAtomicAdd(gimg + p1[u] + (size_t)g.W * g.C + g.C + e, w4 * ge); }
+          }
+          // get_coordinate_weight (deform_conv_kernel_cuda.cu:153-195): d sample / d h, d sample / d w
+          d_h += ge * (hw * (b3[e] - b1[e]) + k[u].lw * (b4[e] - b2[e]));
+          d_w += ge * (hh * (b2[e] - b1[e]) + k[u].lh * (b4[e] - b3[e]));
+          d_m += g4[e] * (w1 * b1[e] + w2 * b2[e] + w3 * b3[e] + w4 * b4[e]);
+        }
+        if (!k[u].valid) d_h = d_w = 0.f;
+        if (g.mask_sigmoid) d_m = d_m * mk[u] * (1.f - mk[u]);
+        if (uniform16) {        // sum over the 16 lanes of the pixel
+#pragma unroll
+          for (int o = 8; o > 0; o >>= 1) {
+            d_h += __shfl_xor(d_h, o, 64);
+            d_w += __shfl_xor(d_w, o, 64);
+            d_m += __shfl_xor(d_m, o, 64);
+          }
+          if (l16 == 0 && on) {
+            atomicAdd(goff_m + grp * 2 * T + 2 * tap, d_h);
+            atomicAdd(goff_m + grp * 2 * T + 2 * tap + 1, d_w);
+            if (gmsk_m) atomicAdd(gmsk_m + grp * T + tap, d_m);
+          }
+        } else if (on) {
+          atomicAdd(goff_m + grp * 2 * T + 2 * tap, d_h);
+          atomicAdd(goff_m + grp * 2 * T + 2 * tap + 1, d_w);
+          if (gmsk_m) atomicAdd(gmsk_m + grp * T + tap, d_m);
+        }
+      }
+    }
+  }
+  __syncthreads();
+  if (gimg) {
+    // flush: 16 lanes x 4 channels per cell, 4 cells per wavefront and step; the rotation is undone on the way out
+    for (int cell = wave * 4 + sub; cell < kDWin * kDWin; cell += 16) {
+      const int gy = oy + cell / kDWin, cxx = cell % kDWin, gxx = ox + cxx;
+      if ((unsigned)gy >= (unsigned)g.H || (unsigned)gxx >= (unsigned)g.W) continue;
+      const float* src = win + (size_t)cell * kDChunk;
+      float* dst = gimg + ((size_t)gy * g.W + gxx) * g.C + c;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float v = src[(l16 * 4 + e + cxx) & (kDChunk - 1)];
+        if (v != 0.f) unsafeAtomicAdd(dst + e, v);
+      }
+    }
+  }
+}
+
 static int deform_check(const char* who, int N, int H, int W, int C, int KH, int KW, int stride, int pad,
                         int dil, int dg, int Ho, int Wo) {
   DADET_REQUIRE(N >= 0 && H > 0 && W > 0 && C > 0 && KH > 0 && KW > 0 && stride > 0 && pad >= 0 && dil > 0 && dg > 0,
@@ -364,6 +511,24 @@ static int deform_sample_backward_impl(const float* x, const float* offset, cons
         return DADET_ELAUNCH;
       }
       attr_set = true;
+    }
+    static const bool one_pixel = getenv("DADET_DEFORM_BWD_LDS") && getenv("DADET_DEFORM_BWD_LDS")[0] == '1';
+    if (!one_pixel && (g.C / g.dg) % 4 == 0 && (((uintptr_t)x | (uintptr_t)gcols) & 15) == 0 && g.C % 4 == 0 &&
+        (uint64_t)g.N * g.Ho * g.Wo * T * g.C * 4 < 0xFFFFFFF0ull) {
+      static bool attr4_set = false;
+      if (!attr4_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(deform_sample_bwd_lds4_kernel),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) {
+          set_error("deform_sample_backward: hipFuncSetAttribute: %s", hipGetErrorString(e));
+          return DADET_ELAUNCH;
+        }
+        attr4_set = true;
+      }
+      hipLaunchKernelGGL(deform_sample_bwd_lds4_kernel,
+                         dim3((unsigned)(g.N * tiles_x * tiles_y), (unsigned)(g.C / kDChunk)), dim3(256), lds,
+                         as_stream(stream), x, offset, mask, gcols, gx, goffset, gmask, g, tiles_x, tiles_y);
+      return check_launch("deform_sample_backward(lds4)");
     }
     hipLaunchKernelGGL(deform_sample_bwd_lds_kernel, dim3((unsigned)(g.N * tiles_x * tiles_y), (unsigned)(g.C / kDChunk)),
                        dim3(256), lds, as_stream(stream), x, offset, mask, gcols, gx, goffset, gmask, g, tiles_x,

@@ -45,34 +45,41 @@ __global__ void relu_bn_backward_kernel(const float4* __restrict__ g, const floa
 // partial[s][c] = sum over the s-th row slab; deterministic two-pass.
 __global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __restrict__ g,
                                                              float* __restrict__ partial, int64_t rows,
-                                                             int C, int64_t rows_per_split) {
-  // block: 64 columns x 4 row lanes
-  __shared__ float red[4][64];
-  const int col = blockIdx.x * 64 + (threadIdx.x & 63);
-  const int rl = threadIdx.x >> 6;
+                                                             int C, int64_t rows_per_split, int cb) {
+  // block: cb columns x (256 / cb) row lanes, cb = 64, 32 or 16 — narrow matrices (the 20 / 28 offset channels of a
+  // deformable conv, 8 .. 64 k rows) keep all 256 lanes busy instead of 20 of every 64
+  __shared__ float red[256];
+  const int lanes = 256 / cb;
+  const int cl = threadIdx.x % cb, rl = threadIdx.x / cb;
+  const int col = blockIdx.x * cb + cl;
   const int64_t r0 = (int64_t)blockIdx.y * rows_per_split;
   int64_t r1 = r0 + rows_per_split;
   if (r1 > rows) r1 = rows;
   float acc = 0.f;
   if (col < C)
-    for (int64_t r = r0 + rl; r < r1; r += 4) acc += g[r * C + col];
-  red[rl][threadIdx.x & 63] = acc;
+    for (int64_t r = r0 + rl; r < r1; r += lanes) acc += g[r * C + col];
+  red[threadIdx.x] = acc;
   __syncthreads();
-  if (rl == 0 && col < C) {
-    const int l = threadIdx.x & 63;
-    partial[(size_t)blockIdx.y * C + col] = (red[0][l] + red[1][l]) + (red[2][l] + red[3][l]);
+  for (int half = lanes / 2; half > 0; half >>= 1) {      // fixed-order tree over the row lanes
+    if (rl < half) red[threadIdx.x] += red[threadIdx.x + half * cb];
+    __syncthreads();
   }
+  if (rl == 0 && col < C) partial[(size_t)blockIdx.y * C + col] = red[cl];
 }
-__global__ void colsum_final_kernel(const float* __restrict__ partial, float* __restrict__ out, int C,
-                                    int splits) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
+// one workgroup per column: the `splits` partial sums in a fixed-order tree (was: one thread per column walking up to 1024
+// partials — 49 us for the 20-column case)
+__global__ __launch_bounds__(64) void colsum_final_kernel(const float* __restrict__ partial, float* __restrict__ out, int C,
+                                                          int splits) {
+  const int c = blockIdx.x;
   float acc = 0.f;
-  for (int s = 0; s < splits; ++s) acc += partial[(size_t)s * C + c];
-  out[c] = acc;
+  for (int s = threadIdx.x; s < splits; s += 64) acc += partial[(size_t)s * C + c];
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 64);
+  if (threadIdx.x == 0) out[c] = acc;
 }
+static int colsum_cb(int C) { return C > 32 ? 64 : (C > 16 ? 32 : 16); }
 static int colsum_splits(int64_t rows, int C) {
-  const int col_blocks = ceil_div(C, 64);
+  const int col_blocks = ceil_div(C, colsum_cb(C));
   int64_t want = ceil_div64(kNumCU * 4, col_blocks);
   int64_t max_by_rows = ceil_div64(rows, 64);
   if (want > max_by_rows) want = max_by_rows;
@@ -489,10 +496,11 @@ extern "C" int dadet_colsum(const float* g, float* out, int64_t rows, int C, voi
     return DADET_EWORKSPACE;
   }
   const int64_t rps = ceil_div64(rows, splits);
-  hipLaunchKernelGGL(colsum_partial_kernel, dim3(ceil_div(C, 64), splits), dim3(256), 0, st, g,
-                     static_cast<float*>(workspace), rows, C, rps);
-  hipLaunchKernelGGL(colsum_final_kernel, dim3(ceil_div(C, 256)), dim3(256), 0, st,
-                     static_cast<const float*>(workspace), out, C, splits);
+  const int cb = colsum_cb(C);
+  hipLaunchKernelGGL(colsum_partial_kernel, dim3(ceil_div(C, cb), splits), dim3(256), 0, st, g,
+                     static_cast<float*>(workspace), rows, C, rps, cb);
+  hipLaunchKernelGGL(colsum_final_kernel, dim3(C), dim3(64), 0, st, static_cast<const float*>(workspace), out, C,
+                     splits);
   return check_launch("colsum");
 }
 

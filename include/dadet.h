@@ -153,16 +153,6 @@ int dadet_conv_forward(const dadet_conv_desc* d, const float* x, const float* w,
 int dadet_set_gemm_mode(int mode);
 int dadet_get_gemm_mode(void);
 
-/* dadet_conv_forward with the weights ALSO given as pre-split bf16 term planes: w_planes = [3][Cout][KH*KW*Cin] bf16, the
- * three terms dadet_weight_planes produces from `w` (hi = bf16(w), mid = bf16(w - hi), lo = bf16(w - hi - mid), round to
- * nearest even).  In mode 3 with K % 8 == 0 the kernels stream the planes into LDS by DMA instead of loading, splitting
- * and storing `w` in every tile; results are bit-identical to dadet_conv_forward.  Otherwise w_planes is ignored.
- * dadet_weight_planes: numel = Cout * K (multiple of 4); planes must hold 3 * numel bf16 (6 * numel bytes). */
-int dadet_conv_forward_wp(const dadet_conv_desc* d, const float* x, const float* w, const void* w_planes,
-                          const float* scale, const float* bias, const float* addend, const float* mask_ref, float* y,
-                          void* stream);
-int dadet_weight_planes(const float* w, void* planes, int64_t numel, void* stream);
-
 /* which tile variant dadet_conv_forward launches for this shape: 0 = 128x128 (conv_fwd_kernel<2,2>),
  * 1 = 128x64 (<2,1>), 2 = 64x64 (<1,1>).  Used by bench.py to attribute per-launch timings. */
 int dadet_conv_forward_variant(const dadet_conv_desc* d);
