@@ -606,11 +606,16 @@ def deform_sample_backward(x, offset, mask, gcols, kh, kw, stride, pad, dil, dg,
     mask = _nhwc(mask) if mask is not None else None
     N, C, H, W = x.shape
     Ho, Wo = offset.shape[2], offset.shape[3]
+    T = kh * kw
     gx = torch.empty_like(x).zero_() if need_x else None
     goffset = torch.empty_like(offset).zero_()
     gmask = torch.empty_like(mask).zero_() if mask is not None else None
-    _lib.call("dadet_deform_sample_backward", _p(x), _p(offset), _p(mask), _p(gcols), _p(gx), _p(goffset), _p(gmask),
-              N, H, W, C, kh, kw, stride, pad, dil, dg, Ho, Wo, _stream())
+    nbytes = ctypes.c_size_t(0)
+    _lib.call("dadet_deform_sample_backward_workspace_bytes", N, H, W, dg, ctypes.byref(nbytes))
+    ws = _workspace(nbytes.value, x.device)      # per-cell sample lists of the gather form (csrc/deform.hip)
+    _lib.call("dadet_deform_sample_backward_ld", _p(x), _p(offset), dg * 2 * T, _p(mask), dg * T, 0, _p(gcols), _p(gx),
+              _p(goffset), dg * 2 * T, _p(gmask), dg * T, N, H, W, C, kh, kw, stride, pad, dil, dg, Ho, Wo, _p(ws),
+              ctypes.c_size_t(ws.numel()), _stream())
     return gx, goffset, gmask
 
 
@@ -643,9 +648,12 @@ def deform_sample_backward_om(x, om, gcols, kh, kw, stride, pad, dil, dg, modula
     T = kh * kw
     gx = torch.empty_like(x).zero_()
     gom = torch.empty_like(om).zero_()
+    nbytes = ctypes.c_size_t(0)
+    _lib.call("dadet_deform_sample_backward_workspace_bytes", N, H, W, dg, ctypes.byref(nbytes))
+    ws = _workspace(nbytes.value, x.device)
     _lib.call("dadet_deform_sample_backward_ld", _p(x), _p(om), ld, _off_ptr(om, 2 * T * dg) if modulated else None, ld,
               1, _p(gcols), _p(gx), _p(gom), ld, _off_ptr(gom, 2 * T * dg) if modulated else None, ld,
-              N, H, W, C, kh, kw, stride, pad, dil, dg, Ho, Wo, _stream())
+              N, H, W, C, kh, kw, stride, pad, dil, dg, Ho, Wo, _p(ws), ctypes.c_size_t(ws.numel()), _stream())
     return gx, gom
 
 

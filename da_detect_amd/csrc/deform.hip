@@ -293,62 +293,67 @@ __global__ __launch_bounds__(256) void deform_sample_bwd_lds_kernel(const float*
   }
 }
 
-// Second form of the LDS-window backward (round 3).  The kernel above walks ONE (pixel, tap) per wavefront and
-// iteration — 4-byte loads, two 6-step wave reductions and a dependent chain of load -> weight -> ds_add -> reduce per
-// step, 144 steps per wavefront: latency bound (rocprofv3: 0.72 ms per call, 30 calls = 21.7 ms of the 85 ms
-// R-101-FPN-DCN step, its largest kernel).  Here a wavefront works on FOUR output pixels at once — 16 lanes x 4 channels
-// (16 bytes) per pixel, the 64 channels of the chunk — and on THREE taps per iteration with all 15 of their 16-byte loads
-// (gradient + four corners each) issued before the first use; the offset / mask gradients need 4-step reductions over 16
-// lanes instead of 6-step ones over 64.  12 iterations per wavefront instead of 144.  The window keeps its [cell][64]
-// float layout with the channel index rotated by the cell's column (channel c of cell (cy, cx) sits at (c + cx) & 63): the
-// four pixels of a wavefront hit neighbouring columns, and unrotated their lanes' ds_add_f32 would pile onto the same 16
-// banks (4-way conflicts).
-__global__ __launch_bounds__(256) void deform_sample_bwd_lds4_kernel(const float* __restrict__ x,
-                                                                     const float* __restrict__ offset,
-                                                                     const float* __restrict__ mask,
-                                                                     const float* __restrict__ gcols,
-                                                                     float* __restrict__ gx,
-                                                                     float* __restrict__ goffset,
-                                                                     float* __restrict__ gmask, DeformGeom g,
-                                                                     int tiles_x, int tiles_y) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  float* win = reinterpret_cast<float*>(smem);   // [kDWin * kDWin][kDChunk], channel index rotated by the column
-  const int tile = blockIdx.x;
-  const int n = tile / (tiles_x * tiles_y);
-  const int ty = (tile / tiles_x) % tiles_y, tx = tile % tiles_x;
-  const int y0 = ty * kDTile, x0 = tx * kDTile;
-  const int oy = y0 - g.pad - kDHalo, ox = x0 - g.pad - kDHalo;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+// ---- backward of the sampling without float atomics on the input gradient (round 3) --------------------------------
+// Measured (tools/deform_bwd_bench.py, res4 shape 2 x 64 x 128 x 256): the LDS-window kernel above spends 0.73 of its
+// 0.85 ms in the window's ds_add_f32 — LDS float atomics retire at ~0.4 lanes per clock and CU on this part — and the
+// reference's global-atomic form takes 1.9 ms.  The scatter is therefore turned into a GATHER through per-cell lists, in
+// two launches:
+//
+//  pass A (deform_sample_bwd_coord_kernel), sample-centric.  A wavefront takes 4 consecutive output pixels (16 lanes x 4
+//    channels each) and walks groups -> taps (three per step, their 15 sixteen-byte buffer loads in flight together) ->
+//    64-channel chunks: the gradients w.r.t. offsets / modulation are reductions over ALL channels of a (pixel, tap, group)
+//    sample, finished by one 4-step reduction over the 16 lanes and written with a plain store (one writer per address: no
+//    atomics, no zero fill, deterministic).  For each of the sample's <= 4 bilinear corners it also appends one 8-byte
+//    entry {sample index, weight * modulation} to the list of the input cell the corner lands on — an INTEGER atomic per
+//    (sample, corner), 36 per output pixel instead of 36 float atomics per output pixel AND CHANNEL.
+//  pass B (deform_gx_gather_kernel), cell-centric: a quarter-wavefront per (input cell, 64-channel chunk) walks the cell's
+//    list — eight entries per round, their gcols rows loaded together — and accumulates weight * gcols in registers, then
+//    adds the sum to gx with one plain 16-byte read-modify-write (it owns the address).  Offsets of any size are handled
+//    alike; gcols is read ~4 times (once per corner), rows of C * 4 bytes.
+// Lists hold kListCap entries per (cell, deformable group) (a regular 3x3 sampling pattern puts 36 on a cell); a corner
+// that finds its list full is added to gx directly with float atomics by pass A (gx is zero-filled by the caller).  The
+// order of a list — hence the last bits of gx — depends on the arrival order of the appends.
+constexpr int kListCap = 96;
+
+struct ListEntry {
+  unsigned sample;   // (m * T + tap): row of gcols
+  float weight;      // bilinear weight x modulation
+};
+
+__global__ __launch_bounds__(256) void deform_sample_bwd_coord_kernel(const float* __restrict__ x,
+                                                                      const float* __restrict__ offset,
+                                                                      const float* __restrict__ mask,
+                                                                      const float* __restrict__ gcols,
+                                                                      float* __restrict__ gx,
+                                                                      float* __restrict__ goffset,
+                                                                      float* __restrict__ gmask, int* __restrict__ counts,
+                                                                      ListEntry* __restrict__ entries, DeformGeom g) {
+  const int lane = threadIdx.x & 63;
   const int sub = lane >> 4, l16 = lane & 15;           // pixel of the wavefront's group of four, channel quad
-  const int c = blockIdx.y * kDChunk + l16 * 4;          // first of this lane's 4 channels
   const int T = g.KH * g.KW;
   const int cpg = g.C / g.dg;
-  const int grp = c / cpg;                               // (C / dg) % 4 == 0: a lane's 4 channels share the group
-  const bool uniform16 = (cpg % kDChunk) == 0;           // the 16 lanes of a pixel share one deformable group
-  {
-    float4* w4 = reinterpret_cast<float4*>(win);
-    for (int i = threadIdx.x; i < kDWin * kDWin * kDChunk / 4; i += 256) w4[i] = zero4();
-  }
-  __syncthreads();
+  const int64_t grp4 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int wo4 = (g.Wo + 3) / 4;
+  if (grp4 >= (int64_t)g.N * g.Ho * wo4) return;
+  const int n = (int)(grp4 / ((int64_t)g.Ho * wo4));
+  const int ho = (int)((grp4 / wo4) % g.Ho);
+  const int wo = (int)(grp4 % wo4) * 4 + sub;
+  const bool live = wo < g.Wo;
+  const size_t m = ((size_t)n * g.Ho + ho) * g.Wo + (live ? wo : 0);
   const float* __restrict__ img = x + (size_t)n * g.H * g.W * g.C;
   float* __restrict__ gimg = gx ? gx + (size_t)n * g.H * g.W * g.C : nullptr;
   const __amdgpu_buffer_rsrc_t xr = make_rsrc(img, (unsigned)((size_t)g.H * g.W * g.C * 4));
   const __amdgpu_buffer_rsrc_t gr = make_rsrc(gcols, (unsigned)((size_t)g.N * g.Ho * g.Wo * T * g.C * 4));
-  // a wavefront takes half a row of the 8 x 8 tile (4 consecutive pixels) per step
-  for (int p4 = wave; p4 < kDTile * kDTile / 4; p4 += 4) {
-    const int py = p4 / 2, px = (p4 & 1) * 4 + sub;
-    const int ho = y0 + py, wo = x0 + px;
-    const bool live = ho < g.Ho && wo < g.Wo;
-    const size_t m = ((size_t)n * g.Ho + (live ? ho : 0)) * g.Wo + (live ? wo : 0);
-    const float* __restrict__ off_m = offset + m * g.off_ld;
-    const float* __restrict__ msk_m = mask ? mask + m * g.mask_ld : nullptr;
-    float* __restrict__ goff_m = goffset + m * g.goff_ld;
-    float* __restrict__ gmsk_m = gmask ? gmask + m * g.gmask_ld : nullptr;
+  const float* __restrict__ off_m = offset + m * g.off_ld;
+  const float* __restrict__ msk_m = mask ? mask + m * g.mask_ld : nullptr;
+  float* __restrict__ goff_m = goffset + m * g.goff_ld;
+  float* __restrict__ gmsk_m = gmask ? gmask + m * g.gmask_ld : nullptr;
+  for (int grp = 0; grp < g.dg; ++grp) {
     for (int tap0 = 0; tap0 < T; tap0 += 3) {
       Corner k[3];
-      float mk[3];
-      float4 gv[3], a1[3], a2[3], a3[3], a4[3];
-      size_t p1[3];
+      float mk[3], cw[3][4];
+      unsigned full[3];       // bit q: corner q found its list full -> float atomics on gx (all lanes of the pixel)
+      unsigned b1o[3];
 #pragma unroll
       for (int u = 0; u < 3; ++u) {
         const int tap = tap0 + u;
@@ -357,87 +362,141 @@ __global__ __launch_bounds__(256) void deform_sample_bwd_lds4_kernel(const float
         const int i = tt / g.KW, j = tt - i * g.KW;
         const float oh = off_m[grp * 2 * T + 2 * tt], ow = off_m[grp * 2 * T + 2 * tt + 1];
         mk[u] = msk_m ? modulation(msk_m, grp * T + tt, g.mask_sigmoid) : 1.f;
-        const float h_im = (float)(ho - g.pad + i * g.dil) + oh;
-        const float w_im = (float)(wo - g.pad + j * g.dil) + ow;
+        const float h_im = (float)(ho * g.stride - g.pad + i * g.dil) + oh;
+        const float w_im = (float)(wo * g.stride - g.pad + j * g.dil) + ow;
         k[u] = corner_of(h_im, w_im, g.H, g.W);
         if (!on) k[u].valid = k[u].in1 = k[u].in2 = k[u].in3 = k[u].in4 = false;
-        p1[u] = ((size_t)k[u].hl * g.W + k[u].wl) * g.C + c;
-        // buffer loads: a corner outside the map / a tap beyond the last one is an out-of-range offset that returns 0 —
-        // no branches, all 15 loads of the three taps are in flight together (conv_common.h)
-        const unsigned b1o = (unsigned)p1[u] * 4u, rowb = (unsigned)(g.W * g.C) * 4u, pixb = (unsigned)g.C * 4u;
-        gv[u] = buf_load4(gr, on ? (unsigned)((m * T + tt) * g.C + c) * 4u : kOOB);
-        a1[u] = buf_load4(xr, k[u].in1 ? b1o : kOOB);
-        a2[u] = buf_load4(xr, k[u].in2 ? b1o + pixb : kOOB);
-        a3[u] = buf_load4(xr, k[u].in3 ? b1o + rowb : kOOB);
-        a4[u] = buf_load4(xr, k[u].in4 ? b1o + rowb + pixb : kOOB);
+        const float hh = 1.f - k[u].lh, hw = 1.f - k[u].lw;
+        cw[u][0] = hh * hw; cw[u][1] = hh * k[u].lw; cw[u][2] = k[u].lh * hw; cw[u][3] = k[u].lh * k[u].lw;
+        b1o[u] = (unsigned)(((size_t)k[u].hl * g.W + k[u].wl) * g.C) * 4u;
+        full[u] = 0;
+        if (gimg && l16 == 0) {        // one lane per pixel appends the sample's corners to their cells' lists
+          const bool cin[4] = {k[u].in1, k[u].in2, k[u].in3, k[u].in4};
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            if (!cin[q]) continue;
+            const size_t cell = ((size_t)n * g.H + (k[u].hl + (q >> 1))) * g.W + (k[u].wl + (q & 1));
+            const size_t list = cell * g.dg + grp;
+            const int slot = atomicAdd(counts + list, 1);
+            if (slot < kListCap) {
+              ListEntry en;
+              en.sample = (unsigned)(m * T + tt);
+              en.weight = cw[u][q] * mk[u];
+              entries[list * kListCap + slot] = en;
+            } else {
+              full[u] |= 1u << q;
+            }
+          }
+        }
+        full[u] = __shfl(full[u], lane & 48, 64);
+      }
+      float d_h[3] = {0.f, 0.f, 0.f}, d_w[3] = {0.f, 0.f, 0.f}, d_m[3] = {0.f, 0.f, 0.f};
+      for (int c = grp * cpg + l16 * 4; c < (grp + 1) * cpg; c += kDChunk) {
+        float4 gv[3], a1[3], a2[3], a3[3], a4[3];
+        const unsigned rowb = (unsigned)(g.W * g.C) * 4u, pixb = (unsigned)g.C * 4u, cb = (unsigned)c * 4u;
+#pragma unroll
+        for (int u = 0; u < 3; ++u) {
+          // buffer loads: a corner outside the map / a tap beyond the last one is an out-of-range offset that returns
+          // 0 — no branches, all 15 loads of the three taps are in flight together (conv_common.h)
+          const bool on = live && tap0 + u < T;
+          gv[u] = buf_load4(gr, on ? (unsigned)((m * T + tap0 + u) * g.C + c) * 4u : kOOB);
+          a1[u] = buf_load4(xr, k[u].in1 ? b1o[u] + cb : kOOB);
+          a2[u] = buf_load4(xr, k[u].in2 ? b1o[u] + pixb + cb : kOOB);
+          a3[u] = buf_load4(xr, k[u].in3 ? b1o[u] + rowb + cb : kOOB);
+          a4[u] = buf_load4(xr, k[u].in4 ? b1o[u] + rowb + pixb + cb : kOOB);
+        }
+#pragma unroll
+        for (int u = 0; u < 3; ++u) {
+          const float hh = 1.f - k[u].lh, hw = 1.f - k[u].lw;
+          const float g4[4] = {gv[u].x, gv[u].y, gv[u].z, gv[u].w};
+          const float b1[4] = {a1[u].x, a1[u].y, a1[u].z, a1[u].w}, b2[4] = {a2[u].x, a2[u].y, a2[u].z, a2[u].w};
+          const float b3[4] = {a3[u].x, a3[u].y, a3[u].z, a3[u].w}, b4[4] = {a4[u].x, a4[u].y, a4[u].z, a4[u].w};
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const float ge = g4[e] * mk[u];   // gradient wrt the unmasked sample
+            // get_coordinate_weight (deform_conv_kernel_cuda.cu:153-195): d sample / d h, d sample / d w
+            d_h[u] += ge * (hw * (b3[e] - b1[e]) + k[u].lw * (b4[e] - b2[e]));
+            d_w[u] += ge * (hh * (b2[e] - b1[e]) + k[u].lh * (b4[e] - b3[e]));
+            d_m[u] += g4[e] * (cw[u][0] * b1[e] + cw[u][1] * b2[e] + cw[u][2] * b3[e] + cw[u][3] * b4[e]);
+          }
+          if (full[u]) {      // overflowed lists (rare): this pixel's corners go to gx directly
+            float* base = gimg + ((size_t)k[u].hl * g.W + k[u].wl) * g.C + c;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              const float ge = g4[e] * mk[u];
+              if (full[u] & 1u) unsafeAtomicAdd(base + e, cw[u][0] * ge);
+              if (full[u] & 2u) unsafeAtomicAdd(base + g.C + e, cw[u][1] * ge);
+              if (full[u] & 4u) unsafeAtomicAdd(base + (size_t)g.W * g.C + e, cw[u][2] * ge);
+              if (full[u] & 8u) unsafeAtomicAdd(base + (size_t)g.W * g.C + g.C + e, cw[u][3] * ge);
+            }
+          }
+        }
       }
 #pragma unroll
       for (int u = 0; u < 3; ++u) {
         const int tap = tap0 + u;
-        const bool on = live && tap < T;
-        const float hh = 1.f - k[u].lh, hw = 1.f - k[u].lw;
-        const float w1 = hh * hw, w2 = hh * k[u].lw, w3 = k[u].lh * hw, w4 = k[u].lh * k[u].lw;
-        const float g4[4] = {gv[u].x, gv[u].y, gv[u].z, gv[u].w};
-        const float b1[4] = {a1[u].x, a1[u].y, a1[u].z, a1[u].w}, b2[4] = {a2[u].x, a2[u].y, a2[u].z, a2[u].w};
-        const float b3[4] = {a3[u].x, a3[u].y, a3[u].z, a3[u].w}, b4[4] = {a4[u].x, a4[u].y, a4[u].z, a4[u].w};
-        const int cy = k[u].hl - oy, cx = k[u].wl - ox;   // window cell of the top-left corner
-        const bool r0 = (unsigned)cy < (unsigned)kDWin, r1 = (unsigned)(cy + 1) < (unsigned)kDWin;
-        const bool q0 = (unsigned)cx < (unsigned)kDWin, q1 = (unsigned)(cx + 1) < (unsigned)kDWin;
-        float* cell = win + ((size_t)cy * kDWin + cx) * kDChunk;
-        float d_h = 0.f, d_w = 0.f, d_m = 0.f;
+        if (!k[u].valid) d_h[u] = d_w[u] = 0.f;
+        if (g.mask_sigmoid) d_m[u] = d_m[u] * mk[u] * (1.f - mk[u]);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const float ge = g4[e] * mk[u];   // gradient wrt the unmasked sample
-          if (gimg) {
-            const int ch = l16 * 4 + e;
-            const int s0 = (ch + cx) & (kDChunk - 1), s1 = (ch + cx + 1) & (kDChunk - 1);   // rotation by the column
-            if (k[u].in1) { if (r0 && q0) unsafeAtomicAdd(cell + s0, w1 * ge); else unsafeAtomicAdd(gimg + p1[u] + e, w1 * ge); }
-            if (k[u].in2) { if (r0 && q1) unsafeAtomicAdd(cell + kDChunk + s1, w2 * ge); else unsafeAtomicAdd(gimg + p1[u] + g.C + e, w2 * ge); }
-            if (k[u].in3) { if (r1 && q0) unsafeAtomicAdd(cell + kDWin * kDChunk + s0, w3 * ge); else unsafeAtomicAdd(gimg + p1[u] + (size_t)g.W * g.C + e, w3 * ge); }
-            if (k[u].in4) { if (r1 && q1) unsafeAtomicAdd(cell + (kDWin + 1) * kDChunk + s1, w4 * ge); else unsafeAtomicAdd(gimg + p1[u] + (size_t)g.W * g.C + g.C + e, w4 * ge); }
-          }
-          // get_coordinate_weight (deform_conv_kernel_cuda.cu:153-195): d sample / d h, d sample / d w
-          d_h += ge * (hw * (b3[e] - b1[e]) + k[u].lw * (b4[e] - b2[e]));
-          d_w += ge * (hh * (b2[e] - b1[e]) + k[u].lh * (b4[e] - b3[e]));
-          d_m += g4[e] * (w1 * b1[e] + w2 * b2[e] + w3 * b3[e] + w4 * b4[e]);
+        for (int o = 8; o > 0; o >>= 1) {      // sum over the 16 lanes of the pixel
+          d_h[u] += __shfl_xor(d_h[u], o, 64);
+          d_w[u] += __shfl_xor(d_w[u], o, 64);
+          d_m[u] += __shfl_xor(d_m[u], o, 64);
         }
-        if (!k[u].valid) d_h = d_w = 0.f;
-        if (g.mask_sigmoid) d_m = d_m * mk[u] * (1.f - mk[u]);
-        if (uniform16) {        // sum over the 16 lanes of the pixel
-#pragma unroll
-          for (int o = 8; o > 0; o >>= 1) {
-            d_h += __shfl_xor(d_h, o, 64);
-            d_w += __shfl_xor(d_w, o, 64);
-            d_m += __shfl_xor(d_m, o, 64);
-          }
-          if (l16 == 0 && on) {
-            atomicAdd(goff_m + grp * 2 * T + 2 * tap, d_h);
-            atomicAdd(goff_m + grp * 2 * T + 2 * tap + 1, d_w);
-            if (gmsk_m) atomicAdd(gmsk_m + grp * T + tap, d_m);
-          }
-        } else if (on) {
-          atomicAdd(goff_m + grp * 2 * T + 2 * tap, d_h);
-          atomicAdd(goff_m + grp * 2 * T + 2 * tap + 1, d_w);
-          if (gmsk_m) atomicAdd(gmsk_m + grp * T + tap, d_m);
+        if (l16 == 0 && live && tap < T) {     // the only writer of these addresses
+          goff_m[grp * 2 * T + 2 * tap] = d_h[u];
+          goff_m[grp * 2 * T + 2 * tap + 1] = d_w[u];
+          if (gmsk_m) gmsk_m[grp * T + tap] = d_m[u];
         }
       }
     }
   }
-  __syncthreads();
-  if (gimg) {
-    // flush: 16 lanes x 4 channels per cell, 4 cells per wavefront and step; the rotation is undone on the way out
-    for (int cell = wave * 4 + sub; cell < kDWin * kDWin; cell += 16) {
-      const int gy = oy + cell / kDWin, cxx = cell % kDWin, gxx = ox + cxx;
-      if ((unsigned)gy >= (unsigned)g.H || (unsigned)gxx >= (unsigned)g.W) continue;
-      const float* src = win + (size_t)cell * kDChunk;
-      float* dst = gimg + ((size_t)gy * g.W + gxx) * g.C + c;
+}
+
+// pass B: gx[cell][ch] += sum over the cell's list of weight * gcols[sample][ch]; a quarter-wavefront per (cell, chunk)
+__global__ __launch_bounds__(256) void deform_gx_gather_kernel(const float* __restrict__ gcols, float* __restrict__ gx,
+                                                               const int* __restrict__ counts,
+                                                               const ListEntry* __restrict__ entries, DeformGeom g) {
+  const int l16 = threadIdx.x & 15;
+  const int chunks = g.C / kDChunk;
+  const int cpg = g.C / g.dg;
+  const int64_t quarter = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 4;
+  const int64_t cells = (int64_t)g.N * g.H * g.W;
+  const int chunk = (int)(quarter % chunks);
+  const int64_t cell = quarter / chunks;
+  if (cell >= cells) return;
+  const int c = chunk * kDChunk + l16 * 4;
+  const size_t list = (size_t)cell * g.dg + c / cpg;
+  const int T = g.KH * g.KW;
+  const __amdgpu_buffer_rsrc_t gr = make_rsrc(gcols, (unsigned)((size_t)g.N * g.Ho * g.Wo * T * g.C * 4));
+  const int cnt = min(counts[list], kListCap);
+  const ListEntry* __restrict__ lst = entries + list * kListCap;
+  float4 acc = zero4();
+  for (int e0 = 0; e0 < cnt; e0 += 8) {
+    ListEntry en[8];
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const float v = src[(l16 * 4 + e + cxx) & (kDChunk - 1)];
-        if (v != 0.f) unsafeAtomicAdd(dst + e, v);
+    for (int u = 0; u < 8; ++u) {
+      if (e0 + u < cnt) {
+        en[u] = lst[e0 + u];
+      } else {
+        en[u].sample = 0xFFFFFFFFu;
+        en[u].weight = 0.f;
       }
     }
+    float4 v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+      v[u] = buf_load4(gr, en[u].sample != 0xFFFFFFFFu ? (unsigned)((size_t)en[u].sample * g.C + c) * 4u : kOOB);
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      acc.x += en[u].weight * v[u].x; acc.y += en[u].weight * v[u].y;
+      acc.z += en[u].weight * v[u].z; acc.w += en[u].weight * v[u].w;
+    }
   }
+  float4* dst = reinterpret_cast<float4*>(gx + (size_t)cell * g.C + c);
+  float4 o = *dst;          // the caller's zero fill + whatever overflowed lists sent here with atomics in pass A
+  o.x += acc.x; o.y += acc.y; o.z += acc.z; o.w += acc.w;
+  *dst = o;
 }
 
 static int deform_check(const char* who, int N, int H, int W, int C, int KH, int KW, int stride, int pad,
@@ -488,7 +547,8 @@ extern "C" int dadet_deform_sample_forward_ld(const float* x, const float* offse
 }
 
 static int deform_sample_backward_impl(const float* x, const float* offset, const float* mask, const float* gcols,
-                                       float* gx, float* goffset, float* gmask, DeformGeom g, void* stream) {
+                                       float* gx, float* goffset, float* gmask, DeformGeom g, void* workspace,
+                                       size_t workspace_bytes, void* stream) {
   int rc = deform_check("deform_sample_backward", g.N, g.H, g.W, g.C, g.KH, g.KW, g.stride, g.pad, g.dil, g.dg, g.Ho, g.Wo);
   if (rc) return rc;
   if (g.N == 0) return DADET_OK;
@@ -512,23 +572,25 @@ static int deform_sample_backward_impl(const float* x, const float* offset, cons
       }
       attr_set = true;
     }
-    static const bool one_pixel = getenv("DADET_DEFORM_BWD_LDS") && getenv("DADET_DEFORM_BWD_LDS")[0] == '1';
-    if (!one_pixel && (g.C / g.dg) % 4 == 0 && (((uintptr_t)x | (uintptr_t)gcols) & 15) == 0 && g.C % 4 == 0 &&
-        (uint64_t)g.N * g.Ho * g.Wo * T * g.C * 4 < 0xFFFFFFF0ull) {
-      static bool attr4_set = false;
-      if (!attr4_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(deform_sample_bwd_lds4_kernel),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) {
-          set_error("deform_sample_backward: hipFuncSetAttribute: %s", hipGetErrorString(e));
-          return DADET_ELAUNCH;
-        }
-        attr4_set = true;
+    static const bool window = getenv("DADET_DEFORM_BWD_LDS") && getenv("DADET_DEFORM_BWD_LDS")[0] == '1';
+    const size_t lists = (size_t)g.N * g.H * g.W * g.dg;
+    const size_t need = lists * sizeof(int) + 256 + lists * kListCap * sizeof(ListEntry);
+    if (!window && workspace && workspace_bytes >= need && ((g.C / g.dg) % kDChunk) == 0 &&
+        (((uintptr_t)x | (uintptr_t)gcols | (uintptr_t)gx | (uintptr_t)workspace) & 15) == 0 &&
+        (uint64_t)g.N * g.Ho * g.Wo * T * g.C * 4 < 0xFFFFFFF0ull && (uint64_t)g.N * g.Ho * g.Wo * T < 0xFFFFFFFFull) {
+      int* counts = static_cast<int*>(workspace);
+      ListEntry* entries = reinterpret_cast<ListEntry*>(static_cast<char*>(workspace) + ((lists * sizeof(int) + 255) & ~(size_t)255));
+      if (gx) (void)hipMemsetAsync(counts, 0, lists * sizeof(int), as_stream(stream));
+      // pass A: offset / modulation gradients + the per-cell lists, one wavefront per 4 pixels
+      const int64_t waves_a = (int64_t)g.N * g.Ho * ((g.Wo + 3) / 4);
+      hipLaunchKernelGGL(deform_sample_bwd_coord_kernel, dim3((unsigned)ceil_div64(waves_a, 4)), dim3(256), 0,
+                         as_stream(stream), x, offset, mask, gcols, gx, goffset, gmask, counts, entries, g);
+      if (gx) {   // pass B: the input gradient, gathered per cell (behind pass A in stream order)
+        const int64_t quarters = (int64_t)g.N * g.H * g.W * (g.C / kDChunk);
+        hipLaunchKernelGGL(deform_gx_gather_kernel, dim3((unsigned)ceil_div64(quarters, 16)), dim3(256), 0,
+                           as_stream(stream), gcols, gx, counts, entries, g);
       }
-      hipLaunchKernelGGL(deform_sample_bwd_lds4_kernel,
-                         dim3((unsigned)(g.N * tiles_x * tiles_y), (unsigned)(g.C / kDChunk)), dim3(256), lds,
-                         as_stream(stream), x, offset, mask, gcols, gx, goffset, gmask, g, tiles_x, tiles_y);
-      return check_launch("deform_sample_backward(lds4)");
+      return check_launch("deform_sample_backward(gather)");
     }
     hipLaunchKernelGGL(deform_sample_bwd_lds_kernel, dim3((unsigned)(g.N * tiles_x * tiles_y), (unsigned)(g.C / kDChunk)),
                        dim3(256), lds, as_stream(stream), x, offset, mask, gcols, gx, goffset, gmask, g, tiles_x,
@@ -547,17 +609,25 @@ extern "C" int dadet_deform_sample_backward(const float* x, const float* offset,
                                             int deformable_groups, int Ho, int Wo, void* stream) {
   const int T = KH * KW, dg = deformable_groups;
   DeformGeom g{N, H, W, C, KH, KW, stride, pad, dil, dg, Ho, Wo, dg * 2 * T, dg * T, dg * 2 * T, dg * T, 0};
-  return deform_sample_backward_impl(x, offset, mask, gcols, gx, goffset, gmask, g, stream);
+  return deform_sample_backward_impl(x, offset, mask, gcols, gx, goffset, gmask, g, nullptr, 0, stream);
+}
+
+extern "C" int dadet_deform_sample_backward_workspace_bytes(int N, int H, int W, int deformable_groups, size_t* bytes_out) {
+  DADET_REQUIRE(N >= 0 && H > 0 && W > 0 && deformable_groups > 0 && bytes_out, "deform_sample_backward_workspace_bytes: bad args");
+  const size_t lists = (size_t)N * H * W * deformable_groups;
+  *bytes_out = lists * sizeof(int) + 256 + lists * kListCap * sizeof(ListEntry);
+  return DADET_OK;
 }
 
 extern "C" int dadet_deform_sample_backward_ld(const float* x, const float* offset, int offset_ld, const float* mask,
                                                int mask_ld, int mask_is_logit, const float* gcols, float* gx,
                                                float* goffset, int goffset_ld, float* gmask, int gmask_ld, int N, int H,
                                                int W, int C, int KH, int KW, int stride, int pad, int dil,
-                                               int deformable_groups, int Ho, int Wo, void* stream) {
+                                               int deformable_groups, int Ho, int Wo, void* workspace,
+                                               size_t workspace_bytes, void* stream) {
   DeformGeom g{N, H, W, C, KH, KW, stride, pad, dil, deformable_groups, Ho, Wo, offset_ld, mask_ld, goffset_ld, gmask_ld,
                mask_is_logit};
-  return deform_sample_backward_impl(x, offset, mask, gcols, gx, goffset, gmask, g, stream);
+  return deform_sample_backward_impl(x, offset, mask, gcols, gx, goffset, gmask, g, workspace, workspace_bytes, stream);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -217,7 +217,11 @@ int dadet_deform_sample_forward_ld(const float* x, const float* offset, int offs
 int dadet_deform_sample_backward_ld(const float* x, const float* offset, int offset_ld, const float* mask, int mask_ld,
                                     int mask_is_logit, const float* gcols, float* gx, float* goffset, int goffset_ld,
                                     float* gmask, int gmask_ld, int N, int H, int W, int C, int KH, int KW, int stride,
-                                    int pad, int dil, int deformable_groups, int Ho, int Wo, void* stream);
+                                    int pad, int dil, int deformable_groups, int Ho, int Wo, void* workspace,
+                                    size_t workspace_bytes, void* stream);
+/* scratch for the gather form of the backward (per-cell lists of the samples whose bilinear corners land on a cell:
+ * csrc/deform.hip); without it (NULL / too small) the atomic forms run */
+int dadet_deform_sample_backward_workspace_bytes(int N, int H, int W, int deformable_groups, size_t* bytes_out);
 
 /* ROIPool — replaces `_C.roi_pool_forward / roi_pool_backward` (csrc/vision.cpp:11-12, ROIPool.h:11-46,
  * cuda/ROIPool_cuda.cu:16-108).  input [B][H][W][C] NHWC, rois [R][5] = (batch, x1, y1, x2, y2), output and
