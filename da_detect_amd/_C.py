@@ -746,6 +746,7 @@ SAMPLE_ROIS_MAX = 4096
 def sample_rois_buffers(rows, device):
     """output buffers of sample_rois for `rows` rows (several images can share one set, each writing its own slice)"""
     return dict(idx=torch.empty(rows, dtype=torch.int64, device=device),
+                objectness=torch.empty(rows, dtype=torch.float32, device=device),
                 boxes=torch.empty((rows, 4), dtype=torch.float32, device=device),
                 labels=torch.empty(rows, dtype=torch.int64, device=device),
                 regression_targets=torch.empty((rows, 4), dtype=torch.float32, device=device),
@@ -775,6 +776,35 @@ def sample_rois(boxes, labels, regression_targets, cap, max_pos, seed, is_source
               _p(out["labels"]), _p(out["regression_targets"]), _p(out["loss_labels"]), _p(out["domain"]),
               _p(counts_out), _stream())
     return out
+
+
+def proposals_sample(pending, gt_boxes, gt_labels, high, low, weights, cap, max_pos, seed, is_source, counts_out,
+                     out=None):
+    """box-head sample of one image straight from the RPN's NMS result on the device (dadet_proposals_sample).
+    pending: structures.bounding_box.PendingProposals.pending (sorted_boxes, sorted_scores, keep, count_dev, post_n, gt).
+    -> (out dict as sample_rois + "objectness", prop_boxes [post_n + G', 4], prop_scores, n_props int32 [1])"""
+    sb, ss = pending["sorted_boxes"].contiguous(), pending["sorted_scores"].contiguous()
+    keep, count = pending["keep"], pending["count_dev"]
+    post_n = int(pending["post_n"])
+    app = pending["gt"].bbox.contiguous() if pending["gt"] is not None else None
+    n_app = int(app.shape[0]) if app is not None else 0
+    dev = sb.device
+    if out is None:
+        out = sample_rois_buffers(cap, dev)
+    if "objectness" not in out:
+        out["objectness"] = torch.empty(cap, dtype=torch.float32, device=dev)
+    G = int(gt_boxes.shape[0]) if gt_boxes is not None else 0
+    prop_boxes = torch.empty((post_n + n_app, 4), dtype=torch.float32, device=dev)
+    prop_scores = torch.empty(post_n + n_app, dtype=torch.float32, device=dev)
+    n_props = torch.empty(1, dtype=torch.int32, device=dev)
+    wx, wy, ww, wh = weights
+    _lib.call("dadet_proposals_sample", _p(sb), _p(ss), _p(keep), _p(count), post_n, _p(app), n_app,
+              _p(gt_boxes.contiguous()) if G else None, _p(gt_labels.contiguous()) if G else None, G, float(high),
+              float(low), float(wx), float(wy), float(ww), float(wh), int(cap), int(max_pos),
+              ctypes.c_uint64(int(seed) & 0xFFFFFFFFFFFFFFFF), 1 if is_source else 0, _p(prop_boxes), _p(prop_scores),
+              _p(n_props), _p(out["idx"]), _p(out["boxes"]), _p(out["labels"]), _p(out["regression_targets"]),
+              _p(out["loss_labels"]), _p(out["domain"]), _p(out["objectness"]), _p(counts_out), _stream())
+    return out, prop_boxes, prop_scores, n_props
 
 
 SAMPLE_ANCHORS_MAX_CAP = 1024

@@ -78,6 +78,8 @@ _SIGNATURES = {
     "dadet_fast_rcnn_loss": [_P, _P, c_int, c_int, _P, _P, c_int, _P, _P, _P, c_int, _P, _P, _P, _P],
     "dadet_fast_rcnn_loss_rows": [_P, _P, c_int, c_int, c_int, _P, _P, _P, _P, _P, _P],
     "dadet_sample_rois": [_P, _P, _P, c_int, c_int, c_int, c_uint64, c_int, _P, _P, _P, _P, _P, _P, _P, _P],
+    "dadet_proposals_sample": [_P, _P, _P, _P, c_int, _P, c_int, _P, _P, c_int, c_float, c_float, c_float, c_float, c_float,
+                               c_float, c_int, c_int, c_uint64, c_int, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P],
     "dadet_sample_anchors": [_P, _P, c_int, c_int, c_int, c_uint64, c_int64, _P, _P, _P, _P, _P],
     "dadet_topk_sorted": [_P, c_int, c_int, c_int64, c_int, _P, _P, _P],
     "dadet_rpn_anchor_targets": [_P, _P, c_int, _P, c_int, c_float, c_float, _P, _P, _P, _P],

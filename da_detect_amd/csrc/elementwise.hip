@@ -1,6 +1,7 @@
 // HBM-bound helpers of the DA Faster R-CNN training path (NHWC fp32, gfx950).
 // Every kernel moves 16 B per lane with lanes along the channel axis and a capped grid-stride launch.
 // Each entry point cites the reference code it stands in for.
+#include "box_match.h"
 #include "common.h"
 #include <float.h>
 
@@ -322,33 +323,11 @@ __global__ void box_match_encode_kernel(const float4* __restrict__ props, int P,
   __syncthreads();
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= P) return;
-  const float4 p = props[i];
-  const float area = (p.z - p.x + 1.f) * (p.w - p.y + 1.f);
-  float best = -1.f;
-  int arg = 0;
-  for (int g = 0; g < G; ++g) {
-    const float4 b = g_box[g];
-    const float w = fmaxf(fminf(b.z, p.z) - fmaxf(b.x, p.x) + 1.f, 0.f);
-    const float h = fmaxf(fminf(b.w, p.w) - fmaxf(b.y, p.y) + 1.f, 0.f);
-    const float inter = w * h;
-    const float iou = inter / (g_area[g] + area - inter);
-    if (iou > best) {
-      best = iou;
-      arg = g;
-    }
-  }
-  int64_t m = arg;
-  if (best < low) m = -1;
-  else if (best < high) m = -2;
+  float4 reg;
+  int64_t m;
+  labels[i] = match_encode_one(props[i], g_box, g_area, gt_labels, G, high, low, wx, wy, ww, wh, &reg, &m);
   matched[i] = m;
-  const int src = m < 0 ? 0 : (int)m;   // matched_idxs.clamp(min=0)
-  labels[i] = m == -1 ? 0 : (m == -2 ? -1 : gt_labels[src]);
-  const float4 r = g_box[src];
-  const float ew = p.z - p.x + 1.f, eh = p.w - p.y + 1.f;
-  const float ecx = p.x + 0.5f * ew, ecy = p.y + 0.5f * eh;
-  const float gw = r.z - r.x + 1.f, gh = r.w - r.y + 1.f;
-  const float gcx = r.x + 0.5f * gw, gcy = r.y + 0.5f * gh;
-  targets[i] = make_float4(wx * (gcx - ecx) / ew, wy * (gcy - ecy) / eh, ww * logf(gw / ew), wh * logf(gh / eh));
+  targets[i] = reg;
 }
 
 // ---- sigmoid focal loss (reference: csrc/cuda/SigmoidFocalLoss_cuda.cu:21-101) ----------------

@@ -15,6 +15,8 @@
 //   * output compaction to ascending ORIGINAL indices (nms_cpu.cpp:64 / nms.cu:127-130) by a
 //     workgroup scan, written as int64.
 // Built with -ffp-contract=off so the IoU arithmetic is the reference's (nms_cpu.cpp:50-60).
+#include <cstdlib>
+
 #include "common.h"
 
 namespace dadet {
@@ -237,6 +239,109 @@ __global__ __launch_bounds__(1024) void nms_sweep_kernel(const unsigned long lon
   }
 }
 
+// ---- greedy sweep, pipelined (round 3) --------------------------------------------------------------------------
+// nms_sweep_kernel above is a dependent chain of col_blocks steps, each "barrier, resolve the diagonal tile, barrier, every
+// thread loads the kept rows' words (1 - 2 round trips to L2), barrier": ~2.3 us per 64-box chunk, 0.44 ms for the RPN's
+// 12 000 boxes — the longest single item between the RPN head and the box head (rocprofv3 timeline, round 3).  The loads
+// are what a step waits for, and only ONE of them is needed at once: chunk c + 1 must know what chunk c's kept boxes
+// remove from it; everything further right has time.  So:
+//   * the (c, c + 1) off-diagonal tile is PREFETCHED one iteration ahead into wave 0's lanes (one word per lane, no
+//     dependence on any decision) and folded into the same scalar loop that resolves the diagonal — when box j is kept,
+//     its diagonal word joins `rem` and its next-tile word joins `adj`, the removed-set of chunk c + 1 contributed by
+//     chunk c; no memory access sits between two chunks' resolutions;
+//   * the other threads' loads for chunk c (word w of every kept row, w >= c + 2) are ISSUED after chunk c's keep bits are
+//     known and CONSUMED one iteration later, i.e. they are in flight while chunk c + 1 is resolved.
+// Same keep bits as nms_sweep_kernel (tests/test_ops_gpu.py runs both).
+__global__ __launch_bounds__(256) void nms_sweep_pipelined_kernel(const unsigned long long* __restrict__ mask, int n,
+                                                                   int col_blocks, int max_keep,
+                                                                   unsigned long long* __restrict__ keep_bits) {
+  __shared__ unsigned long long s_removed_c;  // removed word of the current chunk from chunks <= c - 2
+  __shared__ unsigned long long s_keep;       // keep bits of the current chunk
+  __shared__ int s_kept_total;
+  const int w = threadIdx.x;
+  const int lane = threadIdx.x & 63;
+  const bool wave0 = threadIdx.x < 64;
+  unsigned long long removed = 0;             // word w of the removed set, from the chunks whose loads were consumed
+  constexpr int kFly = 64;
+  unsigned long long fly[kFly];               // this thread's loads in flight: word w of the previous chunk's kept rows
+#pragma unroll
+  for (int u = 0; u < kFly; ++u) fly[u] = 0;
+  if (threadIdx.x == 0) s_kept_total = 0;
+  // wave 0, lane j: diagonal word of box (c * 64 + j) and its word of the next column block, fetched one chunk ahead
+  unsigned long long diag_next = 0, tile_next = 0;
+  if (wave0 && lane < n) {
+    diag_next = mask[(size_t)lane * col_blocks];
+    if (col_blocks > 1) tile_next = mask[(size_t)lane * col_blocks + 1];
+  }
+  unsigned adj_lo = 0, adj_hi = 0;            // wave 0 (uniform): what chunk c - 1's kept boxes remove from chunk c
+  __syncthreads();
+  for (int c = 0; c < col_blocks; ++c) {
+    if (w == c) s_removed_c = removed;        // chunks <= c - 2 (chunk c - 1's part is `adj`)
+    __syncthreads();
+    if (wave0) {
+      const unsigned long long diag = diag_next, tile = tile_next;
+      const int nbox = (c + 1) * 64 + lane;
+      diag_next = (c + 1 < col_blocks && nbox < n) ? mask[(size_t)nbox * col_blocks + c + 1] : 0ULL;
+      tile_next = (c + 2 < col_blocks && nbox < n) ? mask[(size_t)nbox * col_blocks + c + 2] : 0ULL;
+      const unsigned lo = (unsigned)diag, hi = (unsigned)(diag >> 32);
+      const unsigned tlo = (unsigned)tile, thi = (unsigned)(tile >> 32);
+      const unsigned long long rem0 = s_removed_c;
+      const unsigned rem_lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)rem0) | adj_lo;
+      const unsigned rem_hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(rem0 >> 32)) | adj_hi;
+      unsigned long long rem = ((unsigned long long)rem_hi << 32) | (unsigned long long)rem_lo;
+      const int limit = min(64, n - c * 64);
+      const unsigned long long valid = limit >= 64 ? ~0ULL : ((1ULL << limit) - 1ULL);
+      unsigned long long keep = 0;
+      int kept_total = __builtin_amdgcn_readfirstlane(s_kept_total);
+      unsigned long long alive = ~rem & valid;
+      unsigned nlo = 0, nhi = 0;
+      while (alive) {
+        if (max_keep > 0 && kept_total >= max_keep) break;
+        const int j = __ffsll((long long)alive) - 1;
+        keep |= 1ULL << j;
+        ++kept_total;
+        const unsigned dlo = (unsigned)__builtin_amdgcn_readlane((int)lo, j);
+        const unsigned dhi = (unsigned)__builtin_amdgcn_readlane((int)hi, j);
+        nlo |= (unsigned)__builtin_amdgcn_readlane((int)tlo, j);
+        nhi |= (unsigned)__builtin_amdgcn_readlane((int)thi, j);
+        rem |= ((unsigned long long)dhi << 32) | dlo;
+        alive = ~rem & valid & ~((2ULL << j) - 1ULL);
+      }
+      adj_lo = nlo;
+      adj_hi = nhi;
+      if (lane == 0) {
+        s_keep = keep;
+        s_kept_total = kept_total;
+        keep_bits[c] = keep;
+      }
+    }
+    // the loads issued one iteration ago (rows of chunk c - 1, word w) have had a whole resolution to land
+    if (w > c) {
+      unsigned long long acc = 0;
+#pragma unroll
+      for (int u = 0; u < kFly; ++u) acc |= fly[u];
+      removed |= acc;
+    }
+    __syncthreads();
+    if (max_keep > 0 && s_kept_total >= max_keep) {      // quota filled: later chunks keep nothing
+      for (int cc = c + 1 + (int)threadIdx.x; cc < col_blocks; cc += blockDim.x) keep_bits[cc] = 0;
+      break;
+    }
+    // issue the loads for chunk c's kept rows (consumed in the next iteration); word c + 1 is wave 0's `adj`
+    {
+      unsigned long long k = s_keep;
+      const bool mine = w >= c + 2 && w < col_blocks;
+      const unsigned long long* mrow = mask + (size_t)c * 64 * col_blocks + (mine ? w : 0);
+#pragma unroll
+      for (int u = 0; u < kFly; ++u) {
+        const int j = k ? (__ffsll((long long)k) - 1) : -1;
+        k &= (k - 1);
+        fly[u] = (mine && j >= 0) ? mrow[(size_t)j * col_blocks] : 0ULL;
+      }
+    }
+  }
+}
+
 // ---- compaction to ascending original indices ----------------------------------------------
 __global__ void nms_flag_kernel(const unsigned long long* __restrict__ keep_bits,
                                 const int* __restrict__ order, int n, unsigned char* __restrict__ flag) {
@@ -373,8 +478,13 @@ extern "C" int dadet_nms(const float* boxes_xyxy, const float* scores, int n, fl
   else
     hipLaunchKernelGGL(nms_mask_kernel<1>, mgrid, dim3(64), 0, st, sorted, n, thresh, col_blocks, mask);
   const int sweep_threads = col_blocks <= 64 ? 64 : ((col_blocks + 63) / 64) * 64;
-  hipLaunchKernelGGL(nms_sweep_kernel, dim3(1), dim3(sweep_threads), 0, st, mask, n, col_blocks, max_keep,
-                     keep_bits);
+  static const bool plain_sweep = getenv("DADET_NMS_SWEEP") && getenv("DADET_NMS_SWEEP")[0] == '0';
+  if (plain_sweep || sweep_threads > 256)     // the pipelined form holds 64 loads per thread: up to 16 384 boxes
+    hipLaunchKernelGGL(nms_sweep_kernel, dim3(1), dim3(sweep_threads), 0, st, mask, n, col_blocks, max_keep,
+                       keep_bits);
+  else
+    hipLaunchKernelGGL(nms_sweep_pipelined_kernel, dim3(1), dim3(sweep_threads), 0, st, mask, n, col_blocks, max_keep,
+                       keep_bits);
   hipLaunchKernelGGL(nms_flag_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, st, keep_bits, order, n, flag);
   hipLaunchKernelGGL(nms_compact_kernel, dim3(1), dim3(64), 0, st, flag, n, keep_out, num_keep_out);
   return check_launch("nms");

@@ -16,6 +16,7 @@
 #include <cstdint>
 
 #include "common.h"
+#include "box_match.h"
 
 namespace dadet {
 
@@ -126,6 +127,154 @@ __global__ __launch_bounds__(kSampleThreads) void sample_rois_kernel(
   }
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// Proposal hand-over on the device (round 3): NMS -> box-head sample of ONE image without the kept-count round trip.
+//
+// Between the RPN's NMS and the box head's sampler the reference (and this package until round 2) goes through the host:
+// the kept count is read back (rpn/inference.py:102 `boxlist = boxlist[keep]`, a device->host synchronisation), the kept
+// boxes and scores are gathered, the ground-truth boxes of source images are concatenated (rpn/inference.py:51-74), then
+// FastRCNNLossComputation.prepare_targets / subsample run on a proposal list whose length the host knows
+// (roi_heads/box_head/loss.py:55-130).  Here ONE single-workgroup launch reads the NMS result where it lies —
+// keep[0 .. count) in device memory — and does all of it: proposal i is sorted_boxes[keep[i]] for i < min(count, post_n),
+// then the G ground-truth boxes (source images); IoU / Matcher / label rules / BoxCoder.encode per proposal exactly as
+// dadet_box_match_encode (same arithmetic order, match_encode_one in box_match.h); the balanced random sample exactly
+// as sample_rois_kernel above (same keys: splitmix64(seed, position in the proposal list)).  It also leaves the proposal
+// list itself (boxes, objectness, length) in device buffers, for callers that want it on the host later.
+__global__ __launch_bounds__(kSampleThreads) void proposals_sample_kernel(
+    const float4* __restrict__ sorted_boxes, const float* __restrict__ sorted_scores, const int64_t* __restrict__ keep,
+    const int* __restrict__ count_dev, int post_n, const float4* __restrict__ app_gts, int G_app,
+    const float4* __restrict__ gts, const int64_t* __restrict__ gt_labels, int G, float high, float low, float wx,
+    float wy, float ww, float wh, int N, int cap, int max_pos, uint64_t seed,
+    int is_source, float4* __restrict__ prop_boxes, float* __restrict__ prop_scores, int* __restrict__ n_props,
+    int64_t* __restrict__ idx_out, float4* __restrict__ boxes_out, int64_t* __restrict__ labels_out,
+    float4* __restrict__ reg_out, int64_t* __restrict__ loss_labels_out, unsigned char* __restrict__ domain_out,
+    float* __restrict__ obj_out, int* __restrict__ counts) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  uint64_t* keys = reinterpret_cast<uint64_t*>(smem);                     // [N]
+  int* flag = reinterpret_cast<int*>(smem + sizeof(uint64_t) * N);        // [N]
+  float4* g_box = reinterpret_cast<float4*>(smem + (sizeof(uint64_t) + sizeof(int)) * N);   // [G]
+  float* g_area = reinterpret_cast<float*>(g_box + G);                     // [G]
+  __shared__ int s_cnt[2];
+  __shared__ int s_scan[kSampleThreads];
+  const int t = threadIdx.x;
+  if (t < 2) s_cnt[t] = 0;
+  for (int g = t; g < G; g += kSampleThreads) {
+    const float4 b = gts[g];
+    g_box[g] = b;
+    g_area[g] = (b.z - b.x + 1.f) * (b.w - b.y + 1.f);
+  }
+  int kept = *count_dev;
+  if (kept > post_n) kept = post_n;
+  // appended boxes: add_gt_proposals gives SOURCE images their own ground truth (rpn/inference.py:51-74).  The boxes
+  // matched against (gts) are the target list the box head was called with — the same boxes, except in the aligned
+  // triplet passes, which pool another image's proposals (generalized_rcnn.py:110-112)
+  const int n = kept + G_app;
+  __syncthreads();
+  auto proposal = [&](int i, float* score) -> float4 {
+    if (i < kept) {
+      const int64_t src = keep[i];
+      *score = sorted_scores[src];
+      return sorted_boxes[src];
+    }
+    *score = 1.f;
+    return app_gts[i - kept];
+  };
+  int my_pos = 0, my_neg = 0;
+  for (int i = t; i < N; i += kSampleThreads) {
+    uint64_t cls = 3;   // padding sorts last
+    if (i < n) {
+      float sc;
+      const float4 p = proposal(i, &sc);
+      prop_boxes[i] = p;
+      prop_scores[i] = sc;
+      int64_t lab = 0;
+      if (is_source) {
+        float4 reg;
+        lab = match_encode_one(p, g_box, g_area, gt_labels, G, high, low, wx, wy, ww, wh, &reg);
+      }
+      cls = lab >= 1 ? 0 : (lab == 0 ? 1 : 2);
+      my_pos += cls == 0;
+      my_neg += cls == 1;
+    }
+    keys[i] = (cls << 45) | ((uint64_t)sample_key(seed, (uint32_t)i) << 13) | (uint64_t)i;
+    flag[i] = 0;
+  }
+  if (t == 0) *n_props = n;
+  if (my_pos) atomicAdd(&s_cnt[0], my_pos);
+  if (my_neg) atomicAdd(&s_cnt[1], my_neg);
+  __syncthreads();
+  for (int k = 2; k <= N; k <<= 1)
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      for (int i = t; i < N; i += kSampleThreads) {
+        const int p = i ^ j;
+        if (p > i) {
+          const uint64_t a = keys[i], b = keys[p];
+          const bool up = (i & k) == 0;
+          if ((a > b) == up) {
+            keys[i] = b;
+            keys[p] = a;
+          }
+        }
+      }
+      __syncthreads();
+    }
+  const int n_pos = s_cnt[0], n_neg = s_cnt[1];
+  const int num_pos = n_pos < max_pos ? n_pos : max_pos;
+  const int num_neg = n_neg < cap - num_pos ? n_neg : cap - num_pos;
+  for (int p = t; p < N; p += kSampleThreads) {
+    const bool take = p < num_pos || (p >= n_pos && p < n_pos + num_neg);
+    if (take) flag[(int)(keys[p] & 0x1FFFu)] = 1;
+  }
+  __syncthreads();
+  const int C = (N + kSampleThreads - 1) / kSampleThreads;
+  int mine = 0;
+  for (int c = 0; c < C; ++c) {
+    const int i = t * C + c;
+    if (i < N) mine += flag[i];
+  }
+  s_scan[t] = mine;
+  __syncthreads();
+  for (int off = 1; off < kSampleThreads; off <<= 1) {
+    const int v = t >= off ? s_scan[t - off] : 0;
+    __syncthreads();
+    s_scan[t] += v;
+    __syncthreads();
+  }
+  int out = s_scan[t] - mine;
+  for (int c = 0; c < C; ++c) {
+    const int i = t * C + c;
+    if (i < N && flag[i]) {
+      float sc;
+      const float4 p = proposal(i, &sc);
+      int64_t lab = 0;
+      float4 reg = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (is_source) lab = match_encode_one(p, g_box, g_area, gt_labels, G, high, low, wx, wy, ww, wh, &reg);
+      idx_out[out] = i;
+      boxes_out[out] = p;
+      labels_out[out] = lab;
+      reg_out[out] = reg;
+      loss_labels_out[out] = is_source ? lab : -1;
+      domain_out[out] = is_source ? 1 : 0;
+      obj_out[out] = sc;
+      ++out;
+    }
+  }
+  const int total = num_pos + num_neg;
+  for (int r = total + t; r < cap; r += kSampleThreads) {   // rows past the sample: defined, never read
+    idx_out[r] = -1;
+    boxes_out[r] = make_float4(0.f, 0.f, 0.f, 0.f);
+    labels_out[r] = 0;
+    reg_out[r] = make_float4(0.f, 0.f, 0.f, 0.f);
+    loss_labels_out[r] = -1;
+    domain_out[r] = is_source ? 1 : 0;
+    obj_out[r] = 0.f;
+  }
+  if (t == 0) {
+    counts[0] = total;
+    counts[1] = num_pos;
+  }
+}
+
 }  // namespace dadet
 
 using namespace dadet;
@@ -152,6 +301,54 @@ extern "C" int dadet_sample_rois(const float* boxes, const int64_t* labels, cons
                      labels_out, reinterpret_cast<float4*>(regression_targets_out), loss_labels_out, domain_out,
                      counts_out);
   return check_launch("sample_rois");
+}
+
+extern "C" int dadet_proposals_sample(const float* sorted_boxes, const float* sorted_scores, const int64_t* keep,
+                                      const int* count_dev, int post_n, const float* appended_boxes, int num_appended,
+                                      const float* gt_boxes, const int64_t* gt_labels, int G, float high_threshold,
+                                      float low_threshold, float wx, float wy, float ww,
+                                      float wh, int cap, int max_pos, uint64_t seed, int is_source, float* prop_boxes,
+                                      float* prop_scores, int* n_props, int64_t* idx_out, float* boxes_out,
+                                      int64_t* labels_out, float* regression_targets_out, int64_t* loss_labels_out,
+                                      unsigned char* domain_out, float* objectness_out, int* counts_out, void* stream) {
+  using namespace dadet;
+  DADET_REQUIRE(post_n >= 0 && G >= 0 && num_appended >= 0 && post_n + num_appended <= kSampleMaxN,
+                "proposals_sample: post_n + appended = %d outside 0..%d", post_n + num_appended, kSampleMaxN);
+  DADET_REQUIRE(num_appended == 0 || appended_boxes, "proposals_sample: null appended boxes");
+  DADET_REQUIRE(G <= 1024, "proposals_sample: G=%d ground-truth boxes exceed the LDS table", G);
+  DADET_REQUIRE(cap > 0 && max_pos >= 0 && max_pos <= cap, "proposals_sample: bad cap=%d / max_pos=%d", cap, max_pos);
+  DADET_REQUIRE(sorted_boxes && sorted_scores && keep && count_dev && prop_boxes && prop_scores && n_props && idx_out &&
+                    boxes_out && labels_out && regression_targets_out && loss_labels_out && domain_out &&
+                    objectness_out && counts_out && (G == 0 || (gt_boxes && (!is_source || gt_labels))),
+                "proposals_sample: null pointer");
+  DADET_REQUIRE(!is_source || G > 0, "proposals_sample: a source image needs ground-truth boxes");
+  auto a16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
+  DADET_REQUIRE(a16(sorted_boxes) && a16(gt_boxes) && a16(appended_boxes) && a16(prop_boxes) && a16(boxes_out) &&
+                    a16(regression_targets_out),
+                "proposals_sample: box arrays must be 16-byte aligned");
+  int N = 2;
+  while (N < post_n + num_appended) N <<= 1;
+  const size_t lds = (sizeof(uint64_t) + sizeof(int)) * (size_t)N + (size_t)G * 20;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(proposals_sample_kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       (int)((sizeof(uint64_t) + sizeof(int)) * kSampleMaxN + 1024 * 20));
+    if (e != hipSuccess) {
+      set_error("proposals_sample: hipFuncSetAttribute: %s", hipGetErrorString(e));
+      return DADET_ELAUNCH;
+    }
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(proposals_sample_kernel, dim3(1), dim3(kSampleThreads), lds, as_stream(stream),
+                     reinterpret_cast<const float4*>(sorted_boxes), sorted_scores, keep, count_dev, post_n,
+                     reinterpret_cast<const float4*>(appended_boxes), num_appended,
+                     reinterpret_cast<const float4*>(gt_boxes), gt_labels, G, high_threshold, low_threshold, wx, wy, ww,
+                     wh, N, cap, max_pos, (uint64_t)seed, is_source, reinterpret_cast<float4*>(prop_boxes), prop_scores,
+                     n_props, idx_out, reinterpret_cast<float4*>(boxes_out), labels_out,
+                     reinterpret_cast<float4*>(regression_targets_out), loss_labels_out, domain_out, objectness_out,
+                     counts_out);
+  return check_launch("proposals_sample");
 }
 
 // ------------------------------------------------------------------------------------------------------------------

@@ -79,6 +79,9 @@ class GeneralizedRCNN(nn.Module):
                 run_early_da()
         if self.training and self.roi_heads and (self.da_heads or self.da_heads_triplet) and elision_enabled():
             self.rpn.live_images = self._images_with_read_proposals(targets)
+        if self.training and self.roi_heads and features[0].is_cuda:
+            # the box head's sampler reads the NMS result on the device: the RPN need not bring the kept count to the host
+            self.rpn.box_selector_train.defer = self.roi_heads.box.loss_evaluator.accepts_pending()
         proposals, proposal_losses = self.rpn(images, features, targets)
         if self.training:
             pending, self.rpn.after_early_backward = self.rpn.after_early_backward, None

@@ -52,10 +52,11 @@ class ROIBoxHead(torch.nn.Module):
             # sampling runs on the side stream: its host round trips then do not wait for the RPN-head backward
             # queued on the compute stream just before (RPNModule.early_backward)
             after, self.proposals_ready = self.proposals_ready, None
-            with side_section(proposals[0].bbox.device, after=after) as done, torch.no_grad():
+            dev = features[0].device      # (not proposals[0].bbox: that would materialise a device-resident list)
+            with side_section(dev, after=after) as done, torch.no_grad():
                 proposals = self.loss_evaluator.subsample(proposals, targets)
                 for _ in range(burn):
-                    rng.next_seed(proposals[0].bbox.device)
+                    rng.next_seed(dev)
                 # the reference draws the DA ROI sample after the detection losses (box_head.py:102-104); nothing
                 # between the two draws from the random stream, so drawing it here is the same sample — and it keeps
                 # every host synchronisation of the box head in front of the res5 head instead of behind it

@@ -26,6 +26,12 @@ def _nz(mask, size):
 _STATIC = __import__("os").environ.get("DADET_NONZERO_STATIC", "1") == "1"
 # one-launch-per-image sampling (dadet_sample_rois); DADET_FUSED_SAMPLER=0 keeps the ATen chain
 _FUSED = __import__("os").environ.get("DADET_FUSED_SAMPLER", "1") == "1"
+# NMS -> sampler hand-over on the device (dadet_proposals_sample); DADET_PENDING_PROPOSALS=0: the kept count goes through the host
+_PENDING = __import__("os").environ.get("DADET_PENDING_PROPOSALS", "1") == "1"
+
+
+def _is_pending(p):
+    return getattr(type(p), "is_pending_proposals", False) and p.pending is not None
 
 class FastRCNNLossComputation(object):
     def __init__(self, proposal_matcher, fg_bg_sampler, box_coder, cls_agnostic_bbox_reg=False):
@@ -92,43 +98,67 @@ class FastRCNNLossComputation(object):
             proposals[i] = proposals[i][_nz(pm | nm, size=k).squeeze(1)]
         return proposals
 
+    def accepts_pending(self):
+        """the sampler can take the RPN's NMS result where it lies on the device (PendingProposals): true whenever the
+        one-launch device sampler is the one in use"""
+        return (_FUSED and _PENDING and not rng.cpu_stream_enabled()
+                and not self.proposal_matcher.allow_low_quality_matches)
+
     def _fused_ok(self, proposals):
         """the one-launch sampler draws its own random keys on the device: it is the default on the GPU, and it is
         switched off when the draws must come from the reference's random stream (utils.rng.use_cpu_stream, the
         parity tests) — the distribution of the sample is the same, the stream is not"""
-        return (_FUSED and not rng.cpu_stream_enabled() and not self.proposal_matcher.allow_low_quality_matches
-                and all(p.bbox.is_cuda and p.bbox.dtype == torch.float32 and len(p) <= _C.SAMPLE_ROIS_MAX
-                        for p in proposals))
+        if not (_FUSED and not rng.cpu_stream_enabled() and not self.proposal_matcher.allow_low_quality_matches):
+            return False
+        for p in proposals:
+            if _is_pending(p):        # device-resident list: CUDA fp32 by construction (do not touch .bbox: it would sync)
+                if p.upper_bound() > _C.SAMPLE_ROIS_MAX:
+                    return False
+            elif not (p.bbox.is_cuda and p.bbox.dtype == torch.float32 and len(p) <= _C.SAMPLE_ROIS_MAX):
+                return False
+        return True
 
     def _subsample_fused(self, proposals, targets):
         """per image: box_match_encode (source domain only) + sample_rois, then ONE host round trip for the counts"""
         sampler = self.fg_bg_sampler
         cap = sampler.batch_size_per_image
         max_pos = int(cap * sampler.positive_fraction)
-        dev = proposals[0].bbox.device
+        dev = targets[0].bbox.device
         n_img = len(proposals)
         counts = torch.empty((n_img, 2), dtype=torch.int32, device=dev)
         buf = _C.sample_rois_buffers(n_img * cap, dev)
         self._all_negative = []
+        deferred = [False] * n_img
         for i, (prop, tgt) in enumerate(zip(proposals, targets)):
             is_source = is_source_image(tgt)
             self._all_negative.append(not is_source)
             lab = reg = None
+            if is_source and len(tgt) == 0:
+                raise ValueError("No ground-truth boxes available for one of the images during training")
+            out_i = {k: v[i * cap:(i + 1) * cap] for k, v in buf.items()}
+            if _is_pending(prop):
+                # the RPN's NMS result is read where it lies: kept boxes + appended ground truth, target assignment and
+                # the sample in ONE launch, no kept-count round trip in between (csrc/sampling.hip)
+                deferred[i] = True
+                _C.proposals_sample(prop.pending, tgt.bbox if is_source else None,
+                                    tgt.get_field("labels") if is_source else None, self.proposal_matcher.high_threshold,
+                                    self.proposal_matcher.low_threshold, self.box_coder.weights, cap, max_pos,
+                                    rng.next_seed(dev), is_source, counts[i], out=out_i)
+                continue
             if is_source:
-                if len(tgt) == 0:
-                    raise ValueError("No ground-truth boxes available for one of the images during training")
                 _, lab, reg = _C.box_match_encode(
                     prop.bbox, tgt.bbox, tgt.get_field("labels"), self.proposal_matcher.high_threshold,
                     self.proposal_matcher.low_threshold, self.box_coder.weights)
-            _C.sample_rois(prop.bbox, lab, reg, cap, max_pos, rng.next_seed(dev), is_source, counts[i],
-                           out={k: v[i * cap:(i + 1) * cap] for k, v in buf.items()})
+            _C.sample_rois(prop.bbox, lab, reg, cap, max_pos, rng.next_seed(dev), is_source, counts[i], out=out_i)
         host = counts.tolist()
         sampled = []
         for i, prop in enumerate(proposals):
             k = host[i][0]
             rows = slice(i * cap, i * cap + k)
             b = BoxList(buf["boxes"][rows], prop.size, prop.mode)
-            for name in prop.fields():
+            if deferred[i]:
+                b.add_field("objectness", buf["objectness"][rows])
+            for name in ([] if deferred[i] else prop.fields()):
                 if name not in ("labels", "regression_targets", "domain_labels"):
                     b.add_field(name, prop.get_field(name)[buf["idx"][rows]])
             b.add_field("labels", buf["labels"][rows])

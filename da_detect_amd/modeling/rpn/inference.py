@@ -16,7 +16,7 @@ import torch
 
 from ... import _C
 from ...utils.streams import other_stream, record
-from ...structures.bounding_box import BoxList, is_source_image
+from ...structures.bounding_box import BoxList, PendingProposals, is_source_image
 from ...structures.boxlist_ops import cat_boxlist
 from ..box_coder import BoxCoder
 from .utils import permute_and_flatten
@@ -41,11 +41,21 @@ class RPNPostProcessor(torch.nn.Module):
         self.box_coder = box_coder if box_coder is not None else BoxCoder(weights=(1.0, 1.0, 1.0, 1.0))
         self.fpn_post_nms_top_n = post_nms_top_n if fpn_post_nms_top_n is None else fpn_post_nms_top_n
 
+    # set by RPNModule for ONE call: the caller is the training path whose box head samples straight from the NMS result
+    # on the device (FastRCNNLossComputation._subsample_fused): single-level proposals are then handed over as
+    # PendingProposals — no kept-count round trip, no gathers, no concatenation here
+    defer = False
+
     def add_gt_proposals(self, proposals, targets):
         """append the ground-truth boxes of SOURCE images with objectness 1 (inference.py:51-74)"""
-        device = proposals[0].bbox.device
         out = []
         for proposal, target in zip(proposals, targets):
+            if getattr(type(proposal), "is_pending_proposals", False) and proposal.pending is not None:
+                if is_source_image(target):
+                    proposal.attach_ground_truth(target.copy_with_fields(["labels"], skip_missing=True))
+                out.append(proposal)
+                continue
+            device = proposal.bbox.device
             if is_source_image(target):
                 gt = target.copy_with_fields([])
                 gt.add_field("objectness", torch.ones(len(gt), device=device))
@@ -97,6 +107,9 @@ class RPNPostProcessor(torch.nn.Module):
         if use_side:
             record([p[:4] for p in pending[1::2]], main)
             main.wait_stream(side)
+        if self.defer and self.training and self.nms_thresh > 0 and self.min_size <= 0 and dev.type == "cuda":
+            return [PendingProposals(boxes, scores, keep, count, self.post_nms_top_n, size)
+                    for boxes, scores, keep, count, size in pending]
         counts = None
         if self.nms_thresh > 0:
             counts = torch.cat([p[3] for p in pending]).tolist()
@@ -113,9 +126,15 @@ class RPNPostProcessor(torch.nn.Module):
     def forward(self, anchors, objectness, box_regression, targets=None):
         sampled = []
         num_levels = len(objectness)
+        defer, self.defer = self.defer and num_levels == 1 and targets is not None, False
         for a, o, b in zip(list(zip(*anchors)), objectness, box_regression):
+            self.defer = defer
             sampled.append(self.forward_for_single_feature_map(a, o, b))
-        boxlists = [cat_boxlist(per_image) for per_image in zip(*sampled)]
+            self.defer = False
+        if defer and all(getattr(type(p), "is_pending_proposals", False) for p in sampled[0]):
+            boxlists = list(sampled[0])
+        else:
+            boxlists = [cat_boxlist(per_image) for per_image in zip(*sampled)]
         if num_levels > 1:
             boxlists = self.select_over_all_levels(boxlists)
         if self.training and targets is not None:

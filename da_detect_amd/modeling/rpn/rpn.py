@@ -227,8 +227,8 @@ class RPNModule(torch.nn.Module):
         else:
             with torch.no_grad():
                 boxes = self.box_selector_train(anchors, objectness, rpn_box_regression, targets)
-            if boxes[0].bbox.is_cuda:     # the box head's sampling (side stream) may start from here
-                self.proposals_ready = torch.cuda.current_stream(boxes[0].bbox.device).record_event()
+            if objectness[0].is_cuda:     # the box head's sampling (side stream) may start from here
+                self.proposals_ready = torch.cuda.current_stream(objectness[0].device).record_event()
         loss_objectness, loss_rpn_box_reg = self.loss_evaluator.finish(objectness, rpn_box_regression, prep)
         return boxes, {"loss_objectness": loss_objectness, "loss_rpn_box_reg": loss_rpn_box_reg}
 

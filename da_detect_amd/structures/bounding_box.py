@@ -150,6 +150,88 @@ class BoxList(object):
             len(self), self.size[0], self.size[1], self.mode)
 
 
+class PendingProposals(BoxList):
+    """RPN proposals of one image whose NUMBER is still on the device.
+
+    The RPN's NMS leaves `keep` (positions into the score-sorted candidate list) and a kept count in device memory; the
+    reference reads the count back to slice the list (rpn/inference.py:102) and then concatenates the ground-truth boxes
+    of source images (rpn/inference.py:51-74).  The training path does not need the list on the host at all — the box
+    head's sampler (dadet_proposals_sample) reads keep / count where they lie — so this object just carries the pieces.
+    Anything else that looks at it (`.bbox`, `len()`, a field, indexing — tests, evaluation code, a custom head) gets
+    an ordinary BoxList: the first such access materialises it, with the device->host synchronisation the reference
+    pays at that point."""
+
+    is_pending_proposals = True
+
+    def __init__(self, sorted_boxes, sorted_scores, keep, count_dev, post_n, image_size):
+        # deliberately not BoxList.__init__: bbox / extra_fields are properties here
+        self._pending = dict(sorted_boxes=sorted_boxes, sorted_scores=sorted_scores, keep=keep, count_dev=count_dev,
+                             post_n=int(post_n), gt=None)
+        self._bbox = None
+        self._fields = None
+        self.size = image_size
+        self.mode = "xyxy"
+
+    # ---- the deferred form -------------------------------------------------------------------------------------------
+    @property
+    def pending(self):
+        """dict(sorted_boxes, sorted_scores, keep, count_dev, post_n, gt) or None once materialised"""
+        return self._pending
+
+    def attach_ground_truth(self, gt_boxlist):
+        """add_gt_proposals (rpn/inference.py:51-74) for a source image: appended when the list is formed"""
+        if self._pending is None:
+            raise RuntimeError("proposals already materialised")
+        self._pending["gt"] = gt_boxlist
+
+    def upper_bound(self):
+        p = self._pending
+        return len(self) if p is None else p["post_n"] + (len(p["gt"]) if p["gt"] is not None else 0)
+
+    def pending_tensors(self):
+        p = self._pending
+        if p is None:
+            return [self._bbox] + [v for v in self._fields.values() if isinstance(v, torch.Tensor)]
+        out = [p["sorted_boxes"], p["sorted_scores"], p["keep"], p["count_dev"]]
+        if p["gt"] is not None:
+            out.append(p["gt"].bbox)
+        return out
+
+    def _materialize(self):
+        p, self._pending = self._pending, None
+        if p is None:
+            return
+        n = min(int(p["count_dev"].item()), p["post_n"])       # the reference's round trip, paid only when asked for
+        keep = p["keep"][:n]
+        boxes, scores = p["sorted_boxes"][keep], p["sorted_scores"][keep]
+        if p["gt"] is not None:
+            gt = p["gt"]
+            boxes = torch.cat([boxes, gt.bbox.to(boxes.dtype)], dim=0)
+            scores = torch.cat([scores, torch.ones(len(gt), dtype=scores.dtype, device=scores.device)], dim=0)
+        self._bbox = boxes
+        self._fields = {"objectness": scores}
+
+    @property
+    def bbox(self):
+        self._materialize()
+        return self._bbox
+
+    @bbox.setter
+    def bbox(self, value):
+        self._materialize()
+        self._bbox = value
+
+    @property
+    def extra_fields(self):
+        self._materialize()
+        return self._fields
+
+    @extra_fields.setter
+    def extra_fields(self, value):
+        self._materialize()
+        self._fields = value
+
+
 def is_source_image(target):
     """True when the image's ground truth comes from the source domain (`is_source` field, any element set).
     The answer is read back from the device ONCE per BoxList and kept on the object: the training path asks for

@@ -45,6 +45,8 @@ def record(obj, stream):
     elif isinstance(obj, (list, tuple)):
         for v in obj:
             record(v, stream)
+    elif getattr(type(obj), "is_pending_proposals", False):
+        record(obj.pending_tensors(), stream)      # (touching .bbox would materialise it: a host round trip)
     elif hasattr(obj, "bbox") and hasattr(obj, "extra_fields"):
         record(obj.bbox, stream)
         record(obj.extra_fields, stream)

@@ -303,6 +303,22 @@ int dadet_sample_rois(const float* boxes, const int64_t* labels, const float* re
                       int64_t* labels_out, float* regression_targets_out, int64_t* loss_labels_out,
                       unsigned char* domain_out, int* counts_out, void* stream);
 
+/* NMS -> box-head sample of ONE image without leaving the device: proposal i = sorted_boxes[keep[i]] (objectness
+ * sorted_scores[keep[i]]) for i < min(*count_dev, post_n), followed by `num_appended` appended boxes with objectness 1
+ * (RPNPostProcessor.add_gt_proposals, rpn/inference.py:51-74); then, when is_source, IoU / Matcher / label rules /
+ * BoxCoder.encode of every proposal against gt_boxes [G] exactly as dadet_box_match_encode, and the balanced random sample
+ * exactly as dadet_sample_rois (same keys).  Replaces the kept-count read-back of rpn/inference.py:102 and the gathers /
+ * concatenations behind it.  Besides dadet_sample_rois's outputs (+ objectness_out [cap]) it leaves the proposal list
+ * itself in prop_boxes / prop_scores [post_n + num_appended] and its length in *n_props (device memory).
+ * post_n + num_appended <= 4096, G <= 1024. */
+int dadet_proposals_sample(const float* sorted_boxes, const float* sorted_scores, const int64_t* keep,
+                           const int* count_dev, int post_n, const float* appended_boxes, int num_appended,
+                           const float* gt_boxes, const int64_t* gt_labels, int G, float high_threshold,
+                           float low_threshold, float wx, float wy, float ww, float wh, int cap, int max_pos, uint64_t seed,
+                           int is_source, float* prop_boxes, float* prop_scores, int* n_props, int64_t* idx_out,
+                           float* boxes_out, int64_t* labels_out, float* regression_targets_out, int64_t* loss_labels_out,
+                           unsigned char* domain_out, float* objectness_out, int* counts_out, void* stream);
+
 /* RPN anchor sampling of ONE image in one launch: replaces BalancedPositiveNegativeSampler.__call__ on the anchor
  * labels (modeling/balanced_positive_negative_sampler.py:25-68) + the nonzero / gathers of
  * RPNLossComputation.__call__ (modeling/rpn/loss.py:101-123).  labels [A] float (1 positive, 0 negative, -1 ignored),

@@ -77,6 +77,17 @@ def _run_default_path(case, H, W, device, seed, monkeypatch, overrides=(), steps
     monkeypatch.setattr(rng, "dropout_mask", dropout_mask)
     monkeypatch.setattr(_C, "sample_anchors", sample_anchors)
     monkeypatch.setattr(_C, "sample_rois", sample_rois)
+    orig_ps = _C.proposals_sample
+    pending_calls = []
+
+    def proposals_sample(pending, gt_boxes, gt_labels, high, low, weights, cap, max_pos, seed_, is_source, counts, out=None):
+        res = orig_ps(pending, gt_boxes, gt_labels, high, low, weights, cap, max_pos, seed_, is_source, counts, out=out)
+        pending_calls.append(1)
+        rec["rois"].append((res[0], counts, res[3]))       # res[3]: the list's length, still on the device
+        return res
+
+    monkeypatch.setattr(_C, "proposals_sample", proposals_sample)
+    rec["pending_calls"] = pending_calls
     # the proposal lists the RPN hands to the box head (None for images nothing reads): the oracle samples from THESE —
     # its own selection on the same maps yields the same set, but sigmoid-tied neighbours may come out swapped
     # (oracle/model_ref.py training_losses) and an equal sampled index would then name another box
@@ -85,7 +96,10 @@ def _run_default_path(case, H, W, device, seed, monkeypatch, overrides=(), steps
 
     def sel_forward(*a, **k):
         boxes = orig_sel(*a, **k)
-        rec["proposals"] = [(b.bbox.detach().cpu(), b.get_field("objectness").detach().cpu()) for b in boxes]
+        # read AFTER the step (collect_maps): on the default path these are PendingProposals whose length is still on
+        # the device, and looking at .bbox here would materialise them — the box head would then take the host route
+        # instead of dadet_proposals_sample, i.e. not the path under test
+        rec["_proposal_objects"] = list(boxes)
         return boxes
 
     monkeypatch.setattr(sel, "forward", sel_forward)
@@ -95,6 +109,8 @@ def _run_default_path(case, H, W, device, seed, monkeypatch, overrides=(), steps
     def collect_maps():
         rec.update(objectness=torch.cat([a for a, _ in maps]), deltas=torch.cat([b for _, b in maps]))
         del maps[:]
+        rec["proposals"] = [(b.bbox.detach().cpu(), b.get_field("objectness").detach().cpu())
+                            for b in rec.pop("_proposal_objects")]
     torch.manual_seed(seed)
     history = []
     for it in range(steps):
@@ -147,6 +163,7 @@ def _check_indices(rec, inter):
     assert torch.equal(neg, inter["rpn_neg_inds"]), "sampled negative anchors differ"
     first_pass = rec["rois"][: len(inter["sampled_idx"])]
     for i, ((o, cnt, n), want) in enumerate(zip(first_pass, inter["sampled_idx"])):
+        n = int(n)      # a device scalar when the list was handed over on the device (dadet_proposals_sample)
         assert n == len(inter["proposals"][i][0]), "image %d: %d proposals vs %d in the oracle" % (
             i, n, len(inter["proposals"][i][0]))
         got = o["idx"][: int(cnt[0])].cpu()
@@ -198,6 +215,7 @@ def test_default_path_matches_oracle_small(device, monkeypatch, case, overrides)
     seed, H, W = 11, 192, 320
     c, sd, rec, nimg = _run_default_path(case, H, W, device, seed, monkeypatch, overrides)
     assert rec["early_rpn"] and rec["loss_prep_rows"], "not the default schedule"
+    assert rec["pending_calls"], "the NMS -> sampler hand-over did not stay on the device (dadet_proposals_sample)"
     # img_only: the target image is neither sampled nor run through the RPN head (nothing reads its proposals); its
     # sampler seed is still drawn.  Triplet batches: no RPN head pass for the auxiliary image.
     read = {"da_plain": 2, "da_img_only": 1, "da_triplet": 2, "da_triplet_aligned": 2}[case]

@@ -804,6 +804,58 @@ def test_sample_rois_is_seeded_and_uniform(device):
         assert float((hits[sl].float() - trials * prob).abs().max()) < 5 * sigma
 
 
+@pytest.mark.parametrize("n,post_n,is_source,with_gt", [(3000, 2000, True, True), (3000, 2000, False, False),
+                                                        (700, 2000, True, True), (50, 2000, True, True),
+                                                        (1200, 300, True, False)])
+def test_proposals_sample_equals_the_host_chain(device, n, post_n, is_source, with_gt):
+    """dadet_proposals_sample (NMS result read on the device: kept boxes + appended ground truth + target assignment +
+    sample, one launch) against the chain it replaces — kept-count read-back, gathers, concatenation,
+    dadet_box_match_encode, dadet_sample_rois — on the same seed: every output identical, bit for bit; and
+    PendingProposals materialises to the same list.  Cases: more / fewer kept boxes than post_nms_top_n, fewer proposals
+    than the sample size, a target-domain image, matching against ground truth that is not appended (aligned passes)."""
+    from da_detect_amd import _C
+    from da_detect_amd.structures.bounding_box import BoxList, PendingProposals
+
+    rng = np.random.default_rng(n + post_n)
+    boxes = torch.from_numpy(_rand_boxes(rng, n)).to(device)
+    scores = torch.from_numpy(np.sort(rng.uniform(0, 1, n).astype(np.float32))[::-1].copy()).to(device)
+    keep, count = _C.nms_with_count(boxes, None, 0.7, max_keep=post_n)
+    G = 12
+    gt = torch.from_numpy(_rand_boxes(rng, G)).to(device)
+    gt_labels = torch.from_numpy(rng.integers(1, 9, G).astype(np.int64)).to(device)
+    pend = PendingProposals(boxes, scores, keep, count, post_n, (900, 600))
+    if with_gt:
+        pend.attach_ground_truth(BoxList(gt, (900, 600)))
+    cap, max_pos, seed = 256, 64, 4242 + n
+    counts_a = torch.zeros(2, dtype=torch.int32, device=device)
+    out, prop_boxes, prop_scores, n_props = _C.proposals_sample(
+        pend.pending, gt if is_source else None, gt_labels if is_source else None, 0.5, 0.5, (10.0, 10.0, 5.0, 5.0), cap,
+        max_pos, seed, is_source, counts_a)
+    # the host chain
+    k = min(int(count), post_n)
+    kept = keep[:k]
+    pb, ps = boxes[kept], scores[kept]
+    if with_gt:
+        pb, ps = torch.cat([pb, gt]), torch.cat([ps, torch.ones(G, device=device)])
+    lab = reg = None
+    if is_source:
+        _, lab, reg = _C.box_match_encode(pb, gt, gt_labels, 0.5, 0.5, (10.0, 10.0, 5.0, 5.0))
+    counts_b = torch.zeros(2, dtype=torch.int32, device=device)
+    ref = _C.sample_rois(pb, lab, reg, cap, max_pos, seed, is_source, counts_b)
+    assert int(n_props) == pb.shape[0]
+    assert torch.equal(prop_boxes[: pb.shape[0]], pb) and torch.equal(prop_scores[: pb.shape[0]], ps)
+    assert counts_a.tolist() == counts_b.tolist()
+    rows = counts_b.tolist()[0]
+    assert rows == min(cap, pb.shape[0]) or is_source        # (source: ignored rows may leave the sample short)
+    for name in ("idx", "boxes", "labels", "regression_targets", "loss_labels", "domain"):
+        assert torch.equal(out[name], ref[name]), name
+    assert torch.equal(out["objectness"][:rows], ps[ref["idx"][:rows]])
+    # materialisation = the same list
+    assert pend.pending is not None and pend.upper_bound() == post_n + (G if with_gt else 0)
+    assert len(pend) == pb.shape[0] and pend.pending is None
+    assert torch.equal(pend.bbox, pb) and torch.equal(pend.get_field("objectness"), ps)
+
+
 def test_nms_presorted_equals_ranked(device):
     """scores=None: the caller's order is the ranking (RPN top-k output) — same kept set as the ranked call"""
     from da_detect_amd import _C
