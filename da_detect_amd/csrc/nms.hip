@@ -111,10 +111,16 @@ __global__ void nms_gather_boxes_kernel(const float4* __restrict__ boxes, const 
 // ---- IoU bitmask, upper triangle of 64x64 tiles ----------------------------------------------
 // IoU exactly as nms_cpu.cpp:23,50-59: area = (x2-x1+1)*(y2-y1+1); inter = max(0,xx2-xx1+1)*max(0,yy2-yy1+1);
 // ovr = inter / (area_i + area_j - inter).
+// diag_t / adj_t (optional): the diagonal tile and the tile right of it once more, TRANSPOSED — word i of diag_t holds, for
+// box i, the bits of the boxes j < i of its own 64-block that suppress it; word i of adj_t the bits of the boxes of the
+// PREVIOUS block that suppress it.  With its column in a lane, "is box i suppressed by the kept set K" is one AND, and the
+// new kept set one ballot (nms_sweep_pipelined_kernel).  Same IoU expression with the same operands as the row form.
 template <int TIE_RULE>
 __global__ __launch_bounds__(64) void nms_mask_kernel(const float4* __restrict__ sorted, int n,
                                                       float thresh, int col_blocks,
-                                                      unsigned long long* __restrict__ mask) {
+                                                      unsigned long long* __restrict__ mask,
+                                                      unsigned long long* __restrict__ diag_t,
+                                                      unsigned long long* __restrict__ adj_t) {
   // linear block id -> (row_block <= col_block) pair
   const int row_start = blockIdx.y, col_start = blockIdx.x;
   if (col_start < row_start) return;
@@ -122,12 +128,38 @@ __global__ __launch_bounds__(64) void nms_mask_kernel(const float4* __restrict__
   const int col_size = min(n - col_start * 64, 64);
   __shared__ float4 cb[64];
   __shared__ float carea[64];
+  __shared__ float4 rb[64];
+  __shared__ float rarea[64];
+  const bool want_t = diag_t && (col_start == row_start || col_start == row_start + 1);
   if ((int)threadIdx.x < col_size) {
     const float4 b = sorted[col_start * 64 + threadIdx.x];
     cb[threadIdx.x] = b;
     carea[threadIdx.x] = (b.z - b.x + 1.f) * (b.w - b.y + 1.f);
   }
+  if (want_t && (int)threadIdx.x < row_size) {
+    const float4 b = sorted[row_start * 64 + threadIdx.x];
+    rb[threadIdx.x] = b;
+    rarea[threadIdx.x] = (b.z - b.x + 1.f) * (b.w - b.y + 1.f);
+  }
   __syncthreads();
+  if (want_t && (int)threadIdx.x < col_size) {
+    // this thread = COLUMN box b; a = the row box, exactly as in the row form below (same operand order)
+    const float4 b = cb[threadIdx.x];
+    const float barea = carea[threadIdx.x];
+    const int stop = (row_start == col_start) ? (int)threadIdx.x : row_size;    // diagonal: rows j < i only
+    unsigned long long t = 0;
+    for (int i = 0; i < stop; ++i) {
+      const float4 a = rb[i];
+      const float xx1 = fmaxf(a.x, b.x), yy1 = fmaxf(a.y, b.y);
+      const float xx2 = fminf(a.z, b.z), yy2 = fminf(a.w, b.w);
+      const float w = fmaxf(0.f, xx2 - xx1 + 1.f), h = fmaxf(0.f, yy2 - yy1 + 1.f);
+      const float inter = w * h;
+      const float ovr = inter / (rarea[i] + barea - inter);
+      const bool sup = (TIE_RULE == 0) ? (ovr >= thresh) : (ovr > thresh);
+      if (sup) t |= 1ULL << i;
+    }
+    (row_start == col_start ? diag_t : adj_t)[col_start * 64 + threadIdx.x] = t;
+  }
   if ((int)threadIdx.x < row_size) {
     const int cur = row_start * 64 + threadIdx.x;
     const float4 a = sorted[cur];
@@ -240,21 +272,26 @@ __global__ __launch_bounds__(1024) void nms_sweep_kernel(const unsigned long lon
 }
 
 // ---- greedy sweep, pipelined (round 3) --------------------------------------------------------------------------
-// nms_sweep_kernel above is a dependent chain of col_blocks steps, each "barrier, resolve the diagonal tile, barrier, every
-// thread loads the kept rows' words (1 - 2 round trips to L2), barrier": ~2.3 us per 64-box chunk, 0.44 ms for the RPN's
-// 12 000 boxes — the longest single item between the RPN head and the box head (rocprofv3 timeline, round 3).  The loads
-// are what a step waits for, and only ONE of them is needed at once: chunk c + 1 must know what chunk c's kept boxes
-// remove from it; everything further right has time.  So:
-//   * the (c, c + 1) off-diagonal tile is PREFETCHED one iteration ahead into wave 0's lanes (one word per lane, no
-//     dependence on any decision) and folded into the same scalar loop that resolves the diagonal — when box j is kept,
-//     its diagonal word joins `rem` and its next-tile word joins `adj`, the removed-set of chunk c + 1 contributed by
-//     chunk c; no memory access sits between two chunks' resolutions;
+// nms_sweep_kernel above is a dependent chain of col_blocks steps, each "barrier, resolve the diagonal tile box by box on
+// the scalar unit (one v_readlane pair per KEPT box: ~3 us for a chunk that keeps most of its 64 boxes), barrier, every
+// thread loads the kept rows' words (1 - 2 round trips to L2), barrier": 5 - 6 us per 64-box chunk on fresh regions,
+// 0.44 ms inside the training step — the longest single item between the RPN head and the box head (rocprofv3 timeline,
+// profiles/r03_step_timeline_*.txt).  Two changes:
+//   * the chunk is resolved in PARALLEL by fixed-point iteration on transposed tiles.  Lane i holds the column of box i
+//     (diag_t: which boxes j < i of its chunk suppress it; adj_t: which boxes of the previous chunk do).  "Suppressed by
+//     the kept set K" is then one AND per lane and the next K one ballot: K <- alive & ~suppressed_by(K), starting from
+//     K = alive.  The tile is strictly upper triangular, so round t fixes (at least) box t for good; the iteration ends
+//     when K stops changing — after as many rounds as the longest suppression chain in the chunk, typically 2 - 5, never
+//     more than 64 — with exactly the greedy result.  The previous chunk's influence comes through adj_t the same way, so
+//     no memory access sits between two chunks' resolutions;
 //   * the other threads' loads for chunk c (word w of every kept row, w >= c + 2) are ISSUED after chunk c's keep bits are
 //     known and CONSUMED one iteration later, i.e. they are in flight while chunk c + 1 is resolved.
-// Same keep bits as nms_sweep_kernel (tests/test_ops_gpu.py runs both).
-__global__ __launch_bounds__(256) void nms_sweep_pipelined_kernel(const unsigned long long* __restrict__ mask, int n,
-                                                                   int col_blocks, int max_keep,
-                                                                   unsigned long long* __restrict__ keep_bits) {
+// Same keep bits as nms_sweep_kernel (tests/test_ops_gpu.py compares both against the CPU oracle; DADET_NMS_SWEEP=0).
+__global__ __launch_bounds__(256) void nms_sweep_pipelined_kernel(const unsigned long long* __restrict__ mask,
+                                                                  const unsigned long long* __restrict__ diag_t,
+                                                                  const unsigned long long* __restrict__ adj_t, int n,
+                                                                  int col_blocks, int max_keep,
+                                                                  unsigned long long* __restrict__ keep_bits) {
   __shared__ unsigned long long s_removed_c;  // removed word of the current chunk from chunks <= c - 2
   __shared__ unsigned long long s_keep;       // keep bits of the current chunk
   __shared__ int s_kept_total;
@@ -267,52 +304,55 @@ __global__ __launch_bounds__(256) void nms_sweep_pipelined_kernel(const unsigned
 #pragma unroll
   for (int u = 0; u < kFly; ++u) fly[u] = 0;
   if (threadIdx.x == 0) s_kept_total = 0;
-  // wave 0, lane j: diagonal word of box (c * 64 + j) and its word of the next column block, fetched one chunk ahead
-  unsigned long long diag_next = 0, tile_next = 0;
-  if (wave0 && lane < n) {
-    diag_next = mask[(size_t)lane * col_blocks];
-    if (col_blocks > 1) tile_next = mask[(size_t)lane * col_blocks + 1];
-  }
-  unsigned adj_lo = 0, adj_hi = 0;            // wave 0 (uniform): what chunk c - 1's kept boxes remove from chunk c
+  // wave 0, lane i: the transposed diagonal / previous-block words of box (c * 64 + i), fetched one chunk ahead
+  unsigned long long dcol_next = 0, acol_next = 0;
+  if (wave0 && lane < n) dcol_next = diag_t[lane];      // chunk 0 has no previous block
   __syncthreads();
   for (int c = 0; c < col_blocks; ++c) {
-    if (w == c) s_removed_c = removed;        // chunks <= c - 2 (chunk c - 1's part is `adj`)
+    if (w == c) s_removed_c = removed;        // chunks <= c - 2 (chunk c - 1's part comes through adj_t)
     __syncthreads();
     if (wave0) {
-      const unsigned long long diag = diag_next, tile = tile_next;
+      const unsigned long long dcol = dcol_next, acol = acol_next;
       const int nbox = (c + 1) * 64 + lane;
-      diag_next = (c + 1 < col_blocks && nbox < n) ? mask[(size_t)nbox * col_blocks + c + 1] : 0ULL;
-      tile_next = (c + 2 < col_blocks && nbox < n) ? mask[(size_t)nbox * col_blocks + c + 2] : 0ULL;
-      const unsigned lo = (unsigned)diag, hi = (unsigned)(diag >> 32);
-      const unsigned tlo = (unsigned)tile, thi = (unsigned)(tile >> 32);
+      const bool more = c + 1 < col_blocks && nbox < n;
+      dcol_next = more ? diag_t[nbox] : 0ULL;
+      acol_next = more ? adj_t[nbox] : 0ULL;
       const unsigned long long rem0 = s_removed_c;
-      const unsigned rem_lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)rem0) | adj_lo;
-      const unsigned rem_hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(rem0 >> 32)) | adj_hi;
-      unsigned long long rem = ((unsigned long long)rem_hi << 32) | (unsigned long long)rem_lo;
+      const unsigned rem_lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)rem0);
+      const unsigned rem_hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(rem0 >> 32));
+      const unsigned long long prev_keep = c ? s_keep : 0ULL;      // chunk c - 1's kept set (still in LDS)
       const int limit = min(64, n - c * 64);
-      const unsigned long long valid = limit >= 64 ? ~0ULL : ((1ULL << limit) - 1ULL);
-      unsigned long long keep = 0;
-      int kept_total = __builtin_amdgcn_readfirstlane(s_kept_total);
-      unsigned long long alive = ~rem & valid;
-      unsigned nlo = 0, nhi = 0;
-      while (alive) {
-        if (max_keep > 0 && kept_total >= max_keep) break;
-        const int j = __ffsll((long long)alive) - 1;
-        keep |= 1ULL << j;
-        ++kept_total;
-        const unsigned dlo = (unsigned)__builtin_amdgcn_readlane((int)lo, j);
-        const unsigned dhi = (unsigned)__builtin_amdgcn_readlane((int)hi, j);
-        nlo |= (unsigned)__builtin_amdgcn_readlane((int)tlo, j);
-        nhi |= (unsigned)__builtin_amdgcn_readlane((int)thi, j);
-        rem |= ((unsigned long long)dhi << 32) | dlo;
-        alive = ~rem & valid & ~((2ULL << j) - 1ULL);
+      // alive: inside the range, not removed by chunks <= c - 2 (the pushed words), not removed by chunk c - 1's kept
+      // boxes (one AND with the transposed previous-block column)
+      const bool in_range = lane < limit;
+      const bool pushed = ((((unsigned long long)rem_hi << 32) | rem_lo) >> lane) & 1ULL;
+      const bool alive_i = in_range && !pushed && (acol & prev_keep) == 0ULL;
+      const unsigned long long alive = __ballot(alive_i);
+      // greedy keep set by fixed-point iteration: K = alive & ~suppressed_by(K).  The tile is strictly upper triangular, so
+      // after t rounds the first t boxes are final: at most 64 rounds, in practice the depth of the longest suppression
+      // chain in the chunk (a handful).  One AND + compare + ballot per round.
+      unsigned long long K = alive;
+      for (int it = 0; it < 64; ++it) {
+        const unsigned long long Kn = __ballot(alive_i && (dcol & K) == 0ULL);
+        if (Kn == K) break;
+        K = Kn;
       }
-      adj_lo = nlo;
-      adj_hi = nhi;
+      int kept_total = __builtin_amdgcn_readfirstlane(s_kept_total);
+      if (max_keep > 0 && kept_total + __popcll(K) > max_keep) {
+        // quota: keep the first (max_keep - kept_total) of them — later boxes never influence earlier ones
+        int room = max_keep - kept_total;
+        unsigned long long first = 0, k2 = K;
+        while (room-- > 0 && k2) {
+          first |= k2 & (~k2 + 1ULL);
+          k2 &= k2 - 1ULL;
+        }
+        K = first;
+      }
+      kept_total += __popcll(K);
       if (lane == 0) {
-        s_keep = keep;
+        s_keep = K;
         s_kept_total = kept_total;
-        keep_bits[c] = keep;
+        keep_bits[c] = K;
       }
     }
     // the loads issued one iteration ago (rows of chunk c - 1, word w) have had a whole resolution to land
@@ -327,7 +367,7 @@ __global__ __launch_bounds__(256) void nms_sweep_pipelined_kernel(const unsigned
       for (int cc = c + 1 + (int)threadIdx.x; cc < col_blocks; cc += blockDim.x) keep_bits[cc] = 0;
       break;
     }
-    // issue the loads for chunk c's kept rows (consumed in the next iteration); word c + 1 is wave 0's `adj`
+    // issue the loads for chunk c's kept rows (consumed in the next iteration); word c + 1 goes through adj_t
     {
       unsigned long long k = s_keep;
       const bool mine = w >= c + 2 && w < col_blocks;
@@ -385,7 +425,7 @@ static int next_pow2(int n) {
 }
 
 struct NmsWorkspace {
-  size_t order_off, sorted_off, mask_off, keepbits_off, flag_off, keys_off, total;
+  size_t order_off, sorted_off, mask_off, keepbits_off, flag_off, diagt_off, adjt_off, keys_off, total;
 };
 
 static NmsWorkspace nms_layout(int n) {
@@ -398,6 +438,8 @@ static NmsWorkspace nms_layout(int n) {
   ws.mask_off = off;     off = align(off + sizeof(unsigned long long) * (size_t)n * col_blocks);
   ws.keepbits_off = off; off = align(off + sizeof(unsigned long long) * (size_t)col_blocks);
   ws.flag_off = off;     off = align(off + (size_t)n);
+  ws.diagt_off = off;    off = align(off + sizeof(unsigned long long) * (size_t)col_blocks * 64);
+  ws.adjt_off = off;     off = align(off + sizeof(unsigned long long) * (size_t)col_blocks * 64);
   ws.keys_off = off;
   const int p2 = next_pow2(n);
   if (p2 > kSortLdsMax) off = align(off + sizeof(Key) * (size_t)p2);
@@ -442,6 +484,8 @@ extern "C" int dadet_nms(const float* boxes_xyxy, const float* scores, int n, fl
   unsigned long long* mask = reinterpret_cast<unsigned long long*>(base + ws.mask_off);
   unsigned long long* keep_bits = reinterpret_cast<unsigned long long*>(base + ws.keepbits_off);
   unsigned char* flag = reinterpret_cast<unsigned char*>(base + ws.flag_off);
+  unsigned long long* diag_t = reinterpret_cast<unsigned long long*>(base + ws.diagt_off);
+  unsigned long long* adj_t = reinterpret_cast<unsigned long long*>(base + ws.adjt_off);
 
   const int p2 = next_pow2(n);
   if (presorted) {
@@ -473,18 +517,23 @@ extern "C" int dadet_nms(const float* boxes_xyxy, const float* scores, int n, fl
     hipLaunchKernelGGL(nms_gather_boxes_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, st,
                        reinterpret_cast<const float4*>(boxes_xyxy), order, n, sorted);
   const dim3 mgrid(col_blocks, col_blocks);
-  if (tie_rule == 0)
-    hipLaunchKernelGGL(nms_mask_kernel<0>, mgrid, dim3(64), 0, st, sorted, n, thresh, col_blocks, mask);
-  else
-    hipLaunchKernelGGL(nms_mask_kernel<1>, mgrid, dim3(64), 0, st, sorted, n, thresh, col_blocks, mask);
   const int sweep_threads = col_blocks <= 64 ? 64 : ((col_blocks + 63) / 64) * 64;
   static const bool plain_sweep = getenv("DADET_NMS_SWEEP") && getenv("DADET_NMS_SWEEP")[0] == '0';
-  if (plain_sweep || sweep_threads > 256)     // the pipelined form holds 64 loads per thread: up to 16 384 boxes
+  // the pipelined sweep holds 64 loads per thread (256-thread workgroup): up to 16 384 boxes; it reads the transposed
+  // diagonal / next-block tiles the mask kernel then also writes
+  const bool pipelined = !plain_sweep && sweep_threads <= 256;
+  if (tie_rule == 0)
+    hipLaunchKernelGGL(nms_mask_kernel<0>, mgrid, dim3(64), 0, st, sorted, n, thresh, col_blocks, mask,
+                       pipelined ? diag_t : nullptr, adj_t);
+  else
+    hipLaunchKernelGGL(nms_mask_kernel<1>, mgrid, dim3(64), 0, st, sorted, n, thresh, col_blocks, mask,
+                       pipelined ? diag_t : nullptr, adj_t);
+  if (!pipelined)
     hipLaunchKernelGGL(nms_sweep_kernel, dim3(1), dim3(sweep_threads), 0, st, mask, n, col_blocks, max_keep,
                        keep_bits);
   else
-    hipLaunchKernelGGL(nms_sweep_pipelined_kernel, dim3(1), dim3(sweep_threads), 0, st, mask, n, col_blocks, max_keep,
-                       keep_bits);
+    hipLaunchKernelGGL(nms_sweep_pipelined_kernel, dim3(1), dim3(sweep_threads), 0, st, mask, diag_t, adj_t, n,
+                       col_blocks, max_keep, keep_bits);
   hipLaunchKernelGGL(nms_flag_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, st, keep_bits, order, n, flag);
   hipLaunchKernelGGL(nms_compact_kernel, dim3(1), dim3(64), 0, st, flag, n, keep_out, num_keep_out);
   return check_launch("nms");
