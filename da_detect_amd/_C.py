@@ -327,14 +327,123 @@ def conv_forward(x, w, scale=None, bias=None, addend=None, mask_ref=None, stride
     return out
 
 
+def _transpose_now(w, scale, wt):
+    Cout, Cin, KH, KW = w.shape
+    _lib.call("dadet_conv_weight_transpose", _p(w), _p(scale), _p(wt), Cout, KH, KW, Cin, _stream())
+    return wt
+
+
+class _TransposeCache(object):
+    """Transposed (tap-flipped, FrozenBN-folded) weights for the data-gradient GEMMs, refreshed for ALL registered weights
+    by ONE launch per optimizer step instead of one launch in front of every data-gradient GEMM.
+
+    An entry (weight storage, shape, scale storage) owns a persistent output buffer.  It is valid while (a) the weight's
+    autograd version is the one it was computed from and (b) the weight epoch is — the epoch is what in-place updates
+    through raw pointers bump (FusedSGD.step -> bump_weight_epoch(); ATen's in-place ops bump the version themselves).
+    The first request of an epoch recomputes every entry in one batched launch on the current stream; a weight seen for
+    the first time is transposed on the spot and joins the table.  DADET_TRANSPOSE_BATCH=0: one launch per request."""
+
+    def __init__(self):
+        self.entries = {}
+        self.epoch = 0
+        self.batched_epoch = -1
+        self.table = None          # (device tensor, n, total_blocks, keys)
+        self.ready = None          # (stream, event) of the last batched refresh
+        self.enabled = os.environ.get("DADET_TRANSPOSE_BATCH", "1") == "1"
+
+    def bump(self, device=None):
+        """new weight epoch; with a device: refresh every entry at once, on the caller's stream (the optimizer's, behind
+        the update and behind everything that read the old buffers)"""
+        self.epoch += 1
+        if self.enabled and device is not None and self.entries:
+            self._refresh_all(device)
+
+    def _single(self, e, w, scale):
+        """one entry on the current stream, remembered with an event for readers on other streams"""
+        _transpose_now(w, scale, e["wt"])
+        e["epoch"] = self.epoch
+        if w.is_cuda:
+            st = torch.cuda.current_stream(w.device)
+            e["ev"] = (st, st.record_event())
+        return e["wt"]
+
+    def get(self, w, scale):
+        Cout, Cin, KH, KW = w.shape
+        key = (w.data_ptr(), Cout, Cin, KH, KW, scale.data_ptr() if scale is not None else 0, w.device.index)
+        e = self.entries.get(key)
+        if e is None:
+            wt = torch.empty((Cin, Cout, KH, KW), dtype=torch.float32, device=w.device, memory_format=CL)
+            # the entry keeps w / scale alive: their storage addresses are in the device table
+            e = self.entries[key] = dict(w=w, scale=scale, wt=wt, version=w._version, epoch=self.epoch, used=self.epoch,
+                                         ev=None)
+            self.table = None
+            return self._single(e, w, scale)
+        e["used"] = self.epoch
+        if e["version"] != w._version:
+            e["w"], e["version"] = w, w._version
+            return self._single(e, w, scale)
+        if e["epoch"] != self.epoch:
+            if self.batched_epoch != self.epoch:
+                self._refresh_all(w.device)
+            if e["epoch"] != self.epoch:      # joined the table after this epoch's launch
+                return self._single(e, w, scale)
+        # produced on ONE stream (the optimizer's for the batched refresh): a reader on another stream waits for it
+        src = e["ev"] if e["ev"] is not None else self.ready
+        if src is not None and w.is_cuda and torch.cuda.current_stream(w.device) != src[0]:
+            torch.cuda.current_stream(w.device).wait_event(src[1])
+        return e["wt"]
+
+    def _refresh_all(self, device):
+        # weights nobody asked for during the last two epochs belong to a model that is gone: dropped (with their buffers)
+        for k in [k for k, e in self.entries.items() if e["used"] < self.epoch - 2]:
+            del self.entries[k]
+        live = [(k, e) for k, e in self.entries.items() if k[6] == device.index and e["version"] == e["w"]._version]
+        if self.table is None or self.table[3] != [k for k, _ in live]:
+            arr = (_lib.TransposeItem * len(live))()
+            blocks = 0
+            for i, (k, e) in enumerate(live):
+                _, Cout, Cin, KH, KW, _, _ = k
+                it = arr[i]
+                it.w, it.scale, it.wt = e["w"].data_ptr(), (e["scale"].data_ptr() if e["scale"] is not None else None), \
+                    e["wt"].data_ptr()
+                it.Cout, it.KH, it.KW, it.Cin = Cout, KH, KW, Cin
+                it.blocks_ci, it.blocks_co = (Cin + 31) // 32, (Cout + 31) // 32
+                it.first_block = blocks
+                blocks += it.blocks_ci * it.blocks_co * KH * KW
+            host = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).clone()
+            self.table = (host.to(device), len(live), blocks, [k for k, _ in live])
+        dev_t, n, blocks, _ = self.table
+        _lib.call("dadet_conv_weight_transpose_batch", _p(dev_t), n, blocks, _stream())
+        for _, e in live:
+            e["epoch"] = self.epoch
+            e["ev"] = None
+        self.batched_epoch = self.epoch
+        if device.type == "cuda":
+            st = torch.cuda.current_stream(device)
+            self.ready = (st, st.record_event())
+
+
+_TRANSPOSES = _TransposeCache()
+
+
+def bump_weight_epoch(device=None):
+    """weights were updated in place through raw pointers (the fused SGD kernel): cached derived forms are stale"""
+    _TRANSPOSES.bump(device)
+
+
 def conv_weight_transpose(w, scale=None):
-    """[Cout,Cin,KH,KW] -> data-gradient weights [Cin,Cout,KH,KW] (flipped taps, `scale[cout]` folded in)."""
+    """[Cout,Cin,KH,KW] -> data-gradient weights [Cin,Cout,KH,KW] (flipped taps, `scale[cout]` folded in).  The result
+    may be a cached buffer shared by later calls with the same weight: treat it as read-only."""
     _dev(w, "w")
     Cout, Cin, KH, KW = w.shape
     w = _nhwc(w)
+    # cached only for storage that persists across steps — a trainable parameter or a view of one (a temporary's address may
+    # be handed to another tensor by the allocator, and the cache is keyed by address)
+    base = w._base if w._base is not None else w
+    if _TRANSPOSES.enabled and base.is_leaf and base.requires_grad:
+        return _TRANSPOSES.get(w, scale)
     wt = torch.empty((Cin, Cout, KH, KW), dtype=torch.float32, device=w.device, memory_format=CL)
-    _lib.call("dadet_conv_weight_transpose", _p(w), _p(scale), _p(wt), Cout, KH, KW, Cin, _stream())
-    return wt
+    return _transpose_now(w, scale, wt)
 
 
 class WgradBatch(list):

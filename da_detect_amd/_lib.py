@@ -28,6 +28,11 @@ class WgradPending(ctypes.Structure):
                 ("K", c_int), ("splits", c_int), ("accumulate", c_int)]
 
 
+class TransposeItem(ctypes.Structure):
+    _fields_ = [("w", c_void_p), ("scale", c_void_p), ("wt", c_void_p), ("Cout", c_int), ("KH", c_int), ("KW", c_int),
+                ("Cin", c_int), ("first_block", c_int), ("blocks_ci", c_int), ("blocks_co", c_int), ("pad", c_int)]
+
+
 class SgdEntry(ctypes.Structure):
     """mirror of dadet_sgd_entry (include/dadet.h)"""
 
@@ -62,6 +67,7 @@ _SIGNATURES = {
     "dadet_conv_wgrad_partials": [POINTER(ConvDesc), _P, _P, _P, _P, c_int, _P, c_size_t, POINTER(WgradPending), _P],
     "dadet_conv_wgrad_reduce_batch": [POINTER(WgradPending), c_int, _P],
     "dadet_conv_weight_transpose": [_P, _P, _P, c_int, c_int, c_int, c_int, _P],
+    "dadet_conv_weight_transpose_batch": [_P, c_int, c_int, _P],
     "dadet_deform_sample_forward": [_P, _P, _P, _P] + [c_int] * 12 + [_P],
     "dadet_deform_sample_backward": [_P, _P, _P, _P, _P, _P, _P] + [c_int] * 12 + [_P],
     "dadet_deform_sample_forward_ld": [_P, _P, c_int, _P, c_int, c_int, _P] + [c_int] * 12 + [_P],

@@ -397,11 +397,11 @@ __global__ void wgrad_reduce_kernel(const float4* __restrict__ part, const float
   }
 }
 
-// The same reduction for up to kReduceBatch weight gradients in ONE launch (dadet_conv_wgrad_reduce_batch): a residual
+// The same reduction for up to kReduceBatch (32: a step's deferred passes go out in two launches) weight gradients in ONE launch (dadet_conv_wgrad_reduce_batch): a residual
 // block's backward produces 3 - 4 split weight gradients of 0.3 - 9 MB each; one reduction pass per tensor is a
 // 10 - 40 us launch that runs at ~1.5 TB/s because it is over before it fills the chip (45 launches, 1.2 ms per step).
 // Block b belongs to the item whose block range contains it; within an item the arithmetic is wgrad_reduce_kernel's.
-constexpr int kReduceBatch = 8;
+constexpr int kReduceBatch = 32;
 struct ReduceItem {
   const float4* part;
   const float* out_scale;
@@ -466,6 +466,57 @@ __global__ __launch_bounds__(256) void weight_transpose_kernel(const float* __re
   for (int j = ty; j < 32; j += 8) {
     const int ci = ci0 + j, co = co0 + tx;
     if (co < Cout && ci < Cin) wt[(int64_t)ci * Kt + (int64_t)tapT * Cout + co] = tile[tx][j];
+  }
+}
+
+// Every registered weight in ONE launch (dadet_conv_weight_transpose_batch): the backward pass of a step needs the
+// transposed, FrozenBN-folded form of ~44 convolution weights, and producing each right in front of its data-gradient GEMM
+// put 42 launches of ~5 us (plus their dispatch gaps) into the serial GEMM chain (rocprofv3 timeline of round 3: 0.22 ms
+// per step with nothing else running).  The table lives in device memory; block b serves the item whose block range holds it.
+struct TransposeItem {
+  const float* w;
+  const float* scale;
+  float* wt;
+  int Cout, KH, KW, Cin;
+  int first_block, blocks_ci, blocks_co, pad;
+};
+
+__global__ __launch_bounds__(256) void weight_transpose_batch_kernel(const TransposeItem* __restrict__ items, int n) {
+  __shared__ float tile[32][33];
+  __shared__ int s_item;
+  if (threadIdx.x == 0) {
+    int lo = 0, hi = n - 1;                 // last item whose first_block <= blockIdx.x
+    while (lo < hi) {
+      const int mid = (lo + hi + 1) >> 1;
+      if (items[mid].first_block <= (int)blockIdx.x) lo = mid;
+      else hi = mid - 1;
+    }
+    s_item = lo;
+  }
+  __syncthreads();
+  const TransposeItem it = items[s_item];
+  int b = (int)blockIdx.x - it.first_block;
+  const int bx = b % it.blocks_ci;
+  b /= it.blocks_ci;
+  const int by = b % it.blocks_co, tap = b / it.blocks_co;
+  const int r = tap / it.KW, sidx = tap % it.KW;
+  const int tapT = (it.KH - 1 - r) * it.KW + (it.KW - 1 - sidx);
+  const int ci0 = bx * 32, co0 = by * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+  const int64_t K = (int64_t)it.KH * it.KW * it.Cin, Kt = (int64_t)it.KH * it.KW * it.Cout;
+  for (int j = ty; j < 32; j += 8) {
+    const int co = co0 + j, ci = ci0 + tx;
+    float v = 0.f;
+    if (co < it.Cout && ci < it.Cin) {
+      v = it.w[(int64_t)co * K + (int64_t)tap * it.Cin + ci];
+      if (it.scale) v = v * it.scale[co];
+    }
+    tile[j][tx] = v;
+  }
+  __syncthreads();
+  for (int j = ty; j < 32; j += 8) {
+    const int ci = ci0 + j, co = co0 + tx;
+    if (co < it.Cout && ci < it.Cin) it.wt[(int64_t)ci * Kt + (int64_t)tapT * it.Cout + co] = tile[tx][j];
   }
 }
 
@@ -959,4 +1010,15 @@ extern "C" int dadet_conv_weight_transpose(const float* w, const float* scale, f
   hipLaunchKernelGGL(weight_transpose_kernel, dim3(ceil_div(Cin, 32), ceil_div(Cout, 32), KH * KW),
                      dim3(256), 0, as_stream(stream), w, scale, wt, Cout, KH, KW, Cin);
   return check_launch("conv_weight_transpose");
+}
+
+extern "C" int dadet_conv_weight_transpose_batch(const dadet_transpose_item* items_dev, int n, int total_blocks,
+                                                 void* stream) {
+  static_assert(sizeof(dadet_transpose_item) == sizeof(dadet::TransposeItem), "transpose item layout");
+  DADET_REQUIRE(n >= 0 && total_blocks >= 0, "conv_weight_transpose_batch: bad args");
+  if (n == 0 || total_blocks == 0) return DADET_OK;
+  DADET_REQUIRE(items_dev, "conv_weight_transpose_batch: null table");
+  hipLaunchKernelGGL(weight_transpose_batch_kernel, dim3(total_blocks), dim3(256), 0, as_stream(stream),
+                     reinterpret_cast<const dadet::TransposeItem*>(items_dev), n);
+  return check_launch("conv_weight_transpose_batch");
 }

@@ -172,8 +172,10 @@ class _DCNBottleneckFn(torch.autograd.Function):
             dw2 = wgrad(w2, cols, S2, 1, 0, s2, shape=(cout2, kh * kw * cin2, 1, 1))
         gcols = _C.conv_forward(S2, _C.conv_weight_transpose(w2_1x1, s2))
         gy1, gom = _C.deform_sample_backward_om(y1, om, gcols, kh, kw, 1, kh // 2, 1, dg, modulated)
-        if n_off:    # with the block's other weight gradients (same stream, same batched reduction pass)
-            dwo = lane.run(lambda: _C.conv_wgrad(y1, gom, tuple(wo4.shape), 1, kh // 2, pending=batch), y1, gom)
+        if n_off:    # on the block's weight-gradient stream; its result goes back to autograd: reduced at once
+            own = _C.WgradBatch()
+            dwo = lane.run(lambda: _C.conv_wgrad(y1, gom, tuple(wo4.shape), 1, kh // 2, pending=own), y1, gom)
+            lane.reduce_batch(own, now=True)
         if n_boff:
             dbo = _C.colsum(gom)[:n_offch]
         # d y1 = [y1 > 0] * (sampled path + offset-conv path)

@@ -96,6 +96,9 @@ class BucketedGradReducer(object):
             if b["pending"] > 0 and not force:
                 return
             if self.communicate:
+                # split weight gradients whose reduction pass was deferred (utils.streams.WgradLane.reduce_batch) must be
+                # complete in this bucket before it goes out
+                streams.flush_wgrad_reductions(b["flat"].device)
                 b["work"] = self._all_reduce(b["flat"])
             self._next += 1
 

@@ -114,6 +114,9 @@ class FusedSGD(torch.optim.Optimizer):
                   float(momentum), 1 if all(first) else 0, float(grad_scale),
                   ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
         self._steps += 1
+        from .. import _C
+        # parameters changed through raw pointers: the cached transposed weights are refreshed here, in one launch
+        _C.bump_weight_epoch(entries[0][0].device)
         return loss
 
 

@@ -100,6 +100,7 @@ class WgradLane(object):
     def __init__(self, device, defer=False, rows=None):
         self.defer = defer      # direct accumulations are queued until flush_deferred_wgrads() (see there)
         self.on = device.type == "cuda" and (WGRAD_OVERLAP or (rows is not None and rows <= WGRAD_LANE_ROWS))
+        self.plain_used = False   # some weight gradient of this node is returned to autograd instead of accumulated
         if self.on:
             self.main = torch.cuda.current_stream(device)
             self.lane = side_stream(device, 2)
@@ -123,6 +124,7 @@ class WgradLane(object):
         the compute stream never waits for the lane until join_wgrad_lane().  Otherwise: run(plain_fn)."""
         tgt = direct_grad_target(param)
         if tgt is None:
+            self.plain_used = True
             return self.run(plain_fn, *inputs)
         if self.defer and _DEFER_ENABLED:
             _DEFERRED.append((direct_fn, tgt, inputs))
@@ -137,13 +139,22 @@ class WgradLane(object):
             t.record_stream(self.lane)
         return None
 
-    def reduce_batch(self, batch):
+    def reduce_batch(self, batch, now=False):
         """the batched reduction pass of the weight gradients queued through this lane object (same stream as their
-        GEMMs: the lane when it is on, else the current stream)"""
+        GEMMs: the lane when it is on, else the current stream).  When every gradient of the batch is accumulated straight
+        into its persistent buffer (run_into's direct path) nothing reads the result before the gradients' consumers
+        (collectives, optimizer) ask for them through join_wgrad_lane / flush_wgrad_reductions: the pass is then
+        DEFERRED and merged with the other blocks' into a few chip-filling launches at that point, instead of one
+        10 - 40 us launch per block in the middle of the backward GEMM chain (rocprofv3 timeline of round 3: 13 launches,
+        0.49 ms per step with nothing else running).  now=True: results handed back to autograd — reduce at once."""
         if not batch:
             return
         from .. import _C
 
+        if DEFER_WGRAD_REDUCE and DIRECT_WGRAD and not now and not self.plain_used:
+            _PENDING_REDUCES.extend(batch)
+            del batch[:]
+            return
         if self.on:
             with torch.cuda.stream(self.lane):
                 _C.conv_wgrad_reduce_batch(batch)
@@ -215,8 +226,32 @@ def deferred_pending():
     return bool(_DEFERRED)
 
 
+# reduction passes of split weight gradients whose results nobody has asked for yet (WgradLane.reduce_batch)
+_PENDING_REDUCES = []
+DEFER_WGRAD_REDUCE = os.environ.get("DADET_DEFER_WGRAD_REDUCE", "1") == "1"
+
+
+def flush_wgrad_reductions(device):
+    """run the deferred reduction passes on the CURRENT stream (callers: join_wgrad_lane, i.e. everything that reads
+    gradients; the gradient reducer before it issues a bucket's collective)"""
+    global _PENDING_REDUCES
+    if not _PENDING_REDUCES:
+        return
+    items, _PENDING_REDUCES = _PENDING_REDUCES, []
+    from .. import _C
+
+    if device.type == "cuda":
+        cur = torch.cuda.current_stream(device)
+        if lane_in_use():
+            cur.wait_stream(side_stream(device, 2))       # partial sums computed on the lane
+        for it in items:
+            it[1].record_stream(cur)                       # the partial-sum workspaces are read on this stream
+    _C.conv_wgrad_reduce_batch(items)
+
+
 def join_wgrad_lane(device):
     """the current stream waits for every weight gradient queued on the lane (call before reading .grad)"""
     flush_deferred_wgrads(device)
     if device.type == "cuda" and lane_in_use():
         torch.cuda.current_stream(device).wait_stream(side_stream(device, 2))
+    flush_wgrad_reductions(device)

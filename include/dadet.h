@@ -185,6 +185,18 @@ int dadet_conv_wgrad_reduce_batch(const dadet_wgrad_pending* items, int n, void*
 int dadet_conv_weight_transpose(const float* w, const float* scale, float* wt, int Cout, int KH, int KW,
                                 int Cin, void* stream);
 
+/* The same for many weights in ONE launch.  items_dev: device-resident table; item k serves blocks [first_block,
+ * first_block + blocks_ci * blocks_co * KH * KW) of the grid, blocks_ci = ceil(Cin / 32), blocks_co = ceil(Cout / 32);
+ * total_blocks = the sum.  Used once per optimizer step for every weight whose data gradient the backward pass needs. */
+typedef struct dadet_transpose_item {
+  const float* w;
+  const float* scale;
+  float* wt;
+  int Cout, KH, KW, Cin;
+  int first_block, blocks_ci, blocks_co, pad;
+} dadet_transpose_item;
+int dadet_conv_weight_transpose_batch(const dadet_transpose_item* items_dev, int n, int total_blocks, void* stream);
+
 /* ------------------------------------------------------------------------------------------------
  * Deformable convolution v1 / v2 — replaces the vendored tree's `_C.deform_conv_forward / _backward_input /
  * _backward_parameters` and `_C.modulated_deform_conv_forward / _backward`
