@@ -663,6 +663,24 @@ def da_img_head_loss_forward(t, w2, b2, labels, num_images, rows_per_image):
     return logits, sums
 
 
+def da_img_head_loss_backward_g(t, w2, logits, labels, g_bce, g_mean_sig, w_adv, w_cst, num_images, rows_per_image,
+                                need_x=True):
+    """da_img_head_loss_backward with the coefficients formed in the kernel: g_bce 0-d / [1] tensor, g_mean_sig [N] tensor or
+    None, w_adv float or 0-d device tensor, w_cst float -> (g_t_w, g_t_x | None, g_w2 [C1], g_b2 [1])"""
+    C1 = w2.numel()
+    g_t_w = torch.empty_like(t)
+    g_t_x = torch.empty_like(t) if need_x else None
+    acc = torch.zeros(C1 + 1, dtype=torch.float32, device=t.device)       # one zero fill for both sums
+    g_w2, g_b2 = acc[:C1], acc[C1:]
+    adv_dev = w_adv if isinstance(w_adv, torch.Tensor) else None
+    _lib.call("dadet_da_img_head_loss_backward_g", _p(t), _p(w2), _p(logits), _p(labels), _p(g_bce.contiguous()),
+              _p(g_mean_sig.contiguous()) if g_mean_sig is not None else None,
+              _p(adv_dev.reshape(1).to(torch.float32)) if adv_dev is not None else None,
+              0.0 if adv_dev is not None else float(w_adv), float(w_cst), _p(g_t_w), _p(g_t_x), _p(g_w2), _p(g_b2),
+              num_images, rows_per_image, C1, _stream())
+    return g_t_w, g_t_x, g_w2, g_b2
+
+
 def da_img_head_loss_backward(t, w2, logits, labels, coef, num_images, rows_per_image, need_x=True):
     C1 = w2.numel()
     g_t_w = torch.empty_like(t)

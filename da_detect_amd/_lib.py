@@ -108,6 +108,8 @@ _SIGNATURES = {
     "dadet_rpn_decode_clip": [_P, _P, _P, c_int, c_float, c_float, c_float, c_float, c_float, c_float, c_float, _P, _P],
     "dadet_da_img_head_loss_forward": [_P, _P, _P, _P, _P, _P, c_int, c_int, c_int, _P],
     "dadet_da_img_head_loss_backward": [_P, _P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, _P],
+    "dadet_da_img_head_loss_backward_g": [_P, _P, _P, _P, _P, _P, _P, c_float, c_float, _P, _P, _P, _P, c_int, c_int, c_int,
+                                          _P],
     "dadet_da_ins_tail_forward": [_P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P],
     "dadet_da_ins_tail_backward": [_P, _P, _P, _P, _P, _P, c_float, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P],
     "dadet_da_ins_dropout_rows": [_P, _P, _P, c_int64, c_int, _P],

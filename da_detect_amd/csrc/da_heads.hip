@@ -108,7 +108,8 @@ __global__ __launch_bounds__(256) void da_img_bwd_kernel(
     const float* __restrict__ t, const float* __restrict__ w2, const float* __restrict__ logits,
     const float* __restrict__ labels, const float* __restrict__ coef, float* __restrict__ g_t_w,
     float* __restrict__ g_t_x, float* __restrict__ g_w2, float* __restrict__ g_b2, int num_images,
-    int rows_per_image, int C1) {
+    int rows_per_image, int C1, const float* __restrict__ g_bce, const float* __restrict__ g_sig,
+    const float* __restrict__ w_adv_dev, float w_adv, float w_cst) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float* s_w2g = reinterpret_cast<float*>(smem);  // [C1] workgroup partial of g_w2
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -127,7 +128,17 @@ __global__ __launch_bounds__(256) void da_img_bwd_kernel(
     const int img = (int)(m / rows_per_image);
     const float y = labels[img];
     const float s = sigmoidf(logits[m]);
-    const float4 cf = *reinterpret_cast<const float4*>(coef + img * 4);
+    // coef == nullptr: the coefficients are formed here from the upstream gradients (what the host chain
+    // `g / (N H W)`, expand, stack, multiply by the reversal weights took six launches for)
+    float4 cf;
+    if (coef) {
+      cf = *reinterpret_cast<const float4*>(coef + img * 4);
+    } else {
+      cf.x = g_bce[0] / (float)((int64_t)num_images * rows_per_image);
+      cf.y = g_sig ? g_sig[img] / (float)rows_per_image : 0.f;
+      cf.z = cf.x * (w_adv_dev ? w_adv_dev[0] : w_adv);
+      cf.w = cf.y * w_cst;
+    }
     const float d1 = s - y, d2 = s * (1.f - s);
     const float gw = cf.x * d1 + cf.y * d2;
     const float gx = cf.z * d1 + cf.w * d2;
@@ -438,8 +449,29 @@ extern "C" int dadet_da_img_head_loss_backward(const float* t, const float* w2, 
   if (blocks < 1) blocks = 1;
   hipLaunchKernelGGL(da_img_bwd_kernel, dim3((int)blocks), dim3(256), sizeof(float) * C1,
                      as_stream(stream), t, w2, logits, labels, coef, g_t_w, g_t_x, g_w2, g_b2, num_images,
-                     rows_per_image, C1);
+                     rows_per_image, C1, nullptr, nullptr, nullptr, 0.f, 0.f);
   return check_launch("da_img_head_loss_backward");
+}
+
+extern "C" int dadet_da_img_head_loss_backward_g(const float* t, const float* w2, const float* logits,
+                                                 const float* labels, const float* g_bce, const float* g_mean_sig,
+                                                 const float* w_adv_dev, float w_adv, float w_cst, float* g_t_w,
+                                                 float* g_t_x, float* g_w2, float* g_b2, int num_images,
+                                                 int rows_per_image, int C1, void* stream) {
+  DADET_REQUIRE(num_images >= 0 && rows_per_image > 0 && C1 > 0 && C1 % 4 == 0 && C1 <= 1024,
+                "da_img_head_loss_backward_g: C1 must be a multiple of 4 and <= 1024");
+  if (num_images == 0) return DADET_OK;
+  DADET_REQUIRE(t && w2 && logits && labels && g_bce && g_t_w && g_w2 && g_b2 && a16(t) && a16(w2) && a16(g_t_w) &&
+                    a16(g_t_x),
+                "da_img_head_loss_backward_g: bad pointers");
+  const int64_t M = (int64_t)num_images * rows_per_image;
+  int64_t blocks = ceil_div64(M, 4 * 16);
+  if (blocks > kNumCU * 4) blocks = kNumCU * 4;
+  if (blocks < 1) blocks = 1;
+  hipLaunchKernelGGL(da_img_bwd_kernel, dim3((int)blocks), dim3(256), sizeof(float) * C1, as_stream(stream), t, w2,
+                     logits, labels, nullptr, g_t_w, g_t_x, g_w2, g_b2, num_images, rows_per_image, C1, g_bce,
+                     g_mean_sig, w_adv_dev, w_adv, w_cst);
+  return check_launch("da_img_head_loss_backward_g");
 }
 
 extern "C" int dadet_triplet_w_forward(const float* anchor, const float* positive, const float* negative,

@@ -169,8 +169,10 @@ class _RPNHeadLossRows(Function):
         dw3 = dw3.view(w3.shape[0], k, k, C).permute(0, 3, 1, 2)          # the parameter's channels_last layout
         db3 = gt.view(S, -1).sum(0)
         # data gradient: y[r][tap][ci] = sum_co gt[r][co] * w3[co][tap][ci], added at pixel_r + tap offset
-        w_mat = w3.permute(0, 2, 3, 1).reshape(w3.shape[0], k * k * C)
-        y = _C.conv_forward(gt, w_mat.t().contiguous().view(k * k * C, w3.shape[0], 1, 1))
+        # W^T [K, Cout]: the 3x3 weight viewed as a 1x1 convolution over K = (tap, ci) and transposed — through the
+        # per-step cache of transposed weights (one batched launch per optimizer step) instead of a 38 MB copy here
+        w_1x1 = w3.permute(0, 2, 3, 1).reshape(w3.shape[0], k * k * C, 1, 1)
+        y = _C.conv_forward(gt, _C.conv_weight_transpose(w_1x1))
         dx = _C.scatter_pixel_taps_add(y.view(S, k * k, C), pixels, tuple(x.shape), k, k // 2)
         return (dx, dw3, db3, d_head[:A], b_head[:A], d_head[A:5 * A], b_head[A:5 * A]) + (None,) * 8
 

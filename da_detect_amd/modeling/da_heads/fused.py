@@ -33,6 +33,7 @@ class _DAImageHead(Function):
         # only consumed by backward
         ctx.w_adv = w_adv(bce.detach()) if callable(w_adv) else w_adv
         ctx.w_cst = w_cst
+        ctx.sig_used = True
         mean_sig = sums[:, 1] / float(H * W)
         out_logits = logits.view(N, 1, H, W)
         ctx.mark_non_differentiable(out_logits)
@@ -44,11 +45,10 @@ class _DAImageHead(Function):
         x, w1, t, w2v, logits, labels = ctx.saved_tensors
         N, H, W = ctx.dims
         need_x = ctx.needs_input_grad[0]
-        a_bce = (g_bce / float(N * H * W)).reshape(1).expand(N)
-        a_sig = g_mean_sig / float(H * W)
-        coef = torch.stack([a_bce, a_sig, a_bce * ctx.w_adv, a_sig * ctx.w_cst], dim=1).contiguous()
-        g_t_w, g_t_x, g_w2, g_b2 = _C.da_img_head_loss_backward(t, w2v, logits, labels, coef, N, H * W,
-                                                                need_x=need_x)
+        # the four per-image coefficients (1 / (N H W), 1 / (H W), the two reversal weights) are formed in the kernel
+        g_t_w, g_t_x, g_w2, g_b2 = _C.da_img_head_loss_backward_g(
+            t, w2v, logits, labels, g_bce.reshape(1), g_mean_sig if ctx.sig_used else None, ctx.w_adv, ctx.w_cst, N,
+            H * W, need_x=need_x)
         g_w1 = _C.conv_wgrad(x, g_t_w, tuple(w1.shape), 1, 0)
         g_b1 = _C.colsum(g_t_w)
         g_x = _C.conv_forward(g_t_x, _C.conv_weight_transpose(w1)) if need_x else None

@@ -443,6 +443,13 @@ int dadet_da_img_head_loss_backward(const float* t, const float* w2, const float
                                     const float* labels, const float* coef, float* g_t_w, float* g_t_x,
                                     float* g_w2, float* g_b2, int num_images, int rows_per_image, int C1,
                                     void* stream);
+/* the same with the four coefficients formed inside the kernel from the upstream gradients: g_bce [1] (gradient of the mean
+ * BCE), g_mean_sig [num_images] or NULL (gradient of the per-image mean sigmoid), the adversarial reversal weight as a
+ * device scalar (w_adv_dev, e.g. AdvGRL's adaptive weight) or, when NULL, the float w_adv; w_cst the consistency one */
+int dadet_da_img_head_loss_backward_g(const float* t, const float* w2, const float* logits, const float* labels,
+                                      const float* g_bce, const float* g_mean_sig, const float* w_adv_dev, float w_adv,
+                                      float w_cst, float* g_t_w, float* g_t_x, float* g_w2, float* g_b2, int num_images,
+                                      int rows_per_image, int C1, void* stream);
 /* Domain-level triplet loss on NHWC maps [H][W][C] (one image each): L2 distance over the W axis with
  * eps, hinge with margin, loss_sum[0] += sum over (h,c) (the caller zeroes it and divides by H*C).
  * dist_out [H*C][2] keeps (d_ap, d_an) for the backward; g_scale[0] = upstream grad / (H*C).
