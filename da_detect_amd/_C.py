@@ -398,6 +398,9 @@ class _TransposeCache(object):
         for k in [k for k, e in self.entries.items() if e["used"] < self.epoch - 2]:
             del self.entries[k]
         live = [(k, e) for k, e in self.entries.items() if k[6] == device.index and e["version"] == e["w"]._version]
+        if not live:
+            self.batched_epoch = self.epoch
+            return
         if self.table is None or self.table[3] != [k for k, _ in live]:
             arr = (_lib.TransposeItem * len(live))()
             blocks = 0
