@@ -300,15 +300,26 @@ __global__ __launch_bounds__(256) void nms_sweep_pipelined_kernel(const unsigned
   const bool wave0 = threadIdx.x < 64;
   unsigned long long removed = 0;             // word w of the removed set, from the chunks whose loads were consumed
   constexpr int kFly = 64;
-  unsigned long long fly[kFly];               // this thread's loads in flight: word w of the previous chunk's kept rows
+  // this thread's loads in flight: word w of the kept rows of the last EVEN chunk (fly_a) and of the last ODD chunk (fly_b).
+  // The words chunk c pushes are issued at the end of iteration c and consumed at the start of iteration c + 2 — two
+  // resolutions of flight; what chunk c needs from chunk c - 1 comes through adj_t instead.
+  unsigned long long fly_a[kFly], fly_b[kFly];
 #pragma unroll
-  for (int u = 0; u < kFly; ++u) fly[u] = 0;
+  for (int u = 0; u < kFly; ++u) fly_a[u] = fly_b[u] = 0;
   if (threadIdx.x == 0) s_kept_total = 0;
   // wave 0, lane i: the transposed diagonal / previous-block words of box (c * 64 + i), fetched one chunk ahead
   unsigned long long dcol_next = 0, acol_next = 0;
   if (wave0 && lane < n) dcol_next = diag_t[lane];      // chunk 0 has no previous block
   __syncthreads();
-  for (int c = 0; c < col_blocks; ++c) {
+  bool done = false;
+  auto step = [&](const int c, unsigned long long (&fly)[kFly]) {
+    // pushes of chunk c - 2 (issued two iterations ago into this buffer): word w for every w >= c
+    if (w >= c) {
+      unsigned long long acc = 0;
+#pragma unroll
+      for (int u = 0; u < kFly; ++u) acc |= fly[u];
+      removed |= acc;
+    }
     if (w == c) s_removed_c = removed;        // chunks <= c - 2 (chunk c - 1's part comes through adj_t)
     __syncthreads();
     if (wave0) {
@@ -355,30 +366,27 @@ __global__ __launch_bounds__(256) void nms_sweep_pipelined_kernel(const unsigned
         keep_bits[c] = K;
       }
     }
-    // the loads issued one iteration ago (rows of chunk c - 1, word w) have had a whole resolution to land
-    if (w > c) {
-      unsigned long long acc = 0;
-#pragma unroll
-      for (int u = 0; u < kFly; ++u) acc |= fly[u];
-      removed |= acc;
-    }
     __syncthreads();
     if (max_keep > 0 && s_kept_total >= max_keep) {      // quota filled: later chunks keep nothing
       for (int cc = c + 1 + (int)threadIdx.x; cc < col_blocks; cc += blockDim.x) keep_bits[cc] = 0;
-      break;
+      done = true;
+      return;
     }
-    // issue the loads for chunk c's kept rows (consumed in the next iteration); word c + 1 goes through adj_t
-    {
-      unsigned long long k = s_keep;
-      const bool mine = w >= c + 2 && w < col_blocks;
-      const unsigned long long* mrow = mask + (size_t)c * 64 * col_blocks + (mine ? w : 0);
+    // issue the loads for chunk c's kept rows (consumed two iterations on); word c + 1 goes through adj_t
+    unsigned long long k = s_keep;
+    const bool mine = w >= c + 2 && w < col_blocks;
+    const unsigned long long* mrow = mask + (size_t)c * 64 * col_blocks + (mine ? w : 0);
 #pragma unroll
-      for (int u = 0; u < kFly; ++u) {
-        const int j = k ? (__ffsll((long long)k) - 1) : -1;
-        k &= (k - 1);
-        fly[u] = (mine && j >= 0) ? mrow[(size_t)j * col_blocks] : 0ULL;
-      }
+    for (int u = 0; u < kFly; ++u) {
+      const int j = k ? (__ffsll((long long)k) - 1) : -1;
+      k &= (k - 1);
+      fly[u] = (mine && j >= 0) ? mrow[(size_t)j * col_blocks] : 0ULL;
     }
+  };
+  for (int c = 0; c < col_blocks && !done; c += 2) {
+    step(c, fly_a);
+    if (done || c + 1 >= col_blocks) break;
+    step(c + 1, fly_b);
   }
 }
 

@@ -64,13 +64,21 @@ class BucketedGradReducer(object):
             cur_bytes += nbytes
         if cur:
             groups.append(cur)
+        # ONE allocation for all buckets (each bucket a 256-byte aligned slice): zero_grad() is a single fill instead of
+        # one per bucket, and the buckets stay separate tensors for the collectives
+        layouts, total_all = [], 0
         for plist in groups:
             # 16-byte aligned slots so the optimizer's float4 path applies to every tensor
             offsets, total = [], 0
             for p in plist:
                 offsets.append(total)
                 total += (p.numel() + 3) // 4 * 4
-            flat = torch.zeros(total, dtype=plist[0].dtype, device=plist[0].device)
+            layouts.append((plist, offsets, total, total_all))
+            total_all += (total + 63) // 64 * 64
+        first = groups[0][0] if groups else None
+        self._all = torch.zeros(total_all, dtype=first.dtype, device=first.device) if first is not None else None
+        for plist, offsets, total, base in layouts:
+            flat = self._all[base:base + total]
             b = dict(flat=flat, params=plist, pending=len(plist), work=None)
             for p, off in zip(plist, offsets):
                 p.grad = flat[off:off + p.numel()].as_strided(p.size(), p.stride())
@@ -80,8 +88,9 @@ class BucketedGradReducer(object):
     # -- per-step protocol: zero_grad() -> backward (hooks fire) -> finalize() -> optimizer.step() --------
     def zero_grad(self):
         unused = self.static_unused or ()
+        if self._all is not None:
+            self._all.zero_()
         for b in self.buckets:
-            b["flat"].zero_()
             b["pending"] = sum(1 for p in b["params"] if id(p) not in unused)
             b["work"] = None
         self._next = 0
