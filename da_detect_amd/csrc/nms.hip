@@ -373,7 +373,12 @@ __global__ __launch_bounds__(256) void nms_sweep_pipelined_kernel(const unsigned
       return;
     }
     // issue the loads for chunk c's kept rows (consumed two iterations on); word c + 1 goes through adj_t
-    unsigned long long k = s_keep;
+    // the keep word is the same for every thread: its bit scan runs on the scalar unit (readfirstlane).  All 64 slots are
+    // written unconditionally — bounding the loop by the number of kept boxes put every load into its own basic block
+    // and made the sweep 4x slower
+    const unsigned long long kv = s_keep;
+    unsigned long long k = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(kv >> 32)) << 32) |
+                           (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)kv);
     const bool mine = w >= c + 2 && w < col_blocks;
     const unsigned long long* mrow = mask + (size_t)c * 64 * col_blocks + (mine ? w : 0);
 #pragma unroll
