@@ -124,6 +124,9 @@ __global__ __launch_bounds__(64) void nms_mask_kernel(const float4* __restrict__
   // linear block id -> (row_block <= col_block) pair
   const int row_start = blockIdx.y, col_start = blockIdx.x;
   if (col_start < row_start) return;
+  // row n of the matrix: all zeros, what the sweep loads for "no kept box in this slot"
+  if (row_start == 0 && col_start == 0)
+    for (int i = threadIdx.x; i < col_blocks; i += 64) mask[(size_t)n * col_blocks + i] = 0ULL;
   const int row_size = min(n - row_start * 64, 64);
   const int col_size = min(n - col_start * 64, 64);
   __shared__ float4 cb[64];
@@ -292,42 +295,69 @@ __global__ __launch_bounds__(256) void nms_sweep_pipelined_kernel(const unsigned
                                                                   const unsigned long long* __restrict__ adj_t, int n,
                                                                   int col_blocks, int max_keep,
                                                                   unsigned long long* __restrict__ keep_bits) {
+  constexpr int kSlots = 24;                  // kept rows of a chunk whose loads stay in flight for two resolutions
   __shared__ unsigned long long s_removed_c;  // removed word of the current chunk from chunks <= c - 2
   __shared__ unsigned long long s_keep;       // keep bits of the current chunk
   __shared__ int s_kept_total;
+  // mask rows of the current chunk's kept boxes in rank order; every other entry names the all-zero row behind the
+  // matrix (row n, written by the mask kernel), so that EVERY load below is unconditional: with a load under an exec
+  // branch the compiler can no longer count what is in flight and waits with vmcnt(0) — the pushed words then had one
+  // resolution of flight instead of two and an iteration cost ~1700 instructions (ISA of round 3)
+  // (stored as BYTE offsets of the rows, 32 bits: the matrix of 16 384 boxes is 32 MB)
+  __shared__ unsigned s_rows[64 + kSlots];
+  // the keep words, written out once at the end.  A global store inside the loop shares the vmcnt counter with the loads in
+  // flight on gfx9-family targets and may retire out of order with them: the compiler then waits with vmcnt(0) at every
+  // use of a loaded word (seen in the ISA) — again one resolution of flight instead of two
+  __shared__ unsigned long long s_keep_all[258];
   const int w = threadIdx.x;
   const int lane = threadIdx.x & 63;
   const bool wave0 = threadIdx.x < 64;
-  unsigned long long removed = 0;             // word w of the removed set, from the chunks whose loads were consumed
-  constexpr int kFly = 64;
-  // this thread's loads in flight: word w of the kept rows of the last EVEN chunk (fly_a) and of the last ODD chunk (fly_b).
-  // The words chunk c pushes are issued at the end of iteration c and consumed at the start of iteration c + 2 — two
-  // resolutions of flight; what chunk c needs from chunk c - 1 comes through adj_t instead.
-  unsigned long long fly_a[kFly], fly_b[kFly];
-#pragma unroll
-  for (int u = 0; u < kFly; ++u) fly_a[u] = fly_b[u] = 0;
+  const unsigned pitch = (unsigned)col_blocks * 8u;
+  const unsigned zero_row = (unsigned)n * pitch;
+  // Thread w owns word w of the removed set.  No guard on w anywhere: a thread behind the current chunk (or beyond the
+  // last word, clamped) ORs words nobody reads again — word w is published once, at iteration w, and only loads consumed
+  // before that matter.
+  const char* mcol = reinterpret_cast<const char*>(mask + min(w, col_blocks - 1));
+  auto word_at = [&](const unsigned row_bytes) { return *reinterpret_cast<const unsigned long long*>(mcol + row_bytes); };
+  unsigned long long removed = 0;
+  // word w of the kept rows of the last EVEN chunk (fly_a) and of the last ODD chunk (fly_b): issued at the end of iteration
+  // c, consumed at the start of iteration c + 2; what chunk c needs from chunk c - 1 comes through adj_t instead
+  unsigned long long fly_a[kSlots], fly_b[kSlots];
   if (threadIdx.x == 0) s_kept_total = 0;
-  // wave 0, lane i: the transposed diagonal / previous-block words of box (c * 64 + i), fetched one chunk ahead
-  unsigned long long dcol_next = 0, acol_next = 0;
-  if (wave0 && lane < n) dcol_next = diag_t[lane];      // chunk 0 has no previous block
+  for (int i = threadIdx.x; i < 64 + kSlots; i += blockDim.x) s_rows[i] = zero_row;
+  for (int i = threadIdx.x; i < 258; i += blockDim.x) s_keep_all[i] = 0ULL;
+  // wave 0, lane i: the transposed diagonal / previous-block words of box (c * 64 + i), fetched TWO chunks ahead into the
+  // register pair of the same parity (no register copy between iterations: a copy is a wait for the load just issued).
+  //
+  // The compiler derives every s_waitcnt vmcnt(N) from the ORDER in which loads are issued, and at the loop header it
+  // must assume the shorter of "came from the prologue" and "came from the previous iteration".  The prologue therefore
+  // issues exactly the loop's sequence — (diag, adj) of the even chunk, kSlots words, (diag, adj) of the odd chunk, kSlots
+  // words, all unconditional (clamped rows; the pushed words read the zero row) — and nothing inside the loop leaves it
+  // early (the quota is tested once per iteration, at the very end): a branch around the loads that flows back to the
+  // header makes the newest loads look like the oldest, and the waits collapse to vmcnt(0).
+  const unsigned long long* zrow = mask + (size_t)n * (size_t)col_blocks;   // (distinct words: no merged loads)
+  // (diag, adj) are loaded by EVERY thread, in the same block as the pushed words and in front of them: only wave 0 uses
+  // the values, but a load under `if (wave0)` is one the compiler cannot order against the others
+  const int dl = threadIdx.x & 63;
+  unsigned long long d_even = diag_t[min(dl, n - 1)];
+  unsigned long long a_even = adj_t[min(64 + dl, n - 1)];   // (chunk 0 has no previous block: unused, prev_keep = 0)
+#pragma unroll
+  for (int u = 0; u < kSlots; ++u) fly_a[u] = zrow[min(u, col_blocks - 1)];
+  unsigned long long d_odd = diag_t[min(64 + dl, n - 1)];
+  unsigned long long a_odd = adj_t[min(64 + dl, n - 1)];
+#pragma unroll
+  for (int u = 0; u < kSlots; ++u) fly_b[u] = zrow[min(u, col_blocks - 1)];
   __syncthreads();
-  bool done = false;
-  auto step = [&](const int c, unsigned long long (&fly)[kFly]) {
-    // pushes of chunk c - 2 (issued two iterations ago into this buffer): word w for every w >= c
-    if (w >= c) {
+  auto step = [&](const int c, unsigned long long (&fly)[kSlots], unsigned long long& dcol, unsigned long long& acol) {
+    {
       unsigned long long acc = 0;
 #pragma unroll
-      for (int u = 0; u < kFly; ++u) acc |= fly[u];
+      for (int u = 0; u < kSlots; ++u) acc |= fly[u];
       removed |= acc;
     }
     if (w == c) s_removed_c = removed;        // chunks <= c - 2 (chunk c - 1's part comes through adj_t)
     __syncthreads();
     if (wave0) {
-      const unsigned long long dcol = dcol_next, acol = acol_next;
-      const int nbox = (c + 1) * 64 + lane;
-      const bool more = c + 1 < col_blocks && nbox < n;
-      dcol_next = more ? diag_t[nbox] : 0ULL;
-      acol_next = more ? adj_t[nbox] : 0ULL;
       const unsigned long long rem0 = s_removed_c;
       const unsigned rem_lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)rem0);
       const unsigned rem_hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(rem0 >> 32));
@@ -351,7 +381,7 @@ __global__ __launch_bounds__(256) void nms_sweep_pipelined_kernel(const unsigned
       int kept_total = __builtin_amdgcn_readfirstlane(s_kept_total);
       if (max_keep > 0 && kept_total + __popcll(K) > max_keep) {
         // quota: keep the first (max_keep - kept_total) of them — later boxes never influence earlier ones
-        int room = max_keep - kept_total;
+        int room = max(max_keep - kept_total, 0);
         unsigned long long first = 0, k2 = K;
         while (room-- > 0 && k2) {
           first |= k2 & (~k2 + 1ULL);
@@ -360,39 +390,50 @@ __global__ __launch_bounds__(256) void nms_sweep_pipelined_kernel(const unsigned
         K = first;
       }
       kept_total += __popcll(K);
+      // kept rows in rank order (one wave: its LDS writes land in program order)
+      s_rows[lane] = zero_row;
+      if ((K >> lane) & 1ULL) s_rows[__popcll(K & ((1ULL << lane) - 1ULL))] = (unsigned)(c * 64 + lane) * pitch;
       if (lane == 0) {
         s_keep = K;
         s_kept_total = kept_total;
-        keep_bits[c] = K;
+        s_keep_all[c] = K;
       }
     }
     __syncthreads();
-    if (max_keep > 0 && s_kept_total >= max_keep) {      // quota filled: later chunks keep nothing
-      for (int cc = c + 1 + (int)threadIdx.x; cc < col_blocks; cc += blockDim.x) keep_bits[cc] = 0;
-      done = true;
-      return;
-    }
-    // issue the loads for chunk c's kept rows (consumed two iterations on); word c + 1 goes through adj_t
-    // the keep word is the same for every thread: its bit scan runs on the scalar unit (readfirstlane).  All 64 slots are
-    // written unconditionally — bounding the loop by the number of kept boxes put every load into its own basic block
-    // and made the sweep 4x slower
     const unsigned long long kv = s_keep;
-    unsigned long long k = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(kv >> 32)) << 32) |
-                           (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)kv);
-    const bool mine = w >= c + 2 && w < col_blocks;
-    const unsigned long long* mrow = mask + (size_t)c * 64 * col_blocks + (mine ? w : 0);
+    const int cnt = __popc((unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)kv)) +
+                    __popc((unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(kv >> 32)));
+    // a chunk that keeps more than kSlots boxes: the rest at once, waited for here (rare past the first chunks — the
+    // kept boxes thin out as the sweep goes on)
+    for (int base = kSlots; base < cnt; base += kSlots) {
+      unsigned long long t[kSlots];
 #pragma unroll
-    for (int u = 0; u < kFly; ++u) {
-      const int j = k ? (__ffsll((long long)k) - 1) : -1;
-      k &= (k - 1);
-      fly[u] = (mine && j >= 0) ? mrow[(size_t)j * col_blocks] : 0ULL;
+      for (int u = 0; u < kSlots; ++u) t[u] = word_at(s_rows[base + u]);
+      unsigned long long acc = 0;
+#pragma unroll
+      for (int u = 0; u < kSlots; ++u) acc |= t[u];
+      removed |= acc;
     }
+    // (diag, adj) of chunk c + 2, then the first kSlots kept rows: consumed two iterations on (word c + 1 goes through
+    // adj_t)
+    {
+      const int nbox = min((c + 2) * 64 + dl, n - 1);
+      dcol = diag_t[nbox];
+      acol = adj_t[nbox];
+    }
+#pragma unroll
+    for (int u = 0; u < kSlots; ++u) fly[u] = word_at(s_rows[u]);
   };
-  for (int c = 0; c < col_blocks && !done; c += 2) {
-    step(c, fly_a);
-    if (done || c + 1 >= col_blocks) break;
-    step(c + 1, fly_b);
+  int c_end = col_blocks;
+  for (int c = 0; c < c_end; c += 2) {
+    step(c, fly_a, d_even, a_even);
+    step(c + 1, fly_b, d_odd, a_odd);      // (c + 1 == col_blocks: an empty chunk — nothing in range, keeps nothing)
+    // quota filled: later chunks keep nothing (a chunk resolved after the quota was reached has room for 0 boxes).  One
+    // exit, the loop condition: see above
+    c_end = (max_keep > 0 && s_kept_total >= max_keep) ? 0 : col_blocks;
   }
+  __syncthreads();
+  if (w < col_blocks) keep_bits[w] = s_keep_all[w];
 }
 
 // ---- compaction to ascending original indices ----------------------------------------------
@@ -448,7 +489,7 @@ static NmsWorkspace nms_layout(int n) {
   size_t off = 0;
   ws.order_off = off;    off = align(off + sizeof(int) * (size_t)n);
   ws.sorted_off = off;   off = align(off + sizeof(float4) * (size_t)n);
-  ws.mask_off = off;     off = align(off + sizeof(unsigned long long) * (size_t)n * col_blocks);
+  ws.mask_off = off;     off = align(off + sizeof(unsigned long long) * ((size_t)n + 1) * col_blocks);  // + the zero row
   ws.keepbits_off = off; off = align(off + sizeof(unsigned long long) * (size_t)col_blocks);
   ws.flag_off = off;     off = align(off + (size_t)n);
   ws.diagt_off = off;    off = align(off + sizeof(unsigned long long) * (size_t)col_blocks * 64);

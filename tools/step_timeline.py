@@ -2,7 +2,8 @@
 """What runs while no GEMM runs: the GEMM-free stretches of one steady-state training step, from a rocprofv3
 kernel_trace.csv (tools/profile_gaps.sh), each with the kernels that executed inside it.
 
-usage: step_timeline.py <kernel_trace.csv> [min_stretch_us=15] [step_from_end=1]
+usage: step_timeline.py <kernel_trace.csv> [min_stretch_us=15] [step_from_end=1] [list=A:B]
+       list=A:B  also print EVERY kernel (GEMMs included) that starts between A and B ms into the step, in start order
 
 A "GEMM" is one of this repo's MFMA kernels (conv_fwd_* / conv_wgrad_*); everything else — library launches, the
 latency-bound kernels of proposal selection and sampling, ROIAlign, reductions, the optimizer — only costs wall time
@@ -15,6 +16,10 @@ from collections import defaultdict
 path = sys.argv[1]
 min_us = float(sys.argv[2]) if len(sys.argv) > 2 else 15.0
 back = int(sys.argv[3]) if len(sys.argv) > 3 else 1
+window = None
+for a in sys.argv[4:]:
+    if a.startswith("list="):
+        window = tuple(float(v) for v in a[5:].split(":"))
 rows = []
 with open(path, newline="") as f:
     for r in csv.DictReader(f):
@@ -76,3 +81,9 @@ for a, b in sorted(free, key=lambda ab: ab[0] - ab[1]):
 print("time of non-GEMM kernels INSIDE GEMM-free stretches, by kernel (count, us):")
 for n, (c, t) in sorted(tot_by_kernel.items(), key=lambda kv: -kv[1][1])[:40]:
     print("  %4d %8.1f  %s" % (c, t, n))
+if window is not None:
+    print("every kernel starting between +%.2f and +%.2f ms (start offset ms, duration us, queue):" % window)
+    for s0, e0, n, q in step:
+        off = (s0 - lo) / 1e6
+        if window[0] <= off < window[1]:
+            print("  +%7.3f  %7.1f us  q%-3s %s%s" % (off, (e0 - s0) / 1e3, str(q)[-3:], "GEMM " if is_gemm(n) else "", short(n)))
