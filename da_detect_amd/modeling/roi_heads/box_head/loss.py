@@ -1,5 +1,7 @@
 """Fast R-CNN losses with the domain-adaptation sampling rules
 (reference: maskrcnn_benchmark/modeling/roi_heads/box_head/loss.py:16-251)."""
+import os
+
 import torch
 from torch.nn import functional as F
 

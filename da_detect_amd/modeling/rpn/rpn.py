@@ -1,4 +1,6 @@
 """Region proposal network (reference: maskrcnn_benchmark/modeling/rpn/rpn.py:13-138)."""
+import os
+
 import torch
 from torch import nn
 
@@ -11,6 +13,8 @@ from .inference import make_rpn_postprocessor
 from .loss import make_rpn_loss_evaluator
 from ..elision import elision_enabled, leading_source_images
 from ...utils.streams import record, side_section, side_stream
+
+_PROPOSALS_FIRST = os.environ.get("DADET_PROPOSALS_FIRST", "1") == "1"
 
 
 @registry.RPN_HEADS.register("SingleConvRPNHead")
@@ -161,13 +165,31 @@ class RPNModule(torch.nn.Module):
 
     def _finish_overlapped(self, anchors, head_in, objectness, rpn_box_regression, sel_obj, sel_reg, targets, n_live,
                            hidden=None):
-        # overlapped schedule: losses + the RPN branch's backward go to the compute stream first; proposal selection
-        # (sort, decode, single-workgroup NMS sweeps, one host round trip) then runs on the side stream underneath
-        # them, and the box head's sampling continues there (ROIBoxHead.forward)
+        # overlapped schedule: proposal selection (sort, decode, NMS: ~20 latency-bound launches) is ISSUED first, on the
+        # side stream, and the losses + the RPN branch's backward (+ the image-level DA head through the hook) then go to
+        # the compute stream: the chain runs underneath them, and the box head's sampling continues on the side stream
+        # (ROIBoxHead.forward).  Issued after the losses — the order of round 2 — the chain only started once the host had
+        # worked through the loss and DA launches; with the NMS sweep at 0.2 ms the GPU then sat through the whole chain
+        # without a GEMM to run (rocprofv3 timeline of round 3: 0.93 ms GEMM-free around the proposals).
+        # DADET_PROPOSALS_FIRST=0 restores the old order.
         dev = objectness[0].device
         prep = self._prepare_loss_targets(anchors, targets)
         main = torch.cuda.current_stream(dev)
         head_done = main.record_event()
+        side = side_stream(dev)
+
+        def select():
+            side.wait_event(head_done)
+            # the head's maps were allocated on the compute stream and are released when forward() returns: without this
+            # the caching allocator may hand their blocks to a later compute-stream allocation while the side stream still
+            # reads them
+            record([sel_obj, sel_reg], side)
+            with torch.cuda.stream(side), torch.no_grad():
+                out = self.box_selector_train(anchors[:n_live], sel_obj, sel_reg, targets[:n_live])
+                self.proposals_ready = side.record_event()
+            return out
+
+        boxes = select() if _PROPOSALS_FIRST else None
         if hidden is not None and prep["sampled_inds"].numel() > 0:
             h = self.head
             loss_objectness, loss_rpn_box_reg = rpn_head_loss_rows(
@@ -183,15 +205,8 @@ class RPNModule(torch.nn.Module):
         hook, self.after_early_backward = self.after_early_backward, None
         if hook is not None:
             hook()
-        side = side_stream(dev)
-        side.wait_event(head_done)
-        # the head's maps were allocated on the compute stream and are released when forward() returns: without this the
-        # caching allocator may hand their blocks to a later compute-stream allocation while the side stream still reads
-        # them
-        record([sel_obj, sel_reg], side)
-        with torch.cuda.stream(side), torch.no_grad():
-            boxes = self.box_selector_train(anchors[:n_live], sel_obj, sel_reg, targets[:n_live])
-            self.proposals_ready = side.record_event()
+        if boxes is None:
+            boxes = select()
         record(boxes, main)
         boxes = list(boxes) + [None] * (len(targets) - n_live)
         return boxes, {"loss_objectness": loss_objectness.detach(), "loss_rpn_box_reg": loss_rpn_box_reg.detach()}
