@@ -14,7 +14,7 @@ from .loss import make_rpn_loss_evaluator
 from ..elision import elision_enabled, leading_source_images
 from ...utils.streams import record, side_section, side_stream
 
-_PROPOSALS_FIRST = os.environ.get("DADET_PROPOSALS_FIRST", "1") == "1"
+_PROPOSALS_FIRST = os.environ.get("DADET_PROPOSALS_FIRST", "0") == "1"
 
 
 @registry.RPN_HEADS.register("SingleConvRPNHead")
@@ -165,13 +165,14 @@ class RPNModule(torch.nn.Module):
 
     def _finish_overlapped(self, anchors, head_in, objectness, rpn_box_regression, sel_obj, sel_reg, targets, n_live,
                            hidden=None):
-        # overlapped schedule: proposal selection (sort, decode, NMS: ~20 latency-bound launches) is ISSUED first, on the
-        # side stream, and the losses + the RPN branch's backward (+ the image-level DA head through the hook) then go to
-        # the compute stream: the chain runs underneath them, and the box head's sampling continues on the side stream
-        # (ROIBoxHead.forward).  Issued after the losses — the order of round 2 — the chain only started once the host had
-        # worked through the loss and DA launches; with the NMS sweep at 0.2 ms the GPU then sat through the whole chain
-        # without a GEMM to run (rocprofv3 timeline of round 3: 0.93 ms GEMM-free around the proposals).
-        # DADET_PROPOSALS_FIRST=0 restores the old order.
+        # overlapped schedule: losses + the RPN branch's backward (+ the image-level DA head through the hook) go to the
+        # compute stream first; proposal selection (sort, decode, single-workgroup NMS sweeps) then runs on the side stream
+        # underneath them, and the box head's sampling continues there (ROIBoxHead.forward).
+        # DADET_PROPOSALS_FIRST=1 issues the selection chain BEFORE the losses.  MEASURED (round 3, alternating runs of 30
+        # steps on one box): R-50-C4, whose selection never comes back to the host, 19.00 / 19.04 vs 19.07 / 18.99 ms (no
+        # difference: the host is far enough ahead that the issue order does not reach the GPU); R-101-FPN-DCN, whose
+        # per-level selection has host round trips, 64.8 / 65.5 -> 68.7 / 70.0 ms (the host then sits in those round trips
+        # with nothing queued on the compute stream).  Off.
         dev = objectness[0].device
         prep = self._prepare_loss_targets(anchors, targets)
         main = torch.cuda.current_stream(dev)

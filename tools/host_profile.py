@@ -1,5 +1,6 @@
 #!/usr/bin/env python
-"""cProfile of the host side of the bench step (where does the CPU spend its time between kernel launches?)"""
+"""cProfile of the host side of the bench step (where does the CPU spend its time between kernel launches?)
+usage: host_profile.py [steps=5] [workload=img_only]"""
 import cProfile
 import os
 import pstats
@@ -16,9 +17,11 @@ from da_detect_amd.data.synthetic import make_batch  # noqa: E402
 from da_detect_amd.engine.trainer import enable_overlapped_rpn_backward, train_step  # noqa: E402
 
 device = torch.device("cuda", 0)
-c, model, opt, reducer = bench.build(bench.YAML, device, seed=100)
+workload = sys.argv[2] if len(sys.argv) > 2 else "img_only"
+yaml_path, overrides, images_per_gpu, _ = bench.WORKLOADS[workload]
+c, model, opt, reducer = bench.build(yaml_path, device, seed=100, overrides=overrides)
 enable_overlapped_rpn_backward(model)
-images, targets = make_batch(c, 2, bench.HEIGHT, bench.WIDTH, seed=100, device=device)
+images, targets = make_batch(c, images_per_gpu, bench.HEIGHT, bench.WIDTH, seed=100, device=device)
 for _ in range(3):
     train_step(model, opt, images, targets)
 torch.cuda.synchronize()
