@@ -329,7 +329,8 @@ def conv_forward(x, w, scale=None, bias=None, addend=None, mask_ref=None, stride
 
 def _transpose_now(w, scale, wt):
     Cout, Cin, KH, KW = w.shape
-    _lib.call("dadet_conv_weight_transpose", _p(w), _p(scale), _p(wt), Cout, KH, KW, Cin, _stream())
+    cout_pad = wt.shape[1]          # rows of the result: >= Cout (zero columns behind the weight's own)
+    _lib.call("dadet_conv_weight_transpose_padded", _p(w), _p(scale), _p(wt), Cout, KH, KW, Cin, cout_pad, _stream())
     return wt
 
 
@@ -367,12 +368,12 @@ class _TransposeCache(object):
             e["ev"] = (st, st.record_event())
         return e["wt"]
 
-    def get(self, w, scale):
+    def get(self, w, scale, cout_pad=0):
         Cout, Cin, KH, KW = w.shape
-        key = (w.data_ptr(), Cout, Cin, KH, KW, scale.data_ptr() if scale is not None else 0, w.device.index)
+        key = (w.data_ptr(), Cout, Cin, KH, KW, scale.data_ptr() if scale is not None else 0, w.device.index, cout_pad)
         e = self.entries.get(key)
         if e is None:
-            wt = torch.empty((Cin, Cout, KH, KW), dtype=torch.float32, device=w.device, memory_format=CL)
+            wt = torch.empty((Cin, max(Cout, cout_pad), KH, KW), dtype=torch.float32, device=w.device, memory_format=CL)
             # the entry keeps w / scale alive: their storage addresses are in the device table
             e = self.entries[key] = dict(w=w, scale=scale, wt=wt, version=w._version, epoch=self.epoch, used=self.epoch,
                                          ev=None)
@@ -405,12 +406,13 @@ class _TransposeCache(object):
             arr = (_lib.TransposeItem * len(live))()
             blocks = 0
             for i, (k, e) in enumerate(live):
-                _, Cout, Cin, KH, KW, _, _ = k
+                _, Cout, Cin, KH, KW, _, _, cout_pad = k
                 it = arr[i]
                 it.w, it.scale, it.wt = e["w"].data_ptr(), (e["scale"].data_ptr() if e["scale"] is not None else None), \
                     e["wt"].data_ptr()
                 it.Cout, it.KH, it.KW, it.Cin = Cout, KH, KW, Cin
-                it.blocks_ci, it.blocks_co = (Cin + 31) // 32, (Cout + 31) // 32
+                it.cout_pad = cout_pad
+                it.blocks_ci, it.blocks_co = (Cin + 31) // 32, (max(Cout, cout_pad) + 31) // 32
                 it.first_block = blocks
                 blocks += it.blocks_ci * it.blocks_co * KH * KW
             host = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).clone()
@@ -429,23 +431,31 @@ class _TransposeCache(object):
 _TRANSPOSES = _TransposeCache()
 
 
+def weight_epoch():
+    """counts the in-place weight updates made through raw pointers (see bump_weight_epoch)"""
+    return _TRANSPOSES.epoch
+
+
 def bump_weight_epoch(device=None):
     """weights were updated in place through raw pointers (the fused SGD kernel): cached derived forms are stale"""
     _TRANSPOSES.bump(device)
 
 
-def conv_weight_transpose(w, scale=None):
+def conv_weight_transpose(w, scale=None, cout_pad=0):
     """[Cout,Cin,KH,KW] -> data-gradient weights [Cin,Cout,KH,KW] (flipped taps, `scale[cout]` folded in).  The result
-    may be a cached buffer shared by later calls with the same weight: treat it as read-only."""
+    may be a cached buffer shared by later calls with the same weight: treat it as read-only.
+    cout_pad > Cout: [Cin,cout_pad,KH,KW] with zero columns behind the weight's own — for an output gradient whose rows
+    are padded to cout_pad channels (the offset branch of a deformable block)."""
     _dev(w, "w")
     Cout, Cin, KH, KW = w.shape
+    cout_pad = cout_pad if cout_pad > Cout else 0
     w = _nhwc(w)
     # cached only for storage that persists across steps — a trainable parameter or a view of one (a temporary's address may
     # be handed to another tensor by the allocator, and the cache is keyed by address)
     base = w._base if w._base is not None else w
     if _TRANSPOSES.enabled and base.is_leaf and base.requires_grad:
-        return _TRANSPOSES.get(w, scale)
-    wt = torch.empty((Cin, Cout, KH, KW), dtype=torch.float32, device=w.device, memory_format=CL)
+        return _TRANSPOSES.get(w, scale, cout_pad)
+    wt = torch.empty((Cin, max(Cout, cout_pad), KH, KW), dtype=torch.float32, device=w.device, memory_format=CL)
     return _transpose_now(w, scale, wt)
 
 
@@ -474,6 +484,13 @@ def conv_wgrad(x, gy, weight_shape, stride=1, pad=0, out_scale=None, dw=None, ac
     x = _nhwc(x)
     gy = _nhwc(gy)
     Ho, Wo = gy.shape[2], gy.shape[3]
+    # rows of gy padded to a multiple of four channels (Cout itself need not be one): dadet_conv_wgrad_partials_ld
+    gy_ld = gy.shape[1]
+    if gy_ld != Cout and pending is None:
+        own = WgradBatch()
+        dw = conv_wgrad(x, gy, weight_shape, stride, pad, out_scale, dw, accumulate, pending=own)
+        conv_wgrad_reduce_batch(own)
+        return dw
     if dw is None:
         dw = torch.empty((Cout, Cin, KH, KW), dtype=torch.float32, device=x.device, memory_format=CL)
         accumulate = False
@@ -486,7 +503,7 @@ def conv_wgrad(x, gy, weight_shape, stride=1, pad=0, out_scale=None, dw=None, ac
         item = _lib.WgradPending()
 
         def launch():
-            _lib.call("dadet_conv_wgrad_partials", ctypes.byref(d), _p(x), _p(gy), _p(out_scale), _p(dw),
+            _lib.call("dadet_conv_wgrad_partials_ld", ctypes.byref(d), _p(x), _p(gy), gy_ld, _p(out_scale), _p(dw),
                       1 if accumulate else 0, _p(ws), ctypes.c_size_t(ws.numel()), ctypes.byref(item), _stream())
 
         if PROFILER is not None:

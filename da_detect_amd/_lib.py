@@ -30,7 +30,7 @@ class WgradPending(ctypes.Structure):
 
 class TransposeItem(ctypes.Structure):
     _fields_ = [("w", c_void_p), ("scale", c_void_p), ("wt", c_void_p), ("Cout", c_int), ("KH", c_int), ("KW", c_int),
-                ("Cin", c_int), ("first_block", c_int), ("blocks_ci", c_int), ("blocks_co", c_int), ("pad", c_int)]
+                ("Cin", c_int), ("first_block", c_int), ("blocks_ci", c_int), ("blocks_co", c_int), ("cout_pad", c_int)]
 
 
 class SgdEntry(ctypes.Structure):
@@ -67,6 +67,9 @@ _SIGNATURES = {
     "dadet_conv_wgrad_partials": [POINTER(ConvDesc), _P, _P, _P, _P, c_int, _P, c_size_t, POINTER(WgradPending), _P],
     "dadet_conv_wgrad_reduce_batch": [POINTER(WgradPending), c_int, _P],
     "dadet_conv_weight_transpose": [_P, _P, _P, c_int, c_int, c_int, c_int, _P],
+    "dadet_conv_weight_transpose_padded": [_P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P],
+    "dadet_conv_wgrad_partials_ld": [POINTER(ConvDesc), _P, _P, c_int, _P, _P, c_int, _P, c_size_t, POINTER(WgradPending),
+                                     _P],
     "dadet_conv_weight_transpose_batch": [_P, c_int, c_int, _P],
     "dadet_deform_sample_forward": [_P, _P, _P, _P] + [c_int] * 12 + [_P],
     "dadet_deform_sample_backward": [_P, _P, _P, _P, _P, _P, _P] + [c_int] * 12 + [_P],

@@ -77,6 +77,7 @@ struct WgradArgs {
   float* out;       // dw (splits == 1) or workspace [splits][Cout][K]
   int N, H, W, Cin, Cout, KH, KW, stride, pad, Ho, Wo;
   int M, K;
+  int gy_ld;        // floats between consecutive rows of gy (>= Cout, a multiple of 4: rows padded to 16 bytes)
   int tiles_co, tiles_kc, splits, rows_per_split;  // rows_per_split is a multiple of 32
   int direct;       // 1: write dw with scale / accumulate applied here
   int accumulate;

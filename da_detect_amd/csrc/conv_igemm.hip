@@ -289,7 +289,7 @@ __global__ __launch_bounds__(256, 3) void conv_wgrad_kernel(const WgradArgs a) {
     for (int i = 0; i < 4; ++i) {
       const int m = m_cur + lrow + 8 * i;
       const bool mv = m < m_end;
-      rg[i] = buf_load4(gr, (mv && covalid) ? (unsigned)m * (unsigned)a.Cout * 4u + co_off : kOOB);
+      rg[i] = buf_load4(gr, (mv && covalid) ? (unsigned)m * (unsigned)a.gy_ld * 4u + co_off : kOOB);
       const int hi = r_ho[i] * a.stride - a.pad + r;
       const int wi = r_wo[i] * a.stride - a.pad + s;
       const bool ok = mv && kvalid && (unsigned)hi < (unsigned)a.H && (unsigned)wi < (unsigned)a.W;
@@ -445,14 +445,16 @@ __global__ __launch_bounds__(256) void wgrad_reduce_batch_kernel(const ReduceBat
 __global__ __launch_bounds__(256) void weight_transpose_kernel(const float* __restrict__ w,
                                                                const float* __restrict__ scale,
                                                                float* __restrict__ wt, int Cout, int KH,
-                                                               int KW, int Cin) {
+                                                               int KW, int Cin, int CoutPad) {
+  // CoutPad >= Cout: the output rows are CoutPad wide, the columns co >= Cout are zeros (a weight whose output channels the
+  // forward pads to a multiple of four — the offset branch of a deformable block)
   __shared__ float tile[32][33];
   const int tap = blockIdx.z;
   const int r = tap / KW, s = tap % KW;
   const int tapT = (KH - 1 - r) * KW + (KW - 1 - s);
   const int ci0 = blockIdx.x * 32, co0 = blockIdx.y * 32;
   const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
-  const int64_t K = (int64_t)KH * KW * Cin, Kt = (int64_t)KH * KW * Cout;
+  const int64_t K = (int64_t)KH * KW * Cin, Kt = (int64_t)KH * KW * CoutPad;
   for (int j = ty; j < 32; j += 8) {
     const int co = co0 + j, ci = ci0 + tx;
     float v = 0.f;
@@ -465,7 +467,7 @@ __global__ __launch_bounds__(256) void weight_transpose_kernel(const float* __re
   __syncthreads();
   for (int j = ty; j < 32; j += 8) {
     const int ci = ci0 + j, co = co0 + tx;
-    if (co < Cout && ci < Cin) wt[(int64_t)ci * Kt + (int64_t)tapT * Cout + co] = tile[tx][j];
+    if (co < CoutPad && ci < Cin) wt[(int64_t)ci * Kt + (int64_t)tapT * CoutPad + co] = tile[tx][j];
   }
 }
 
@@ -478,7 +480,8 @@ struct TransposeItem {
   const float* scale;
   float* wt;
   int Cout, KH, KW, Cin;
-  int first_block, blocks_ci, blocks_co, pad;
+  int first_block, blocks_ci, blocks_co;
+  int cout_pad;     // width of the output rows (>= Cout; 0: Cout), see weight_transpose_kernel
 };
 
 __global__ __launch_bounds__(256) void weight_transpose_batch_kernel(const TransposeItem* __restrict__ items, int n) {
@@ -503,7 +506,8 @@ __global__ __launch_bounds__(256) void weight_transpose_batch_kernel(const Trans
   const int tapT = (it.KH - 1 - r) * it.KW + (it.KW - 1 - sidx);
   const int ci0 = bx * 32, co0 = by * 32;
   const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
-  const int64_t K = (int64_t)it.KH * it.KW * it.Cin, Kt = (int64_t)it.KH * it.KW * it.Cout;
+  const int cout_pad = it.cout_pad > it.Cout ? it.cout_pad : it.Cout;
+  const int64_t K = (int64_t)it.KH * it.KW * it.Cin, Kt = (int64_t)it.KH * it.KW * cout_pad;
   for (int j = ty; j < 32; j += 8) {
     const int co = co0 + j, ci = ci0 + tx;
     float v = 0.f;
@@ -516,7 +520,7 @@ __global__ __launch_bounds__(256) void weight_transpose_batch_kernel(const Trans
   __syncthreads();
   for (int j = ty; j < 32; j += 8) {
     const int ci = ci0 + j, co = co0 + tx;
-    if (co < it.Cout && ci < it.Cin) it.wt[(int64_t)ci * Kt + (int64_t)tapT * it.Cout + co] = tile[tx][j];
+    if (co < cout_pad && ci < it.Cin) it.wt[(int64_t)ci * Kt + (int64_t)tapT * cout_pad + co] = tile[tx][j];
   }
 }
 
@@ -862,7 +866,7 @@ extern "C" int dadet_conv_wgrad_workspace_bytes(const dadet_conv_desc* d, size_t
 
 static int conv_wgrad_impl(const dadet_conv_desc* d, const float* x, const float* gy, const float* out_scale, float* dw,
                            int accumulate, void* workspace, size_t workspace_bytes, dadet_wgrad_pending* pending,
-                           void* stream) {
+                           void* stream, int gy_ld = 0) {
   if (pending) pending->splits = 0;
   int rc = conv_desc_check(d, "conv_wgrad");
   if (rc) return rc;
@@ -874,13 +878,19 @@ static int conv_wgrad_impl(const dadet_conv_desc* d, const float* x, const float
     return check_launch("conv_wgrad(empty)");
   }
   DADET_REQUIRE(x && gy && al16(x) && al16(gy) && al16(dw), "conv_wgrad: pointers must be 16-byte aligned");
-  DADET_REQUIRE(d->Cout % 4 == 0, "conv_wgrad: Cout=%d must be a multiple of 4", d->Cout);
+  // gy_ld: rows of gy padded to a multiple of four channels (the offset branch of a deformable block: 18 / 27 channels in
+  // rows of 20 / 28) — the padding columns are read with the last channel quad and never stored
+  if (gy_ld == 0) gy_ld = d->Cout;
+  DADET_REQUIRE(gy_ld % 4 == 0 && gy_ld >= d->Cout && gy_ld - d->Cout < 4,
+                "conv_wgrad: gy rows of %d floats for Cout=%d (need a multiple of 4, less than 4 above Cout)", gy_ld, d->Cout);
+  DADET_REQUIRE(K % 4 == 0, "conv_wgrad: KH*KW*Cin=%d must be a multiple of 4", K);
   WgradArgs a;
+  a.gy_ld = gy_ld;
   a.x = x; a.gy = gy; a.out_scale = out_scale;
   a.N = d->N; a.H = d->H; a.W = d->W; a.Cin = d->Cin; a.Cout = d->Cout; a.KH = d->KH; a.KW = d->KW;
   a.stride = d->stride; a.pad = d->pad; a.Ho = d->Ho; a.Wo = d->Wo;
   a.M = d->N * d->Ho * d->Wo; a.K = K;
-  const uint64_t xb = (uint64_t)d->N * d->H * d->W * d->Cin * 4, gb = (uint64_t)a.M * d->Cout * 4;
+  const uint64_t xb = (uint64_t)d->N * d->H * d->W * d->Cin * 4, gb = (uint64_t)a.M * gy_ld * 4;
   DADET_REQUIRE(xb < 0xFFFFFFF0ull && gb < 0xFFFFFFF0ull,
                 "conv_wgrad: tensors of 4 GB or more are not addressable through one buffer descriptor");
   a.x_bytes = (unsigned)xb; a.gy_bytes = (unsigned)gb;
@@ -970,6 +980,13 @@ extern "C" int dadet_conv_wgrad_partials(const dadet_conv_desc* d, const float* 
   return conv_wgrad_impl(d, x, gy, out_scale, dw, accumulate, workspace, workspace_bytes, pending_out, stream);
 }
 
+extern "C" int dadet_conv_wgrad_partials_ld(const dadet_conv_desc* d, const float* x, const float* gy, int gy_ld,
+                                            const float* out_scale, float* dw, int accumulate, void* workspace,
+                                            size_t workspace_bytes, dadet_wgrad_pending* pending_out, void* stream) {
+  DADET_REQUIRE(pending_out, "conv_wgrad_partials_ld: null pending_out");
+  return conv_wgrad_impl(d, x, gy, out_scale, dw, accumulate, workspace, workspace_bytes, pending_out, stream, gy_ld);
+}
+
 extern "C" int dadet_conv_wgrad_reduce_batch(const dadet_wgrad_pending* items, int n, void* stream) {
   DADET_REQUIRE(n >= 0 && (n == 0 || items), "conv_wgrad_reduce_batch: bad arguments");
   hipStream_t st = as_stream(stream);
@@ -1003,13 +1020,24 @@ extern "C" int dadet_conv_wgrad_reduce_batch(const dadet_wgrad_pending* items, i
   return DADET_OK;
 }
 
-extern "C" int dadet_conv_weight_transpose(const float* w, const float* scale, float* wt, int Cout, int KH,
-                                           int KW, int Cin, void* stream) {
+static int weight_transpose_impl(const float* w, const float* scale, float* wt, int Cout, int KH, int KW, int Cin,
+                                 int cout_pad, void* stream) {
   DADET_REQUIRE(w && wt && Cout > 0 && KH > 0 && KW > 0 && Cin > 0, "conv_weight_transpose: bad args");
   DADET_REQUIRE(KH * KW <= 65535, "conv_weight_transpose: kernel too large");
-  hipLaunchKernelGGL(weight_transpose_kernel, dim3(ceil_div(Cin, 32), ceil_div(Cout, 32), KH * KW),
-                     dim3(256), 0, as_stream(stream), w, scale, wt, Cout, KH, KW, Cin);
+  DADET_REQUIRE(cout_pad >= Cout, "conv_weight_transpose: cout_pad=%d < Cout=%d", cout_pad, Cout);
+  hipLaunchKernelGGL(weight_transpose_kernel, dim3(ceil_div(Cin, 32), ceil_div(cout_pad, 32), KH * KW),
+                     dim3(256), 0, as_stream(stream), w, scale, wt, Cout, KH, KW, Cin, cout_pad);
   return check_launch("conv_weight_transpose");
+}
+
+extern "C" int dadet_conv_weight_transpose(const float* w, const float* scale, float* wt, int Cout, int KH,
+                                           int KW, int Cin, void* stream) {
+  return weight_transpose_impl(w, scale, wt, Cout, KH, KW, Cin, Cout, stream);
+}
+
+extern "C" int dadet_conv_weight_transpose_padded(const float* w, const float* scale, float* wt, int Cout, int KH,
+                                                  int KW, int Cin, int cout_pad, void* stream) {
+  return weight_transpose_impl(w, scale, wt, Cout, KH, KW, Cin, cout_pad, stream);
 }
 
 extern "C" int dadet_conv_weight_transpose_batch(const dadet_transpose_item* items_dev, int n, int total_blocks,

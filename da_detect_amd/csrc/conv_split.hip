@@ -1078,7 +1078,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_split_kernel(const WgradArg
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const int m = m_cur + mg * 4 + j;
-      rg[j] = buf_load4(gr, (m < m_end && covalid) ? (unsigned)m * (unsigned)a.Cout * 4u + co_off : kOOB);
+      rg[j] = buf_load4(gr, (m < m_end && covalid) ? (unsigned)m * (unsigned)a.gy_ld * 4u + co_off : kOOB);
     }
   };
   auto load_x = [&]() {   // also advances to the next 32-row step

@@ -140,15 +140,15 @@ class _DCNBottleneckFn(torch.autograd.Function):
         y2 = _C.conv_forward(cols, _as_1x1(w2), s2, b2, relu_mode=1)
         idn = x if wd is None else _C.conv_forward(x, wd, sd, bd, stride=stride)
         out = _C.conv_forward(y2, w3, s3, b3, addend=idn, relu_mode=1)
-        ctx.conf = (stride, in_relu, out_private, modulated, dg, kh, kw, w_off.shape[0])
-        ctx.save_for_backward(x, y1, om, cols, y2, out, w1, w2, w3, wd, wo4, s1, s2, s3, sd)
+        ctx.conf = (stride, in_relu, out_private, modulated, dg, kh, kw, w_off.shape[0], wo4.shape[0])
+        ctx.save_for_backward(x, y1, om, cols, y2, out, w1, w2, w3, wd, w_off, s1, s2, s3, sd)
         return out
 
     @staticmethod
     @torch.autograd.function.once_differentiable
     def backward(ctx, G):
-        x, y1, om, cols, y2, out, w1, w2, w3, wd, wo4, s1, s2, s3, sd = ctx.saved_tensors
-        stride, in_relu, out_private, modulated, dg, kh, kw, n_offch = ctx.conf
+        x, y1, om, cols, y2, out, w1, w2, w3, wd, w_off, s1, s2, s3, sd = ctx.saved_tensors
+        stride, in_relu, out_private, modulated, dg, kh, kw, n_offch, n_offpad = ctx.conf
         need_x, n1, n2, n3, nd, n_off, n_boff = ctx.needs_input_grad[:7]
         cout2, cin2 = w2.shape[0], w2.shape[1]
         S3 = G.contiguous(memory_format=torch.channels_last) if out_private else _C.relu_bn_backward(G, out, None)[1]
@@ -172,15 +172,23 @@ class _DCNBottleneckFn(torch.autograd.Function):
             dw2 = wgrad(w2, cols, S2, 1, 0, s2, shape=(cout2, kh * kw * cin2, 1, 1))
         gcols = _C.conv_forward(S2, _C.conv_weight_transpose(w2_1x1, s2))
         gy1, gom = _C.deform_sample_backward_om(y1, om, gcols, kh, kw, 1, kh // 2, 1, dg, modulated)
-        if n_off:    # on the block's weight-gradient stream; its result goes back to autograd: reduced at once
+        if n_off and _OFFSET_LEGACY:
+            wo4 = _pad_out_channels(w_off, None)[0]
             own = _C.WgradBatch()
             dwo = lane.run(lambda: _C.conv_wgrad(y1, gom, tuple(wo4.shape), 1, kh // 2, pending=own), y1, gom)
             lane.reduce_batch(own, now=True)
+            dwo = dwo[:n_offch]
+        elif n_off:
+            # gom's rows are padded to a multiple of four channels; the weight gradient keeps the parameter's own shape
+            # (conv_wgrad reads the padded rows, dadet_conv_wgrad_partials_ld) and lands in its gradient buffer like every
+            # other weight of the block
+            dwo = wgrad(w_off, y1, gom, 1, kh // 2, None)
         if n_boff:
             dbo = _C.colsum(gom)[:n_offch]
-        # d y1 = [y1 > 0] * (sampled path + offset-conv path)
-        S1 = _C.conv_forward(gom, _C.conv_weight_transpose(wo4), pad=kh // 2, addend=gy1, out=gy1, relu_mode=2,
-                             mask_ref=y1)
+        # d y1 = [y1 > 0] * (sampled path + offset-conv path); the transposed weights carry zero columns for the padding
+        wt_off = (_C.conv_weight_transpose(_pad_out_channels(w_off, None)[0]) if _OFFSET_LEGACY
+                  else _C.conv_weight_transpose(w_off, cout_pad=n_offpad))
+        S1 = _C.conv_forward(gom, wt_off, pad=kh // 2, addend=gy1, out=gy1, relu_mode=2, mask_ref=y1)
         if n1:
             dw1 = wgrad(w1, x, S1, stride, 0, s1)
         if nd and wd is not None:
@@ -199,8 +207,6 @@ class _DCNBottleneckFn(torch.autograd.Function):
                 dx = _C.conv_forward(S1, _C.conv_weight_transpose(w1, s1), addend=t, out=t,
                                      out_spatial_stride=stride, out_hw=hw, **gate)
         lane.join()
-        if dwo is not None:
-            dwo = dwo[:n_offch]
         if dw2 is not None:     # returned to autograd (no persistent gradient buffer): back in w2's logical shape
             dw2 = torch.as_strided(dw2, (cout2, cin2, kh, kw), (kh * kw * cin2, 1, kw * cin2, cin2))
         return (dx, dw1, dw2, dw3, dwd, dwo, dbo) + (None,) * 13
@@ -212,11 +218,74 @@ def _as_1x1(weight):
     return weight.contiguous(memory_format=torch.channels_last).permute(0, 2, 3, 1).reshape(cout, kh * kw * cin, 1, 1)
 
 
+class _PaddedWeights(object):
+    """weights / biases with zero output channels appended up to a multiple of 4 (16-byte rows for the kernels that
+    contract over them), kept in persistent buffers.  Padding on the spot cost 5 launches per deformable block and forward
+    pass (two F.pad = fill + copy each, one layout copy): 150 launches of ~6 us per step of R-101-FPN-DCN.  Here every
+    registered parameter is refreshed by ONE multi-tensor copy, the first time one of them is asked for after the weights
+    changed (autograd version of the parameter, or the weight epoch that the fused optimizer bumps)."""
+
+    def __init__(self):
+        self.entries = {}          # id(weight) -> dict(ref, wp, bp, bias_ref)
+        self.stamp = None
+
+    def _stamp(self):
+        ws = [e["w"]() for e in self.entries.values()]
+        bs = [e["b"]() for e in self.entries.values() if e["b"] is not None]
+        if any(t is None for t in ws) or any(t is None for t in bs):
+            return None                                    # a parameter is gone: rebuild
+        return (_C.weight_epoch(), tuple(t._version for t in ws), tuple(t._version for t in bs))
+
+    def _fresh(self):
+        stamp = self._stamp()
+        if stamp is not None and stamp == self.stamp:
+            return
+        for k in [k for k, e in self.entries.items() if e["w"]() is None or (e["b"] is not None and e["b"]() is None)]:
+            del self.entries[k]
+        dst, src = [], []
+        for e in self.entries.values():
+            w = e["w"]()
+            dst.append(e["wp"][:w.shape[0]])
+            src.append(w.detach())
+            if e["b"] is not None:
+                dst.append(e["bp"][:w.shape[0]])
+                src.append(e["b"]().detach())
+        if dst:
+            torch._foreach_copy_(dst, src)
+        self.stamp = self._stamp()
+
+    def get(self, weight, bias, pad):
+        import weakref
+
+        e = self.entries.get(id(weight))
+        if e is None or e["w"]() is not weight or (bias is not None) != (e["b"] is not None) \
+                or (bias is not None and e["b"]() is not bias):
+            cout, cin, kh, kw = weight.shape
+            wp = torch.zeros((cout + pad, cin, kh, kw), dtype=weight.dtype, device=weight.device).contiguous(
+                memory_format=torch.channels_last)
+            bp = torch.zeros(cout + pad, dtype=bias.dtype, device=bias.device) if bias is not None else None
+            self.entries[id(weight)] = dict(w=weakref.ref(weight), b=weakref.ref(bias) if bias is not None else None,
+                                            wp=wp, bp=bp)
+            self.stamp = None
+        self._fresh()
+        e = self.entries[id(weight)]
+        return e["wp"], e["bp"]
+
+
+_PADDED = _PaddedWeights()
+# DADET_DCN_OFFSET_LEGACY=1: the offset branch as in the first fused version (weights padded on the spot, their gradient
+# computed on the padded shape, reduced at once, sliced and handed to autograd) — for A/B measurements
+_OFFSET_LEGACY = __import__("os").environ.get("DADET_DCN_OFFSET_LEGACY", "0") == "1"
+
+
 def _pad_out_channels(weight, bias):
     """zero output channels appended up to a multiple of 4 (16-byte rows for the kernels that contract over them)"""
     pad = (-weight.shape[0]) % 4
     if pad == 0:
         return weight, bias
+    if (not _OFFSET_LEGACY and weight.is_cuda and weight.is_leaf and weight.requires_grad
+            and (bias is None or bias.is_leaf)):
+        return _PADDED.get(weight, bias, pad)
     w = F.pad(weight, (0, 0, 0, 0, 0, 0, 0, pad)).contiguous(memory_format=torch.channels_last)
     return w, (F.pad(bias, (0, pad)) if bias is not None else None)
 

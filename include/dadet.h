@@ -179,11 +179,22 @@ int dadet_conv_wgrad_partials(const dadet_conv_desc* d, const float* x, const fl
                               float* dw, int accumulate, void* workspace, size_t workspace_bytes,
                               dadet_wgrad_pending* pending_out, void* stream);
 int dadet_conv_wgrad_reduce_batch(const dadet_wgrad_pending* items, int n, void* stream);
+/* gy with rows of gy_ld floats, gy_ld = Cout rounded up to a multiple of 4 (Cout itself need not be one): the weight
+ * gradient of a convolution whose output rows the forward pads to 16 bytes — the offset / modulation branch of a
+ * deformable block (18 | 27 channels in rows of 20 | 28; reference: layers/misc.py:139-151 `self.offset`).  dw keeps its
+ * own [Cout][KH][KW][Cin] shape, so the gradient can be accumulated straight into the parameter's buffer. */
+int dadet_conv_wgrad_partials_ld(const dadet_conv_desc* d, const float* x, const float* gy, int gy_ld,
+                                 const float* out_scale, float* dw, int accumulate, void* workspace,
+                                 size_t workspace_bytes, dadet_wgrad_pending* pending_out, void* stream);
 
 /* weight re-layout for the data gradient: wt[ci][KH-1-r][KW-1-s][co] = w[co][r][s][ci] * scale[co].
  * dgrad of a stride-1 conv is then dadet_conv_forward(gy, wt) with pad' = K-1-pad. */
 int dadet_conv_weight_transpose(const float* w, const float* scale, float* wt, int Cout, int KH, int KW,
                                 int Cin, void* stream);
+/* the same into rows of cout_pad >= Cout columns, the columns co >= Cout zero: wt[ci][tap][cout_pad] — the data-gradient
+ * weights for an output gradient whose rows are padded (see dadet_conv_wgrad_partials_ld) */
+int dadet_conv_weight_transpose_padded(const float* w, const float* scale, float* wt, int Cout, int KH, int KW,
+                                       int Cin, int cout_pad, void* stream);
 
 /* The same for many weights in ONE launch.  items_dev: device-resident table; item k serves blocks [first_block,
  * first_block + blocks_ci * blocks_co * KH * KW) of the grid, blocks_ci = ceil(Cin / 32), blocks_co = ceil(Cout / 32);
@@ -193,7 +204,8 @@ typedef struct dadet_transpose_item {
   const float* scale;
   float* wt;
   int Cout, KH, KW, Cin;
-  int first_block, blocks_ci, blocks_co, pad;
+  int first_block, blocks_ci, blocks_co;
+  int cout_pad;            /* width of the output rows, >= Cout (0: Cout); blocks_co = ceil(max(Cout, cout_pad) / 32) */
 } dadet_transpose_item;
 int dadet_conv_weight_transpose_batch(const dadet_transpose_item* items_dev, int n, int total_blocks, void* stream);
 
