@@ -69,12 +69,26 @@ __device__ inline float wave_sum_f(float v) {
   return v;
 }
 
-// one workgroup per output pixel m = (n, ho, wo); loop over taps; lanes over channels
+// XCD-aware work order, MEASURED and left out (round 3, R-101-FPN-DCN shapes): workgroups are dealt to the 8 XCDs round-robin
+// and each XCD has its own L2, so contiguous eighths of the pixels per XCD, and bands of 4 / 8 / 16 image rows dealt
+// round-robin, were tried on all three kernels.  With one 64-thread workgroup per pixel the forward went 67 -> 39 us
+// (64x128 map) — but so it did in plain order once a workgroup took 256 / (C/4) pixels (41 us): the kernel had been bound
+// by the workgroup dispatch rate, not by L2 misses.  On the fat workgroups the order changes nothing (forward 41.1 / 41.6,
+// pass A 85 / 86, pass B 51 / 51 us), and contiguous eighths made the 128x256 map 50% slower in pass A.
+// a group of C/4 threads per output pixel m = (n, ho, wo), 256 / (C/4) pixels per workgroup (one when C >= 1024 or C/4 does
+// not divide 256); loop over taps; lanes over channels.  One 64-thread workgroup per pixel (C = 128: 65 536 of them, half
+// their lanes idle) was bound by the workgroup dispatch rate: 137 us for 302 MB.
 __global__ __launch_bounds__(256) void deform_sample_fwd_kernel(const float* __restrict__ x,
                                                                 const float* __restrict__ offset,
                                                                 const float* __restrict__ mask,
                                                                 float* __restrict__ cols, DeformGeom g) {
-  const int m = blockIdx.x;
+  const int lanes = g.C / 4;
+  const bool shared = lanes < (int)blockDim.x && (int)blockDim.x % lanes == 0;    // several pixels per workgroup
+  const int ppb = shared ? (int)blockDim.x / lanes : 1;
+  const int t = shared ? (int)threadIdx.x % lanes : (int)threadIdx.x;
+  const int tstep = shared ? lanes : (int)blockDim.x;
+  const int m = (int)blockIdx.x * ppb + (shared ? (int)threadIdx.x / lanes : 0);
+  if (m >= g.N * g.Ho * g.Wo) return;
   const int wo = m % g.Wo;
   const int ho = (m / g.Wo) % g.Ho;
   const int n = m / (g.Wo * g.Ho);
@@ -86,7 +100,7 @@ __global__ __launch_bounds__(256) void deform_sample_fwd_kernel(const float* __r
   float* __restrict__ col_m = cols + (size_t)m * T * g.C;
   for (int tap = 0; tap < T; ++tap) {
     const int i = tap / g.KW, j = tap - i * g.KW;
-    for (int c = threadIdx.x * 4; c < g.C; c += blockDim.x * 4) {
+    for (int c = t * 4; c < g.C; c += tstep * 4) {
       const int grp = c / cpg;
       const float oh = off_m[grp * 2 * T + 2 * tap], ow = off_m[grp * 2 * T + 2 * tap + 1];
       const float mk = msk_m ? modulation(msk_m, grp * T + tap, g.mask_sigmoid) : 1.f;
@@ -370,7 +384,11 @@ __global__ __launch_bounds__(256) void deform_sample_bwd_coord_kernel(const floa
         cw[u][0] = hh * hw; cw[u][1] = hh * k[u].lw; cw[u][2] = k[u].lh * hw; cw[u][3] = k[u].lh * k[u].lw;
         b1o[u] = (unsigned)(((size_t)k[u].hl * g.W + k[u].wl) * g.C) * 4u;
         full[u] = 0;
-        if (gimg && l16 == 0) {        // one lane per pixel appends the sample's corners to their cells' lists
+        // one lane per pixel appends the sample's corners to their cells' lists.  (MEASURED: the 12 (tap, corner) pairs of a
+        // step appended from 12 different lanes at once — one atomic round trip per step instead of 12 — made the kernel
+        // SLOWER, 86 -> 117 us on the 64x128 map: the appends of neighbouring pixels hit the same counters, and it is that
+        // contention, not the latency of one lane's chain, that the kernel waits for.)
+        if (gimg && l16 == 0) {
           const bool cin[4] = {k[u].in1, k[u].in2, k[u].in3, k[u].in4};
 #pragma unroll
           for (int q = 0; q < 4; ++q) {
@@ -518,14 +536,17 @@ static bool al16d(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) 
 
 static int deform_sample_forward_impl(const float* x, const float* offset, const float* mask, float* cols, DeformGeom g,
                                       void* stream) {
+  const int lanes = g.C / 4;
+  const int threads = (lanes < 256 && 256 % lanes == 0) ? 256 : ((lanes >= 256) ? 256 : ((lanes + 63) / 64) * 64);
+  const int ppb = (lanes < threads && threads % lanes == 0) ? threads / lanes : 1;      // output pixels per workgroup
   int rc = deform_check("deform_sample_forward", g.N, g.H, g.W, g.C, g.KH, g.KW, g.stride, g.pad, g.dil, g.dg, g.Ho, g.Wo);
   if (rc) return rc;
   if (g.N == 0) return DADET_OK;
   DADET_REQUIRE(x && offset && cols && al16d(x) && al16d(cols), "deform_sample_forward: bad pointers");
   const int T = g.KH * g.KW;
   DADET_REQUIRE(g.off_ld >= g.dg * 2 * T && (!mask || g.mask_ld >= g.dg * T), "deform_sample_forward: row stride too small");
-  const int threads = (g.C / 4 >= 256) ? 256 : ((g.C / 4 + 63) / 64) * 64;
-  hipLaunchKernelGGL(deform_sample_fwd_kernel, dim3((unsigned)(g.N * g.Ho * g.Wo)), dim3(threads), 0,
+  hipLaunchKernelGGL(deform_sample_fwd_kernel, dim3((unsigned)ceil_div64((int64_t)g.N * g.Ho * g.Wo, ppb)),
+                     dim3(threads), 0,
                      as_stream(stream), x, offset, mask, cols, g);
   return check_launch("deform_sample_forward");
 }
