@@ -1,0 +1,29 @@
+#!/bin/bash
+# The profile set of a round, on the GPU box (one gpurun call): kernel stats of the four bench workloads, HBM counters
+# of the three R-50-C4 ones, step timeline + idle gaps, per-shape GEMM table with the GEMM-free stretches, and the default
+# bench line.  Everything lands under gpurun_out/<tag>_*; copy what is to be judged into profiles/.
+# usage: tools/profile_round.sh <tag>
+set -u
+TAG=${1:-r03}
+R=${GRAFT_REPO_ROOT:-/root/repo}
+cd $R
+for wl in img_only da triplet fpn_dcn_da; do
+  echo "=== kernel stats: $wl"
+  bash tools/profile_bench.sh ${TAG}_stats_$wl --workload $wl --others none --steps 12 --warmup 6 > gpurun_out/${TAG}_stats_$wl.log 2>&1
+  grep '^{"metric"' gpurun_out/${TAG}_stats_$wl/bench.log | tail -1 | cut -c1-200
+done
+for wl in img_only da triplet; do
+  echo "=== PMC: $wl"
+  bash tools/profile_pmc.sh ${TAG}_pmc_$wl --workload $wl --others none --steps 6 --warmup 3 > gpurun_out/${TAG}_pmc_$wl.log 2>&1
+  python tools/pmc_combine.py gpurun_out/${TAG}_pmc_$wl/FETCH_SIZE.csv gpurun_out/${TAG}_pmc_$wl/WRITE_SIZE.csv \
+      gpurun_out/${TAG}_pmc_$wl/hbm_traffic.json "bench.py --workload $wl --others none --steps 6 --warmup 3 (two rocprofv3 --pmc passes)"
+  ls -la gpurun_out/${TAG}_pmc_$wl | tail -4
+done
+for wl in img_only da; do
+  echo "=== timeline: $wl"
+  bash tools/profile_gaps.sh ${TAG}_gaps_$wl --workload $wl --steps 12 --warmup 6 --others none 2>&1 | tail -3
+done
+echo "=== GEMM table"
+python tools/gemm_table.py --workload img_only --steps 3 --top 60 --holes > gpurun_out/${TAG}_gemm_table_img_only.txt 2>&1; tail -3 gpurun_out/${TAG}_gemm_table_img_only.txt
+echo "=== default bench"
+python bench.py > gpurun_out/${TAG}_bench_default.json 2> gpurun_out/${TAG}_bench_default.err; tail -1 gpurun_out/${TAG}_bench_default.json | cut -c1-300
