@@ -173,7 +173,7 @@ def _check_indices(rec, inter):
 
 def _check_gradients(grads, want, rounding_tol=5e-5, flip_tol=4e-3, flipped_share=0.1):
     """GPU parameter gradients against the oracle evaluated in FLOAT64.  Measured on these cases
-    (tools/scratch/grad_noise_table.py, profiles/r02_grad_noise_floor.txt): against the fp64 oracle the HIP path is at
+    (tools/probes/grad_noise_table.py, profiles/r02_grad_noise_floor.txt): against the fp64 oracle the HIP path is at
     1e-5 relative L2 on every tensor (the fp32 CPU oracle itself is at 1e-4 .. 1e-3 against fp64), except where a ReLU
     whose pre-activation is within rounding of zero fires on one side and not on the other: ONE flipped unit in a
     24 x 40 map moves that layer's (and the layer below's) weight gradient by ~1e-3 of its norm.  So: every tensor

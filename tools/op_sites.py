@@ -1,7 +1,7 @@
 """which python call sites launch the small ATen kernels of one training step (torch.profiler, CPU-side op records with
 stacks; usage: op_sites.py [workload=fpn_dcn_da])"""
 import os, sys, collections
-ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 wl = sys.argv[1] if len(sys.argv) > 1 else "fpn_dcn_da"
 sys.argv = [sys.argv[0]]
