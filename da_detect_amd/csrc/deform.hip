@@ -30,6 +30,7 @@ struct DeformGeom {
   // no concatenation (DFConv2d, layers/misc.py:187-188 of the vendored tree slices [:, :18] and [:, -9:])
   int off_ld, mask_ld, goff_ld, gmask_ld;
   int mask_sigmoid;   // the mask tensor holds LOGITS: modulation = sigmoid(logit), gmask is the gradient w.r.t. the logit
+  int ablate;         // experiments only (DADET_DEFORM_ABLATE): 1 = pass A without the list appends, 2 = without the channel loop
 };
 
 __device__ inline float modulation(const float* __restrict__ msk_m, int idx, int sig) {
@@ -327,6 +328,11 @@ __global__ __launch_bounds__(256) void deform_sample_bwd_lds_kernel(const float*
 // Lists hold kListCap entries per (cell, deformable group) (a regular 3x3 sampling pattern puts 36 on a cell); a corner
 // that finds its list full is added to gx directly with float atomics by pass A (gx is zero-filled by the caller).  The
 // order of a list — hence the last bits of gx — depends on the arrival order of the appends.
+// Where pass A's time goes (DADET_DEFORM_ABLATE, `tools/probes/deform_prof.sh`, 64x128x256 / 128x256x128 / 32x64x512 maps):
+// whole 84 / 298 / 50 us; without the list appends 60 / 162 / 36; appends alone 52 / 195 / 25 — the 36 counter atomics per
+// pixel cost about as much as the 151 / 302 / 75 MB of gcols + 4 corner rows the channel loop reads.  One entry per
+// (pixel, tap) in the list of the sample's top-left cell, the four corner weights rebuilt by the gathering side from
+// (lh, lw), would need a quarter of the atomics: not built.
 constexpr int kListCap = 96;
 
 struct ListEntry {
@@ -388,7 +394,7 @@ __global__ __launch_bounds__(256) void deform_sample_bwd_coord_kernel(const floa
         // step appended from 12 different lanes at once — one atomic round trip per step instead of 12 — made the kernel
         // SLOWER, 86 -> 117 us on the 64x128 map: the appends of neighbouring pixels hit the same counters, and it is that
         // contention, not the latency of one lane's chain, that the kernel waits for.)
-        if (gimg && l16 == 0) {
+        if (gimg && l16 == 0 && g.ablate != 1) {
           const bool cin[4] = {k[u].in1, k[u].in2, k[u].in3, k[u].in4};
 #pragma unroll
           for (int q = 0; q < 4; ++q) {
@@ -409,7 +415,7 @@ __global__ __launch_bounds__(256) void deform_sample_bwd_coord_kernel(const floa
         full[u] = __shfl(full[u], lane & 48, 64);
       }
       float d_h[3] = {0.f, 0.f, 0.f}, d_w[3] = {0.f, 0.f, 0.f}, d_m[3] = {0.f, 0.f, 0.f};
-      for (int c = grp * cpg + l16 * 4; c < (grp + 1) * cpg; c += kDChunk) {
+      for (int c = grp * cpg + l16 * 4; c < (g.ablate == 2 ? 0 : (grp + 1) * cpg); c += kDChunk) {
         float4 gv[3], a1[3], a2[3], a3[3], a4[3];
         const unsigned rowb = (unsigned)(g.W * g.C) * 4u, pixb = (unsigned)g.C * 4u, cb = (unsigned)c * 4u;
 #pragma unroll
@@ -570,6 +576,8 @@ extern "C" int dadet_deform_sample_forward_ld(const float* x, const float* offse
 static int deform_sample_backward_impl(const float* x, const float* offset, const float* mask, const float* gcols,
                                        float* gx, float* goffset, float* gmask, DeformGeom g, void* workspace,
                                        size_t workspace_bytes, void* stream) {
+  static const int ablate = getenv("DADET_DEFORM_ABLATE") ? atoi(getenv("DADET_DEFORM_ABLATE")) : 0;
+  g.ablate = ablate;
   int rc = deform_check("deform_sample_backward", g.N, g.H, g.W, g.C, g.KH, g.KW, g.stride, g.pad, g.dil, g.dg, g.Ho, g.Wo);
   if (rc) return rc;
   if (g.N == 0) return DADET_OK;
