@@ -318,27 +318,33 @@ __global__ __launch_bounds__(256) void deform_sample_bwd_lds_kernel(const float*
 //    channels each) and walks groups -> taps (three per step, their 15 sixteen-byte buffer loads in flight together) ->
 //    64-channel chunks: the gradients w.r.t. offsets / modulation are reductions over ALL channels of a (pixel, tap, group)
 //    sample, finished by one 4-step reduction over the 16 lanes and written with a plain store (one writer per address: no
-//    atomics, no zero fill, deterministic).  For each of the sample's <= 4 bilinear corners it also appends one 8-byte
-//    entry {sample index, weight * modulation} to the list of the input cell the corner lands on — an INTEGER atomic per
-//    (sample, corner), 36 per output pixel instead of 36 float atomics per output pixel AND CHANNEL.
-//  pass B (deform_gx_gather_kernel), cell-centric: a quarter-wavefront per (input cell, 64-channel chunk) walks the cell's
-//    list — eight entries per round, their gcols rows loaded together — and accumulates weight * gcols in registers, then
-//    adds the sum to gx with one plain 16-byte read-modify-write (it owns the address).  Offsets of any size are handled
-//    alike; gcols is read ~4 times (once per corner), rows of C * 4 bytes.
-// Lists hold kListCap entries per (cell, deformable group) (a regular 3x3 sampling pattern puts 36 on a cell); a corner
-// that finds its list full is added to gx directly with float atomics by pass A (gx is zero-filled by the caller).  The
-// order of a list — hence the last bits of gx — depends on the arrival order of the appends.
-// Where pass A's time goes (DADET_DEFORM_ABLATE, `tools/probes/deform_prof.sh`, 64x128x256 / 128x256x128 / 32x64x512 maps):
-// whole 84 / 298 / 50 us; without the list appends 60 / 162 / 36; appends alone 52 / 195 / 25 — the 36 counter atomics per
-// pixel cost about as much as the 151 / 302 / 75 MB of gcols + 4 corner rows the channel loop reads.  One entry per
-// (pixel, tap) in the list of the sample's top-left cell, the four corner weights rebuilt by the gathering side from
-// (lh, lw), would need a quarter of the atomics: not built.
-constexpr int kListCap = 96;
+//    atomics, no zero fill, deterministic).  It also appends the sample to the list of the position its bilinear footprint
+//    starts at — an INTEGER atomic per sample, 9 per output pixel instead of 36 float atomics per output pixel AND CHANNEL.
+//  pass B (deform_gx_gather_kernel), cell-centric: a quarter-wavefront per (input cell, 64-channel chunk) walks the four
+//    lists that cover the cell — eight entries per round, their gcols rows loaded together — and accumulates weight * gcols
+//    in registers, then adds the sum to gx with one plain 16-byte read-modify-write (it owns the address).  Offsets of any
+//    size are handled alike; gcols is read ~4 times (once per corner), rows of C * 4 bytes.
+// A list belongs to a TOP-LEFT position (hl, wl) in [-1, H-1] x [-1, W-1] and a deformable group, and holds one 16-byte entry
+// {sample, lh, lw, modulation} per (pixel, tap) whose bilinear footprint starts there: ONE integer atomic per sample (9 per
+// output pixel) — the first version of this scheme kept one list per CELL with an entry per corner, 36 atomics per pixel, and
+// the stage ablation (DADET_DEFORM_ABLATE, `tools/probes/deform_prof.sh`; 64x128x256 / 128x256x128 / 32x64x512 maps) showed
+// them to cost as much as the whole channel loop: pass A 84 / 298 / 50 us, without the appends 60 / 162 / 36, appends alone
+// 52 / 195 / 25.  A cell gathers from the four lists whose footprint covers it — top-left positions (y, x), (y, x-1), (y-1, x),
+// (y-1, x-1), as corner 0 .. 3 — and rebuilds its corner weight from (lh, lw) with the forward's own expression.
+// Lists hold kListCap entries (a regular 3x3 pattern puts 9 on a position); a sample that finds its list full is added to gx
+// directly with float atomics by pass A (gx is zero-filled by the caller).  The order of a list — hence the last bits of gx
+// — depends on the arrival order of the appends.
+constexpr int kListCap = 32;
 
 struct ListEntry {
   unsigned sample;   // (m * T + tap): row of gcols
-  float weight;      // bilinear weight x modulation
+  float lh, lw;      // fractional parts of the sampling position
+  float mk;          // modulation
 };
+
+__device__ inline size_t tl_list(const DeformGeom& g, int n, int hl, int wl, int grp) {
+  return (((size_t)n * (g.H + 1) + (hl + 1)) * (g.W + 1) + (wl + 1)) * g.dg + grp;
+}
 
 __global__ __launch_bounds__(256) void deform_sample_bwd_coord_kernel(const float* __restrict__ x,
                                                                       const float* __restrict__ offset,
@@ -390,26 +396,22 @@ __global__ __launch_bounds__(256) void deform_sample_bwd_coord_kernel(const floa
         cw[u][0] = hh * hw; cw[u][1] = hh * k[u].lw; cw[u][2] = k[u].lh * hw; cw[u][3] = k[u].lh * k[u].lw;
         b1o[u] = (unsigned)(((size_t)k[u].hl * g.W + k[u].wl) * g.C) * 4u;
         full[u] = 0;
-        // one lane per pixel appends the sample's corners to their cells' lists.  (MEASURED: the 12 (tap, corner) pairs of a
-        // step appended from 12 different lanes at once — one atomic round trip per step instead of 12 — made the kernel
-        // SLOWER, 86 -> 117 us on the 64x128 map: the appends of neighbouring pixels hit the same counters, and it is that
-        // contention, not the latency of one lane's chain, that the kernel waits for.)
-        if (gimg && l16 == 0 && g.ablate != 1) {
-          const bool cin[4] = {k[u].in1, k[u].in2, k[u].in3, k[u].in4};
-#pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            if (!cin[q]) continue;
-            const size_t cell = ((size_t)n * g.H + (k[u].hl + (q >> 1))) * g.W + (k[u].wl + (q & 1));
-            const size_t list = cell * g.dg + grp;
-            const int slot = atomicAdd(counts + list, 1);
-            if (slot < kListCap) {
-              ListEntry en;
-              en.sample = (unsigned)(m * T + tt);
-              en.weight = cw[u][q] * mk[u];
-              entries[list * kListCap + slot] = en;
-            } else {
-              full[u] |= 1u << q;
-            }
+        // one lane per pixel appends the sample to the list of its top-left position.  (MEASURED on the per-corner lists:
+        // the 12 (tap, corner) pairs of a step appended from 12 different lanes at once — one atomic round trip per step
+        // instead of 12 — made the kernel SLOWER, 86 -> 117 us on the 64x128 map: neighbouring pixels hit the same
+        // counters, and it is that contention, not the latency of one lane's chain, that the kernel waits for.)
+        if (gimg && l16 == 0 && g.ablate != 1 && k[u].valid) {
+          const size_t list = tl_list(g, n, k[u].hl, k[u].wl, grp);
+          const int slot = atomicAdd(counts + list, 1);
+          if (slot < kListCap) {
+            ListEntry en;
+            en.sample = (unsigned)(m * T + tt);
+            en.lh = k[u].lh;
+            en.lw = k[u].lw;
+            en.mk = mk[u];
+            entries[list * kListCap + slot] = en;
+          } else {          // list full: the corners inside the map go to gx directly (all lanes of the pixel, below)
+            full[u] = (k[u].in1 ? 1u : 0u) | (k[u].in2 ? 2u : 0u) | (k[u].in3 ? 4u : 0u) | (k[u].in4 ? 8u : 0u);
           }
         }
         full[u] = __shfl(full[u], lane & 48, 64);
@@ -477,7 +479,8 @@ __global__ __launch_bounds__(256) void deform_sample_bwd_coord_kernel(const floa
   }
 }
 
-// pass B: gx[cell][ch] += sum over the cell's list of weight * gcols[sample][ch]; a quarter-wavefront per (cell, chunk)
+// pass B: gx[cell][ch] += sum over the four lists covering the cell of weight * gcols[sample][ch]; a quarter-wavefront per
+// (cell, chunk)
 __global__ __launch_bounds__(256) void deform_gx_gather_kernel(const float* __restrict__ gcols, float* __restrict__ gx,
                                                                const int* __restrict__ counts,
                                                                const ListEntry* __restrict__ entries, DeformGeom g) {
@@ -490,31 +493,62 @@ __global__ __launch_bounds__(256) void deform_gx_gather_kernel(const float* __re
   const int64_t cell = quarter / chunks;
   if (cell >= cells) return;
   const int c = chunk * kDChunk + l16 * 4;
-  const size_t list = (size_t)cell * g.dg + c / cpg;
+  const int grp = c / cpg;
+  const int x = (int)(cell % g.W), y = (int)((cell / g.W) % g.H), n = (int)(cell / ((int64_t)g.W * g.H));
   const int T = g.KH * g.KW;
   const __amdgpu_buffer_rsrc_t gr = make_rsrc(gcols, (unsigned)((size_t)g.N * g.Ho * g.Wo * T * g.C * 4));
-  const int cnt = min(counts[list], kListCap);
-  const ListEntry* __restrict__ lst = entries + list * kListCap;
+  // corner q of a sample whose footprint starts at (hl, wl) is the cell (hl + (q >> 1), wl + (q & 1))
+  size_t lst[4];
+  int end[4];                       // running ends of the four lists laid end to end
+  int total = 0;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    lst[q] = tl_list(g, n, y - (q >> 1), x - (q & 1), grp);
+    total += min(counts[lst[q]], kListCap);
+    end[q] = total;
+  }
   float4 acc = zero4();
-  for (int e0 = 0; e0 < cnt; e0 += 8) {
-    ListEntry en[8];
+  const int lane = threadIdx.x & 63;
+  // The 16 lanes of the quarter share the entries: lane u < 8 decodes entry e0 + u (which list, the corner weight) once, the
+  // others pick it up by a lane shuffle — decoding all eight in every lane made this kernel VALU-bound (51 -> 86 us on the
+  // 64x128 map when the lists moved from cells to top-left positions).  The next round's entries are fetched and decoded
+  // while this round's gcols rows are in flight.
+  auto decode = [&](const int e0, unsigned& smp_out, float& wgt_out) {
+    smp_out = 0xFFFFFFFFu;
+    wgt_out = 0.f;
+    const int e = e0 + (l16 & 7);
+    if (e < total) {
+      const int q = (e >= end[0]) + (e >= end[1]) + (e >= end[2]);
+      const int first = q == 0 ? 0 : (q == 1 ? end[0] : (q == 2 ? end[1] : end[2]));
+      const size_t l = q == 0 ? lst[0] : (q == 1 ? lst[1] : (q == 2 ? lst[2] : lst[3]));
+      const ListEntry en = entries[l * kListCap + (e - first)];
+      // the forward's corner weights (hh * hw, hh * lw, lh * hw, lh * lw), then the modulation — same expression order
+      const float hh = 1.f - en.lh, hw = 1.f - en.lw;
+      const float a = (q & 2) ? en.lh : hh, b = (q & 1) ? en.lw : hw;
+      smp_out = en.sample;
+      wgt_out = (a * b) * en.mk;
+    }
+  };
+  unsigned my_smp;
+  float my_wgt;
+  decode(0, my_smp, my_wgt);
+  for (int e0 = 0; e0 < total; e0 += 8) {
+    unsigned smp[8];
+    float wgt[8];
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
-      if (e0 + u < cnt) {
-        en[u] = lst[e0 + u];
-      } else {
-        en[u].sample = 0xFFFFFFFFu;
-        en[u].weight = 0.f;
-      }
+      smp[u] = (unsigned)__shfl((int)my_smp, (lane & 48) | u, 64);
+      wgt[u] = __shfl(my_wgt, (lane & 48) | u, 64);
     }
     float4 v[8];
 #pragma unroll
     for (int u = 0; u < 8; ++u)
-      v[u] = buf_load4(gr, en[u].sample != 0xFFFFFFFFu ? (unsigned)((size_t)en[u].sample * g.C + c) * 4u : kOOB);
+      v[u] = buf_load4(gr, smp[u] != 0xFFFFFFFFu ? (unsigned)((size_t)smp[u] * g.C + c) * 4u : kOOB);
+    decode(e0 + 8, my_smp, my_wgt);
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
-      acc.x += en[u].weight * v[u].x; acc.y += en[u].weight * v[u].y;
-      acc.z += en[u].weight * v[u].z; acc.w += en[u].weight * v[u].w;
+      acc.x += wgt[u] * v[u].x; acc.y += wgt[u] * v[u].y;
+      acc.z += wgt[u] * v[u].z; acc.w += wgt[u] * v[u].w;
     }
   }
   float4* dst = reinterpret_cast<float4*>(gx + (size_t)cell * g.C + c);
@@ -602,7 +636,7 @@ static int deform_sample_backward_impl(const float* x, const float* offset, cons
       attr_set = true;
     }
     static const bool window = getenv("DADET_DEFORM_BWD_LDS") && getenv("DADET_DEFORM_BWD_LDS")[0] == '1';
-    const size_t lists = (size_t)g.N * g.H * g.W * g.dg;
+    const size_t lists = (size_t)g.N * (g.H + 1) * (g.W + 1) * g.dg;
     const size_t need = lists * sizeof(int) + 256 + lists * kListCap * sizeof(ListEntry);
     if (!window && workspace && workspace_bytes >= need && ((g.C / g.dg) % kDChunk) == 0 &&
         (((uintptr_t)x | (uintptr_t)gcols | (uintptr_t)gx | (uintptr_t)workspace) & 15) == 0 &&
@@ -643,7 +677,7 @@ extern "C" int dadet_deform_sample_backward(const float* x, const float* offset,
 
 extern "C" int dadet_deform_sample_backward_workspace_bytes(int N, int H, int W, int deformable_groups, size_t* bytes_out) {
   DADET_REQUIRE(N >= 0 && H > 0 && W > 0 && deformable_groups > 0 && bytes_out, "deform_sample_backward_workspace_bytes: bad args");
-  const size_t lists = (size_t)N * H * W * deformable_groups;
+  const size_t lists = (size_t)N * (H + 1) * (W + 1) * deformable_groups;
   *bytes_out = lists * sizeof(int) + 256 + lists * kListCap * sizeof(ListEntry);
   return DADET_OK;
 }

@@ -1,5 +1,5 @@
 cd /tmp && export TMPDIR=/tmp
-for v in 0 1 2; do
+for v in 0; do
   rm -rf /tmp/dp_$v; DADET_DEFORM_ABLATE=$v rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/dp_$v -- python $GRAFT_REPO_ROOT/tools/deform_bwd_bench.py 1.5 > /tmp/dp_$v.log 2>&1
   echo "== DADET_DEFORM_ABLATE=$v"; grep -v amdgpu /tmp/dp_$v.log | tail -3
   F=$(find /tmp/dp_$v -name "*kernel_trace.csv" | head -1)
