@@ -208,6 +208,8 @@ def elided_work(c, model, targets):
         out.append("RPN head backward on images without labelled anchors (target / auxiliary: identically zero)")
         if _os.environ.get("DADET_RPN_ROW_BACKWARD", "1") == "1":
             out.append("RPN head backward as dense GEMMs: run on the <= 256 sampled anchors' rows of the source image")
+    if not single_level and model.rpn.early_backward and _os.environ.get("DADET_RPN_ROW_BACKWARD", "1") == "1":
+        out.append("RPN head backward as dense GEMMs over the five pyramid maps: run on the sampled anchors' rows, level by level")
     return out
 
 

@@ -818,9 +818,12 @@ def rpn_loss(objectness, box_regression, sampled_inds, labels_sampled, pos_inds,
     return losses, g_obj, g_reg
 
 
-def rpn_loss_rows(objectness, box_regression, sampled_inds, labels_sampled, num_pos, targets_pos, beta):
+def rpn_loss_rows(objectness, box_regression, sampled_inds, labels_sampled, num_pos, targets_pos, beta, level=None):
     """RPN losses with the gradient in row form (dadet_rpn_loss_rows): -> (losses [2], grad rows [S, ldg] with ldg = 5A
-    rounded up to a multiple of 4, pixel index of every row int32 [S])"""
+    rounded up to a multiple of 4, pixel index of every row int32 [S]).
+    level = (anchors per image over all levels, this level's offset in an image, this level's anchors H*W*A): the maps are
+    ONE level of a pyramid, sampled_inds index the concatenation over levels; rows of other levels stay zero, pixel -1
+    (dadet_rpn_loss_rows_level)"""
     _dev(objectness, "objectness"), _dev(box_regression, "box_regression")
     obj, reg = _nhwc(objectness), _nhwc(box_regression)
     A = obj.shape[1]
@@ -829,6 +832,13 @@ def rpn_loss_rows(objectness, box_regression, sampled_inds, labels_sampled, num_
     losses = torch.empty(2, dtype=torch.float32, device=obj.device)
     rows = torch.empty((S, ldg), dtype=torch.float32, device=obj.device)
     pixels = torch.empty(S, dtype=torch.int32, device=obj.device)
+    if level is not None:
+        per_image, off, cnt = (int(v) for v in level)
+        assert cnt == obj.shape[1] * obj.shape[2] * obj.shape[3]
+        _lib.call("dadet_rpn_loss_rows_level", _p(obj), _p(reg), _p(sampled_inds.contiguous()),
+                  _p(labels_sampled.contiguous()), S, int(num_pos), _p(targets_pos.contiguous()), A, float(beta), per_image,
+                  off, cnt, _p(losses), _p(rows), ldg, _p(pixels), _stream())
+        return losses, rows, pixels
     _lib.call("dadet_rpn_loss_rows", _p(obj), _p(reg), _p(sampled_inds.contiguous()), _p(labels_sampled.contiguous()),
               S, int(num_pos), _p(targets_pos.contiguous()), A, float(beta), _p(losses), _p(rows), ldg, _p(pixels),
               _stream())
@@ -852,7 +862,7 @@ def scatter_pixel_taps_add(y, pixels, shape, ksize=1, pad=0):
     _dev(y, "y")
     assert pixels.is_cuda and pixels.dtype == torch.int32
     N, C, H, W = shape
-    dx = torch.zeros((N, C, H, W), dtype=torch.float32, device=y.device).contiguous(memory_format=CL)
+    dx = torch.empty((N, C, H, W), dtype=torch.float32, device=y.device, memory_format=CL).zero_()
     _lib.call("dadet_scatter_pixel_taps_add", _p(y.contiguous()), _p(pixels), int(pixels.numel()), N, H, W, C, ksize,
               ksize, pad, _p(dx), _stream())
     return dx

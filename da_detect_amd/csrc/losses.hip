@@ -167,14 +167,28 @@ __global__ __launch_bounds__(256) void rpn_loss_rows_kernel(const float* __restr
                                                             const float* __restrict__ labels_sampled, int S, int Pn,
                                                             const float* __restrict__ targets_pos, int A, float beta,
                                                             float* __restrict__ losses, float* __restrict__ G, int ldg,
-                                                            int* __restrict__ pixels) {
+                                                            int* __restrict__ pixels, int64_t per_image, int64_t level_off,
+                                                            int64_t level_cnt) {
+  // per_image > 0: ONE LEVEL of a feature pyramid.  sampled_inds index the concatenation over levels the losses are
+  // defined on (concat_box_prediction_layers, rpn/utils.py:10-45: image-major, then level, then (h, w, a)); the maps
+  // given here are this level's, an anchor of another level leaves its row zero and its pixel -1, and the sum of the
+  // levels' launches is the loss (all of them divide by the same S)
   __shared__ float red[4];
   const float inv = S > 0 ? 1.f / (float)S : 0.f;
   for (int i = threadIdx.x; i < S * ldg; i += 256) G[i] = 0.f;
   __syncthreads();
+  auto local = [&](int64_t idx) -> int64_t {
+    if (per_image <= 0) return idx;
+    const int64_t img = idx / per_image, rem = idx - img * per_image - level_off;
+    return (rem >= 0 && rem < level_cnt) ? img * level_cnt + rem : -1;
+  };
   float bce = 0.f;
   for (int i = threadIdx.x; i < S; i += 256) {
-    const int64_t idx = sampled_inds[i];
+    const int64_t idx = local(sampled_inds[i]);
+    if (idx < 0) {
+      pixels[i] = -1;
+      continue;
+    }
     const int a = (int)(idx % A);
     const float x = objectness[idx], y = labels_sampled[i];
     bce += fmaxf(x, 0.f) - x * y + log1pf(expf(-fabsf(x)));
@@ -184,7 +198,8 @@ __global__ __launch_bounds__(256) void rpn_loss_rows_kernel(const float* __restr
   float box = 0.f;
   for (int i = threadIdx.x; i < Pn * 4; i += 256) {
     const int r = i >> 2, j = i & 3;
-    const int64_t idx = sampled_inds[r];
+    const int64_t idx = local(sampled_inds[r]);
+    if (idx < 0) continue;
     const int a = (int)(idx % A);
     float g;
     box += smooth_l1_term(box_regression[idx * 4 + j], targets_pos[i], beta, &g);
@@ -204,10 +219,10 @@ __global__ __launch_bounds__(256) void gather_pixel_taps_kernel(const float4* __
                                                                 int H, int W, int C4, int KH, int KW, int pad,
                                                                 float4* __restrict__ out) {
   const int r = blockIdx.x / (KH * KW), tap = blockIdx.x % (KH * KW);
-  const int p = pixels[r];
+  const int p = pixels[r];                  // -1: a row that belongs to another pyramid level (zeros)
   const int n = p / (H * W), rem = p - n * H * W;
   const int h = rem / W + tap / KW - pad, w = rem % W + tap % KW - pad;
-  const bool inside = h >= 0 && h < H && w >= 0 && w < W;
+  const bool inside = p >= 0 && h >= 0 && h < H && w >= 0 && w < W;
   const float4* src = x + ((size_t)(n * H + h) * W + w) * C4;
   float4* dst = out + (size_t)blockIdx.x * C4;
   for (int c = threadIdx.x; c < C4; c += 256) dst[c] = inside ? src[c] : make_float4(0.f, 0.f, 0.f, 0.f);
@@ -220,6 +235,7 @@ __global__ __launch_bounds__(256) void scatter_pixel_taps_add_kernel(const float
                                                                      int KH, int KW, int pad, float* __restrict__ dx) {
   const int r = blockIdx.x / (KH * KW), tap = blockIdx.x % (KH * KW);
   const int p = pixels[r];
+  if (p < 0) return;
   const int n = p / (H * W), rem = p - n * H * W;
   const int h = rem / W + tap / KW - pad, w = rem % W + tap % KW - pad;
   if (h < 0 || h >= H || w < 0 || w >= W) return;
@@ -279,20 +295,44 @@ extern "C" int dadet_fast_rcnn_loss_rows(const float* class_logits, const float*
   return check_launch("fast_rcnn_loss_rows");
 }
 
-extern "C" int dadet_rpn_loss_rows(const float* objectness, const float* box_regression, const int64_t* sampled_inds,
-                                   const float* labels_sampled, int num_sampled, int num_pos,
-                                   const float* regression_targets_pos, int anchors_per_location, float beta,
-                                   float* losses_out, float* grad_rows, int ldg, int* pixels_out, void* stream) {
+static int rpn_loss_rows_impl(const float* objectness, const float* box_regression, const int64_t* sampled_inds,
+                              const float* labels_sampled, int num_sampled, int num_pos,
+                              const float* regression_targets_pos, int anchors_per_location, float beta,
+                              float* losses_out, float* grad_rows, int ldg, int* pixels_out, int64_t per_image,
+                              int64_t level_off, int64_t level_cnt, void* stream) {
   DADET_REQUIRE(num_sampled > 0 && num_pos >= 0 && num_pos <= num_sampled && anchors_per_location > 0,
                 "rpn_loss_rows: bad counts (%d sampled, %d positive)", num_sampled, num_pos);
   DADET_REQUIRE(ldg >= 5 * anchors_per_location, "rpn_loss_rows: ldg=%d < 5 * %d", ldg, anchors_per_location);
   DADET_REQUIRE(objectness && box_regression && sampled_inds && labels_sampled && losses_out && grad_rows && pixels_out,
                 "rpn_loss_rows: null pointer");
   DADET_REQUIRE(num_pos == 0 || regression_targets_pos, "rpn_loss_rows: null regression targets");
+  DADET_REQUIRE(per_image == 0 || (per_image > 0 && level_off >= 0 && level_cnt > 0 && level_off + level_cnt <= per_image &&
+                                   level_cnt % anchors_per_location == 0),
+                "rpn_loss_rows: bad level window");
   hipLaunchKernelGGL(rpn_loss_rows_kernel, dim3(1), dim3(256), 0, as_stream(stream), objectness, box_regression,
                      sampled_inds, labels_sampled, num_sampled, num_pos, regression_targets_pos, anchors_per_location,
-                     beta, losses_out, grad_rows, ldg, pixels_out);
+                     beta, losses_out, grad_rows, ldg, pixels_out, per_image, level_off, level_cnt);
   return check_launch("rpn_loss_rows");
+}
+
+extern "C" int dadet_rpn_loss_rows(const float* objectness, const float* box_regression, const int64_t* sampled_inds,
+                                   const float* labels_sampled, int num_sampled, int num_pos,
+                                   const float* regression_targets_pos, int anchors_per_location, float beta,
+                                   float* losses_out, float* grad_rows, int ldg, int* pixels_out, void* stream) {
+  return rpn_loss_rows_impl(objectness, box_regression, sampled_inds, labels_sampled, num_sampled, num_pos,
+                            regression_targets_pos, anchors_per_location, beta, losses_out, grad_rows, ldg, pixels_out, 0,
+                            0, 0, stream);
+}
+
+extern "C" int dadet_rpn_loss_rows_level(const float* objectness, const float* box_regression, const int64_t* sampled_inds,
+                                         const float* labels_sampled, int num_sampled, int num_pos,
+                                         const float* regression_targets_pos, int anchors_per_location, float beta,
+                                         int64_t anchors_per_image, int64_t level_offset, int64_t level_anchors,
+                                         float* losses_out, float* grad_rows, int ldg, int* pixels_out, void* stream) {
+  DADET_REQUIRE(anchors_per_image > 0, "rpn_loss_rows_level: anchors_per_image must be positive");
+  return rpn_loss_rows_impl(objectness, box_regression, sampled_inds, labels_sampled, num_sampled, num_pos,
+                            regression_targets_pos, anchors_per_location, beta, losses_out, grad_rows, ldg, pixels_out,
+                            anchors_per_image, level_offset, level_anchors, stream);
 }
 
 extern "C" int dadet_gather_pixel_taps(const float* x, const int* pixels, int num_rows, int N, int H, int W, int C, int KH,

@@ -140,9 +140,11 @@ class _RPNHeadLossRows(Function):
 
     @staticmethod
     def forward(ctx, x, w3, b3, wc, bc, wb, bb, t, objectness, box_regression, sampled_inds, labels_sampled, n_pos,
-                targets_pos, beta):
+                targets_pos, beta, level=None):
+        # level (anchors per image over the pyramid, this level's offset, this level's anchors): one level of an FPN head —
+        # rows of anchors on other levels are zero and contribute nothing below; the levels' losses add up
         losses, rows, pixels = _C.rpn_loss_rows(objectness, box_regression, sampled_inds, labels_sampled, n_pos,
-                                                targets_pos, beta)
+                                                targets_pos, beta, level=level)
         ctx.save_for_backward(x, w3, wc, wb, t, rows, pixels)
         ctx.A = objectness.shape[1]
         return losses[0], losses[1]
@@ -174,7 +176,7 @@ class _RPNHeadLossRows(Function):
         w_1x1 = w3.permute(0, 2, 3, 1).reshape(w3.shape[0], k * k * C, 1, 1)
         y = _C.conv_forward(gt, _C.conv_weight_transpose(w_1x1))
         dx = _C.scatter_pixel_taps_add(y.view(S, k * k, C), pixels, tuple(x.shape), k, k // 2)
-        return (dx, dw3, db3, d_head[:A], b_head[:A], d_head[A:5 * A], b_head[A:5 * A]) + (None,) * 8
+        return (dx, dw3, db3, d_head[:A], b_head[:A], d_head[A:5 * A], b_head[A:5 * A]) + (None,) * 9
 
 
 rpn_head_loss_rows = _RPNHeadLossRows.apply
