@@ -30,6 +30,10 @@ from .utils import permute_and_flatten
 _TOPK_KERNEL = __import__("os").environ.get("DADET_TOPK_KERNEL", "0") == "1"
 
 
+# DADET_FPN_DEVICE_SELECT=0: multi-level training selection with the reference's host round trips
+_DEVICE_SELECT = __import__("os").environ.get("DADET_FPN_DEVICE_SELECT", "1") == "1"
+
+
 class RPNPostProcessor(torch.nn.Module):
     def __init__(self, pre_nms_top_n, post_nms_top_n, nms_thresh, min_size, box_coder=None,
                  fpn_post_nms_top_n=None):
@@ -64,8 +68,10 @@ class RPNPostProcessor(torch.nn.Module):
                 out.append(proposal)
         return out
 
-    def forward_for_single_feature_map(self, anchors, objectness, box_regression):
-        """anchors: list[BoxList] (one per image); objectness [N,A,H,W]; box_regression [N,4A,H,W]"""
+    def forward_for_single_feature_map(self, anchors, objectness, box_regression, raw=False):
+        """anchors: list[BoxList] (one per image); objectness [N,A,H,W]; box_regression [N,4A,H,W].
+        raw: return the per-image (score-ordered boxes, scores, NMS keep buffer, kept count on the device, size) tuples
+        without reading the counts back (the multi-level device-side selection, _select_over_all_levels_device)"""
         N, A, H, W = objectness.shape
         scores_all = permute_and_flatten(objectness, N, A, 1, H, W).reshape(N, -1).sigmoid()
         deltas_all = permute_and_flatten(box_regression, N, A, 4, H, W).contiguous()  # [N, HWA, 4]
@@ -107,6 +113,8 @@ class RPNPostProcessor(torch.nn.Module):
         if use_side:
             record([p[:4] for p in pending[1::2]], main)
             main.wait_stream(side)
+        if raw:
+            return pending
         if self.defer and self.training and self.nms_thresh > 0 and self.min_size <= 0 and dev.type == "cuda":
             return [PendingProposals(boxes, scores, keep, count, self.post_nms_top_n, size)
                     for boxes, scores, keep, count, size in pending]
@@ -126,6 +134,12 @@ class RPNPostProcessor(torch.nn.Module):
     def forward(self, anchors, objectness, box_regression, targets=None):
         sampled = []
         num_levels = len(objectness)
+        if (self.defer and _DEVICE_SELECT and num_levels > 1 and targets is not None and self.training
+                and self.nms_thresh > 0 and self.min_size <= 0 and objectness[0].is_cuda):
+            self.defer = False
+            per_level = [self.forward_for_single_feature_map(a, o, b, raw=True)
+                         for a, o, b in zip(list(zip(*anchors)), objectness, box_regression)]
+            return self.add_gt_proposals(self._select_over_all_levels_device(per_level), targets)
         defer, self.defer = self.defer and num_levels == 1 and targets is not None, False
         for a, o, b in zip(list(zip(*anchors)), objectness, box_regression):
             self.defer = defer
@@ -140,6 +154,45 @@ class RPNPostProcessor(torch.nn.Module):
         if self.training and targets is not None:
             boxlists = self.add_gt_proposals(boxlists, targets)
         return boxlists
+
+    def _select_over_all_levels_device(self, per_level):
+        """Training-mode multi-level selection (inference.py:102-121 per level, :154-167 over the batch) with every count
+        left on the device: per image the levels' NMS results are laid end to end in fixed-capacity buffers (entries behind
+        a level's kept count carry score -1), the batch-wide top fpn_post_nms_top_n is a mask over those buffers, and each
+        image leaves as PendingProposals (positions of its selected entries + their number in device memory) for the box
+        head's sampler.  The host path did the same with one count round trip per level, boolean-mask indexing per image
+        (two more) and ~340 launches; nothing overlaps that chain since the RPN head's backward runs over rows.
+        per_level[l][i] = (boxes [n_l, 4] in score order, scores [n_l], keep int64 [n_l], count int32 [1], size)."""
+        n_img = len(per_level[0])
+        dev = per_level[0][0][0].device
+        img_boxes, img_scores = [], []
+        for i in range(n_img):
+            bs, ss = [], []
+            for lvl in per_level:
+                boxes, scores, keep, count, _ = lvl[i]
+                cap = min(int(boxes.shape[0]), self.post_nms_top_n)
+                if cap == 0:
+                    continue
+                kk = keep[:cap].clamp(0, boxes.shape[0] - 1)         # (the buffer is uninitialised behind the count)
+                valid = torch.arange(cap, device=dev) < count.to(torch.int64)
+                bs.append(boxes[kk])
+                ss.append(torch.where(valid, scores[kk], scores.new_full((), -1.0)))
+            img_boxes.append(torch.cat(bs, dim=0))
+            img_scores.append(torch.cat(ss, dim=0))
+        sizes = [int(s.numel()) for s in img_scores]
+        all_scores = torch.cat(img_scores, dim=0)
+        k = min(self.fpn_post_nms_top_n, int(all_scores.numel()))
+        _, inds = torch.topk(all_scores, k, dim=0, sorted=True)
+        mask = torch.zeros_like(all_scores, dtype=torch.bool)
+        mask[inds] = True
+        mask &= all_scores >= 0          # fewer valid entries than k: the rest of the top-k are padding
+        out = []
+        for i, m in enumerate(mask.split(sizes)):
+            keep_i = torch.nonzero_static(m, size=sizes[i], fill_value=0).reshape(-1)
+            count_i = m.sum().to(torch.int32).reshape(1)
+            out.append(PendingProposals(img_boxes[i], img_scores[i], keep_i, count_i, min(k, sizes[i]),
+                                        per_level[0][i][4]))
+        return out
 
     def select_over_all_levels(self, boxlists):
         """FPN: keep fpn_post_nms_top_n over the whole batch (train) / per image (test) (inference.py:154-181)"""

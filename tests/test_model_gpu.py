@@ -691,3 +691,41 @@ def test_early_image_level_da_backward_gives_the_same_gradients(device):
     assert set(g0) == set(g1) and any(n.startswith("da_heads.imghead") for n in g0)
     for n in g0:
         assert float((g0[n] - g1[n]).norm()) <= 1e-5 * float(g0[n].norm()) + 1e-10, n
+
+
+def test_fpn_device_side_selection_equals_the_host_chain(device, monkeypatch):
+    """multi-level training selection with every count left on the device (rpn/inference.py
+    `_select_over_all_levels_device`: fixed-capacity buffers, batch-wide top-k as a mask, PendingProposals) against the
+    host chain of the reference (per-level count round trips, `select_over_all_levels`, `add_gt_proposals`): the same
+    boxes with the same scores in the same order, per image"""
+    from da_detect_amd.data.synthetic import make_batch
+    from da_detect_amd.modeling.detector import build_detection_model
+    from da_detect_amd.modeling.rpn import inference as inf
+    from da_detect_amd.structures.image_list import to_image_list
+    from golden.cases import fpn_dcn_da_cfg
+    from golden.fill import fill_state_dict
+
+    c = fpn_dcn_da_cfg()
+    model = build_detection_model(c)
+    model.load_state_dict(fill_state_dict(model.state_dict(), 5))
+    model = model.to(device).train()
+    images, targets = make_batch(c, 2, 192, 320, seed=5, device=device)
+    with torch.no_grad():
+        il = to_image_list(images)
+        feats = model.backbone(il.tensors)
+        obj, reg = model.rpn.head(feats)
+        anchors = model.rpn.anchor_generator(il, feats)
+        sel = model.rpn.box_selector_train
+        monkeypatch.setattr(inf, "_DEVICE_SELECT", True)
+        sel.defer = True
+        dev_out = sel(anchors, obj, reg, targets)
+        assert all(getattr(type(p), "is_pending_proposals", False) for p in dev_out)
+        monkeypatch.setattr(inf, "_DEVICE_SELECT", False)
+        sel.defer = False
+        host_out = sel(anchors, obj, reg, targets)
+    assert len(dev_out) == len(host_out) == 2
+    for d, h in zip(dev_out, host_out):
+        assert not getattr(type(h), "is_pending_proposals", False)
+        assert len(d) == len(h) and len(h) > 50
+        assert torch.equal(d.bbox, h.bbox)
+        assert torch.equal(d.get_field("objectness"), h.get_field("objectness"))
