@@ -12,6 +12,17 @@ for p in (ROOT, HERE):  # repo root (da_detect_amd, oracle) and tests/ (golden.*
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    config.addinivalue_line("markers", "slow: a test whose coverage other tests of the default run repeat; runs with "
+                                       "DADET_RUN_SLOW=1 (keeps the GPU suite under 8 minutes on the driver's box)")
+
+
+def pytest_collection_modifyitems(config, items):
+    if os.environ.get("DADET_RUN_SLOW") == "1":
+        return
+    skip = pytest.mark.skip(reason="slow and covered elsewhere (see the test's docstring); DADET_RUN_SLOW=1 runs it")
+    for item in items:
+        if "slow" in item.keywords:
+            item.add_marker(skip)
 
 
 @pytest.fixture(scope="session")
