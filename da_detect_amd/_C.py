@@ -818,26 +818,35 @@ def rpn_loss(objectness, box_regression, sampled_inds, labels_sampled, pos_inds,
     return losses, g_obj, g_reg
 
 
-def rpn_loss_rows(objectness, box_regression, sampled_inds, labels_sampled, num_pos, targets_pos, beta, level=None):
+def rpn_loss_rows(objectness, box_regression, sampled_inds, labels_sampled, num_pos, targets_pos, beta, level=None,
+                  shared=None):
     """RPN losses with the gradient in row form (dadet_rpn_loss_rows): -> (losses [2], grad rows [S, ldg] with ldg = 5A
     rounded up to a multiple of 4, pixel index of every row int32 [S]).
     level = (anchors per image over all levels, this level's offset in an image, this level's anchors H*W*A): the maps are
     ONE level of a pyramid, sampled_inds index the concatenation over levels; rows of other levels stay zero, pixel -1
-    (dadet_rpn_loss_rows_level)"""
+    (dadet_rpn_loss_rows_level).
+    shared = (level id, rows [S, ldg] zero-filled once by the caller, pixels int32 [S], row_level int32 [S]): the buffers
+    of all levels' launches — this one writes the rows of its own anchors and tags them; -> (losses [2], rows, pixels)"""
     _dev(objectness, "objectness"), _dev(box_regression, "box_regression")
     obj, reg = _nhwc(objectness), _nhwc(box_regression)
     A = obj.shape[1]
     S = int(sampled_inds.numel())
     ldg = (5 * A + 3) // 4 * 4
     losses = torch.empty(2, dtype=torch.float32, device=obj.device)
-    rows = torch.empty((S, ldg), dtype=torch.float32, device=obj.device)
-    pixels = torch.empty(S, dtype=torch.int32, device=obj.device)
+    if shared is not None:
+        level_id, rows, pixels, row_level = shared
+        assert rows.shape == (S, ldg) and rows.is_contiguous() and pixels.dtype == row_level.dtype == torch.int32
+    else:
+        level_id, row_level = 0, None
+        rows = torch.empty((S, ldg), dtype=torch.float32, device=obj.device)
+        pixels = torch.empty(S, dtype=torch.int32, device=obj.device)
     if level is not None:
         per_image, off, cnt = (int(v) for v in level)
         assert cnt == obj.shape[1] * obj.shape[2] * obj.shape[3]
         _lib.call("dadet_rpn_loss_rows_level", _p(obj), _p(reg), _p(sampled_inds.contiguous()),
                   _p(labels_sampled.contiguous()), S, int(num_pos), _p(targets_pos.contiguous()), A, float(beta), per_image,
-                  off, cnt, _p(losses), _p(rows), ldg, _p(pixels), _stream())
+                  off, cnt, int(level_id), _p(row_level), 1 if shared is not None else 0, _p(losses), _p(rows), ldg,
+                  _p(pixels), _stream())
         return losses, rows, pixels
     _lib.call("dadet_rpn_loss_rows", _p(obj), _p(reg), _p(sampled_inds.contiguous()), _p(labels_sampled.contiguous()),
               S, int(num_pos), _p(targets_pos.contiguous()), A, float(beta), _p(losses), _p(rows), ldg, _p(pixels),
@@ -845,24 +854,35 @@ def rpn_loss_rows(objectness, box_regression, sampled_inds, labels_sampled, num_
     return losses, rows, pixels
 
 
-def gather_pixel_taps(x, pixels, ksize=1, pad=0):
-    """x [N,C,H,W] channels_last, pixels int32 [S] -> [S, ksize*ksize, C]: the rows x[pixel + tap offset] (zero outside)"""
+def gather_pixel_taps(x, pixels, ksize=1, pad=0, row_level=None, level=0, out=None):
+    """x [N,C,H,W] channels_last, pixels int32 [S] -> [S, ksize*ksize, C]: the rows x[pixel + tap offset] (zero outside).
+    row_level / level / out: only the rows tagged `level` are written, into the shared buffer `out`"""
     _dev(x, "x")
     assert pixels.is_cuda and pixels.dtype == torch.int32
     N, C, H, W = x.shape
     x = _nhwc(x)
     S = int(pixels.numel())
-    out = torch.empty((S, ksize * ksize, C), dtype=torch.float32, device=x.device)
+    if out is None:
+        out = torch.empty((S, ksize * ksize, C), dtype=torch.float32, device=x.device)
+    if row_level is not None:
+        _lib.call("dadet_gather_pixel_taps_level", _p(x), _p(pixels), _p(row_level), int(level), S, N, H, W, C, ksize,
+                  ksize, pad, _p(out), _stream())
+        return out
     _lib.call("dadet_gather_pixel_taps", _p(x), _p(pixels), S, N, H, W, C, ksize, ksize, pad, _p(out), _stream())
     return out
 
 
-def scatter_pixel_taps_add(y, pixels, shape, ksize=1, pad=0):
-    """y [S, ksize*ksize, C] -> zero [N,C,H,W] channels_last map with y[r, tap] added at pixel_r + tap offset"""
+def scatter_pixel_taps_add(y, pixels, shape, ksize=1, pad=0, row_level=None, level=0):
+    """y [S, ksize*ksize, C] -> zero [N,C,H,W] channels_last map with y[r, tap] added at pixel_r + tap offset
+    (row_level / level: only the rows tagged `level`)"""
     _dev(y, "y")
     assert pixels.is_cuda and pixels.dtype == torch.int32
     N, C, H, W = shape
     dx = torch.empty((N, C, H, W), dtype=torch.float32, device=y.device, memory_format=CL).zero_()
+    if row_level is not None:
+        _lib.call("dadet_scatter_pixel_taps_add_level", _p(y.contiguous()), _p(pixels), _p(row_level), int(level),
+                  int(pixels.numel()), N, H, W, C, ksize, ksize, pad, _p(dx), _stream())
+        return dx
     _lib.call("dadet_scatter_pixel_taps_add", _p(y.contiguous()), _p(pixels), int(pixels.numel()), N, H, W, C, ksize,
               ksize, pad, _p(dx), _stream())
     return dx

@@ -83,7 +83,10 @@ _SIGNATURES = {
     "dadet_rpn_loss": [_P, _P, _P, _P, c_int, _P, _P, c_int, c_float, _P, _P, _P, _P],
     "dadet_rpn_loss_rows": [_P, _P, _P, _P, c_int, c_int, _P, c_int, c_float, _P, _P, c_int, _P, _P],
     "dadet_rpn_loss_rows_level": [_P, _P, _P, _P, c_int, c_int, _P, c_int, c_float, ctypes.c_longlong, ctypes.c_longlong,
-                                  ctypes.c_longlong, _P, _P, c_int, _P, _P],
+                                  ctypes.c_longlong, c_int, _P, c_int, _P, _P, c_int, _P, _P],
+    "dadet_gather_pixel_taps_level": [_P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P, _P],
+    "dadet_scatter_pixel_taps_add_level": [_P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P,
+                                           _P],
     "dadet_gather_pixel_taps": [_P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P, _P],
     "dadet_scatter_pixel_taps_add": [_P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P, _P],
     "dadet_fast_rcnn_loss": [_P, _P, c_int, c_int, _P, _P, c_int, _P, _P, _P, c_int, _P, _P, _P, _P],

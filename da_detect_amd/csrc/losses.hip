@@ -168,15 +168,20 @@ __global__ __launch_bounds__(256) void rpn_loss_rows_kernel(const float* __restr
                                                             const float* __restrict__ targets_pos, int A, float beta,
                                                             float* __restrict__ losses, float* __restrict__ G, int ldg,
                                                             int* __restrict__ pixels, int64_t per_image, int64_t level_off,
-                                                            int64_t level_cnt) {
+                                                            int64_t level_cnt, int level_id, int* __restrict__ row_level,
+                                                            int keep_rows) {
   // per_image > 0: ONE LEVEL of a feature pyramid.  sampled_inds index the concatenation over levels the losses are
   // defined on (concat_box_prediction_layers, rpn/utils.py:10-45: image-major, then level, then (h, w, a)); the maps
   // given here are this level's, an anchor of another level leaves its row zero and its pixel -1, and the sum of the
   // levels' launches is the loss (all of them divide by the same S)
+  // keep_rows: G / pixels / row_level are SHARED by the launches of all levels (the caller zero-fills G once); this launch
+  // writes the rows of its own anchors only and tags them with level_id — every sampled anchor lies on exactly one level
   __shared__ float red[4];
   const float inv = S > 0 ? 1.f / (float)S : 0.f;
-  for (int i = threadIdx.x; i < S * ldg; i += 256) G[i] = 0.f;
-  __syncthreads();
+  if (!keep_rows) {
+    for (int i = threadIdx.x; i < S * ldg; i += 256) G[i] = 0.f;
+    __syncthreads();
+  }
   auto local = [&](int64_t idx) -> int64_t {
     if (per_image <= 0) return idx;
     const int64_t img = idx / per_image, rem = idx - img * per_image - level_off;
@@ -186,9 +191,10 @@ __global__ __launch_bounds__(256) void rpn_loss_rows_kernel(const float* __restr
   for (int i = threadIdx.x; i < S; i += 256) {
     const int64_t idx = local(sampled_inds[i]);
     if (idx < 0) {
-      pixels[i] = -1;
+      if (!keep_rows) pixels[i] = -1;
       continue;
     }
+    if (row_level) row_level[i] = level_id;
     const int a = (int)(idx % A);
     const float x = objectness[idx], y = labels_sampled[i];
     bce += fmaxf(x, 0.f) - x * y + log1pf(expf(-fabsf(x)));
@@ -217,8 +223,10 @@ __global__ __launch_bounds__(256) void rpn_loss_rows_kernel(const float* __restr
 // of a KH x KW stride-1 convolution's weight gradient; KH = KW = 1: plain row gather
 __global__ __launch_bounds__(256) void gather_pixel_taps_kernel(const float4* __restrict__ x, const int* __restrict__ pixels,
                                                                 int H, int W, int C4, int KH, int KW, int pad,
-                                                                float4* __restrict__ out) {
+                                                                float4* __restrict__ out, const int* __restrict__ row_level,
+                                                                int level) {
   const int r = blockIdx.x / (KH * KW), tap = blockIdx.x % (KH * KW);
+  if (row_level && row_level[r] != level) return;      // a row of another pyramid level: written by that level's launch
   const int p = pixels[r];                  // -1: a row that belongs to another pyramid level (zeros)
   const int n = p / (H * W), rem = p - n * H * W;
   const int h = rem / W + tap / KW - pad, w = rem % W + tap % KW - pad;
@@ -232,8 +240,10 @@ __global__ __launch_bounds__(256) void gather_pixel_taps_kernel(const float4* __
 // (dx zero-filled by the caller; rows of neighbouring or equal pixels meet on the same dx row: hardware fp32 atomics)
 __global__ __launch_bounds__(256) void scatter_pixel_taps_add_kernel(const float* __restrict__ y,
                                                                      const int* __restrict__ pixels, int H, int W, int C,
-                                                                     int KH, int KW, int pad, float* __restrict__ dx) {
+                                                                     int KH, int KW, int pad, float* __restrict__ dx,
+                                                                     const int* __restrict__ row_level, int level) {
   const int r = blockIdx.x / (KH * KW), tap = blockIdx.x % (KH * KW);
+  if (row_level && row_level[r] != level) return;
   const int p = pixels[r];
   if (p < 0) return;
   const int n = p / (H * W), rem = p - n * H * W;
@@ -299,7 +309,8 @@ static int rpn_loss_rows_impl(const float* objectness, const float* box_regressi
                               const float* labels_sampled, int num_sampled, int num_pos,
                               const float* regression_targets_pos, int anchors_per_location, float beta,
                               float* losses_out, float* grad_rows, int ldg, int* pixels_out, int64_t per_image,
-                              int64_t level_off, int64_t level_cnt, void* stream) {
+                              int64_t level_off, int64_t level_cnt, int level_id, int* row_level_out, int keep_rows,
+                              void* stream) {
   DADET_REQUIRE(num_sampled > 0 && num_pos >= 0 && num_pos <= num_sampled && anchors_per_location > 0,
                 "rpn_loss_rows: bad counts (%d sampled, %d positive)", num_sampled, num_pos);
   DADET_REQUIRE(ldg >= 5 * anchors_per_location, "rpn_loss_rows: ldg=%d < 5 * %d", ldg, anchors_per_location);
@@ -311,7 +322,8 @@ static int rpn_loss_rows_impl(const float* objectness, const float* box_regressi
                 "rpn_loss_rows: bad level window");
   hipLaunchKernelGGL(rpn_loss_rows_kernel, dim3(1), dim3(256), 0, as_stream(stream), objectness, box_regression,
                      sampled_inds, labels_sampled, num_sampled, num_pos, regression_targets_pos, anchors_per_location,
-                     beta, losses_out, grad_rows, ldg, pixels_out, per_image, level_off, level_cnt);
+                     beta, losses_out, grad_rows, ldg, pixels_out, per_image, level_off, level_cnt, level_id, row_level_out,
+                     keep_rows);
   return check_launch("rpn_loss_rows");
 }
 
@@ -321,39 +333,65 @@ extern "C" int dadet_rpn_loss_rows(const float* objectness, const float* box_reg
                                    float* losses_out, float* grad_rows, int ldg, int* pixels_out, void* stream) {
   return rpn_loss_rows_impl(objectness, box_regression, sampled_inds, labels_sampled, num_sampled, num_pos,
                             regression_targets_pos, anchors_per_location, beta, losses_out, grad_rows, ldg, pixels_out, 0,
-                            0, 0, stream);
+                            0, 0, 0, nullptr, 0, stream);
 }
 
 extern "C" int dadet_rpn_loss_rows_level(const float* objectness, const float* box_regression, const int64_t* sampled_inds,
                                          const float* labels_sampled, int num_sampled, int num_pos,
                                          const float* regression_targets_pos, int anchors_per_location, float beta,
                                          int64_t anchors_per_image, int64_t level_offset, int64_t level_anchors,
-                                         float* losses_out, float* grad_rows, int ldg, int* pixels_out, void* stream) {
+                                         int level_id, int* row_level_out, int shared_rows, float* losses_out,
+                                         float* grad_rows, int ldg, int* pixels_out, void* stream) {
   DADET_REQUIRE(anchors_per_image > 0, "rpn_loss_rows_level: anchors_per_image must be positive");
+  DADET_REQUIRE(!shared_rows || row_level_out, "rpn_loss_rows_level: shared rows need row_level_out");
   return rpn_loss_rows_impl(objectness, box_regression, sampled_inds, labels_sampled, num_sampled, num_pos,
                             regression_targets_pos, anchors_per_location, beta, losses_out, grad_rows, ldg, pixels_out,
-                            anchors_per_image, level_offset, level_anchors, stream);
+                            anchors_per_image, level_offset, level_anchors, level_id, row_level_out, shared_rows, stream);
 }
 
-extern "C" int dadet_gather_pixel_taps(const float* x, const int* pixels, int num_rows, int N, int H, int W, int C, int KH,
-                                       int KW, int pad, float* out, void* stream) {
+static int gather_pixel_taps_impl(const float* x, const int* pixels, int num_rows, int N, int H, int W, int C, int KH,
+                                  int KW, int pad, float* out, const int* row_level, int level, void* stream) {
   DADET_REQUIRE(num_rows >= 0 && N > 0 && H > 0 && W > 0 && C > 0 && C % 4 == 0 && KH > 0 && KW > 0 && pad >= 0,
                 "gather_pixel_taps: bad dims (C=%d must be a multiple of 4)", C);
   if (num_rows == 0) return DADET_OK;
   DADET_REQUIRE(x && pixels && out && (reinterpret_cast<uintptr_t>(x) & 15) == 0 && (reinterpret_cast<uintptr_t>(out) & 15) == 0,
                 "gather_pixel_taps: null or unaligned pointer");
   hipLaunchKernelGGL(gather_pixel_taps_kernel, dim3(num_rows * KH * KW), dim3(256), 0, as_stream(stream),
-                     reinterpret_cast<const float4*>(x), pixels, H, W, C / 4, KH, KW, pad, reinterpret_cast<float4*>(out));
+                     reinterpret_cast<const float4*>(x), pixels, H, W, C / 4, KH, KW, pad, reinterpret_cast<float4*>(out),
+                     row_level, level);
   return check_launch("gather_pixel_taps");
 }
 
-extern "C" int dadet_scatter_pixel_taps_add(const float* y, const int* pixels, int num_rows, int N, int H, int W, int C,
-                                            int KH, int KW, int pad, float* dx, void* stream) {
+extern "C" int dadet_gather_pixel_taps(const float* x, const int* pixels, int num_rows, int N, int H, int W, int C, int KH,
+                                       int KW, int pad, float* out, void* stream) {
+  return gather_pixel_taps_impl(x, pixels, num_rows, N, H, W, C, KH, KW, pad, out, nullptr, 0, stream);
+}
+
+extern "C" int dadet_gather_pixel_taps_level(const float* x, const int* pixels, const int* row_level, int level, int num_rows,
+                                             int N, int H, int W, int C, int KH, int KW, int pad, float* out, void* stream) {
+  DADET_REQUIRE(row_level, "gather_pixel_taps_level: null row_level");
+  return gather_pixel_taps_impl(x, pixels, num_rows, N, H, W, C, KH, KW, pad, out, row_level, level, stream);
+}
+
+static int scatter_pixel_taps_add_impl(const float* y, const int* pixels, int num_rows, int N, int H, int W, int C, int KH,
+                                       int KW, int pad, float* dx, const int* row_level, int level, void* stream) {
   DADET_REQUIRE(num_rows >= 0 && N > 0 && H > 0 && W > 0 && C > 0 && KH > 0 && KW > 0 && pad >= 0,
                 "scatter_pixel_taps_add: bad dims");
   if (num_rows == 0) return DADET_OK;
   DADET_REQUIRE(y && pixels && dx, "scatter_pixel_taps_add: null pointer");
   hipLaunchKernelGGL(scatter_pixel_taps_add_kernel, dim3(num_rows * KH * KW), dim3(256), 0, as_stream(stream), y, pixels,
-                     H, W, C, KH, KW, pad, dx);
+                     H, W, C, KH, KW, pad, dx, row_level, level);
   return check_launch("scatter_pixel_taps_add");
+}
+
+extern "C" int dadet_scatter_pixel_taps_add(const float* y, const int* pixels, int num_rows, int N, int H, int W, int C,
+                                            int KH, int KW, int pad, float* dx, void* stream) {
+  return scatter_pixel_taps_add_impl(y, pixels, num_rows, N, H, W, C, KH, KW, pad, dx, nullptr, 0, stream);
+}
+
+extern "C" int dadet_scatter_pixel_taps_add_level(const float* y, const int* pixels, const int* row_level, int level,
+                                                  int num_rows, int N, int H, int W, int C, int KH, int KW, int pad,
+                                                  float* dx, void* stream) {
+  DADET_REQUIRE(row_level, "scatter_pixel_taps_add_level: null row_level");
+  return scatter_pixel_taps_add_impl(y, pixels, num_rows, N, H, W, C, KH, KW, pad, dx, row_level, level, stream);
 }

@@ -182,6 +182,75 @@ class _RPNHeadLossRows(Function):
 rpn_head_loss_rows = _RPNHeadLossRows.apply
 
 
+class _RPNHeadLossRowsPyramid(Function):
+    """_RPNHeadLossRows for the SHARED head of a feature pyramid, all levels in one node.  Every sampled anchor lies on
+    exactly one level, so the row-form gradient G [S, 5A], the hidden rows and the 3x3 operand rows of ALL levels fit the
+    same S-row buffers: each level's launches write the rows tagged with its id (dadet_rpn_loss_rows_level with shared rows,
+    dadet_gather_pixel_taps_level), the four GEMMs of the head's backward run ONCE, and the data gradient is scattered per
+    level.  Same sums as one node per level (cross-level terms are products with zero rows), a fifth of the launches and no
+    autograd additions of the head's parameter gradients across levels.
+    apply(w3, b3, wc, bc, wb, bb, sampled_inds, labels_sampled, n_pos, targets_pos, beta, levels, *x_t_obj_reg) with
+    levels = [(anchors per image, offset, count)] and x, t, objectness, box_regression per level; gradients for the six
+    parameters and every x."""
+
+    @staticmethod
+    def forward(ctx, w3, b3, wc, bc, wb, bb, sampled_inds, labels_sampled, n_pos, targets_pos, beta, levels, *maps):
+        L = len(levels)
+        xs, ts, objs, regs = maps[:L], maps[L:2 * L], maps[2 * L:3 * L], maps[3 * L:4 * L]
+        A = objs[0].shape[1]
+        S = int(sampled_inds.numel())
+        ldg = (5 * A + 3) // 4 * 4
+        dev = objs[0].device
+        rows = torch.zeros((S, ldg), dtype=torch.float32, device=dev)
+        pixels = torch.empty(S, dtype=torch.int32, device=dev)
+        row_level = torch.full((S,), -1, dtype=torch.int32, device=dev)
+        losses = []
+        for lvl in range(L):
+            l, _, _ = _C.rpn_loss_rows(objs[lvl], regs[lvl], sampled_inds, labels_sampled, n_pos, targets_pos, beta,
+                                       level=levels[lvl], shared=(lvl, rows, pixels, row_level))
+            losses.append(l)
+        total = torch.stack(losses).sum(0)
+        ctx.save_for_backward(w3, wc, wb, rows, pixels, row_level, *xs, *ts)
+        ctx.A, ctx.L = A, L
+        return total[0], total[1]
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g0, g1):
+        saved = ctx.saved_tensors
+        w3, wc, wb, rows, pixels, row_level = saved[:6]
+        A, L = ctx.A, ctx.L
+        xs, ts = saved[6:6 + L], saved[6 + L:6 + 2 * L]
+        S, ldg = rows.shape
+        C = xs[0].shape[1]
+        k = w3.shape[2]
+        scale = torch.cat([g0.reshape(1).expand(A), g1.reshape(1).expand(4 * A), rows.new_zeros(ldg - 5 * A)])
+        G = (rows * scale).view(S, ldg, 1, 1)
+        # (zero-filled: a row no level claims — there is none — must not put uninitialised memory next to its zero G row)
+        t_rows = torch.zeros((S, 1, C), dtype=torch.float32, device=rows.device)
+        x_cols = torch.zeros((S, k * k, C), dtype=torch.float32, device=rows.device)
+        for lvl in range(L):
+            _C.gather_pixel_taps(ts[lvl], pixels, row_level=row_level, level=lvl, out=t_rows)
+            _C.gather_pixel_taps(xs[lvl], pixels, k, k // 2, row_level=row_level, level=lvl, out=x_cols)
+        t_rows, x_cols = t_rows.view(S, C, 1, 1), x_cols.view(S, k * k * C, 1, 1)
+        w_head = torch.cat([wc.reshape(A, C), wb.reshape(4 * A, C), rows.new_zeros(ldg - 5 * A, C)], 0)
+        d_head = _C.conv_wgrad(t_rows, G, (ldg, C, 1, 1))
+        b_head = G.view(S, ldg).sum(0)
+        gt = _C.conv_forward(G, w_head.t().contiguous().view(C, ldg, 1, 1), relu_mode=2, mask_ref=t_rows)
+        dw3 = _C.conv_wgrad(x_cols, gt, (w3.shape[0], k * k * C, 1, 1))
+        dw3 = dw3.view(w3.shape[0], k, k, C).permute(0, 3, 1, 2)
+        db3 = gt.view(S, -1).sum(0)
+        w_1x1 = w3.permute(0, 2, 3, 1).reshape(w3.shape[0], k * k * C, 1, 1)
+        y = _C.conv_forward(gt, _C.conv_weight_transpose(w_1x1)).view(S, k * k, C)
+        dxs = [_C.scatter_pixel_taps_add(y, pixels, tuple(xs[lvl].shape), k, k // 2, row_level=row_level, level=lvl)
+               for lvl in range(L)]
+        return (dw3, db3, d_head[:A], b_head[:A], d_head[A:5 * A], b_head[A:5 * A]) + (None,) * 6 + tuple(dxs) + \
+            (None,) * (3 * L)
+
+
+rpn_head_loss_rows_pyramid = _RPNHeadLossRowsPyramid.apply
+
+
 class _FastRCNNLoss(Function):
     """(classification_loss, box_loss) with the gradients produced by the same launch"""
 

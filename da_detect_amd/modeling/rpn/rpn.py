@@ -5,7 +5,7 @@ import torch
 from torch import nn
 
 from ...layers import Conv2d, conv1x1_multi
-from ...layers.misc import rpn_head_loss_rows
+from ...layers.misc import rpn_head_loss_rows, rpn_head_loss_rows_pyramid
 from .. import registry
 from ..box_coder import BoxCoder
 from .anchor_generator import make_anchor_generator
@@ -208,17 +208,15 @@ class RPNModule(torch.nn.Module):
             # level normalises by the same count, so the levels' losses add up to rpn/loss.py:125-143
             h = self.head
             per_image = sum(int(o.shape[1] * o.shape[2] * o.shape[3]) for o in objectness)
-            n_pos, off = int(prep["pos_inds"].numel()), 0
-            loss_objectness = loss_rpn_box_reg = None
-            for lvl, (o, r) in enumerate(zip(objectness, rpn_box_regression)):
+            levels, off = [], 0
+            for o in objectness:
                 cnt = int(o.shape[1] * o.shape[2] * o.shape[3])
-                lo, lr = rpn_head_loss_rows(
-                    head_in[lvl], h.conv.weight, h.conv.bias, h.cls_logits.weight, h.cls_logits.bias, h.bbox_pred.weight,
-                    h.bbox_pred.bias, hidden[lvl], o, r, prep["sampled_inds"], prep["labels_sampled"], n_pos,
-                    prep["regression_targets_pos"], 1.0 / 9, (per_image, off, cnt))
-                loss_objectness = lo if loss_objectness is None else loss_objectness + lo
-                loss_rpn_box_reg = lr if loss_rpn_box_reg is None else loss_rpn_box_reg + lr
+                levels.append((per_image, off, cnt))
                 off += cnt
+            loss_objectness, loss_rpn_box_reg = rpn_head_loss_rows_pyramid(
+                h.conv.weight, h.conv.bias, h.cls_logits.weight, h.cls_logits.bias, h.bbox_pred.weight, h.bbox_pred.bias,
+                prep["sampled_inds"], prep["labels_sampled"], int(prep["pos_inds"].numel()),
+                prep["regression_targets_pos"], 1.0 / 9, levels, *head_in, *hidden, *objectness, *rpn_box_regression)
         elif hidden is not None and not isinstance(hidden, list) and prep["sampled_inds"].numel() > 0:
             h = self.head
             loss_objectness, loss_rpn_box_reg = rpn_head_loss_rows(

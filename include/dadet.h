@@ -298,15 +298,24 @@ int dadet_rpn_loss_rows(const float* objectness, const float* box_regression, co
                         int* pixels_out, void* stream);
 /* One level of a feature pyramid: sampled_inds index the concatenation over levels on which the reference defines the RPN
  * losses (concat_box_prediction_layers, modeling/rpn/utils.py:10-45: image-major, anchors_per_image per image, this level's
- * level_anchors = H*W*A entries at level_offset, ordered (h, w, a)); objectness / box_regression are THIS level's maps.  An
- * anchor of another level leaves its row zero and its pixel -1 (dadet_gather_pixel_taps then writes zeros,
- * dadet_scatter_pixel_taps_add skips the row); every level divides by the same num_sampled, so the levels' losses add up
- * to rpn/loss.py:125-143. */
+ * level_anchors = H*W*A entries at level_offset, ordered (h, w, a)); objectness / box_regression are THIS level's maps.
+ * Every level divides by the same num_sampled, so the levels' losses add up to rpn/loss.py:125-143.
+ * shared_rows = 0: grad_rows / pixels_out belong to this launch; an anchor of another level leaves its row zero and its
+ *   pixel -1 (dadet_gather_pixel_taps then writes zeros, dadet_scatter_pixel_taps_add skips the row).
+ * shared_rows = 1: grad_rows (zero-filled by the caller once), pixels_out and row_level_out are shared by the launches of all
+ *   levels; this launch writes the rows of its own anchors only and tags them with level_id in row_level_out.  The head's
+ *   backward then runs ONCE over the rows of all levels: dadet_gather_pixel_taps_level / dadet_scatter_pixel_taps_add_level
+ *   touch only the rows tagged `level` (the operand rows of the other levels are written by their own calls). */
 int dadet_rpn_loss_rows_level(const float* objectness, const float* box_regression, const int64_t* sampled_inds,
                               const float* labels_sampled, int num_sampled, int num_pos,
                               const float* regression_targets_pos, int anchors_per_location, float beta,
-                              int64_t anchors_per_image, int64_t level_offset, int64_t level_anchors, float* losses_out,
-                              float* grad_rows, int ldg, int* pixels_out, void* stream);
+                              int64_t anchors_per_image, int64_t level_offset, int64_t level_anchors, int level_id,
+                              int* row_level_out, int shared_rows, float* losses_out, float* grad_rows, int ldg,
+                              int* pixels_out, void* stream);
+int dadet_gather_pixel_taps_level(const float* x, const int* pixels, const int* row_level, int level, int num_rows, int N,
+                                  int H, int W, int C, int KH, int KW, int pad, float* out, void* stream);
+int dadet_scatter_pixel_taps_add_level(const float* y, const int* pixels, const int* row_level, int level, int num_rows,
+                                       int N, int H, int W, int C, int KH, int KW, int pad, float* dx, void* stream);
 int dadet_gather_pixel_taps(const float* x, const int* pixels, int num_rows, int N, int H, int W, int C, int KH, int KW,
                             int pad, float* out, void* stream);
 int dadet_scatter_pixel_taps_add(const float* y, const int* pixels, int num_rows, int N, int H, int W, int C, int KH,
