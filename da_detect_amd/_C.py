@@ -888,6 +888,36 @@ def scatter_pixel_taps_add(y, pixels, shape, ksize=1, pad=0, row_level=None, lev
     return dx
 
 
+def fpn_merge_levels(per_image, post_n):
+    """per_image[i] = [(boxes [n,4] in score order, scores [n], keep int64 [n], count int32 [1]) per level] -> per image
+    (boxes [cap_i, 4], scores [cap_i]) with the levels' NMS results laid end to end, cap = min(n, post_n) slots per level,
+    score -1 behind a level's kept count (dadet_fpn_merge_levels: one launch, no count read back)"""
+    entries, outs, keepalive = [], [], []
+    for levels in per_image:
+        caps = [min(int(b.shape[0]), int(post_n)) for b, _, _, _ in levels]
+        dev = levels[0][0].device
+        boxes_out = torch.empty((sum(caps), 4), dtype=torch.float32, device=dev)
+        scores_out = torch.empty(sum(caps), dtype=torch.float32, device=dev)
+        off = 0
+        for (b, sc, keep, count), cap in zip(levels, caps):
+            if cap == 0:
+                continue
+            b, sc = b.contiguous(), sc.contiguous()
+            keepalive.append((b, sc))
+            e = _lib.MergeEntry()
+            e.boxes, e.scores, e.keep, e.count = b.data_ptr(), sc.data_ptr(), keep.data_ptr(), count.data_ptr()
+            e.boxes_out, e.scores_out = boxes_out[off:].data_ptr(), scores_out[off:].data_ptr()
+            e.n, e.cap = int(b.shape[0]), cap
+            entries.append(e)
+            off += cap
+        outs.append((boxes_out, scores_out))
+    for i in range(0, len(entries), 24):
+        chunk = entries[i:i + 24]
+        arr = (_lib.MergeEntry * len(chunk))(*chunk)
+        _lib.call("dadet_fpn_merge_levels", arr, len(chunk), _stream())
+    return outs
+
+
 def fast_rcnn_loss(class_logits, box_regression, src, labels_src, rows_pos, map_inds, targets_pos):
     """Fast R-CNN losses + gradients in one launch (dadet_fast_rcnn_loss) -> (losses [2], g_cls, g_reg)"""
     _dev(class_logits, "class_logits"), _dev(box_regression, "box_regression")

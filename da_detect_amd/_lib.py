@@ -33,6 +33,13 @@ class TransposeItem(ctypes.Structure):
                 ("Cin", c_int), ("first_block", c_int), ("blocks_ci", c_int), ("blocks_co", c_int), ("cout_pad", c_int)]
 
 
+class MergeEntry(ctypes.Structure):
+    """mirror of dadet_merge_entry (include/dadet.h)"""
+
+    _fields_ = [("boxes", c_void_p), ("scores", c_void_p), ("keep", c_void_p), ("count", c_void_p), ("boxes_out", c_void_p),
+                ("scores_out", c_void_p), ("n", c_int), ("cap", c_int)]
+
+
 class SgdEntry(ctypes.Structure):
     """mirror of dadet_sgd_entry (include/dadet.h)"""
 
@@ -81,6 +88,7 @@ _SIGNATURES = {
     "dadet_image_resample_v_normalize": [_P, c_int, c_int, _P, _P, c_int, c_int, c_int, c_int, POINTER(c_float),
                                          POINTER(c_float), _P, c_int, _P],
     "dadet_rpn_loss": [_P, _P, _P, _P, c_int, _P, _P, c_int, c_float, _P, _P, _P, _P],
+    "dadet_fpn_merge_levels": [POINTER(MergeEntry), c_int, _P],
     "dadet_rpn_loss_rows": [_P, _P, _P, _P, c_int, c_int, _P, c_int, c_float, _P, _P, c_int, _P, _P],
     "dadet_rpn_loss_rows_level": [_P, _P, _P, _P, c_int, c_int, _P, c_int, c_float, ctypes.c_longlong, ctypes.c_longlong,
                                   ctypes.c_longlong, c_int, _P, c_int, _P, _P, c_int, _P, _P],

@@ -275,6 +275,38 @@ __global__ __launch_bounds__(kSampleThreads) void proposals_sample_kernel(
   }
 }
 
+// ---- multi-level proposal lists laid end to end (training-mode selection over a feature pyramid) -------------------------
+// One (level, image) pair per blockIdx.y: its NMS result — positions `keep[0 .. count)` into the score-ordered candidates —
+// is copied into the image's fixed-capacity buffers at the pair's offset; the slots behind the kept count get score -1
+// (and the first candidate's box, never read).  Replaces clamp / arange / compare / two gathers / where per pair
+// (rpn/inference.py `_select_over_all_levels_device`): one launch instead of ~100 on the host-bound stretch between the RPN
+// head and the box head.
+struct MergeEntry {
+  const float4* boxes;
+  const float* scores;
+  const int64_t* keep;
+  const int* count;
+  float4* boxes_out;
+  float* scores_out;
+  int n, cap;
+};
+constexpr int kMergeMax = 24;
+struct MergeTable {
+  MergeEntry e[kMergeMax];
+};
+
+__global__ __launch_bounds__(256) void fpn_merge_levels_kernel(const MergeTable t) {
+  const MergeEntry& e = t.e[blockIdx.y];
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= e.cap) return;
+  const int cnt = min(*e.count, e.cap);
+  const bool valid = j < cnt;
+  int64_t idx = valid ? e.keep[j] : 0;
+  if (idx < 0 || idx >= e.n) idx = 0;
+  e.boxes_out[j] = e.boxes[idx];
+  e.scores_out[j] = valid ? e.scores[idx] : -1.f;
+}
+
 }  // namespace dadet
 
 using namespace dadet;
@@ -521,4 +553,32 @@ extern "C" int dadet_sample_anchors(const float* labels, const float* regression
                      index_offset, pos_inds_out, neg_inds_out, reinterpret_cast<float4*>(regression_targets_pos_out),
                      counts_out);
   return check_launch("sample_anchors");
+}
+
+extern "C" int dadet_fpn_merge_levels(const dadet_merge_entry* entries, int n, void* stream) {
+  static_assert(sizeof(dadet_merge_entry) == sizeof(dadet::MergeEntry), "merge entry layout");
+  DADET_REQUIRE(n >= 0 && n <= kMergeMax, "fpn_merge_levels: %d (level, image) pairs (at most %d per call)", n, kMergeMax);
+  if (n == 0) return DADET_OK;
+  DADET_REQUIRE(entries, "fpn_merge_levels: null table");
+  MergeTable t;
+  int max_cap = 0;
+  for (int i = 0; i < n; ++i) {
+    const dadet_merge_entry& s = entries[i];
+    DADET_REQUIRE(s.boxes && s.scores && s.keep && s.count && s.boxes_out && s.scores_out && s.n > 0 && s.cap >= 0 &&
+                      (reinterpret_cast<uintptr_t>(s.boxes) & 15) == 0 && (reinterpret_cast<uintptr_t>(s.boxes_out) & 15) == 0,
+                  "fpn_merge_levels: entry %d is malformed", i);
+    MergeEntry& e = t.e[i];
+    e.boxes = reinterpret_cast<const float4*>(s.boxes);
+    e.scores = s.scores;
+    e.keep = s.keep;
+    e.count = s.count;
+    e.boxes_out = reinterpret_cast<float4*>(s.boxes_out);
+    e.scores_out = s.scores_out;
+    e.n = s.n;
+    e.cap = s.cap;
+    max_cap = s.cap > max_cap ? s.cap : max_cap;
+  }
+  if (max_cap == 0) return DADET_OK;
+  hipLaunchKernelGGL(fpn_merge_levels_kernel, dim3(ceil_div(max_cap, 256), n), dim3(256), 0, as_stream(stream), t);
+  return check_launch("fpn_merge_levels");
 }

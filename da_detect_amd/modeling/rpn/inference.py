@@ -164,21 +164,8 @@ class RPNPostProcessor(torch.nn.Module):
         (two more) and ~340 launches; nothing overlaps that chain since the RPN head's backward runs over rows.
         per_level[l][i] = (boxes [n_l, 4] in score order, scores [n_l], keep int64 [n_l], count int32 [1], size)."""
         n_img = len(per_level[0])
-        dev = per_level[0][0][0].device
-        img_boxes, img_scores = [], []
-        for i in range(n_img):
-            bs, ss = [], []
-            for lvl in per_level:
-                boxes, scores, keep, count, _ = lvl[i]
-                cap = min(int(boxes.shape[0]), self.post_nms_top_n)
-                if cap == 0:
-                    continue
-                kk = keep[:cap].clamp(0, boxes.shape[0] - 1)         # (the buffer is uninitialised behind the count)
-                valid = torch.arange(cap, device=dev) < count.to(torch.int64)
-                bs.append(boxes[kk])
-                ss.append(torch.where(valid, scores[kk], scores.new_full((), -1.0)))
-            img_boxes.append(torch.cat(bs, dim=0))
-            img_scores.append(torch.cat(ss, dim=0))
+        merged = _C.fpn_merge_levels([[lvl[i][:4] for lvl in per_level] for i in range(n_img)], self.post_nms_top_n)
+        img_boxes, img_scores = [m[0] for m in merged], [m[1] for m in merged]
         sizes = [int(s.numel()) for s in img_scores]
         all_scores = torch.cat(img_scores, dim=0)
         k = min(self.fpn_post_nms_top_n, int(all_scores.numel()))

@@ -347,6 +347,22 @@ int dadet_sample_rois(const float* boxes, const int64_t* labels, const float* re
                       int64_t* labels_out, float* regression_targets_out, int64_t* loss_labels_out,
                       unsigned char* domain_out, int* counts_out, void* stream);
 
+/* Multi-level proposal lists laid end to end (training-mode selection over a feature pyramid: rpn/inference.py:102-121 per
+ * level, then the concatenation of :141-152).  Per (level, image) pair: boxes [n][4] / scores [n] in score order, the NMS
+ * keep buffer and kept count (device memory, dadet_nms), and where the pair's cap = min(n, post_nms_top_n) slots start in the
+ * image's output buffers: boxes_out[j] = boxes[keep[j]], scores_out[j] = scores[keep[j]] for j < count, score -1 behind.
+ * At most 24 pairs per call; `entries` is a HOST array. */
+typedef struct dadet_merge_entry {
+  const float* boxes;
+  const float* scores;
+  const int64_t* keep;
+  const int* count;
+  float* boxes_out;
+  float* scores_out;
+  int n, cap;
+} dadet_merge_entry;
+int dadet_fpn_merge_levels(const dadet_merge_entry* entries, int n, void* stream);
+
 /* NMS -> box-head sample of ONE image without leaving the device: proposal i = sorted_boxes[keep[i]] (objectness
  * sorted_scores[keep[i]]) for i < min(*count_dev, post_n), followed by `num_appended` appended boxes with objectness 1
  * (RPNPostProcessor.add_gt_proposals, rpn/inference.py:51-74); then, when is_source, IoU / Matcher / label rules /
