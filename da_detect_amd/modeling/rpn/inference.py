@@ -32,6 +32,56 @@ _TOPK_KERNEL = __import__("os").environ.get("DADET_TOPK_KERNEL", "0") == "1"
 
 # DADET_FPN_DEVICE_SELECT=0: multi-level training selection with the reference's host round trips
 _DEVICE_SELECT = __import__("os").environ.get("DADET_FPN_DEVICE_SELECT", "1") == "1"
+# DADET_SELECT_GRAPH=1: the device-side selection as one captured HIP graph instead of launch by launch.  MEASURED (round 3,
+# ROCm 7.0 / PyTorch 2.10, four alternating runs of 30 steps on one box): 59.4 - 60.8 ms per step launch by launch,
+# 64.5 - 65.5 ms with the graph — replaying the ~250-node graph costs more than issuing its launches from Python.  Off.
+_SELECT_GRAPH = __import__("os").environ.get("DADET_SELECT_GRAPH", "0") == "1"
+
+
+class _SelectionGraph(object):
+    """The device-side multi-level selection (~250 launches: per level sigmoid, a 16-launch stable sort, decode, and per
+    image the four NMS kernels; then the merge, the batch-wide top-k and the masks) has fixed shapes and no host round
+    trip, and nothing else runs on the GPU while the host issues it (the stretch between the RPN head and the box head:
+    2.3 - 2.8 ms of an R-101-FPN-DCN step with the next GEMM issued 0.05 ms before it starts, tools/gemm_table.py --holes).
+    It can be captured ONCE per (map shapes, anchor buffers) as a HIP graph — inputs copied into the graph's static buffers,
+    one graph launch per step (capture works; the replay is slower than the launches it replaces on this software stack,
+    see _SELECT_GRAPH).  Anything that makes capture fail (an unsupported call in a future PyTorch, a shape the
+    capture did not see) falls back to launch-by-launch execution for the rest of the process."""
+
+    def __init__(self):
+        self.graphs = {}
+        self.failed = False
+
+    def run(self, proc, anchors, objectness, box_regression):
+        if self.failed:
+            return None
+        key = (tuple(tuple(o.shape) for o in objectness), tuple(tuple(b.shape) for b in box_regression),
+               tuple(a.bbox.data_ptr() for lvls in anchors for a in lvls), tuple(tuple(lvls[0].size) for lvls in anchors))
+        entry = self.graphs.get(key)
+        inputs = list(objectness) + list(box_regression)
+        if entry is None:
+            try:
+                static_in = [torch.empty_like(t) for t in inputs]
+                for s_, t in zip(static_in, inputs):
+                    s_.copy_(t)
+                n = len(objectness)
+                proc._device_selection(anchors, static_in[:n], static_in[n:])          # warm-up outside the capture
+                graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(graph, capture_error_mode="thread_local"):
+                    parts = proc._device_selection(anchors, static_in[:n], static_in[n:])
+                entry = self.graphs[key] = (graph, static_in, parts, [a for lvls in anchors for a in lvls])
+                if len(self.graphs) > 8:                       # variable-size batches: do not hoard graphs
+                    self.graphs.pop(next(iter(self.graphs)))
+            except Exception as exc:   # noqa: BLE001 — any capture failure means: run eagerly from now on
+                import warnings
+                warnings.warn("proposal-selection graph capture failed (%r): running launch by launch" % (exc,))
+                self.failed = True
+                return None
+        graph, static_in, parts, _ = entry
+        for s_, t in zip(static_in, inputs):
+            s_.copy_(t)
+        graph.replay()
+        return parts
 
 
 class RPNPostProcessor(torch.nn.Module):
@@ -44,6 +94,7 @@ class RPNPostProcessor(torch.nn.Module):
         self.min_size = min_size
         self.box_coder = box_coder if box_coder is not None else BoxCoder(weights=(1.0, 1.0, 1.0, 1.0))
         self.fpn_post_nms_top_n = post_nms_top_n if fpn_post_nms_top_n is None else fpn_post_nms_top_n
+        self._graph = _SelectionGraph()
 
     # set by RPNModule for ONE call: the caller is the training path whose box head samples straight from the NMS result
     # on the device (FastRCNNLossComputation._subsample_fused): single-level proposals are then handed over as
@@ -111,7 +162,8 @@ class RPNPostProcessor(torch.nn.Module):
                     keep, count = _C.nms_with_count(boxes, None, self.nms_thresh, max_keep=self.post_nms_top_n)
             pending.append((boxes, scores, keep, count, (im_w, im_h)))
         if use_side:
-            record([p[:4] for p in pending[1::2]], main)
+            if not torch.cuda.is_current_stream_capturing():     # (a captured graph owns its memory: nothing to register)
+                record([p[:4] for p in pending[1::2]], main)
             main.wait_stream(side)
         if raw:
             return pending
@@ -137,9 +189,12 @@ class RPNPostProcessor(torch.nn.Module):
         if (self.defer and _DEVICE_SELECT and num_levels > 1 and targets is not None and self.training
                 and self.nms_thresh > 0 and self.min_size <= 0 and objectness[0].is_cuda):
             self.defer = False
-            per_level = [self.forward_for_single_feature_map(a, o, b, raw=True)
-                         for a, o, b in zip(list(zip(*anchors)), objectness, box_regression)]
-            return self.add_gt_proposals(self._select_over_all_levels_device(per_level), targets)
+            parts = self._graph.run(self, anchors, objectness, box_regression) if _SELECT_GRAPH else None
+            if parts is None:
+                parts = self._device_selection(anchors, objectness, box_regression)
+            out = [PendingProposals(b, sc, keep, cnt, post_n, anchors[i][0].size)
+                   for i, (b, sc, keep, cnt, post_n) in enumerate(parts)]
+            return self.add_gt_proposals(out, targets)
         defer, self.defer = self.defer and num_levels == 1 and targets is not None, False
         for a, o, b in zip(list(zip(*anchors)), objectness, box_regression):
             self.defer = defer
@@ -154,6 +209,13 @@ class RPNPostProcessor(torch.nn.Module):
         if self.training and targets is not None:
             boxlists = self.add_gt_proposals(boxlists, targets)
         return boxlists
+
+    def _device_selection(self, anchors, objectness, box_regression):
+        """the whole multi-level selection as a function of tensors at fixed shapes with no host round trip: -> per image
+        (boxes, scores, keep, count, upper bound).  This is what _SelectionGraph captures."""
+        per_level = [self.forward_for_single_feature_map(a, o, b, raw=True)
+                     for a, o, b in zip(list(zip(*anchors)), objectness, box_regression)]
+        return self._select_over_all_levels_device(per_level)
 
     def _select_over_all_levels_device(self, per_level):
         """Training-mode multi-level selection (inference.py:102-121 per level, :154-167 over the batch) with every count
@@ -171,14 +233,13 @@ class RPNPostProcessor(torch.nn.Module):
         k = min(self.fpn_post_nms_top_n, int(all_scores.numel()))
         _, inds = torch.topk(all_scores, k, dim=0, sorted=True)
         mask = torch.zeros_like(all_scores, dtype=torch.bool)
-        mask[inds] = True
+        mask.scatter_(0, inds, True)     # (not mask[inds] = True: that copies a host scalar, which a graph capture forbids)
         mask &= all_scores >= 0          # fewer valid entries than k: the rest of the top-k are padding
         out = []
         for i, m in enumerate(mask.split(sizes)):
             keep_i = torch.nonzero_static(m, size=sizes[i], fill_value=0).reshape(-1)
             count_i = m.sum().to(torch.int32).reshape(1)
-            out.append(PendingProposals(img_boxes[i], img_scores[i], keep_i, count_i, min(k, sizes[i]),
-                                        per_level[0][i][4]))
+            out.append((img_boxes[i], img_scores[i], keep_i, count_i, min(k, sizes[i])))
         return out
 
     def select_over_all_levels(self, boxlists):

@@ -19,11 +19,14 @@ for wl in img_only da triplet; do
       gpurun_out/${TAG}_pmc_$wl/hbm_traffic.json "bench.py --workload $wl --others none --steps 6 --warmup 3 (two rocprofv3 --pmc passes)"
   ls -la gpurun_out/${TAG}_pmc_$wl | tail -4
 done
-for wl in img_only da; do
+for wl in img_only da fpn_dcn_da; do
   echo "=== timeline: $wl"
   bash tools/profile_gaps.sh ${TAG}_gaps_$wl --workload $wl --steps 12 --warmup 6 --others none 2>&1 | tail -3
 done
 echo "=== GEMM table"
 python tools/gemm_table.py --workload img_only --steps 3 --top 60 --holes > gpurun_out/${TAG}_gemm_table_img_only.txt 2>&1; tail -3 gpurun_out/${TAG}_gemm_table_img_only.txt
+python tools/gemm_table.py --workload img_only --steps 3 --top 60 > gpurun_out/${TAG}_gemm_table_per_shape.txt 2>&1
+echo "=== R-101-FPN-DCN bench line"
+python bench.py --workload fpn_dcn_da --others none --no-cpu-baseline > gpurun_out/${TAG}_bench_fpn_dcn_da.json 2>/dev/null; tail -1 gpurun_out/${TAG}_bench_fpn_dcn_da.json | cut -c1-200
 echo "=== default bench"
 python bench.py > gpurun_out/${TAG}_bench_default.json 2> gpurun_out/${TAG}_bench_default.err; tail -1 gpurun_out/${TAG}_bench_default.json | cut -c1-300
