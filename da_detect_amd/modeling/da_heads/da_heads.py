@@ -336,13 +336,13 @@ class DomainAdaptationModule_triplet(torch.nn.Module):
                 s, p, n, self.triplet_ins[-1], adaptive=False, lr=0.001, max_margin=self.triplet_max_margin,
                 margin=self.triplet_metric_ins)
             losses["triplet_loss_instance"] = self.triplet_ins_weight * loss
-            self.triplet_ins = [loss.detach().cpu()]  # only [-1] is ever read
+            self.triplet_ins = [_later_value(loss)]  # only [-1] is ever read
         if self.triplet_img_weight > 0:
             loss = self.loss_evaluator.triplet_img_loss(
                 img_fea_set[0][0], img_fea_set[1][0], img_fea_set[2][0], self.triplet_img[-1], adaptive=True,
                 lr=0.001, max_margin=self.triplet_max_margin, margin=self.triplet_metric_img)
             losses["triplet_loss_image"] = self.triplet_img_weight * loss
-            self.triplet_img = [loss.detach().cpu()]
+            self.triplet_img = [_later_value(loss)]
 
         need_img = self.img_weight > 0 or self.cst_weight > 0
         if need_img:
@@ -377,6 +377,37 @@ class DomainAdaptationModule_triplet(torch.nn.Module):
             losses["loss_da_consistency"] = self.cst_weight * da_consist_loss(img_mean_sig, ins_consist,
                                                                               da_ins_labels)
         return losses
+
+
+class _LaterValue(object):
+    """the value of a 0-d device tensor, read on the host one iteration LATER.  The reference keeps `loss.detach().cpu()`
+    of the triplet losses (da_heads.py:320,325) for the next iteration's adaptive margin (loss.py:128-222: `prev_loss ==
+    0.0`), i.e. a device->host round trip in the middle of every forward pass; here the copy into pinned memory is queued
+    behind the loss and the comparison — made when the NEXT iteration asks — waits for an event that fired long ago."""
+
+    def __init__(self, t):
+        self.host = torch.empty((), dtype=t.dtype, pin_memory=True)
+        self.host.copy_(t.detach(), non_blocking=True)
+        self.event = torch.cuda.Event()
+        self.event.record(torch.cuda.current_stream(t.device))
+
+    def value(self):
+        self.event.synchronize()
+        return float(self.host)
+
+    def __eq__(self, other):
+        return self.value() == other
+
+    def __ne__(self, other):
+        return self.value() != other
+
+    def __float__(self):
+        return self.value()
+
+
+def _later_value(loss):
+    loss = loss.detach()
+    return _LaterValue(loss) if loss.is_cuda else loss.cpu()
 
 
 def _triplet_fused_instance_losses(self, feat, da_ins_labels, img_mean_sig):
