@@ -9,7 +9,8 @@ import os
 from ctypes import POINTER, c_char_p, c_float, c_int, c_int64, c_size_t, c_uint64, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libdadet_hip.so")
+# DADET_LIB: another build of the same library (A/B runs of build-time switches on one box)
+LIB_PATH = os.environ.get("DADET_LIB") or os.path.join(_HERE, "libdadet_hip.so")
 _lib = None
 
 

@@ -457,8 +457,15 @@ __device__ __forceinline__ void conv_fwd_split_body(const ConvArgs& a, char* sme
   else conv_epilogue<TM, TN>(a, acc, bm0, bn0, wm, wn, lane, split_y);
 }
 
+// (64x64 tiles: 97 VGPRs as compiled — one above the 96 that let FIVE wavefronts share a SIMD; its 30 KB of LDS allow five
+// workgroups per CU too.  The bound asks for that occupancy: the short-K layers this variant serves are all prologue and
+// epilogue, and a fifth resident workgroup is one more to cover them.  DADET_FWD_OCC5=0 at BUILD time restores (256, 2).)
+#ifndef DADET_FWD_OCC5
+#define DADET_FWD_OCC5 1
+#endif
 template <int TM, int TN, int TERMS, int AB = 0>
-__global__ __launch_bounds__(256, 2) void conv_fwd_split_kernel(const ConvArgs a) {
+__global__ __launch_bounds__(256, (DADET_FWD_OCC5 && TM * TN == 1 && TERMS == 3 && AB == 0) ? 5 : 2)
+void conv_fwd_split_kernel(const ConvArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int k_lo = a.ksplit ? (int)blockIdx.y * a.ksplit : 0;
   const int k_hi = a.ksplit ? min(a.K, k_lo + a.ksplit) : a.K;
