@@ -172,13 +172,7 @@ class _DCNBottleneckFn(torch.autograd.Function):
             dw2 = wgrad(w2, cols, S2, 1, 0, s2, shape=(cout2, kh * kw * cin2, 1, 1))
         gcols = _C.conv_forward(S2, _C.conv_weight_transpose(w2_1x1, s2))
         gy1, gom = _C.deform_sample_backward_om(y1, om, gcols, kh, kw, 1, kh // 2, 1, dg, modulated)
-        if n_off and _OFFSET_LEGACY:
-            wo4 = _pad_out_channels(w_off, None)[0]
-            own = _C.WgradBatch()
-            dwo = lane.run(lambda: _C.conv_wgrad(y1, gom, tuple(wo4.shape), 1, kh // 2, pending=own), y1, gom)
-            lane.reduce_batch(own, now=True)
-            dwo = dwo[:n_offch]
-        elif n_off:
+        if n_off:
             # gom's rows are padded to a multiple of four channels; the weight gradient keeps the parameter's own shape
             # (conv_wgrad reads the padded rows, dadet_conv_wgrad_partials_ld) and lands in its gradient buffer like every
             # other weight of the block
@@ -186,9 +180,8 @@ class _DCNBottleneckFn(torch.autograd.Function):
         if n_boff:
             dbo = _C.colsum(gom)[:n_offch]
         # d y1 = [y1 > 0] * (sampled path + offset-conv path); the transposed weights carry zero columns for the padding
-        wt_off = (_C.conv_weight_transpose(_pad_out_channels(w_off, None)[0]) if _OFFSET_LEGACY
-                  else _C.conv_weight_transpose(w_off, cout_pad=n_offpad))
-        S1 = _C.conv_forward(gom, wt_off, pad=kh // 2, addend=gy1, out=gy1, relu_mode=2, mask_ref=y1)
+        S1 = _C.conv_forward(gom, _C.conv_weight_transpose(w_off, cout_pad=n_offpad), pad=kh // 2, addend=gy1, out=gy1,
+                             relu_mode=2, mask_ref=y1)
         if n1:
             dw1 = wgrad(w1, x, S1, stride, 0, s1)
         if nd and wd is not None:
@@ -273,9 +266,8 @@ class _PaddedWeights(object):
 
 
 _PADDED = _PaddedWeights()
-# DADET_DCN_OFFSET_LEGACY=1: the offset branch as in the first fused version (weights padded on the spot, their gradient
-# computed on the padded shape, reduced at once, sliced and handed to autograd) — for A/B measurements
-_OFFSET_LEGACY = __import__("os").environ.get("DADET_DCN_OFFSET_LEGACY", "0") == "1"
+# (measured against the first fused version — weights padded on the spot, their gradient computed on the padded shape,
+# reduced at once, sliced and handed to autograd: R-101-FPN-DCN 65.2 -> 64.0 ms per step on one box)
 
 
 def _pad_out_channels(weight, bias):
@@ -283,8 +275,7 @@ def _pad_out_channels(weight, bias):
     pad = (-weight.shape[0]) % 4
     if pad == 0:
         return weight, bias
-    if (not _OFFSET_LEGACY and weight.is_cuda and weight.is_leaf and weight.requires_grad
-            and (bias is None or bias.is_leaf)):
+    if weight.is_cuda and weight.is_leaf and weight.requires_grad and (bias is None or bias.is_leaf):
         return _PADDED.get(weight, bias, pad)
     w = F.pad(weight, (0, 0, 0, 0, 0, 0, 0, pad)).contiguous(memory_format=torch.channels_last)
     return w, (F.pad(bias, (0, pad)) if bias is not None else None)
