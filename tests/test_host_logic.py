@@ -312,3 +312,33 @@ def test_lane_tuner_keeps_one_stream_unless_clearly_faster(monkeypatch):
         t.step_end()
         assert not t.active and streams.WGRAD_LANE_ROWS == want, (times, streams.WGRAD_LANE_ROWS)
     monkeypatch.setattr(streams, "WGRAD_LANE_ROWS", 0)
+
+
+def test_later_value_falls_back_to_a_host_tensor_on_cpu():
+    """da_heads._later_value: on CPU the previous triplet loss is kept as the reference keeps it (a detached CPU tensor);
+    the adaptive-margin rule compares it with 0.0 either way"""
+    from da_detect_amd.modeling.da_heads.da_heads import _later_value
+    from da_detect_amd.modeling.da_heads.loss import TripletMargins
+
+    zero, one = _later_value(torch.tensor(0.0, requires_grad=True) * 1.0), _later_value(torch.tensor(1.0))
+    assert not zero.requires_grad and (zero == 0.0) and not (one == 0.0)
+    m = TripletMargins()
+    a, p, n = torch.randn(1, 8, 3, 4), torch.randn(1, 8, 3, 4), torch.randn(1, 8, 3, 4)
+    m.triplet_img_loss(a, p, n, one, adaptive=True, lr=0.5, max_margin=3.0, margin=1.0)
+    assert m.margin_img == 1.0
+    m.triplet_img_loss(a, p, n, zero, adaptive=True, lr=0.5, max_margin=3.0, margin=1.0)
+    assert m.margin_img == 1.5          # grows only after an exactly-zero loss
+
+
+def test_offset_branch_padding_on_cpu_matches_zero_padding():
+    """backbone.resnet._pad_out_channels: the persistent-buffer cache is a CUDA-only shortcut; on CPU (and for non-leaf
+    weights) the output channels are zero-padded on the spot — same values either way"""
+    from da_detect_amd.modeling.backbone.resnet import _pad_out_channels
+
+    w = torch.nn.Parameter(torch.randn(27, 8, 3, 3))
+    b = torch.nn.Parameter(torch.randn(27))
+    wp, bp = _pad_out_channels(w, b)
+    assert wp.shape == (28, 8, 3, 3) and bp.shape == (28,)
+    assert torch.equal(wp[:27], w) and torch.equal(bp[:27], b) and float(wp[27].abs().sum()) == 0.0 and float(bp[27]) == 0.0
+    w4 = torch.nn.Parameter(torch.randn(28, 8, 3, 3))
+    assert _pad_out_channels(w4, None)[0] is w4
