@@ -323,11 +323,11 @@ def test_later_value_falls_back_to_a_host_tensor_on_cpu():
     zero, one = _later_value(torch.tensor(0.0, requires_grad=True) * 1.0), _later_value(torch.tensor(1.0))
     assert not zero.requires_grad and (zero == 0.0) and not (one == 0.0)
     m = TripletMargins()
-    a, p, n = torch.randn(1, 8, 3, 4), torch.randn(1, 8, 3, 4), torch.randn(1, 8, 3, 4)
-    m.triplet_img_loss(a, p, n, one, adaptive=True, lr=0.5, max_margin=3.0, margin=1.0)
-    assert m.margin_img == 1.0
-    m.triplet_img_loss(a, p, n, zero, adaptive=True, lr=0.5, max_margin=3.0, margin=1.0)
-    assert m.margin_img == 1.5          # grows only after an exactly-zero loss
+    a, p, n = torch.randn(4, 8), torch.randn(4, 8), torch.randn(4, 8)      # (the instance form runs on the CPU)
+    m.triplet_ins_loss(a, p, n, one, adaptive=True, lr=0.5, max_margin=3.0, margin=1.0)
+    assert m.margin_ins == 1.0
+    m.triplet_ins_loss(a, p, n, zero, adaptive=True, lr=0.5, max_margin=3.0, margin=1.0)
+    assert m.margin_ins == 1.5          # grows only after an exactly-zero loss
 
 
 def test_offset_branch_padding_on_cpu_matches_zero_padding():
