@@ -402,6 +402,9 @@ __device__ inline int roi_contributions(const RoiGeom& g, int r, int H, int W, i
   return n;
 }
 
+// (MEASURED, round 3, R-101-FPN-DCN — three launches per step on maps of up to 2 x 256 x 512 pixels, 0.64 ms together: a
+// cover map of the 8 x 8-pixel cells any ROI can reach, so that tiles of untouched cells zero-fill without walking the
+// ROI ranges, changed nothing, 60.2 / 60.4 vs 60.3 / 60.7 ms per step: the empty tiles are not where the time goes.)
 template <int VEC, int MAXC>   // MAXC channel groups per lane: C <= 256 * VEC * MAXC
 __global__ __launch_bounds__(256) void roi_align_bwd_list_kernel(
     const float* __restrict__ grad_out, const float* __restrict__ rois, float* __restrict__ grad_in, int B, int C,
