@@ -333,8 +333,13 @@ def other_in_subprocess(args, name):
         cmd.append("--no-kernel-timing")
     if args.no_overlap:
         cmd.append("--no-overlap")
+    # a plain single-process run, whatever launched this one (under torch.distributed.run with one rank the rendezvous
+    # variables would send the child to the parent's store)
+    env = {k: v for k, v in os.environ.items()
+           if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE", "GROUP_RANK", "ROLE_RANK", "MASTER_ADDR",
+                        "MASTER_PORT") and not k.startswith("TORCHELASTIC_")}
     try:
-        out = subprocess.run(cmd, stdout=subprocess.PIPE, timeout=900, check=True).stdout.decode()
+        out = subprocess.run(cmd, stdout=subprocess.PIPE, timeout=900, check=True, env=env).stdout.decode()
         line = json.loads([l for l in out.splitlines() if l.startswith("{")][-1])
     except Exception as exc:      # noqa: BLE001 — the headline line must still come out
         print("bench.py: the %s run failed: %r" % (name, exc), file=sys.stderr, flush=True)
