@@ -8,8 +8,10 @@ all-reduce when n_gpus > 1) + fused SGD over one such batch; inputs are resident
 Weak scaling: every rank processes its own (source, target) pair.
 Work the recipe never reads is not evaluated (DESIGN.md section 4 "Unread work"; the line's `elided` list says what,
 `flop_per_step` says how many algorithmic FLOPs a step executes, `step_frac` = flop_per_step / time / ceiling).  After
-the headline loop the paper's own recipes (BASELINE configs[2] `da`, configs[3] `triplet`) are timed for a few steps
-each and reported under `other_workloads`.
+the headline loop the other BASELINE recipes (configs[2] `da`, configs[3] `triplet`, configs[4] `fpn_dcn_da`: R-101-FPN +
+DCN) are timed for a few steps each, every one in a process of its own, and reported under `other_workloads`; `resolutions`
+holds `img_only` and `da` at the reference yaml's own training size (INPUT.MIN/MAX_SIZE_TRAIN 600 / 1200 -> 608 x 1216
+padded).  With N > 1 ranks the line carries `comm` (bucket count, all-reduce time, exposed wait in finalize()).
 
 Launch:  python bench.py --gpus 1 --steps K --warmup W
          python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
@@ -41,7 +43,8 @@ BF16_MFMA_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense bf16 MFMA (v_mfma_f
 GEMM_MODES = {
     0: ("exact fp32 MFMA (v_mfma_f32_32x32x2_f32)", 1),
     3: ("fp32 operands split into 3 bf16 terms, 6 x v_mfma_f32_32x32x16_bf16 per K=16, fp32 accumulate "
-        "(measured error <= the exact-fp32 kernel's)", 6),
+        "(error against fp64 at production K: RMS <= 1.1x, max <= 1.5x of the exact-fp32 kernel's error, "
+        "tests/test_ops_gpu.py::test_split_bf16_accuracy_at_production_k)", 6),
     2: ("fp32 operands split into 2 bf16 terms, 3 x v_mfma_f32_32x32x16_bf16 per K=16 (~2^-16 products)", 3),
 }
 
@@ -244,6 +247,8 @@ def run_workload(args, name, device, rank, world, steps, warmup, headline):
         tuner.step_end()
     for _ in range(warmup):
         loss_dict = train_step(model, opt, images, targets)
+    if world > 1:
+        reducer.record_comm(True)
     profiler = None
     if headline and not args.no_kernel_timing and rank == 0:
         # timed region: only the dominant kernel family (128x128-tile forward / data-gradient GEMM) is bracketed —
@@ -260,6 +265,24 @@ def run_workload(args, name, device, rank, world, steps, warmup, headline):
     barrier()
     elapsed = time.perf_counter() - t0
     _C.PROFILER = None
+    comm = reducer.comm_summary() if world > 1 else None
+    reducer.record_comm(False)
+    one_stream = None
+    if headline and world == 1 and streams.lane_in_use() and not args.no_kernel_timing:
+        # the schedule every N > 1 run uses (the tuner is single-process): the same loop with the second GEMM stream off,
+        # so that a scaling curve can be read against a like-for-like N = 1 point
+        saved = (streams.WGRAD_OVERLAP, streams.WGRAD_LANE_ROWS)
+        streams.join_wgrad_lane(device)
+        streams.WGRAD_OVERLAP, streams.WGRAD_LANE_ROWS = False, 0
+        for _ in range(2):
+            train_step(model, opt, images, targets)
+        barrier()
+        t1 = time.perf_counter()
+        for _ in range(steps):
+            train_step(model, opt, images, targets)
+        barrier()
+        one_stream = (time.perf_counter() - t1) / steps
+        streams.WGRAD_OVERLAP, streams.WGRAD_LANE_ROWS = saved
     if mem0 is not None:       # allocator activity inside the timed region (diagnostics, stderr)
         mem1 = torch.cuda.memory_stats(device)
         print("memstats: " + ", ".join("%s %+d" % (k, mem1[k] - mem0[k]) for k in (
@@ -318,10 +341,10 @@ def run_workload(args, name, device, rank, world, steps, warmup, headline):
                 schedule=tuner.report(), profiler=profiler, everything=everything, exclusive=exclusive, extra=extra,
                 extra_elapsed=extra_elapsed, ranks_in_sync=ranks_in_sync, flop_per_step=flop_per_step,
                 lane_overlap=streams.WGRAD_OVERLAP, lane_rows=streams.WGRAD_LANE_ROWS,
-                elided=elided_work(c, model, targets))
+                elided=elided_work(c, model, targets), comm=comm, one_stream=one_stream)
 
 
-def other_in_subprocess(args, name):
+def other_in_subprocess(args, name, image_hw=None):
     """`python bench.py --workload <name> --others none` with this run's settings, in a child process on the same GPU;
     -> the child's line reduced to the `other_workloads` record (None if the child failed: stderr says why)"""
     import subprocess
@@ -329,6 +352,8 @@ def other_in_subprocess(args, name):
     cmd = [sys.executable, os.path.abspath(__file__), "--gpus", "1", "--workload", name, "--others", "none",
            "--steps", str(args.other_steps), "--warmup", str(max(3, args.warmup // 2)), "--no-cpu-baseline",
            "--gemm-mode", str(args.gemm_mode)]
+    if image_hw is not None:
+        cmd += ["--image-hw", image_hw]
     if args.no_kernel_timing:
         cmd.append("--no-kernel-timing")
     if args.no_overlap:
@@ -346,9 +371,11 @@ def other_in_subprocess(args, name):
         return None
     cfg_ = line.get("config", {})
     rec = {"workload": cfg_.get("workload"), "yaml": WORKLOADS[name][0], "images_per_step": WORKLOADS[name][2],
+           "image_hw": cfg_.get("image_hw"),
            "steps": line["steps"], "ms_per_step": line["ms_per_step"], "images_per_s": line["value"],
            "schedule": cfg_.get("schedule"), "elided": line.get("elided"), "process": "its own (python bench.py "
-           "--workload %s --others none --steps %d --warmup %d)" % (name, line["steps"], line["warmup"])}
+           "--workload %s --others none --steps %d --warmup %d%s)" % (
+               name, line["steps"], line["warmup"], "" if image_hw is None else " --image-hw " + image_hw)}
     if line.get("flop_per_step") is not None:
         rec["flop_per_step"] = line["flop_per_step"]
         rec["flop_unit"] = "TFLOP (algorithmic fp32, 2*MAC, all GEMM launches of one step per GPU)"
@@ -371,7 +398,11 @@ def main():
                          "triplet_aligned | fpn_dcn_da (configs[4]); non-default workloads are extra measurements")
     ap.add_argument("--others", default=None,
                     help="comma-separated workloads timed after the headline loop and reported under other_workloads "
-                         "(default: da,triplet next to the default headline, none otherwise; 'none' switches it off)")
+                         "(default: da,triplet,fpn_dcn_da next to the default headline, none otherwise; 'none' switches "
+                         "it off)")
+    ap.add_argument("--resolutions", default=None,
+                    help="HxW at which img_only and da are timed again and reported under `resolutions` (default: 608x1216, "
+                         "the reference yaml's own training size, next to the default headline; 'none' switches it off)")
     ap.add_argument("--other-steps", type=int, default=10)
     ap.add_argument("--image-hw", default=None, help="HxW of the synthetic images (default 1024x2048)")
     ap.add_argument("--no-overlap", action="store_true", help="keep the RPN backward inside the main backward pass")
@@ -396,6 +427,9 @@ def main():
     device = torch.device("cuda", dev_index)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        # the process group then keeps start / end events of every collective on RCCL's stream (Work._get_duration): the
+        # `comm.allreduce_ms` of the line
+        os.environ.setdefault("TORCH_NCCL_ENABLE_TIMING", "1")
         dist.init_process_group(backend="gloo" if share else "nccl", init_method="env://")  # "nccl" is RCCL on ROCm
     assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
 
@@ -409,14 +443,14 @@ def main():
 
     r = run_workload(args, args.workload, device, rank, world, args.steps, args.warmup, headline=True)
     if args.others is None:
-        others = ["da", "triplet"] if (args.workload == "img_only" and args.image_hw is None) else []
+        others = ["da", "triplet", "fpn_dcn_da"] if (args.workload == "img_only" and args.image_hw is None) else []
     else:
         others = [w for w in args.others.split(",") if w and w != "none"]
     other_results = {}
     isolate = world == 1 and os.environ.get("DADET_BENCH_OTHERS_IN_PROCESS") != "1"
     for name in others:
-        # the paper's own recipes on the same GPU(s), same sizes, a few steps each: the headline recipe is the one that
-        # loses the most work to `elided`, these two lose the least
+        # the other BASELINE recipes on the same GPU(s), same sizes, a few steps each: the headline recipe is the one that
+        # loses the most work to `elided`, `da` / `triplet` lose the least; `fpn_dcn_da` is the one furthest from the roofline
         if isolate:
             # Single-process runs time each of them in a process of its own, as a training run of that recipe is.  Built
             # as the SECOND model of this process, `da` was measured 7 - 9% slower than alone (29.9 vs 27.3 ms per step on
@@ -444,6 +478,16 @@ def main():
         if o["ranks_in_sync"] is not None:
             rec["ranks_in_sync_after_run"] = o["ranks_in_sync"]
         other_results[name] = rec
+
+    resolutions = {}
+    default_run = args.workload == "img_only" and args.image_hw is None
+    res_hw = ("608x1216" if default_run else "none") if args.resolutions is None else args.resolutions
+    if res_hw != "none" and world == 1 and isolate:
+        # SURVEY.md 8(d) "report both": the shipped yaml resizes Cityscapes to 600 x 1200 (608 x 1216 after padding to /32)
+        for name in ("img_only", "da"):
+            rec = other_in_subprocess(args, name, image_hw=res_hw)
+            if rec is not None:
+                resolutions["%s@%s" % (name, res_hw)] = rec
 
     if rank == 0:
         elapsed, steps = r["elapsed"], r["steps"]
@@ -499,8 +543,28 @@ def main():
             if exclusive is not None:
                 ek = exclusive.summary().get(name)
                 if ek:
-                    roofline["gemm_streams"]["exclusive_tflops"] = round(ek["achieved"] / 1e12, 2)
-                    roofline["gemm_streams"]["exclusive_frac"] = round(ek["achieved"] / 1e12 / peak, 4)
+                    # The headline `frac` is a KERNEL figure: it must not move with a per-box schedule decision.  When the
+                    # tuner kept the second GEMM stream, the launches bracketed in the timed region shared the GPU with a
+                    # weight-gradient GEMM; `achieved` / `frac` / `avg_launch_ms` then come from the extra pass that ran
+                    # the same launches with the second stream off (HIP events, same process, right after the timed
+                    # loop), and the under-contention numbers of the timed region move to gemm_streams.shared_*.
+                    gs = roofline["gemm_streams"]
+                    gs["shared_tflops"], gs["shared_frac"] = roofline["achieved"], roofline["frac"]
+                    gs["shared_avg_launch_ms"] = roofline["avg_launch_ms"]
+                    gs["exclusive_tflops"] = round(ek["achieved"] / 1e12, 2)
+                    gs["exclusive_frac"] = round(ek["achieved"] / 1e12 / peak, 4)
+                    ex = ek["achieved"] / 1e12
+                    roofline.update({"achieved": round(ex, 2), "frac": round(ex / peak, 4),
+                                     "avg_launch_ms": round(ek["avg_ms"], 4),
+                                     "executed_mfma_tflops": round(ex * mfma_per_product, 1),
+                                     "vs_fp32_mfma_peak": round(ex / FP32_MFMA_PEAK_TFLOPS, 3),
+                                     "measured_in": "extra untimed pass of %d steps with the second GEMM stream off (the "
+                                                    "timed region's launches share the GPU: gemm_streams.shared_*)" % r["extra"]})
+            elif roofline is not None:
+                roofline["measured_in"] = "timed region (one GEMM stream: a bracketed launch has the GPU to itself)"
+                if "gemm_streams" in roofline:
+                    roofline["gemm_streams"]["exclusive_tflops"] = roofline["achieved"]
+                    roofline["gemm_streams"]["exclusive_frac"] = roofline["frac"]
         cpu = None
         if not args.no_cpu_baseline and world == 1:
             try:
@@ -531,6 +595,7 @@ def main():
             "elided": r["elided"],
             "roofline": roofline, "cpu_baseline": cpu,
             "other_workloads": other_results,
+            "resolutions": resolutions,
             "kernel_timing": {k: {"launches": v["launches"], "total_ms": round(v["total_ms"], 3),
                                   "tflops": round(v["achieved"] / 1e12, 2)} for k, v in kernels.items()},
             "final_losses": {k: round(v, 5) for k, v in r["losses"].items()},
@@ -545,6 +610,17 @@ def main():
                                                "of the same batch incl. its redundant second box-head pass (SURVEY.md 8d)"}
         if r["ranks_in_sync"] is not None:
             line["config"]["ranks_in_sync_after_run"] = r["ranks_in_sync"]
+        if r["one_stream"] is not None:
+            # N > 1 runs keep one GEMM stream (engine.trainer.WgradLaneTuner is single-process): the like-for-like N = 1 point
+            line["one_stream"] = {"ms_per_step": round(r["one_stream"] * 1e3, 3),
+                                  "value": round(world * images_per_gpu / r["one_stream"], 3), "unit": "images/s",
+                                  "note": "the same timed loop with the second GEMM stream off — the schedule every "
+                                          "N > 1 run uses; compute scaling efficiency against this value"}
+        elif world == 1:
+            line["one_stream"] = {"ms_per_step": round(ms_per_step, 3), "value": round(value, 3), "unit": "images/s",
+                                  "note": "the headline run already used one GEMM stream"}
+        if r["comm"] is not None:
+            line["comm"] = r["comm"]
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()

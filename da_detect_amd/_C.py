@@ -437,7 +437,11 @@ def weight_epoch():
 
 
 def bump_weight_epoch(device=None):
-    """weights were updated in place through raw pointers (the fused SGD kernel): cached derived forms are stale"""
+    """weights were updated in place through raw pointers (the fused SGD kernel) or through `.data` (a broadcast, a
+    checkpoint load, an EMA, a manual `p.data.copy_`): cached derived forms are stale.  REQUIRED after any weight write
+    that does not go through autograd's version counter — the data-gradient GEMMs otherwise keep using the transposed /
+    padded copies of the old values.  FusedSGD.step, BucketedGradReducer.broadcast_parameters and Checkpointer.load call
+    it themselves."""
     _TRANSPOSES.bump(device)
 
 
@@ -948,6 +952,7 @@ def fast_rcnn_loss_rows(class_logits, box_regression, loss_labels, regression_ta
 
 
 SAMPLE_ROIS_MAX = 4096
+PROPOSALS_SAMPLE_MAX_GT = 1024      # ground-truth boxes per image dadet_proposals_sample holds in LDS (csrc/sampling.hip)
 
 
 def sample_rois_buffers(rows, device):

@@ -29,7 +29,7 @@ __device__ inline void buf_store1(__amdgpu_buffer_rsrc_t r, unsigned byte_off, f
 }
 
 // Write-through (sc1) 16-byte stores and sc1 loads for tiles handed from one workgroup to another INSIDE a launch (the
-// stream-K tail, the in-kernel reduction of the weight-gradient splits).  The XCDs' L2s are not coherent with each other:
+// stream-K tail).  The XCDs' L2s are not coherent with each other:
 // a plain store may sit dirty in the producer's L2.  An agent-scope release fence writes the whole L2 back (~2 - 6 us
 // each: with one per workgroup the fused weight-gradient reduction made the step 2x SLOWER); write-through stores drained
 // with s_waitcnt vmcnt(0) before the arrival counter is bumped, and sc1 loads on the consumer side, need no fence
@@ -82,11 +82,6 @@ struct WgradArgs {
   int direct;       // 1: write dw with scale / accumulate applied here
   int accumulate;
   unsigned x_bytes, gy_bytes;
-  // in-kernel reduction of the splits (conv_wgrad_split_kernel): the workgroup that parks a tile's LAST partial result
-  // sums the `splits` partials in split order, applies out_scale / accumulate and writes `final`; nullptr: the partials
-  // are left for wgrad_reduce_kernel
-  int* counters;    // one per (co, kc) tile, zero between launches
-  float* final;
 };
 
 // tile variant chosen for a forward / dgrad GEMM of M rows and Cout columns
@@ -109,7 +104,6 @@ inline int fwd_variant(int M, int Cout) {
 int gemm_mode();
 int launch_fwd_split(ConvArgs& a, int variant, int terms, hipStream_t st);
 int launch_fwd_split_sk(ConvArgs& a, int terms, hipStream_t st);
-int launch_fwd_split_db(ConvArgs& a, hipStream_t st);
 int launch_wgrad_split(WgradArgs& a, int terms, hipStream_t st);
 
 }  // namespace dadet

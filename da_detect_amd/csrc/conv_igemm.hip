@@ -749,12 +749,6 @@ extern "C" int dadet_conv_forward(const dadet_conv_desc* d, const float* x, cons
   a.sk_counters = nullptr;
   if (gemm_mode() != 0) {
     const int variant = split_fwd_variant(a.M, a.Cout, a.K);
-    {
-      // experiment (DADET_DB=1): double-buffered K-steps of 16 for the 128x128 variant, whole-K launches only
-      const char* env = getenv("DADET_DB");
-      if (env && env[0] == '1' && variant == 0 && gemm_mode() == 3 && a.Cin % 16 == 0 && !a.ablate)
-        return launch_fwd_split_db(a, st);
-    }
     SkPlan sk;
     if (streamk_plan(a, variant, &sk)) {
       // partial tiles in the per-stream scratch (reused in stream order), arrival counters in their own buffer
@@ -859,7 +853,7 @@ extern "C" int dadet_conv_wgrad_workspace_bytes(const dadet_conv_desc* d, size_t
   if (d->N == 0) { *bytes_out = 0; return DADET_OK; }
   int tco, tkc, splits, rps;
   wgrad_plan(d, &tco, &tkc, &splits, &rps);
-  // whole 128 x 128 tiles: the in-kernel reduction parks the partial tiles lane-linear, ragged edges included
+  // (rounded up to whole 128 x 128 tiles)
   *bytes_out = splits > 1 ? sizeof(float) * (size_t)splits * tco * tkc * 128 * 128 : 0;
   return DADET_OK;
 }
@@ -908,25 +902,9 @@ static int conv_wgrad_impl(const dadet_conv_desc* d, const float* x, const float
     a.direct = 0;
     a.out = static_cast<float*>(workspace);
   }
-  a.counters = nullptr;
-  a.final = dw;
-  {
-    // DADET_WGRAD_FUSED=1: the last-arriving split of a tile sums the partials inside the GEMM kernel instead of the
-    // separate wgrad_reduce_kernel pass (46 launches, 0.7 ms of kernel time per step).  OFF by default — measured on the
-    // BASELINE step: 32.1 ms against 28.8 ms.  Every one of the ~800 workgroups of a launch must publish its 64 KB tile
-    // write-through (2.4 GB per step through the fabric, ~3 us on every workgroup's tail), where the separate pass reads
-    // partials that mostly still sit in L2 / MALL; with agent-scope release fences instead it was 66.7 ms (one L2
-    // write-back per workgroup).  The stream-K tail of the forward kernels uses the same hand-off and wins because only
-    // the few workgroups that cut a tile publish.  Results are bit-identical either way (tests/test_ops_gpu.py).
-    const char* env = getenv("DADET_WGRAD_FUSED");
-    if (a.splits > 1 && gemm_mode() != 0 && env && env[0] == '1' && a.tiles_co * a.tiles_kc <= kSkCounters) {
-      a.counters = stream_counters(st);
-      if (!a.counters) {
-        set_error("conv_wgrad: could not allocate the arrival counters");
-        return DADET_ELAUNCH;
-      }
-    }
-  }
+  // (measured and removed, round 2: the last-arriving split of a tile summing the partials inside the GEMM kernel — 32.1 ms
+  // against 28.8 ms per step: every one of the ~800 workgroups of a launch had to publish its 64 KB tile write-through, where
+  // the separate pass reads partials that mostly still sit in L2 / MALL)
   const size_t lds = sizeof(float) * 2 * 32 * 128;  // 32 KB: three workgroups per CU
   static bool attr_set = false;
   if (!attr_set) {
@@ -945,7 +923,7 @@ static int conv_wgrad_impl(const dadet_conv_desc* d, const float* x, const float
     rc = check_launch("conv_wgrad");
   }
   if (rc) return rc;
-  if (a.splits > 1 && !a.counters && pending) {      // the caller batches the reduction passes
+  if (a.splits > 1 && pending) {      // the caller batches the reduction passes
     pending->partials = static_cast<const float*>(workspace);
     pending->out_scale = out_scale;
     pending->dw = dw;
@@ -955,7 +933,7 @@ static int conv_wgrad_impl(const dadet_conv_desc* d, const float* x, const float
     pending->accumulate = accumulate;
     return DADET_OK;
   }
-  if (a.splits > 1 && !a.counters) {
+  if (a.splits > 1) {
     const int64_t total4 = (int64_t)d->Cout * K / 4;
     int64_t blocks = ceil_div64(total4, 256);
     if (blocks > kMaxStreamBlocks) blocks = kMaxStreamBlocks;

@@ -22,10 +22,6 @@ namespace dadet {
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 constexpr int PLANE_STRIDE = 40;  // bf16 per staged row: 32 + 8 pad = 80 bytes
-#ifndef DADET_PRIO_SPLIT
-#define DADET_PRIO_SPLIT 0   /* measured: no effect on MFMA-only or full kernels; kept for experiments */
-#endif
-constexpr bool PRIO_SPLIT = DADET_PRIO_SPLIT != 0;
 
 static int g_gemm_mode = 3;
 int gemm_mode() { return g_gemm_mode; }
@@ -213,14 +209,6 @@ __device__ __forceinline__ void conv_fwd_split_body(const ConvArgs& a, char* sme
   const int lane = t & 63, wave = t >> 6;
   const int wm = wave >> 1, wn = wave & 1;
   const int lcol = t & 7;
-  // Two workgroups share a CU, i.e. two waves share each SIMD's matrix pipe.  With equal priority they advance in
-  // lockstep and reach their barrier / LDS-store sections at the same time, leaving the pipe idle; a static priority
-  // by hardware wave slot (HW_ID.wave_id bit 0: co-resident waves of one SIMD sit in different slots) lets one run
-  // its MFMA phase at full rate while the other fills the gaps.
-  if (PRIO_SPLIT) {
-    const unsigned slot = __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 4);   // HW_REG_HW_ID, wave_id[3:0]
-    if (slot & 1u) __builtin_amdgcn_s_setprio(2);
-  }
   // staged row of this thread.  Eight lanes write one row's 64 bytes; a ds_write_b64 is serviced in 16-lane
   // groups over 32 banks, and with 80-byte rows two rows are bank-disjoint exactly when they are 4 (mod 8) apart,
   // so consecutive 8-lane groups take rows r and r + 4 (PMC: 33% of LDS cycles were conflicts with r, r + 1).
@@ -515,421 +503,10 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_split_sk_kernel(const ConvArg
   }
 }
 
-// ------------------------------------------------------------------------------------------------
-// Double-buffered variant of the 128x128 kernel with K-steps of 16 (experiment, DADET_DB=1).
-// conv_fwd_split_body keeps ONE LDS image of a 32-deep K-tile and pays, per K-tile, "barrier, 12 ds_writes, barrier" with
-// no MFMA in flight for that workgroup (stage ablation: 0.16 of 1.61 ms on the RPN conv).  Here a K-step is 16 deep
-// (one MFMA k-group), the LDS holds TWO steps (2 x 3 planes x 256 rows x 48 B = 72 KB: two workgroups per CU still fit),
-// and the planes of step s + 1 are written into the other buffer WHILE the MFMAs of step s run — one barrier per step
-// and no store phase.  48-byte rows: ds_read_b128 of 16 consecutive rows and ds_write_b64 of 8 same-parity rows each
-// cover all 64 banks exactly once.
-constexpr int DB_STRIDE = 24;   // bf16 per staged row: 16 + 8 pad = 48 bytes
-
-template <int TERMS>
-__global__ __launch_bounds__(256, 2) void conv_fwd_split_db_kernel(const ConvArgs a) {
-  constexpr int TM = 2, TN = 2, BM = 128, BN = 128, KS = 16;
-  constexpr int PLANE = 128 * DB_STRIDE;                 // bf16 elements of one operand plane
-  constexpr int BUF = 2 * TERMS * PLANE;                 // one buffer: A planes then B planes
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  __bf16* lds = reinterpret_cast<__bf16*>(smem);
-  const int tile = xcd_remap(blockIdx.x, a.tiles_m * a.tiles_n);
-  const int bm0 = (tile / a.tiles_n) * BM;
-  const int bn0 = (tile % a.tiles_n) * BN;
-  const int t = threadIdx.x;
-  const int lane = t & 63, wave = t >> 6;
-  const int wm = wave >> 1, wn = wave & 1;
-  const int lcol = t & 3;                                // 4 lanes x 4 floats = the 16 k of a row
-  const int slot = lane >> 2;                            // 16 row slots per wave: 8 even rows, then 8 odd rows
-  const int lrow = wave * 16 + (slot < 8 ? 2 * slot : 2 * (slot - 8) + 1);
-
-  const __amdgpu_buffer_rsrc_t xr = make_rsrc(a.x, a.x_bytes);
-  const __amdgpu_buffer_rsrc_t wr = make_rsrc(a.w, a.w_bytes);
-  int pixbase[2], hi0[2], wi0[2];
-  const int HoWo = a.Ho * a.Wo;
-#pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    const int m = bm0 + lrow + 64 * i;
-    if (m < a.M) {
-      const int img = m / HoWo;
-      const int rem = m - img * HoWo;
-      const int ho = rem / a.Wo;
-      const int wo = rem - ho * a.Wo;
-      pixbase[i] = img * a.H * a.W;
-      hi0[i] = ho * a.stride - a.pad;
-      wi0[i] = wo * a.stride - a.pad;
-    } else {
-      pixbase[i] = 0;
-      hi0[i] = -(1 << 28);
-      wi0[i] = 0;
-    }
-  }
-  unsigned wrow[2];
-#pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    const int n = bn0 + lrow + 64 * i;
-    wrow[i] = n < a.Cout ? (unsigned)n * (unsigned)a.K * 4u : kOOB;
-  }
-  float4 ra[2], rb[2];
-  int kk = lcol * 4;
-  int tap = kk / a.Cin;
-  int kc = kk - tap * a.Cin;
-  int kr = tap / a.KW;
-  int ks = tap - kr * a.KW;
-  auto load_ab = [&]() {
-    const bool kvalid = kk < a.K;
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int hi = hi0[i] + kr, wi = wi0[i] + ks;
-      const bool ok = kvalid && (unsigned)hi < (unsigned)a.H && (unsigned)wi < (unsigned)a.W;
-      const unsigned off = ((unsigned)(pixbase[i] + hi * a.W + wi) * (unsigned)a.Cin + (unsigned)kc) * 4u;
-      ra[i] = buf_load4(xr, ok ? off : kOOB);
-    }
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-      rb[i] = buf_load4(wr, (kvalid && wrow[i] != kOOB) ? wrow[i] + (unsigned)kk * 4u : kOOB);
-  };
-  auto advance = [&]() {
-    kk += KS;
-    kc += KS;
-    while (kc >= a.Cin) {
-      kc -= a.Cin;
-      if (++ks == a.KW) {
-        ks = 0;
-        ++kr;
-      }
-    }
-  };
-  uint2 pa_[2][TERMS], pb_[2][TERMS];
-  auto split_ab = [&]() {
-#pragma unroll
-    for (int i = 0; i < 2; ++i) split4<TERMS>(ra[i], pa_[i]);
-#pragma unroll
-    for (int i = 0; i < 2; ++i) split4<TERMS>(rb[i], pb_[i]);
-  };
-  auto store_step = [&](int buf) {
-    __bf16* As = lds + buf * BUF;
-    __bf16* Bs = As + TERMS * PLANE;
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-      for (int p = 0; p < TERMS; ++p) {
-        *reinterpret_cast<uint2*>(As + p * PLANE + (lrow + 64 * i) * DB_STRIDE + lcol * 4) = pa_[i][p];
-        *reinterpret_cast<uint2*>(Bs + p * PLANE + (lrow + 64 * i) * DB_STRIDE + lcol * 4) = pb_[i][p];
-      }
-  };
-
-  f32x16 acc[TM][TN];
-#pragma unroll
-  for (int i = 0; i < TM; ++i)
-#pragma unroll
-    for (int j = 0; j < TN; ++j)
-#pragma unroll
-      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
-
-  const int nsteps = (a.K + KS - 1) / KS;
-  load_ab();
-  advance();
-  split_ab();
-  store_step(0);
-  load_ab();       // step 1 is in flight while step 0 is multiplied
-  advance();
-  __syncthreads();
-
-  const int frag_row = lane & 31;
-  const int frag_k = (lane >> 5) * 8;
-  const int a_off = (wm * 64 + frag_row) * DB_STRIDE + frag_k;
-  const int b_off = TERMS * PLANE + (wn * 64 + frag_row) * DB_STRIDE + frag_k;
-  for (int s = 0; s < nsteps; ++s) {
-    const __bf16* cur = lds + (s & 1) * BUF;
-    bf16x8 fa[TERMS][TM], fb[TERMS][TN];
-#pragma unroll
-    for (int p = 0; p < TERMS; ++p) {
-#pragma unroll
-      for (int i = 0; i < TM; ++i)
-        fa[p][i] = *reinterpret_cast<const bf16x8*>(cur + a_off + p * PLANE + i * 32 * DB_STRIDE);
-#pragma unroll
-      for (int i = 0; i < TN; ++i)
-        fb[p][i] = *reinterpret_cast<const bf16x8*>(cur + b_off + p * PLANE + i * 32 * DB_STRIDE);
-    }
-    // step s + 1's operands landed a step ago: split them in the shadow of the MFMAs and write them into the OTHER buffer
-    // (every wave finished reading it before the barrier that ended step s - 1)
-    split_ab();
-#pragma unroll
-    for (int order = 2 * (TERMS - 1); order >= 0; --order) {
-#pragma unroll
-      for (int pa = 0; pa < TERMS; ++pa) {
-        const int pb = order - pa;
-        if (pb < 0 || pb >= TERMS) continue;
-        if (pa + pb > TERMS - 1) continue;
-#pragma unroll
-        for (int im = 0; im < TM; ++im)
-#pragma unroll
-          for (int in = 0; in < TN; ++in)
-            acc[im][in] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[pa][im], fb[pb][in], acc[im][in], 0, 0, 0);
-      }
-    }
-    store_step((s + 1) & 1);
-    {
-      constexpr int kMfma = TM * TN * (TERMS == 3 ? 6 : 3);
-      constexpr int kValuPerMfma = 4 * (TERMS == 3 ? 26 : 14) / kMfma + 1;
-      __builtin_amdgcn_sched_group_barrier(0x100, TERMS * (TM + TN), 0);   // DS reads
-#pragma unroll
-      for (int i = 0; i < kMfma; ++i) {
-        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                 // one MFMA
-        __builtin_amdgcn_sched_group_barrier(0x002, kValuPerMfma, 0);      // VALU in its shadow
-        if (i >= kMfma / 2 && i < kMfma / 2 + 4 * TERMS)
-          __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);               // one DS write per MFMA in the second half
-      }
-    }
-    load_ab();     // step s + 2 (out of range past the end: zeros)
-    advance();
-    __syncthreads();
-  }
-  conv_epilogue<TM, TN>(a, acc, bm0, bn0, wm, wn, lane, 0);
-}
-
-// ------------------------------------------------------------------------------------------------
-// Wave-specialised variant of the 128x128 split kernel (8 wavefronts): waves 0-3 are CONSUMERS (LDS fragment
-// reads + bf16 MFMAs on a 64x64 sub-tile each), waves 4-7 are PRODUCERS (buffer loads of tile t+2, operand
-// split of tile t+1, ds_writes into the other LDS buffer).  A SIMD hosts one consumer and one producer wave, so
-// the matrix pipe and the VALU / memory pipes run concurrently by construction instead of by luck
-// (stage ablation of the 4-wave kernel on the RPN conv: MFMAs alone 1.0 ms, everything else alone 1.0 ms,
-// together 1.74 ms — the two halves barely overlapped).  LDS is double buffered (2 x TERMS x 256 rows x 80 B =
-// 120 KB), one barrier per K-tile, one workgroup per CU.
-template <int TERMS>
-__global__ __launch_bounds__(512, 2) void conv_fwd_split_ws_kernel(const ConvArgs a) {
-  constexpr int BM = 128, BN = 128, TM = 2, TN = 2;
-  constexpr int A_LOADS = BM / 32, B_LOADS = BN / 32;
-  constexpr int A_PLANE = BM * PLANE_STRIDE, B_PLANE = BN * PLANE_STRIDE;
-  constexpr int BUF = TERMS * (A_PLANE + B_PLANE);  // bf16 elements per LDS buffer
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  __bf16* lds = reinterpret_cast<__bf16*>(smem);
-
-  const int nwg = a.tiles_m * a.tiles_n;
-  const int tile = xcd_remap(blockIdx.x, nwg);
-  const int bm0 = (tile / a.tiles_n) * BM;
-  const int bn0 = (tile % a.tiles_n) * BN;
-  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int lane = threadIdx.x & 63;
-  const int nk = (a.K + BK - 1) / BK;
-  const int HoWo = a.Ho * a.Wo;
-
-  if (wave >= 4) {
-    // ------------------------------------------------------------------ producers
-    const int t = threadIdx.x - 256;
-    const int lcol = t & 7;
-    const int lgrp = t >> 3;
-    const int lrow = (lgrp >> 3) * 8 + (lgrp & 1) * 4 + ((lgrp >> 1) & 3);  // conflict-free ds_write_b64 rows
-    const __amdgpu_buffer_rsrc_t xr = make_rsrc(a.x, a.x_bytes);
-    const __amdgpu_buffer_rsrc_t wr = make_rsrc(a.w, a.w_bytes);
-    int pixbase[A_LOADS], hi0[A_LOADS], wi0[A_LOADS];
-#pragma unroll
-    for (int i = 0; i < A_LOADS; ++i) {
-      const int m = bm0 + lrow + 32 * i;
-      if (m < a.M) {
-        const int img = m / HoWo;
-        const int rem = m - img * HoWo;
-        const int ho = rem / a.Wo;
-        const int wo = rem - ho * a.Wo;
-        pixbase[i] = img * a.H * a.W;
-        hi0[i] = ho * a.stride - a.pad;
-        wi0[i] = wo * a.stride - a.pad;
-      } else {
-        pixbase[i] = 0;
-        hi0[i] = -(1 << 28);
-        wi0[i] = 0;
-      }
-    }
-    unsigned wrow[B_LOADS];
-#pragma unroll
-    for (int i = 0; i < B_LOADS; ++i) {
-      const int n = bn0 + lrow + 32 * i;
-      wrow[i] = n < a.Cout ? (unsigned)n * (unsigned)a.K * 4u : kOOB;
-    }
-    float4 ra[A_LOADS], rb[B_LOADS];
-    int kk = lcol * 4;
-    int tap = kk / a.Cin;
-    int kc = kk - tap * a.Cin;
-    int kr = tap / a.KW;
-    int ks = tap - kr * a.KW;
-    auto load_tile = [&]() {
-      const bool kvalid = kk < a.K;
-#pragma unroll
-      for (int i = 0; i < A_LOADS; ++i) {
-        const int hi = hi0[i] + kr, wi = wi0[i] + ks;
-        const bool ok = kvalid && (unsigned)hi < (unsigned)a.H && (unsigned)wi < (unsigned)a.W;
-        const unsigned off = ((unsigned)(pixbase[i] + hi * a.W + wi) * (unsigned)a.Cin + (unsigned)kc) * 4u;
-        ra[i] = buf_load4(xr, ok ? off : kOOB);
-      }
-#pragma unroll
-      for (int i = 0; i < B_LOADS; ++i)
-        rb[i] = buf_load4(wr, (kvalid && wrow[i] != kOOB) ? wrow[i] + (unsigned)kk * 4u : kOOB);
-      kk += BK;
-      kc += BK;
-      while (kc >= a.Cin) {
-        kc -= a.Cin;
-        if (++ks == a.KW) {
-          ks = 0;
-          ++kr;
-        }
-      }
-    };
-    uint2 pa_[A_LOADS][TERMS], pb_[B_LOADS][TERMS];
-    auto split_tile = [&]() {
-#pragma unroll
-      for (int i = 0; i < A_LOADS; ++i) split4<TERMS>(ra[i], pa_[i]);
-#pragma unroll
-      for (int i = 0; i < B_LOADS; ++i) split4<TERMS>(rb[i], pb_[i]);
-    };
-    auto store_tile = [&](int buf) {
-      __bf16* As = lds + buf * BUF;
-      __bf16* Bs = As + TERMS * A_PLANE;
-#pragma unroll
-      for (int i = 0; i < A_LOADS; ++i)
-#pragma unroll
-        for (int p = 0; p < TERMS; ++p)
-          *reinterpret_cast<uint2*>(As + p * A_PLANE + (lrow + 32 * i) * PLANE_STRIDE + lcol * 4) = pa_[i][p];
-#pragma unroll
-      for (int i = 0; i < B_LOADS; ++i)
-#pragma unroll
-        for (int p = 0; p < TERMS; ++p)
-          *reinterpret_cast<uint2*>(Bs + p * B_PLANE + (lrow + 32 * i) * PLANE_STRIDE + lcol * 4) = pb_[i][p];
-    };
-    load_tile();                 // tile 0
-    split_tile();
-    if (nk > 1) load_tile();     // tile 1 in flight
-    store_tile(0);
-    __syncthreads();             // buffer 0 published
-    for (int kt = 0; kt < nk; ++kt) {
-      if (kt + 1 < nk) {
-        split_tile();                      // tile kt+1 (its loads were issued one iteration ago)
-        if (kt + 2 < nk) load_tile();      // tile kt+2 goes in flight, registers are free again
-        store_tile((kt + 1) & 1);
-      }
-      __syncthreads();
-    }
-    return;
-  }
-
-  // -------------------------------------------------------------------- consumers
-  const int wm = wave >> 1, wn = wave & 1;
-  f32x16 acc[TM][TN];
-#pragma unroll
-  for (int i = 0; i < TM; ++i)
-#pragma unroll
-    for (int j = 0; j < TN; ++j)
-#pragma unroll
-      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
-  const int frag_row = lane & 31;
-  const int frag_k = (lane >> 5) * 8;
-  const int a_off = (wm * TM * 32 + frag_row) * PLANE_STRIDE + frag_k;
-  const int b_off = TERMS * A_PLANE + (wn * TN * 32 + frag_row) * PLANE_STRIDE + frag_k;
-  __syncthreads();  // buffer 0 published
-  for (int kt = 0; kt < nk; ++kt) {
-    const __bf16* Ab = lds + (kt & 1) * BUF + a_off;
-    const __bf16* Bb = lds + (kt & 1) * BUF + b_off;
-#pragma unroll
-    for (int step = 0; step < BK / 16; ++step) {
-      bf16x8 fa[TERMS][TM], fb[TERMS][TN];
-#pragma unroll
-      for (int p = 0; p < TERMS; ++p) {
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-          fa[p][i] = *reinterpret_cast<const bf16x8*>(Ab + p * A_PLANE + i * 32 * PLANE_STRIDE + step * 16);
-#pragma unroll
-        for (int i = 0; i < TN; ++i)
-          fb[p][i] = *reinterpret_cast<const bf16x8*>(Bb + p * B_PLANE + i * 32 * PLANE_STRIDE + step * 16);
-      }
-#pragma unroll
-      for (int order = 2 * (TERMS - 1); order >= 0; --order) {
-#pragma unroll
-        for (int pa = 0; pa < TERMS; ++pa) {
-          const int pb = order - pa;
-          if (pb < 0 || pb >= TERMS) continue;
-          if (pa + pb > TERMS - 1) continue;
-#pragma unroll
-          for (int im = 0; im < TM; ++im)
-#pragma unroll
-            for (int in = 0; in < TN; ++in)
-              acc[im][in] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[pa][im], fb[pb][in], acc[im][in], 0, 0, 0);
-        }
-      }
-    }
-    __syncthreads();
-  }
-
-  const __amdgpu_buffer_rsrc_t yr = make_rsrc(a.y, a.y_bytes);
-  const __amdgpu_buffer_rsrc_t ar = make_rsrc(a.addend ? a.addend : a.y, a.addend ? a.y_bytes : 0u);
-  const __amdgpu_buffer_rsrc_t mr = make_rsrc(a.mask_ref ? a.mask_ref : a.y, a.mask_ref ? a.y_bytes : 0u);
-  const int col_in = lane & 31;
-  const int row_hi = 4 * (lane >> 5);
-#pragma unroll
-  for (int in = 0; in < TN; ++in) {
-    const int n = bn0 + wn * TN * 32 + in * 32 + col_in;
-    const bool nvalid = n < a.Cout;
-    const float sc = (a.scale && nvalid) ? a.scale[n] : 1.f;
-    const float bi = (a.bias && nvalid) ? a.bias[n] : 0.f;
-#pragma unroll
-    for (int im = 0; im < TM; ++im) {
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        unsigned offs[4];
-        float add[4], msk[4];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const int m = bm0 + wm * TM * 32 + im * 32 + q + 8 * g + row_hi;
-          unsigned orow = (unsigned)m;
-          if (a.os != 1) {
-            const int img = m / HoWo;
-            const int rem = m - img * HoWo;
-            const int ho = rem / a.Wo;
-            const int wo = rem - ho * a.Wo;
-            orow = (unsigned)((img * a.OutH + ho * a.os) * a.OutW + wo * a.os);
-          }
-          offs[q] = (nvalid && m < a.M) ? (orow * (unsigned)a.Cout + (unsigned)n) * 4u : kOOB;
-        }
-        if (a.addend) {
-#pragma unroll
-          for (int q = 0; q < 4; ++q) add[q] = buf_load1(ar, offs[q]);
-        }
-        if (a.relu_mode == 2) {
-#pragma unroll
-          for (int q = 0; q < 4; ++q) msk[q] = buf_load1(mr, offs[q]);
-        }
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          float v = acc[im][in][g * 4 + q];
-          if (a.scale) v = v * sc;
-          if (a.bias) v = v + bi;
-          if (a.addend) v = v + add[q];
-          if (a.relu_mode == 1) v = fmaxf(v, 0.f);
-          else if (a.relu_mode == 2) v = (msk[q] > 0.f) ? v : 0.f;
-          buf_store1(yr, offs[q], v);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-      }
-    }
-  }
-}
-
-template <int TERMS>
-static int launch_split_ws(ConvArgs& a, hipStream_t st) {
-  a.tiles_m = ceil_div(a.M, 128);
-  a.tiles_n = ceil_div(a.Cout, 128);
-  const size_t lds = sizeof(__bf16) * 2 * TERMS * 256 * PLANE_STRIDE;
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_fwd_split_ws_kernel<TERMS>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) {
-      set_error("conv_forward(split, wave-specialised): hipFuncSetAttribute: %s", hipGetErrorString(e));
-      return DADET_ELAUNCH;
-    }
-    attr_set = true;
-  }
-  hipLaunchKernelGGL((conv_fwd_split_ws_kernel<TERMS>), dim3(a.tiles_m * a.tiles_n), dim3(512), lds, st, a);
-  return check_launch("conv_forward(split, wave-specialised)");
-}
+// (measured and removed, rounds 1 - 2: a double-buffered variant with K-steps of 16 — +1.7% on the RPN conv, +6% on res5
+// 3x3, -2 .. -4% on the 256-tile layers; a wave-specialised producer / consumer variant with 8 wavefronts — the same as the
+// 4-wave kernel on long-K layers, slower on short-K ones; a static wave priority by hardware wave slot — no effect.
+// DESIGN.md section 6.)
 
 template <int TM, int TN, int TERMS, int AB = 0>
 static int launch_split(ConvArgs& a, hipStream_t st) {
@@ -970,24 +547,6 @@ static int launch_split_sk(ConvArgs& a, hipStream_t st) {
   return check_launch("conv_forward(split, stream-K)");
 }
 
-int launch_fwd_split_db(ConvArgs& a, hipStream_t st) {
-  a.tiles_m = ceil_div(a.M, 128);
-  a.tiles_n = ceil_div(a.Cout, 128);
-  const size_t lds = sizeof(__bf16) * 2 * 2 * 3 * 128 * DB_STRIDE;
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_fwd_split_db_kernel<3>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) {
-      set_error("conv_forward(split, double-buffered): hipFuncSetAttribute: %s", hipGetErrorString(e));
-      return DADET_ELAUNCH;
-    }
-    attr_set = true;
-  }
-  hipLaunchKernelGGL((conv_fwd_split_db_kernel<3>), dim3(a.tiles_m * a.tiles_n), dim3(256), lds, st, a);
-  return check_launch("conv_forward(split, double-buffered)");
-}
-
 int launch_fwd_split_sk(ConvArgs& a, int terms, hipStream_t st) {
   a.tiles_m = ceil_div(a.M, 128);
   a.tiles_n = ceil_div(a.Cout, 128);
@@ -995,10 +554,6 @@ int launch_fwd_split_sk(ConvArgs& a, int terms, hipStream_t st) {
 }
 
 int launch_fwd_split(ConvArgs& a, int variant, int terms, hipStream_t st) {
-  // the producer/consumer variant measured the same as the 4-wave kernel on long-K layers and slower on short-K
-  // ones (one workgroup per CU): opt-in for experiments only
-  static const bool use_ws = getenv("DADET_WS") && atoi(getenv("DADET_WS"));
-  if (variant == 0 && use_ws) return terms == 2 ? launch_split_ws<2>(a, st) : launch_split_ws<3>(a, st);
   if (a.ablate && variant == 0 && terms == 3) {   // profiling experiments only (DADET_ABLATE)
     switch (a.ablate) {
       case 1: return launch_split<2, 2, 3, 1>(a, st);
@@ -1214,52 +769,8 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_split_kernel(const WgradArg
     }
   }
 
-  const bool fused = !a.direct && a.counters;
-  if (fused) {
-    // in-kernel reduction over the splits: every split parks its tile lane-linear (16-byte write-through stores), the
-    // one that draws the last ticket sums the parts in split order and goes on to the final epilogue
-    __shared__ int s_ticket;
-    const size_t tile_bytes = (size_t)a.splits * TILE * TILE * 4;
-    const __amdgpu_buffer_rsrc_t pr = make_rsrc(reinterpret_cast<const char*>(a.out) + (size_t)tile * tile_bytes,
-                                                (unsigned)tile_bytes);
-    const unsigned mine = (unsigned)split * (TILE * TILE * 4) + (unsigned)t * 16u;
-#pragma unroll
-    for (int im = 0; im < 2; ++im)
-#pragma unroll
-      for (int in = 0; in < 2; ++in)
-#pragma unroll
-        for (int g = 0; g < 4; ++g)
-          buf_store4_wt(pr, mine + ((im * 2 + in) * 4 + g) * 4096u,
-                        make_float4(acc[im][in][g * 4], acc[im][in][g * 4 + 1], acc[im][in][g * 4 + 2],
-                                    acc[im][in][g * 4 + 3]));
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (t == 0) s_ticket = __hip_atomic_fetch_add(a.counters + tile, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __syncthreads();
-    if (s_ticket != a.splits - 1) return;
-    if (t == 0) a.counters[tile] = 0;      // ready for the next launch
-#pragma unroll
-    for (int im = 0; im < 2; ++im)
-#pragma unroll
-      for (int in = 0; in < 2; ++in)
-#pragma unroll
-        for (int e = 0; e < 16; ++e) acc[im][in][e] = 0.f;
-    for (int p = 0; p < a.splits; ++p) {
-      const unsigned src = (unsigned)p * (TILE * TILE * 4) + (unsigned)t * 16u;
-#pragma unroll
-      for (int im = 0; im < 2; ++im)
-#pragma unroll
-        for (int in = 0; in < 2; ++in)
-#pragma unroll
-          for (int g = 0; g < 4; ++g) {
-            const float4 v = buf_load4_sc1(pr, src + ((im * 2 + in) * 4 + g) * 4096u);
-            acc[im][in][g * 4] += v.x; acc[im][in][g * 4 + 1] += v.y;
-            acc[im][in][g * 4 + 2] += v.z; acc[im][in][g * 4 + 3] += v.w;
-          }
-    }
-  }
-  const bool final_out = a.direct || fused;     // this workgroup writes dw itself (scale / accumulate applied here)
-  float* out = a.direct ? a.out : (fused ? a.final : a.out + (size_t)split * a.Cout * a.K);
+  const bool final_out = a.direct;              // this workgroup writes dw itself (scale / accumulate applied here)
+  float* out = a.direct ? a.out : a.out + (size_t)split * a.Cout * a.K;
   const int col_in = lane & 31, row_hi = 4 * (lane >> 5);
 #pragma unroll
   for (int in = 0; in < 2; ++in) {

@@ -29,13 +29,8 @@ class _ROIAlign(Function):
     def backward(ctx, grad_pooled):
         (rois,) = ctx.saved_tensors
         scale, ph, pw, ratio, n, c, h, w = ctx.geometry
-        # weight gradients queued by the preceding node (ROI head's first block) run on the lane beside this gather
-        after = None
-        if grad_pooled.is_cuda and streams.deferred_pending():
-            after = torch.cuda.current_stream(grad_pooled.device).record_event()
         grad_features = _C.roi_align_backward(grad_pooled, rois, scale, ph, pw, n, c, h, w, ratio,
                                               bin_stride=ctx.bin_stride, live_images=ctx.live_images)
-        streams.flush_deferred_wgrads(grad_pooled.device, after)
         return grad_features, None, None, None, None, None, None
 
 

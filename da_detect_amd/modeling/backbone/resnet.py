@@ -55,14 +55,12 @@ class _BottleneckFn(torch.autograd.Function):
     out_private: `out` feeds ONLY a following _BottleneckFn with in_relu (inside _Stage), so G arrives gated."""
 
     @staticmethod
-    def forward(ctx, x, w1, w2, w3, wd, s1, b1, s2, b2, s3, b3, sd, bd, stride, in_relu, out_private,
-                defer_wgrad=False):
+    def forward(ctx, x, w1, w2, w3, wd, s1, b1, s2, b2, s3, b3, sd, bd, stride, in_relu, out_private):
         y1 = _C.conv_forward(x, w1, s1, b1, stride=stride, relu_mode=1)
         y2 = _C.conv_forward(y1, w2, s2, b2, pad=1, relu_mode=1)
         idn = x if wd is None else _C.conv_forward(x, wd, sd, bd, stride=stride)
         out = _C.conv_forward(y2, w3, s3, b3, addend=idn, relu_mode=1)
         ctx.stride, ctx.in_relu, ctx.out_private = stride, in_relu, out_private
-        ctx.defer_wgrad = defer_wgrad
         ctx.save_for_backward(x, y1, y2, out, w1, w2, w3, wd, s1, s2, s3, sd)
         return out
 
@@ -75,9 +73,9 @@ class _BottleneckFn(torch.autograd.Function):
         S3 = G.contiguous(memory_format=torch.channels_last) if ctx.out_private else \
             _C.relu_bn_backward(G, out, None)[1]
         dw1 = dw2 = dw3 = dwd = dx = None
-        lane = WgradLane(G.device, defer=ctx.defer_wgrad, rows=G.shape[0] * G.shape[2] * G.shape[3])
+        lane = WgradLane(G.device, rows=G.shape[0] * G.shape[2] * G.shape[3])
         # the block's 3 - 4 weight gradients share ONE reduction launch over their split partial results (_WGRAD_BATCH)
-        batch = _C.WgradBatch() if (_WGRAD_BATCH and not (ctx.defer_wgrad and streams._DEFER_ENABLED)) else None
+        batch = _C.WgradBatch() if _WGRAD_BATCH else None
 
         def wgrad(w, xin, gout, st, pd, sc):
             return lane.run_into(w, lambda acc: _C.conv_wgrad(xin, gout, tuple(w.shape), st, pd, out_scale=sc, dw=acc,
@@ -110,7 +108,7 @@ class _BottleneckFn(torch.autograd.Function):
                 dx = _C.conv_forward(S1, _C.conv_weight_transpose(w1, s1), addend=t, out=t,
                                      out_spatial_stride=stride, out_hw=hw, **gate)
         lane.join()
-        return (dx, dw1, dw2, dw3, dwd) + (None,) * 12
+        return (dx, dw1, dw2, dw3, dwd) + (None,) * 11
 
 
 class _DCNBottleneckFn(torch.autograd.Function):
@@ -321,10 +319,6 @@ class Bottleneck(nn.Module):
         for l in (self.conv1, self.conv3) + (() if self.with_dcn else (self.conv2,)):
             nn.init.kaiming_uniform_(l.weight, a=1)
 
-    # set by an owner whose backward is followed by a GEMM-free kernel (the ROI head's first block: ROIAlign backward):
-    # this block's weight gradients are then queued for utils.streams.flush_deferred_wgrads
-    defer_wgrad = False
-
     def forward(self, x, in_relu=False, out_private=False, stride=None):
         """in_relu / out_private: structural promises made by _Stage (see _BottleneckFn); a direct call makes none.
         stride: overrides the stride of conv1 and the shortcut (see input_is_strided_1x1) — fused path only"""
@@ -348,8 +342,7 @@ class Bottleneck(nn.Module):
                 wd, (sd, bd) = self.downsample[0].weight, self.downsample[1].folded()
             return _BottleneckFn.apply(x, self.conv1.weight, self.conv2.weight, self.conv3.weight, wd,
                                        *self.bn1.folded(), *self.bn2.folded(), *self.bn3.folded(), sd, bd,
-                                       self.conv1.stride[0] if stride is None else stride, in_relu, out_private,
-                                       self.defer_wgrad)
+                                       self.conv1.stride[0] if stride is None else stride, in_relu, out_private)
         assert stride is None
         return self._forward_per_conv(x)
 
@@ -537,8 +530,6 @@ class ResNetHead(nn.Module):
                                               dilation=dilation))
             stride = None
             self.stages.append(name)
-        first = getattr(self, self.stages[0])[0]
-        first.defer_wgrad = True   # last node of the head's backward, in front of the pooler's backward
 
     def forward(self, x, first_stride=None):
         for i, stage in enumerate(self.stages):

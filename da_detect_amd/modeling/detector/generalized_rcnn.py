@@ -81,7 +81,7 @@ class GeneralizedRCNN(nn.Module):
             self.rpn.live_images = self._images_with_read_proposals(targets)
         if self.training and self.roi_heads and features[0].is_cuda:
             # the box head's sampler reads the NMS result on the device: the RPN need not bring the kept count to the host
-            self.rpn.box_selector_train.defer = self.roi_heads.box.loss_evaluator.accepts_pending()
+            self.rpn.box_selector_train.defer = self.roi_heads.box.loss_evaluator.accepts_pending(targets)
         proposals, proposal_losses = self.rpn(images, features, targets)
         if self.training:
             pending, self.rpn.after_early_backward = self.rpn.after_early_backward, None

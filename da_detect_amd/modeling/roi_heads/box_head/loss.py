@@ -100,9 +100,13 @@ class FastRCNNLossComputation(object):
             proposals[i] = proposals[i][_nz(pm | nm, size=k).squeeze(1)]
         return proposals
 
-    def accepts_pending(self):
+    def accepts_pending(self, targets=None):
         """the sampler can take the RPN's NMS result where it lies on the device (PendingProposals): true whenever the
-        one-launch device sampler is the one in use"""
+        one-launch device sampler is the one in use.  dadet_proposals_sample keeps an image's ground truth in an LDS
+        table of _C.PROPOSALS_SAMPLE_MAX_GT boxes: a batch with a more crowded image gets ordinary BoxLists from the
+        RPN instead (and then the two-launch box_match_encode + sample_rois path, which has no such bound)"""
+        if targets is not None and any(len(t) > _C.PROPOSALS_SAMPLE_MAX_GT for t in targets):
+            return False
         return (_FUSED and _PENDING and not rng.cpu_stream_enabled()
                 and not self.proposal_matcher.allow_low_quality_matches)
 

@@ -22,66 +22,18 @@ from ..box_coder import BoxCoder
 from .utils import permute_and_flatten
 
 
-# DADET_TOPK_KERNEL=1: the one-launch dadet_topk_sorted instead of torch.sort.  OFF by default: measured on the RPN's shape
-# (2 x 122 880 scores, k = 12 000, tools/topk_bench.py) the single-workgroup-per-image kernel takes 0.45 ms against
-# 0.20 ms for the library's segmented sort of ALL scores (36 launches, but they spread over the whole chip; one
-# workgroup reads its 480 KB row four times from one CU and then sorts 16 384 pairs in LDS).  Indices are identical
-# (tests/test_topk_gpu.py); the kernel stays for launch-bound situations.
-_TOPK_KERNEL = __import__("os").environ.get("DADET_TOPK_KERNEL", "0") == "1"
+# the one-launch dadet_topk_sorted instead of torch.sort.  False: measured on the RPN's shape (2 x 122 880 scores,
+# k = 12 000, tools/topk_bench.py) the single-workgroup-per-image kernel takes 0.45 ms against 0.20 ms for the library's
+# segmented sort of ALL scores (36 launches, but they spread over the whole chip; one workgroup reads its 480 KB row four
+# times from one CU and then sorts 16 384 pairs in LDS).  Indices are identical; tests/test_topk_gpu.py runs the selection
+# chain both ways.  No environment switch: a caller that wants it sets the module attribute.
+_TOPK_KERNEL = False
 
 
 # DADET_FPN_DEVICE_SELECT=0: multi-level training selection with the reference's host round trips
 _DEVICE_SELECT = __import__("os").environ.get("DADET_FPN_DEVICE_SELECT", "1") == "1"
-# DADET_SELECT_GRAPH=1: the device-side selection as one captured HIP graph instead of launch by launch.  MEASURED (round 3,
-# ROCm 7.0 / PyTorch 2.10, four alternating runs of 30 steps on one box): 59.4 - 60.8 ms per step launch by launch,
-# 64.5 - 65.5 ms with the graph — replaying the ~250-node graph costs more than issuing its launches from Python.  Off.
-_SELECT_GRAPH = __import__("os").environ.get("DADET_SELECT_GRAPH", "0") == "1"
-
-
-class _SelectionGraph(object):
-    """The device-side multi-level selection (~250 launches: per level sigmoid, a 16-launch stable sort, decode, and per
-    image the four NMS kernels; then the merge, the batch-wide top-k and the masks) has fixed shapes and no host round
-    trip, and nothing else runs on the GPU while the host issues it (the stretch between the RPN head and the box head:
-    2.3 - 2.8 ms of an R-101-FPN-DCN step with the next GEMM issued 0.05 ms before it starts, tools/gemm_table.py --holes).
-    It can be captured ONCE per (map shapes, anchor buffers) as a HIP graph — inputs copied into the graph's static buffers,
-    one graph launch per step (capture works; the replay is slower than the launches it replaces on this software stack,
-    see _SELECT_GRAPH).  Anything that makes capture fail (an unsupported call in a future PyTorch, a shape the
-    capture did not see) falls back to launch-by-launch execution for the rest of the process."""
-
-    def __init__(self):
-        self.graphs = {}
-        self.failed = False
-
-    def run(self, proc, anchors, objectness, box_regression):
-        if self.failed:
-            return None
-        key = (tuple(tuple(o.shape) for o in objectness), tuple(tuple(b.shape) for b in box_regression),
-               tuple(a.bbox.data_ptr() for lvls in anchors for a in lvls), tuple(tuple(lvls[0].size) for lvls in anchors))
-        entry = self.graphs.get(key)
-        inputs = list(objectness) + list(box_regression)
-        if entry is None:
-            try:
-                static_in = [torch.empty_like(t) for t in inputs]
-                for s_, t in zip(static_in, inputs):
-                    s_.copy_(t)
-                n = len(objectness)
-                proc._device_selection(anchors, static_in[:n], static_in[n:])          # warm-up outside the capture
-                graph = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(graph, capture_error_mode="thread_local"):
-                    parts = proc._device_selection(anchors, static_in[:n], static_in[n:])
-                entry = self.graphs[key] = (graph, static_in, parts, [a for lvls in anchors for a in lvls])
-                if len(self.graphs) > 8:                       # variable-size batches: do not hoard graphs
-                    self.graphs.pop(next(iter(self.graphs)))
-            except Exception as exc:   # noqa: BLE001 — any capture failure means: run eagerly from now on
-                import warnings
-                warnings.warn("proposal-selection graph capture failed (%r): running launch by launch" % (exc,))
-                self.failed = True
-                return None
-        graph, static_in, parts, _ = entry
-        for s_, t in zip(static_in, inputs):
-            s_.copy_(t)
-        graph.replay()
-        return parts
+# (measured in round 3 and removed: the device-side selection as one captured HIP graph — 64.5 - 65.5 ms per step against
+# 59.4 - 60.8 launch by launch; replaying the ~250-node graph cost more than issuing its launches from Python)
 
 
 class RPNPostProcessor(torch.nn.Module):
@@ -94,7 +46,6 @@ class RPNPostProcessor(torch.nn.Module):
         self.min_size = min_size
         self.box_coder = box_coder if box_coder is not None else BoxCoder(weights=(1.0, 1.0, 1.0, 1.0))
         self.fpn_post_nms_top_n = post_nms_top_n if fpn_post_nms_top_n is None else fpn_post_nms_top_n
-        self._graph = _SelectionGraph()
 
     # set by RPNModule for ONE call: the caller is the training path whose box head samples straight from the NMS result
     # on the device (FastRCNNLossComputation._subsample_fused): single-level proposals are then handed over as
@@ -189,9 +140,7 @@ class RPNPostProcessor(torch.nn.Module):
         if (self.defer and _DEVICE_SELECT and num_levels > 1 and targets is not None and self.training
                 and self.nms_thresh > 0 and self.min_size <= 0 and objectness[0].is_cuda):
             self.defer = False
-            parts = self._graph.run(self, anchors, objectness, box_regression) if _SELECT_GRAPH else None
-            if parts is None:
-                parts = self._device_selection(anchors, objectness, box_regression)
+            parts = self._device_selection(anchors, objectness, box_regression)
             out = [PendingProposals(b, sc, keep, cnt, post_n, anchors[i][0].size)
                    for i, (b, sc, keep, cnt, post_n) in enumerate(parts)]
             return self.add_gt_proposals(out, targets)
@@ -212,7 +161,7 @@ class RPNPostProcessor(torch.nn.Module):
 
     def _device_selection(self, anchors, objectness, box_regression):
         """the whole multi-level selection as a function of tensors at fixed shapes with no host round trip: -> per image
-        (boxes, scores, keep, count, upper bound).  This is what _SelectionGraph captures."""
+        (boxes, scores, keep, count, upper bound)."""
         per_level = [self.forward_for_single_feature_map(a, o, b, raw=True)
                      for a, o, b in zip(list(zip(*anchors)), objectness, box_regression)]
         return self._select_over_all_levels_device(per_level)

@@ -14,7 +14,6 @@ from .loss import make_rpn_loss_evaluator
 from ..elision import elision_enabled, leading_source_images
 from ...utils.streams import record, side_section, side_stream
 
-_PROPOSALS_FIRST = os.environ.get("DADET_PROPOSALS_FIRST", "0") == "1"
 
 
 @registry.RPN_HEADS.register("SingleConvRPNHead")
@@ -180,11 +179,9 @@ class RPNModule(torch.nn.Module):
         # overlapped schedule: losses + the RPN branch's backward (+ the image-level DA head through the hook) go to the
         # compute stream first; proposal selection (sort, decode, single-workgroup NMS sweeps) then runs on the side stream
         # underneath them, and the box head's sampling continues there (ROIBoxHead.forward).
-        # DADET_PROPOSALS_FIRST=1 issues the selection chain BEFORE the losses.  MEASURED (round 3, alternating runs of 30
-        # steps on one box): R-50-C4, whose selection never comes back to the host, 19.00 / 19.04 vs 19.07 / 18.99 ms (no
-        # difference: the host is far enough ahead that the issue order does not reach the GPU); R-101-FPN-DCN, whose
-        # per-level selection has host round trips, 64.8 / 65.5 -> 68.7 / 70.0 ms (the host then sits in those round trips
-        # with nothing queued on the compute stream).  Off.
+        # (issuing the selection chain BEFORE the losses was measured in round 3 and removed: R-50-C4 19.00 / 19.04 vs
+        # 19.07 / 18.99 ms, R-101-FPN-DCN 64.8 / 65.5 -> 68.7 / 70.0 ms — the host then sits in the per-level round trips
+        # with nothing queued on the compute stream)
         dev = objectness[0].device
         prep = self._prepare_loss_targets(anchors, targets)
         main = torch.cuda.current_stream(dev)
@@ -202,7 +199,6 @@ class RPNModule(torch.nn.Module):
                 self.proposals_ready = side.record_event()
             return out
 
-        boxes = select() if _PROPOSALS_FIRST else None
         if isinstance(hidden, list) and prep["sampled_inds"].numel() > 0:
             # one launch chain per pyramid level over the SAME sampled rows (rows of the other levels are zero); every
             # level normalises by the same count, so the levels' losses add up to rpn/loss.py:125-143
@@ -232,8 +228,7 @@ class RPNModule(torch.nn.Module):
         hook, self.after_early_backward = self.after_early_backward, None
         if hook is not None:
             hook()
-        if boxes is None:
-            boxes = select()
+        boxes = select()
         record(boxes, main)
         boxes = list(boxes) + [None] * (len(targets) - n_live)
         return boxes, {"loss_objectness": loss_objectness.detach(), "loss_rpn_box_reg": loss_rpn_box_reg.detach()}

@@ -51,6 +51,13 @@ class BucketedGradReducer(object):
         self.static_unused = None  # ids of the parameters no rank touched in the first step (None: not learned yet)
         self.mean_scale = 1.0      # what the buckets must still be multiplied by after finalize(mean=False)
         self._touched_any = frozenset()
+        # communication evidence (record_comm(True); bench.py's N > 1 line, tests): per step — buckets whose collective
+        # went out from a gradient hook (during backward) / only in finalize(), the GPU time the compute stream spent in
+        # finalize() waiting for collectives (events on the compute stream around the waits: exposed communication), and the
+        # collectives' own durations on RCCL's stream where the backend reports them (TORCH_NCCL_ENABLE_TIMING=1)
+        self._record = False
+        self._comm_steps = []
+        self._step_rec = None
 
     def _build(self, bucket_bytes):
         cur, cur_bytes = [], 0
@@ -88,6 +95,9 @@ class BucketedGradReducer(object):
     # -- per-step protocol: zero_grad() -> backward (hooks fire) -> finalize() -> optimizer.step() --------
     def zero_grad(self):
         unused = self.static_unused or ()
+        # reduction passes still queued from a backward that no step() followed would be added into the NEXT step's
+        # gradients (and pin ~1.5 GB of partial sums meanwhile): they belong to the gradients being cleared
+        streams.discard_wgrad_reductions()
         if self._all is not None:
             self._all.zero_()
         for b in self.buckets:
@@ -96,6 +106,48 @@ class BucketedGradReducer(object):
         self._next = 0
         self._finalized = False
         self.touched = set()
+        if self._record:
+            self._step_rec = dict(in_backward=0, in_finalize=0, works=[], wait=None)
+
+    def record_comm(self, flag=True):
+        self._record = bool(flag) and self.communicate
+        self._comm_steps, self._step_rec = [], None
+
+    def comm_summary(self, skip=0):
+        """aggregate of the recorded steps (after `skip` leading ones).  Synchronises the device: call it outside timed
+        regions.  allreduce_ms is None when the backend does not report durations."""
+        steps = self._comm_steps[skip:]
+        if not steps:
+            return None
+        if self.buckets and self.buckets[0]["flat"].is_cuda:
+            torch.cuda.synchronize(self.buckets[0]["flat"].device)
+        exposed, allred, have_dur = [], [], True
+        for r in steps:
+            exposed.append(r["wait"][0].elapsed_time(r["wait"][1]) if r["wait"] is not None else 0.0)
+            tot = 0.0
+            for w in r["works"]:
+                try:
+                    tot += float(w._get_duration())
+                except Exception:       # noqa: BLE001 — gloo, timing disabled, older c10d
+                    have_dur = False
+                    break
+            allred.append(tot)
+        n = float(len(steps))
+        out = {"backend": dist.get_backend(self.group) if dist.is_initialized() else None, "world": self.world_size,
+               "buckets": len(self.buckets), "bucket_mb": round(max(b["flat"].numel() for b in self.buckets) * 4 / 2**20, 2),
+               "grad_mb": round(self.grad_bytes() / 2**20, 2), "steps": len(steps),
+               "buckets_issued_during_backward": sum(r["in_backward"] for r in steps) / n,
+               "buckets_issued_in_finalize": sum(r["in_finalize"] for r in steps) / n,
+               "exposed_ms": round(sum(exposed) / n, 4),
+               "allreduce_ms": round(sum(allred) / n, 4) if have_dur else None}
+        if have_dur and out["allreduce_ms"]:
+            out["overlap_frac"] = round(max(0.0, 1.0 - out["exposed_ms"] / out["allreduce_ms"]), 4)
+        else:
+            out["overlap_frac"] = None
+        out["note"] = ("exposed_ms = GPU time between finalize()'s first wait and its last one on the compute stream (what "
+                       "the step pays for communication that backward did not hide); allreduce_ms = sum of the collectives' "
+                       "durations on the backend's stream")
+        return out
 
     def _launch_ready(self, force=False):
         """collectives must be issued in the same order on every rank: buckets are launched strictly by index,
@@ -109,6 +161,9 @@ class BucketedGradReducer(object):
                 # complete in this bucket before it goes out
                 streams.flush_wgrad_reductions(b["flat"].device)
                 b["work"] = self._all_reduce(b["flat"])
+                if self._step_rec is not None:
+                    self._step_rec["in_finalize" if force else "in_backward"] += 1
+                    self._step_rec["works"].append(b["work"])
             self._next += 1
 
     def _all_reduce(self, flat):
@@ -118,7 +173,6 @@ class BucketedGradReducer(object):
         current position — the compute stream itself is not held up."""
         dev = flat.device
         if dev.type == "cuda" and streams.DIRECT_WGRAD and streams.lane_in_use():
-            streams.flush_deferred_wgrads(dev)
             lane = streams.side_stream(dev, 2)
             lane.wait_event(torch.cuda.current_stream(dev).record_event())
             with torch.cuda.stream(lane):
@@ -147,10 +201,23 @@ class BucketedGradReducer(object):
             streams.join_wgrad_lane(self.buckets[0]["flat"].device)
         self._launch_ready(force=True)
         if self.communicate:
+            rec = self._step_rec
+            cuda = bool(self.buckets) and self.buckets[0]["flat"].is_cuda
+            if rec is not None and cuda:
+                e0 = torch.cuda.Event(enable_timing=True)
+                e0.record()
             for b in self.buckets:
                 if b["work"] is not None:
                     b["work"].wait()
-                if mean and self.world_size > 1:
+            if rec is not None and cuda:
+                e1 = torch.cuda.Event(enable_timing=True)
+                e1.record()
+                rec["wait"] = (e0, e1)
+            if rec is not None:
+                self._comm_steps.append(rec)
+                self._step_rec = None
+            if mean and self.world_size > 1:
+                for b in self.buckets:
                     b["flat"].mul_(1.0 / self.world_size)
         self.mean_scale = 1.0 if (mean or self.world_size == 1) else 1.0 / self.world_size
         self._finalized = True
@@ -174,7 +241,11 @@ class BucketedGradReducer(object):
         (torch.optim.SGD skips `grad is None`: no weight decay, no momentum step).  Several ranks: every parameter ANY
         rank touched — its averaged gradient is the same everywhere, so is its update (DDP with find_unused_parameters
         behaves the same); deciding by the LOCAL touched set would let weights, momentum and weight decay of a
-        parameter used on rank A only drift apart between the ranks"""
+        parameter used on rank A only drift apart between the ranks.
+        Known difference from one rank (and from DDP, which leaves the gradient of a globally unused parameter None): with
+        the learned `static_unused` mask, a parameter that was touched in the FIRST step and that no rank touches in some
+        later step (the instance head in a step where no ROI is sampled) still takes weight decay and a momentum step on
+        its zero gradient there.  learn_unused=False re-agrees every step and has no such case."""
         if self.world_size == 1:
             return self.touched
         if self.static_unused is not None:
@@ -195,6 +266,10 @@ class BucketedGradReducer(object):
         if self.world_size > 1:
             for p in self.params:
                 dist.broadcast(p.data, src=src, group=self.group)
+            # a write through .data does not bump the tensors' autograd version: the caches of transposed / padded weights
+            # (_C._TransposeCache, backbone.resnet._PaddedWeights) are keyed by (version, weight epoch)
+            from .. import _C
+            _C.bump_weight_epoch()
 
     def grad_bytes(self):
         return sum(b["flat"].numel() * b["flat"].element_size() for b in self.buckets)

@@ -87,6 +87,10 @@ class Checkpointer(object):
 
     def _load_model(self, checkpoint):
         load_state_dict(self.model, checkpoint.pop("model"))
+        # the loader copies into the parameters through .data-style writes that need not bump their autograd version: the
+        # caches of derived weights (transposed / padded forms) are keyed by (version, weight epoch)
+        from .. import _C
+        _C.bump_weight_epoch()
 
 
 class DetectronCheckpointer(Checkpointer):

@@ -97,8 +97,7 @@ class WgradLane(object):
     workgroups.  `run(fn, *tensors)` queues fn() there once the tensors exist on the compute stream; `join()` makes
     the compute stream wait before the gradients are handed to autograd."""
 
-    def __init__(self, device, defer=False, rows=None):
-        self.defer = defer      # direct accumulations are queued until flush_deferred_wgrads() (see there)
+    def __init__(self, device, rows=None):
         self.on = device.type == "cuda" and (WGRAD_OVERLAP or (rows is not None and rows <= WGRAD_LANE_ROWS))
         self.plain_used = False   # some weight gradient of this node is returned to autograd instead of accumulated
         if self.on:
@@ -126,11 +125,6 @@ class WgradLane(object):
         if tgt is None:
             self.plain_used = True
             return self.run(plain_fn, *inputs)
-        if reduce_in_flight(tgt):
-            flush_wgrad_reductions(tgt.device)     # a second contribution to the same buffer in one step: order them
-        if self.defer and _DEFER_ENABLED:
-            _DEFERRED.append((direct_fn, tgt, inputs))
-            return None
         if not self.on:
             direct_fn(tgt)
             return None
@@ -154,12 +148,18 @@ class WgradLane(object):
         from .. import _C
 
         if DEFER_WGRAD_REDUCE and DIRECT_WGRAD and not now and not self.plain_used:
-            _PENDING_REDUCES.extend(batch)
+            # One merged launch sums every queued item with a plain read-modify-write of its dw (`dw = dw + sum of the
+            # partials`, no atomics).  Two items with the SAME dw in one launch would race and lose a contribution: a
+            # weight used twice in a graph (the res5 head run twice under DADET_NO_ROI_DEDUP=1, two backward() calls in
+            # front of one step()).  The earlier item is then reduced first, in stream order.
+            if any(it[0].dw in _PENDING_DW for it in batch):
+                flush_wgrad_reductions(batch[0][1].device)
+            for it in batch:
+                if it[0].dw in _PENDING_DW:            # twice inside one node's own batch
+                    flush_wgrad_reductions(it[1].device)
+                _PENDING_DW.add(it[0].dw)
+                _PENDING_REDUCES.append(it)
             del batch[:]
-            if REDUCE_STREAM and len(_PENDING_REDUCES) >= REDUCE_STREAM_ITEMS:
-                dev = _PENDING_REDUCES[0][1].device
-                if dev.type == "cuda":
-                    _issue_on_reduce_stream(dev)
             return
         if self.on:
             with torch.cuda.stream(self.lane):
@@ -196,95 +196,29 @@ def direct_grad_target(param):
     return g
 
 
-# Deferred weight gradients: the backward node that ends the box head (first res5 block) is followed by the ROIAlign
-# backward — an L2-bound gather during which no GEMM can run, because the backbone's backward needs its result
-# (tools/gemm_table.py --holes: 1.0 ms per step).  That block's weight gradients do not feed anything: they are queued
-# and issued on the lane together with the ROIAlign backward, so the matrix pipe has work while the gather runs.
-_DEFERRED = []
-# MEASURED: slower (31.05 vs 30.53 ms per step on the same box): the GEMMs slow the gather, which is on the critical
-# path, by more than they gain — off by default, DADET_DEFER_WGRAD=1 to reproduce.
-_DEFER_ENABLED = os.environ.get("DADET_DEFER_WGRAD", "0") == "1"
-
-
-def flush_deferred_wgrads(device, after=None):
-    """issue the queued accumulations on the lane; `after`: event of the compute stream they must wait for (default:
-    everything queued on it so far)"""
-    global _DEFERRED
-    if not _DEFERRED:
-        return
-    items, _DEFERRED = _DEFERRED, []
-    if device.type == "cuda" and lane_in_use():
-        main = torch.cuda.current_stream(device)
-        lane = side_stream(device, 2)
-        lane.wait_event(after if after is not None else main.record_event())
-        with torch.cuda.stream(lane):
-            for fn, tgt, _ in items:
-                fn(tgt)
-        for _, _, inputs in items:
-            for t in inputs:
-                t.record_stream(lane)
-    else:
-        for fn, tgt, _ in items:
-            fn(tgt)
-
-
-def deferred_pending():
-    return bool(_DEFERRED)
-
-
 # reduction passes of split weight gradients whose results nobody has asked for yet (WgradLane.reduce_batch)
 _PENDING_REDUCES = []
 DEFER_WGRAD_REDUCE = os.environ.get("DADET_DEFER_WGRAD_REDUCE", "1") == "1"
-# The passes are pure HBM traffic (img_only: 1.47 GB read + 0.09 GB written per step, 4.2 TB/s in the merged launches —
-# 0.37 ms with nothing else running when they all sit in front of the optimizer).  Issued on their own stream (3) as soon
-# as REDUCE_STREAM_ITEMS of them are queued, they run beside the MFMA-bound backward GEMMs that follow instead;
-# flush_wgrad_reductions() then only joins that stream.  MEASURED (round 3, two alternating runs of 40 steps): 19.29 /
-# 19.53 ms per step with the stream against 19.22 / 19.23 without, 19.22 - 19.26 with 1 or 12 items per launch — the HBM
-# traffic slows the (power-limited) GEMMs it runs beside by what it saves at the end.  Off by default;
-# DADET_WGRAD_REDUCE_STREAM=1 to reproduce.
-REDUCE_STREAM = os.environ.get("DADET_WGRAD_REDUCE_STREAM", "0") == "1"
-REDUCE_STREAM_ITEMS = int(os.environ.get("DADET_WGRAD_REDUCE_STREAM_ITEMS", "6"))
-_INFLIGHT_DW = set()      # gradient buffers a pass on the reduce stream is (possibly still) adding into
+_PENDING_DW = set()          # dw pointers of the queued items (see WgradLane.reduce_batch)
+# (measured in round 3 and removed: the same passes on a stream of their own beside the backward GEMMs — 19.29 / 19.53 ms
+# per step against 19.22 / 19.23: the HBM traffic slows the power-limited GEMMs by what it saves at the end)
 
 
-def _issue_on_reduce_stream(device):
-    global _PENDING_REDUCES
-    items, _PENDING_REDUCES = _PENDING_REDUCES, []
-    from .. import _C
-
-    cur = torch.cuda.current_stream(device)
-    rs = side_stream(device, 3)
-    rs.wait_stream(cur)                                    # the partial sums (and the zeroed buffers) exist
-    if lane_in_use():
-        rs.wait_stream(side_stream(device, 2))
-    for it in items:
-        it[1].record_stream(rs)                            # the partial-sum workspace
-        if it[3] is not None:
-            it[3].record_stream(rs)
-        _INFLIGHT_DW.add(it[0].dw)
-    with torch.cuda.stream(rs):
-        _C.conv_wgrad_reduce_batch(items)
-
-
-def reduce_in_flight(tensor):
-    """a pass on the reduce stream may still be adding into this gradient buffer"""
-    return bool(_INFLIGHT_DW) and tensor.data_ptr() in _INFLIGHT_DW
+def discard_wgrad_reductions():
+    """drop the queued passes without running them: their gradient buffers are about to be zeroed (a backward that was
+    not followed by step(); BucketedGradReducer.zero_grad).  Also releases the partial-sum workspaces they pin."""
+    del _PENDING_REDUCES[:]
+    _PENDING_DW.clear()
 
 
 def flush_wgrad_reductions(device):
     """every deferred reduction pass is complete for the CURRENT stream after this (callers: join_wgrad_lane, i.e.
     everything that reads gradients; the gradient reducer before it issues a bucket's collective)"""
-    global _PENDING_REDUCES
-    if device.type == "cuda" and REDUCE_STREAM:
-        if _PENDING_REDUCES:
-            _issue_on_reduce_stream(device)
-        if _INFLIGHT_DW:
-            torch.cuda.current_stream(device).wait_stream(side_stream(device, 3))
-            _INFLIGHT_DW.clear()
-        return
     if not _PENDING_REDUCES:
         return
-    items, _PENDING_REDUCES = _PENDING_REDUCES, []
+    items = list(_PENDING_REDUCES)
+    del _PENDING_REDUCES[:]
+    _PENDING_DW.clear()
     from .. import _C
 
     if device.type == "cuda":
@@ -298,7 +232,6 @@ def flush_wgrad_reductions(device):
 
 def join_wgrad_lane(device):
     """the current stream waits for every weight gradient queued on the lane (call before reading .grad)"""
-    flush_deferred_wgrads(device)
     if device.type == "cuda" and lane_in_use():
         torch.cuda.current_stream(device).wait_stream(side_stream(device, 2))
     flush_wgrad_reductions(device)

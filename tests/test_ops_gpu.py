@@ -970,45 +970,6 @@ def test_stream_k_tail_matches_the_plain_grid(device, shape, monkeypatch):
     torch.testing.assert_close(out["1"][0].cpu(), ref, rtol=1e-4, atol=1e-4)
 
 
-@pytest.mark.parametrize("shape", [
-    # N, Cin, H, W, Cout, k, stride, pad
-    (512, 512, 7, 7, 512, 3, 1, 1),       # res5 3x3: 4 x 36 tiles, 7 splits
-    (2, 1024, 64, 128, 1024, 3, 1, 1),    # RPN 3x3: 8 x 72 tiles
-    (2, 256, 40, 60, 200, 3, 1, 1),       # ragged Cout / K tiles
-    (512, 2048, 7, 7, 512, 1, 1, 0),      # res5 1x1
-])
-def test_wgrad_in_kernel_split_reduction_is_bit_identical(device, shape):
-    """conv_wgrad_split_kernel with the last-arriving split of a tile summing the partial results (split order, then
-    out_scale, then accumulate) against the separate wgrad_reduce_kernel pass: same operations in the same order ->
-    identical bits; also with accumulate into an existing gradient"""
-    import os
-
-    from da_detect_amd import _C
-
-    N, Cin, H, W, Cout, k, stride, pad = shape
-    g = torch.Generator().manual_seed(sum(shape))
-    CL = torch.channels_last
-    x = torch.randn((N, Cin, H, W), generator=g).to(device).contiguous(memory_format=CL)
-    Ho, Wo = (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
-    gy = torch.randn((N, Cout, Ho, Wo), generator=g).to(device).contiguous(memory_format=CL)
-    scale = (torch.rand(Cout, generator=g) + 0.5).to(device)
-    prev = torch.randn((Cout, Cin, k, k), generator=g).to(device).contiguous(memory_format=CL)
-    out = {}
-    for flag in ("0", "1"):
-        os.environ["DADET_WGRAD_FUSED"] = flag
-        try:
-            a = _C.conv_wgrad(x, gy, (Cout, Cin, k, k), stride, pad, out_scale=scale)
-            b = _C.conv_wgrad(x, gy, (Cout, Cin, k, k), stride, pad, out_scale=scale, dw=prev.clone(memory_format=torch.preserve_format),
-                              accumulate=True)
-            c = _C.conv_wgrad(x, gy, (Cout, Cin, k, k), stride, pad, out_scale=scale)     # counters were reset
-        finally:
-            os.environ.pop("DADET_WGRAD_FUSED")     # default: the separate reduction pass
-        out[flag] = (a, b, c)
-    for u, v in zip(out["0"], out["1"]):
-        assert torch.equal(u, v)
-    assert torch.equal(out["1"][0], out["1"][2])
-
-
 def test_hip_ops_against_the_reference_build_itself(device):
     """The reference's OWN compiled CPU operators (oracle/_ref/ref_C.so, built from maskrcnn_benchmark/csrc/{vision.cpp,
     cpu/*.cpp} by oracle/build_ref.py; the binary travels to the GPU box, the sources do not) called on the same inputs
