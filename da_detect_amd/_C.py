@@ -304,13 +304,16 @@ def conv_forward(x, w, scale=None, bias=None, addend=None, mask_ref=None, stride
         mask_ref = _nhwc(mask_ref)
     d = _desc(N, H, W, Cin, Cout, KH, KW, stride, pad, Ho, Wo, OutH, OutW, out_spatial_stride, relu_mode)
     if PROFILER is not None:
-        key = (N * Ho * Wo, Cout, Cin * KH * KW)
+        key = (N * Ho * Wo, Cout, Cin * KH * KW, KH, pad, out_spatial_stride)
         kname = _KNAME_CACHE.get(key)
         if kname is None:
             variant = _lib.load().dadet_conv_forward_variant(ctypes.byref(d))
             mode = get_gemm_mode()
-            kname = ("conv_fwd_kernel<%s>" if mode == 0 else ("conv_fwd_split_kernel<%%s,%d>" % mode)) % \
-                ("2,2", "2,1", "1,1")[variant]
+            if variant == 3:
+                kname = "conv1x1_ws_kernel<%d,%d>" % (Cin, 64 if Cin == 256 else 128)
+            else:
+                kname = ("conv_fwd_kernel<%s>" if mode == 0 else ("conv_fwd_split_kernel<%%s,%d>" % mode)) % \
+                    ("2,2", "2,1", "1,1")[variant]
             _KNAME_CACHE[key] = kname
         if getattr(PROFILER, "detail", False):   # tools/gemm_table.py: one row per problem shape
             kname = "%s|M=%d N=%d K=%d k%dx%d s%d%s" % (kname, N * Ho * Wo, Cout, Cin * KH * KW, KH, KW, stride,

@@ -41,6 +41,35 @@ __device__ inline float4 buf_load4_sc1(__amdgpu_buffer_rsrc_t r, unsigned byte_o
   return __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)byte_off, 0, 16));
 }
 
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+
+__device__ inline unsigned pack_bf16(float lo, float hi) {
+  unsigned r;
+  asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));   // pure: free to be scheduled between MFMAs
+  return r;
+}
+__device__ inline float lo_as_float(unsigned p) { return __builtin_bit_cast(float, p << 16); }
+__device__ inline float hi_as_float(unsigned p) { return __builtin_bit_cast(float, p & 0xFFFF0000u); }
+
+// split four consecutive-k floats into TERMS planes of 4 bf16 (8 bytes each)
+template <int TERMS>
+__device__ inline void split4(const float4 v, uint2 (&out)[TERMS]) {
+  float a = v.x, b = v.y, c = v.z, d = v.w;
+#pragma unroll
+  for (int t = 0; t < TERMS; ++t) {
+    const unsigned p0 = pack_bf16(a, b), p1 = pack_bf16(c, d);
+    out[t] = make_uint2(p0, p1);
+    if (t + 1 < TERMS) {
+      a -= lo_as_float(p0); b -= hi_as_float(p0);
+      c -= lo_as_float(p1); d -= hi_as_float(p1);
+    }
+  }
+}
+
+constexpr int PLANE_STRIDE = 40;  // bf16 per staged row: 32 + 8 pad = 80 bytes
+constexpr int EPI_STRIDE = 40;    // floats per transposed row of the 16-byte epilogue
+
 constexpr int BK = 32;          // K-tile
 constexpr int LDS_STRIDE = 36;  // floats per staged row (32 + 4 pad, keeps 16-byte alignment)
 
@@ -105,5 +134,8 @@ int gemm_mode();
 int launch_fwd_split(ConvArgs& a, int variant, int terms, hipStream_t st);
 int launch_fwd_split_sk(ConvArgs& a, int terms, hipStream_t st);
 int launch_wgrad_split(WgradArgs& a, int terms, hipStream_t st);
+// weight-stationary 1x1 kernel for K = 64 / 128 / 256 (conv_ws.hip)
+bool ws_eligible(const ConvArgs& a);
+int launch_fwd_ws(ConvArgs& a, hipStream_t st);
 
 }  // namespace dadet

@@ -747,6 +747,7 @@ extern "C" int dadet_conv_forward(const dadet_conv_desc* d, const float* x, cons
   a.sk_dp_tiles = a.sk_tiles = a.sk_units = a.sk_iters = a.sk_max_parts = 0;
   a.sk_ws = nullptr;
   a.sk_counters = nullptr;
+  if (gemm_mode() == 3 && ws_eligible(a)) return launch_fwd_ws(a, st);     // weight-stationary 1x1, K <= 256 (conv_ws.hip)
   if (gemm_mode() != 0) {
     const int variant = split_fwd_variant(a.M, a.Cout, a.K);
     SkPlan sk;
@@ -803,6 +804,15 @@ extern "C" int dadet_conv_forward(const dadet_conv_desc* d, const float* x, cons
 extern "C" int dadet_conv_forward_variant(const dadet_conv_desc* d) {
   if (!d) return -1;
   const int M = d->N * d->Ho * d->Wo;
+  if (gemm_mode() == 3) {      // 3: the weight-stationary 1x1 kernel (assuming 16-byte aligned tensors, as torch allocates them)
+    ConvArgs a;
+    a.KH = d->KH; a.KW = d->KW; a.pad = d->pad; a.os = d->out_spatial_stride > 0 ? d->out_spatial_stride : 1;
+    a.ksplit = 0; a.K = d->KH * d->KW * d->Cin; a.Cout = d->Cout; a.M = M;
+    a.epi_v4 = a.os == 1 && d->Cout % 4 == 0;
+    a.x_bytes = (unsigned)((uint64_t)d->N * d->H * d->W * d->Cin * 4 > 0x7FFFFFFFull ? 0x80000000u : (uint64_t)d->N * d->H * d->W * d->Cin * 4);
+    a.w_bytes = 0;
+    if (ws_eligible(a)) return 3;
+  }
   return gemm_mode() != 0 ? split_fwd_variant(M, d->Cout, d->KH * d->KW * d->Cin) : fwd_variant(M, d->Cout);
 }
 

@@ -19,35 +19,8 @@
 
 namespace dadet {
 
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-
-constexpr int PLANE_STRIDE = 40;  // bf16 per staged row: 32 + 8 pad = 80 bytes
-
 static int g_gemm_mode = 3;
 int gemm_mode() { return g_gemm_mode; }
-
-__device__ inline unsigned pack_bf16(float lo, float hi) {
-  unsigned r;
-  asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));   // pure: free to be scheduled between MFMAs
-  return r;
-}
-__device__ inline float lo_as_float(unsigned p) { return __builtin_bit_cast(float, p << 16); }
-__device__ inline float hi_as_float(unsigned p) { return __builtin_bit_cast(float, p & 0xFFFF0000u); }
-
-// split four consecutive-k floats into TERMS planes of 4 bf16 (8 bytes each)
-template <int TERMS>
-__device__ inline void split4(const float4 v, uint2 (&out)[TERMS]) {
-  float a = v.x, b = v.y, c = v.z, d = v.w;
-#pragma unroll
-  for (int t = 0; t < TERMS; ++t) {
-    const unsigned p0 = pack_bf16(a, b), p1 = pack_bf16(c, d);
-    out[t] = make_uint2(p0, p1);
-    if (t + 1 < TERMS) {
-      a -= lo_as_float(p0); b -= hi_as_float(p0);
-      c -= lo_as_float(p1); d -= hi_as_float(p1);
-    }
-  }
-}
 
 // AB: stage-ablation mask for profiling experiments (tools/ablate.py).  It is a COMPILE-TIME parameter: as run-time
 // branches the checks cut the K loop into a dozen basic blocks and the scheduler could no longer interleave the
@@ -61,7 +34,6 @@ __device__ inline void split4(const float4 v, uint2 (&out)[TERMS]) {
 // COLUMNS of 4 rows and y / addend / mask move 16 bytes per lane.  Same arithmetic per element, in the same order:
 // results are bit-identical to the scalar epilogue (tests/test_ops_gpu.py).  Needs Cout % 4 == 0, 16-byte aligned
 // tensors, no output stride; otherwise the scalar form runs.
-constexpr int EPI_STRIDE = 40;     // floats per transposed row
 
 template <int TM, int TN>
 __device__ __forceinline__ void conv_epilogue_v4(const ConvArgs& a, f32x16 (&acc)[TM][TN], char* smem, const int bm0,
@@ -73,6 +45,39 @@ __device__ __forceinline__ void conv_epilogue_v4(const ConvArgs& a, f32x16 (&acc
   const __amdgpu_buffer_rsrc_t mr = make_rsrc(a.mask_ref ? a.mask_ref : a.y, a.mask_ref ? a.y_bytes : 0u);
   const int col_in = lane & 31, row_hi = 4 * (lane >> 5);
   const int rrow = lane >> 3, c4 = (lane & 7) * 4;      // read side: 8 lanes x 16 B = one 32-column row
+  // Round 4: EVERY residual / gate load of the tile is issued here, before the first block is turned through LDS (the
+  // K loop's staging registers are dead by now: up to 2 x 64 VGPRs for a 128 x 128 tile).  Before, each 32 x 32 block
+  // issued its own loads behind its LDS writes and waited for them — four dependent HBM round trips per workgroup on every
+  // data-gradient launch (they all gate), with the matrix pipe idle chip-wide on single-pass grids.
+  unsigned offs[TM][TN][4];
+  float4 ad[TM][TN][4], mk[TM][TN][4];
+#pragma unroll
+  for (int in = 0; in < TN; ++in) {
+    const int n = bn0 + wn * TN * 32 + in * 32 + c4;
+#pragma unroll
+    for (int im = 0; im < TM; ++im)
+#pragma unroll
+      for (int pass = 0; pass < 4; ++pass) {
+        const int m = bm0 + wm * TM * 32 + im * 32 + pass * 8 + rrow;
+        offs[im][in][pass] = (n < a.Cout && m < a.M) ? ((unsigned)m * (unsigned)a.Cout + (unsigned)n) * 4u : kOOB;
+      }
+  }
+  if (a.addend) {
+#pragma unroll
+    for (int in = 0; in < TN; ++in)
+#pragma unroll
+      for (int im = 0; im < TM; ++im)
+#pragma unroll
+        for (int pass = 0; pass < 4; ++pass) ad[im][in][pass] = buf_load4(ar, offs[im][in][pass]);
+  }
+  if (a.relu_mode == 2) {
+#pragma unroll
+    for (int in = 0; in < TN; ++in)
+#pragma unroll
+      for (int im = 0; im < TM; ++im)
+#pragma unroll
+        for (int pass = 0; pass < 4; ++pass) mk[im][in][pass] = buf_load4(mr, offs[im][in][pass]);
+  }
   __syncthreads();                                       // every wave is done with the operand planes
 #pragma unroll
   for (int in = 0; in < TN; ++in) {
@@ -94,27 +99,26 @@ __device__ __forceinline__ void conv_epilogue_v4(const ConvArgs& a, f32x16 (&acc
       for (int pass = 0; pass < 4; ++pass) {
         const int row = pass * 8 + rrow;
         const float4 v4 = *reinterpret_cast<const float4*>(tile + row * EPI_STRIDE + c4);
-        const int m = bm0 + wm * TM * 32 + im * 32 + row;
-        const unsigned off = (nvalid && m < a.M) ? ((unsigned)m * (unsigned)a.Cout + (unsigned)n) * 4u : kOOB;
+        const unsigned off = offs[im][in][pass];
         float v[4] = {v4.x, v4.y, v4.z, v4.w};
         const float s4[4] = {sc.x, sc.y, sc.z, sc.w}, b4[4] = {bi.x, bi.y, bi.z, bi.w};
-        float ad[4] = {0.f, 0.f, 0.f, 0.f}, mk[4] = {1.f, 1.f, 1.f, 1.f};
+        float adv[4] = {0.f, 0.f, 0.f, 0.f}, mkv[4] = {1.f, 1.f, 1.f, 1.f};
         if (a.addend) {
-          const float4 t = buf_load4(ar, off);
-          ad[0] = t.x; ad[1] = t.y; ad[2] = t.z; ad[3] = t.w;
+          const float4 t = ad[im][in][pass];
+          adv[0] = t.x; adv[1] = t.y; adv[2] = t.z; adv[3] = t.w;
         }
         if (a.relu_mode == 2) {
-          const float4 t = buf_load4(mr, off);
-          mk[0] = t.x; mk[1] = t.y; mk[2] = t.z; mk[3] = t.w;
+          const float4 t = mk[im][in][pass];
+          mkv[0] = t.x; mkv[1] = t.y; mkv[2] = t.z; mkv[3] = t.w;
         }
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           float x = v[e];
           if (a.scale) x = x * s4[e];
           if (a.bias) x = x + b4[e];
-          if (a.addend) x = x + ad[e];
+          if (a.addend) x = x + adv[e];
           if (a.relu_mode == 1) x = fmaxf(x, 0.f);
-          else if (a.relu_mode == 2) x = (mk[e] > 0.f) ? x : 0.f;
+          else if (a.relu_mode == 2) x = (mkv[e] > 0.f) ? x : 0.f;
           v[e] = x;
         }
         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, make_float4(v[0], v[1], v[2], v[3])), yr,

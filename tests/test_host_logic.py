@@ -342,3 +342,62 @@ def test_offset_branch_padding_on_cpu_matches_zero_padding():
     assert torch.equal(wp[:27], w) and torch.equal(bp[:27], b) and float(wp[27].abs().sum()) == 0.0 and float(bp[27]) == 0.0
     w4 = torch.nn.Parameter(torch.randn(28, 8, 3, 3))
     assert _pad_out_channels(w4, None)[0] is w4
+
+
+def test_deferred_weight_gradient_reductions_never_share_a_buffer_in_one_launch(monkeypatch):
+    """utils.streams: the merged reduction launch adds every queued item into its dw with a plain read-modify-write, so two
+    items with the same dw must not meet in one launch (a weight used twice in a graph).  The queue flushes the
+    earlier one first; zero_grad() drops what a backward without step() left behind."""
+    import types
+
+    import torch
+    from da_detect_amd import _C
+    from da_detect_amd.utils import streams
+
+    launches = []
+    monkeypatch.setattr(_C, "conv_wgrad_reduce_batch", lambda items: launches.append([it[0].dw for it in items]))
+    monkeypatch.setattr(streams, "DIRECT_WGRAD", True)
+    ws = torch.zeros(1)
+
+    def item(dw):
+        return (types.SimpleNamespace(dw=dw), ws, None, None)
+
+    streams.discard_wgrad_reductions()
+    lane = streams.WgradLane(torch.device("cpu"))
+    lane.reduce_batch([item(0x1000), item(0x2000)])
+    lane.reduce_batch([item(0x3000)])
+    assert launches == [] and len(streams._PENDING_REDUCES) == 3           # distinct buffers: merged, deferred
+    lane.reduce_batch([item(0x2000), item(0x4000)])                         # 0x2000 again: the queued pass goes first
+    assert launches == [[0x1000, 0x2000, 0x3000]]
+    assert [it[0].dw for it in streams._PENDING_REDUCES] == [0x2000, 0x4000]
+    lane.reduce_batch([item(0x5000), item(0x5000)])                         # twice inside one node's own batch
+    assert launches[1] == [0x2000, 0x4000, 0x5000] and [it[0].dw for it in streams._PENDING_REDUCES] == [0x5000]
+    streams.flush_wgrad_reductions(torch.device("cpu"))
+    assert launches[2] == [0x5000] and not streams._PENDING_REDUCES and not streams._PENDING_DW
+    # a backward that no step() followed: the next zero_grad() drops its queued passes instead of adding them later
+    from da_detect_amd.parallel.reducer import BucketedGradReducer
+
+    lane.reduce_batch([item(0x6000)])
+    red = BucketedGradReducer([torch.nn.Parameter(torch.ones(4))])
+    red.zero_grad()
+    assert not streams._PENDING_REDUCES and not streams._PENDING_DW and len(launches) == 3
+
+
+def test_crowded_images_take_the_unbounded_sampler_path():
+    """dadet_proposals_sample holds an image's ground truth in an LDS table of 1024 boxes: a batch with a more crowded image
+    must not be handed over as PendingProposals — the RPN then returns BoxLists and the box head's
+    box_match_encode + sample_rois path, which has no such bound, runs"""
+    import torch
+    from da_detect_amd import _C
+    from da_detect_amd.modeling.roi_heads.box_head import loss as L
+    from da_detect_amd.structures.bounding_box import BoxList
+
+    ev = L.FastRCNNLossComputation.__new__(L.FastRCNNLossComputation)
+    ev.proposal_matcher = type("M", (), {"allow_low_quality_matches": False})()
+
+    def target(n):
+        return BoxList(torch.zeros((n, 4)), (100, 100), mode="xyxy")
+
+    base = ev.accepts_pending()
+    assert ev.accepts_pending([target(8), target(_C.PROPOSALS_SAMPLE_MAX_GT)]) == base
+    assert ev.accepts_pending([target(8), target(_C.PROPOSALS_SAMPLE_MAX_GT + 1)]) is False

@@ -653,6 +653,39 @@ def test_direct_weight_gradient_accumulation_matches_the_autograd_path(device):
         torch.testing.assert_close(p1[n], p0[n], rtol=1e-5, atol=1e-7, msg=lambda m, n=n: "%s: %s" % (n, m))
 
 
+def test_a_block_used_twice_keeps_both_weight_gradient_contributions(device):
+    """one Bottleneck applied twice in a graph with direct weight-gradient accumulation: both uses add split partial sums
+    into the SAME gradient buffers, and the merged reduction launch must not see the two items at once (it is a plain
+    read-modify-write per buffer).  Compared with autograd accumulating the two contributions."""
+    from da_detect_amd.modeling.backbone.resnet import BottleneckWithFixedBatchNorm
+    from da_detect_amd.parallel.reducer import BucketedGradReducer
+    from da_detect_amd.utils import streams
+
+    torch.manual_seed(3)
+    block = BottleneckWithFixedBatchNorm(256, 64, 256, stride=1).to(device)
+    x = torch.randn((2, 256, 64, 96), device=device).contiguous(memory_format=torch.channels_last)
+    params = [p for p in block.parameters() if p.requires_grad]
+    grads = []
+    for direct in (False, True):
+        red = BucketedGradReducer(params)
+        streams.enable_direct_wgrad(direct)
+        try:
+            red.zero_grad()
+            y = block(block(x, in_relu=False, out_private=False), in_relu=True, out_private=False)
+            y.square().mean().backward()
+            if direct:
+                assert len(streams._PENDING_REDUCES) > 0, "the case needs split weight gradients queued for the merged pass"
+            red.finalize()
+            torch.cuda.synchronize()
+            grads.append([p.grad.clone() for p in params])
+        finally:
+            streams.enable_direct_wgrad(False)
+            for h in red._hooks:
+                h.remove()
+    for a, b in zip(*grads):
+        torch.testing.assert_close(b, a, rtol=2e-5, atol=1e-7)
+
+
 def test_early_image_level_da_backward_gives_the_same_gradients(device):
     """without a consistency term the image-level DA loss and its backward are queued in front of the box head
     (DomainAdaptationModule.early_image_level) and the instance-head passes run on a side stream: losses and every

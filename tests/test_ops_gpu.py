@@ -1143,3 +1143,73 @@ def test_roi_align_backward_skips_images_without_rois(device):
         full = _C.roi_align_backward(gg, rois, 1 / 16, 14, 14, B, C, H, W, 0, bin_stride=stride)
         lean = _C.roi_align_backward(gg, rois, 1 / 16, 14, 14, B, C, H, W, 0, bin_stride=stride, live_images=1)
         assert torch.equal(full, lean) and float(full[1:].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("case", [
+    # N, Cin(K), H, W, Cout, stride, epilogue
+    (2, 256, 64, 128, 1024, 1, "add_relu"),     # res4 conv3 forward (BASELINE size): K = 256, BN = 64
+    (2, 256, 64, 128, 1024, 1, "add_gate"),     # res4 conv1 data gradient: residual gradient + ReLU gate
+    (2, 128, 128, 256, 512, 1, "add_relu"),     # res3 conv3: K = 128, BN = 128
+    (2, 64, 256, 256, 256, 1, "add_relu"),      # res2 conv3: K = 64 (two slabs per loop iteration)
+    (2, 64, 200, 164, 256, 1, "plain"),         # M = 65600: ragged last slab, odd slab count per workgroup
+    (1, 256, 259, 262, 160, 2, "affine"),       # stride 2 (projection shortcut), Cout not a multiple of the panel
+    (3, 128, 96, 100, 384, 1, "gate"),          # M = 28800, three panels
+])
+def test_weight_stationary_1x1_kernel(device, case):
+    """conv1x1_ws_kernel (csrc/conv_ws.hip) against a float64 contraction and against the tiled split kernel it replaces
+    on the same inputs: same products, another summation order -> fp32 rounding apart; error vs float64 not larger than the
+    tiled kernel's (both within the bound of the accuracy test above)."""
+    import os
+
+    from da_detect_amd import _C
+
+    N, K, H, W, Cout, stride, epi = case
+    g = torch.Generator().manual_seed(sum(case[:6]))
+    x = torch.randn((N, K, H, W), generator=g).to(device).contiguous(memory_format=CL)
+    w = (torch.randn((Cout, K, 1, 1), generator=g) * (2.0 / K) ** 0.5).to(device).contiguous(memory_format=CL)
+    Ho, Wo = (H - 1) // stride + 1, (W - 1) // stride + 1
+    kw = {}
+    if epi in ("add_relu", "affine", "add_gate"):
+        kw["scale"] = (torch.rand(Cout, generator=g) + 0.5).to(device)
+        kw["bias"] = torch.randn(Cout, generator=g).to(device)
+    if epi in ("add_relu", "add_gate"):
+        kw["addend"] = torch.randn((N, Cout, Ho, Wo), generator=g).to(device).contiguous(memory_format=CL)
+    if epi == "add_relu":
+        kw["relu_mode"] = 1
+    if epi in ("add_gate", "gate"):
+        kw["relu_mode"] = 2
+        kw["mask_ref"] = torch.randn((N, Cout, Ho, Wo), generator=g).clamp_min(0).to(device).contiguous(memory_format=CL)
+    d = _C._desc(N, H, W, K, Cout, 1, 1, stride, 0, Ho, Wo)
+    import ctypes
+    from da_detect_amd import _lib
+    assert _lib.load().dadet_conv_forward_variant(ctypes.byref(d)) == 3, "the case must take the weight-stationary kernel"
+    out = {}
+    for flag in ("0", "1"):
+        os.environ["DADET_WS_1X1"] = flag
+        try:
+            out[flag] = _C.conv_forward(x, w, stride=stride, **kw)
+            again = _C.conv_forward(x, w, stride=stride, **kw)
+        finally:
+            os.environ.pop("DADET_WS_1X1")
+        assert torch.equal(out[flag], again)
+    # float64 reference on the device
+    xs = x[:, :, ::stride, ::stride].double().permute(0, 2, 3, 1).reshape(-1, K)
+    ref = xs @ w.double().reshape(Cout, K).t()
+    if "scale" in kw:
+        ref = ref * kw["scale"].double() + kw["bias"].double()
+    if "addend" in kw:
+        ref = ref + kw["addend"].double().permute(0, 2, 3, 1).reshape(-1, Cout)
+    if kw.get("relu_mode") == 1:
+        ref = ref.clamp_min(0)
+    if kw.get("relu_mode") == 2:
+        ref = ref * (kw["mask_ref"].permute(0, 2, 3, 1).reshape(-1, Cout) > 0)
+    errs = {}
+    for flag in ("0", "1"):
+        got = out[flag].permute(0, 2, 3, 1).reshape(-1, Cout).double()
+        e = (got - ref).abs()
+        errs[flag] = (float(e.pow(2).mean().sqrt()), float(e.max()))
+    scale_ = float(ref.abs().mean()) + 1e-30
+    assert errs["1"][1] <= 2e-5 * max(1.0, float(ref.abs().max())), errs
+    assert errs["1"][0] <= 1.25 * errs["0"][0] + 1e-9 * scale_, errs
+    # ReLU at an exact tie may fire on one side only; everything else agrees to fp32 rounding
+    torch.testing.assert_close(out["1"], out["0"], rtol=2e-5, atol=2e-5 * max(1.0, float(ref.abs().max())))

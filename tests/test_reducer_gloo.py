@@ -30,6 +30,7 @@ def _worker(rank, world, port, out):
     red = BucketedGradReducer(params, bucket_bytes=256)  # several tiny buckets
     assert len(red.buckets) > 2 and red._bucket_of[id(never)] is red.buckets[0]
     red.broadcast_parameters(0)
+    red.record_comm(True)
     early = []
     for step in range(3):
         red.zero_grad()
@@ -46,6 +47,13 @@ def _worker(rank, world, port, out):
     # (rank 0 touches it), whose bucket and its successors go out in finalize().
     assert red.static_unused == frozenset([id(never)]), red.static_unused
     assert early[0] == 0 and early[1] == early[2]
+    # communication evidence: every bucket's collective is counted once per step, in backward or in finalize()
+    comm = red.comm_summary(skip=1)
+    assert comm["backend"] == "gloo" and comm["world"] == 2 and comm["buckets"] == len(red.buckets) and comm["steps"] == 2
+    assert comm["buckets_issued_during_backward"] == early[1]
+    assert comm["buckets_issued_during_backward"] + comm["buckets_issued_in_finalize"] == len(red.buckets)
+    assert comm["exposed_ms"] == 0.0 and comm["allreduce_ms"] is None      # CPU tensors: no device events, no durations
+    red.record_comm(False)
     assert early[1] == (len(red.buckets) if rank == 0 else red.buckets.index(red._bucket_of[id(unused)])), early
     # which parameters the optimizer updates: everything some rank touched — `unused` also on rank 1, which never
     # touched it (its averaged gradient is the same on both ranks, so must be its update); `never` on neither
