@@ -240,6 +240,35 @@ def roi_align_backward(grad, rois, spatial_scale, pooled_height, pooled_width, b
     return gin
 
 
+def roi_align_forward_level(input, rois, levels, level, out, spatial_scale, pooled_height, pooled_width, sampling_ratio):
+    """one pyramid level of a multi-level ROIAlign (dadet_roi_align_forward_level): the ROIs with levels[r] == level are
+    pooled from `input` into their rows of `out` [R,C,ph,pw] (channels_last); the other rows are not touched"""
+    _dev(input, "input"), _dev(rois, "rois")
+    assert levels.is_cuda and levels.dtype == torch.int64 and levels.is_contiguous() and levels.numel() == rois.shape[0]
+    assert out.is_contiguous(memory_format=CL) and out.shape[0] == rois.shape[0]
+    B, C, H, W = input.shape
+    x = _nhwc(input)
+    rois = rois.contiguous()
+    ws = _roi_workspace(B, H, W, rois.shape[0], input.device)
+    _lib.call("dadet_roi_align_forward_level", _p(x), _p(rois), _p(levels), int(level), _p(out), B, C, H, W, rois.shape[0],
+              pooled_height, pooled_width, float(spatial_scale), int(sampling_ratio), _p(ws), ctypes.c_size_t(ws.numel()),
+              _stream())
+    return out
+
+
+def roi_align_backward_level(grad, rois, levels, level, spatial_scale, pooled_height, pooled_width, batch_size, channels,
+                             height, width, sampling_ratio):
+    """gradient of one level's map from the ROIs of that level (dadet_roi_align_backward_level) -> [B,C,H,W]"""
+    _dev(grad, "grad"), _dev(rois, "rois")
+    assert levels.is_cuda and levels.dtype == torch.int64 and levels.is_contiguous() and levels.numel() == rois.shape[0]
+    g = _nhwc(grad)
+    gin = torch.empty((batch_size, channels, height, width), dtype=torch.float32, device=grad.device, memory_format=CL)
+    _lib.call("dadet_roi_align_backward_level", _p(g), _p(rois.contiguous()), _p(levels), int(level), _p(gin), batch_size,
+              channels, height, width, rois.shape[0], pooled_height, pooled_width, float(spatial_scale), int(sampling_ratio),
+              _stream())
+    return gin
+
+
 def sigmoid_focalloss_forward(logits, targets, num_classes, gamma, alpha):
     """_C.sigmoid_focalloss_forward(logits[N,C], targets[N] int32, C, gamma, alpha) -> [N,C]"""
     _dev(logits, "logits")

@@ -62,6 +62,10 @@ _SIGNATURES = {
     "dadet_roi_align_backward_atomic": [_P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_float, c_int, _P],
     "dadet_roi_align_forward_sub": [_P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_float, c_int, c_int,
                                     _P, c_size_t, _P],
+    "dadet_roi_align_forward_level": [_P, _P, _P, c_int, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_float, c_int, _P,
+                                      c_size_t, _P],
+    "dadet_roi_align_backward_level": [_P, _P, _P, c_int, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_float, c_int,
+                                       _P],
     "dadet_roi_align_backward_sub": [_P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_float, c_int, c_int,
                                      _P],
     "dadet_sigmoid_focal_loss_forward": [_P, _P, _P, c_int, c_int, c_float, c_float, _P],

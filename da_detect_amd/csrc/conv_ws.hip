@@ -52,13 +52,15 @@ __global__ __launch_bounds__(512, 1) void conv1x1_ws_kernel(const ConvArgs a) {
   constexpr int SUPER = CH < 4 ? 4 : CH;    // chunks per loop iteration: whole slabs, a multiple of the ring
   constexpr int SL = SUPER / CH;            // slabs per loop iteration (2 for K = 64)
   // column blocks whose residual / gate loads are in flight together (register budget: 256 with two waves per SIMD)
-  constexpr int EPB = (NB >= 4) ? 2 : 1;
+  constexpr int EPB = 2;
+  constexpr bool EARLY = NB == 2;           // residual / gate loads of a slab issued in the middle of its contraction
 
   extern __shared__ __attribute__((aligned(16))) char smem[];
   __bf16* Bs = reinterpret_cast<__bf16*>(smem);                      // [3][BN][STRIDE]
   const int t = threadIdx.x;
   const int lane = t & 63, wave = t >> 6;
   float* tile = reinterpret_cast<float*>(smem + 3 * PLANE * 2) + wave * (32 * EPI_STRIDE);
+  float* s_affine = reinterpret_cast<float*>(smem + 3 * PLANE * 2) + 8 * (32 * EPI_STRIDE);   // [BN] scale, [BN] bias
 
   // hardware deals workgroup b to XCD b % 8: the `panels` workgroups of one row group sit on ONE XCD, so the activation
   // rows they all read come through one L2
@@ -110,6 +112,11 @@ __global__ __launch_bounds__(512, 1) void conv1x1_ws_kernel(const ConvArgs a) {
 #pragma unroll
       for (int pl = 0; pl < 3; ++pl) *reinterpret_cast<uint2*>(Bs + pl * PLANE + n * STRIDE + kq * 4) = p[pl];
     }
+  }
+  if (t < BN) {
+    const int n = n0 + t;
+    s_affine[t] = (a.scale && n < a.Cout) ? a.scale[n] : 1.f;
+    s_affine[BN + t] = (a.bias && n < a.Cout) ? a.bias[n] : 0.f;
   }
   __syncthreads();                          // the only workgroup barrier of the kernel
   // the first four chunks go in flight (after the panel: its staging registers are free again)
@@ -194,75 +201,91 @@ __global__ __launch_bounds__(512, 1) void conv1x1_ws_kernel(const ConvArgs a) {
   const int rrow = lane >> 3, c4 = (lane & 7) * 4;
 
   // fused epilogue of one slab (conv_epilogue_v4's: every 32 x 32 accumulator block turned through the wave's private
-  // LDS slice so that a lane owns 4 consecutive columns; y / residual / gate move 16 bytes per lane), then acc = 0
-  auto epilogue = [&](int tile_idx) __attribute__((always_inline)) {
+  // LDS slice so that a lane owns 4 consecutive columns; y / residual / gate move 16 bytes per lane), then acc = 0.
+  // Two phases: epi_issue computes the addresses of EPB column blocks and puts their residual / gate loads in flight,
+  // epi_finish consumes them.  With registers to spare (EARLY: the K = 256 / BN = 64 form, 170 VGPRs without them) the
+  // loads of a slab go out in the MIDDLE of its contraction: a wave then spends its epilogue storing, not waiting — with
+  // two waves per SIMD a wave that waits leaves the matrix pipe to ONE wave for the ~2 us of an HBM round trip, which is
+  // 40% of a slab's 5 us.
+  unsigned e_offs[EPB][4];                  // EARLY only: alive from the middle of a slab to its epilogue
+  float4 e_ad[EPB][4], e_mk[EPB][4];
+  auto epi_issue = [&](int tile_idx, int nb0, unsigned (&offs)[EPB][4], float4 (&ad)[EPB][4], float4 (&mk)[EPB][4])
+      __attribute__((always_inline)) {
     const int mbase = tile_idx * WS_ROWS + wave * 32;
 #pragma unroll
+    for (int e = 0; e < EPB; ++e) {
+      const int n = n0 + (nb0 + e) * 32 + c4;
+#pragma unroll
+      for (int pass = 0; pass < 4; ++pass) {
+        const int m = mbase + pass * 8 + rrow;
+        offs[e][pass] = (n < a.Cout && tile_idx < tiles && m < a.M) ? ((unsigned)m * (unsigned)a.Cout + (unsigned)n) * 4u : kOOB;
+      }
+    }
+    if (a.addend) {
+#pragma unroll
+      for (int e = 0; e < EPB; ++e)
+#pragma unroll
+        for (int pass = 0; pass < 4; ++pass) ad[e][pass] = buf_load4(ar, offs[e][pass]);
+    }
+    if (a.relu_mode == 2) {
+#pragma unroll
+      for (int e = 0; e < EPB; ++e)
+#pragma unroll
+        for (int pass = 0; pass < 4; ++pass) mk[e][pass] = buf_load4(mr, offs[e][pass]);
+    }
+  };
+  auto epi_finish = [&](int nb0, const unsigned (&offs)[EPB][4], const float4 (&ad)[EPB][4], const float4 (&mk)[EPB][4])
+      __attribute__((always_inline)) {
+#pragma unroll
+    for (int e = 0; e < EPB; ++e) {
+      const float4 sc = *reinterpret_cast<const float4*>(s_affine + (nb0 + e) * 32 + c4);
+      const float4 bi = *reinterpret_cast<const float4*>(s_affine + BN + (nb0 + e) * 32 + c4);
+#pragma unroll
+      for (int g = 0; g < 4; ++g)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) tile[(q + 8 * g + row_hi) * EPI_STRIDE + col_in] = acc[nb0 + e][g * 4 + q];
+      __builtin_amdgcn_s_waitcnt(0xc07f);                // lgkmcnt(0): a wave's own LDS traffic is ordered
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int pass = 0; pass < 4; ++pass) {
+        const float4 v4 = *reinterpret_cast<const float4*>(tile + (pass * 8 + rrow) * EPI_STRIDE + c4);
+        float v[4] = {v4.x, v4.y, v4.z, v4.w};
+        const float s4[4] = {sc.x, sc.y, sc.z, sc.w}, b4[4] = {bi.x, bi.y, bi.z, bi.w};
+        float adv[4] = {0.f, 0.f, 0.f, 0.f}, mkv[4] = {1.f, 1.f, 1.f, 1.f};
+        if (a.addend) {
+          const float4 q4 = ad[e][pass];
+          adv[0] = q4.x; adv[1] = q4.y; adv[2] = q4.z; adv[3] = q4.w;
+        }
+        if (a.relu_mode == 2) {
+          const float4 q4 = mk[e][pass];
+          mkv[0] = q4.x; mkv[1] = q4.y; mkv[2] = q4.z; mkv[3] = q4.w;
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          float x = v[k];
+          if (a.scale) x = x * s4[k];
+          if (a.bias) x = x + b4[k];
+          if (a.addend) x = x + adv[k];
+          if (a.relu_mode == 1) x = fmaxf(x, 0.f);
+          else if (a.relu_mode == 2) x = (mkv[k] > 0.f) ? x : 0.f;
+          v[k] = x;
+        }
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, make_float4(v[0], v[1], v[2], v[3])), yr,
+                                               (int)offs[e][pass], 0, 0);
+      }
+      __builtin_amdgcn_wave_barrier();                   // the slice is rewritten by the next block
+    }
+  };
+  auto epilogue = [&](int tile_idx) __attribute__((always_inline)) {
+#pragma unroll
     for (int nb0 = 0; nb0 < NB; nb0 += EPB) {
-      unsigned offs[EPB][4];
-      float4 ad[EPB][4], mk[EPB][4], sc[EPB], bi[EPB];
-#pragma unroll
-      for (int e = 0; e < EPB; ++e) {
-        const int n = n0 + (nb0 + e) * 32 + c4;
-        const bool nvalid = n < a.Cout;
-        sc[e] = make_float4(1.f, 1.f, 1.f, 1.f);
-        bi[e] = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (a.scale && nvalid) sc[e] = *reinterpret_cast<const float4*>(a.scale + n);
-        if (a.bias && nvalid) bi[e] = *reinterpret_cast<const float4*>(a.bias + n);
-#pragma unroll
-        for (int pass = 0; pass < 4; ++pass) {
-          const int m = mbase + pass * 8 + rrow;
-          offs[e][pass] = (nvalid && tile_idx < tiles && m < a.M) ? ((unsigned)m * (unsigned)a.Cout + (unsigned)n) * 4u : kOOB;
-        }
-      }
-      if (a.addend) {
-#pragma unroll
-        for (int e = 0; e < EPB; ++e)
-#pragma unroll
-          for (int pass = 0; pass < 4; ++pass) ad[e][pass] = buf_load4(ar, offs[e][pass]);
-      }
-      if (a.relu_mode == 2) {
-#pragma unroll
-        for (int e = 0; e < EPB; ++e)
-#pragma unroll
-          for (int pass = 0; pass < 4; ++pass) mk[e][pass] = buf_load4(mr, offs[e][pass]);
-      }
-#pragma unroll
-      for (int e = 0; e < EPB; ++e) {
-#pragma unroll
-        for (int g = 0; g < 4; ++g)
-#pragma unroll
-          for (int q = 0; q < 4; ++q) tile[(q + 8 * g + row_hi) * EPI_STRIDE + col_in] = acc[nb0 + e][g * 4 + q];
-        __builtin_amdgcn_s_waitcnt(0xc07f);                // lgkmcnt(0): a wave's own LDS traffic is ordered
-        __builtin_amdgcn_wave_barrier();
-#pragma unroll
-        for (int pass = 0; pass < 4; ++pass) {
-          const float4 v4 = *reinterpret_cast<const float4*>(tile + (pass * 8 + rrow) * EPI_STRIDE + c4);
-          float v[4] = {v4.x, v4.y, v4.z, v4.w};
-          const float s4[4] = {sc[e].x, sc[e].y, sc[e].z, sc[e].w}, b4[4] = {bi[e].x, bi[e].y, bi[e].z, bi[e].w};
-          float adv[4] = {0.f, 0.f, 0.f, 0.f}, mkv[4] = {1.f, 1.f, 1.f, 1.f};
-          if (a.addend) {
-            const float4 q4 = ad[e][pass];
-            adv[0] = q4.x; adv[1] = q4.y; adv[2] = q4.z; adv[3] = q4.w;
-          }
-          if (a.relu_mode == 2) {
-            const float4 q4 = mk[e][pass];
-            mkv[0] = q4.x; mkv[1] = q4.y; mkv[2] = q4.z; mkv[3] = q4.w;
-          }
-#pragma unroll
-          for (int k = 0; k < 4; ++k) {
-            float x = v[k];
-            if (a.scale) x = x * s4[k];
-            if (a.bias) x = x + b4[k];
-            if (a.addend) x = x + adv[k];
-            if (a.relu_mode == 1) x = fmaxf(x, 0.f);
-            else if (a.relu_mode == 2) x = (mkv[k] > 0.f) ? x : 0.f;
-            v[k] = x;
-          }
-          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, make_float4(v[0], v[1], v[2], v[3])), yr,
-                                                 (int)offs[e][pass], 0, 0);
-        }
-        __builtin_amdgcn_wave_barrier();                   // the slice is rewritten by the next block
+      if (EARLY && nb0 == 0) {
+        epi_finish(nb0, e_offs, e_ad, e_mk);
+      } else {
+        unsigned offs[EPB][4];
+        float4 ad[EPB][4], mk[EPB][4];
+        epi_issue(tile_idx, nb0, offs, ad, mk);
+        epi_finish(nb0, offs, ad, mk);
       }
     }
 #pragma unroll
@@ -279,6 +302,7 @@ __global__ __launch_bounds__(512, 1) void conv1x1_ws_kernel(const ConvArgs a) {
     for (int k = 0; k < 4; ++k) ahead[k] = (k <= (SUPER + 3) / CH) ? row_off(tl + k * G) : kOOBws;
     ws_unroll<SUPER>([&](auto Q) __attribute__((always_inline)) {
       constexpr int q = decltype(Q)::value;
+      if (EARLY && (q % CH) == CH / 2) epi_issue(tl + (q / CH) * G, 0, e_offs, e_ad, e_mk);
       step(Q, std::integral_constant<int, 0>{}, ahead);
       step(Q, std::integral_constant<int, 1>{}, ahead);
       if ((q + 1) % CH == 0) epilogue(tl + (q / CH) * G);   // a slab past the end (K = 64, odd slab count) stores nothing
@@ -303,7 +327,7 @@ bool ws_eligible(const ConvArgs& a) {
 
 template <int K, int BN>
 static int launch_ws(ConvArgs& a, hipStream_t st) {
-  const size_t lds = (size_t)3 * BN * (K + 8) * 2 + 8 * 32 * EPI_STRIDE * 4;
+  const size_t lds = (size_t)3 * BN * (K + 8) * 2 + 8 * 32 * EPI_STRIDE * 4 + 2 * BN * 4;
   static bool attr_set = false;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv1x1_ws_kernel<K, BN>),

@@ -92,7 +92,7 @@ template <int VEC>
 __global__ __launch_bounds__(256) void roi_align_fwd_kernel(
     const float* __restrict__ input, const float* __restrict__ rois, float* __restrict__ output, int C,
     int H, int W, int pooled_h, int pooled_w, float scale, int sampling_ratio, const int* __restrict__ order,
-    int bin_stride) {
+    int bin_stride, const int64_t* __restrict__ levels, int level) {
   // XCD-aware order: the 14 bin rows of one ROI read overlapping feature rows; hardware deals consecutive workgroup
   // ids to the 8 XCDs round-robin, which made every XCD's L2 fetch the same rows again (PMC: 1.95 GB through the
   // fabric for 0.48 GB of algorithmic traffic).  The remap gives each XCD a contiguous range of (roi, ph).
@@ -107,6 +107,9 @@ __global__ __launch_bounds__(256) void roi_align_fwd_kernel(
   const int r = order ? order[wg / out_h] : wg / out_h;
   const int oph = wg % out_h;
   const int ph = oph * bin_stride;
+  // feature pyramids (dadet_roi_align_forward_level): one launch per level over ALL ROIs, every ROI pooled by the launch
+  // of its own level into its own output row — no per-level index lists, no host round trip to size them
+  if (levels && levels[r] != (int64_t)level) return;
   const RoiGeom g = roi_geometry(rois + (size_t)r * 5, scale, pooled_h, pooled_w, sampling_ratio);
   const float* __restrict__ img = input + (size_t)g.batch * H * W * C;
   float* __restrict__ out_row = output + ((size_t)r * out_h + oph) * out_w * C;
@@ -408,7 +411,8 @@ __device__ inline int roi_contributions(const RoiGeom& g, int r, int H, int W, i
 template <int VEC, int MAXC>   // MAXC channel groups per lane: C <= 256 * VEC * MAXC
 __global__ __launch_bounds__(256) void roi_align_bwd_list_kernel(
     const float* __restrict__ grad_out, const float* __restrict__ rois, float* __restrict__ grad_in, int B, int C,
-    int H, int W, int R, int pooled_h, int pooled_w, float scale, int sampling_ratio, int bin_stride) {
+    int H, int W, int R, int pooled_h, int pooled_w, float scale, int sampling_ratio, int bin_stride,
+    const int64_t* __restrict__ levels, int level) {
   __shared__ Contribution s_list[kListCap];
   __shared__ int s_ids[256];        // touching ROIs of the current range, ascending
   __shared__ int s_wave_n[4];
@@ -479,7 +483,7 @@ __global__ __launch_bounds__(256) void roi_align_bwd_list_kernel(
     bool hit = false;
     if (r < R) {
       const RoiGeom g = roi_geometry(rois + (size_t)r * 5, scale, pooled_h, pooled_w, sampling_ratio);
-      hit = g.batch == b && roi_touches_tile(g, pooled_h, pooled_w, y0, x0);
+      hit = g.batch == b && (!levels || levels[r] == (int64_t)level) && roi_touches_tile(g, pooled_h, pooled_w, y0, x0);
     }
     const unsigned long long ballot = __ballot(hit);
     if (lane == 0) s_wave_n[wave] = __popcll(ballot);
@@ -573,7 +577,8 @@ extern "C" int dadet_roi_align_workspace_bytes(int B, int H, int W, int R, size_
 
 static int roi_align_forward_impl(const float* input, const float* rois, float* output, int B, int C, int H, int W, int R,
                                   int pooled_h, int pooled_w, float spatial_scale, int sampling_ratio, void* workspace,
-                                  size_t workspace_bytes, void* stream, int bin_stride = 1) {
+                                  size_t workspace_bytes, void* stream, int bin_stride = 1,
+                                  const int64_t* levels = nullptr, int level = 0) {
   int rc = roi_args_ok(input, rois, output, B, C, H, W, R, pooled_h, pooled_w);
   if (rc) return rc;
   DADET_REQUIRE(bin_stride >= 1 && bin_stride <= pooled_h && bin_stride <= pooled_w, "roi_align_forward: bin_stride=%d",
@@ -595,11 +600,11 @@ static int roi_align_forward_impl(const float* input, const float* rois, float* 
   if (vec) {
     const int threads = (C / 4 >= 256) ? 256 : ((C / 4 + 63) / 64) * 64;
     hipLaunchKernelGGL(roi_align_fwd_kernel<4>, grid, dim3(threads), 0, as_stream(stream), input, rois,
-                       output, C, H, W, pooled_h, pooled_w, spatial_scale, sampling_ratio, order, bin_stride);
+                       output, C, H, W, pooled_h, pooled_w, spatial_scale, sampling_ratio, order, bin_stride, levels, level);
   } else {
     const int threads = (C >= 256) ? 256 : ((C + 63) / 64) * 64;
     hipLaunchKernelGGL(roi_align_fwd_kernel<1>, grid, dim3(threads), 0, as_stream(stream), input, rois,
-                       output, C, H, W, pooled_h, pooled_w, spatial_scale, sampling_ratio, order, bin_stride);
+                       output, C, H, W, pooled_h, pooled_w, spatial_scale, sampling_ratio, order, bin_stride, levels, level);
   }
   return check_launch("roi_align_forward");
 }
@@ -648,7 +653,7 @@ extern "C" int dadet_roi_align_backward_atomic(const float* grad_output, const f
 
 static int roi_align_backward_impl(const float* grad_output, const float* rois, float* grad_input, int B, int C, int H,
                                    int W, int R, int pooled_h, int pooled_w, float spatial_scale, int sampling_ratio,
-                                   int bin_stride, void* stream) {
+                                   int bin_stride, void* stream, const int64_t* levels = nullptr, int level = 0) {
   int rc = roi_args_ok(grad_output, rois, grad_input, B, C, H, W, R, pooled_h, pooled_w);
   if (rc) return rc;
   DADET_REQUIRE(bin_stride >= 1 && bin_stride <= pooled_h && bin_stride <= pooled_w, "roi_align_backward: bin_stride=%d",
@@ -670,10 +675,14 @@ static int roi_align_backward_impl(const float* grad_output, const float* rois, 
     const dim3 tgrid((unsigned)(((supers + kNumXCD - 1) / kNumXCD) * kNumXCD * 4), 1, 1);
     if (C <= 1024)
       hipLaunchKernelGGL((roi_align_bwd_list_kernel<4, 1>), tgrid, dim3(256), 0, st, grad_output, rois, grad_input, B, C,
-                         H, W, R, pooled_h, pooled_w, spatial_scale, sampling_ratio, bin_stride);
+                         H, W, R, pooled_h, pooled_w, spatial_scale, sampling_ratio, bin_stride, levels, level);
     else
       hipLaunchKernelGGL((roi_align_bwd_list_kernel<4, 4>), tgrid, dim3(256), 0, st, grad_output, rois, grad_input, B, C,
-                         H, W, R, pooled_h, pooled_w, spatial_scale, sampling_ratio, bin_stride);
+                         H, W, R, pooled_h, pooled_w, spatial_scale, sampling_ratio, bin_stride, levels, level);
+  } else if (levels) {
+    set_error("roi_align_backward_level: needs C %% 4 == 0 (C=%d), 16-byte aligned buffers and a pooled grid of at most "
+              "14 x 14 (%d x %d)", C, pooled_h, pooled_w);
+    return DADET_EUNSUPPORTED;
   } else if (bin_stride != 1) {
     set_error("roi_align_backward_sub: needs C %% 4 == 0 (C=%d), 16-byte aligned buffers and a pooled grid of at most "
               "14 x 14 (%d x %d)", C, pooled_h, pooled_w);
@@ -702,4 +711,27 @@ extern "C" int dadet_roi_align_backward_sub(const float* grad_output, const floa
                                             int sampling_ratio, int bin_stride, void* stream) {
   return roi_align_backward_impl(grad_output, rois, grad_input, B, C, H, W, R, pooled_h, pooled_w, spatial_scale,
                                  sampling_ratio, bin_stride, stream);
+}
+
+// Feature pyramids (reference: modeling/poolers.py:91-121 splits the ROIs by level with nonzero and scatters the per-level
+// results back with an index_put): `levels[r]` (int64, the LevelMapper's result on the device) names the level of ROI r; the
+// launch for `level` pools exactly those ROIs into THEIR rows of the shared [R][ph][pw][C] output and leaves the others
+// alone.  One call per level with the same rois / levels / output; every ROI has exactly one level, so the output is
+// complete after the last call.
+extern "C" int dadet_roi_align_forward_level(const float* input, const float* rois, const int64_t* levels, int level,
+                                             float* output, int B, int C, int H, int W, int R, int pooled_h, int pooled_w,
+                                             float spatial_scale, int sampling_ratio, void* workspace,
+                                             size_t workspace_bytes, void* stream) {
+  DADET_REQUIRE(levels || R == 0, "roi_align_forward_level: null levels");
+  return roi_align_forward_impl(input, rois, output, B, C, H, W, R, pooled_h, pooled_w, spatial_scale, sampling_ratio,
+                                workspace, workspace_bytes, stream, 1, levels, level);
+}
+
+// gradient of the level's map: the gather sweeps its pixel tiles and takes the ROIs of this level only
+extern "C" int dadet_roi_align_backward_level(const float* grad_output, const float* rois, const int64_t* levels, int level,
+                                              float* grad_input, int B, int C, int H, int W, int R, int pooled_h,
+                                              int pooled_w, float spatial_scale, int sampling_ratio, void* stream) {
+  DADET_REQUIRE(levels || R == 0, "roi_align_backward_level: null levels");
+  return roi_align_backward_impl(grad_output, rois, grad_input, B, C, H, W, R, pooled_h, pooled_w, spatial_scale,
+                                 sampling_ratio, 1, stream, levels, level);
 }

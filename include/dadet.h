@@ -106,6 +106,17 @@ int dadet_roi_align_forward_sub(const float* input, const float* rois, float* ou
 int dadet_roi_align_backward_sub(const float* grad_output, const float* rois, float* grad_input, int B, int C, int H,
                                  int W, int R, int pooled_h, int pooled_w, float spatial_scale, int sampling_ratio,
                                  int bin_stride, void* stream);
+/* Feature pyramids — replaces the per-level split of `Pooler.forward` (reference: modeling/poolers.py:91-121: LevelMapper,
+ * one `nonzero` + `_C.roi_align_forward` + index_put per level).  `levels` [R] int64 on the device: the level of every
+ * ROI (poolers.py:11-42).  Call once per level with that level's map / scale and the SAME rois, levels and output
+ * [R][ph][pw][C]: the launch pools the ROIs of `level` into their own rows and leaves the other rows alone.  Backward:
+ * grad_input [B][H][W][C] of the level's map from the ROIs of that level (deterministic gather, C % 4 == 0). */
+int dadet_roi_align_forward_level(const float* input, const float* rois, const int64_t* levels, int level, float* output,
+                                  int B, int C, int H, int W, int R, int pooled_h, int pooled_w, float spatial_scale,
+                                  int sampling_ratio, void* workspace, size_t workspace_bytes, void* stream);
+int dadet_roi_align_backward_level(const float* grad_output, const float* rois, const int64_t* levels, int level,
+                                   float* grad_input, int B, int C, int H, int W, int R, int pooled_h, int pooled_w,
+                                   float spatial_scale, int sampling_ratio, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * SigmoidFocalLoss — replaces `_C.sigmoid_focalloss_forward/backward`

@@ -757,6 +757,49 @@ def test_sample_anchors_takes_a_balanced_sample_in_anchor_order(device, A, frac_
         assert not torch.equal(other["neg"], out["neg"])
 
 
+@pytest.mark.parametrize("A,frac_pos,frac_ign", [
+    (122880, 0.0005, 0.4),      # C4 at 1024 x 2048: a few positives, ~70 000 negatives
+    (523776, 0.0003, 0.5),      # five-level pyramid
+    (122880, 0.01, 0.2),        # more positives than max_pos: the positives are thresholded too
+    (122880, 0.08, 0.0),        # > 4096 positives: candidate list overflow -> one-workgroup algorithm
+    (65536, 0.0, 0.999),        # ~65 negatives in all: every one is taken (fewer than wanted)
+    (200000, 0.0, 0.9985),      # ~300 negatives, 256 wanted, ~3 listed: the lists do not hold the answer -> fallback
+    (40000, 0.001, 0.1),
+])
+def test_chip_wide_anchor_scan_equals_the_one_workgroup_sampler(device, A, frac_pos, frac_ign):
+    """dadet_sample_anchors for A >= 32768 scans the labels with one workgroup per 4096 anchors and finishes in one
+    (csrc/sampling.hip, round 4); the result must be the one-workgroup kernel's (DADET_ANCHOR_SCAN=0) bit for bit — the k
+    smallest keys per class, ties to the lower index — including when the candidate lists overflow or fall short and the
+    finishing workgroup runs the old algorithm; and the per-stream scratch must be clean for the next call"""
+    import os
+
+    from da_detect_amd import _C
+
+    rng = np.random.default_rng(A + int(frac_pos * 1e6))
+    cap, max_pos, offset = 256, 128, 12345
+    lab = np.where(rng.uniform(0, 1, A) < frac_pos, 1.0, 0.0)
+    lab = np.where(rng.uniform(0, 1, A) < frac_ign, -1.0, lab).astype(np.float32)
+    labels = torch.from_numpy(lab).to(device)
+    reg = torch.from_numpy(rng.standard_normal((A, 4)).astype(np.float32)).to(device)
+    for seed in (3, 0xDEADBEEFCAFE, 2 ** 63 + 11):
+        got = {}
+        for flag in ("0", "1", "1"):            # the scan twice in a row: counters left at zero by the first call
+            os.environ["DADET_ANCHOR_SCAN"] = flag
+            try:
+                counts = torch.full((2,), -7, dtype=torch.int32, device=device)
+                out = _C.sample_anchors(labels, reg, cap, max_pos, seed, offset, counts)
+            finally:
+                os.environ.pop("DADET_ANCHOR_SCAN")
+            cur = (counts.tolist(), out["pos"].cpu(), out["neg"].cpu(), out["regression_targets_pos"].cpu())
+            if flag in got:
+                prev = got[flag]
+                assert cur[0] == prev[0] and all(torch.equal(a, b) for a, b in zip(cur[1:], prev[1:]))
+            got[flag] = cur
+        assert got["0"][0] == got["1"][0], (got["0"][0], got["1"][0])
+        for a, b in zip(got["0"][1:], got["1"][1:]):
+            assert torch.equal(a, b)
+
+
 def test_sample_anchors_is_uniform(device):
     """over many seeds every negative (and every positive when there are more than max_pos) is taken equally often"""
     from da_detect_amd import _C
@@ -1213,3 +1256,39 @@ def test_weight_stationary_1x1_kernel(device, case):
     assert errs["1"][0] <= 1.25 * errs["0"][0] + 1e-9 * scale_, errs
     # ReLU at an exact tie may fire on one side only; everything else agrees to fp32 rounding
     torch.testing.assert_close(out["1"], out["0"], rtol=2e-5, atol=2e-5 * max(1.0, float(ref.abs().max())))
+
+
+def test_pyramid_roi_align_equals_the_per_level_split(device):
+    """Pooler over four pyramid levels: one launch per level over all ROIs with the level filter in the kernel
+    (dadet_roi_align_forward_level / _backward_level, no host round trip) against the reference's structure — per level
+    nonzero, gather, ROIAlign, index_put (poolers.py:108-121): identical features, identical map gradients"""
+    from da_detect_amd.modeling import poolers as P
+    from da_detect_amd.structures.bounding_box import BoxList
+
+    rng = np.random.default_rng(11)
+    scales = (0.25, 0.125, 0.0625, 0.03125)
+    H0, W0 = 640, 1024
+    feats = [torch.from_numpy(rng.standard_normal((2, 64, int(H0 * s), int(W0 * s))).astype(np.float32)).to(device)
+             .contiguous(memory_format=CL).requires_grad_(True) for s in scales]
+    boxes = []
+    for n in (150, 97):
+        xy = rng.uniform(0, 300, (n, 2))
+        wh = np.exp(rng.uniform(np.log(8), np.log(900), (n, 2)))          # every level is hit
+        b = np.concatenate([xy, np.minimum(xy + wh, [W0 - 1, H0 - 1])], 1).astype(np.float32)
+        boxes.append(BoxList(torch.from_numpy(b).to(device), (W0, H0), mode="xyxy"))
+    pooler = P.Pooler((7, 7), scales, 2).to(device)
+    levels = pooler.map_levels(boxes)
+    assert sorted(int(v) for v in levels.unique().tolist()) == [0, 1, 2, 3]
+    gy = torch.from_numpy(rng.standard_normal((247, 64, 7, 7)).astype(np.float32)).to(device)
+    res = {}
+    for flag in (False, True):
+        P._PYRAMID_KERNELS = flag
+        try:
+            out = pooler(feats, boxes)
+            grads = torch.autograd.grad(out, feats, gy)
+        finally:
+            P._PYRAMID_KERNELS = True
+        res[flag] = (out.detach(), grads)
+    assert torch.equal(res[True][0], res[False][0])
+    for a, b in zip(res[True][1], res[False][1]):
+        assert torch.equal(a, b)

@@ -3,8 +3,31 @@
 # of the three R-50-C4 ones, step timeline + idle gaps, per-shape GEMM table with the GEMM-free stretches, and the default
 # bench line.  Everything lands under gpurun_out/<tag>_*; copy what is to be judged into profiles/.
 # usage: tools/profile_round.sh <tag>
+#        tools/profile_round.sh <tag> --ranks N     (an N-GPU node: kernel trace of the N-rank bench with the RCCL kernels)
 set -u
-TAG=${1:-r03}
+TAG=${1:-r04}
+if [ "${2:-}" = "--ranks" ]; then
+  # One rocprofv3 per rank (launched under torch.distributed.run, one output directory per rank): the kernel trace holds
+  # the ncclDevKernel_* launches of the bucket all-reduces on RCCL's stream next to the backward GEMMs of the compute stream;
+  # tools/step_timeline.py on rank 0's trace shows where in backward each of them ran.  The bench line's `comm` block carries
+  # the same overlap as numbers (buckets issued during backward, all-reduce time, exposed wait in finalize()).
+  N=${3:?--ranks N}
+  R=${GRAFT_REPO_ROOT:-/root/repo}
+  cd $R
+  export TMPDIR=/tmp HSA_ENABLE_IPC_MODE_LEGACY=0
+  OUT=gpurun_out/${TAG}_ranks${N}
+  mkdir -p $OUT
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node $N --master-addr 127.0.0.1 --master-port 29517 \
+      --no-python bash -c "cd /tmp && rocprofv3 --kernel-trace --stats -d $R/$OUT/rank\$RANK -o trace -- \
+      python $R/bench.py --gpus $N --steps 12 --warmup 6 --others none --resolutions none --no-cpu-baseline" \
+      > $OUT/bench.log 2> $OUT/bench.err
+  grep '^{"metric"' $OUT/bench.log | tail -1 | python -c "import sys, json; d = json.loads(sys.stdin.read()); print(d['value'], d['ms_per_step'], d.get('comm'))"
+  for r in $(seq 0 $((N - 1))); do
+    f=$(ls $OUT/rank$r/*/*kernel_stats.csv 2>/dev/null | head -1)
+    [ -n "$f" ] && { echo "== rank $r: RCCL kernels"; grep -i "nccl" $f | cut -c1-160 | head -5; }
+  done
+  exit 0
+fi
 R=${GRAFT_REPO_ROOT:-/root/repo}
 cd $R
 for wl in img_only da triplet fpn_dcn_da; do
