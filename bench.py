@@ -443,7 +443,11 @@ def main():
 
     r = run_workload(args, args.workload, device, rank, world, args.steps, args.warmup, headline=True)
     if args.others is None:
-        others = ["da", "triplet", "fpn_dcn_da"] if (args.workload == "img_only" and args.image_hw is None) else []
+        # N > 1 (the driver's scaling runs): the headline recipe only — the other recipes would be built as further models
+        # of every rank's process, and a failure of one of them on one rank would leave the others waiting in a collective
+        # with the headline line unprinted; `--others da,triplet,fpn_dcn_da` asks for them explicitly
+        others = ["da", "triplet", "fpn_dcn_da"] if (args.workload == "img_only" and args.image_hw is None
+                                                     and world == 1) else []
     else:
         others = [w for w in args.others.split(",") if w and w != "none"]
     other_results = {}

@@ -200,7 +200,7 @@ def roi_align_forward(input, rois, spatial_scale, pooled_height, pooled_width, s
 
 
 # forward: ROIs processed in spatial (Z-order) order through a scratch buffer; False = the plain entry point
-ROI_ALIGN_WORKSPACE = os.environ.get("DADET_ROI_WORKSPACE", "1") == "1"
+ROI_ALIGN_WORKSPACE = True
 
 
 def _roi_workspace(B, H, W, R, device):
@@ -374,7 +374,7 @@ class _TransposeCache(object):
     autograd version is the one it was computed from and (b) the weight epoch is — the epoch is what in-place updates
     through raw pointers bump (FusedSGD.step -> bump_weight_epoch(); ATen's in-place ops bump the version themselves).
     The first request of an epoch recomputes every entry in one batched launch on the current stream; a weight seen for
-    the first time is transposed on the spot and joins the table.  DADET_TRANSPOSE_BATCH=0: one launch per request."""
+    the first time is transposed on the spot and joins the table.  `enabled = False`: one launch per request."""
 
     def __init__(self):
         self.entries = {}
@@ -382,7 +382,7 @@ class _TransposeCache(object):
         self.batched_epoch = -1
         self.table = None          # (device tensor, n, total_blocks, keys)
         self.ready = None          # (stream, event) of the last batched refresh
-        self.enabled = os.environ.get("DADET_TRANSPOSE_BATCH", "1") == "1"
+        self.enabled = True
 
     def bump(self, device=None):
         """new weight epoch; with a device: refresh every entry at once, on the caller's stream (the optimizer's, behind
@@ -1089,6 +1089,29 @@ def topk_sorted(scores, k):
     _lib.call("dadet_topk_sorted", _p(scores), rows, n, ctypes.c_int64(scores.stride(0)), int(k), _p(vals), _p(idx),
               _stream())
     return vals, idx
+
+
+TOPK_ROWS_MAX = 16
+
+
+def topk_sorted_rows(score_rows, ks):
+    """sorted top-k of several 1-D score tensors of different lengths in one call (dadet_topk_sorted_rows: five launches
+    for all of them) -> [(scores [k_i] descending, indices [k_i] int64, ties by ascending index)]"""
+    assert 0 < len(score_rows) <= TOPK_ROWS_MAX and len(ks) == len(score_rows)
+    dev = score_rows[0].device
+    rows, outs = (_lib.TopkRow * len(score_rows))(), []
+    for i, (s, k) in enumerate(zip(score_rows, ks)):
+        _dev(s, "scores")
+        assert s.dim() == 1 and s.is_contiguous() and 0 < k <= min(s.numel(), TOPK_SORTED_MAX)
+        o_s = torch.empty(k, dtype=torch.float32, device=dev)
+        o_i = torch.empty(k, dtype=torch.int64, device=dev)
+        rows[i] = _lib.TopkRow(s.data_ptr(), o_s.data_ptr(), o_i.data_ptr(), s.numel(), int(k))
+        outs.append((o_s, o_i))
+    nbytes = ctypes.c_size_t(0)
+    _lib.call("dadet_topk_sorted_rows_workspace_bytes", len(score_rows), int(max(ks)), ctypes.byref(nbytes))
+    ws = _workspace(nbytes.value, dev)
+    _lib.call("dadet_topk_sorted_rows", rows, len(score_rows), _p(ws), ctypes.c_size_t(ws.numel()), _stream())
+    return outs
 
 
 def rpn_anchor_targets(anchors, visible, gt_boxes, high_threshold, low_threshold):

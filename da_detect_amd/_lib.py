@@ -41,6 +41,12 @@ class MergeEntry(ctypes.Structure):
                 ("scores_out", c_void_p), ("n", c_int), ("cap", c_int)]
 
 
+class TopkRow(ctypes.Structure):
+    """mirror of dadet_topk_row (include/dadet.h)"""
+
+    _fields_ = [("scores", c_void_p), ("out_scores", c_void_p), ("out_idx", c_void_p), ("n", c_int), ("k", c_int)]
+
+
 class SgdEntry(ctypes.Structure):
     """mirror of dadet_sgd_entry (include/dadet.h)"""
 
@@ -109,6 +115,8 @@ _SIGNATURES = {
                                c_float, c_int, c_int, c_uint64, c_int, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P],
     "dadet_sample_anchors": [_P, _P, c_int, c_int, c_int, c_uint64, c_int64, _P, _P, _P, _P, _P],
     "dadet_topk_sorted": [_P, c_int, c_int, c_int64, c_int, _P, _P, _P],
+    "dadet_topk_sorted_rows_workspace_bytes": [c_int, c_int, POINTER(c_size_t)],
+    "dadet_topk_sorted_rows": [POINTER(TopkRow), c_int, _P, c_size_t, _P],
     "dadet_rpn_anchor_targets": [_P, _P, c_int, _P, c_int, c_float, c_float, _P, _P, _P, _P],
     "dadet_box_match_encode": [_P, c_int, _P, _P, c_int, c_float, c_float, c_float, c_float, c_float, c_float, _P, _P,
                                _P, _P],

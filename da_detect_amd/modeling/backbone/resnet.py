@@ -37,7 +37,7 @@ ResNet152FPNStagesTo5 = _specs((1, 3, True), (2, 8, True), (3, 36, True), (4, 3,
 
 
 # one reduction launch per block for its split weight gradients (dadet_conv_wgrad_reduce_batch); 0: one pass per tensor
-_WGRAD_BATCH = __import__("os").environ.get("DADET_WGRAD_BATCH", "1") == "1"
+_WGRAD_BATCH = True
 
 
 class _BottleneckFn(torch.autograd.Function):

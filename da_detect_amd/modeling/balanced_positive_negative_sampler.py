@@ -8,13 +8,13 @@ from ..utils import rng
 
 
 def _nz(mask, size):
-    """nonzero with a host-known result size (no device->host round trip); DADET_NONZERO_STATIC=0 restores nonzero()"""
+    """nonzero with a host-known result size (no device->host round trip); `_STATIC = False` restores nonzero()"""
     if _STATIC:
         return torch.nonzero_static(mask, size=size)
     return torch.nonzero(mask)
 
 
-_STATIC = __import__("os").environ.get("DADET_NONZERO_STATIC", "1") == "1"
+_STATIC = True
 
 class BalancedPositiveNegativeSampler(object):
     def __init__(self, batch_size_per_image, positive_fraction):

@@ -19,7 +19,7 @@ from .fused import INS_DROPOUT_P, da_image_head, da_instance_head
 from .loss import TripletMargins, da_consist_loss, da_ins_loss, image_domain_labels
 
 
-_EARLY_DA = __import__("os").environ.get("DADET_EARLY_DA", "1") == "1"   # A/B switch of early_image_level
+_EARLY_DA = True   # A/B switch of early_image_level
 
 
 class DAImgHead(nn.Module):
@@ -79,7 +79,7 @@ class DAInsHead(nn.Module):
         return linear(x, self.fc3_da.weight, self.fc3_da.bias)
 
 
-_FUSED_INS = __import__("os").environ.get("DADET_FUSED_INS_HEAD", "1") == "1"   # 0: one DAInsHead.forward per pass + ATen losses
+_FUSED_INS = True   # 0: one DAInsHead.forward per pass + ATen losses
 _GRL_CACHE = {}
 
 

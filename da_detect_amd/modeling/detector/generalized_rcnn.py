@@ -19,7 +19,7 @@ from ..roi_heads.roi_heads import build_roi_heads
 from ..rpn.rpn import build_rpn
 
 
-_DA_AFTER_RPN = os.environ.get("DADET_DA_AFTER_RPN", "1") == "1"
+_DA_AFTER_RPN = True
 
 
 class GeneralizedRCNN(nn.Module):

@@ -90,7 +90,7 @@ class Pooler(nn.Module):
                 and self.output_size[0] == self.output_size[1]):
             conf = (out_size, tuple(p.spatial_scale for p in self.poolers), self.poolers[0].sampling_ratio)
             # (the mapper's result is a float tensor, as the reference's: int64 minus the Python float k_min)
-            return _PyramidROIAlign.apply(rois, levels.to(torch.int64).contiguous(), conf, *x)
+            return _PyramidROIAlign.apply(rois, levels.to(torch.int64).contiguous(), conf, *x[:len(self.poolers)])
         result = torch.zeros((len(rois), x[0].shape[1], out_size, out_size), dtype=x[0].dtype,
                              device=x[0].device).contiguous(memory_format=torch.channels_last)
         for level, (feat, pooler) in enumerate(zip(x, self.poolers)):

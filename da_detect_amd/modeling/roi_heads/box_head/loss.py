@@ -19,17 +19,17 @@ from ....utils import rng
 
 
 def _nz(mask, size):
-    """nonzero with a host-known result size (no device->host round trip); DADET_NONZERO_STATIC=0 restores nonzero()"""
+    """nonzero with a host-known result size (no device->host round trip)"""
     if _STATIC:
         return torch.nonzero_static(mask, size=size)
     return torch.nonzero(mask)
 
 
-_STATIC = __import__("os").environ.get("DADET_NONZERO_STATIC", "1") == "1"
-# one-launch-per-image sampling (dadet_sample_rois); DADET_FUSED_SAMPLER=0 keeps the ATen chain
-_FUSED = __import__("os").environ.get("DADET_FUSED_SAMPLER", "1") == "1"
-# NMS -> sampler hand-over on the device (dadet_proposals_sample); DADET_PENDING_PROPOSALS=0: the kept count goes through the host
-_PENDING = __import__("os").environ.get("DADET_PENDING_PROPOSALS", "1") == "1"
+_STATIC = True
+# one-launch-per-image sampling (dadet_sample_rois); False keeps the ATen chain (the path of the reference's random stream, utils.rng)
+_FUSED = True
+# NMS -> sampler hand-over on the device (dadet_proposals_sample); False: the kept count goes through the host
+_PENDING = True
 
 
 def _is_pending(p):

@@ -30,8 +30,11 @@ from .utils import permute_and_flatten
 _TOPK_KERNEL = False
 
 
-# DADET_FPN_DEVICE_SELECT=0: multi-level training selection with the reference's host round trips
-_DEVICE_SELECT = __import__("os").environ.get("DADET_FPN_DEVICE_SELECT", "1") == "1"
+# one batched ranking call for all pyramid levels (dadet_topk_sorted_rows); False: one library sort per level
+_ROWS_TOPK = True
+# False: multi-level training selection with the reference's host round trips (the path taken on CPU tensors and in eval
+# mode; tests/test_model_gpu.py compares the two)
+_DEVICE_SELECT = True
 # (measured in round 3 and removed: the device-side selection as one captured HIP graph — 64.5 - 65.5 ms per step against
 # 59.4 - 60.8 launch by launch; replaying the ~250-node graph cost more than issuing its launches from Python)
 
@@ -70,22 +73,32 @@ class RPNPostProcessor(torch.nn.Module):
                 out.append(proposal)
         return out
 
-    def forward_for_single_feature_map(self, anchors, objectness, box_regression, raw=False):
-        """anchors: list[BoxList] (one per image); objectness [N,A,H,W]; box_regression [N,4A,H,W].
-        raw: return the per-image (score-ordered boxes, scores, NMS keep buffer, kept count on the device, size) tuples
-        without reading the counts back (the multi-level device-side selection, _select_over_all_levels_device)"""
+    def _level_inputs(self, objectness, box_regression):
+        """sigmoid scores [N, HWA], deltas [N, HWA, 4] (both in anchor order) and this level's pre-NMS count"""
         N, A, H, W = objectness.shape
         scores_all = permute_and_flatten(objectness, N, A, 1, H, W).reshape(N, -1).sigmoid()
         deltas_all = permute_and_flatten(box_regression, N, A, 4, H, W).contiguous()  # [N, HWA, 4]
-        num_anchors = A * H * W
-        pre_nms_top_n = min(self.pre_nms_top_n, num_anchors)
-        if scores_all.is_cuda and pre_nms_top_n <= _C.TOPK_SORTED_MAX and _TOPK_KERNEL:
-            # radix select + in-LDS sort of the selected scores, one launch for the batch (csrc/topk.hip)
-            sorted_scores, topk_idx = _C.topk_sorted(scores_all, pre_nms_top_n)
+        return scores_all, deltas_all, min(self.pre_nms_top_n, A * H * W)
+
+    def forward_for_single_feature_map(self, anchors, objectness, box_regression, raw=False, prepared=None):
+        """anchors: list[BoxList] (one per image); objectness [N,A,H,W]; box_regression [N,4A,H,W].
+        raw: return the per-image (score-ordered boxes, scores, NMS keep buffer, kept count on the device, size) tuples
+        without reading the counts back (the multi-level device-side selection, _select_over_all_levels_device).
+        prepared: (deltas [N,HWA,4], [(sorted scores, indices) per image]) when the ranking was done for all levels at once
+        (_device_selection)"""
+        N = objectness.shape[0]
+        if prepared is not None:
+            deltas_all, ranked = prepared
+            sorted_scores, topk_idx = [r[0] for r in ranked], [r[1] for r in ranked]
         else:
-            sorted_scores, order = torch.sort(scores_all, dim=1, descending=True, stable=True)
-            sorted_scores = sorted_scores[:, :pre_nms_top_n].contiguous()
-            topk_idx = order[:, :pre_nms_top_n].contiguous()
+            scores_all, deltas_all, pre_nms_top_n = self._level_inputs(objectness, box_regression)
+            if scores_all.is_cuda and pre_nms_top_n <= _C.TOPK_SORTED_MAX and _TOPK_KERNEL:
+                # radix select + in-LDS sort of the selected scores, one launch for the batch (csrc/topk.hip)
+                sorted_scores, topk_idx = _C.topk_sorted(scores_all, pre_nms_top_n)
+            else:
+                sorted_scores, order = torch.sort(scores_all, dim=1, descending=True, stable=True)
+                sorted_scores = sorted_scores[:, :pre_nms_top_n].contiguous()
+                topk_idx = order[:, :pre_nms_top_n].contiguous()
 
         # The greedy sweep of one image is a single workgroup: images are independent, so every second image runs
         # on the side stream and the sweeps overlap; the kept counts come back in ONE host round trip.
@@ -162,8 +175,19 @@ class RPNPostProcessor(torch.nn.Module):
     def _device_selection(self, anchors, objectness, box_regression):
         """the whole multi-level selection as a function of tensors at fixed shapes with no host round trip: -> per image
         (boxes, scores, keep, count, upper bound)."""
-        per_level = [self.forward_for_single_feature_map(a, o, b, raw=True)
-                     for a, o, b in zip(list(zip(*anchors)), objectness, box_regression)]
+        levels = list(zip(list(zip(*anchors)), objectness, box_regression))
+        n_img = objectness[0].shape[0]
+        prepared = [None] * len(levels)
+        if _ROWS_TOPK and len(levels) * n_img <= _C.TOPK_ROWS_MAX and self.pre_nms_top_n <= _C.TOPK_SORTED_MAX:
+            # the ranking of every (level, image) row in ONE call (five launches, csrc/topk.hip `dadet_topk_sorted_rows`)
+            # instead of one segmented library sort per level (17 launches each + slicing): same indices
+            inputs = [self._level_inputs(o, b) for _, o, b in levels]
+            rows = [sc[i] for sc, _, _ in inputs for i in range(n_img)]
+            ks = [k for _, _, k in inputs for _ in range(n_img)]
+            ranked = _C.topk_sorted_rows(rows, ks)
+            prepared = [(inputs[l][1], ranked[l * n_img:(l + 1) * n_img]) for l in range(len(levels))]
+        per_level = [self.forward_for_single_feature_map(a, o, b, raw=True, prepared=p)
+                     for (a, o, b), p in zip(levels, prepared)]
         return self._select_over_all_levels_device(per_level)
 
     def _select_over_all_levels_device(self, per_level):

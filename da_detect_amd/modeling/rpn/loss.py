@@ -19,15 +19,15 @@ from .utils import concat_box_prediction_layers
 
 
 def _nz(mask, size):
-    """nonzero with a host-known result size (no device->host round trip); DADET_NONZERO_STATIC=0 restores nonzero()"""
+    """nonzero with a host-known result size (no device->host round trip)"""
     if _STATIC:
         return torch.nonzero_static(mask, size=size)
     return torch.nonzero(mask)
 
 
-_STATIC = __import__("os").environ.get("DADET_NONZERO_STATIC", "1") == "1"
-# one-launch-per-image anchor sampling (dadet_sample_anchors); DADET_FUSED_SAMPLER=0 keeps the ATen chain
-_FUSED = __import__("os").environ.get("DADET_FUSED_SAMPLER", "1") == "1"
+_STATIC = True
+# one-launch-per-image anchor sampling (dadet_sample_anchors); False keeps the ATen chain (the path of the reference's random stream, utils.rng)
+_FUSED = True
 
 class RPNLossComputation(object):
     def __init__(self, proposal_matcher, fg_bg_sampler, box_coder, generate_labels_func):

@@ -14,7 +14,7 @@ import torch
 import os
 
 _SIDE = {}
-_HIGH_PRIORITY = os.environ.get("DADET_SIDE_PRIORITY", "1") == "1"
+_HIGH_PRIORITY = True
 
 
 def side_stream(device, which=0):
@@ -198,7 +198,7 @@ def direct_grad_target(param):
 
 # reduction passes of split weight gradients whose results nobody has asked for yet (WgradLane.reduce_batch)
 _PENDING_REDUCES = []
-DEFER_WGRAD_REDUCE = os.environ.get("DADET_DEFER_WGRAD_REDUCE", "1") == "1"
+DEFER_WGRAD_REDUCE = True
 _PENDING_DW = set()          # dw pointers of the queued items (see WgradLane.reduce_batch)
 # (measured in round 3 and removed: the same passes on a stream of their own beside the backward GEMMs — 19.29 / 19.53 ms
 # per step against 19.22 / 19.23: the HBM traffic slows the power-limited GEMMs by what it saves at the end)

@@ -408,6 +408,20 @@ int dadet_sample_anchors(const float* labels, const float* regression_targets, i
 int dadet_topk_sorted(const float* scores, int rows, int n, int64_t row_stride, int k, float* out_scores,
                       int64_t* out_idx, void* stream);
 
+/* The same ranking for up to 16 rows of DIFFERENT lengths in one call — the per-level `objectness.topk(pre_nms_top_n)` of
+ * the multi-level proposal selection (modeling/rpn/inference.py:124-152: one row per (pyramid level, image)).  Five
+ * launches for all rows together, every radix pass spread over the chip (one workgroup per 8192 scores).  Row i: the
+ * k_i <= min(n_i, 16384) largest of scores_i[0 .. n_i) in descending order, equal scores by ascending index, into
+ * out_scores_i / out_idx_i [k_i].  workspace: dadet_topk_sorted_rows_workspace_bytes(rows, max k), 8-byte aligned. */
+typedef struct dadet_topk_row {
+  const float* scores;
+  float* out_scores;
+  int64_t* out_idx;
+  int n, k;
+} dadet_topk_row;
+int dadet_topk_sorted_rows_workspace_bytes(int rows, int k_max, size_t* bytes_out);
+int dadet_topk_sorted_rows(const dadet_topk_row* rows_in, int rows, void* workspace, size_t workspace_bytes, void* stream);
+
 /* RPN anchor labelling in two launches: replaces boxlist_iou + Matcher(high, low, allow_low_quality_matches=True) +
  * the label rules of RPNLossComputation.prepare_targets (modeling/rpn/loss.py:57-98, modeling/matcher.py:42-112) +
  * BoxCoder((1,1,1,1)).encode.  visible[a] != 0: anchor inside the image.  labels: 1 matched, 0 below the low threshold,
