@@ -248,7 +248,8 @@ def test_one_rank_over_rccl_at_production_geometry_with_the_lane(device):
     assert p.exitcode == 0
     for lane_rows, (comm, params, bucket_bytes) in res.items():
         assert comm["backend"] == "nccl" and comm["world"] == 1 and comm["steps"] == 3
-        assert comm["buckets"] == len(bucket_bytes) >= 5 and 20.0 <= comm["bucket_mb"] <= 26.0, comm
+        # 25 MB buckets; a tensor larger than that (the RPN's 3x3 conv: 36 MB) is a bucket of its own
+        assert comm["buckets"] == len(bucket_bytes) >= 5 and 20.0 <= comm["bucket_mb"] <= 40.0, comm
         assert comm["buckets_issued_during_backward"] == comm["buckets"] and comm["buckets_issued_in_finalize"] == 0, comm
         assert comm["allreduce_ms"] is not None and comm["allreduce_ms"] > 0.0, comm
         assert comm["exposed_ms"] >= 0.0 and comm["overlap_frac"] is not None, comm
