@@ -121,13 +121,13 @@ def cpu_baseline(cfg_path, seed, budget_s=90.0):
 
 
 def pmc_traffic(kernel_name, gemm_mode):
-    """HBM bytes per launch of `kernel_name` from the committed PMC passes (profiles/r03_pmc_hbm_traffic.json, made by
+    """HBM bytes per launch of `kernel_name` from the committed PMC passes (profiles/r04_pmc_hbm_traffic.json, made by
     tools/profile_pmc.sh from this same bench command in mode 3; counters cannot be read from inside the process).
     The 128x128-tile family is launched in two forms with the same tile body — conv_fwd_split_kernel<2,2,3> and, where
     the tile grid leaves a partly empty last pass, conv_fwd_split_sk_kernel<3> (stream-K tail) — and the in-process
     timer brackets both under one name: the figure is the launch-weighted mean over both.  None when the summary does
     not cover the kernel / mode."""
-    path = os.path.join(ROOT, "profiles", "r03_pmc_hbm_traffic.json")
+    path = os.path.join(ROOT, "profiles", "r04_pmc_hbm_traffic.json")
     if gemm_mode != 3 or not os.path.exists(path):
         return None, None
     want = [kernel_name.replace(" ", "").rstrip(">")]      # "conv_fwd_split_kernel<2,2,3" also matches "...<2,2,3,0>"
@@ -485,7 +485,8 @@ def main():
 
     resolutions = {}
     default_run = args.workload == "img_only" and args.image_hw is None
-    res_hw = ("608x1216" if default_run else "none") if args.resolutions is None else args.resolutions
+    # (an explicit --others, e.g. the profiling scripts' `--others none`, also switches the default resolutions pass off)
+    res_hw = ("608x1216" if (default_run and args.others is None) else "none") if args.resolutions is None else args.resolutions
     if res_hw != "none" and world == 1 and isolate:
         # SURVEY.md 8(d) "report both": the shipped yaml resizes Cityscapes to 600 x 1200 (608 x 1216 after padding to /32)
         for name in ("img_only", "da"):

@@ -588,17 +588,24 @@ def relu_bn_backward(g, y=None, scale=None, want_unscaled=False):
     return g_out, g_scaled
 
 
-def colsum(g):
-    """sum over every axis but channels of a channels_last / [M,C] tensor -> [C]"""
+def colsum(g, out=None, accumulate=False, cols=None):
+    """sum over every axis but channels of a channels_last / [M,C] tensor -> [C].  cols: only the first `cols` channels
+    (rows stay C floats apart); out + accumulate: added into an existing [cols] buffer (a bias gradient's slot in the
+    flat gradient bucket)"""
     _dev(g, "g")
     g = _nhwc(g) if g.dim() == 4 else g.contiguous()
-    C = g.shape[1]
-    rows = g.numel() // C
-    out = torch.empty(C, dtype=torch.float32, device=g.device)
+    ld = g.shape[1]
+    C = ld if cols is None else int(cols)
+    rows = g.numel() // ld
+    if out is None:
+        out = torch.empty(C, dtype=torch.float32, device=g.device)
+        accumulate = False
+    assert out.numel() == C and out.is_contiguous() and out.dtype == torch.float32
     nbytes = ctypes.c_size_t(0)
     _lib.call("dadet_colsum_workspace_bytes", rows, C, ctypes.byref(nbytes))
     ws = _workspace(nbytes.value, g.device)
-    _lib.call("dadet_colsum", _p(g), _p(out), rows, C, _p(ws), ctypes.c_size_t(ws.numel()), _stream())
+    _lib.call("dadet_colsum_ld", _p(g), ld, _p(out), rows, C, 1 if accumulate else 0, _p(ws), ctypes.c_size_t(ws.numel()),
+              _stream())
     return out
 
 
@@ -829,8 +836,11 @@ def deform_sample_backward_om(x, om, gcols, kh, kw, stride, pad, dil, dg, modula
     N, C, H, W = x.shape
     ld, Ho, Wo = om.shape[1], om.shape[2], om.shape[3]
     T = kh * kw
-    gx = torch.empty_like(x).zero_()
-    gom = torch.empty_like(om).zero_()
+    # both gradients in ONE zero-filled allocation (one fill launch per deformable block instead of two; x.numel() is a
+    # multiple of 4 floats, so the second view stays 16-byte aligned)
+    flat = torch.zeros(x.numel() + om.numel(), dtype=torch.float32, device=x.device)
+    gx = flat[:x.numel()].view(N, H, W, C).permute(0, 3, 1, 2)
+    gom = flat[x.numel():].view(N, Ho, Wo, ld).permute(0, 3, 1, 2)
     nbytes = ctypes.c_size_t(0)
     _lib.call("dadet_deform_sample_backward_workspace_bytes", N, H, W, dg, ctypes.byref(nbytes))
     ws = _workspace(nbytes.value, x.device)

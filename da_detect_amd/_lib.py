@@ -129,6 +129,7 @@ _SIGNATURES = {
     "dadet_relu_bn_backward": [_P, _P, _P, _P, _P, c_int64, c_int, _P],
     "dadet_colsum_workspace_bytes": [c_int64, c_int, POINTER(c_size_t)],
     "dadet_colsum": [_P, _P, c_int64, c_int, _P, c_size_t, _P],
+    "dadet_colsum_ld": [_P, c_int, _P, c_int64, c_int, c_int, _P, c_size_t, _P],
     "dadet_channel_affine": [_P, _P, _P, _P, c_int64, c_int, c_int, _P],
     "dadet_maxpool3x3s2_forward": [_P, _P, c_int, c_int, c_int, c_int, c_int, c_int, _P],
     "dadet_avgpool_forward": [_P, _P, c_int, c_int, c_int, _P],

@@ -46,7 +46,7 @@ __global__ void relu_bn_backward_kernel(const float4* __restrict__ g, const floa
 // partial[s][c] = sum over the s-th row slab; deterministic two-pass.
 __global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __restrict__ g,
                                                              float* __restrict__ partial, int64_t rows,
-                                                             int C, int64_t rows_per_split, int cb) {
+                                                             int C, int64_t rows_per_split, int cb, int ld) {
   // block: cb columns x (256 / cb) row lanes, cb = 64, 32 or 16 — narrow matrices (the 20 / 28 offset channels of a
   // deformable conv, 8 .. 64 k rows) keep all 256 lanes busy instead of 20 of every 64
   __shared__ float red[256];
@@ -58,7 +58,7 @@ __global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __rest
   if (r1 > rows) r1 = rows;
   float acc = 0.f;
   if (col < C)
-    for (int64_t r = r0 + rl; r < r1; r += lanes) acc += g[r * C + col];
+    for (int64_t r = r0 + rl; r < r1; r += lanes) acc += g[r * ld + col];
   red[threadIdx.x] = acc;
   __syncthreads();
   for (int half = lanes / 2; half > 0; half >>= 1) {      // fixed-order tree over the row lanes
@@ -70,13 +70,13 @@ __global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __rest
 // one workgroup per column: the `splits` partial sums in a fixed-order tree (was: one thread per column walking up to 1024
 // partials — 49 us for the 20-column case)
 __global__ __launch_bounds__(64) void colsum_final_kernel(const float* __restrict__ partial, float* __restrict__ out, int C,
-                                                          int splits) {
+                                                          int splits, int accumulate) {
   const int c = blockIdx.x;
   float acc = 0.f;
   for (int s = threadIdx.x; s < splits; s += 64) acc += partial[(size_t)s * C + c];
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 64);
-  if (threadIdx.x == 0) out[c] = acc;
+  if (threadIdx.x == 0) out[c] = accumulate ? out[c] + acc : acc;
 }
 static int colsum_cb(int C) { return C > 32 ? 64 : (C > 16 ? 32 : 16); }
 static int colsum_splits(int64_t rows, int C) {
@@ -461,14 +461,18 @@ extern "C" int dadet_colsum_workspace_bytes(int64_t rows, int C, size_t* bytes_o
   return DADET_OK;
 }
 
-extern "C" int dadet_colsum(const float* g, float* out, int64_t rows, int C, void* workspace,
-                            size_t workspace_bytes, void* stream) {
-  DADET_REQUIRE(rows >= 0 && C > 0 && out, "colsum: bad args");
+// rows of g may be longer than C (`ld` floats apart: the padded 20 / 28-float rows of a deformable block's offset
+// gradient, of which the parameter owns 18 / 27); accumulate: out[c] += (the bias gradient lands in the parameter's slot
+// of the flat gradient bucket, utils.streams.direct_bias_target — no autograd accumulation launch behind it)
+extern "C" int dadet_colsum_ld(const float* g, int ld, float* out, int64_t rows, int C, int accumulate, void* workspace,
+                               size_t workspace_bytes, void* stream) {
+  DADET_REQUIRE(rows >= 0 && C > 0 && ld >= C && out, "colsum: bad args (rows=%lld C=%d ld=%d)", (long long)rows, C, ld);
   hipStream_t st = as_stream(stream);
   if (rows == 0) {
-    (void)hipMemsetAsync(out, 0, sizeof(float) * C, st);
+    if (!accumulate) (void)hipMemsetAsync(out, 0, sizeof(float) * C, st);
     return check_launch("colsum(empty)");
   }
+  DADET_REQUIRE(g, "colsum: null input");
   const int splits = colsum_splits(rows, C);
   if (workspace_bytes < sizeof(float) * (size_t)splits * C || !workspace) {
     set_error("colsum: workspace too small");
@@ -477,10 +481,15 @@ extern "C" int dadet_colsum(const float* g, float* out, int64_t rows, int C, voi
   const int64_t rps = ceil_div64(rows, splits);
   const int cb = colsum_cb(C);
   hipLaunchKernelGGL(colsum_partial_kernel, dim3(ceil_div(C, cb), splits), dim3(256), 0, st, g,
-                     static_cast<float*>(workspace), rows, C, rps, cb);
+                     static_cast<float*>(workspace), rows, C, rps, cb, ld);
   hipLaunchKernelGGL(colsum_final_kernel, dim3(C), dim3(64), 0, st, static_cast<const float*>(workspace), out, C,
-                     splits);
+                     splits, accumulate);
   return check_launch("colsum");
+}
+
+extern "C" int dadet_colsum(const float* g, float* out, int64_t rows, int C, void* workspace,
+                            size_t workspace_bytes, void* stream) {
+  return dadet_colsum_ld(g, C, out, rows, C, 0, workspace, workspace_bytes, stream);
 }
 
 extern "C" int dadet_channel_affine(const float* x, const float* scale, const float* bias, float* y,

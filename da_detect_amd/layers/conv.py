@@ -12,7 +12,7 @@ from torch.autograd import Function
 from torch.autograd.function import once_differentiable
 
 from .. import _C
-from ..utils.streams import WgradLane
+from ..utils.streams import WgradLane, bias_grad
 
 CL = torch.channels_last
 
@@ -26,6 +26,7 @@ class _ConvAffineAct(Function):
         ctx.has_res = residual is not None
         ctx.x_shape = tuple(x.shape)
         ctx.save_for_backward(x, weight, scale, y if relu else None)
+        ctx.bias = bias          # (not saved for its values: backward only asks whether it has a direct gradient slot)
         return y
 
     @staticmethod
@@ -61,7 +62,7 @@ class _ConvAffineAct(Function):
                 raise NotImplementedError("data gradient of a strided %dx%d convolution (the reference's "
                                           "configs keep the stride in the 1x1, STRIDE_IN_1X1=True)" % (k, k))
         if need_b:
-            gb = _C.colsum(S)
+            gb = bias_grad(ctx.bias, S)
         lane.join()
         return gx, gw, None, gb, (S if need_res else None), None, None, None, None
 

@@ -139,6 +139,7 @@ class _DCNBottleneckFn(torch.autograd.Function):
         idn = x if wd is None else _C.conv_forward(x, wd, sd, bd, stride=stride)
         out = _C.conv_forward(y2, w3, s3, b3, addend=idn, relu_mode=1)
         ctx.conf = (stride, in_relu, out_private, modulated, dg, kh, kw, w_off.shape[0], wo4.shape[0])
+        ctx.b_off = b_off
         ctx.save_for_backward(x, y1, om, cols, y2, out, w1, w2, w3, wd, w_off, s1, s2, s3, sd)
         return out
 
@@ -176,7 +177,7 @@ class _DCNBottleneckFn(torch.autograd.Function):
             # other weight of the block
             dwo = wgrad(w_off, y1, gom, 1, kh // 2, None)
         if n_boff:
-            dbo = _C.colsum(gom)[:n_offch]
+            dbo = streams.bias_grad(ctx.b_off, gom, cols=n_offch)
         # d y1 = [y1 > 0] * (sampled path + offset-conv path); the transposed weights carry zero columns for the padding
         S1 = _C.conv_forward(gom, _C.conv_weight_transpose(w_off, cout_pad=n_offpad), pad=kh // 2, addend=gy1, out=gy1,
                              relu_mode=2, mask_ref=y1)

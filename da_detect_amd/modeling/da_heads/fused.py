@@ -14,6 +14,7 @@ from torch.autograd import Function
 from torch.autograd.function import once_differentiable
 
 from ... import _C
+from ...utils.streams import bias_grad
 
 CL = torch.channels_last
 
@@ -26,6 +27,7 @@ class _DAImageHead(Function):
         w2v = w2.reshape(-1).contiguous()
         logits, sums = _C.da_img_head_loss_forward(t, w2v, b2, labels, N, H * W)
         ctx.save_for_backward(x, w1, t, w2v, logits, labels)
+        ctx.b1 = b1
         ctx.dims = (N, H, W)
         ctx.w2_shape = tuple(w2.shape)
         bce = sums[:, 0].sum() / float(N * H * W)
@@ -50,7 +52,7 @@ class _DAImageHead(Function):
             t, w2v, logits, labels, g_bce.reshape(1), g_mean_sig if ctx.sig_used else None, ctx.w_adv, ctx.w_cst, N,
             H * W, need_x=need_x)
         g_w1 = _C.conv_wgrad(x, g_t_w, tuple(w1.shape), 1, 0)
-        g_b1 = _C.colsum(g_t_w)
+        g_b1 = bias_grad(ctx.b1, g_t_w)
         g_x = _C.conv_forward(g_t_x, _C.conv_weight_transpose(w1)) if need_x else None
         return g_x, g_w1, g_b1, g_w2.view(ctx.w2_shape), g_b2, None, None, None
 
@@ -94,6 +96,7 @@ class _DAInsHead(Function):
         logits, sums = _C.da_ins_tail_forward(h2, w3v, b3, labels_f, means if r_cst else None, r_bce, r_cst, n_src)
         ctx.save_for_backward(x, w1, w2, w3v, h1, h1s, masks1, h2, logits, labels_f, means if r_cst else None, grl)
         ctx.conf = (R, P, r_bce, r_cst, n_src, tuple(w3.shape))
+        ctx.biases = (b1, b2)
         levels = int(means.shape[0]) if r_cst else 1
         bce = sums[0] / float(max(r_bce, 1))
         cst = sums[1] / float(max(r_cst, 1) * levels)
@@ -116,12 +119,12 @@ class _DAInsHead(Function):
                                                             r_bce, r_cst, n_src)
         g_z2 = g_z2.view(P * R, C2, 1, 1)
         g_w2 = _C.conv_wgrad(h1s.view(P * R, C1, 1, 1), g_z2, (C2, C1, 1, 1), 1, 0).view(C2, C1)
-        g_b2 = _C.colsum(g_z2)
+        g_b2 = bias_grad(ctx.biases[1], g_z2)
         g_h1s = _C.conv_forward(g_z2, _C.conv_weight_transpose(w2.view(C2, C1, 1, 1)))
         g1_w, g1_x = _C.da_ins_merge(g_h1s.view(P * R, C1), masks1, h1, grl, need_x=need_x)
         g1_w4 = g1_w.view(R, C1, 1, 1)
         g_w1 = _C.conv_wgrad(x.reshape(R, C0, 1, 1), g1_w4, (C1, C0, 1, 1), 1, 0).view(C1, C0)
-        g_b1 = _C.colsum(g1_w4)
+        g_b1 = bias_grad(ctx.biases[0], g1_w4)
         g_x = None
         if need_x:
             g_x = _C.conv_forward(g1_x.view(R, C1, 1, 1), _C.conv_weight_transpose(w1.view(C1, C0, 1, 1))).view(R, C0)

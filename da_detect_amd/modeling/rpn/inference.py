@@ -32,6 +32,9 @@ _TOPK_KERNEL = False
 
 # one batched ranking call for all pyramid levels (dadet_topk_sorted_rows); False: one library sort per level
 _ROWS_TOPK = True
+# (the same kernels for the single-level C4 ranking, k = 12 000 of 122 880, measured and removed: img_only 18.57 / 18.62 ->
+# 19.01 / 18.97 ms per step, da unchanged — the finishing workgroup's 16 384-pair LDS sort costs more than the library's
+# segmented sort; tools/probes/variant_ab.py)
 # False: multi-level training selection with the reference's host round trips (the path taken on CPU tensors and in eval
 # mode; tests/test_model_gpu.py compares the two)
 _DEVICE_SELECT = True

@@ -196,6 +196,29 @@ def direct_grad_target(param):
     return g
 
 
+def direct_bias_target(param):
+    """the persistent gradient slot of a bias (1-D leaf) when direct accumulation is on — `_C.colsum(..., out=slot,
+    accumulate=True)` then leaves nothing for autograd to add (its post-accumulate hooks still fire)"""
+    if not DIRECT_WGRAD or param is None or not param.requires_grad or not param.is_leaf:
+        return None
+    g = param.grad
+    if g is None or not g.is_cuda or g.dtype != torch.float32 or g.dim() != 1 or not g.is_contiguous():
+        return None
+    return g
+
+
+def bias_grad(param, g2d, cols=None):
+    """bias gradient = column sums of g2d: straight into the bias's gradient slot when there is one (returns None for
+    autograd), else a fresh tensor"""
+    from .. import _C
+
+    tgt = direct_bias_target(param)
+    if tgt is not None and tgt.numel() == (g2d.shape[1] if cols is None else cols):
+        _C.colsum(g2d, out=tgt, accumulate=True, cols=cols)
+        return None
+    return _C.colsum(g2d, cols=cols)
+
+
 # reduction passes of split weight gradients whose results nobody has asked for yet (WgradLane.reduce_batch)
 _PENDING_REDUCES = []
 DEFER_WGRAD_REDUCE = True

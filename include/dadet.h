@@ -466,6 +466,8 @@ int dadet_relu_bn_backward(const float* g, const float* y, const float* scale, f
                            float* g_scaled, int64_t rows, int C, void* stream);
 /* out[c] = sum_m g[m][c]  (bias gradient); workspace >= dadet_colsum_workspace_bytes */
 int dadet_colsum_workspace_bytes(int64_t rows, int C, size_t* bytes_out);
+int dadet_colsum_ld(const float* g, int ld, float* out, int64_t rows, int C, int accumulate, void* workspace,
+                    size_t workspace_bytes, void* stream);   /* rows `ld` >= C floats apart; accumulate: out[c] += */
 int dadet_colsum(const float* g, float* out, int64_t rows, int C, void* workspace, size_t workspace_bytes,
                  void* stream);
 /* y = x * scale[c] + bias[c]  (standalone FrozenBatchNorm2d, layers/batch_norm.py:19-24) */

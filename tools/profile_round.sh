@@ -51,5 +51,7 @@ python tools/gemm_table.py --workload img_only --steps 3 --top 60 --holes > gpur
 python tools/gemm_table.py --workload img_only --steps 3 --top 60 > gpurun_out/${TAG}_gemm_table_per_shape.txt 2>&1
 echo "=== R-101-FPN-DCN bench line"
 python bench.py --workload fpn_dcn_da --others none --no-cpu-baseline > gpurun_out/${TAG}_bench_fpn_dcn_da.json 2>/dev/null; tail -1 gpurun_out/${TAG}_bench_fpn_dcn_da.json | cut -c1-200
+echo "=== two ranks on one GPU over gloo (functional rig: the N > 1 line with its comm block)"
+DADET_BENCH_SHARE_GPU=1 python bench.py --gpus 2 --steps 6 --warmup 4 > gpurun_out/${TAG}_bench_2ranks_one_gpu_gloo.json 2> gpurun_out/${TAG}_bench_2ranks.err; tail -1 gpurun_out/${TAG}_bench_2ranks_one_gpu_gloo.json | cut -c1-200
 echo "=== default bench"
 python bench.py > gpurun_out/${TAG}_bench_default.json 2> gpurun_out/${TAG}_bench_default.err; tail -1 gpurun_out/${TAG}_bench_default.json | cut -c1-300
