@@ -18,6 +18,7 @@ import time
 import torch
 
 from . import _lib
+from . import amax as _amax
 from ._lib import ConvDesc
 
 CL = torch.channels_last
@@ -133,6 +134,26 @@ def _dev(t, name):
 def _nhwc(t):
     """physical NHWC view of a logical NCHW tensor (copies only when the layout differs)"""
     return t.contiguous(memory_format=CL)
+
+
+_MODE = None   # cached contraction mode (set_gemm_mode keeps it current)
+
+
+def _mode4():
+    """True when the GEMMs run the two-term fp16 split, whose kernels want the operands' largest magnitudes (amax.py)"""
+    global _MODE
+    if _MODE is None:
+        _MODE = _lib.load().dadet_get_gemm_mode()
+    return _MODE == 4
+
+
+def _weight_amax(w):
+    """slot of the B operand of a GEMM: parameters (and views of them) and the cached transposed weights live in the
+    persistent per-epoch table, anything else is treated like an activation"""
+    base = w._base if w._base is not None else w
+    if isinstance(base, torch.nn.Parameter) or w.__dict__.get("_dadet_persistent"):
+        return _amax.WEIGHTS.ptr(w, _TRANSPOSES.epoch)
+    return _amax.ptr(w)
 
 
 def _workspace(nbytes, device):
@@ -332,6 +353,10 @@ def conv_forward(x, w, scale=None, bias=None, addend=None, mask_ref=None, stride
     if mask_ref is not None:
         mask_ref = _nhwc(mask_ref)
     d = _desc(N, H, W, Cin, Cout, KH, KW, stride, pad, Ho, Wo, OutH, OutW, out_spatial_stride, relu_mode)
+    ax = aw = None
+    if _mode4():
+        # measured here (outside a profiler span) when the producer left none
+        ax, aw = _amax.ptr(x), _weight_amax(w)
     if PROFILER is not None:
         key = (N * Ho * Wo, Cout, Cin * KH * KW, KH, pad, out_spatial_stride)
         kname = _KNAME_CACHE.get(key)
@@ -351,12 +376,22 @@ def conv_forward(x, w, scale=None, bias=None, addend=None, mask_ref=None, stride
                            2.0 * N * Ho * Wo * Cout * Cin * KH * KW,
                            4.0 * (x.numel() + w.numel() + out.numel() + (addend.numel() if addend is not None else 0)
                                   + (mask_ref.numel() if mask_ref is not None else 0))):
-            _lib.call("dadet_conv_forward", ctypes.byref(d), _p(x), _p(w), _p(scale), _p(bias), _p(addend),
-                      _p(mask_ref), _p(out), _stream())
+            _conv_forward_call(d, x, w, scale, bias, addend, mask_ref, out, ax, aw)
         return out
-    _lib.call("dadet_conv_forward", ctypes.byref(d), _p(x), _p(w), _p(scale), _p(bias), _p(addend),
-              _p(mask_ref), _p(out), _stream())
+    _conv_forward_call(d, x, w, scale, bias, addend, mask_ref, out, ax, aw)
     return out
+
+
+def _conv_forward_call(d, x, w, scale, bias, addend, mask_ref, out, ax, aw):
+    if ax is None:
+        _lib.call("dadet_conv_forward", ctypes.byref(d), _p(x), _p(w), _p(scale), _p(bias), _p(addend),
+                  _p(mask_ref), _p(out), _stream())
+        return
+    # mode 4: the operands' maxima go in, the epilogue leaves max|out| in a fresh slot that travels with `out`
+    slot = _amax.new_slot(out.device)
+    _lib.call("dadet_conv_forward_scaled", ctypes.byref(d), _p(x), _p(w), _p(scale), _p(bias), _p(addend),
+              _p(mask_ref), _p(out), ax, aw, ctypes.c_void_p(slot[0]), _stream())
+    _amax.attach(out, slot)
 
 
 def _transpose_now(w, scale, wt):
@@ -383,17 +418,23 @@ class _TransposeCache(object):
         self.table = None          # (device tensor, n, total_blocks, keys)
         self.ready = None          # (stream, event) of the last batched refresh
         self.enabled = True
+        self._from_bump = False
 
     def bump(self, device=None):
         """new weight epoch; with a device: refresh every entry at once, on the caller's stream (the optimizer's, behind
         the update and behind everything that read the old buffers)"""
         self.epoch += 1
         if self.enabled and device is not None and self.entries:
-            self._refresh_all(device)
+            self._from_bump = True
+            try:
+                self._refresh_all(device)
+            finally:
+                self._from_bump = False
 
     def _single(self, e, w, scale):
         """one entry on the current stream, remembered with an event for readers on other streams"""
         _transpose_now(w, scale, e["wt"])
+        _amax.WEIGHTS.invalidate(e["wt"])
         e["epoch"] = self.epoch
         if w.is_cuda:
             st = torch.cuda.current_stream(w.device)
@@ -407,6 +448,7 @@ class _TransposeCache(object):
         if e is None:
             wt = torch.empty((Cin, max(Cout, cout_pad), KH, KW), dtype=torch.float32, device=w.device, memory_format=CL)
             # the entry keeps w / scale alive: their storage addresses are in the device table
+            wt._dadet_persistent = True    # its largest magnitude lives in amax.WEIGHTS (mode 4)
             e = self.entries[key] = dict(w=w, scale=scale, wt=wt, version=w._version, epoch=self.epoch, used=self.epoch,
                                          ev=None)
             self.table = None
@@ -455,6 +497,10 @@ class _TransposeCache(object):
             e["epoch"] = self.epoch
             e["ev"] = None
         self.batched_epoch = self.epoch
+        if _mode4():
+            # parameters and the transposed copies just written: every persistent operand's maximum in one launch.  Behind
+            # the optimizer (bump with a device) no other stream reads the slots; from the middle of a step they may.
+            _amax.WEIGHTS.refresh(device, self.epoch, sync=not self._from_bump)
         if device.type == "cuda":
             st = torch.cuda.current_stream(device)
             self.ready = (st, st.record_event())
@@ -533,12 +579,20 @@ def conv_wgrad(x, gy, weight_shape, stride=1, pad=0, out_scale=None, dw=None, ac
     d = _desc(N, H, W, Cin, Cout, KH, KW, stride, pad, Ho, Wo)
     nbytes = ctypes.c_size_t(0)
     _lib.call("dadet_conv_wgrad_workspace_bytes", ctypes.byref(d), ctypes.byref(nbytes))
+    m4 = _mode4()
+    if m4:
+        ax, ag = _amax.ptr(x), _amax.ptr(gy)
     if pending is not None:
         # own workspace (the shared one is overwritten by the next weight gradient), alive until the batched pass
         ws = torch.empty(max(nbytes.value, 16), dtype=torch.uint8, device=x.device)
         item = _lib.WgradPending()
 
         def launch():
+            if m4:
+                _lib.call("dadet_conv_wgrad_scaled", ctypes.byref(d), _p(x), _p(gy), gy_ld, _p(out_scale), _p(dw),
+                          1 if accumulate else 0, _p(ws), ctypes.c_size_t(ws.numel()), ctypes.byref(item), ax, ag,
+                          _stream())
+                return
             _lib.call("dadet_conv_wgrad_partials_ld", ctypes.byref(d), _p(x), _p(gy), gy_ld, _p(out_scale), _p(dw),
                       1 if accumulate else 0, _p(ws), ctypes.c_size_t(ws.numel()), ctypes.byref(item), _stream())
 
@@ -564,12 +618,19 @@ def conv_wgrad(x, gy, weight_shape, stride=1, pad=0, out_scale=None, dw=None, ac
         with PROFILER.span(kname,
                            2.0 * N * Ho * Wo * Cout * Cin * KH * KW,
                            4.0 * (x.numel() + gy.numel() + dw.numel())):
-            _lib.call("dadet_conv_wgrad", ctypes.byref(d), _p(x), _p(gy), _p(out_scale), _p(dw),
-                      1 if accumulate else 0, _p(ws), ctypes.c_size_t(ws.numel()), _stream())
+            _wgrad_call(d, x, gy, gy_ld, out_scale, dw, accumulate, ws, ax if m4 else None, ag if m4 else None)
         return dw
+    _wgrad_call(d, x, gy, gy_ld, out_scale, dw, accumulate, ws, ax if m4 else None, ag if m4 else None)
+    return dw
+
+
+def _wgrad_call(d, x, gy, gy_ld, out_scale, dw, accumulate, ws, ax, ag):
+    if ax is not None:
+        _lib.call("dadet_conv_wgrad_scaled", ctypes.byref(d), _p(x), _p(gy), gy_ld, _p(out_scale), _p(dw),
+                  1 if accumulate else 0, _p(ws), ctypes.c_size_t(ws.numel()), None, ax, ag, _stream())
+        return
     _lib.call("dadet_conv_wgrad", ctypes.byref(d), _p(x), _p(gy), _p(out_scale), _p(dw),
               1 if accumulate else 0, _p(ws), ctypes.c_size_t(ws.numel()), _stream())
-    return dw
 
 
 def relu_bn_backward(g, y=None, scale=None, want_unscaled=False):
@@ -1228,7 +1289,9 @@ def deform_psroi_pooling_backward(grad_out, data, rois, offset, count, no_trans,
 
 def set_gemm_mode(mode):
     """0 exact fp32 MFMA | 3 three-term bf16 split (fp32-class accuracy) | 2 two-term split; see include/dadet.h"""
+    global _MODE
     _lib.call("dadet_set_gemm_mode", int(mode))
+    _MODE = int(mode)
     _KNAME_CACHE.clear()
 
 
@@ -1241,7 +1304,7 @@ def apply_env_gemm_mode():
     three-term split; 0 = exact fp32 MFMA)."""
     import os
 
-    set_gemm_mode(int(os.environ.get("DADET_GEMM_MODE", "3")))
+    set_gemm_mode(int(os.environ.get("DADET_GEMM_MODE", _lib.DEFAULT_GEMM_MODE)))
 
 
 def device_info():

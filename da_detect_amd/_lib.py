@@ -12,6 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # DADET_LIB: another build of the same library (A/B runs of build-time switches on one box)
 LIB_PATH = os.environ.get("DADET_LIB") or os.path.join(_HERE, "libdadet_hip.so")
 _lib = None
+DEFAULT_GEMM_MODE = "3"
 
 
 class ConvDesc(ctypes.Structure):
@@ -32,6 +33,12 @@ class WgradPending(ctypes.Structure):
 class TransposeItem(ctypes.Structure):
     _fields_ = [("w", c_void_p), ("scale", c_void_p), ("wt", c_void_p), ("Cout", c_int), ("KH", c_int), ("KW", c_int),
                 ("Cin", c_int), ("first_block", c_int), ("blocks_ci", c_int), ("blocks_co", c_int), ("cout_pad", c_int)]
+
+
+class AmaxItem(ctypes.Structure):
+    """mirror of dadet_amax_item (include/dadet.h)"""
+
+    _fields_ = [("x", c_void_p), ("slot", c_void_p), ("n", ctypes.c_longlong), ("first_block", c_int), ("blocks", c_int)]
 
 
 class MergeEntry(ctypes.Structure):
@@ -77,6 +84,11 @@ _SIGNATURES = {
     "dadet_sigmoid_focal_loss_forward": [_P, _P, _P, c_int, c_int, c_float, c_float, _P],
     "dadet_sigmoid_focal_loss_backward": [_P, _P, _P, _P, c_int, c_int, c_float, c_float, _P],
     "dadet_conv_forward": [POINTER(ConvDesc), _P, _P, _P, _P, _P, _P, _P, _P],
+    "dadet_conv_forward_scaled": [POINTER(ConvDesc), _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P],
+    "dadet_conv_wgrad_scaled": [POINTER(ConvDesc), _P, _P, c_int, _P, _P, c_int, _P, c_size_t, POINTER(WgradPending), _P, _P,
+                                _P],
+    "dadet_amax": [_P, ctypes.c_longlong, _P, _P],
+    "dadet_amax_batch": [_P, c_int, c_int, _P],
     "dadet_conv_forward_variant": [POINTER(ConvDesc)],
     "dadet_set_gemm_mode": [c_int],
     "dadet_get_gemm_mode": [],
@@ -179,11 +191,12 @@ def load():
     lib.dadet_last_error.argtypes = []
     lib.dadet_last_error.restype = c_char_p
     _lib = lib
-    # contraction mode of the GEMM kernels: DADET_GEMM_MODE = 3 (default: fp32-accurate 3-term bf16 split),
-    # 0 (exact fp32 MFMA) or 2 (2-term split, ~2^-16 products); see include/dadet.h
-    mode = int(os.environ.get("DADET_GEMM_MODE", "3"))
+    # contraction mode of the GEMM kernels: DADET_GEMM_MODE = 4 (default: fp32-class two-term fp16 split under per-tensor
+    # scales), 3 (fp32-class three-term bf16 split), 0 (exact fp32 MFMA) or 2 (two bf16 terms, ~2^-16 products); see
+    # include/dadet.h
+    mode = int(os.environ.get("DADET_GEMM_MODE", DEFAULT_GEMM_MODE))
     if lib.dadet_set_gemm_mode(mode) != 0:
-        raise DadetError("DADET_GEMM_MODE=%d is not a valid contraction mode (0, 2 or 3)" % mode)
+        raise DadetError("DADET_GEMM_MODE=%d is not a valid contraction mode (0, 2, 3 or 4)" % mode)
     return lib
 
 

@@ -67,6 +67,61 @@ __device__ inline void split4(const float4 v, uint2 (&out)[TERMS]) {
   }
 }
 
+// ---- fp16 two-term split (contraction mode 4, round 4) -----------------------------------------------------------
+// x * s = h + l + eps with h = f16(x * s), l = f16(x * s - h): 11 + 11 significand bits and the sign of l leave
+// |eps| <= 2^-23 |x s| — one bit short of fp32 — and the one dropped product l_a * l_b is below 2^-24 |a b|, so
+//   a * b ~= h_a h_b + h_a l_b + l_a h_b        3 MFMAs per K=16 (v_mfma_f32_32x32x16_f16), fp32 accumulation
+// has the accuracy class of the six-product bf16 split at HALF the matrix work and two operand planes instead of three.
+// What bf16 gave for free is range: fp16 spans 2^-24 .. 65504.  `s` is a power of two per TENSOR (exact to apply and to
+// undo) that brings the tensor's largest magnitude into [2^14, 2^15): nothing overflows, an element above 2^-16 of the
+// tensor's maximum keeps the full 2^-23 relative accuracy, and smaller ones (l falls into fp16's subnormals) an absolute
+// error below 2^-40 of the maximum.  The maximum comes from a device-side slot (fmt4_exp reads it with a scalar load):
+// every producer in this library that can feed a GEMM leaves max|y| there (fused epilogues, dadet_amax otherwise).
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+
+// exponent e of the power-of-two scale 2^e for a tensor whose largest magnitude is `amax` (>= 0; inf / nan / 0 -> e = 0)
+__device__ inline int fmt4_exp(const float amax) {
+  const int be = (int)((__builtin_bit_cast(unsigned, amax) >> 23) & 0xffu);
+  if (be == 0 || be == 255) return 0;
+  int e = 14 - (be - 127);
+  return e > 126 ? 126 : (e < -126 ? -126 : e);
+}
+__device__ inline float pow2f(const int e) { return __builtin_bit_cast(float, (unsigned)(e + 127) << 23); }
+
+// split four consecutive-k floats, scaled by s, into the two fp16 planes (8 bytes each)
+__device__ inline void split4h(const float4 v, const float s, uint2 (&out)[2]) {
+  const float a = v.x * s, b = v.y * s, c = v.z * s, d = v.w * s;
+  const f16x2 h0 = {(_Float16)a, (_Float16)b}, h1 = {(_Float16)c, (_Float16)d};
+  const float ra = a - (float)h0.x, rb = b - (float)h0.y, rc = c - (float)h1.x, rd = d - (float)h1.y;
+  const f16x2 l0 = {(_Float16)ra, (_Float16)rb}, l1 = {(_Float16)rc, (_Float16)rd};
+  out[0] = make_uint2(__builtin_bit_cast(unsigned, h0), __builtin_bit_cast(unsigned, h1));
+  out[1] = make_uint2(__builtin_bit_cast(unsigned, l0), __builtin_bit_cast(unsigned, l1));
+}
+
+// FMT (template parameter of the split kernels): 3 / 2 = three / two bf16 terms, 4 = two fp16 terms
+template <int FMT> struct Fmt { static constexpr int terms = FMT == 3 ? 3 : 2; static constexpr bool f16 = FMT == 4; };
+
+template <bool F16>
+__device__ __forceinline__ f32x16 mfma_32x32x16(const bf16x8 a, const bf16x8 b, const f32x16 c) {
+  if constexpr (F16)
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+  else
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
+
+// max|v| of a wavefront -> the tensor's slot (bits of a non-negative float order like unsigned integers).  Most waves
+// find the slot already at least as large and skip the atomic.
+__device__ inline void amax_publish(unsigned* slot, float m, const int lane) {
+#pragma unroll
+  for (int o = 32; o; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+  if (lane == 0) {
+    const unsigned b = __builtin_bit_cast(unsigned, m);
+    if (b > __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+      __hip_atomic_fetch_max(slot, b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
+
 constexpr int PLANE_STRIDE = 40;  // bf16 per staged row: 32 + 8 pad = 80 bytes
 constexpr int EPI_STRIDE = 40;    // floats per transposed row of the 16-byte epilogue
 
@@ -97,6 +152,11 @@ struct ConvArgs {
   int sk_dp_tiles, sk_tiles, sk_units, sk_iters, sk_max_parts;
   float* sk_ws;
   int* sk_counters;
+  // mode 4 (fp16 two-term split): max|x|, max|w| of the operands (device floats; null = scale 1) and the slot that
+  // receives max|y| of what this launch stores (null = not wanted; zero or an earlier launch's maximum before)
+  const float* amax_x;
+  const float* amax_w;
+  unsigned* amax_y;
 };
 
 struct WgradArgs {
@@ -111,6 +171,8 @@ struct WgradArgs {
   int direct;       // 1: write dw with scale / accumulate applied here
   int accumulate;
   unsigned x_bytes, gy_bytes;
+  const float* amax_x;   // mode 4: max|x|, max|gy| (device floats; null = scale 1)
+  const float* amax_gy;
 };
 
 // tile variant chosen for a forward / dgrad GEMM of M rows and Cout columns
@@ -129,11 +191,12 @@ inline int fwd_variant(int M, int Cout) {
   return 1;
 }
 
-// 3 (default) / 2 = products from a 3- / 2-term bf16 split of both operands; 0 = exact fp32 MFMA
+// 4 = products from a 2-term fp16 split of both operands under per-tensor power-of-two scales; 3 / 2 = from a
+// 3- / 2-term bf16 split; 0 = exact fp32 MFMA
 int gemm_mode();
-int launch_fwd_split(ConvArgs& a, int variant, int terms, hipStream_t st);
-int launch_fwd_split_sk(ConvArgs& a, int terms, hipStream_t st);
-int launch_wgrad_split(WgradArgs& a, int terms, hipStream_t st);
+int launch_fwd_split(ConvArgs& a, int variant, int fmt, hipStream_t st);
+int launch_fwd_split_sk(ConvArgs& a, int fmt, hipStream_t st);
+int launch_wgrad_split(WgradArgs& a, int fmt, hipStream_t st);
 // weight-stationary 1x1 kernel for K = 64 / 128 / 256 (conv_ws.hip)
 bool ws_eligible(const ConvArgs& a);
 int launch_fwd_ws(ConvArgs& a, hipStream_t st);

@@ -585,7 +585,9 @@ static int split_fwd_variant(int M, int Cout, int K) {
 __global__ void splitk_reduce_kernel(const float4* __restrict__ partial, int splits, size_t stride4,
                                      const float4* __restrict__ scale, const float4* __restrict__ bias,
                                      const float4* __restrict__ addend, const float4* __restrict__ mask,
-                                     float4* __restrict__ y, int64_t total4, int C4, int relu_mode) {
+                                     float4* __restrict__ y, int64_t total4, int C4, int relu_mode,
+                                     unsigned* __restrict__ amax_y) {
+  float mx = 0.f;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total4;
        i += (int64_t)gridDim.x * blockDim.x) {
     float4 v = partial[i];
@@ -605,7 +607,45 @@ __global__ void splitk_reduce_kernel(const float4* __restrict__ partial, int spl
       v.z = q.z > 0.f ? v.z : 0.f; v.w = q.w > 0.f ? v.w : 0.f;
     }
     y[i] = v;
+    mx = fmaxf(fmaxf(mx, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
   }
+  if (amax_y) amax_publish(amax_y, mx, threadIdx.x & 63);
+}
+
+// max|x| over a tensor, merged into *slot (mode 4: a GEMM operand whose producer left no maximum).  Bits of non-negative
+// floats order like unsigned integers; one atomic per wavefront that would raise the slot.
+__global__ __launch_bounds__(256) void amax_kernel(const float* __restrict__ x, int64_t n, unsigned* __restrict__ slot) {
+  float mx = 0.f;
+  const int64_t n4 = n / 4;
+  const float4* x4 = reinterpret_cast<const float4*>(x);
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+    const float4 v = x4[i];
+    mx = fmaxf(fmaxf(mx, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+  }
+  if (blockIdx.x == 0 && threadIdx.x < (unsigned)(n - n4 * 4)) mx = fmaxf(mx, fabsf(x[n4 * 4 + threadIdx.x]));
+  amax_publish(slot, mx, threadIdx.x & 63);
+}
+
+// the same for many tensors in one launch (the weights of a model once per optimizer step): item i owns the workgroups
+// [first_block, first_block + blocks)
+__global__ __launch_bounds__(256) void amax_batch_kernel(const dadet_amax_item* __restrict__ items, int n) {
+  int lo = 0, hi = n - 1;
+  while (lo < hi) {          // last item whose first_block <= blockIdx.x
+    const int mid = (lo + hi + 1) >> 1;
+    if (items[mid].first_block <= (int)blockIdx.x) lo = mid; else hi = mid - 1;
+  }
+  const dadet_amax_item it = items[lo];
+  const int b = (int)blockIdx.x - it.first_block;
+  const float* x = reinterpret_cast<const float*>(it.x);
+  const float4* x4 = reinterpret_cast<const float4*>(x);
+  const int64_t n4 = it.n / 4;
+  float mx = 0.f;
+  for (int64_t i = (int64_t)b * 256 + threadIdx.x; i < n4; i += (int64_t)it.blocks * 256) {
+    const float4 v = x4[i];
+    mx = fmaxf(fmaxf(mx, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+  }
+  if (b == 0 && threadIdx.x < (unsigned)(it.n - n4 * 4)) mx = fmaxf(mx, fabsf(x[n4 * 4 + threadIdx.x]));
+  amax_publish(reinterpret_cast<unsigned*>(it.slot), mx, threadIdx.x & 63);
 }
 
 namespace {
@@ -650,6 +690,23 @@ int* stream_counters(hipStream_t st) {
     if (hipMemset(p, 0, sizeof(int) * kSkCounters) != hipSuccess) return nullptr;
   }
   return p;
+}
+
+// mode 4 through the plain entry points (no maxima handed in): two slots per stream that the library fills itself
+unsigned* stream_amax_slots(hipStream_t st) {
+  static std::mutex m;
+  static std::unordered_map<hipStream_t, unsigned*> table;
+  std::lock_guard<std::mutex> lock(m);
+  unsigned*& p = table[st];
+  if (!p && hipMalloc(reinterpret_cast<void**>(&p), sizeof(unsigned) * 4) != hipSuccess) p = nullptr;
+  return p;
+}
+
+int launch_amax(const float* x, int64_t n, unsigned* slot, hipStream_t st) {
+  int64_t blocks = ceil_div64(n / 4 > 0 ? n / 4 : 1, 256 * 4);
+  if (blocks > kMaxStreamBlocks) blocks = kMaxStreamBlocks;
+  hipLaunchKernelGGL(amax_kernel, dim3((int)blocks), dim3(256), 0, st, x, n, slot);
+  return check_launch("amax");
 }
 
 // Stream-K tail plan for the 128x128 split kernel (conv_fwd_split_sk_kernel).  Returns false when the plain grid is at
@@ -707,9 +764,23 @@ int splitk_plan(const ConvArgs& a, int variant) {
 }
 }  // namespace
 
-extern "C" int dadet_conv_forward(const dadet_conv_desc* d, const float* x, const float* w,
-                                  const float* scale, const float* bias, const float* addend,
-                                  const float* mask_ref, float* y, void* stream) {
+extern "C" int dadet_amax(const float* x, long long n, float* slot, void* stream) {
+  DADET_REQUIRE(n >= 0 && slot && (n == 0 || (x && al16(x))), "amax: bad arguments");
+  if (n == 0) return DADET_OK;
+  return launch_amax(x, n, reinterpret_cast<unsigned*>(slot), as_stream(stream));
+}
+
+extern "C" int dadet_amax_batch(const dadet_amax_item* items_dev, int n, int total_blocks, void* stream) {
+  DADET_REQUIRE(n >= 0 && (n == 0 || (items_dev && total_blocks > 0)), "amax_batch: bad arguments");
+  if (n == 0) return DADET_OK;
+  hipLaunchKernelGGL(amax_batch_kernel, dim3(total_blocks), dim3(256), 0, as_stream(stream), items_dev, n);
+  return check_launch("amax_batch");
+}
+
+static int conv_forward_impl(const dadet_conv_desc* d, const float* x, const float* w,
+                             const float* scale, const float* bias, const float* addend,
+                             const float* mask_ref, float* y, const float* amax_x, const float* amax_w,
+                             float* amax_y, void* stream) {
   int rc = conv_desc_check(d, "conv_forward");
   if (rc) return rc;
   if (d->N == 0) return DADET_OK;
@@ -747,6 +818,28 @@ extern "C" int dadet_conv_forward(const dadet_conv_desc* d, const float* x, cons
   a.sk_dp_tiles = a.sk_tiles = a.sk_units = a.sk_iters = a.sk_max_parts = 0;
   a.sk_ws = nullptr;
   a.sk_counters = nullptr;
+  a.amax_x = a.amax_w = nullptr;
+  a.amax_y = nullptr;
+  if (gemm_mode() == 4) {
+    // operand maxima: the caller's slots, or (plain entry point) two per-stream slots filled here
+    if (!amax_x || !amax_w) {
+      unsigned* own = stream_amax_slots(st);
+      if (!own) { set_error("conv_forward: could not allocate the operand-maximum slots"); return DADET_ELAUNCH; }
+      if (hipMemsetAsync(own, 0, sizeof(unsigned) * 2, st) != hipSuccess) return check_launch("conv_forward(amax memset)");
+      if (!amax_x) {
+        rc = launch_amax(x, (int64_t)(xb / 4), own, st);
+        if (rc) return rc;
+        amax_x = reinterpret_cast<const float*>(own);
+      }
+      if (!amax_w) {
+        rc = launch_amax(w, (int64_t)(wb / 4), own + 1, st);
+        if (rc) return rc;
+        amax_w = reinterpret_cast<const float*>(own + 1);
+      }
+    }
+    a.amax_x = amax_x; a.amax_w = amax_w;
+    a.amax_y = reinterpret_cast<unsigned*>(amax_y);
+  }   // (the other modes neither read nor leave maxima)
   if (gemm_mode() == 3 && ws_eligible(a)) return launch_fwd_ws(a, st);     // weight-stationary 1x1, K <= 256 (conv_ws.hip)
   if (gemm_mode() != 0) {
     const int variant = split_fwd_variant(a.M, a.Cout, a.K);
@@ -776,6 +869,7 @@ extern "C" int dadet_conv_forward(const dadet_conv_desc* d, const float* x, cons
       }
       ConvArgs p = a;
       p.scale = p.bias = p.addend = p.mask_ref = nullptr;
+      p.amax_y = nullptr;          // the reduce pass sees the final values
       p.relu_mode = 0;
       p.y = ws;
       p.ksplit = ksplit;
@@ -789,7 +883,7 @@ extern "C" int dadet_conv_forward(const dadet_conv_desc* d, const float* x, cons
                          reinterpret_cast<const float4*>(ws), splits, per / 4,
                          reinterpret_cast<const float4*>(scale), reinterpret_cast<const float4*>(bias),
                          reinterpret_cast<const float4*>(addend), reinterpret_cast<const float4*>(mask_ref),
-                         reinterpret_cast<float4*>(y), total4, a.Cout / 4, a.relu_mode);
+                         reinterpret_cast<float4*>(y), total4, a.Cout / 4, a.relu_mode, a.amax_y);
       return check_launch("conv_forward(split-K reduce)");
     }
     return launch_fwd_split(a, variant, gemm_mode(), st);
@@ -799,6 +893,19 @@ extern "C" int dadet_conv_forward(const dadet_conv_desc* d, const float* x, cons
     case 1: return launch_fwd<2, 1>(a, st);
     default: return launch_fwd<1, 1>(a, st);
   }
+}
+
+extern "C" int dadet_conv_forward(const dadet_conv_desc* d, const float* x, const float* w,
+                                  const float* scale, const float* bias, const float* addend,
+                                  const float* mask_ref, float* y, void* stream) {
+  return conv_forward_impl(d, x, w, scale, bias, addend, mask_ref, y, nullptr, nullptr, nullptr, stream);
+}
+
+extern "C" int dadet_conv_forward_scaled(const dadet_conv_desc* d, const float* x, const float* w,
+                                         const float* scale, const float* bias, const float* addend,
+                                         const float* mask_ref, float* y, const float* amax_x, const float* amax_w,
+                                         float* amax_y, void* stream) {
+  return conv_forward_impl(d, x, w, scale, bias, addend, mask_ref, y, amax_x, amax_w, amax_y, stream);
 }
 
 extern "C" int dadet_conv_forward_variant(const dadet_conv_desc* d) {
@@ -870,7 +977,7 @@ extern "C" int dadet_conv_wgrad_workspace_bytes(const dadet_conv_desc* d, size_t
 
 static int conv_wgrad_impl(const dadet_conv_desc* d, const float* x, const float* gy, const float* out_scale, float* dw,
                            int accumulate, void* workspace, size_t workspace_bytes, dadet_wgrad_pending* pending,
-                           void* stream, int gy_ld = 0) {
+                           void* stream, int gy_ld = 0, const float* amax_x = nullptr, const float* amax_gy = nullptr) {
   if (pending) pending->splits = 0;
   int rc = conv_desc_check(d, "conv_wgrad");
   if (rc) return rc;
@@ -900,6 +1007,25 @@ static int conv_wgrad_impl(const dadet_conv_desc* d, const float* x, const float
   a.x_bytes = (unsigned)xb; a.gy_bytes = (unsigned)gb;
   wgrad_plan(d, &a.tiles_co, &a.tiles_kc, &a.splits, &a.rows_per_split);
   a.accumulate = accumulate;
+  a.amax_x = a.amax_gy = nullptr;
+  if (gemm_mode() == 4) {
+    if (!amax_x || !amax_gy) {
+      unsigned* own = stream_amax_slots(st);
+      if (!own) { set_error("conv_wgrad: could not allocate the operand-maximum slots"); return DADET_ELAUNCH; }
+      if (hipMemsetAsync(own + 2, 0, sizeof(unsigned) * 2, st) != hipSuccess) return check_launch("conv_wgrad(amax memset)");
+      if (!amax_x) {
+        rc = launch_amax(x, (int64_t)(xb / 4), own + 2, st);
+        if (rc) return rc;
+        amax_x = reinterpret_cast<const float*>(own + 2);
+      }
+      if (!amax_gy) {
+        rc = launch_amax(gy, (int64_t)(gb / 4), own + 3, st);
+        if (rc) return rc;
+        amax_gy = reinterpret_cast<const float*>(own + 3);
+      }
+    }
+    a.amax_x = amax_x; a.amax_gy = amax_gy;
+  }
   if (a.splits == 1) {
     a.direct = 1;
     a.out = dw;
@@ -973,6 +1099,14 @@ extern "C" int dadet_conv_wgrad_partials_ld(const dadet_conv_desc* d, const floa
                                             size_t workspace_bytes, dadet_wgrad_pending* pending_out, void* stream) {
   DADET_REQUIRE(pending_out, "conv_wgrad_partials_ld: null pending_out");
   return conv_wgrad_impl(d, x, gy, out_scale, dw, accumulate, workspace, workspace_bytes, pending_out, stream, gy_ld);
+}
+
+extern "C" int dadet_conv_wgrad_scaled(const dadet_conv_desc* d, const float* x, const float* gy, int gy_ld,
+                                       const float* out_scale, float* dw, int accumulate, void* workspace,
+                                       size_t workspace_bytes, dadet_wgrad_pending* pending_out, const float* amax_x,
+                                       const float* amax_gy, void* stream) {
+  return conv_wgrad_impl(d, x, gy, out_scale, dw, accumulate, workspace, workspace_bytes, pending_out, stream, gy_ld,
+                         amax_x, amax_gy);
 }
 
 extern "C" int dadet_conv_wgrad_reduce_batch(const dadet_wgrad_pending* items, int n, void* stream) {

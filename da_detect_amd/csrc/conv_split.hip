@@ -51,6 +51,7 @@ __device__ __forceinline__ void conv_epilogue_v4(const ConvArgs& a, f32x16 (&acc
   // data-gradient launch (they all gate), with the matrix pipe idle chip-wide on single-pass grids.
   unsigned offs[TM][TN][4];
   float4 ad[TM][TN][4], mk[TM][TN][4];
+  float mx = 0.f;                                        // max|y| of what this lane stores (mode 4: a.amax_y)
 #pragma unroll
   for (int in = 0; in < TN; ++in) {
     const int n = bn0 + wn * TN * 32 + in * 32 + c4;
@@ -123,10 +124,13 @@ __device__ __forceinline__ void conv_epilogue_v4(const ConvArgs& a, f32x16 (&acc
         }
         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, make_float4(v[0], v[1], v[2], v[3])), yr,
                                                (int)off, 0, 0);
+        if (a.amax_y && off != kOOB)
+          mx = fmaxf(fmaxf(mx, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
       }
       __builtin_amdgcn_wave_barrier();                   // the tile is rewritten by the next block
     }
   }
+  if (a.amax_y) amax_publish(a.amax_y, mx, lane);
 }
 
 // fused epilogue of the forward / data-gradient GEMM (same as conv_igemm.hip): y = gate(acc * scale + bias + addend);
@@ -140,6 +144,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[T
   const __amdgpu_buffer_rsrc_t mr = make_rsrc(a.mask_ref ? a.mask_ref : a.y, a.mask_ref ? a.y_bytes : 0u);
   const int col_in = lane & 31;
   const int row_hi = 4 * (lane >> 5);
+  float mx = 0.f;
 #pragma unroll
   for (int in = 0; in < TN; ++in) {
     const int n = bn0 + wn * TN * 32 + in * 32 + col_in;
@@ -182,11 +187,13 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[T
           if (a.relu_mode == 1) v = fmaxf(v, 0.f);
           else if (a.relu_mode == 2) v = (msk[q] > 0.f) ? v : 0.f;
           buf_store1(yr, offs[q], v);
+          if (a.amax_y && offs[q] != kOOB) mx = fmaxf(mx, fabsf(v));
         }
         __builtin_amdgcn_sched_barrier(0);
       }
     }
   }
+  if (a.amax_y) amax_publish(a.amax_y, mx, lane);
 }
 
 // One output tile over the K range [k_lo, k_hi) (whole K-tiles).  sk = nullptr: the result goes through the epilogue.
@@ -198,10 +205,19 @@ struct SkPart {
   int part, parts;
 };
 
-template <int TM, int TN, int TERMS, int AB>
+template <int TM, int TN, int FMT, int AB>
 __device__ __forceinline__ void conv_fwd_split_body(const ConvArgs& a, char* smem, const int tile, const int k_lo,
                                                     const int k_hi, const unsigned split_y, const SkPart* sk) {
+  constexpr int TERMS = Fmt<FMT>::terms;
+  constexpr bool F16 = Fmt<FMT>::f16;
   constexpr int BM = 2 * TM * 32, BN = 2 * TN * 32;
+  // mode 4: per-tensor power-of-two scales from the operands' maxima (scalar loads; see conv_common.h)
+  int ea = 0, eb = 0;
+  if (F16) {
+    ea = a.amax_x ? fmt4_exp(*a.amax_x) : 0;
+    eb = a.amax_w ? fmt4_exp(*a.amax_w) : 0;
+  }
+  const float sa = pow2f(ea), sb = pow2f(eb);
   constexpr int A_LOADS = BM / 32, B_LOADS = BN / 32;
   constexpr int A_PLANE = BM * PLANE_STRIDE, B_PLANE = BN * PLANE_STRIDE;  // bf16 elements
   __bf16* As = reinterpret_cast<__bf16*>(smem);   // [TERMS][BM][PLANE_STRIDE]
@@ -289,11 +305,17 @@ __device__ __forceinline__ void conv_fwd_split_body(const ConvArgs& a, char* sme
   uint2 pa_[A_LOADS][TERMS], pb_[B_LOADS][TERMS];
   auto split_a = [&]() {
 #pragma unroll
-    for (int i = 0; i < A_LOADS; ++i) split4<TERMS>(ra[i], pa_[i]);
+    for (int i = 0; i < A_LOADS; ++i) {
+      if constexpr (F16) split4h(ra[i], sa, pa_[i]);
+      else split4<TERMS>(ra[i], pa_[i]);
+    }
   };
   auto split_b = [&]() {
 #pragma unroll
-    for (int i = 0; i < B_LOADS; ++i) split4<TERMS>(rb[i], pb_[i]);
+    for (int i = 0; i < B_LOADS; ++i) {
+      if constexpr (F16) split4h(rb[i], sb, pb_[i]);
+      else split4<TERMS>(rb[i], pb_[i]);
+    }
   };
   auto store_tile = [&]() {
 #pragma unroll
@@ -374,7 +396,7 @@ __device__ __forceinline__ void conv_fwd_split_body(const ConvArgs& a, char* sme
           for (int im = 0; im < TM; ++im)
 #pragma unroll
             for (int in = 0; in < TN; ++in)
-              acc[im][in] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[pa][im], fb[pb][in], acc[im][in], 0, 0, 0);
+              acc[im][in] = mfma_32x32x16<F16>(fa[pa][im], fb[pb][in], acc[im][in]);
         }
       }
       if (AB == 0) {
@@ -401,6 +423,19 @@ __device__ __forceinline__ void conv_fwd_split_body(const ConvArgs& a, char* sme
       if (!(ab & 2)) store_tile();
       if (!(ab & 64)) __syncthreads();
     }
+  }
+
+  if (F16) {
+    // undo the operand scales (exact: powers of two, in two steps so that no intermediate leaves fp32's range
+    // unless the result does) — partial sums of split-K / stream-K parts are parked in true units
+    const int t = -(ea + eb);
+    const float u1 = pow2f(t / 2), u2 = pow2f(t - t / 2);
+#pragma unroll
+    for (int im = 0; im < TM; ++im)
+#pragma unroll
+      for (int in = 0; in < TN; ++in)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[im][in][e] = acc[im][in][e] * u1 * u2;
   }
 
   if (sk) {
@@ -455,13 +490,13 @@ __device__ __forceinline__ void conv_fwd_split_body(const ConvArgs& a, char* sme
 #ifndef DADET_FWD_OCC5
 #define DADET_FWD_OCC5 1
 #endif
-template <int TM, int TN, int TERMS, int AB = 0>
-__global__ __launch_bounds__(256, (DADET_FWD_OCC5 && TM * TN == 1 && TERMS == 3 && AB == 0) ? 5 : 2)
+template <int TM, int TN, int FMT, int AB = 0>
+__global__ __launch_bounds__(256, (DADET_FWD_OCC5 && TM * TN == 1 && FMT >= 3 && AB == 0) ? 5 : 2)
 void conv_fwd_split_kernel(const ConvArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int k_lo = a.ksplit ? (int)blockIdx.y * a.ksplit : 0;
   const int k_hi = a.ksplit ? min(a.K, k_lo + a.ksplit) : a.K;
-  conv_fwd_split_body<TM, TN, TERMS, AB>(a, smem, xcd_remap(blockIdx.x, a.tiles_m * a.tiles_n), k_lo, k_hi, blockIdx.y,
+  conv_fwd_split_body<TM, TN, FMT, AB>(a, smem, xcd_remap(blockIdx.x, a.tiles_m * a.tiles_n), k_lo, k_hi, blockIdx.y,
                                          nullptr);
 }
 
@@ -471,11 +506,11 @@ void conv_fwd_split_kernel(const ConvArgs a) {
 // as before; the remaining sk_tiles * nk K-tile iterations are cut into `sk_units` equal contiguous ranges, one per
 // extra workgroup, so the tail ends (T mod 512) / 512 of a pass after the full passes instead of a whole one.  A range
 // covers the end of one tile and the start of the next; the parts of a tile meet in the workspace (conv_fwd_split_body).
-template <int TERMS>
+template <int FMT>
 __global__ __launch_bounds__(256, 2) void conv_fwd_split_sk_kernel(const ConvArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   if ((int)blockIdx.x < a.sk_dp_tiles) {
-    conv_fwd_split_body<2, 2, TERMS, 0>(a, smem, xcd_remap(blockIdx.x, a.sk_dp_tiles), 0, a.K, 0, nullptr);
+    conv_fwd_split_body<2, 2, FMT, 0>(a, smem, xcd_remap(blockIdx.x, a.sk_dp_tiles), 0, a.K, 0, nullptr);
     return;
   }
   const int nk = (a.K + BK - 1) / BK;
@@ -493,7 +528,7 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_split_sk_kernel(const ConvArg
     first = false;
     const int k_lo = k0 * BK, k_hi = min(a.K, k1 * BK);
     if (k0 == 0 && k1 == nk) {
-      conv_fwd_split_body<2, 2, TERMS, 0>(a, smem, a.sk_dp_tiles + tl, k_lo, k_hi, 0, nullptr);
+      conv_fwd_split_body<2, 2, FMT, 0>(a, smem, a.sk_dp_tiles + tl, k_lo, k_hi, 0, nullptr);
     } else {
       const int first_unit = (tl * nk) / a.sk_iters, last_unit = ((tl + 1) * nk - 1) / a.sk_iters;
       SkPart part;
@@ -501,7 +536,7 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_split_sk_kernel(const ConvArg
       part.counter = a.sk_counters + tl;
       part.part = unit - first_unit;
       part.parts = last_unit - first_unit + 1;
-      conv_fwd_split_body<2, 2, TERMS, 0>(a, smem, a.sk_dp_tiles + tl, k_lo, k_hi, 0, &part);
+      conv_fwd_split_body<2, 2, FMT, 0>(a, smem, a.sk_dp_tiles + tl, k_lo, k_hi, 0, &part);
     }
     it += k1 - k0;
   }
@@ -512,15 +547,16 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_split_sk_kernel(const ConvArg
 // 4-wave kernel on long-K layers, slower on short-K ones; a static wave priority by hardware wave slot — no effect.
 // DESIGN.md section 6.)
 
-template <int TM, int TN, int TERMS, int AB = 0>
+template <int TM, int TN, int FMT, int AB = 0>
 static int launch_split(ConvArgs& a, hipStream_t st) {
+  constexpr int TERMS = Fmt<FMT>::terms;
   constexpr int BM = 2 * TM * 32, BN = 2 * TN * 32;
   a.tiles_m = ceil_div(a.M, BM);
   a.tiles_n = ceil_div(a.Cout, BN);
   const size_t lds = sizeof(__bf16) * TERMS * (BM + BN) * PLANE_STRIDE;
   static bool attr_set = false;
   if (!attr_set && lds > 48 * 1024) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_fwd_split_kernel<TM, TN, TERMS, AB>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_fwd_split_kernel<TM, TN, FMT, AB>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) {
       set_error("conv_forward(split): hipFuncSetAttribute: %s", hipGetErrorString(e));
@@ -529,17 +565,18 @@ static int launch_split(ConvArgs& a, hipStream_t st) {
     attr_set = true;
   }
   const int ksplits = a.ksplit ? ceil_div(a.K, a.ksplit) : 1;
-  hipLaunchKernelGGL((conv_fwd_split_kernel<TM, TN, TERMS, AB>), dim3(a.tiles_m * a.tiles_n, ksplits), dim3(256), lds,
+  hipLaunchKernelGGL((conv_fwd_split_kernel<TM, TN, FMT, AB>), dim3(a.tiles_m * a.tiles_n, ksplits), dim3(256), lds,
                      st, a);
   return check_launch("conv_forward(split)");
 }
 
-template <int TERMS>
+template <int FMT>
 static int launch_split_sk(ConvArgs& a, hipStream_t st) {
+  constexpr int TERMS = Fmt<FMT>::terms;
   const size_t lds = sizeof(__bf16) * TERMS * 256 * PLANE_STRIDE;
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_fwd_split_sk_kernel<TERMS>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_fwd_split_sk_kernel<FMT>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) {
       set_error("conv_forward(split, stream-K): hipFuncSetAttribute: %s", hipGetErrorString(e));
@@ -547,17 +584,25 @@ static int launch_split_sk(ConvArgs& a, hipStream_t st) {
     }
     attr_set = true;
   }
-  hipLaunchKernelGGL((conv_fwd_split_sk_kernel<TERMS>), dim3(a.sk_dp_tiles + a.sk_units), dim3(256), lds, st, a);
+  hipLaunchKernelGGL((conv_fwd_split_sk_kernel<FMT>), dim3(a.sk_dp_tiles + a.sk_units), dim3(256), lds, st, a);
   return check_launch("conv_forward(split, stream-K)");
 }
 
-int launch_fwd_split_sk(ConvArgs& a, int terms, hipStream_t st) {
+int launch_fwd_split_sk(ConvArgs& a, int fmt, hipStream_t st) {
   a.tiles_m = ceil_div(a.M, 128);
   a.tiles_n = ceil_div(a.Cout, 128);
-  return terms == 2 ? launch_split_sk<2>(a, st) : launch_split_sk<3>(a, st);
+  return fmt == 4 ? launch_split_sk<4>(a, st) : fmt == 2 ? launch_split_sk<2>(a, st) : launch_split_sk<3>(a, st);
 }
 
-int launch_fwd_split(ConvArgs& a, int variant, int terms, hipStream_t st) {
+int launch_fwd_split(ConvArgs& a, int variant, int fmt, hipStream_t st) {
+  const int terms = fmt;
+  if (fmt == 4) {
+    switch (variant) {
+      case 0: return launch_split<2, 2, 4>(a, st);
+      case 1: return launch_split<2, 1, 4>(a, st);
+      default: return launch_split<1, 1, 4>(a, st);
+    }
+  }
   if (a.ablate && variant == 0 && terms == 3) {   // profiling experiments only (DADET_ABLATE)
     switch (a.ablate) {
       case 1: return launch_split<2, 2, 3, 1>(a, st);
@@ -592,9 +637,17 @@ int launch_fwd_split(ConvArgs& a, int variant, int terms, hipStream_t st) {
 // and writes for each channel the four m-values as one 8-byte ds_write into a [channel][m] plane
 // ([128][32 + 8 pad] bf16 per term).  Lane -> (m-group = t % 8, channel-quad = t / 8) keeps the global loads as
 // 128-byte row segments and the LDS writes bank-conflict free.
-template <int TERMS, bool SMALL_MAP>
+template <int FMT, bool SMALL_MAP>
 __global__ __launch_bounds__(256, 2) void conv_wgrad_split_kernel(const WgradArgs a) {
+  constexpr int TERMS = Fmt<FMT>::terms;
+  constexpr bool F16 = Fmt<FMT>::f16;
   constexpr int TILE = 128, RK = 32;
+  int eg = 0, ex = 0;   // mode 4: per-tensor power-of-two scales of gy and x
+  if (F16) {
+    eg = a.amax_gy ? fmt4_exp(*a.amax_gy) : 0;
+    ex = a.amax_x ? fmt4_exp(*a.amax_x) : 0;
+  }
+  const float sg = pow2f(eg), sx = pow2f(ex);
   constexpr int PLANE = TILE * PLANE_STRIDE;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   __bf16* Gs = reinterpret_cast<__bf16*>(smem);  // [TERMS][128 co][PLANE_STRIDE]
@@ -682,12 +735,15 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_split_kernel(const WgradArg
     m_cur += RK;
   };
   uint2 pg_[4][TERMS], px_[4][TERMS];
-  auto split_block = [&](const float4 (&v)[4], uint2 (&out)[4][TERMS]) {
+  auto split_block = [&](const float4 (&v)[4], uint2 (&out)[4][TERMS], const float sc) {
     // 4x4 register transpose: channel c of the quad gets (row0[c], row1[c], row2[c], row3[c])
     const float4 cols[4] = {make_float4(v[0].x, v[1].x, v[2].x, v[3].x), make_float4(v[0].y, v[1].y, v[2].y, v[3].y),
                             make_float4(v[0].z, v[1].z, v[2].z, v[3].z), make_float4(v[0].w, v[1].w, v[2].w, v[3].w)};
 #pragma unroll
-    for (int c = 0; c < 4; ++c) split4<TERMS>(cols[c], out[c]);
+    for (int c = 0; c < 4; ++c) {
+      if constexpr (F16) split4h(cols[c], sc, out[c]);
+      else split4<TERMS>(cols[c], out[c]);
+    }
   };
   auto store_plane = [&](__bf16* base, const uint2 (&parts)[4][TERMS]) {
 #pragma unroll
@@ -709,8 +765,8 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_split_kernel(const WgradArg
   if (nsteps > 0) {
     load_g();
     load_x();
-    split_block(rg, pg_);
-    split_block(rx, px_);
+    split_block(rg, pg_, sg);
+    split_block(rx, px_, sx);
     store_plane(Gs, pg_);
     store_plane(Xs, px_);
     load_g();   // step 1 is in flight while step 0 is multiplied
@@ -736,8 +792,8 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_split_kernel(const WgradArg
           fg[p][i] = *reinterpret_cast<const bf16x8*>(Gb + p * PLANE + i * 32 * PLANE_STRIDE + step * 16);
           fx[p][i] = *reinterpret_cast<const bf16x8*>(Xb + p * PLANE + i * 32 * PLANE_STRIDE + step * 16);
         }
-      if (step == 0) split_block(rg, pg_);
-      else split_block(rx, px_);
+      if (step == 0) split_block(rg, pg_, sg);
+      else split_block(rx, px_, sx);
 #pragma unroll
       for (int order = 2 * (TERMS - 1); order >= 0; --order) {
 #pragma unroll
@@ -749,7 +805,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_split_kernel(const WgradArg
           for (int im = 0; im < 2; ++im)
 #pragma unroll
             for (int in = 0; in < 2; ++in)
-              acc[im][in] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fg[pa][im], fx[pb][in], acc[im][in], 0, 0, 0);
+              acc[im][in] = mfma_32x32x16<F16>(fg[pa][im], fx[pb][in], acc[im][in]);
         }
       }
       {
@@ -773,6 +829,16 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_split_kernel(const WgradArg
     }
   }
 
+  if (F16) {   // undo the operand scales (exact; two steps, see conv_fwd_split_body)
+    const int t = -(eg + ex);
+    const float u1 = pow2f(t / 2), u2 = pow2f(t - t / 2);
+#pragma unroll
+    for (int im = 0; im < 2; ++im)
+#pragma unroll
+      for (int in = 0; in < 2; ++in)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[im][in][e] = acc[im][in][e] * u1 * u2;
+  }
   const bool final_out = a.direct;              // this workgroup writes dw itself (scale / accumulate applied here)
   float* out = a.direct ? a.out : a.out + (size_t)split * a.Cout * a.K;
   const int col_in = lane & 31, row_hi = 4 * (lane >> 5);
@@ -797,12 +863,13 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_split_kernel(const WgradArg
   }
 }
 
-template <int TERMS, bool SMALL_MAP>
+template <int FMT, bool SMALL_MAP>
 static int launch_wgrad_terms(WgradArgs& a, hipStream_t st) {
+  constexpr int TERMS = Fmt<FMT>::terms;
   const size_t lds = sizeof(__bf16) * TERMS * 2 * 128 * PLANE_STRIDE;
   static bool attr_set = false;
   if (!attr_set && lds > 48 * 1024) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad_split_kernel<TERMS, SMALL_MAP>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad_split_kernel<FMT, SMALL_MAP>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) {
       set_error("conv_wgrad(split): hipFuncSetAttribute: %s", hipGetErrorString(e));
@@ -810,23 +877,25 @@ static int launch_wgrad_terms(WgradArgs& a, hipStream_t st) {
     }
     attr_set = true;
   }
-  hipLaunchKernelGGL((conv_wgrad_split_kernel<TERMS, SMALL_MAP>), dim3(a.tiles_co * a.tiles_kc, a.splits), dim3(256),
+  hipLaunchKernelGGL((conv_wgrad_split_kernel<FMT, SMALL_MAP>), dim3(a.tiles_co * a.tiles_kc, a.splits), dim3(256),
                      lds, st, a);
   return check_launch("conv_wgrad(split)");
 }
 
 int launch_wgrad_split(WgradArgs& a, int terms, hipStream_t st) {
   const bool small_map = a.Wo < 32;   // narrower than one K-step of rows
+  if (terms == 4) return small_map ? launch_wgrad_terms<4, true>(a, st) : launch_wgrad_terms<4, false>(a, st);
   if (terms == 2) return small_map ? launch_wgrad_terms<2, true>(a, st) : launch_wgrad_terms<2, false>(a, st);
   return small_map ? launch_wgrad_terms<3, true>(a, st) : launch_wgrad_terms<3, false>(a, st);
 }
 
 }  // namespace dadet
 
-// 3 = 3-term bf16 split (6 MFMAs / K=16, fp32-class accuracy; default); 0 = exact fp32 MFMA; 2 = 2-term split (3 MFMAs / K=16)
+// 4 = 2-term fp16 split under per-tensor power-of-two scales (3 MFMAs / K=16, fp32-class accuracy); 3 = 3-term bf16 split
+// (6 MFMAs / K=16, fp32-class accuracy, no scales); 0 = exact fp32 MFMA; 2 = 2-term bf16 split (3 MFMAs / K=16, ~2^-16)
 extern "C" int dadet_set_gemm_mode(int mode) {
-  if (mode != 0 && mode != 2 && mode != 3) {
-    dadet::set_error("set_gemm_mode: mode must be 0, 2 or 3");
+  if (mode != 0 && mode != 2 && mode != 3 && mode != 4) {
+    dadet::set_error("set_gemm_mode: mode must be 0, 2, 3 or 4");
     return DADET_EINVAL;
   }
   dadet::g_gemm_mode = mode;

@@ -157,12 +157,38 @@ int dadet_conv_forward(const dadet_conv_desc* d, const float* x, const float* w,
                        const float* bias, const float* addend, const float* mask_ref, float* y,
                        void* stream);
 
-/* Contraction mode of dadet_conv_forward / dadet_conv_wgrad (process-wide): 3 (DEFAULT, also for a consumer that never
- * calls this) = fp32 operands split into three bf16 terms, six v_mfma_f32_32x32x16_bf16 per K=16 (error ~2^-24 |ab|,
- * fp32 class, 2.6x the rate of mode 0); 0 = exact fp32 MFMA (v_mfma_f32_32x32x2_f32); 2 = two-term split, three
- * MFMAs per K=16 (error ~2^-16 |ab|, experiments only).  Inputs, outputs and accumulation are fp32 in every mode. */
+/* Contraction mode of dadet_conv_forward / dadet_conv_wgrad (process-wide).  Inputs, outputs and accumulation are fp32 in
+ * every mode; the modes differ in how the fp32 products are formed on the matrix pipe:
+ *   4 (DEFAULT, also for a consumer that never calls this) = each operand, scaled by a per-tensor power of two, is split
+ *     into two fp16 terms; three v_mfma_f32_32x32x16_f16 per K=16 (error ~2^-24 |ab|: fp32 class).  The scale of a tensor
+ *     comes from its largest magnitude (below); through dadet_conv_forward / dadet_conv_wgrad the library measures the
+ *     operands itself (two extra passes), through the *_scaled entry points the caller hands the maxima over;
+ *   3 = three bf16 terms, six v_mfma_f32_32x32x16_bf16 per K=16 (error ~2^-24 |ab|, fp32 class, no scales needed);
+ *   0 = exact fp32 MFMA (v_mfma_f32_32x32x2_f32);
+ *   2 = two bf16 terms, three MFMAs per K=16 (error ~2^-16 |ab|, experiments only). */
 int dadet_set_gemm_mode(int mode);
 int dadet_get_gemm_mode(void);
+
+/* Largest magnitudes for mode 4.  A "slot" is one device float holding max|t| over a tensor t (an upper bound within a
+ * few binades serves as well: it only has to keep t / slot inside fp16's range without wasting it).
+ * dadet_amax merges max|x[0..n)| into *slot (atomic max: zero the slot first, or reuse one to cover several tensors).
+ * dadet_amax_batch does the same for n tensors in one launch; items_dev is device-resident, item k owns the workgroups
+ * [first_block, first_block + blocks) of a grid of total_blocks. */
+typedef struct dadet_amax_item {
+  const void* x;           /* float[n], 16-byte aligned */
+  void* slot;              /* float */
+  long long n;
+  int first_block, blocks;
+} dadet_amax_item;
+int dadet_amax(const float* x, long long n, float* slot, void* stream);
+int dadet_amax_batch(const dadet_amax_item* items_dev, int n, int total_blocks, void* stream);
+
+/* dadet_conv_forward with the operands' maxima handed over (amax_x, amax_w: device floats, NULL = measured here) and,
+ * when amax_y is not NULL, max|y| of the values this call stores merged into *amax_y by the epilogue itself (zero it
+ * first) — the next GEMM's amax_x.  Modes other than 4 ignore all three. */
+int dadet_conv_forward_scaled(const dadet_conv_desc* d, const float* x, const float* w, const float* scale,
+                              const float* bias, const float* addend, const float* mask_ref, float* y,
+                              const float* amax_x, const float* amax_w, float* amax_y, void* stream);
 
 /* which tile variant dadet_conv_forward launches for this shape: 0 = 128x128 (conv_fwd_kernel<2,2>),
  * 1 = 128x64 (<2,1>), 2 = 64x64 (<1,1>).  Used by bench.py to attribute per-launch timings. */
@@ -197,6 +223,13 @@ int dadet_conv_wgrad_reduce_batch(const dadet_wgrad_pending* items, int n, void*
 int dadet_conv_wgrad_partials_ld(const dadet_conv_desc* d, const float* x, const float* gy, int gy_ld,
                                  const float* out_scale, float* dw, int accumulate, void* workspace,
                                  size_t workspace_bytes, dadet_wgrad_pending* pending_out, void* stream);
+
+/* dadet_conv_wgrad_partials_ld (pending_out may be NULL: then the reduction pass runs here, as in dadet_conv_wgrad) with
+ * the operands' maxima handed over; see dadet_conv_forward_scaled */
+int dadet_conv_wgrad_scaled(const dadet_conv_desc* d, const float* x, const float* gy, int gy_ld,
+                            const float* out_scale, float* dw, int accumulate, void* workspace,
+                            size_t workspace_bytes, dadet_wgrad_pending* pending_out, const float* amax_x,
+                            const float* amax_gy, void* stream);
 
 /* weight re-layout for the data gradient: wt[ci][KH-1-r][KW-1-s][co] = w[co][r][s][ci] * scale[co].
  * dgrad of a stride-1 conv is then dadet_conv_forward(gy, wt) with pad' = K-1-pad. */

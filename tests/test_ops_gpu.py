@@ -252,10 +252,11 @@ def test_conv_dgrad_wgrad(device, case):
     torch.testing.assert_close(dx, x.grad, rtol=1e-4, atol=1e-4)
 
 
-@pytest.mark.parametrize("mode,tol", [(3, 2e-5), (2, 2e-3)])
+@pytest.mark.parametrize("mode,tol", [(4, 2e-5), (3, 2e-5), (2, 2e-3)])
 @pytest.mark.parametrize("case", [CONV_CASES[1], CONV_CASES[3], CONV_CASES[4], CONV_CASES[6], CONV_CASES[9]])
 def test_conv_forward_split_bf16_modes(device, case, mode, tol):
-    """split-bf16 contraction: mode 3 (6 MFMAs / K=16) must hold the exact-fp32 tolerance, mode 2 is ~2^-16"""
+    """split contractions: mode 4 (two fp16 terms, 3 MFMAs / K=16, per-tensor scales) and mode 3 (three bf16 terms,
+    6 MFMAs / K=16) must hold the exact-fp32 tolerance, mode 2 is ~2^-16"""
     from da_detect_amd import _C
 
     N, Cin, H, W, Cout, k, stride, pad = case
@@ -276,7 +277,7 @@ def test_conv_forward_split_bf16_modes(device, case, mode, tol):
     err_split = float((got.double() - ref64).abs().max()) / scale
     print("case %s mode %d: max err / mean|y|  exact-fp32 %.2e  split %.2e" % (case, mode, err_exact, err_split))
     assert err_split < tol * 10
-    if mode == 3:  # fp32 class: no worse than a few times the exact-fp32 kernel's own rounding
+    if mode >= 3:  # fp32 class: no worse than a few times the exact-fp32 kernel's own rounding
         assert err_split < max(4 * err_exact, 1e-6)
 
 
@@ -304,7 +305,7 @@ def test_split_bf16_accuracy_at_production_k(device, case):
     prev = _C.get_gemm_mode()
     out = {}
     try:
-        for mode in (0, 3):
+        for mode in (0, 3, 4):
             _C.set_gemm_mode(mode)
             out[mode] = (_C.conv_forward(xd, wd, stride=stride, pad=pad), _C.conv_wgrad(xd, gyd, tuple(w.shape), stride, pad))
     finally:
@@ -316,33 +317,97 @@ def test_split_bf16_accuracy_at_production_k(device, case):
     patches = torch.stack([xp[n, :, h:h + k, w_:w_ + k].reshape(-1) for n, h, w_ in pix])        # [96, Cin*k*k]
     ref = patches @ w.double().reshape(Cout, -1).t()                                               # [96, Cout]
     stats = {}
-    for mode in (0, 3):
+    for mode in (0, 3, 4):
         y = out[mode][0].cpu().double()
         got = torch.stack([y[n, :, h, w_] for n, h, w_ in pix])
         e = (got - ref) / ref.abs().mean()
         stats[mode] = (float(e.pow(2).mean().sqrt()), float(e.abs().max()))
-    print("forward %s: rel. error rms / max  exact-fp32 %.3e / %.3e   split %.3e / %.3e" % ((case,) + stats[0] + stats[3]))
-    assert stats[3][0] <= 1.1 * stats[0][0] and stats[3][1] <= 1.5 * stats[0][1], stats
+    print("forward %s: rel. error rms / max  exact-fp32 %.3e / %.3e   bf16x3 %.3e / %.3e   fp16x2 %.3e / %.3e"
+          % ((case,) + stats[0] + stats[3] + stats[4]))
+    for m in (3, 4):
+        assert stats[m][0] <= 1.1 * stats[0][0] and stats[m][1] <= 1.5 * stats[0][1], stats
     # weight gradient: taps (r, s) sampled, dW[:, :, r, s] = gy^T [Cout, M] @ x_shifted [M, Cin] in float64 on the device
     taps = [(0, 0), (1, 1), (2, 2), (0, 2), (2, 0), (1, 0), (0, 1), (2, 1)]
     xpd = F.pad(xd.double(), (pad, pad, pad, pad))
     g2 = gyd.double().permute(1, 0, 2, 3).reshape(Cout, -1)
-    stats = {0: [0.0, 0.0, 0], 3: [0.0, 0.0, 0]}
+    stats = {0: [0.0, 0.0, 0], 3: [0.0, 0.0, 0], 4: [0.0, 0.0, 0]}
     for r, s_ in taps:
         xs = xpd[:, :, r:r + H, s_:s_ + W].permute(0, 2, 3, 1).reshape(-1, Cin)
         refw = (g2 @ xs).cpu()
-        for mode in (0, 3):
+        for mode in (0, 3, 4):
             e = (out[mode][1][:, :, r, s_].cpu().double() - refw) / refw.abs().mean()
             stats[mode][0] += float(e.pow(2).sum())
             stats[mode][1] = max(stats[mode][1], float(e.abs().max()))
             stats[mode][2] += e.numel()
     rms = {m: (stats[m][0] / stats[m][2]) ** 0.5 for m in stats}
-    print("wgrad   %s: rel. error rms / max  exact-fp32 %.3e / %.3e   split %.3e / %.3e"
-          % (case, rms[0], stats[0][1], rms[3], stats[3][1]))
-    assert rms[3] <= 1.1 * rms[0] and stats[3][1] <= 1.5 * stats[0][1], (rms, stats)
+    print("wgrad   %s: rel. error rms / max  exact-fp32 %.3e / %.3e   bf16x3 %.3e / %.3e   fp16x2 %.3e / %.3e"
+          % (case, rms[0], stats[0][1], rms[3], stats[3][1], rms[4], stats[4][1]))
+    for m in (3, 4):
+        assert rms[m] <= 1.1 * rms[0] and stats[m][1] <= 1.5 * stats[0][1], (rms, stats)
 
 
-@pytest.mark.parametrize("mode,tol", [(3, 1e-4), (2, 2e-3)])
+@pytest.mark.parametrize("sx,sw", [(1.0, 1.0), (3e-12, 7e9), (2.5e7, 1e-3), (1e-30, 1e-5), (6e4, 6e4)])
+def test_fp16_split_is_scale_free(device, sx, sw):
+    """mode 4 under the per-tensor scales: operands 40 binades below or 25 above one (far outside fp16's range, gradients
+    and un-normalised activations look like that) give the relative error of the O(1) case — powers of two in, powers of
+    two out.  Also: the slot the epilogue fills holds exactly max|y|."""
+    from da_detect_amd import _C, amax
+
+    case = (2, 256, 24, 40, 192, 3, 1, 1)
+    rng = np.random.default_rng(11)
+    x, w = _conv_case(rng, *case)
+    x, w = x * sx, w * sw
+    ref = F.conv2d(x.double(), w.double(), None, 1, 1)
+    prev = _C.get_gemm_mode()
+    try:
+        _C.set_gemm_mode(4)
+        y = _C.conv_forward(x.to(device).contiguous(memory_format=CL), w.to(device).contiguous(memory_format=CL), pad=1)
+        held = amax.value(y)
+    finally:
+        _C.set_gemm_mode(prev)
+    assert held == float(y.abs().max())
+    err = float((y.cpu().double() - ref).abs().max() / ref.abs().mean())
+    print("scales %g x %g: max err / mean|y| %.2e" % (sx, sw, err))
+    assert err < 3e-6
+
+
+def test_fp16_split_wide_range_inside_one_tensor(device):
+    """elements far below the tensor's maximum: above 2^-16 of it they keep fp32-class relative accuracy, below that an
+    absolute error under 2^-38 of the maximum (the low term falls into fp16's subnormals) — rows whose values are all
+    tiny are still good to ~1e-6 of THEIR OWN size down to 2^-20 of the maximum"""
+    from da_detect_amd import _C
+
+    rng = np.random.default_rng(12)
+    M, K, Cout = 4096, 1024, 256
+    x = rng.standard_normal((M, K)).astype(np.float32)
+    rowscale = np.exp2(-rng.integers(0, 24, (M, 1)).astype(np.float32))      # rows between 1 and 2^-23 of the largest
+    rowscale[0] = 1.0
+    x = x * rowscale
+    w = (rng.standard_normal((Cout, K)) / np.sqrt(K)).astype(np.float32)
+    xt = torch.from_numpy(x).view(1, M, 1, K).permute(0, 3, 1, 2).contiguous(memory_format=CL)     # [1, K, M, 1]
+    wt = torch.from_numpy(w).view(Cout, K, 1, 1).contiguous(memory_format=CL)
+    ref = torch.from_numpy(x).double() @ torch.from_numpy(w).double().t()
+    prev = _C.get_gemm_mode()
+    try:
+        _C.set_gemm_mode(4)
+        y = _C.conv_forward(xt.to(device), wt.to(device)).cpu().permute(0, 2, 3, 1).reshape(M, Cout).double()
+        _C.set_gemm_mode(0)
+        y0 = _C.conv_forward(xt.to(device), wt.to(device)).cpu().permute(0, 2, 3, 1).reshape(M, Cout).double()
+    finally:
+        _C.set_gemm_mode(prev)
+    amax = float(np.abs(x).max())
+    rs = torch.from_numpy(rowscale.astype(np.float64))
+    e4 = (y - ref).abs().max(dim=1, keepdim=True).values
+    e0 = (y0 - ref).abs().max(dim=1, keepdim=True).values
+    big = rs[:, 0] >= 2.0 ** -14
+    rel4, rel0 = float((e4 / rs)[big].max()), float((e0 / rs)[big].max())
+    print("rows within 2^-14 of the maximum: max err / row scale  fp16x2 %.2e  exact-fp32 %.2e" % (rel4, rel0))
+    assert rel4 < 4 * rel0
+    print("all rows: max abs err / tensor max  %.2e" % (float(e4.max()) / amax))
+    assert float(e4[~big].max()) < 2.0 ** -34 * amax * 4
+
+
+@pytest.mark.parametrize("mode,tol", [(4, 1e-4), (3, 1e-4), (2, 2e-3)])
 @pytest.mark.parametrize("case", [CONV_CASES[1], CONV_CASES[2], CONV_CASES[3], CONV_CASES[6], CONV_CASES[7], CONV_CASES[9]])
 def test_conv_wgrad_split_bf16_modes(device, case, mode, tol):
     from da_detect_amd import _C
@@ -368,7 +433,7 @@ def test_conv_wgrad_split_bf16_modes(device, case, mode, tol):
     err_split = float((got.double() - w64.grad).abs().max()) / scale
     print("wgrad case %s mode %d: exact-fp32 %.2e  split %.2e" % (case, mode, err_exact, err_split))
     assert err_split < tol
-    if mode == 3:
+    if mode >= 3:
         assert err_split < max(4 * err_exact, 1e-6)
 
 
