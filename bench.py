@@ -41,6 +41,9 @@ HEIGHT, WIDTH, IMAGES_PER_GPU = 1024, 2048, 2
 FP32_MFMA_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 64 FLOP/clk/SIMD x 1024 SIMDs x 2.4 GHz
 BF16_MFMA_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense bf16 MFMA (v_mfma_f32_32x32x16_bf16)
 GEMM_MODES = {
+    4: ("fp32 operands, scaled per tensor by a power of two, split into 2 fp16 terms, 3 x v_mfma_f32_32x32x16_f16 per "
+        "K=16, fp32 accumulate (error against fp64 at production K: RMS <= 1.1x, max <= 1.5x of the exact-fp32 kernel's "
+        "error, tests/test_ops_gpu.py::test_split_bf16_accuracy_at_production_k)", 3),
     0: ("exact fp32 MFMA (v_mfma_f32_32x32x2_f32)", 1),
     3: ("fp32 operands split into 3 bf16 terms, 6 x v_mfma_f32_32x32x16_bf16 per K=16, fp32 accumulate "
         "(error against fp64 at production K: RMS <= 1.1x, max <= 1.5x of the exact-fp32 kernel's error, "

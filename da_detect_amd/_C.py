@@ -207,7 +207,7 @@ def roi_align_forward(input, rois, spatial_scale, pooled_height, pooled_width, s
         _lib.call("dadet_roi_align_forward_sub", _p(x), _p(rois), _p(out), B, C, H, W, R, pooled_height, pooled_width,
                   float(spatial_scale), int(sampling_ratio), s, _p(ws) if ws is not None else None,
                   ctypes.c_size_t(ws.numel() if ws is not None else 0), _stream())
-        return out
+        return _amax.carry(out, input)     # averages of bilinear samples: bounded by the map's largest magnitude
     out = torch.empty((R, C, pooled_height, pooled_width), dtype=torch.float32, device=input.device,
                       memory_format=CL)
     if ROI_ALIGN_WORKSPACE:
@@ -217,7 +217,7 @@ def roi_align_forward(input, rois, spatial_scale, pooled_height, pooled_width, s
     else:
         _lib.call("dadet_roi_align_forward", _p(x), _p(rois), _p(out), B, C, H, W, R, pooled_height,
                   pooled_width, float(spatial_scale), int(sampling_ratio), _stream())
-    return out
+    return _amax.carry(out, input)
 
 
 # forward: ROIs processed in spatial (Z-order) order through a scratch buffer; False = the plain entry point
@@ -646,6 +646,11 @@ def relu_bn_backward(g, y=None, scale=None, want_unscaled=False):
     g_scaled = torch.empty_like(g)
     _lib.call("dadet_relu_bn_backward", _p(g), _p(yy), _p(scale), _p(g_out), _p(g_scaled), rows, C,
               _stream())
+    # a gate only removes values: the input's largest magnitude bounds the gated copies (amax.py)
+    if g_out is not None:
+        _amax.carry(g_out, g)
+    if scale is None:
+        _amax.carry(g_scaled, g)
     return g_out, g_scaled
 
 
@@ -687,7 +692,7 @@ def maxpool3x3s2(x):
     Ho, Wo = (H + 2 - 3) // 2 + 1, (W + 2 - 3) // 2 + 1
     y = torch.empty((N, C, Ho, Wo), dtype=torch.float32, device=x.device, memory_format=CL)
     _lib.call("dadet_maxpool3x3s2_forward", _p(x), _p(y), N, H, W, C, Ho, Wo, _stream())
-    return y
+    return _amax.carry(y, x)
 
 
 def avgpool_forward(x):
@@ -697,7 +702,7 @@ def avgpool_forward(x):
     R, C, h, w = x.shape
     y = torch.empty((R, C), dtype=torch.float32, device=x.device)
     _lib.call("dadet_avgpool_forward", _p(x), _p(y), R, h * w, C, _stream())
-    return y
+    return _amax.carry(y, x)
 
 
 def avgpool_backward(gy, h, w):
@@ -706,7 +711,7 @@ def avgpool_backward(gy, h, w):
     R, C = gy.shape
     gx = torch.empty((R, C, h, w), dtype=torch.float32, device=gy.device, memory_format=CL)
     _lib.call("dadet_avgpool_backward", _p(gy), _p(gx), R, h * w, C, _stream())
-    return gx
+    return _amax.carry(gx, gy)     # gy / (h w): a bound (a few binades above the maximum cost nothing that matters)
 
 
 def nchw3_to_nhwc4(x):
@@ -887,7 +892,8 @@ def deform_sample_forward_om(x, om, kh, kw, stride, pad, dil, dg, modulated):
     cols = torch.empty((N, T * C, Ho, Wo), dtype=torch.float32, device=x.device, memory_format=CL)
     _lib.call("dadet_deform_sample_forward_ld", _p(x), _p(om), ld, _off_ptr(om, 2 * T * dg) if modulated else None, ld,
               1, _p(cols), N, H, W, C, kh, kw, stride, pad, dil, dg, Ho, Wo, _stream())
-    return cols
+    # bilinear samples (weights summing to at most one) times a sigmoid: bounded by the map's largest magnitude
+    return _amax.carry(cols, x)
 
 
 def deform_sample_backward_om(x, om, gcols, kh, kw, stride, pad, dil, dg, modulated):
@@ -976,7 +982,7 @@ def gather_pixel_taps(x, pixels, ksize=1, pad=0, row_level=None, level=0, out=No
                   ksize, pad, _p(out), _stream())
         return out
     _lib.call("dadet_gather_pixel_taps", _p(x), _p(pixels), S, N, H, W, C, ksize, ksize, pad, _p(out), _stream())
-    return out
+    return _amax.carry(out, x)
 
 
 def scatter_pixel_taps_add(y, pixels, shape, ksize=1, pad=0, row_level=None, level=0):

@@ -1,9 +1,10 @@
 """Largest magnitudes of GEMM operands for contraction mode 4 (two fp16 terms under a per-tensor power-of-two scale,
 `csrc/conv_common.h`).
 
-A *slot* is one device float that holds max|t| (or an upper bound within a few binades) of a tensor t.  The GEMM kernels
-read the operands' slots with scalar loads and derive the scales themselves; nothing here ever brings a maximum to the
-host.  Where slots come from:
+A *slot* holds max|t| (or an upper bound within a few binades) of a tensor t: eight device floats, `STRIDE` apart, whose
+maximum is the value (writers merge into the shard of their XCD; include/dadet.h).  Slots are columns of zero-filled
+[8][STRIDE] arrays.  The GEMM kernels read the operands' slots with scalar loads and derive the scales themselves; nothing
+here ever brings a maximum to the host.  Where slots come from:
 
 * the output of a GEMM: the kernel's own epilogue merges max|y| into a fresh slot (`dadet_conv_forward_scaled`), which
   `_C.conv_forward` attaches to the result as the Python attribute `_dadet_amax`.  The attribute belongs to the tensor
@@ -24,7 +25,8 @@ import torch
 
 from . import _lib
 
-_POOL_SLOTS = 1 << 16
+STRIDE = 1 << 16     # DADET_AMAX_STRIDE
+_POOL_SLOTS = STRIDE
 _pools = {}          # device index -> [tensor, next]
 MEASURED = 0         # dadet_amax launches issued by ptr() for activations (not weights)
 
@@ -38,7 +40,7 @@ def new_slot(device):
     idx = device.index if device.index is not None else torch.cuda.current_device()
     pool = _pools.get(idx)
     if pool is None or pool[1] >= _POOL_SLOTS:
-        t = torch.zeros(_POOL_SLOTS, dtype=torch.float32, device=device)
+        t = torch.zeros((8, STRIDE), dtype=torch.float32, device=device)
         # the fill is ordered on THIS stream only, and slots are handed to kernels on any stream
         torch.cuda.current_stream(device).synchronize()
         pool = _pools[idx] = [t, 0]
@@ -78,7 +80,7 @@ def value(t):
     s = slot_of(t)
     if s is None:
         return None
-    return float(s[1][(s[0] - s[1].data_ptr()) // 4])
+    return float(s[1].view(8, STRIDE)[:, (s[0] - s[1].data_ptr()) // 4].max())
 
 
 def measure(t):
@@ -114,14 +116,14 @@ class WeightSlots(object):
         idx = device.index if device.index is not None else torch.cuda.current_device()
         d = self.by_dev.get(idx)
         if d is None:
-            slots = torch.zeros(self.CAP, dtype=torch.float32, device=device)
+            slots = torch.zeros((8, STRIDE), dtype=torch.float32, device=device)
             torch.cuda.current_stream(device).synchronize()
             d = self.by_dev[idx] = dict(slots=slots, n=0, entries={}, table=None, epoch=-1)
         return d
 
     def _measure_one(self, d, e):
         # its own slot back to zero, then one pass: same stream, ordered
-        d["slots"][e["i"]:e["i"] + 1].zero_()
+        d["slots"][:, e["i"]].zero_()
         _lib.call("dadet_amax", ctypes.c_void_p(e["t"].data_ptr()), ctypes.c_longlong(e["t"].numel()),
                   ctypes.c_void_p(d["slots"].data_ptr() + 4 * e["i"]), _stream())
 
@@ -183,7 +185,7 @@ class WeightSlots(object):
                 blocks += it.blocks
             host = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).clone()
             d["table"] = (host.to(device), blocks, len(live), keys)
-        d["slots"].zero_()
+        d["slots"][:, :d["n"]].zero_()
         dev_t, blocks, n, _ = d["table"]
         _lib.call("dadet_amax_batch", ctypes.c_void_p(dev_t.data_ptr()), n, blocks, _stream())
         for e in live:

@@ -75,7 +75,7 @@ __device__ inline void split4(const float4 v, uint2 (&out)[TERMS]) {
 // What bf16 gave for free is range: fp16 spans 2^-24 .. 65504.  `s` is a power of two per TENSOR (exact to apply and to
 // undo) that brings the tensor's largest magnitude into [2^14, 2^15): nothing overflows, an element above 2^-16 of the
 // tensor's maximum keeps the full 2^-23 relative accuracy, and smaller ones (l falls into fp16's subnormals) an absolute
-// error below 2^-40 of the maximum.  The maximum comes from a device-side slot (fmt4_exp reads it with a scalar load):
+// error below 2^-40 of the maximum.  The maximum comes from a device-side slot (amax_read: scalar loads):
 // every producer in this library that can feed a GEMM leaves max|y| there (fused epilogues, dadet_amax otherwise).
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
@@ -110,15 +110,37 @@ __device__ __forceinline__ f32x16 mfma_32x32x16(const bf16x8 a, const bf16x8 b, 
     return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
 }
 
-// max|v| of a wavefront -> the tensor's slot (bits of a non-negative float order like unsigned integers).  Most waves
-// find the slot already at least as large and skip the atomic.
-__device__ inline void amax_publish(unsigned* slot, float m, const int lane) {
+// A slot is EIGHT words, DADET_AMAX_STRIDE floats apart (include/dadet.h): workgroup b merges into shard b % 8 (hardware
+// deals workgroups round-robin to the 8 XCDs), a reader takes the maximum of the eight.  One word takes ~12 ns per
+// device-scope atomic (MI355X_MICROARCH.md, "fanin"): the first version — one atomic per wavefront on one word — cost
+// the 128x128 GEMM 20 us per launch (2048 waves).  Here: one LDS reduction per workgroup, one check per workgroup of
+// the shard's current value (an sc1 load; the atomics drop the line from L2, so the next load sees them), and an atomic
+// only from a workgroup that would raise it — a few per shard and launch.
+constexpr int kAmaxStride = DADET_AMAX_STRIDE;
+__device__ inline float amax_read(const float* slot) {
+  float m = slot[0];
+#pragma unroll
+  for (int s = 1; s < 8; ++s) m = fmaxf(m, slot[s * kAmaxStride]);
+  return m;
+}
+// every thread of the workgroup calls this once (it contains barriers); m >= 0: max|v| of what the thread stored.
+// Bits of non-negative floats order like unsigned integers.
+__device__ inline void amax_publish(unsigned* slot, float m) {
+  __shared__ unsigned s_amax;
+  unsigned* shard = slot + (size_t)((blockIdx.x + blockIdx.y) & 7) * kAmaxStride;
+  unsigned seen = 0;
+  if (threadIdx.x == 0) {
+    s_amax = 0;
+    seen = __hip_atomic_load(shard, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);    // lands while the others reduce
+  }
 #pragma unroll
   for (int o = 32; o; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
-  if (lane == 0) {
-    const unsigned b = __builtin_bit_cast(unsigned, m);
-    if (b > __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
-      __hip_atomic_fetch_max(slot, b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) atomicMax(&s_amax, __builtin_bit_cast(unsigned, m));
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const unsigned b = s_amax;
+    if (b > seen) __hip_atomic_fetch_max(shard, b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
 }
 

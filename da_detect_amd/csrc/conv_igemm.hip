@@ -609,11 +609,11 @@ __global__ void splitk_reduce_kernel(const float4* __restrict__ partial, int spl
     y[i] = v;
     mx = fmaxf(fmaxf(mx, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
   }
-  if (amax_y) amax_publish(amax_y, mx, threadIdx.x & 63);
+  if (amax_y) amax_publish(amax_y, mx);
 }
 
 // max|x| over a tensor, merged into *slot (mode 4: a GEMM operand whose producer left no maximum).  Bits of non-negative
-// floats order like unsigned integers; one atomic per wavefront that would raise the slot.
+// floats order like unsigned integers; amax_publish: at most one atomic per workgroup, sharded by XCD.
 __global__ __launch_bounds__(256) void amax_kernel(const float* __restrict__ x, int64_t n, unsigned* __restrict__ slot) {
   float mx = 0.f;
   const int64_t n4 = n / 4;
@@ -623,7 +623,7 @@ __global__ __launch_bounds__(256) void amax_kernel(const float* __restrict__ x, 
     mx = fmaxf(fmaxf(mx, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
   }
   if (blockIdx.x == 0 && threadIdx.x < (unsigned)(n - n4 * 4)) mx = fmaxf(mx, fabsf(x[n4 * 4 + threadIdx.x]));
-  amax_publish(slot, mx, threadIdx.x & 63);
+  amax_publish(slot, mx);
 }
 
 // the same for many tensors in one launch (the weights of a model once per optimizer step): item i owns the workgroups
@@ -645,7 +645,7 @@ __global__ __launch_bounds__(256) void amax_batch_kernel(const dadet_amax_item* 
     mx = fmaxf(fmaxf(mx, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
   }
   if (b == 0 && threadIdx.x < (unsigned)(it.n - n4 * 4)) mx = fmaxf(mx, fabsf(x[n4 * 4 + threadIdx.x]));
-  amax_publish(reinterpret_cast<unsigned*>(it.slot), mx, threadIdx.x & 63);
+  amax_publish(reinterpret_cast<unsigned*>(it.slot), mx);
 }
 
 namespace {
@@ -698,8 +698,13 @@ unsigned* stream_amax_slots(hipStream_t st) {
   static std::unordered_map<hipStream_t, unsigned*> table;
   std::lock_guard<std::mutex> lock(m);
   unsigned*& p = table[st];
-  if (!p && hipMalloc(reinterpret_cast<void**>(&p), sizeof(unsigned) * 4) != hipSuccess) p = nullptr;
+  if (!p && hipMalloc(reinterpret_cast<void**>(&p), sizeof(unsigned) * (7 * (size_t)kAmaxStride + 4)) != hipSuccess)
+    p = nullptr;
   return p;
+}
+// zero the eight shards of `n` adjacent slots
+hipError_t zero_slots(unsigned* first, int n, hipStream_t st) {
+  return hipMemset2DAsync(first, sizeof(unsigned) * kAmaxStride, 0, sizeof(unsigned) * n, 8, st);
 }
 
 int launch_amax(const float* x, int64_t n, unsigned* slot, hipStream_t st) {
@@ -825,7 +830,7 @@ static int conv_forward_impl(const dadet_conv_desc* d, const float* x, const flo
     if (!amax_x || !amax_w) {
       unsigned* own = stream_amax_slots(st);
       if (!own) { set_error("conv_forward: could not allocate the operand-maximum slots"); return DADET_ELAUNCH; }
-      if (hipMemsetAsync(own, 0, sizeof(unsigned) * 2, st) != hipSuccess) return check_launch("conv_forward(amax memset)");
+      if (zero_slots(own, 2, st) != hipSuccess) return check_launch("conv_forward(amax memset)");
       if (!amax_x) {
         rc = launch_amax(x, (int64_t)(xb / 4), own, st);
         if (rc) return rc;
@@ -1012,7 +1017,7 @@ static int conv_wgrad_impl(const dadet_conv_desc* d, const float* x, const float
     if (!amax_x || !amax_gy) {
       unsigned* own = stream_amax_slots(st);
       if (!own) { set_error("conv_wgrad: could not allocate the operand-maximum slots"); return DADET_ELAUNCH; }
-      if (hipMemsetAsync(own + 2, 0, sizeof(unsigned) * 2, st) != hipSuccess) return check_launch("conv_wgrad(amax memset)");
+      if (zero_slots(own + 2, 2, st) != hipSuccess) return check_launch("conv_wgrad(amax memset)");
       if (!amax_x) {
         rc = launch_amax(x, (int64_t)(xb / 4), own + 2, st);
         if (rc) return rc;

@@ -130,7 +130,7 @@ __device__ __forceinline__ void conv_epilogue_v4(const ConvArgs& a, f32x16 (&acc
       __builtin_amdgcn_wave_barrier();                   // the tile is rewritten by the next block
     }
   }
-  if (a.amax_y) amax_publish(a.amax_y, mx, lane);
+  if (a.amax_y) amax_publish(a.amax_y, mx);
 }
 
 // fused epilogue of the forward / data-gradient GEMM (same as conv_igemm.hip): y = gate(acc * scale + bias + addend);
@@ -193,7 +193,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[T
       }
     }
   }
-  if (a.amax_y) amax_publish(a.amax_y, mx, lane);
+  if (a.amax_y) amax_publish(a.amax_y, mx);
 }
 
 // One output tile over the K range [k_lo, k_hi) (whole K-tiles).  sk = nullptr: the result goes through the epilogue.
@@ -214,8 +214,8 @@ __device__ __forceinline__ void conv_fwd_split_body(const ConvArgs& a, char* sme
   // mode 4: per-tensor power-of-two scales from the operands' maxima (scalar loads; see conv_common.h)
   int ea = 0, eb = 0;
   if (F16) {
-    ea = a.amax_x ? fmt4_exp(*a.amax_x) : 0;
-    eb = a.amax_w ? fmt4_exp(*a.amax_w) : 0;
+    ea = a.amax_x ? fmt4_exp(amax_read(a.amax_x)) : 0;
+    eb = a.amax_w ? fmt4_exp(amax_read(a.amax_w)) : 0;
   }
   const float sa = pow2f(ea), sb = pow2f(eb);
   constexpr int A_LOADS = BM / 32, B_LOADS = BN / 32;
@@ -644,8 +644,8 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_split_kernel(const WgradArg
   constexpr int TILE = 128, RK = 32;
   int eg = 0, ex = 0;   // mode 4: per-tensor power-of-two scales of gy and x
   if (F16) {
-    eg = a.amax_gy ? fmt4_exp(*a.amax_gy) : 0;
-    ex = a.amax_x ? fmt4_exp(*a.amax_x) : 0;
+    eg = a.amax_gy ? fmt4_exp(amax_read(a.amax_gy)) : 0;
+    ex = a.amax_x ? fmt4_exp(amax_read(a.amax_x)) : 0;
   }
   const float sg = pow2f(eg), sx = pow2f(ex);
   constexpr int PLANE = TILE * PLANE_STRIDE;

@@ -12,6 +12,7 @@ from torch.autograd import Function
 from torch.autograd.function import once_differentiable
 
 from .. import _C
+from .. import amax as _amax
 from ..utils.streams import WgradLane, bias_grad
 
 CL = torch.channels_last
@@ -97,8 +98,9 @@ def linear(x, weight, bias=None, relu=False):
     pad = (-out_f) % 4
     w = _pad_rows(weight, pad).view(out_f + pad, weight.shape[1], 1, 1)
     b = _pad_rows(bias, pad) if bias is not None else None
-    y = conv2d_affine_act(x.reshape(x.shape[0], x.shape[1], 1, 1), w, None, b, relu=relu)
-    y = y.view(y.shape[0], out_f + pad)
+    # (views are new tensor objects: the largest magnitude the producer attached is handed on by hand, amax.py)
+    y4 = conv2d_affine_act(_amax.carry(x.reshape(x.shape[0], x.shape[1], 1, 1), x), w, None, b, relu=relu)
+    y = _amax.carry(y4.view(y4.shape[0], out_f + pad), y4)
     return y[:, :out_f] if pad else y
 
 

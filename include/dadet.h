@@ -169,21 +169,25 @@ int dadet_conv_forward(const dadet_conv_desc* d, const float* x, const float* w,
 int dadet_set_gemm_mode(int mode);
 int dadet_get_gemm_mode(void);
 
-/* Largest magnitudes for mode 4.  A "slot" is one device float holding max|t| over a tensor t (an upper bound within a
- * few binades serves as well: it only has to keep t / slot inside fp16's range without wasting it).
- * dadet_amax merges max|x[0..n)| into *slot (atomic max: zero the slot first, or reuse one to cover several tensors).
+/* Largest magnitudes for mode 4.  A "slot" holds max|t| over a tensor t (an upper bound within a few binades serves as
+ * well: it only has to keep t / slot inside fp16's range without wasting it).  It is addressed by one pointer p and
+ * consists of EIGHT floats, p[0], p[S], ..., p[7 S] with S = DADET_AMAX_STRIDE: the value is the maximum of the eight
+ * (writers merge into the shard of their XCD, so that the chip's workgroups do not queue on one word).  Allocate slots as
+ * columns of a zero-filled [8][S] float array — column i is slot i, p = array + i.
+ * dadet_amax merges max|x[0..n)| into a slot (atomic max: zero the slot first, or reuse one to cover several tensors).
  * dadet_amax_batch does the same for n tensors in one launch; items_dev is device-resident, item k owns the workgroups
  * [first_block, first_block + blocks) of a grid of total_blocks. */
+#define DADET_AMAX_STRIDE 65536
 typedef struct dadet_amax_item {
   const void* x;           /* float[n], 16-byte aligned */
-  void* slot;              /* float */
+  void* slot;              /* a slot (see above) */
   long long n;
   int first_block, blocks;
 } dadet_amax_item;
 int dadet_amax(const float* x, long long n, float* slot, void* stream);
 int dadet_amax_batch(const dadet_amax_item* items_dev, int n, int total_blocks, void* stream);
 
-/* dadet_conv_forward with the operands' maxima handed over (amax_x, amax_w: device floats, NULL = measured here) and,
+/* dadet_conv_forward with the operands' maxima handed over (amax_x, amax_w: slots, NULL = measured here) and,
  * when amax_y is not NULL, max|y| of the values this call stores merged into *amax_y by the epilogue itself (zero it
  * first) — the next GEMM's amax_x.  Modes other than 4 ignore all three. */
 int dadet_conv_forward_scaled(const dadet_conv_desc* d, const float* x, const float* w, const float* scale,
