@@ -124,18 +124,19 @@ def cpu_baseline(cfg_path, seed, budget_s=90.0):
 
 
 def pmc_traffic(kernel_name, gemm_mode):
-    """HBM bytes per launch of `kernel_name` from the committed PMC passes (profiles/r04_pmc_hbm_traffic.json, made by
-    tools/profile_pmc.sh from this same bench command in mode 3; counters cannot be read from inside the process).
-    The 128x128-tile family is launched in two forms with the same tile body — conv_fwd_split_kernel<2,2,3> and, where
-    the tile grid leaves a partly empty last pass, conv_fwd_split_sk_kernel<3> (stream-K tail) — and the in-process
+    """HBM bytes per launch of `kernel_name` from the committed PMC passes (profiles/r04_pmc_hbm_traffic[_mode4].json,
+    made by tools/profile_pmc.sh from this same bench command in that mode; counters cannot be read from inside the
+    process).  The 128x128-tile family is launched in two forms with the same tile body — conv_fwd_split_kernel<2,2,M>
+    and, where the tile grid leaves a partly empty last pass, conv_fwd_split_sk_kernel<M> (stream-K tail) — and the in-process
     timer brackets both under one name: the figure is the launch-weighted mean over both.  None when the summary does
     not cover the kernel / mode."""
-    path = os.path.join(ROOT, "profiles", "r04_pmc_hbm_traffic.json")
-    if gemm_mode != 3 or not os.path.exists(path):
+    path = os.path.join(ROOT, "profiles", {3: "r04_pmc_hbm_traffic.json", 4: "r04_pmc_hbm_traffic_mode4.json"}.get(
+        gemm_mode, "none"))
+    if not os.path.exists(path):
         return None, None
     want = [kernel_name.replace(" ", "").rstrip(">")]      # "conv_fwd_split_kernel<2,2,3" also matches "...<2,2,3,0>"
-    if want[0].endswith("<2,2,3"):
-        want.append("conv_fwd_split_sk_kernel<3")
+    if want[0].endswith("<2,2,%d" % gemm_mode):
+        want.append("conv_fwd_split_sk_kernel<%d" % gemm_mode)
     with open(path) as f:
         table = json.load(f)["kernels"]
     launches = total = 0.0
@@ -409,7 +410,7 @@ def main():
     ap.add_argument("--other-steps", type=int, default=10)
     ap.add_argument("--image-hw", default=None, help="HxW of the synthetic images (default 1024x2048)")
     ap.add_argument("--no-overlap", action="store_true", help="keep the RPN backward inside the main backward pass")
-    ap.add_argument("--gemm-mode", type=int, default=int(os.environ.get("DADET_GEMM_MODE", "3")),
+    ap.add_argument("--gemm-mode", type=int, default=int(os.environ.get("DADET_GEMM_MODE", "4")),
                     help="3: fp32 operands as 3 bf16 terms, 6 bf16 MFMAs per K=16 (fp32-class accuracy, default); "
                          "0: exact fp32 MFMA; 2: 2-term split (~2^-16 products)")
     args = ap.parse_args()
@@ -441,7 +442,8 @@ def main():
     _C.set_gemm_mode(args.gemm_mode)
     desc, mfma_per_product = GEMM_MODES[args.gemm_mode]
     # peak for ALGORITHMIC flops: the fp32 pipe's peak in mode 0; in the split modes every fp32 product
-    # costs `mfma_per_product` bf16 MFMAs, so the algorithmic ceiling is the bf16 dense peak divided by it
+    # costs `mfma_per_product` bf16 / fp16 MFMAs (both 2.5 PFLOP/s dense), so the algorithmic ceiling is that peak divided
+    # by it: 833.3 TFLOP/s in mode 4 (three fp16 MFMAs), 416.7 in mode 3 (six bf16 MFMAs)
     peak = FP32_MFMA_PEAK_TFLOPS if args.gemm_mode == 0 else BF16_MFMA_PEAK_TFLOPS / mfma_per_product
 
     r = run_workload(args, args.workload, device, rank, world, args.steps, args.warmup, headline=True)
@@ -513,8 +515,8 @@ def main():
             k = kernels[name]
             achieved = k["achieved"] / 1e12
             traffic, traffic_src = pmc_traffic(name, args.gemm_mode)
-            shown = name + (" (+ its stream-K launch form conv_fwd_split_sk_kernel<3>, same tile body)"
-                            if name.endswith("<2,2,3>") else "")
+            shown = name + (" (+ its stream-K launch form conv_fwd_split_sk_kernel<%d>, same tile body)" % args.gemm_mode
+                            if name.endswith("<2,2,%d>" % args.gemm_mode) else "")
             roofline = {"bound": "mfma", "kernel": shown, "achieved": round(achieved, 2),
                         "peak": round(peak, 1), "unit": "TFLOP/s",
                         "frac": round(achieved / peak, 4), "traffic": traffic, "traffic_unit": "HBM bytes/launch",

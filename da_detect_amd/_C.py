@@ -364,7 +364,7 @@ def conv_forward(x, w, scale=None, bias=None, addend=None, mask_ref=None, stride
             variant = _lib.load().dadet_conv_forward_variant(ctypes.byref(d))
             mode = get_gemm_mode()
             if variant == 3:
-                kname = "conv1x1_ws_kernel<%d,%d>" % (Cin, 64 if Cin == 256 else 128)
+                kname = "conv1x1_ws_kernel<%d,%d,%d>" % (Cin, 64 if Cin == 256 else 128, mode)
             else:
                 kname = ("conv_fwd_kernel<%s>" if mode == 0 else ("conv_fwd_split_kernel<%%s,%d>" % mode)) % \
                     ("2,2", "2,1", "1,1")[variant]
@@ -802,11 +802,19 @@ def da_img_head_loss_backward_g(t, w2, logits, labels, g_bce, g_mean_sig, w_adv,
     acc = torch.zeros(C1 + 1, dtype=torch.float32, device=t.device)       # one zero fill for both sums
     g_w2, g_b2 = acc[:C1], acc[C1:]
     adv_dev = w_adv if isinstance(w_adv, torch.Tensor) else None
-    _lib.call("dadet_da_img_head_loss_backward_g", _p(t), _p(w2), _p(logits), _p(labels), _p(g_bce.contiguous()),
+    # contraction mode 4: the two maps feed GEMMs; the kernel leaves their largest magnitudes in fresh slots
+    sw = _amax.new_slot(t.device) if _mode4() else None
+    sx = _amax.new_slot(t.device) if (sw is not None and need_x) else None
+    _lib.call("dadet_da_img_head_loss_backward_gm", _p(t), _p(w2), _p(logits), _p(labels), _p(g_bce.contiguous()),
               _p(g_mean_sig.contiguous()) if g_mean_sig is not None else None,
               _p(adv_dev.reshape(1).to(torch.float32)) if adv_dev is not None else None,
               0.0 if adv_dev is not None else float(w_adv), float(w_cst), _p(g_t_w), _p(g_t_x), _p(g_w2), _p(g_b2),
-              num_images, rows_per_image, C1, _stream())
+              num_images, rows_per_image, C1, ctypes.c_void_p(sw[0]) if sw else None,
+              ctypes.c_void_p(sx[0]) if sx else None, _stream())
+    if sw:
+        _amax.attach(g_t_w, sw)
+    if sx:
+        _amax.attach(g_t_x, sx)
     return g_t_w, g_t_x, g_w2, g_b2
 
 

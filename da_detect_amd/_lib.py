@@ -12,7 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # DADET_LIB: another build of the same library (A/B runs of build-time switches on one box)
 LIB_PATH = os.environ.get("DADET_LIB") or os.path.join(_HERE, "libdadet_hip.so")
 _lib = None
-DEFAULT_GEMM_MODE = "3"
+DEFAULT_GEMM_MODE = "4"
 
 
 class ConvDesc(ctypes.Structure):
@@ -152,6 +152,8 @@ _SIGNATURES = {
     "dadet_da_img_head_loss_backward": [_P, _P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, _P],
     "dadet_da_img_head_loss_backward_g": [_P, _P, _P, _P, _P, _P, _P, c_float, c_float, _P, _P, _P, _P, c_int, c_int, c_int,
                                           _P],
+    "dadet_da_img_head_loss_backward_gm": [_P, _P, _P, _P, _P, _P, _P, c_float, c_float, _P, _P, _P, _P, c_int, c_int, c_int,
+                                          _P, _P, _P],
     "dadet_da_ins_tail_forward": [_P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P],
     "dadet_da_ins_tail_backward": [_P, _P, _P, _P, _P, _P, c_float, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P],
     "dadet_da_ins_dropout_rows": [_P, _P, _P, c_int64, c_int, _P],

@@ -12,7 +12,8 @@ here ever brings a maximum to the host.  Where slots come from:
   bumps `_version`, which invalidates it — a stale maximum cannot be picked up by construction;
 * tensors written by other kernels of this library: `carry(dst, src)` where max|dst| <= max|src| by the operation's
   nature (max-pooling, ROIAlign, average pooling, gathers, ReLU gates) — a bound, not a measurement;
-* anything else: `ptr(t)` measures it (`dadet_amax`, one pass over t) the first time a GEMM asks;
+* views of a tensor that carries a slot use it (`ptr`); anything else is measured (`dadet_amax`, one pass over t) the
+  first time a GEMM asks;
 * parameters and the cached transposed weights of the data-gradient GEMMs: slots in a persistent per-device array, all
   re-measured by ONE launch per weight epoch (`WeightSlots.refresh`, called where the transposed weights are refreshed:
   behind the optimizer step).
@@ -20,6 +21,7 @@ here ever brings a maximum to the host.  Where slots come from:
 `MEASURED` counts the one-pass measurements (tools / tests read it to see which producers still lack a fused maximum).
 """
 import ctypes
+import weakref
 
 import torch
 
@@ -94,23 +96,31 @@ def measure(t):
 
 
 def ptr(t):
-    """address of the slot of t as a ctypes pointer; measures t when it carries none"""
+    """address of the slot of t as a ctypes pointer.  A view (reshape, slice, permute ...) of a tensor that carries a slot
+    uses its base's — a subset of the values under the same bound, and view and base share one version counter; anything
+    else without a valid slot is measured."""
     a = t.__dict__.get("_dadet_amax")
     if a is None or a[2] != t._version:
-        measure(t)
-        a = t.__dict__["_dadet_amax"]
+        base = t._base
+        ab = base.__dict__.get("_dadet_amax") if base is not None else None
+        if ab is not None and ab[2] == base._version:
+            a = t._dadet_amax = (ab[0], ab[1], t._version)
+        else:
+            measure(t)
+            a = t.__dict__["_dadet_amax"]
     return ctypes.c_void_p(a[0])
 
 
 class WeightSlots(object):
     """Slots of tensors that persist across steps and change once per step: parameters (updated in place by the fused
     optimizer through raw pointers — no version bump, hence the explicit epoch) and the transposed-weight buffers of the
-    data-gradient GEMMs.  Keyed by (address, numel); an entry keeps its tensor alive."""
+    data-gradient GEMMs.  Keyed by (address, numel).  An entry holds a WEAK reference to the tensor that owns the storage
+    (the parameter itself for a view of one): when a model is gone its entries are swept and their slots reused."""
 
     CAP = 4096
 
     def __init__(self):
-        self.by_dev = {}      # device index -> dict(slots=tensor, n=int, entries={key: entry}, table=None, epoch=int)
+        self.by_dev = {}      # device index -> dict(slots=tensor, free=[...], entries={key: entry}, table=None, epoch=int)
 
     def _dev(self, device):
         idx = device.index if device.index is not None else torch.cuda.current_device()
@@ -118,33 +128,54 @@ class WeightSlots(object):
         if d is None:
             slots = torch.zeros((8, STRIDE), dtype=torch.float32, device=device)
             torch.cuda.current_stream(device).synchronize()
-            d = self.by_dev[idx] = dict(slots=slots, n=0, entries={}, table=None, epoch=-1)
+            d = self.by_dev[idx] = dict(slots=slots, free=list(range(self.CAP - 1, -1, -1)), entries={}, table=None,
+                                        epoch=-1)
         return d
+
+    @staticmethod
+    def _alive(e):
+        o = e["ref"]()
+        return o is not None and o._version == e["version"]
+
+    def _sweep(self, d, epoch):
+        """forget entries whose owner is gone, or that nobody asked about during the last two epochs"""
+        dead = [k for k, e in d["entries"].items() if e["ref"]() is None or e["used"] < epoch - 2]
+        for k in dead:
+            d["free"].append(d["entries"].pop(k)["i"])
+        if dead:
+            d["table"] = None
 
     def _measure_one(self, d, e):
         # its own slot back to zero, then one pass: same stream, ordered
         d["slots"][:, e["i"]].zero_()
-        _lib.call("dadet_amax", ctypes.c_void_p(e["t"].data_ptr()), ctypes.c_longlong(e["t"].numel()),
+        _lib.call("dadet_amax", ctypes.c_void_p(e["ptr"]), ctypes.c_longlong(e["n"]),
                   ctypes.c_void_p(d["slots"].data_ptr() + 4 * e["i"]), _stream())
 
     def ptr(self, t, epoch):
         d = self._dev(t.device)
         key = (t.data_ptr(), t.numel())
         e = d["entries"].get(key)
+        owner = t._base if t._base is not None else t
+        if e is not None and e["ref"]() is not owner:        # the address went to another tensor
+            d["free"].append(d["entries"].pop(key)["i"])
+            d["table"] = None
+            e = None
         if e is None:
-            if d["n"] >= self.CAP:
-                raise _lib.DadetError("amax: more than %d persistent GEMM operands registered" % self.CAP)
-            e = d["entries"][key] = dict(t=t, i=d["n"], version=t._version, epoch=epoch, used=epoch)
-            d["n"] += 1
+            if not d["free"]:
+                self._sweep(d, epoch)
+            if not d["free"]:
+                raise _lib.DadetError("amax: more than %d persistent GEMM operands alive" % self.CAP)
+            e = d["entries"][key] = dict(ref=weakref.ref(owner), ptr=key[0], n=key[1], i=d["free"].pop(),
+                                         version=owner._version, epoch=epoch, used=epoch)
             d["table"] = None
             self._measure_one(d, e)
         else:
             e["used"] = epoch
-            if e["version"] != t._version or e["epoch"] != epoch:
-                if e["version"] == t._version and d["epoch"] != epoch:
+            if e["version"] != owner._version or e["epoch"] != epoch:
+                if e["version"] == owner._version and d["epoch"] != epoch:
                     self.refresh(t.device, epoch, sync=True)
-                if e["version"] != t._version or e["epoch"] != epoch:
-                    e["t"], e["version"], e["epoch"] = t, t._version, epoch
+                if e["version"] != owner._version or e["epoch"] != epoch:
+                    e["version"], e["epoch"] = owner._version, epoch
                     self._measure_one(d, e)
         return ctypes.c_void_p(d["slots"].data_ptr() + 4 * e["i"])
 
@@ -162,30 +193,24 @@ class WeightSlots(object):
             torch.cuda.synchronize(device)
         d = self._dev(device)
         d["epoch"] = epoch
-        # tensors nobody asked about during the last two epochs belong to a model that is gone
-        stale = [k for k, e in d["entries"].items() if e["used"] < epoch - 2]
-        if stale:
-            # their slot indices are not reused (the array is large); just forget them
-            for k in stale:
-                del d["entries"][k]
-            d["table"] = None
-        live = [e for e in d["entries"].values() if e["version"] == e["t"]._version]
+        self._sweep(d, epoch)
+        live = [e for e in d["entries"].values() if self._alive(e)]
         if not live:
             return
-        keys = [e["i"] for e in live]
+        keys = [(e["i"], e["ptr"], e["n"]) for e in live]
         if d["table"] is None or d["table"][3] != keys:
             arr = (_lib.AmaxItem * len(live))()
             blocks = 0
             for k, e in enumerate(live):
                 it = arr[k]
-                n = e["t"].numel()
-                it.x, it.slot, it.n = e["t"].data_ptr(), d["slots"].data_ptr() + 4 * e["i"], n
+                n = e["n"]
+                it.x, it.slot, it.n = e["ptr"], d["slots"].data_ptr() + 4 * e["i"], n
                 it.first_block = blocks
-                it.blocks = max(1, min(64, (n // 4 + 1023) // 1024))
+                it.blocks = max(1, min(512, (n // 4 + 511) // 512))     # two float4 per thread and pass
                 blocks += it.blocks
             host = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).clone()
             d["table"] = (host.to(device), blocks, len(live), keys)
-        d["slots"][:, :d["n"]].zero_()
+        d["slots"][:, :self.CAP].zero_()
         dev_t, blocks, n, _ = d["table"]
         _lib.call("dadet_amax_batch", ctypes.c_void_p(dev_t.data_ptr()), n, blocks, _stream())
         for e in live:

@@ -89,14 +89,31 @@ __device__ inline int fmt4_exp(const float amax) {
 }
 __device__ inline float pow2f(const int e) { return __builtin_bit_cast(float, (unsigned)(e + 127) << 23); }
 
-// split four consecutive-k floats, scaled by s, into the two fp16 planes (8 bytes each)
+// split four consecutive-k floats, scaled by s, into the two fp16 planes (8 bytes each).  Inline assembly for two reasons:
+// v_fma_mix_f32 forms the residual x * s - h straight from the packed half (one instruction instead of a conversion and
+// a subtraction; x * s is exact, so the single rounding is the subtraction's), and written as plain conversions the
+// whole split was SUNK by hipcc out of the K loop's MFMA blocks into the block between the two barriers (seen in the
+// ISA: 64 conversions serialised behind the MFMAs, the GEMM 40% slower on all-zero operands than the bf16 two-term form).
+__device__ inline unsigned pack_f16(float lo, float hi) {
+  unsigned r;
+  asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
+  return r;
+}
+__device__ inline float resid_lo(float x, float s, unsigned h) {   // x * s - (low half of h)
+  float r;
+  asm("v_fma_mix_f32 %0, %1, %2, -%3 op_sel_hi:[0,0,1]" : "=v"(r) : "v"(x), "v"(s), "v"(h));
+  return r;
+}
+__device__ inline float resid_hi(float x, float s, unsigned h) {   // x * s - (high half of h)
+  float r;
+  asm("v_fma_mix_f32 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "=v"(r) : "v"(x), "v"(s), "v"(h));
+  return r;
+}
 __device__ inline void split4h(const float4 v, const float s, uint2 (&out)[2]) {
-  const float a = v.x * s, b = v.y * s, c = v.z * s, d = v.w * s;
-  const f16x2 h0 = {(_Float16)a, (_Float16)b}, h1 = {(_Float16)c, (_Float16)d};
-  const float ra = a - (float)h0.x, rb = b - (float)h0.y, rc = c - (float)h1.x, rd = d - (float)h1.y;
-  const f16x2 l0 = {(_Float16)ra, (_Float16)rb}, l1 = {(_Float16)rc, (_Float16)rd};
-  out[0] = make_uint2(__builtin_bit_cast(unsigned, h0), __builtin_bit_cast(unsigned, h1));
-  out[1] = make_uint2(__builtin_bit_cast(unsigned, l0), __builtin_bit_cast(unsigned, l1));
+  const unsigned h0 = pack_f16(v.x * s, v.y * s), h1 = pack_f16(v.z * s, v.w * s);
+  out[0] = make_uint2(h0, h1);
+  out[1] = make_uint2(pack_f16(resid_lo(v.x, s, h0), resid_hi(v.y, s, h0)),
+                      pack_f16(resid_lo(v.z, s, h1), resid_hi(v.w, s, h1)));
 }
 
 // FMT (template parameter of the split kernels): 3 / 2 = three / two bf16 terms, 4 = two fp16 terms
@@ -221,6 +238,6 @@ int launch_fwd_split_sk(ConvArgs& a, int fmt, hipStream_t st);
 int launch_wgrad_split(WgradArgs& a, int fmt, hipStream_t st);
 // weight-stationary 1x1 kernel for K = 64 / 128 / 256 (conv_ws.hip)
 bool ws_eligible(const ConvArgs& a);
-int launch_fwd_ws(ConvArgs& a, hipStream_t st);
+int launch_fwd_ws(ConvArgs& a, int fmt, hipStream_t st);
 
 }  // namespace dadet

@@ -845,7 +845,7 @@ static int conv_forward_impl(const dadet_conv_desc* d, const float* x, const flo
     a.amax_x = amax_x; a.amax_w = amax_w;
     a.amax_y = reinterpret_cast<unsigned*>(amax_y);
   }   // (the other modes neither read nor leave maxima)
-  if (gemm_mode() == 3 && ws_eligible(a)) return launch_fwd_ws(a, st);     // weight-stationary 1x1, K <= 256 (conv_ws.hip)
+  if (gemm_mode() >= 3 && ws_eligible(a)) return launch_fwd_ws(a, gemm_mode(), st);   // weight-stationary 1x1, K <= 256
   if (gemm_mode() != 0) {
     const int variant = split_fwd_variant(a.M, a.Cout, a.K);
     SkPlan sk;
@@ -916,7 +916,7 @@ extern "C" int dadet_conv_forward_scaled(const dadet_conv_desc* d, const float* 
 extern "C" int dadet_conv_forward_variant(const dadet_conv_desc* d) {
   if (!d) return -1;
   const int M = d->N * d->Ho * d->Wo;
-  if (gemm_mode() == 3) {      // 3: the weight-stationary 1x1 kernel (assuming 16-byte aligned tensors, as torch allocates them)
+  if (gemm_mode() >= 3) {      // 3: the weight-stationary 1x1 kernel (assuming 16-byte aligned tensors, as torch allocates them)
     ConvArgs a;
     a.KH = d->KH; a.KW = d->KW; a.pad = d->pad; a.os = d->out_spatial_stride > 0 ? d->out_spatial_stride : 1;
     a.ksplit = 0; a.K = d->KH * d->KW * d->Cin; a.Cout = d->Cout; a.M = M;

@@ -19,7 +19,7 @@
 
 namespace dadet {
 
-static int g_gemm_mode = 3;
+static int g_gemm_mode = 4;
 int gemm_mode() { return g_gemm_mode; }
 
 // AB: stage-ablation mask for profiling experiments (tools/ablate.py).  It is a COMPILE-TIME parameter: as run-time

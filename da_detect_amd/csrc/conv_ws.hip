@@ -40,8 +40,12 @@ __device__ __forceinline__ void ws_unroll(F&& f) {
   }
 }
 
-template <int K, int BN>
+// FMT 3: three bf16 term planes, six MFMAs per k16 step; FMT 4: two fp16 term planes under the per-tensor scales, three
+// MFMAs (conv_common.h) — the panel is a third smaller, an activation element costs 3 VALU operations instead of ~4.8
+template <int K, int BN, int FMT>
 __global__ __launch_bounds__(512, 1) void conv1x1_ws_kernel(const ConvArgs a) {
+  constexpr int T = Fmt<FMT>::terms;
+  constexpr bool F16 = Fmt<FMT>::f16;
   constexpr int NB = BN / 32;               // 32-column blocks per wave
   constexpr int STRIDE = K + 8;             // bf16 per weight row in LDS: (2K + 16) bytes = 4 banks mod 64 -> conflict-free b128 reads
   constexpr int PLANE = BN * STRIDE;
@@ -56,11 +60,19 @@ __global__ __launch_bounds__(512, 1) void conv1x1_ws_kernel(const ConvArgs a) {
   constexpr bool EARLY = NB == 2;           // residual / gate loads of a slab issued in the middle of its contraction
 
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  __bf16* Bs = reinterpret_cast<__bf16*>(smem);                      // [3][BN][STRIDE]
+  __bf16* Bs = reinterpret_cast<__bf16*>(smem);                      // [T][BN][STRIDE]
   const int t = threadIdx.x;
   const int lane = t & 63, wave = t >> 6;
-  float* tile = reinterpret_cast<float*>(smem + 3 * PLANE * 2) + wave * (32 * EPI_STRIDE);
-  float* s_affine = reinterpret_cast<float*>(smem + 3 * PLANE * 2) + 8 * (32 * EPI_STRIDE);   // [BN] scale, [BN] bias
+  float* tile = reinterpret_cast<float*>(smem + T * PLANE * 2) + wave * (32 * EPI_STRIDE);
+  float* s_affine = reinterpret_cast<float*>(smem + T * PLANE * 2) + 8 * (32 * EPI_STRIDE);   // [BN] scale, [BN] bias
+  int ea = 0, eb = 0;                       // FMT 4: exponents of the operands' power-of-two scales
+  if (F16) {
+    ea = a.amax_x ? fmt4_exp(amax_read(a.amax_x)) : 0;
+    eb = a.amax_w ? fmt4_exp(amax_read(a.amax_w)) : 0;
+  }
+  const float sa = pow2f(ea), sb = pow2f(eb);
+  const float u1 = pow2f(-(ea + eb) / 2), u2 = pow2f(-(ea + eb) - (-(ea + eb)) / 2);   // undo both, in two exact steps
+  float mx = 0.f;                           // max|y| of what this lane stores (a.amax_y)
 
   // hardware deals workgroup b to XCD b % 8: the `panels` workgroups of one row group sit on ONE XCD, so the activation
   // rows they all read come through one L2
@@ -107,10 +119,11 @@ __global__ __launch_bounds__(512, 1) void conv1x1_ws_kernel(const ConvArgs a) {
     for (int i = 0; i < PER; ++i) {
       const int idx = t + i * 512;
       const int n = idx / Q, kq = idx - n * Q;
-      uint2 p[3];
-      split4<3>(wv[i], p);
+      uint2 p[T];
+      if constexpr (F16) split4h(wv[i], sb, p);
+      else split4<T>(wv[i], p);
 #pragma unroll
-      for (int pl = 0; pl < 3; ++pl) *reinterpret_cast<uint2*>(Bs + pl * PLANE + n * STRIDE + kq * 4) = p[pl];
+      for (int pl = 0; pl < T; ++pl) *reinterpret_cast<uint2*>(Bs + pl * PLANE + n * STRIDE + kq * 4) = p[pl];
     }
   }
   if (t < BN) {
@@ -134,16 +147,21 @@ __global__ __launch_bounds__(512, 1) void conv1x1_ws_kernel(const ConvArgs a) {
 #pragma unroll
     for (int e = 0; e < 16; ++e) acc[nb][e] = 0.f;
 
-  // term planes of one k16 step of this lane's row: 8 floats -> 3 x 8 bf16
-  auto split8 = [&](const float4 lo, const float4 hi, bf16x8 (&out)[3]) __attribute__((always_inline)) {
-    uint2 pl[3], ph[3];
-    split4<3>(lo, pl);
-    split4<3>(hi, ph);
+  // term planes of one k16 step of this lane's row: 8 floats -> T x 8 bf16 / fp16
+  auto split8 = [&](const float4 lo, const float4 hi, bf16x8 (&out)[T]) __attribute__((always_inline)) {
+    uint2 pl[T], ph[T];
+    if constexpr (F16) {
+      split4h(lo, sa, pl);
+      split4h(hi, sa, ph);
+    } else {
+      split4<T>(lo, pl);
+      split4<T>(hi, ph);
+    }
 #pragma unroll
-    for (int p = 0; p < 3; ++p) out[p] = __builtin_bit_cast(bf16x8, make_uint4(pl[p].x, pl[p].y, ph[p].x, ph[p].y));
+    for (int p = 0; p < T; ++p) out[p] = __builtin_bit_cast(bf16x8, make_uint4(pl[p].x, pl[p].y, ph[p].x, ph[p].y));
   };
   const __bf16* Bb = Bs + frow * STRIDE + fh * 16;
-  bf16x8 pa[3];                             // planes of the NEXT step to be multiplied (carried across buffers / slabs)
+  bf16x8 pa[T];                             // planes of the NEXT step to be multiplied (carried across buffers / slabs)
 
   // One k16 step: chunk position q of the iteration (slot q & 3), half s.  The planes of the NEXT step are formed (VALU)
   // in the shadow of this step's MFMAs; in the second half of a chunk the slot is free (both its halves are split) and the
@@ -157,30 +175,30 @@ __global__ __launch_bounds__(512, 1) void conv1x1_ws_kernel(const ConvArgs a) {
 #pragma unroll
       for (int v = 0; v < 4; ++v) raw[slot][v] = buf_load4(xr, o + (unsigned)((qa % CH) * 128 + v * 16));
     }
-    bf16x8 fb[3][NB];
+    bf16x8 fb[T][NB];
 #pragma unroll
-    for (int p = 0; p < 3; ++p)
+    for (int p = 0; p < T; ++p)
 #pragma unroll
       for (int nb = 0; nb < NB; ++nb)
         fb[p][nb] = *reinterpret_cast<const bf16x8*>(Bb + p * PLANE + nb * 32 * STRIDE + c * 32 + sidx * 8);
-    bf16x8 pn[3];
+    bf16x8 pn[T];
     if (sidx == 0) split8(raw[slot][2], raw[slot][3], pn);
     else split8(raw[(q + 1) & 3][0], raw[(q + 1) & 3][1], pn);
     // smallest cross terms first, the leading a0*b0 last (the tiled kernel's order)
 #pragma unroll
-    for (int order = 4; order >= 0; --order)
+    for (int order = 2 * (T - 1); order >= 0; --order)
 #pragma unroll
-      for (int x = 0; x < 3; ++x) {
+      for (int x = 0; x < T; ++x) {
         const int y = order - x;
-        if (y < 0 || y >= 3 || x + y > 2) continue;
+        if (y < 0 || y >= T || x + y > T - 1) continue;
 #pragma unroll
-        for (int nb = 0; nb < NB; ++nb) acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa[x], fb[y][nb], acc[nb], 0, 0, 0);
+        for (int nb = 0; nb < NB; ++nb) acc[nb] = mfma_32x32x16<F16>(pa[x], fb[y][nb], acc[nb]);
       }
     {
-      constexpr int kMfma = 6 * NB;
-      constexpr int kValuPerMfma = 56 / kMfma + 1;
+      constexpr int kMfma = (T == 3 ? 6 : 3) * NB;
+      constexpr int kValuPerMfma = (T == 3 ? 56 : 28) / kMfma + 1;
       if (sidx == 1) __builtin_amdgcn_sched_group_barrier(0x020, 4, 0);    // the slot's refill first
-      __builtin_amdgcn_sched_group_barrier(0x100, 3 * NB, 0);              // DS reads
+      __builtin_amdgcn_sched_group_barrier(0x100, T * NB, 0);              // DS reads
 #pragma unroll
       for (int m = 0; m < kMfma; ++m) {
         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                 // one MFMA
@@ -188,7 +206,7 @@ __global__ __launch_bounds__(512, 1) void conv1x1_ws_kernel(const ConvArgs a) {
       }
     }
 #pragma unroll
-    for (int p = 0; p < 3; ++p) pa[p] = pn[p];
+    for (int p = 0; p < T; ++p) pa[p] = pn[p];
     // a step is one scheduling region: without this fence the slot refills of the second half of a slab (same base
     // register: the NEXT slab's row) were clustered behind the slab's last MFMA, i.e. not prefetched at all
     __builtin_amdgcn_sched_barrier(0);
@@ -243,7 +261,8 @@ __global__ __launch_bounds__(512, 1) void conv1x1_ws_kernel(const ConvArgs a) {
 #pragma unroll
       for (int g = 0; g < 4; ++g)
 #pragma unroll
-        for (int q = 0; q < 4; ++q) tile[(q + 8 * g + row_hi) * EPI_STRIDE + col_in] = acc[nb0 + e][g * 4 + q];
+        for (int q = 0; q < 4; ++q)
+          tile[(q + 8 * g + row_hi) * EPI_STRIDE + col_in] = F16 ? acc[nb0 + e][g * 4 + q] * u1 * u2 : acc[nb0 + e][g * 4 + q];
       __builtin_amdgcn_s_waitcnt(0xc07f);                // lgkmcnt(0): a wave's own LDS traffic is ordered
       __builtin_amdgcn_wave_barrier();
 #pragma unroll
@@ -272,6 +291,8 @@ __global__ __launch_bounds__(512, 1) void conv1x1_ws_kernel(const ConvArgs a) {
         }
         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, make_float4(v[0], v[1], v[2], v[3])), yr,
                                                (int)offs[e][pass], 0, 0);
+        if (F16 && a.amax_y && offs[e][pass] != kOOB)
+          mx = fmaxf(fmaxf(mx, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
       }
       __builtin_amdgcn_wave_barrier();                   // the slice is rewritten by the next block
     }
@@ -308,10 +329,11 @@ __global__ __launch_bounds__(512, 1) void conv1x1_ws_kernel(const ConvArgs a) {
       if ((q + 1) % CH == 0) epilogue(tl + (q / CH) * G);   // a slab past the end (K = 64, odd slab count) stores nothing
     });
   }
+  if (F16 && a.amax_y) amax_publish(a.amax_y, mx);          // once per workgroup: it walked all of its slabs
 }
 
-// panel width per K: the three planes of BN x (K + 8) bf16 plus the epilogue slices (40 KB) must fit 160 KB
-static int ws_bn(int K) { return K == 256 ? 64 : 128; }
+// panel width per K: the three (FMT 4: two) planes of BN x (K + 8) 16-bit terms plus the epilogue slices (40 KB) must
+// fit 160 KB: 128 columns for K = 64 / 128, 64 for K = 256
 
 bool ws_eligible(const ConvArgs& a) {
   const char* env = getenv("DADET_WS_1X1");           // read per call: the tests and A/B runs flip it at run time
@@ -325,12 +347,12 @@ bool ws_eligible(const ConvArgs& a) {
   return true;
 }
 
-template <int K, int BN>
+template <int K, int BN, int FMT>
 static int launch_ws(ConvArgs& a, hipStream_t st) {
-  const size_t lds = (size_t)3 * BN * (K + 8) * 2 + 8 * 32 * EPI_STRIDE * 4 + 2 * BN * 4;
+  const size_t lds = (size_t)Fmt<FMT>::terms * BN * (K + 8) * 2 + 8 * 32 * EPI_STRIDE * 4 + 2 * BN * 4;
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv1x1_ws_kernel<K, BN>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv1x1_ws_kernel<K, BN, FMT>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) {
       set_error("conv_forward(weight-stationary 1x1): hipFuncSetAttribute: %s", hipGetErrorString(e));
@@ -345,15 +367,22 @@ static int launch_ws(ConvArgs& a, hipStream_t st) {
   if (G < 8) G = 8;
   const int need = ceil_div(a.tiles_m, 8) * 8;
   if (G > need) G = need;
-  hipLaunchKernelGGL((conv1x1_ws_kernel<K, BN>), dim3(a.tiles_n * G), dim3(512), lds, st, a);
+  hipLaunchKernelGGL((conv1x1_ws_kernel<K, BN, FMT>), dim3(a.tiles_n * G), dim3(512), lds, st, a);
   return check_launch("conv_forward(weight-stationary 1x1)");
 }
 
-int launch_fwd_ws(ConvArgs& a, hipStream_t st) {
+int launch_fwd_ws(ConvArgs& a, int fmt, hipStream_t st) {
+  if (fmt == 4) {
+    switch (a.K) {
+      case 64: return launch_ws<64, 128, 4>(a, st);
+      case 128: return launch_ws<128, 128, 4>(a, st);
+      default: return launch_ws<256, 64, 4>(a, st);
+    }
+  }
   switch (a.K) {
-    case 64: return launch_ws<64, 128>(a, st);
-    case 128: return launch_ws<128, 128>(a, st);
-    default: return launch_ws<256, 64>(a, st);
+    case 64: return launch_ws<64, 128, 3>(a, st);
+    case 128: return launch_ws<128, 128, 3>(a, st);
+    default: return launch_ws<256, 64, 3>(a, st);
   }
 }
 

@@ -19,7 +19,7 @@
 // The 1024->512 1x1 conv (the FLOPs) runs on the MFMA implicit-GEMM kernel with its bias+ReLU epilogue; the
 // kernels here consume its output t[M][C1] one wavefront per row: 64 lanes x float4 along the channel
 // axis, DPP/shuffle wave reduction, one atomic per wavefront for the loss sums.
-#include "common.h"
+#include "conv_common.h"   // amax_publish (contraction mode 4)
 
 namespace dadet {
 
@@ -109,7 +109,8 @@ __global__ __launch_bounds__(256) void da_img_bwd_kernel(
     const float* __restrict__ labels, const float* __restrict__ coef, float* __restrict__ g_t_w,
     float* __restrict__ g_t_x, float* __restrict__ g_w2, float* __restrict__ g_b2, int num_images,
     int rows_per_image, int C1, const float* __restrict__ g_bce, const float* __restrict__ g_sig,
-    const float* __restrict__ w_adv_dev, float w_adv, float w_cst) {
+    const float* __restrict__ w_adv_dev, float w_adv, float w_cst, unsigned* __restrict__ amax_w,
+    unsigned* __restrict__ amax_x) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float* s_w2g = reinterpret_cast<float*>(smem);  // [C1] workgroup partial of g_w2
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -122,6 +123,7 @@ __global__ __launch_bounds__(256) void da_img_bwd_kernel(
 #pragma unroll
   for (int k = 0; k < 4; ++k) wacc[k] = make_float4(0.f, 0.f, 0.f, 0.f);
   float bacc = 0.f;
+  float mw = 0.f, mxx = 0.f;    // contraction mode 4: max|g_t_w|, max|g_t_x| of what this lane stores (slots amax_w / amax_x)
   const int wave_global = blockIdx.x * nw_block + wave;
   const int nwaves = gridDim.x * nw_block;
   for (int64_t m = wave_global; m < M; m += nwaves) {
@@ -157,6 +159,8 @@ __global__ __launch_bounds__(256) void da_img_bwd_kernel(
         ox.z = tv.z > 0.f ? gx * wv.z : 0.f; ox.w = tv.w > 0.f ? gx * wv.w : 0.f;
         *reinterpret_cast<float4*>(g_t_w + m * C1 + c) = ow;
         if (g_t_x) *reinterpret_cast<float4*>(g_t_x + m * C1 + c) = ox;
+        mw = fmaxf(fmaxf(mw, fmaxf(fabsf(ow.x), fabsf(ow.y))), fmaxf(fabsf(ow.z), fabsf(ow.w)));
+        mxx = fmaxf(fmaxf(mxx, fmaxf(fabsf(ox.x), fabsf(ox.y))), fmaxf(fabsf(ox.z), fabsf(ox.w)));
         wacc[k].x += gw * tv.x; wacc[k].y += gw * tv.y; wacc[k].z += gw * tv.z; wacc[k].w += gw * tv.w;
       }
     }
@@ -174,6 +178,8 @@ __global__ __launch_bounds__(256) void da_img_bwd_kernel(
   __syncthreads();
   for (int c = threadIdx.x; c < C1; c += blockDim.x) atomicAdd(&g_w2[c], s_w2g[c]);
   if (lane == 0) atomicAdd(g_b2, bacc);  // bacc is wavefront-uniform
+  if (amax_w) amax_publish(amax_w, mw);
+  if (amax_x && g_t_x) amax_publish(amax_x, mxx);
 }
 
 // ---- instance-level domain classifier tail -------------------------------------------------------
@@ -449,7 +455,7 @@ extern "C" int dadet_da_img_head_loss_backward(const float* t, const float* w2, 
   if (blocks < 1) blocks = 1;
   hipLaunchKernelGGL(da_img_bwd_kernel, dim3((int)blocks), dim3(256), sizeof(float) * C1,
                      as_stream(stream), t, w2, logits, labels, coef, g_t_w, g_t_x, g_w2, g_b2, num_images,
-                     rows_per_image, C1, nullptr, nullptr, nullptr, 0.f, 0.f);
+                     rows_per_image, C1, nullptr, nullptr, nullptr, 0.f, 0.f, nullptr, nullptr);
   return check_launch("da_img_head_loss_backward");
 }
 
@@ -458,6 +464,16 @@ extern "C" int dadet_da_img_head_loss_backward_g(const float* t, const float* w2
                                                  const float* w_adv_dev, float w_adv, float w_cst, float* g_t_w,
                                                  float* g_t_x, float* g_w2, float* g_b2, int num_images,
                                                  int rows_per_image, int C1, void* stream) {
+  return dadet_da_img_head_loss_backward_gm(t, w2, logits, labels, g_bce, g_mean_sig, w_adv_dev, w_adv, w_cst, g_t_w, g_t_x,
+                                            g_w2, g_b2, num_images, rows_per_image, C1, nullptr, nullptr, stream);
+}
+
+extern "C" int dadet_da_img_head_loss_backward_gm(const float* t, const float* w2, const float* logits,
+                                                  const float* labels, const float* g_bce, const float* g_mean_sig,
+                                                  const float* w_adv_dev, float w_adv, float w_cst, float* g_t_w,
+                                                  float* g_t_x, float* g_w2, float* g_b2, int num_images,
+                                                  int rows_per_image, int C1, float* amax_w, float* amax_x,
+                                                  void* stream) {
   DADET_REQUIRE(num_images >= 0 && rows_per_image > 0 && C1 > 0 && C1 % 4 == 0 && C1 <= 1024,
                 "da_img_head_loss_backward_g: C1 must be a multiple of 4 and <= 1024");
   if (num_images == 0) return DADET_OK;
@@ -470,7 +486,8 @@ extern "C" int dadet_da_img_head_loss_backward_g(const float* t, const float* w2
   if (blocks < 1) blocks = 1;
   hipLaunchKernelGGL(da_img_bwd_kernel, dim3((int)blocks), dim3(256), sizeof(float) * C1, as_stream(stream), t, w2,
                      logits, labels, nullptr, g_t_w, g_t_x, g_w2, g_b2, num_images, rows_per_image, C1, g_bce,
-                     g_mean_sig, w_adv_dev, w_adv, w_cst);
+                     g_mean_sig, w_adv_dev, w_adv, w_cst, reinterpret_cast<unsigned*>(amax_w),
+                     reinterpret_cast<unsigned*>(amax_x));
   return check_launch("da_img_head_loss_backward_g");
 }
 

@@ -7,6 +7,7 @@ from torch.autograd import Function
 from torch.autograd.function import once_differentiable
 
 from .. import _C
+from .. import amax as _amax
 from .conv import conv2d_affine_act
 
 CL = torch.channels_last
@@ -80,7 +81,7 @@ class _GradientScalarLayer(Function):
     @staticmethod
     def forward(ctx, input, weight):
         ctx.weight = weight
-        return input.view_as(input)
+        return _amax.carry(input.view_as(input), input)
 
     @staticmethod
     def backward(ctx, grad_output):
@@ -159,8 +160,11 @@ class _RPNHeadLossRows(Function):
         # upstream factors of the two losses (1 and 1 when they enter the total loss unweighted)
         scale = torch.cat([g0.reshape(1).expand(A), g1.reshape(1).expand(4 * A), rows.new_zeros(ldg - 5 * A)])
         G = (rows * scale).view(S, ldg, 1, 1)
-        t_rows = _C.gather_pixel_taps(t, pixels).view(S, C, 1, 1)
-        x_cols = _C.gather_pixel_taps(x, pixels, k, k // 2).view(S, k * k * C, 1, 1)
+        # (gathered rows are bounded by their map's largest magnitude; views are new objects: handed on by hand, amax.py)
+        t_rows = _C.gather_pixel_taps(t, pixels)
+        t_rows = _amax.carry(t_rows.view(S, C, 1, 1), t_rows)
+        x_cols = _C.gather_pixel_taps(x, pixels, k, k // 2)
+        x_cols = _amax.carry(x_cols.view(S, k * k * C, 1, 1), x_cols)
         # the two 1x1 heads as one [5A (+pad), C] matrix, like the forward pass (layers.conv1x1_multi)
         w_head = torch.cat([wc.reshape(A, C), wb.reshape(4 * A, C), rows.new_zeros(ldg - 5 * A, C)], 0)
         d_head = _C.conv_wgrad(t_rows, G, (ldg, C, 1, 1))

@@ -59,7 +59,8 @@ class _InjectGrad(torch.autograd.Function):
         ctx.event = event
         ctx.save_for_backward(*[t for t in (g, e) if t is not None])
         ctx.has = (g is not None, e is not None)
-        return x.view_as(x)
+        from ... import amax
+        return amax.carry(x.view_as(x), x)
 
     @staticmethod
     def backward(ctx, grad_out):
@@ -155,7 +156,9 @@ class RPNModule(torch.nn.Module):
         n_img = f.shape[0]
         n_grad = leading_source_images(targets) or n_img      # unusual batch order: no restriction
         n_live = n_img if live is None else max(n_grad, min(int(live), n_img))
-        head_in = [f[:n_grad].detach().requires_grad_(True)]
+        from ... import amax
+        # (a slice is bounded by the whole map's largest magnitude: amax.py)
+        head_in = [amax.carry(f[:n_grad].detach().requires_grad_(True), f)]
         hidden = None
         if _ROW_BACKWARD and isinstance(self.head, RPNHead):
             # the head's backward is hand-written over the sampled rows (layers.misc._RPNHeadLossRows): no autograd graph
@@ -168,7 +171,7 @@ class RPNModule(torch.nn.Module):
         sel_obj, sel_reg = [objectness[0].detach()], [rpn_box_regression[0].detach()]
         if n_live > n_grad:
             with torch.no_grad():
-                o, r = self.head([f[n_grad:n_live]])
+                o, r = self.head([amax.carry(f[n_grad:n_live], f)])
             sel_obj, sel_reg = [torch.cat([sel_obj[0], o[0]], dim=0)], [torch.cat([sel_reg[0], r[0]], dim=0)]
         anchors = self.anchor_generator(images, features)
         return self._finish_overlapped(anchors, head_in, objectness, rpn_box_regression, sel_obj, sel_reg, targets,

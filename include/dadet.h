@@ -562,6 +562,13 @@ int dadet_da_img_head_loss_backward_g(const float* t, const float* w2, const flo
                                       const float* g_bce, const float* g_mean_sig, const float* w_adv_dev, float w_adv,
                                       float w_cst, float* g_t_w, float* g_t_x, float* g_w2, float* g_b2, int num_images,
                                       int rows_per_image, int C1, void* stream);
+/* ... and with max|g_t_w| / max|g_t_x| merged into the slots amax_w / amax_x (each may be NULL; zero them first): the two
+ * maps feed conv1_da's weight- and data-gradient GEMMs, whose mode-4 contraction wants their largest magnitudes (see
+ * dadet_conv_forward_scaled) */
+int dadet_da_img_head_loss_backward_gm(const float* t, const float* w2, const float* logits, const float* labels,
+                                       const float* g_bce, const float* g_mean_sig, const float* w_adv_dev, float w_adv,
+                                       float w_cst, float* g_t_w, float* g_t_x, float* g_w2, float* g_b2, int num_images,
+                                       int rows_per_image, int C1, float* amax_w, float* amax_x, void* stream);
 /* Domain-level triplet loss on NHWC maps [H][W][C] (one image each): L2 distance over the W axis with
  * eps, hinge with margin, loss_sum[0] += sum over (h,c) (the caller zeroes it and divides by H*C).
  * dist_out [H*C][2] keeps (d_ap, d_an) for the backward; g_scale[0] = upstream grad / (H*C).

@@ -364,7 +364,11 @@ def test_three_step_trajectory_matches_oracle(device, monkeypatch):
     names = list(rec["grads"])
     # fp32 oracle here (its three backward passes in fp64 took 140 s): the trajectory's tolerances are set by the
     # compounding of per-step differences, an order of magnitude above the fp32 oracle's own noise
-    osd = {k: v.clone() for k, v in sd.items()}
+    # DADET_TRAJECTORY_FP64=1: the oracle's three steps in float64 (140 s) — the run that separates the GPU path's own
+    # deviation from the fp32 oracle's; prints the per-tensor table either way
+    import os
+    dt = torch.float64 if os.environ.get("DADET_TRAJECTORY_FP64") == "1" else torch.float32
+    osd = {k: (v.clone().to(dt) if v.is_floating_point() else v.clone()) for k, v in sd.items()}
     groups = []
     for n in names:
         osd[n].requires_grad_(True)
@@ -373,6 +377,7 @@ def test_three_step_trajectory_matches_oracle(device, monkeypatch):
                        "weight_decay": c.SOLVER.WEIGHT_DECAY_BIAS if bias else c.SOLVER.WEIGHT_DECAY})
     opt = torch.optim.SGD(groups, c.SOLVER.BASE_LR, momentum=c.SOLVER.MOMENTUM)
     cpu_images, cpu_targets = make_batch(c, nimg, H, W, seed=seed, device=torch.device("cpu"))
+    cpu_images.tensors = cpu_images.tensors.to(dt)
     gts = model_ref.targets_to_dicts(cpu_targets)
     state = {}
     first = None
@@ -399,12 +404,22 @@ def test_three_step_trajectory_matches_oracle(device, monkeypatch):
     # Tolerances: after the first step the two runs start each step from parameters that already differ by rounding and
     # flipped ReLUs, so the per-step differences of _check_gradients compound (measured: 5e-4 .. 9e-4 on most tensors
     # after three steps at this rate against the fp64 oracle; the fp32 oracle used here adds its own 1e-4 .. 1e-3 and put
-    # 8 of 62 tensors at 2e-3 .. 4e-3): "rounding level" is 2e-3 here for at least 80% of the tensors, the hard bound 1e-2.
+    # 8 of 62 tensors at 2e-3 .. 4e-3): "rounding level" is 2e-3 here for at least 70% of the tensors, the hard bound 1e-2.
+    # Round 4, both contractions against both oracles on one box (DADET_TRAJECTORY_FP64, per-tensor relative L2 of the
+    # three-step update): mode 3 vs float32 median 3.0e-4 / 80th percentile 6.5e-4, vs float64 3.5e-4 / 8.0e-4; mode 4
+    # (the default) vs float32 5.1e-4 / 9.0e-4, vs float64 2.6e-4 / 3.7e-4, none above 2e-3 — against the exact oracle the
+    # fp16 two-term contraction is the closer one; against the float32 oracle the count above 2e-3 is that oracle's own
+    # noise (8 .. 13 of 62 momentum buffers over runs and modes), hence the 30% share below.
+    upd = sorted(float(((rec["params"][n].double() - sd[n].double()) - (osd[n].detach().double() - sd[n].double())).norm()
+                       / ((osd[n].detach().double() - sd[n].double()).norm() + 1e-30)) for n in names)
+    print("three-step updates vs the %s oracle: median %.2e  80th percentile %.2e  max %.2e  above 2e-3: %d of %d"
+          % ("float64" if dt == torch.float64 else "float32", upd[len(upd) // 2], upd[int(0.8 * len(upd))], upd[-1],
+             sum(u >= 2e-3 for u in upd), len(upd)))
     _check_gradients({n: rec["params"][n].double() - sd[n].double() for n in names},
                      {n: osd[n].detach() - sd[n].double() for n in names}, rounding_tol=2e-3, flip_tol=1e-2,
-                     flipped_share=0.2)
+                     flipped_share=0.3)
     _check_gradients(rec["momentum"], {n: opt.state[osd[n]]["momentum_buffer"] for n in rec["momentum"]},
-                     rounding_tol=2e-3, flip_tol=1e-2, flipped_share=0.2)
+                     rounding_tol=2e-3, flip_tol=1e-2, flipped_share=0.3)
     assert abs(state["margin_img"] - c.MODEL.DA_HEADS.TRIPLET_MARGIN_IMG) < 1e-9      # never exactly 0 here: no growth
 
 

@@ -45,8 +45,9 @@ orig = amax.measure
 
 def traced(t):
     frames = [f for f in traceback.extract_stack()[:-1]
-              if not f.filename.endswith(("_C.py", "amax.py", "amax_sites.py"))]
-    key = " <- ".join("%s:%d %s" % (os.path.relpath(f.filename, ROOT), f.lineno, f.name) for f in frames[-1:-4:-1])
+              if not f.filename.endswith(("_C.py", "amax.py", "amax_sites.py")) and "/torch/" not in f.filename]
+    key = " <- ".join("%s:%d %s" % (os.path.relpath(f.filename, ROOT).replace("da_detect_amd/", ""), f.lineno, f.name)
+                      for f in frames[-1:-6:-1])
     sites[key] += 1
     nbytes[key] += t.numel() * 4
     return orig(t)
