@@ -644,13 +644,22 @@ def relu_bn_backward(g, y=None, scale=None, want_unscaled=False):
         yy = _nhwc(y) if y.dim() == 4 else y.contiguous()
     g_out = torch.empty_like(g) if want_unscaled else None
     g_scaled = torch.empty_like(g)
-    _lib.call("dadet_relu_bn_backward", _p(g), _p(yy), _p(scale), _p(g_out), _p(g_scaled), rows, C,
-              _stream())
-    # a gate only removes values: the input's largest magnitude bounds the gated copies (amax.py)
-    if g_out is not None:
-        _amax.carry(g_out, g)
-    if scale is None:
-        _amax.carry(g_scaled, g)
+    if not _mode4():
+        _lib.call("dadet_relu_bn_backward", _p(g), _p(yy), _p(scale), _p(g_out), _p(g_scaled), rows, C, _stream())
+        return g_out, g_scaled
+    # contraction mode 4: both outputs feed GEMMs.  A gate only removes values, so the input's largest magnitude bounds
+    # the gated copy when the input carries one; otherwise (and for the scaled copy) the kernel leaves the exact maxima
+    so = ss = None
+    if g_out is not None and _amax.slot_of(_amax.carry(g_out, g)) is None:
+        so = _amax.new_slot(g.device)
+    if scale is not None or _amax.slot_of(_amax.carry(g_scaled, g)) is None:
+        ss = _amax.new_slot(g.device)
+    _lib.call("dadet_relu_bn_backward_m", _p(g), _p(yy), _p(scale), _p(g_out), _p(g_scaled), rows, C,
+              ctypes.c_void_p(so[0]) if so else None, ctypes.c_void_p(ss[0]) if ss else None, _stream())
+    if so:
+        _amax.attach(g_out, so)
+    if ss:
+        _amax.attach(g_scaled, ss)
     return g_out, g_scaled
 
 
@@ -722,6 +731,9 @@ def nchw3_to_nhwc4(x):
     assert C == 3
     y = torch.empty((N, 4, H, W), dtype=torch.float32, device=x.device, memory_format=CL)
     _lib.call("dadet_nchw3_to_nhwc4", _p(x), _p(y), N, H, W, _stream())
+    if _mode4():
+        _amax.ptr(x)              # three of the staged tensor's four channels (a batch tensor that is reused is measured once)
+        _amax.carry(y, x)
     return y
 
 

@@ -139,6 +139,7 @@ _SIGNATURES = {
     "dadet_deform_psroi_pool_backward": [_P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int,
                                          c_float, c_int, c_int, c_int, c_int, c_int, c_float, c_int, _P],
     "dadet_relu_bn_backward": [_P, _P, _P, _P, _P, c_int64, c_int, _P],
+    "dadet_relu_bn_backward_m": [_P, _P, _P, _P, _P, c_int64, c_int, _P, _P, _P],
     "dadet_colsum_workspace_bytes": [c_int64, c_int, POINTER(c_size_t)],
     "dadet_colsum": [_P, _P, c_int64, c_int, _P, c_size_t, _P],
     "dadet_colsum_ld": [_P, c_int, _P, c_int64, c_int, c_int, _P, c_size_t, _P],

@@ -2,7 +2,7 @@
 // Every kernel moves 16 B per lane with lanes along the channel axis and a capped grid-stride launch.
 // Each entry point cites the reference code it stands in for.
 #include "box_match.h"
-#include "common.h"
+#include "conv_common.h"   // amax_publish (contraction mode 4)
 #include <float.h>
 
 namespace dadet {
@@ -18,7 +18,9 @@ static inline int stream_blocks(int64_t work_items, int threads) {
 // reference: F.relu_ + FrozenBatchNorm2d.forward (layers/batch_norm.py:19-24) differentiated by autograd.
 __global__ void relu_bn_backward_kernel(const float4* __restrict__ g, const float4* __restrict__ y,
                                         const float4* __restrict__ scale, float4* __restrict__ g_out,
-                                        float4* __restrict__ g_scaled, int64_t total4, int C4) {
+                                        float4* __restrict__ g_scaled, int64_t total4, int C4,
+                                        unsigned* __restrict__ amax_out, unsigned* __restrict__ amax_scaled) {
+  float mo = 0.f, ms = 0.f;     // contraction mode 4: max|g_out|, max|g_scaled| (slots; both feed GEMMs)
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total4;
        i += (int64_t)gridDim.x * blockDim.x) {
     const float4 gv = g[i];
@@ -31,6 +33,7 @@ __global__ void relu_bn_backward_kernel(const float4* __restrict__ g, const floa
       r.w = yv.w > 0.f ? gv.w : 0.f;
     }
     if (g_out) g_out[i] = r;
+    mo = fmaxf(fmaxf(mo, fmaxf(fabsf(r.x), fabsf(r.y))), fmaxf(fabsf(r.z), fabsf(r.w)));
     if (g_scaled) {
       float4 s = r;
       if (scale) {
@@ -38,8 +41,11 @@ __global__ void relu_bn_backward_kernel(const float4* __restrict__ g, const floa
         s.x *= sc.x; s.y *= sc.y; s.z *= sc.z; s.w *= sc.w;
       }
       g_scaled[i] = s;
+      ms = fmaxf(fmaxf(ms, fmaxf(fabsf(s.x), fabsf(s.y))), fmaxf(fabsf(s.z), fabsf(s.w)));
     }
   }
+  if (amax_out) amax_publish(amax_out, mo);
+  if (amax_scaled) amax_publish(amax_scaled, ms);
 }
 
 // ---- column sum (bias gradient) -------------------------------------------------------------
@@ -442,6 +448,12 @@ static bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 
 
 extern "C" int dadet_relu_bn_backward(const float* g, const float* y, const float* scale, float* g_out,
                                       float* g_scaled, int64_t rows, int C, void* stream) {
+  return dadet_relu_bn_backward_m(g, y, scale, g_out, g_scaled, rows, C, nullptr, nullptr, stream);
+}
+
+extern "C" int dadet_relu_bn_backward_m(const float* g, const float* y, const float* scale, float* g_out,
+                                        float* g_scaled, int64_t rows, int C, float* amax_out, float* amax_scaled,
+                                        void* stream) {
   DADET_REQUIRE(rows >= 0 && C > 0 && C % 4 == 0, "relu_bn_backward: C=%d must be a multiple of 4", C);
   if (rows == 0) return DADET_OK;
   DADET_REQUIRE(g && (g_out || g_scaled), "relu_bn_backward: null pointer");
@@ -451,7 +463,9 @@ extern "C" int dadet_relu_bn_backward(const float* g, const float* y, const floa
   hipLaunchKernelGGL(relu_bn_backward_kernel, dim3(stream_blocks(total4, 256)), dim3(256), 0,
                      as_stream(stream), reinterpret_cast<const float4*>(g),
                      reinterpret_cast<const float4*>(y), reinterpret_cast<const float4*>(scale),
-                     reinterpret_cast<float4*>(g_out), reinterpret_cast<float4*>(g_scaled), total4, C / 4);
+                     reinterpret_cast<float4*>(g_out), reinterpret_cast<float4*>(g_scaled), total4, C / 4,
+                     reinterpret_cast<unsigned*>(g_out ? amax_out : nullptr),
+                     reinterpret_cast<unsigned*>(g_scaled ? amax_scaled : nullptr));
   return check_launch("relu_bn_backward");
 }
 

@@ -187,7 +187,8 @@ class DomainAdaptationModule(torch.nn.Module):
         if not (_EARLY_DA and self.training and self.early_backward and torch.is_grad_enabled() and self.cst_weight == 0
                 and self.img_weight > 0 and all(f.is_cuda and f.requires_grad for f in img_features)):
             return None
-        head_in = [f.detach().requires_grad_(True) for f in img_features]
+        from ... import amax
+        head_in = [amax.carry(f.detach().requires_grad_(True), f) for f in img_features]
         da_img_loss, _ = self._image_level(head_in, targets)
         loss = self.img_weight * da_img_loss
         torch.autograd.backward([loss])

@@ -123,7 +123,9 @@ class RPNModule(torch.nn.Module):
                  and all(f.requires_grad for f in features))
         if early and features[0].is_cuda and len(features) == 1 and elision_enabled():
             return self._forward_train_overlapped(images, features, targets, live)
-        head_in = [f.detach().requires_grad_(True) for f in features] if early else features
+        from ... import amax
+        # (a detached alias is a new tensor object: its map's largest magnitude is handed on by hand, amax.py)
+        head_in = [amax.carry(f.detach().requires_grad_(True), f) for f in features] if early else features
         if (early and features[0].is_cuda and len(features) > 1 and elision_enabled() and _ROW_BACKWARD
                 and isinstance(self.head, RPNHead)):
             # feature pyramid: the shared head runs WITHOUT autograd on every level and keeps its hidden activations; its

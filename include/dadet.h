@@ -501,6 +501,10 @@ int dadet_deform_psroi_pool_backward(const float* grad_out, const float* top_cou
  * NULL; scale may be NULL (=1).  Outputs may alias g.   (ReLU + FrozenBN backward, batch_norm.py:19-24) */
 int dadet_relu_bn_backward(const float* g, const float* y, const float* scale, float* g_out,
                            float* g_scaled, int64_t rows, int C, void* stream);
+/* ... with max|g_out| / max|g_scaled| merged into the slots amax_out / amax_scaled (either may be NULL; zero them first):
+ * both maps feed GEMMs (contraction mode 4, see dadet_conv_forward_scaled) */
+int dadet_relu_bn_backward_m(const float* g, const float* y, const float* scale, float* g_out, float* g_scaled,
+                             int64_t rows, int C, float* amax_out, float* amax_scaled, void* stream);
 /* out[c] = sum_m g[m][c]  (bias gradient); workspace >= dadet_colsum_workspace_bytes */
 int dadet_colsum_workspace_bytes(int64_t rows, int C, size_t* bytes_out);
 int dadet_colsum_ld(const float* g, int ld, float* out, int64_t rows, int C, int accumulate, void* workspace,
