@@ -150,6 +150,9 @@ def _mode4():
 def _weight_amax(w):
     """slot of the B operand of a GEMM: parameters (and views of them) and the cached transposed weights live in the
     persistent per-epoch table, anything else is treated like an activation"""
+    like = w.__dict__.get("_dadet_amax_like")     # a padded copy of a parameter (zero rows appended): the parameter's maximum
+    if like is not None and like() is not None:
+        w = like()
     base = w._base if w._base is not None else w
     if isinstance(base, torch.nn.Parameter) or w.__dict__.get("_dadet_persistent"):
         return _amax.WEIGHTS.ptr(w, _TRANSPOSES.epoch)

@@ -731,8 +731,12 @@ bool streamk_plan(const ConvArgs& a, int variant, SkPlan* p) {
     // between one workgroup per CU and two (e.g. the 392 tiles of the res5 GEMMs over 256 ROIs): all workgroups are
     // resident at once, but 136 CUs run two of them and 120 run one — the launch lasts as long as the pairs.  All tiles
     // become stream-K tiles: 512 equal ranges, every CU gets two.  DADET_STREAMK_SMALL=0 switches this case off.
+    // Mode 4 (three MFMAs per K=16): a tile's K loop is short enough that parking / summing the partial tiles and the
+    // operand panels the ranges no longer share cost more than the uneven CUs — `img_only` 15.27 -> 14.81 ms, R-101-FPN-DCN
+    // 49.1 -> 46.6 ms with this case off (three alternating runs each on one box); it stays on for the six-MFMA mode 3,
+    // where it was measured (+18% on the res5 GEMMs).  DADET_STREAMK_SMALL = 0 / 1 forces it.
     const char* small = getenv("DADET_STREAMK_SMALL");
-    if (small && small[0] == '0') return false;
+    if (small ? small[0] == '0' : gemm_mode() == 4) return false;
     p->dp_tiles = 0;
     p->sk_tiles = tiles;
     p->iters = ceil_div(tiles * nk, slots);

@@ -256,6 +256,7 @@ class _PaddedWeights(object):
             wp = torch.zeros((cout + pad, cin, kh, kw), dtype=weight.dtype, device=weight.device).contiguous(
                 memory_format=torch.channels_last)
             bp = torch.zeros(cout + pad, dtype=bias.dtype, device=bias.device) if bias is not None else None
+            wp._dadet_amax_like = weakref.ref(weight)     # same largest magnitude as the parameter (amax.py, mode 4)
             self.entries[id(weight)] = dict(w=weakref.ref(weight), b=weakref.ref(bias) if bias is not None else None,
                                             wp=wp, bp=bp)
             self.stamp = None

@@ -1041,6 +1041,8 @@ def test_roi_align_workspace_variants_are_bit_identical_at_full_size(device, mon
     (2, 256, 40, 60, 200, 3, 1),        # ragged M (4800 rows) and Cout
     (1, 512, 7, 7 * 96, 512, 3, 1),     # 37 x 4 = 148 tiles, 144 K-tiles (the res5 3x3 shape, fewer ROIs)
     (2, 1024, 52, 128, 1024, 1, 0),     # 104 x 8 = 832 tiles: 512 one per workgroup + 320 stream-K, 32 K-tiles
+    (1, 512, 7, 7 * 256, 512, 3, 1),    # 98 x 4 = 392 tiles (res5 3x3 over 256 ROIs): between one and two workgroups per
+                                        # CU, every tile a stream-K tile (DADET_STREAMK_SMALL: default in mode 3 only)
 ])
 def test_stream_k_tail_matches_the_plain_grid(device, shape, monkeypatch):
     """conv_fwd_split_sk_kernel (stream-K tail: partial tiles parked in a workspace, the last arriver sums the parts in
@@ -1063,6 +1065,7 @@ def test_stream_k_tail_matches_the_plain_grid(device, shape, monkeypatch):
     cases = [dict(), dict(scale=scale, bias=bias, relu_mode=1), dict(scale=scale, bias=bias, addend=addend, relu_mode=1),
              dict(addend=addend, mask_ref=mask, relu_mode=2)]
     out = {}
+    monkeypatch.setenv("DADET_STREAMK_SMALL", "1")
     for flag in ("0", "1"):
         monkeypatch.setenv("DADET_STREAMK", flag)
         os.environ["DADET_STREAMK"] = flag
