@@ -17,6 +17,11 @@
 #include "conv_common.h"
 #include <stdlib.h>
 
+// build-time A/B switch (a second library through DADET_LIB): 0 = fragment reads per k16 group also in mode 4
+#ifndef DADET_FRAG2
+#define DADET_FRAG2 1
+#endif
+
 namespace dadet {
 
 static int g_gemm_mode = 4;
@@ -365,19 +370,31 @@ __device__ __forceinline__ void conv_fwd_split_body(const ConvArgs& a, char* sme
     // slots), then fetch that operand of tile kt + 2 into the registers just freed.  Everything is unconditional on
     // purpose: past the last K-tile every offset is out of range (the loads return 0) and the split works on dead
     // registers — loads, MFMAs and split stay in ONE basic block for the scheduler.
-#pragma unroll
-    for (int step = 0; step < BK / 16; ++step) {
-      bf16x8 fa[TERMS][TM], fb[TERMS][TN];
-      if (!(ab & 16) || kt == 0)
+    // FRAG2 (mode 4): the fragments of BOTH k16 steps of the tile are read up front.  With 12 MFMAs per group instead of
+    // 24, the LDS round trip in front of each group (reads issued, then waited for) is twice as large a share of it; the
+    // second group's reads now land under the first group's MFMAs (32 more VGPRs).
+    constexpr bool FRAG2 = F16 && AB == 0 && DADET_FRAG2;
+    bf16x8 fa_[BK / 16][TERMS][TM], fb_[BK / 16][TERMS][TN];
+    auto read_frags = [&](const int step) {
 #pragma unroll
       for (int p = 0; p < TERMS; ++p) {
 #pragma unroll
         for (int i = 0; i < TM; ++i)
-          fa[p][i] = *reinterpret_cast<const bf16x8*>(Ab + p * A_PLANE + i * 32 * PLANE_STRIDE + step * 16);
+          fa_[step][p][i] = *reinterpret_cast<const bf16x8*>(Ab + p * A_PLANE + i * 32 * PLANE_STRIDE + step * 16);
 #pragma unroll
         for (int i = 0; i < TN; ++i)
-          fb[p][i] = *reinterpret_cast<const bf16x8*>(Bb + p * B_PLANE + i * 32 * PLANE_STRIDE + step * 16);
+          fb_[step][p][i] = *reinterpret_cast<const bf16x8*>(Bb + p * B_PLANE + i * 32 * PLANE_STRIDE + step * 16);
       }
+    };
+    if (FRAG2) {
+#pragma unroll
+      for (int step = 0; step < BK / 16; ++step) read_frags(step);
+    }
+#pragma unroll
+    for (int step = 0; step < BK / 16; ++step) {
+      auto& fa = fa_[step];
+      auto& fb = fb_[step];
+      if (!FRAG2 && (!(ab & 16) || kt == 0)) read_frags(step);
       // the next tile's operands have landed by now: split one operand per k16 group of MFMAs
       if (!(ab & 1)) {
         if (step == 0) split_a();
@@ -404,7 +421,8 @@ __device__ __forceinline__ void conv_fwd_split_body(const ConvArgs& a, char* sme
         // instructions that fit in its shadow
         constexpr int kMfma = TM * TN * (TERMS == 3 ? 6 : 3);
         constexpr int kValuPerMfma = (TM == 2 ? A_LOADS : B_LOADS) * (TERMS == 3 ? 26 : 14) / kMfma + 1;
-        __builtin_amdgcn_sched_group_barrier(0x100, TERMS * (TM + TN), 0);   // DS reads
+        if (!FRAG2) __builtin_amdgcn_sched_group_barrier(0x100, TERMS * (TM + TN), 0);                  // DS reads
+        else if (step == 0) __builtin_amdgcn_sched_group_barrier(0x100, (BK / 16) * TERMS * (TM + TN), 0);
 #pragma unroll
         for (int i = 0; i < kMfma; ++i) {
           __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                 // one MFMA
@@ -782,16 +800,27 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_split_kernel(const WgradArg
     // LDS holds step st, the registers hold step st + 1.  Per k16 group: split (and 4x4-transpose) one operand of
     // step st + 1 in the shadow of the MFMAs, then fetch that operand of step st + 2 into the freed registers.  All
     // unconditional (rows past m_end load zeros): loads, MFMAs and split stay in one basic block for the scheduler.
-#pragma unroll
-    for (int step = 0; step < RK / 16; ++step) {
-      bf16x8 fg[TERMS][2], fx[TERMS][2];
+    // (mode 4: the fragments of both k16 groups are read up front — see FRAG2 in conv_fwd_split_body)
+    constexpr bool FRAG2 = F16 && DADET_FRAG2;
+    bf16x8 fg_[RK / 16][TERMS][2], fx_[RK / 16][TERMS][2];
+    auto read_frags = [&](const int step) {
 #pragma unroll
       for (int p = 0; p < TERMS; ++p)
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
-          fg[p][i] = *reinterpret_cast<const bf16x8*>(Gb + p * PLANE + i * 32 * PLANE_STRIDE + step * 16);
-          fx[p][i] = *reinterpret_cast<const bf16x8*>(Xb + p * PLANE + i * 32 * PLANE_STRIDE + step * 16);
+          fg_[step][p][i] = *reinterpret_cast<const bf16x8*>(Gb + p * PLANE + i * 32 * PLANE_STRIDE + step * 16);
+          fx_[step][p][i] = *reinterpret_cast<const bf16x8*>(Xb + p * PLANE + i * 32 * PLANE_STRIDE + step * 16);
         }
+    };
+    if (FRAG2) {
+#pragma unroll
+      for (int step = 0; step < RK / 16; ++step) read_frags(step);
+    }
+#pragma unroll
+    for (int step = 0; step < RK / 16; ++step) {
+      auto& fg = fg_[step];
+      auto& fx = fx_[step];
+      if (!FRAG2) read_frags(step);
       if (step == 0) split_block(rg, pg_, sg);
       else split_block(rx, px_, sx);
 #pragma unroll
@@ -811,7 +840,8 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_split_kernel(const WgradArg
       {
         constexpr int kMfma = 4 * (TERMS == 3 ? 6 : 3);
         constexpr int kValuPerMfma = 4 * (TERMS == 3 ? 26 : 14) / kMfma + 1;
-        __builtin_amdgcn_sched_group_barrier(0x100, TERMS * 4, 0);          // DS reads
+        if (!FRAG2) __builtin_amdgcn_sched_group_barrier(0x100, TERMS * 4, 0);          // DS reads
+        else if (step == 0) __builtin_amdgcn_sched_group_barrier(0x100, (RK / 16) * TERMS * 4, 0);
 #pragma unroll
         for (int i = 0; i < kMfma; ++i) {
           __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                // one MFMA
