@@ -433,6 +433,8 @@ class _TransposeCache(object):
                 self._refresh_all(device)
             finally:
                 self._from_bump = False
+        elif device is not None and _mode4():
+            _amax.WEIGHTS.refresh(device, self.epoch)      # no transposed copies registered: the weights' maxima alone
 
     def _single(self, e, w, scale):
         """one entry on the current stream, remembered with an event for readers on other streams"""

@@ -371,6 +371,79 @@ def test_fp16_split_is_scale_free(device, sx, sw):
     assert err < 3e-6
 
 
+def test_fused_maxima_equal_the_tensors_maximum(device, monkeypatch):
+    """mode 4 reads every operand's largest magnitude from a slot its PRODUCER filled.  Each producing kernel form — tiled
+    epilogue (16-byte and scalar), stream-K tail, split-K reduction pass, weight-stationary 1x1, the ReLU / FrozenBN
+    backward, the image-level DA backward — leaves exactly max|y| there; bounds handed on by hand stay bounds; the batched
+    pass over persistent weights agrees with torch."""
+    from da_detect_amd import _C, amax
+
+    g = torch.Generator().manual_seed(5)
+
+    def rnd(*shape):
+        return torch.randn(shape, generator=g).to(device)
+
+    prev = _C.get_gemm_mode()
+    try:
+        _C.set_gemm_mode(4)
+        cases = {
+            "tiled 128x128 + residual + relu": dict(x=(2, 256, 40, 64), w=(256, 256, 3, 3), kw=dict(pad=1, relu_mode=1), add=True),
+            "stream-K tail": dict(x=(2, 1024, 52, 128), w=(1024, 1024, 1, 1), kw={}),
+            "split-K reduce (M = 512 linear)": dict(x=(512, 2048, 1, 1), w=(1024, 2048, 1, 1), kw=dict(relu_mode=1)),
+            "weight-stationary 1x1": dict(x=(2, 256, 64, 128), w=(1024, 256, 1, 1), kw={}, add=True),
+            "scalar epilogue (strided scatter)": dict(x=(2, 64, 20, 24), w=(128, 64, 1, 1),
+                                                      kw=dict(out_spatial_stride=2, out_hw=(40, 48))),
+            "ragged 128x64": dict(x=(2, 128, 19, 23), w=(72, 128, 3, 3), kw=dict(pad=1)),
+        }
+        for name, c in cases.items():
+            x = rnd(*c["x"]).contiguous(memory_format=CL)
+            w = (rnd(*c["w"]) * 0.05).contiguous(memory_format=CL)
+            kw = dict(c["kw"])
+            y_shape = None
+            if c.get("add"):
+                ho, wo = _C.conv_out_size(c["x"][2], c["x"][3], c["w"][2], c["w"][3], 1, kw.get("pad", 0))
+                kw["addend"] = rnd(c["x"][0], c["w"][0], ho, wo).contiguous(memory_format=CL)
+            y = _C.conv_forward(x, w, **kw)
+            assert amax.value(y) == float(y.abs().max()), name
+            assert amax.value(x) == float(x.abs().max()), name            # measured on demand (dadet_amax)
+        # elementwise producers
+        gy, yy = rnd(2, 256, 24, 40).contiguous(memory_format=CL), rnd(2, 256, 24, 40).contiguous(memory_format=CL)
+        sc = torch.rand(256, generator=g).to(device) + 0.5
+        g_out, g_sc = _C.relu_bn_backward(gy, yy, sc, want_unscaled=True)
+        assert amax.value(g_out) == float(g_out.abs().max()) and amax.value(g_sc) == float(g_sc.abs().max())
+        amax.measure(gy)
+        g_out2, _ = _C.relu_bn_backward(gy, yy, sc, want_unscaled=True)        # the gate's input carries one: a bound
+        assert amax.value(g_out2) == float(gy.abs().max()) >= float(g_out2.abs().max())
+        pooled = _C.maxpool3x3s2(amax.measure(rnd(2, 64, 32, 48).contiguous(memory_format=CL)))
+        assert amax.value(pooled) >= float(pooled.abs().max())
+        # image-level DA backward
+        N, H, W, C1 = 2, 12, 20, 512
+        t = rnd(N, C1, H, W).clamp_min(0).contiguous(memory_format=CL)
+        w2, b2 = rnd(C1) * 0.05, rnd(1)
+        labels = torch.tensor([1.0, 0.0], device=device)
+        logits, _ = _C.da_img_head_loss_forward(t, w2, b2, labels, N, H * W)
+        gw, gx, _, _ = _C.da_img_head_loss_backward_g(t, w2, logits, labels, torch.ones(1, device=device),
+                                                      torch.full((N,), 0.3, device=device), 0.7, 0.2, N, H * W)
+        assert amax.value(gw) == float(gw.abs().max()) and amax.value(gx) == float(gx.abs().max())
+        # persistent weights: one batched pass per weight epoch
+        params = [torch.nn.Parameter((rnd(*s_) * k_).contiguous(memory_format=CL))
+                  for s_, k_ in (((64, 64, 3, 3), 0.1), ((256, 64, 1, 1), 3.0), ((1024, 1024, 3, 3), 1e-3))]
+        xs = rnd(2, 64, 16, 16).contiguous(memory_format=CL)
+        with torch.no_grad():
+            _C.conv_forward(xs, params[0], pad=1)
+            _C.conv_forward(xs, params[1])
+            _C.conv_forward(rnd(1, 1024, 8, 8).contiguous(memory_format=CL), params[2], pad=1)
+            for p_ in params:
+                p_.data.mul_(1.5)                 # a raw in-place update, as the fused optimizer makes it
+        _C.bump_weight_epoch(xs.device)
+        d = amax.WEIGHTS.by_dev[xs.device.index]
+        for p_ in params:
+            e = d["entries"][(p_.data_ptr(), p_.numel())]
+            assert float(d["slots"][:, e["i"]].max()) == float(p_.detach().abs().max())
+    finally:
+        _C.set_gemm_mode(prev)
+
+
 def test_fp16_split_wide_range_inside_one_tensor(device):
     """elements far below the tensor's maximum: above 2^-16 of it they keep fp32-class relative accuracy, below that an
     absolute error under 2^-38 of the maximum (the low term falls into fp16's subnormals) — rows whose values are all
