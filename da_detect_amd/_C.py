@@ -523,8 +523,9 @@ def bump_weight_epoch(device=None):
     """weights were updated in place through raw pointers (the fused SGD kernel) or through `.data` (a broadcast, a
     checkpoint load, an EMA, a manual `p.data.copy_`): cached derived forms are stale.  REQUIRED after any weight write
     that does not go through autograd's version counter — the data-gradient GEMMs otherwise keep using the transposed /
-    padded copies of the old values.  FusedSGD.step, BucketedGradReducer.broadcast_parameters and Checkpointer.load call
-    it themselves."""
+    padded copies of the old values, and (contraction mode 4) the old largest magnitude of the weight: a weight that grew
+    past twice its recorded maximum overflows fp16's range inside the GEMM and the step ends in inf / nan, loudly.
+    FusedSGD.step, BucketedGradReducer.broadcast_parameters and Checkpointer.load call it themselves."""
     _TRANSPOSES.bump(device)
 
 
