@@ -57,12 +57,10 @@ def attach(t, slot):
     return t
 
 
-def carry(dst, src, *more):
-    """max|dst| <= max over the sources: dst takes over a source's slot.  With several sources (an addition's operands do
-    NOT qualify: |a + b| can exceed both) the caller guarantees the bound; only the first VALID source's slot is used when
-    there is one source, otherwise nothing is attached and dst is measured on demand."""
-    if more:
-        return dst
+def carry(dst, src):
+    """max|dst| <= max|src| by the nature of the operation that made dst from src (a gate, a pooling, a gather, a view, a
+    slice ...): dst takes over src's slot when src carries a valid one; otherwise nothing is attached and dst is measured
+    when a GEMM first asks.  NOT for sums: |a + b| can exceed both."""
     a = src.__dict__.get("_dadet_amax") if src is not None else None
     if a is not None and a[2] == src._version:
         dst._dadet_amax = (a[0], a[1], dst._version)

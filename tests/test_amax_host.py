@@ -60,4 +60,3 @@ def test_carry_hands_a_valid_bound_on_and_nothing_else(monkeypatch):
     other = torch.zeros(2)
     assert amax.slot_of(amax.carry(other, src)) is None        # stale source
     assert amax.slot_of(dst)[0] == 0x4000                      # what was handed on before stays (dst was not written)
-    assert amax.slot_of(amax.carry(torch.zeros(2), src, dst)) is None   # several sources: never a bound by itself
