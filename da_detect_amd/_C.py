@@ -366,7 +366,9 @@ def conv_forward(x, w, scale=None, bias=None, addend=None, mask_ref=None, stride
         if kname is None:
             variant = _lib.load().dadet_conv_forward_variant(ctypes.byref(d))
             mode = get_gemm_mode()
-            if variant == 3:
+            if variant == 4:
+                kname = "conv_big_kernel<256>"
+            elif variant == 3:
                 kname = "conv1x1_ws_kernel<%d,%d,%d>" % (Cin, 64 if Cin == 256 else 128, mode)
             else:
                 kname = ("conv_fwd_kernel<%s>" if mode == 0 else ("conv_fwd_split_kernel<%%s,%d>" % mode)) % \

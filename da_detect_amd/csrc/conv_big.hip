@@ -1,0 +1,523 @@
+// Large-tile implicit-GEMM convolution of contraction mode 4 (fp32 operands as two fp16 terms under per-tensor
+// power-of-two scales, 3 x v_mfma_f32_32x32x16_f16 per K = 16; conv_common.h) — the forward / data-gradient kernel for
+// the long-K layers since round 5.
+//
+// Why another kernel.  conv_fwd_split_kernel<2,2,4> (128 x 128 tile, 4 waves of 64 x 64, one set of operand planes, two
+// barriers per K-tile, two workgroups per CU) issues 7.65 VALU and 1.0 LDS instructions per MFMA and sits at 0.28 - 0.36 of
+// the contraction's ceiling; tools/native/gemm_lab.hip measures what the tile shape and the schedule are worth on RANDOM
+// operands (profiles/r05_gemm_lab.txt): the same arithmetic in a 256 x 256 tile with 8 waves of 128 x 64 runs 35% faster
+// (0.35 -> 0.46 of 833 TF/s), and with the two waves of every SIMD taking TURNS on the matrix pipe 42% faster (0.49) — 75%
+// of what a register-only MFMA stream sustains on such operand bits under this part's power management (1625 of the
+// nominal 2500 TF/s).  Per MFMA the loop carries 1.5 VALU, 0.5 ds_read_b128 and 0.33 ds_write_b64.
+//
+// Structure.  One workgroup = 512 threads = 8 waves = a 256 x BN output tile (BN = 256: 2 x 4 waves of 128 x 64), one
+// workgroup per CU, two waves per SIMD.  Waves 0-3 (group 0) and 4-7 (group 1) — one wave of each group on every SIMD —
+// run COMPLEMENTARY segments separated by workgroup barriers (the guide's 8-phase idea, T3 / T4):
+//     multiply segment   24 MFMAs of one k16 step from registers, nothing else
+//     load segment       read the 12 fragments of the wave's next k16 step, wait for the global loads issued one load
+//                        segment ago, split them (2 VALU per element: v_fma_mix{lo,hi}_f16) and store a quarter of a future
+//                        K-tile's planes, issue the next global loads
+// so the matrix pipe of a SIMD always has one wave multiplying while its partner does everything else, fragments are read
+// when the wave does not multiply (ONE fragment register set), and the load segment may branch (tap changes) without
+// cutting an MFMA schedule.  Segment s: group 0 multiplies step s / 2 for even s, group 1 step (s - 1) / 2 for odd s.
+// Group 0 stages the activation rows (the implicit-GEMM gather), group 1 the weight rows; K-tile T + 1 is written during
+// segments 4T - 1 .. 4T + 2 into the slot K-tile T - 1 was last read from in segment 4T - 2 (two slots of 64 KB).
+//
+// LDS image of a K-tile: planes A_h | A_l | B_h | B_l of [rows][32 k] fp16 (64-byte rows); the four 16-byte chunks of a
+// row are XOR-swizzled with (row >> 2) & 3, which makes the ds_read_b128 fragment reads (lane groups of 16: rows {0-3,
+// 12-15, 20-27} / {4-11, 16-19, 28-31} of one chunk column) and the 8-byte staging stores conflict-free without padding.
+//
+// Small grids.  A 256 x 256 tile leaves layers such as res4 3x3 (64 tiles) or the RPN conv (128) short of the 256 CUs:
+// the reduction is cut into S contiguous K ranges (tiles x S <= 256 workgroups).  The parts of a tile meet in a workspace:
+// a part takes an arrival ticket; all but the last park their sums (lane-linear 16-byte write-through stores, drained, then
+// one "parked" count) and leave; the last one waits for the parked count (the others are resident and past their K loop: a
+// bounded wait, no dependence on workgroups that may not have been dispatched), adds the parked parts to its registers in
+// part order — its own at its index, so the sum does not depend on who arrives last — and runs the epilogue.
+//
+// Epilogue: conv_split.hip's 16-byte form (every 32 x 32 accumulator block turned through LDS so that a lane owns 4
+// consecutive columns), two blocks per round of residual / gate loads.
+#include "conv_common.h"
+
+namespace dadet {
+
+namespace {
+constexpr unsigned kBigOOB = 0x80000000u;   // an invalid row: beyond any buffer the dispatcher admits (< 2 GB), survives + soffset
+
+// x s = h + l, h = f16(x s), l = f16(x s - h) for four consecutive-k floats.  v_fma_mix{lo,hi}_f16 form the scaled value /
+// the residual in fp32 (both exact: s is a power of two, the residual of a rounding is representable) and round once to
+// fp16 into one half of the destination — the same bits as conv_common.h's split4h at 2 instead of 3 VALU per element.
+__device__ __forceinline__ void split4m(const float4 v, const float s, uint2& h, uint2& l) {
+  unsigned h0, h1, l0, l1;
+  asm("v_fma_mixlo_f16 %0, %1, %2, 0 op_sel_hi:[0,0,0]" : "=v"(h0) : "v"(v.x), "v"(s));
+  asm("v_fma_mixhi_f16 %0, %1, %2, 0 op_sel_hi:[0,0,0]" : "+v"(h0) : "v"(v.y), "v"(s));
+  asm("v_fma_mixlo_f16 %0, %1, %2, 0 op_sel_hi:[0,0,0]" : "=v"(h1) : "v"(v.z), "v"(s));
+  asm("v_fma_mixhi_f16 %0, %1, %2, 0 op_sel_hi:[0,0,0]" : "+v"(h1) : "v"(v.w), "v"(s));
+  asm("v_fma_mixlo_f16 %0, %1, %2, -%3 op_sel_hi:[0,0,1]" : "=v"(l0) : "v"(v.x), "v"(s), "v"(h0));
+  asm("v_fma_mixhi_f16 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "+v"(l0) : "v"(v.y), "v"(s), "v"(h0));
+  asm("v_fma_mixlo_f16 %0, %1, %2, -%3 op_sel_hi:[0,0,1]" : "=v"(l1) : "v"(v.z), "v"(s), "v"(h1));
+  asm("v_fma_mixhi_f16 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "+v"(l1) : "v"(v.w), "v"(s), "v"(h1));
+  h = make_uint2(h0, h1);
+  l = make_uint2(l0, l1);
+}
+
+// m / d for 0 <= m < 2^24 (d > 0, rd = 1 / d): a float estimate and one correction each way
+__device__ __forceinline__ int div_small(const int m, const int d, const float rd, int& rem) {
+  int q = (int)((float)m * rd);
+  int r = m - q * d;
+  if (r < 0) { --q; r += d; }
+  if (r >= d) { ++q; r -= d; }
+  rem = r;
+  return q;
+}
+}  // namespace
+
+template <int BN>
+__global__ __launch_bounds__(512, 2) void conv_big_kernel(const ConvArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  static_assert(BN == 256, "wave layout below is 2 x 4 waves of 128 x 64");
+  constexpr int TM = 4, TN = 2;
+  constexpr int kPlane = 256 * 64;          // one fp16 plane of 256 rows x 32 k
+  constexpr int kStage = 4 * kPlane;        // A_h | A_l | B_h | B_l
+  const int t = threadIdx.x, lane = t & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(t >> 6);   // wave-uniform: everything derived from it stays scalar
+  const int grp = wave >> 2, tg = t & 255;
+  const int wm = wave >> 2, wn = wave & 3;
+  const int T = a.tiles_m * a.tiles_n, S = a.big_splits;
+  // workgroup -> (K part, tile): hardware deals workgroup b to XCD b % 8; the remap gives every XCD a contiguous range of
+  // (part, tile) pairs, i.e. neighbouring tiles of one K range, which share operand panels in that XCD's L2
+  const int lid = xcd_remap(blockIdx.x, T * S);
+  const int part = lid / T, tile = lid - part * T;
+  const int bm0 = (tile / a.tiles_n) * 256, bn0 = (tile % a.tiles_n) * BN;
+  const int nk = a.K / 32;
+  const int kt_lo = (int)(((long long)nk * part) / S), kt_hi = (int)(((long long)nk * (part + 1)) / S);
+  const int nT = kt_hi - kt_lo;
+
+  const int ea = a.amax_x ? fmt4_exp(amax_read(a.amax_x)) : 0;
+  const int eb = a.amax_w ? fmt4_exp(amax_read(a.amax_w)) : 0;
+  const float sc = pow2f(grp ? eb : ea);
+
+  // ---- staging state: 8 lanes per 128-byte row, 32 rows per pass, 4 passes = one QUARTER of a K-tile (half of the
+  // group's operand: 128 rows).  Quarter q of a group = (K-tile q / 2 of the part, half q % 2).
+  const int lcol = tg & 7, lrow = tg >> 3;
+  const __amdgpu_buffer_rsrc_t rr = grp ? make_rsrc(a.w, a.w_bytes) : make_rsrc(a.x, a.x_bytes);
+  unsigned goff[2][4];          // byte offset of this thread's 16 bytes in row (half, pass) at the load stream's tap
+  // group 0's row descriptors (first pixel of the row's image, hi0 << 16 | wi0 & 0xffff) live in LDS behind the two
+  // K-tile slots: they are needed only when the load stream crosses into the next filter tap
+  int* desc = reinterpret_cast<int*>(smem + 2 * kStage) + tg;      // [16][256] ints, element k at desc[k * 256]
+  // load stream: K-tile index (absolute), channel offset inside the tap, tap row / column
+  int ld_kt = kt_lo, ld_kc, ld_kr, ld_ks;
+  {
+    const int k0 = kt_lo * 32;
+    const int tap = k0 / a.Cin;
+    ld_kc = k0 - tap * a.Cin;
+    ld_kr = tap / a.KW;
+    ld_ks = tap - ld_kr * a.KW;
+  }
+  auto recompute = [&]() {      // group 0: offsets of the eight rows at tap (ld_kr, ld_ks)
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int px = desc[(h * 4 + i) * 256], hw = desc[(8 + h * 4 + i) * 256];
+        const int hi = (hw >> 16) + ld_kr, wi = (int)(short)(hw & 0xffff) + ld_ks;
+        const bool ok = ((unsigned)hi < (unsigned)a.H) & ((unsigned)wi < (unsigned)a.W);   // no short circuit: no branches
+        goff[h][i] = ok ? ((unsigned)(px + hi * a.W + wi) * (unsigned)a.Cin + (unsigned)(lcol * 4)) * 4u : kBigOOB;
+      }
+  };
+  if (grp == 0) {
+    const int HoWo = a.Ho * a.Wo;
+    const float r_howo = 1.0f / (float)HoWo, r_wo = 1.0f / (float)a.Wo;
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int m = bm0 + h * 128 + lrow + 32 * i;
+        int px = 0, hw = (int)0xC0000000;     // hi0 = -16384: no tap brings an invalid row inside the map
+        if (m < a.M) {
+          int rem, wo;
+          const int img = div_small(m, HoWo, r_howo, rem);
+          const int ho = div_small(rem, a.Wo, r_wo, wo);
+          px = img * a.H * a.W;
+          hw = (int)(((unsigned)(ho * a.stride - a.pad) << 16) | ((unsigned)(wo * a.stride - a.pad) & 0xffffu));
+        }
+        desc[(h * 4 + i) * 256] = px;
+        desc[(8 + h * 4 + i) * 256] = hw;
+      }
+    recompute();                // (a thread reads back its own words only: no barrier needed)
+  } else {
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int n = bn0 + h * 128 + lrow + 32 * i;
+        goff[h][i] = n < a.Cout ? ((unsigned)n * (unsigned)a.K + (unsigned)(lcol * 4)) * 4u : kBigOOB;
+      }
+  }
+  // this thread's 8-byte piece inside a plane, pass i of half h at + (h * 128 + 32 * i) * 64
+  const unsigned wofs = (grp ? 2 * kPlane : 0) + lrow * 64 + ((((lcol >> 1) ^ ((lrow >> 2) & 3))) << 4) + (lcol & 1) * 8;
+  const int fr = lane & 31;
+  const unsigned fo = fr * 64 + ((((lane >> 5)) ^ ((fr >> 2) & 3)) << 4);
+  const unsigned fa_base = (wm * 128) * 64 + fo;
+  const unsigned fb_base = 2 * kPlane + (wn * 64) * 64 + fo;
+
+  // two staging buffers: a load segment first issues the global loads of the quarter after next into one of them, then
+  // splits and stores the other (fetched one load segment — a multiply segment and a half — earlier)
+  float4 raw[2][4];
+  f16x8 fa[2][TM], fb[2][TN];
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  // fetch the load stream's next quarter; after a second half the stream moves on by one K-tile.  Past the part's last
+  // K-tile the stream keeps walking (the data lands in a slot nobody reads again); offsets beyond a buffer return zeros.
+  auto loads = [&](float4 (&dst)[4], const int half) {
+    const int soff = grp ? ld_kt * 128 : ld_kc * 4;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      dst[i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rr, (int)(half ? goff[1][i] : goff[0][i]), soff, 0));
+    if (half) {
+      ++ld_kt;
+      ld_kc += 32;
+      if (ld_kc >= a.Cin) {
+        ld_kc = 0;
+        if (++ld_ks == a.KW) { ld_ks = 0; ++ld_kr; }
+        if (grp == 0) recompute();
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);      // the loads go out FIRST in their segment
+  };
+  auto stage = [&](const float4 (&v)[4], const int slot, const int half) {
+    char* st = smem + slot * kStage + wofs + half * (128 * 64);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      uint2 h, l;
+      split4m(v[i], sc, h, l);
+      *reinterpret_cast<uint2*>(st + i * 2048) = h;
+      *reinterpret_cast<uint2*>(st + kPlane + i * 2048) = l;
+    }
+  };
+  auto read_frags = [&](const int slot, const int step) {
+    const char* cur = smem + slot * kStage;
+    // in the order the MFMAs want them: l_a h_b first
+#pragma unroll
+    for (int i = 0; i < TN; ++i) fb[0][i] = *reinterpret_cast<const f16x8*>(cur + ((fb_base + i * 2048) ^ (step * 32)));
+#pragma unroll
+    for (int i = 0; i < TM; ++i) fa[1][i] = *reinterpret_cast<const f16x8*>(cur + kPlane + ((fa_base + i * 2048) ^ (step * 32)));
+#pragma unroll
+    for (int i = 0; i < TM; ++i) fa[0][i] = *reinterpret_cast<const f16x8*>(cur + ((fa_base + i * 2048) ^ (step * 32)));
+#pragma unroll
+    for (int i = 0; i < TN; ++i) fb[1][i] = *reinterpret_cast<const f16x8*>(cur + kPlane + ((fb_base + i * 2048) ^ (step * 32)));
+  };
+  // multiply segment: the 24 MFMAs of one k16 step and NOTHING else (smallest cross terms first: l_a h_b, h_a l_b, h_a h_b).
+  // (Measured, round 5: the split's VALU placed behind these MFMAs instead of in the load segment — 0.464 -> 0.445 of the
+  // ceiling on 16384 x 4096 x 4096: a wave's own VALU between its MFMAs costs the pipe more than the partner's.)
+  auto mfma_seg = [&]() {
+#pragma unroll
+    for (int term = 0; term < 3; ++term) {
+      const int pa = term == 0 ? 1 : 0, pb = term == 1 ? 1 : 0;
+#pragma unroll
+      for (int im = 0; im < TM; ++im)
+#pragma unroll
+        for (int in = 0; in < TN; ++in)
+          acc[im][in] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[pa][im], fb[pb][in], acc[im][in], 0, 0, 0);
+    }
+  };
+  auto bar = [&]() {
+    __builtin_amdgcn_sched_barrier(0);
+    __syncthreads();
+    __builtin_amdgcn_sched_barrier(0);
+  };
+
+  // Schedule (quarters q of a group's own operand; K-tile T of the part in slot T & 1):
+  //   group 0 multiplies in even segments; its load segment 2v + 1 stores quarter v + 3 and fetches quarter v + 4
+  //   group 1 multiplies in odd segments;  its load segment 2v     stores quarter v + 2 and fetches quarter v + 3
+  // prologue: quarters 0 .. 2 (group 0) / 0 .. 1 (group 1) stored synchronously, the next one in flight
+  loads(raw[0], 0); stage(raw[0], 0, 0);
+  loads(raw[1], 1); stage(raw[1], 0, 1);
+  loads(raw[0], 0);
+  if (grp == 0) {
+    stage(raw[0], 1, 0);
+    loads(raw[1], 1);
+  }
+  bar();
+  if (grp == 0) {
+    read_frags(0, 0);
+    for (int Tt = 0; Tt < nT; ++Tt) {
+      const int cur = Tt & 1;
+      mfma_seg();                                                      // segment 4T: step 2T
+      bar();
+      loads(raw[0], 0); read_frags(cur, 1); stage(raw[1], cur ^ 1, 1);  // segment 4T + 1: second half of K-tile T + 1
+      bar();
+      mfma_seg();                                                      // segment 4T + 2: step 2T + 1
+      bar();
+      loads(raw[1], 1); read_frags(cur ^ 1, 0); stage(raw[0], cur, 0);  // segment 4T + 3: first half of K-tile T + 2
+      bar();
+    }
+  } else {
+    for (int Tt = 0; Tt < nT; ++Tt) {
+      const int cur = Tt & 1;
+      loads(raw[1], 1); read_frags(cur, 0); stage(raw[0], cur ^ 1, 0);  // segment 4T: first half of K-tile T + 1
+      bar();
+      mfma_seg();                                                      // segment 4T + 1: step 2T
+      bar();
+      loads(raw[0], 0); read_frags(cur, 1); stage(raw[1], cur ^ 1, 1);  // segment 4T + 2: second half of K-tile T + 1
+      bar();
+      mfma_seg();                                                      // segment 4T + 3: step 2T + 1
+      bar();
+    }
+  }
+
+  {
+    // undo the operand scales (exact: powers of two, in two steps so that no intermediate leaves fp32's range unless the
+    // result does): the parts of a split reduction are parked in true units
+    const int tt = -(ea + eb);
+    const float u1 = pow2f(tt / 2), u2 = pow2f(tt - tt / 2);
+#pragma unroll
+    for (int im = 0; im < TM; ++im)
+#pragma unroll
+      for (int in = 0; in < TN; ++in)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[im][in][e] = acc[im][in][e] * u1 * u2;
+  }
+
+  int* s_word = reinterpret_cast<int*>(smem);        // the operand planes are dead (every wave passed the last barrier)
+  if (S > 1) {
+    const __amdgpu_buffer_rsrc_t pr = make_rsrc(a.sk_ws + (size_t)tile * S * (256 * BN), (unsigned)(S * 256 * BN * 4));
+    int* arrive = a.sk_counters + tile;
+    int* parked = a.sk_counters + 2048 + tile;
+    if (t == 0) s_word[0] = __hip_atomic_fetch_add(arrive, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    const int ticket = s_word[0];
+    if (ticket != S - 1) {
+      // park: lane-linear, 16 bytes per lane and store, written through to memory
+      const unsigned mine = (unsigned)part * (256 * BN * 4) + (unsigned)t * 16u;
+#pragma unroll
+      for (int im = 0; im < TM; ++im)
+#pragma unroll
+        for (int in = 0; in < TN; ++in)
+#pragma unroll
+          for (int g = 0; g < 4; ++g)
+            buf_store4_wt(pr, mine + ((im * TN + in) * 4 + g) * 8192u,
+                          make_float4(acc[im][in][g * 4], acc[im][in][g * 4 + 1], acc[im][in][g * 4 + 2],
+                                      acc[im][in][g * 4 + 3]));
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // every wave drains its stores ...
+      __syncthreads();                                    // ... before one lane announces the part
+      if (t == 0) __hip_atomic_fetch_add(parked, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      return;
+    }
+    // the last part to arrive: the others have left their K loops (they hold tickets) and only finish their stores
+    if (t == 0) {
+      while (__hip_atomic_load(parked, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != S - 1) __builtin_amdgcn_s_sleep(8);
+      *arrive = 0;        // ready for the next launch on this stream (no memset per launch)
+      *parked = 0;
+    }
+    __syncthreads();
+    // sum in part order, this part's registers at its own index: the result does not depend on who came last
+#pragma unroll
+    for (int im = 0; im < TM; ++im)
+#pragma unroll
+      for (int in = 0; in < TN; ++in) {
+        float4 own[4], sum[4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          own[g] = make_float4(acc[im][in][g * 4], acc[im][in][g * 4 + 1], acc[im][in][g * 4 + 2], acc[im][in][g * 4 + 3]);
+          sum[g] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        for (int p = 0; p < S; ++p) {
+          float4 v[4];
+          if (p != part) {
+            const unsigned src = (unsigned)p * (256 * BN * 4) + (unsigned)t * 16u + ((im * TN + in) * 4) * 8192u;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) v[g] = buf_load4_sc1(pr, src + g * 8192u);
+          } else {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) v[g] = own[g];
+          }
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            sum[g].x += v[g].x; sum[g].y += v[g].y; sum[g].z += v[g].z; sum[g].w += v[g].w;
+          }
+        }
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          acc[im][in][g * 4] = sum[g].x; acc[im][in][g * 4 + 1] = sum[g].y;
+          acc[im][in][g * 4 + 2] = sum[g].z; acc[im][in][g * 4 + 3] = sum[g].w;
+        }
+      }
+    __syncthreads();      // s_word is about to be reused as transpose space
+  }
+
+  // ---- epilogue: y = gate(acc * scale + bias + addend), 16 bytes per lane through an LDS transpose (conv_split.hip:
+  // conv_epilogue_v4), the same arithmetic per element in the same order
+  float* tile_f = reinterpret_cast<float*>(smem) + wave * (2 * 32 * EPI_STRIDE);
+  const __amdgpu_buffer_rsrc_t yr = make_rsrc(a.y, a.y_bytes);
+  const __amdgpu_buffer_rsrc_t ar = make_rsrc(a.addend ? a.addend : a.y, a.addend ? a.y_bytes : 0u);
+  const __amdgpu_buffer_rsrc_t mr = make_rsrc(a.mask_ref ? a.mask_ref : a.y, a.mask_ref ? a.y_bytes : 0u);
+  const int col_in = lane & 31, row_hi = 4 * (lane >> 5);
+  const int rrow = lane >> 3, c4 = (lane & 7) * 4;
+  float mx = 0.f;
+#pragma unroll
+  for (int in = 0; in < TN; ++in) {
+    const int n = bn0 + wn * 64 + in * 32 + c4;
+    const bool nvalid = n < a.Cout;                      // Cout % 4 == 0: the four columns are valid together
+    float4 scv = make_float4(1.f, 1.f, 1.f, 1.f), biv = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (a.scale && nvalid) scv = *reinterpret_cast<const float4*>(a.scale + n);
+    if (a.bias && nvalid) biv = *reinterpret_cast<const float4*>(a.bias + n);
+#pragma unroll
+    for (int q = 0; q < TM / 2; ++q) {
+      unsigned offs[2][4];
+      float4 ad[2][4], mk[2][4];
+#pragma unroll
+      for (int b = 0; b < 2; ++b)
+#pragma unroll
+        for (int pass = 0; pass < 4; ++pass) {
+          const int m = bm0 + wm * 128 + (2 * q + b) * 32 + pass * 8 + rrow;
+          offs[b][pass] = (nvalid && m < a.M) ? ((unsigned)m * (unsigned)a.Cout + (unsigned)n) * 4u : kBigOOB;
+        }
+      if (a.addend) {
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+          for (int pass = 0; pass < 4; ++pass) ad[b][pass] = buf_load4(ar, offs[b][pass]);
+      }
+      if (a.relu_mode == 2) {
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+          for (int pass = 0; pass < 4; ++pass) mk[b][pass] = buf_load4(mr, offs[b][pass]);
+      }
+#pragma unroll
+      for (int b = 0; b < 2; ++b) {
+        const int im = 2 * q + b;
+        float* tl = tile_f + b * (32 * EPI_STRIDE);
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) tl[(e + 8 * g + row_hi) * EPI_STRIDE + col_in] = acc[im][in][g * 4 + e];
+      }
+      // a wave's own data only: no workgroup barrier, the LDS traffic of one wave is ordered
+      __builtin_amdgcn_s_waitcnt(0xc07f);                // lgkmcnt(0)
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int b = 0; b < 2; ++b) {
+        const float* tl = tile_f + b * (32 * EPI_STRIDE);
+#pragma unroll
+        for (int pass = 0; pass < 4; ++pass) {
+          const int row = pass * 8 + rrow;
+          const float4 v4 = *reinterpret_cast<const float4*>(tl + row * EPI_STRIDE + c4);
+          const unsigned off = offs[b][pass];
+          float v[4] = {v4.x, v4.y, v4.z, v4.w};
+          const float s4[4] = {scv.x, scv.y, scv.z, scv.w}, b4[4] = {biv.x, biv.y, biv.z, biv.w};
+          float adv[4] = {0.f, 0.f, 0.f, 0.f}, mkv[4] = {1.f, 1.f, 1.f, 1.f};
+          if (a.addend) {
+            const float4 tv = ad[b][pass];
+            adv[0] = tv.x; adv[1] = tv.y; adv[2] = tv.z; adv[3] = tv.w;
+          }
+          if (a.relu_mode == 2) {
+            const float4 tv = mk[b][pass];
+            mkv[0] = tv.x; mkv[1] = tv.y; mkv[2] = tv.z; mkv[3] = tv.w;
+          }
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            float x = v[e];
+            if (a.scale) x = x * s4[e];
+            if (a.bias) x = x + b4[e];
+            if (a.addend) x = x + adv[e];
+            if (a.relu_mode == 1) x = fmaxf(x, 0.f);
+            else if (a.relu_mode == 2) x = (mkv[e] > 0.f) ? x : 0.f;
+            v[e] = x;
+          }
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, make_float4(v[0], v[1], v[2], v[3])), yr,
+                                                 (int)off, 0, 0);
+          if (a.amax_y && off != kBigOOB)
+            mx = fmaxf(fmaxf(mx, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
+        }
+      }
+      __builtin_amdgcn_wave_barrier();                   // the transpose space is rewritten by the next round
+    }
+  }
+  if (a.amax_y) amax_publish(a.amax_y, mx);
+}
+
+// ---- host side -------------------------------------------------------------------------------------------------------
+// 0: never, 1: where the plan below expects a gain, 2: wherever the kernel is applicable (tests).  DADET_BIG_GEMM sets the
+// start-up value (A/B runs); dadet_set_big_gemm changes it at run time
+static int g_big_mode = [] {
+  const char* e = getenv("DADET_BIG_GEMM");
+  const int v = e ? atoi(e) : 1;
+  return v >= 0 && v <= 2 ? v : 1;
+}();
+
+// Number of K ranges a tile's reduction is cut into.  Reductions of K >= 4096 (the RPN 3x3 conv, res5 3x3) are ALWAYS cut in
+// two: the hand-over (the last part reads one parked tile, ~4 us) is small against >= 144 K-tiles per tile, and the result of
+// such a layer then does not depend on how many rows the launch happens to have — the overlapped training schedule runs
+// the RPN head on the labelled images only, the plain one on all of them, and tests/test_full_size_gpu.py asks both for
+// the same sampled ROIs.  Shorter reductions are cut in two only when the grid leaves half of the CUs without a tile.
+static int big_split_plan(const int tiles, const int nk) {
+  if (const char* e = getenv("DADET_BIG_SPLITS")) {     // read per call: tests and A/B runs force the part count
+    const int v = atoi(e);
+    if (v >= 1 && v <= 8 && nk / v >= 1) return v;
+  }
+  if (nk >= 128) return 2;
+  return (tiles <= kNumCU / 2 && nk >= 16) ? 2 : 1;
+}
+
+bool big_eligible(const ConvArgs& a) {
+  if (g_big_mode == 0) return false;
+  if (a.os != 1 || !a.epi_v4 || a.Cin % 32 != 0 || a.K % 32 != 0 || a.Cout % 4 != 0) return false;
+  if (a.x_bytes >= 0x7FFFFF00u || a.w_bytes >= 0x7FFFFF00u || a.y_bytes >= 0x7FFFFF00u) return false;
+  if (a.M >= (1 << 24)) return false;
+  if (g_big_mode == 2) return true;
+  // plan: long reductions over wide outputs — what the 128 x 128 kernel serves worst (profiles/r05_gemm_lab.txt)
+  // (tools/native/gemm_lab.hip, profiles/r05_gemm_lab.txt: +29 .. +35% where the grid fills the chip with at most two K
+  // parts per tile; 64 tiles in four parts — res4 3x3 — only equal the 128 x 128 kernel: the last part reads 768 KB)
+  if (a.Cout < 256 || a.K < 512 || a.M < 4096) return false;
+  const int tiles = ceil_div(a.M, 256) * ceil_div(a.Cout, 256);
+  if (tiles < 96) return false;
+  return true;
+}
+
+int launch_fwd_big(ConvArgs& a, hipStream_t st, float* ws, int* counters) {
+  constexpr int BN = 256;
+  a.tiles_m = ceil_div(a.M, 256);
+  a.tiles_n = ceil_div(a.Cout, BN);
+  const int tiles = a.tiles_m * a.tiles_n;
+  a.big_splits = (ws && counters && tiles <= 2048) ? big_split_plan(tiles, a.K / 32) : 1;
+  a.sk_ws = ws;
+  a.sk_counters = counters;
+  const size_t lds = 2 * 4 * 256 * 64 + 16 * 256 * sizeof(int);   // two K-tile slots + group 0's row descriptors
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_big_kernel<BN>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) {
+      set_error("conv_forward(big): hipFuncSetAttribute: %s", hipGetErrorString(e));
+      return DADET_ELAUNCH;
+    }
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((conv_big_kernel<BN>), dim3(tiles * a.big_splits), dim3(512), lds, st, a);
+  return check_launch("conv_forward(big)");
+}
+
+size_t big_workspace_bytes(const ConvArgs& a) {
+  const int tiles = ceil_div(a.M, 256) * ceil_div(a.Cout, 256);
+  const int s = tiles <= 2048 ? big_split_plan(tiles, a.K / 32) : 1;
+  return s > 1 ? (size_t)tiles * s * 256 * 256 * sizeof(float) : 0;
+}
+
+}  // namespace dadet
+
+extern "C" int dadet_set_big_gemm(int mode) {
+  if (mode < 0 || mode > 2) {
+    dadet::set_error("set_big_gemm: mode must be 0 (off), 1 (planned) or 2 (wherever applicable)");
+    return DADET_EINVAL;
+  }
+  dadet::g_big_mode = mode;
+  return DADET_OK;
+}
+extern "C" int dadet_get_big_gemm(void) { return dadet::g_big_mode; }

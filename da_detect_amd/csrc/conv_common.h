@@ -191,6 +191,9 @@ struct ConvArgs {
   int sk_dp_tiles, sk_tiles, sk_units, sk_iters, sk_max_parts;
   float* sk_ws;
   int* sk_counters;
+  // large-tile kernel (conv_big.hip): number of K ranges a tile's reduction is cut into (0: another kernel runs); the
+  // parts meet in sk_ws ([tile][part][256 x 256] floats) under sk_counters[tile] (arrivals) / [2048 + tile] (parked)
+  int big_splits;
   // mode 4 (fp16 two-term split): max|x|, max|w| of the operands (device floats; null = scale 1) and the slot that
   // receives max|y| of what this launch stores (null = not wanted; zero or an earlier launch's maximum before)
   const float* amax_x;
@@ -236,6 +239,11 @@ int gemm_mode();
 int launch_fwd_split(ConvArgs& a, int variant, int fmt, hipStream_t st);
 int launch_fwd_split_sk(ConvArgs& a, int fmt, hipStream_t st);
 int launch_wgrad_split(WgradArgs& a, int fmt, hipStream_t st);
+// 256 x 256-tile kernel of mode 4 for the long-K layers (conv_big.hip); ws / counters: split-reduction workspace of
+// big_workspace_bytes(a) bytes and the stream's zeroed counters (may be null when that is 0)
+bool big_eligible(const ConvArgs& a);
+size_t big_workspace_bytes(const ConvArgs& a);
+int launch_fwd_big(ConvArgs& a, hipStream_t st, float* ws, int* counters);
 // weight-stationary 1x1 kernel for K = 64 / 128 / 256 (conv_ws.hip)
 bool ws_eligible(const ConvArgs& a);
 int launch_fwd_ws(ConvArgs& a, int fmt, hipStream_t st);

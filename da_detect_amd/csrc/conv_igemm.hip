@@ -860,6 +860,17 @@ static int conv_forward_impl(const dadet_conv_desc* d, const float* x, const flo
     a.amax_y = reinterpret_cast<unsigned*>(amax_y);
   }   // (the other modes neither read nor leave maxima)
   if (gemm_mode() >= 3 && ws_eligible(a)) return launch_fwd_ws(a, gemm_mode(), st);   // weight-stationary 1x1, K <= 256
+  a.big_splits = 0;
+  if (gemm_mode() == 4 && big_eligible(a)) {                                           // 256 x 256 tiles, long K
+    const size_t ws_bytes = big_workspace_bytes(a);
+    float* ws = ws_bytes ? static_cast<float*>(stream_scratch(st, ws_bytes)) : nullptr;
+    int* counters = ws_bytes ? stream_counters(st) : nullptr;
+    if (ws_bytes && (!ws || !counters)) {
+      set_error("conv_forward: could not allocate %zu bytes of split-reduction scratch", ws_bytes);
+      return DADET_ELAUNCH;
+    }
+    return launch_fwd_big(a, st, ws, counters);
+  }
   if (gemm_mode() != 0) {
     const int variant = split_fwd_variant(a.M, a.Cout, a.K);
     SkPlan sk;
@@ -938,6 +949,15 @@ extern "C" int dadet_conv_forward_variant(const dadet_conv_desc* d) {
     a.x_bytes = (unsigned)((uint64_t)d->N * d->H * d->W * d->Cin * 4 > 0x7FFFFFFFull ? 0x80000000u : (uint64_t)d->N * d->H * d->W * d->Cin * 4);
     a.w_bytes = 0;
     if (ws_eligible(a)) return 3;
+    if (gemm_mode() == 4) {    // 4: the 256 x 256-tile kernel (conv_big.hip)
+      a.Cin = d->Cin;
+      const uint64_t xb = (uint64_t)d->N * d->H * d->W * d->Cin * 4, wb = (uint64_t)d->Cout * a.K * 4,
+                     yb = (uint64_t)d->N * d->OutH * d->OutW * d->Cout * 4;
+      a.x_bytes = xb > 0x7FFFFFFFull ? 0x80000000u : (unsigned)xb;
+      a.w_bytes = wb > 0x7FFFFFFFull ? 0x80000000u : (unsigned)wb;
+      a.y_bytes = yb > 0x7FFFFFFFull ? 0x80000000u : (unsigned)yb;
+      if (big_eligible(a)) return 4;
+    }
   }
   return gemm_mode() != 0 ? split_fwd_variant(M, d->Cout, d->KH * d->KW * d->Cin) : fwd_variant(M, d->Cout);
 }

@@ -169,6 +169,14 @@ int dadet_conv_forward(const dadet_conv_desc* d, const float* x, const float* w,
 int dadet_set_gemm_mode(int mode);
 int dadet_get_gemm_mode(void);
 
+/* Large-tile kernel of mode 4 (256 x 256 output tile, 8 waves, the two waves of a SIMD alternating between the matrix pipe
+ * and the operand staging; csrc/conv_big.hip) for dadet_conv_forward[_scaled] (process-wide):
+ *   1 (DEFAULT) = on the layers where it is expected to win (Cout >= 256, K >= 1024, M >= 4096, Cin % 32 == 0, unit output stride);
+ *   0 = never;  2 = wherever it is applicable (Cin % 32 == 0, Cout % 4 == 0, 16-byte aligned tensors below 2 GB) — tests.
+ * Results differ from the 128 x 128 kernel's only by fp32 summation order. */
+int dadet_set_big_gemm(int mode);
+int dadet_get_big_gemm(void);
+
 /* Largest magnitudes for mode 4.  A "slot" holds max|t| over a tensor t (an upper bound within a few binades serves as
  * well: it only has to keep t / slot inside fp16's range without wasting it).  It is addressed by one pointer p and
  * consists of EIGHT floats, p[0], p[S], ..., p[7 S] with S = DADET_AMAX_STRIDE: the value is the maximum of the eight

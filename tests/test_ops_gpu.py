@@ -1212,12 +1212,19 @@ def test_vectorised_epilogue_is_bit_identical(device, shape):
              dict(scale=scale, bias=bias, addend=addend, relu_mode=1), dict(addend=addend, mask_ref=mask, relu_mode=2),
              dict(mask_ref=mask, relu_mode=2)]
     out = {}
-    for flag in ("0", "1"):
-        os.environ["DADET_EPILOGUE_V4"] = flag
-        try:
-            out[flag] = [_C.conv_forward(x, w, stride=stride, pad=pad, **kw) for kw in cases]
-        finally:
-            os.environ.pop("DADET_EPILOGUE_V4")
+    from da_detect_amd import _lib
+    lib = _lib.load()
+    big = lib.dadet_get_big_gemm()
+    lib.dadet_set_big_gemm(0)          # the two epilogues of the 128 x 128 kernel (the 256 x 256 one has the 16-byte form only)
+    try:
+        for flag in ("0", "1"):
+            os.environ["DADET_EPILOGUE_V4"] = flag
+            try:
+                out[flag] = [_C.conv_forward(x, w, stride=stride, pad=pad, **kw) for kw in cases]
+            finally:
+                os.environ.pop("DADET_EPILOGUE_V4")
+    finally:
+        lib.dadet_set_big_gemm(big)
     for a, b, kw in zip(out["0"], out["1"], cases):
         assert torch.equal(a, b), sorted(kw)
 

@@ -1,0 +1,750 @@
+// GEMM laboratory for the mode-4 contraction (fp32 operands as two fp16 terms, 3 x v_mfma_f32_32x32x16_f16 per K = 16):
+// what does a larger tile / deeper pipeline return on gfx950, on RANDOM operands, next to the production kernel?
+//   part 1  register-only MFMA streams: bf16 / f16, quiet / random operand bits (the matrix pipe's own ceiling under DVFS)
+//   part 2  C[M][N] = sum_k A[m][k] B[n][k] (a 1x1 convolution), fp32 in / out:
+//             P   production library (dadet_conv_forward_scaled: 128 x 128 tile, 4 waves, 2 workgroups per CU)
+//             B   256 x 256 tile, 8 waves of 128 x 64, double-buffered planes, split in the loop, one barrier per K-tile
+//             C   256 x 256 tile, 8 waves, operand planes pre-split in HBM, LDS filled by buffer_load ... lds
+//   hipcc --offload-arch=gfx950 -O3 -w tools/native/gemm_lab.hip -Lda_detect_amd -ldadet_hip -o tools/native/gemm_lab
+//   LD_LIBRARY_PATH=da_detect_amd tools/native/gemm_lab
+#include <hip/hip_runtime.h>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+#include "../../include/dadet.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); exit(1); } } while (0)
+
+// ---------------------------------------------------------------------------------------------------------------------
+// part 1: MFMA-only streams
+template <bool F16>
+__global__ __launch_bounds__(256, 2) void mfma_stream(const u32x4* __restrict__ frags, float* out, int iters) {
+  f32x16 acc[8];
+  for (int i = 0; i < 8; ++i)
+    for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;
+  u32x4 fa[4], fb[4];
+  for (int i = 0; i < 4; ++i) {
+    fa[i] = frags[(i * 256 + threadIdx.x)];
+    fb[i] = frags[((4 + i) * 256 + threadIdx.x)];
+  }
+  for (int it = 0; it < iters; ++it) {
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        if (F16)
+          acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, fa[(i + r) & 3]),
+                                                          __builtin_bit_cast(f16x8, fb[(i >> 1) & 3]), acc[i], 0, 0, 0);
+        else
+          acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fa[(i + r) & 3]),
+                                                           __builtin_bit_cast(bf16x8, fb[(i >> 1) & 3]), acc[i], 0, 0, 0);
+      }
+  }
+  float s = 0.f;
+  for (int i = 0; i < 8; ++i)
+    for (int e = 0; e < 16; ++e) s += acc[i][e];
+  out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// shared pieces
+constexpr unsigned kOOB = 0xFFFFFFF0u;
+__device__ inline __amdgpu_buffer_rsrc_t make_rsrc(const void* p, unsigned bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, (int)bytes, 0x00020000);
+}
+__device__ inline float pow2f(const int e) { return __builtin_bit_cast(float, (unsigned)(e + 127) << 23); }
+
+// two fp16 planes of four consecutive-k floats scaled by s: h = f16(x s), l = f16(x s - h).  v_fma_mix{lo,hi}_f16 form the
+// scaled value / the residual in fp32 and round once to fp16 into one half of the destination: 2 VALU per element.
+__device__ __forceinline__ void split4(const float4 v, const float s, uint2& h, uint2& l) {
+  unsigned h0, h1, l0, l1;
+  asm("v_fma_mixlo_f16 %0, %1, %2, 0 op_sel_hi:[0,0,0]" : "=v"(h0) : "v"(v.x), "v"(s));
+  asm("v_fma_mixhi_f16 %0, %1, %2, 0 op_sel_hi:[0,0,0]" : "+v"(h0) : "v"(v.y), "v"(s));
+  asm("v_fma_mixlo_f16 %0, %1, %2, 0 op_sel_hi:[0,0,0]" : "=v"(h1) : "v"(v.z), "v"(s));
+  asm("v_fma_mixhi_f16 %0, %1, %2, 0 op_sel_hi:[0,0,0]" : "+v"(h1) : "v"(v.w), "v"(s));
+  asm("v_fma_mixlo_f16 %0, %1, %2, -%3 op_sel_hi:[0,0,1]" : "=v"(l0) : "v"(v.x), "v"(s), "v"(h0));
+  asm("v_fma_mixhi_f16 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "+v"(l0) : "v"(v.y), "v"(s), "v"(h0));
+  asm("v_fma_mixlo_f16 %0, %1, %2, -%3 op_sel_hi:[0,0,1]" : "=v"(l1) : "v"(v.z), "v"(s), "v"(h1));
+  asm("v_fma_mixhi_f16 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "+v"(l1) : "v"(v.w), "v"(s), "v"(h1));
+  h = make_uint2(h0, h1);
+  l = make_uint2(l0, l1);
+}
+
+struct GemmArgs {
+  const float* A;        // [M][K]
+  const float* B;        // [N][K]
+  float* C;              // [M][N]
+  const unsigned short* Ah;   // pre-split planes (variant C): [M][K] fp16 each
+  const unsigned short* Al;
+  const unsigned short* Bh;
+  const unsigned short* Bl;
+  int M, N, K, ea, eb, tiles_m, tiles_n;
+};
+
+__device__ inline int xcd_remap(int bid, int nwg) {
+  const int q = nwg / 8, r = nwg % 8;
+  const int xcd = bid % 8, idx = bid / 8;
+  const int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+  return base + idx;
+}
+
+// LDS image of one stage (64 KB): four planes [256 rows][32 k] fp16 = 64-byte rows, A_h | A_l | B_h | B_l.  The four
+// 16-byte chunks of a row are XOR-swizzled with (row >> 2) & 3: a ds_read_b128 lane group (16 lanes = rows {0-3, 12-15,
+// 20-27} or {4-11, 16-19, 28-31} of one chunk column) then covers all sixteen 16-byte bank groups once.
+constexpr int kPlane = 256 * 64;
+constexpr int kStage = 4 * kPlane;
+
+template <int TM, int TN>
+__device__ __forceinline__ void store_tile(const GemmArgs& a, f32x16 (&acc)[TM][TN], int bm0, int bn0, int wm, int wn,
+                                           int lane, float u1, float u2) {
+  const int col_in = lane & 31, row_hi = 4 * (lane >> 5);
+#pragma unroll
+  for (int im = 0; im < TM; ++im)
+#pragma unroll
+    for (int in = 0; in < TN; ++in) {
+      const int n = bn0 + wn * TN * 32 + in * 32 + col_in;
+#pragma unroll
+      for (int g = 0; g < 4; ++g)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int m = bm0 + wm * TM * 32 + im * 32 + q + 8 * g + row_hi;
+          if (m < a.M && n < a.N) a.C[(size_t)m * a.N + n] = acc[im][in][g * 4 + q] * u1 * u2;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// variant B: 256 x 256 x 32, 8 waves (2 x 4) of 128 x 64, split at staging time, two stages, one barrier per K-tile
+//   SCHED 0: compiler's order, 1: sched_group_barrier pattern
+template <int SCHED>
+__global__ __launch_bounds__(512, 2) void gemm_b_kernel(const GemmArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int TM = 4, TN = 2;
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int wm = wave >> 2, wn = wave & 3;
+  const int tile = xcd_remap(blockIdx.x, a.tiles_m * a.tiles_n);
+  const int bm0 = (tile / a.tiles_n) * 256, bn0 = (tile % a.tiles_n) * 256;
+  const float sa = pow2f(a.ea), sb = pow2f(a.eb);
+  const int lcol = t & 7, lrow = t >> 3;
+  const __amdgpu_buffer_rsrc_t ar = make_rsrc(a.A, (unsigned)((size_t)a.M * a.K * 4));
+  const __amdgpu_buffer_rsrc_t br = make_rsrc(a.B, (unsigned)((size_t)a.N * a.K * 4));
+  unsigned aoff[4], boff[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int m = bm0 + lrow + 64 * i, n = bn0 + lrow + 64 * i;
+    aoff[i] = m < a.M ? ((unsigned)m * (unsigned)a.K + lcol * 4) * 4u : kOOB;
+    boff[i] = n < a.N ? ((unsigned)n * (unsigned)a.K + lcol * 4) * 4u : kOOB;
+  }
+  const unsigned wofs = lrow * 64 + ((((lcol >> 1) ^ ((lrow >> 2) & 3))) << 4) + (lcol & 1) * 8;
+  const int fr = lane & 31;
+  const unsigned fo = fr * 64 + ((((lane >> 5)) ^ ((fr >> 2) & 3)) << 4);
+  const unsigned fa_base = (wm * 128) * 64 + fo;
+  const unsigned fb_base = 2 * kPlane + (wn * 64) * 64 + fo;
+
+  float4 ra[4], rb[4];
+  auto load_a = [&](int kt) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      ra[i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(ar, (int)aoff[i], kt * 128, 0));
+  };
+  auto load_b = [&](int kt) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      rb[i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(br, (int)boff[i], kt * 128, 0));
+  };
+  auto stage_a = [&](char* st) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      uint2 h, l;
+      split4(ra[i], sa, h, l);
+      *reinterpret_cast<uint2*>(st + wofs + i * 4096) = h;
+      *reinterpret_cast<uint2*>(st + kPlane + wofs + i * 4096) = l;
+    }
+  };
+  auto stage_b = [&](char* st) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      uint2 h, l;
+      split4(rb[i], sb, h, l);
+      *reinterpret_cast<uint2*>(st + 2 * kPlane + wofs + i * 4096) = h;
+      *reinterpret_cast<uint2*>(st + 3 * kPlane + wofs + i * 4096) = l;
+    }
+  };
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  const int nk = a.K / 32;
+  load_a(0);
+  load_b(0);
+  stage_a(smem);
+  stage_b(smem);
+  load_a(nk > 1 ? 1 : 0);
+  load_b(nk > 1 ? 1 : 0);
+  __syncthreads();
+
+  for (int kt = 0; kt < nk; ++kt) {
+    char* cur = smem + (kt & 1) * kStage;
+    char* nxt = smem + ((kt & 1) ^ 1) * kStage;
+    const int knext = kt + 2 < nk ? kt + 2 : nk - 1;
+#pragma unroll
+    for (int step = 0; step < 2; ++step) {
+      f16x8 fa[2][TM], fb[2][TN];
+#pragma unroll
+      for (int p = 0; p < 2; ++p) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+          fa[p][i] = *reinterpret_cast<const f16x8*>(cur + p * kPlane + ((fa_base + i * 2048) ^ (step * 32)));
+#pragma unroll
+        for (int i = 0; i < TN; ++i)
+          fb[p][i] = *reinterpret_cast<const f16x8*>(cur + p * kPlane + ((fb_base + i * 2048) ^ (step * 32)));
+      }
+      // the other stage receives tile kt + 1: one operand per k16 group, in the shadow of the MFMAs; the freed registers
+      // fetch that operand of tile kt + 2
+      if (step == 0) stage_a(nxt);
+      else stage_b(nxt);
+      // smallest cross terms first: l_a h_b, h_a l_b, h_a h_b
+#pragma unroll
+      for (int term = 0; term < 3; ++term) {
+        const int pa = term == 0 ? 1 : 0, pb = term == 1 ? 1 : 0;
+#pragma unroll
+        for (int im = 0; im < TM; ++im)
+#pragma unroll
+          for (int in = 0; in < TN; ++in)
+            acc[im][in] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[pa][im], fb[pb][in], acc[im][in], 0, 0, 0);
+      }
+      if (step == 0) load_a(knext);
+      else load_b(knext);
+      if (SCHED == 1) {
+        __builtin_amdgcn_sched_group_barrier(0x100, 12, 0);   // fragment reads
+#pragma unroll
+        for (int i = 0; i < 24; ++i) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // one MFMA
+          if (i < 8) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);   // one staging store
+          if (i >= 20) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0); // one global load
+        }
+      }
+    }
+    __syncthreads();
+  }
+  const int tt = -(a.ea + a.eb);
+  store_tile<TM, TN>(a, acc, bm0, bn0, wm, wn, lane, pow2f(tt / 2), pow2f(tt - tt / 2));
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// variant C: operand planes pre-split in HBM ([rows][K] fp16, hi and lo), LDS filled by DMA (buffer_load ... lds):
+// no VALU and no VGPRs in the staging path.  The DMA writes lane-linear (wave-uniform LDS base + lane * 16), so a wave's
+// 64 lanes fill 16 rows x 64 bytes; the XOR swizzle is applied on the SOURCE side: lane (row r, slot p) fetches chunk
+// p ^ ((r >> 2) & 3) of its row.
+template <int DEPTH>
+__global__ __launch_bounds__(512, 2) void gemm_c_kernel(const GemmArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int TM = 4, TN = 2;
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int wm = wave >> 2, wn = wave & 3;
+  const int tile = xcd_remap(blockIdx.x, a.tiles_m * a.tiles_n);
+  const int bm0 = (tile / a.tiles_n) * 256, bn0 = (tile % a.tiles_n) * 256;
+  // each wave fills 32 rows of each of the four planes per K-tile: two DMA instructions (16 rows each) per plane
+  const int drow = lane >> 2, dslot = lane & 3;
+  const __amdgpu_buffer_rsrc_t r_ah = make_rsrc(a.Ah, (unsigned)((size_t)a.M * a.K * 2));
+  const __amdgpu_buffer_rsrc_t r_al = make_rsrc(a.Al, (unsigned)((size_t)a.M * a.K * 2));
+  const __amdgpu_buffer_rsrc_t r_bh = make_rsrc(a.Bh, (unsigned)((size_t)a.N * a.K * 2));
+  const __amdgpu_buffer_rsrc_t r_bl = make_rsrc(a.Bl, (unsigned)((size_t)a.N * a.K * 2));
+  unsigned aoff[2], boff[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int r = wave * 32 + i * 16 + drow;          // row within the 256-row tile
+    const int chunk = dslot ^ ((r >> 2) & 3);
+    const int m = bm0 + r, n = bn0 + r;
+    aoff[i] = m < a.M ? ((unsigned)m * (unsigned)a.K) * 2u + chunk * 16 : kOOB;
+    boff[i] = n < a.N ? ((unsigned)n * (unsigned)a.K) * 2u + chunk * 16 : kOOB;
+  }
+  const int fr = lane & 31;
+  const unsigned fo = fr * 64 + ((((lane >> 5)) ^ ((fr >> 2) & 3)) << 4);
+  const unsigned fa_base = (wm * 128) * 64 + fo;
+  const unsigned fb_base = 2 * kPlane + (wn * 64) * 64 + fo;
+
+  auto dma_tile = [&](int kt, int stage) {
+    char* st = smem + stage * kStage + wave * 2048;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(r_ah, (__attribute__((address_space(3))) void*)(st + i * 1024), 16, (int)aoff[i], kt * 64, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(r_al, (__attribute__((address_space(3))) void*)(st + kPlane + i * 1024), 16, (int)aoff[i], kt * 64, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(r_bh, (__attribute__((address_space(3))) void*)(st + 2 * kPlane + i * 1024), 16, (int)boff[i], kt * 64, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(r_bl, (__attribute__((address_space(3))) void*)(st + 3 * kPlane + i * 1024), 16, (int)boff[i], kt * 64, 0, 0);
+    }
+  };
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  const int nk = a.K / 32;
+  // DEPTH stages in flight: tile kt lives in stage kt % DEPTH (DEPTH = 2: 128 KB of LDS)
+  dma_tile(0, 0);
+  for (int kt = 0; kt < nk; ++kt) {
+    const int stage = kt % DEPTH;
+    // tile kt + 1 goes into the stage every wave finished reading at the barrier that ended iteration kt - 1
+    if (kt + 1 < nk) dma_tile(kt + 1, (kt + 1) % DEPTH);
+    // wait for tile kt only (8 DMAs of tile kt + 1 may stay in flight), then let every wave see it
+    if (kt + 1 < nk) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    char* cur = smem + stage * kStage;
+#pragma unroll
+    for (int step = 0; step < 2; ++step) {
+      f16x8 fa[2][TM], fb[2][TN];
+#pragma unroll
+      for (int p = 0; p < 2; ++p) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+          fa[p][i] = *reinterpret_cast<const f16x8*>(cur + p * kPlane + ((fa_base + i * 2048) ^ (step * 32)));
+#pragma unroll
+        for (int i = 0; i < TN; ++i)
+          fb[p][i] = *reinterpret_cast<const f16x8*>(cur + p * kPlane + ((fb_base + i * 2048) ^ (step * 32)));
+      }
+#pragma unroll
+      for (int term = 0; term < 3; ++term) {
+        const int pa = term == 0 ? 1 : 0, pb = term == 1 ? 1 : 0;
+#pragma unroll
+        for (int im = 0; im < TM; ++im)
+#pragma unroll
+          for (int in = 0; in < TN; ++in)
+            acc[im][in] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[pa][im], fb[pb][in], acc[im][in], 0, 0, 0);
+      }
+    }
+    // every wave is done reading stage kt % DEPTH before iteration kt + 1 overwrites stage (kt + 2) % DEPTH == it (DEPTH 2)
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+  }
+  const int tt = -(a.ea + a.eb);
+  store_tile<TM, TN>(a, acc, bm0, bn0, wm, wn, lane, pow2f(tt / 2), pow2f(tt - tt / 2));
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// variant D: variant B's tile, planes and staging, but the two waves of every SIMD ALTERNATE roles (the guide's 8-phase idea):
+// waves 0-3 (group 0) and waves 4-7 (group 1, one wave of each group per SIMD) run complementary segments separated by
+// workgroup barriers — while one group issues the 24 MFMAs of a k16 step from registers, the other reads its next
+// fragments, splits / stores a quarter of a future K-tile and issues the global loads behind it.  Fragments are read when
+// the wave does NOT multiply: one register set suffices.  Segment s: group 0 multiplies step s / 2 when s is even,
+// group 1 multiplies step (s - 1) / 2 when s is odd.  K-tile T + 1 is written during segments 4T - 1 .. 4T + 2 (group 0
+// stages the A rows, group 1 the B rows, half of them per load segment) into the slot K-tile T - 1 left at segment 4T - 2.
+template <int PRIO>
+__global__ __launch_bounds__(512, 2) void gemm_d_kernel(const GemmArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int TM = 4, TN = 2;
+  const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);   // wave-uniform: scalar
+  const int grp = wave >> 2, tg = t & 255;
+  const int wm = wave >> 2, wn = wave & 3;
+  const int tile = xcd_remap(blockIdx.x, a.tiles_m * a.tiles_n);
+  const int bm0 = (tile / a.tiles_n) * 256, bn0 = (tile % a.tiles_n) * 256;
+  const float sc = pow2f(grp ? a.eb : a.ea);
+  const int lcol = tg & 7, lrow = tg >> 3;            // 32 rows x 128 bytes per pass, 4 passes = 128 rows = half an operand
+  const __amdgpu_buffer_rsrc_t rr = grp ? make_rsrc(a.B, (unsigned)((size_t)a.N * a.K * 4))
+                                        : make_rsrc(a.A, (unsigned)((size_t)a.M * a.K * 4));
+  const int row0 = grp ? bn0 : bm0, rows = grp ? a.N : a.M;
+  unsigned goff[2][4];
+#pragma unroll
+  for (int h = 0; h < 2; ++h)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int r = row0 + h * 128 + lrow + 32 * i;
+      goff[h][i] = r < rows ? ((unsigned)r * (unsigned)a.K + lcol * 4) * 4u : 0x80000000u;
+    }
+  // LDS byte offset of this thread's 8-byte piece inside a plane, for pass i of half h: + (h * 128 + 32 * i) * 64
+  const unsigned wofs = (grp ? 2 * kPlane : 0) + lrow * 64 + ((((lcol >> 1) ^ ((lrow >> 2) & 3))) << 4) + (lcol & 1) * 8;
+  const int fr = lane & 31;
+  const unsigned fo = fr * 64 + ((((lane >> 5)) ^ ((fr >> 2) & 3)) << 4);
+  const unsigned fa_base = (wm * 128) * 64 + fo;
+  const unsigned fb_base = 2 * kPlane + (wn * 64) * 64 + fo;
+
+  float4 rs[4];
+  f16x8 fa[2][TM], fb[2][TN];
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+  const int nT = a.K / 32;
+
+  auto loads = [&](int kt, int half) {
+    kt = kt < nT ? kt : nT - 1;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      rs[i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rr, (int)(half ? goff[1][i] : goff[0][i]), kt * 128, 0));
+  };
+  auto stage = [&](int slot, int half) {
+    char* st = smem + slot * kStage + wofs + half * (128 * 64);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      uint2 h, l;
+      split4(rs[i], sc, h, l);
+      *reinterpret_cast<uint2*>(st + i * 2048) = h;
+      *reinterpret_cast<uint2*>(st + kPlane + i * 2048) = l;
+    }
+  };
+  auto read_frags = [&](int slot, int step) {
+    const char* cur = smem + slot * kStage;
+    // in the order the MFMAs want them: l_a h_b first
+#pragma unroll
+    for (int i = 0; i < TN; ++i) fb[0][i] = *reinterpret_cast<const f16x8*>(cur + ((fb_base + i * 2048) ^ (step * 32)));
+#pragma unroll
+    for (int i = 0; i < TM; ++i) fa[1][i] = *reinterpret_cast<const f16x8*>(cur + kPlane + ((fa_base + i * 2048) ^ (step * 32)));
+#pragma unroll
+    for (int i = 0; i < TM; ++i) fa[0][i] = *reinterpret_cast<const f16x8*>(cur + ((fa_base + i * 2048) ^ (step * 32)));
+#pragma unroll
+    for (int i = 0; i < TN; ++i) fb[1][i] = *reinterpret_cast<const f16x8*>(cur + kPlane + ((fb_base + i * 2048) ^ (step * 32)));
+  };
+  auto mfma_seg = [&]() {
+    if (PRIO) __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int term = 0; term < 3; ++term) {
+      const int pa = term == 0 ? 1 : 0, pb = term == 1 ? 1 : 0;
+#pragma unroll
+      for (int im = 0; im < TM; ++im)
+#pragma unroll
+        for (int in = 0; in < TN; ++in)
+          acc[im][in] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[pa][im], fb[pb][in], acc[im][in], 0, 0, 0);
+    }
+    if (PRIO) __builtin_amdgcn_s_setprio(0);
+  };
+  auto bar = [&]() {
+    __builtin_amdgcn_sched_barrier(0);
+    __syncthreads();
+    __builtin_amdgcn_sched_barrier(0);
+  };
+
+  // prologue: K-tile 0 complete, group 0's half a of K-tile 1 staged (its segment "-1"), the next loads in flight
+  loads(0, 0); stage(0, 0);
+  loads(0, 1); stage(0, 1);
+  if (grp == 0) {
+    loads(1, 0); stage(1, 0);
+    loads(1, 1);
+  } else {
+    loads(1, 0);
+  }
+  bar();
+  if (grp == 0) {
+    read_frags(0, 0);
+    for (int T = 0; T < nT; ++T) {
+      const int cur = T & 1;
+      mfma_seg();                                                  // segment 4T: step 2T
+      bar();
+      read_frags(cur, 1); stage(cur ^ 1, 1); loads(T + 2, 0);      // segment 4T + 1
+      bar();
+      mfma_seg();                                                  // segment 4T + 2: step 2T + 1
+      bar();
+      read_frags(cur ^ 1, 0); stage(cur, 0); loads(T + 2, 1);      // segment 4T + 3
+      bar();
+    }
+  } else {
+    for (int T = 0; T < nT; ++T) {
+      const int cur = T & 1;
+      read_frags(cur, 0); stage(cur ^ 1, 0); loads(T + 1, 1);      // segment 4T
+      bar();
+      mfma_seg();                                                  // segment 4T + 1: step 2T
+      bar();
+      read_frags(cur, 1); stage(cur ^ 1, 1); loads(T + 2, 0);      // segment 4T + 2
+      bar();
+      mfma_seg();                                                  // segment 4T + 3: step 2T + 1
+      bar();
+    }
+  }
+  const int tt = -(a.ea + a.eb);
+  store_tile<TM, TN>(a, acc, bm0, bn0, wm, wn, lane, pow2f(tt / 2), pow2f(tt - tt / 2));
+}
+
+// what does a raw buffer load return when voffset marks "invalid" and soffset is added?  out[0..3]
+__global__ void oob_probe(const float* p, unsigned bytes, float* out) {
+  const __amdgpu_buffer_rsrc_t r = make_rsrc(p, bytes);
+  if (threadIdx.x == 0) {
+    out[0] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, (int)0xFFFFFFF0u, 0, 0));
+    out[1] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, (int)0xFFFFFFF0u, 128, 0));   // wraps to 112?
+    out[2] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, (int)0x80000000u, 128, 0));
+    out[3] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, 16, 128, 0));                  // element 36
+    out[4] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, (int)(bytes - 64), 128, 0));   // past the end via soffset
+  }
+}
+
+// pre-split pass: x s = h + l, both planes fp16 [rows][K]
+__global__ void presplit_kernel(const float4* __restrict__ x, uint2* __restrict__ h, uint2* __restrict__ l, size_t n4, int e) {
+  const float s = pow2f(e);
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+    uint2 hh, ll;
+    split4(x[i], s, hh, ll);
+    h[i] = hh;
+    l[i] = ll;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+static double gauss(unsigned long long& st) {
+  auto u = [&]() { st = st * 6364136223846793005ULL + 1442695040888963407ULL; return ((st >> 11) + 0.5) / 9007199254740992.0; };
+  return std::sqrt(-2.0 * std::log(u())) * std::cos(6.283185307179586 * u());
+}
+static int fmt4_exp_host(float amax) {
+  int be = (int)((*(unsigned*)&amax >> 23) & 0xffu);
+  if (be == 0 || be == 255) return 0;
+  return 14 - (be - 127);
+}
+
+struct Timer {
+  hipEvent_t e0, e1;
+  Timer() { CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1)); }
+  template <class F> float ms(F f, int reps) {
+    f();
+    CK(hipDeviceSynchronize());
+    float best = 1e30f, sum = 0.f;
+    for (int r = 0; r < reps; ++r) {
+      CK(hipEventRecord(e0));
+      f();
+      CK(hipEventRecord(e1));
+      CK(hipEventSynchronize(e1));
+      float m = 0.f;
+      CK(hipEventElapsedTime(&m, e0, e1));
+      best = m < best ? m : best;
+      sum += m;
+    }
+    last_mean = sum / reps;
+    return best;
+  }
+  float last_mean = 0.f;
+};
+
+static void part1() {
+  printf("== part 1: register-only MFMA streams, 2 waves per SIMD (TFLOP/s of executed MFMA work; nominal 2500)\n");
+  const int blocks = 512;
+  std::vector<unsigned> host(8 * 256 * 4);
+  u32x4* frags; float* out;
+  CK(hipMalloc(&frags, host.size() * 4));
+  CK(hipMalloc(&out, blocks * 256 * 4));
+  Timer tm;
+  for (int fmt = 0; fmt < 2; ++fmt)         // 0 bf16, 1 f16
+    for (int fill = 0; fill < 3; ++fill) {  // 0 zeros, 1 small integers, 2 hi/lo terms of gaussians
+      unsigned long long st = 12345;
+      for (size_t i = 0; i < host.size(); ++i) {
+        unsigned v = 0;
+        if (fill == 1) v = fmt ? 0x3C003C00u : 0x3F803F80u;
+        if (fill == 2) {
+          unsigned short hs[2];
+          for (int j = 0; j < 2; ++j) {
+            const float x = (float)gauss(st) * 4096.f;
+            if (fmt) {
+              _Float16 h = (_Float16)x;
+              const bool lo = (i >> 10) & 1;                    // half of the fragments are residual terms
+              _Float16 v16 = lo ? (_Float16)(x - (float)h) : h;
+              memcpy(&hs[j], &v16, 2);
+            } else {
+              unsigned b; memcpy(&b, &x, 4);
+              unsigned hb = (b + 0x7FFF + ((b >> 16) & 1)) >> 16;
+              const bool lo = (i >> 10) & 1;
+              if (lo) { float hf; unsigned hb32 = hb << 16; memcpy(&hf, &hb32, 4); float r = x - hf; memcpy(&b, &r, 4); hb = (b + 0x7FFF + ((b >> 16) & 1)) >> 16; }
+              hs[j] = (unsigned short)hb;
+            }
+          }
+          v = hs[0] | ((unsigned)hs[1] << 16);
+        }
+        host[i] = v;
+      }
+      CK(hipMemcpy(frags, host.data(), host.size() * 4, hipMemcpyHostToDevice));
+      const int iters = 20000;
+      float ms = fmt ? tm.ms([&] { mfma_stream<true><<<blocks, 256>>>(frags, out, iters); }, 5)
+                     : tm.ms([&] { mfma_stream<false><<<blocks, 256>>>(frags, out, iters); }, 5);
+      const double flops = (double)blocks * 4 * (double)iters * 24.0 * 32768.0;
+      printf("  %-5s %-28s %8.3f ms  %7.0f TF/s\n", fmt ? "f16" : "bf16",
+             fill == 0 ? "zeros" : fill == 1 ? "ones" : "hi / lo terms of gaussians", ms, flops / ms / 1e9);
+    }
+  CK(hipFree(frags));
+  CK(hipFree(out));
+}
+
+static void part2(int M, int N, int K, bool check) {
+  printf("== part 2: M=%d N=%d K=%d  (%.2f GF algorithmic; randn A, 0.02 randn B)\n", M, N, K, 2.0 * M * N * K / 1e9);
+  std::vector<float> hA((size_t)M * K), hB((size_t)N * K);
+  unsigned long long st = 777;
+  float amaxA = 0.f, amaxB = 0.f;
+  for (auto& v : hA) { v = (float)gauss(st); amaxA = fmaxf(amaxA, fabsf(v)); }
+  for (auto& v : hB) { v = (float)gauss(st) * 0.02f; amaxB = fmaxf(amaxB, fabsf(v)); }
+  float *dA, *dB, *dC, *slots;
+  unsigned short *dAh, *dAl, *dBh, *dBl;
+  CK(hipMalloc(&dA, hA.size() * 4)); CK(hipMalloc(&dB, hB.size() * 4)); CK(hipMalloc(&dC, (size_t)M * N * 4));
+  CK(hipMalloc(&dAh, hA.size() * 2)); CK(hipMalloc(&dAl, hA.size() * 2));
+  CK(hipMalloc(&dBh, hB.size() * 2)); CK(hipMalloc(&dBl, hB.size() * 2));
+  CK(hipMalloc(&slots, 8 * DADET_AMAX_STRIDE * 4));
+  CK(hipMemset(slots, 0, 8 * DADET_AMAX_STRIDE * 4));
+  CK(hipMemcpy(dA, hA.data(), hA.size() * 4, hipMemcpyHostToDevice));
+  CK(hipMemcpy(dB, hB.data(), hB.size() * 4, hipMemcpyHostToDevice));
+  GemmArgs g{};
+  g.A = dA; g.B = dB; g.C = dC; g.Ah = dAh; g.Al = dAl; g.Bh = dBh; g.Bl = dBl;
+  g.M = M; g.N = N; g.K = K; g.ea = fmt4_exp_host(amaxA); g.eb = fmt4_exp_host(amaxB);
+  g.tiles_m = (M + 255) / 256; g.tiles_n = (N + 255) / 256;
+  Timer tm;
+  const double gf = 2.0 * M * N * K / 1e9;
+  std::vector<float> hC((size_t)M * N);
+  auto verify = [&](const char* what) {
+    if (!check) return;
+    CK(hipMemcpy(hC.data(), dC, hC.size() * 4, hipMemcpyDeviceToHost));
+    double worst = 0, sumsq = 0; int cnt = 0;
+    unsigned long long s2 = 99;
+    for (int it = 0; it < 4000; ++it) {
+      s2 = s2 * 6364136223846793005ULL + 1442695040888963407ULL;
+      const int m = (int)((s2 >> 33) % M);
+      s2 = s2 * 6364136223846793005ULL + 1442695040888963407ULL;
+      const int n = (int)((s2 >> 33) % N);
+      double ref = 0, mag = 0;
+      for (int k = 0; k < K; ++k) { const double p = (double)hA[(size_t)m * K + k] * hB[(size_t)n * K + k]; ref += p; mag += fabs(p); }
+      const double err = fabs(hC[(size_t)m * N + n] - ref) / (mag / sqrt((double)K) + 1e-30);
+      worst = err > worst ? err : worst; sumsq += err * err; ++cnt;
+    }
+    printf("      %-10s error vs fp64 (relative to |a||b| sqrt K scale): rms %.2e  max %.2e\n", what, sqrt(sumsq / cnt), worst);
+  };
+  // P: production library
+  {
+    dadet_conv_desc d{};
+    d.N = 1; d.H = 1; d.W = M; d.Cin = K; d.Cout = N; d.KH = d.KW = 1; d.stride = 1; d.pad = 0; d.Ho = 1; d.Wo = M;
+    d.OutH = 1; d.OutW = M; d.out_spatial_stride = 1; d.relu_mode = 0;
+    float* sx = slots; float* sw = slots + 1;
+    dadet_amax(dA, (long long)M * K, sx, nullptr);
+    dadet_amax(dB, (long long)N * K, sw, nullptr);
+    CK(hipDeviceSynchronize());
+    int rc = 0;
+    float ms = tm.ms([&] { rc |= dadet_conv_forward_scaled(&d, dA, dB, nullptr, nullptr, nullptr, nullptr, dC, sx, sw, nullptr, nullptr); }, 10);
+    printf("  P  production (variant %d)          %8.4f ms (mean %.4f)  %6.1f TF/s algorithmic  %.3f of 833  rc %d\n",
+           dadet_conv_forward_variant(&d), ms, tm.last_mean, gf / ms, gf / ms / 833.3, rc);
+    verify("P");
+  }
+  const int grid = g.tiles_m * g.tiles_n;
+  CK(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_b_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * kStage));
+  CK(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_b_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * kStage));
+  CK(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_c_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * kStage));
+  {
+    CK(hipMemset(dC, 0, (size_t)M * N * 4));
+    float ms = tm.ms([&] { gemm_b_kernel<0><<<grid, 512, 2 * kStage>>>(g); }, 10);
+    printf("  B0 256x256 split in loop           %8.4f ms (mean %.4f)  %6.1f TF/s algorithmic  %.3f of 833  (%d tiles)\n", ms,
+           tm.last_mean, gf / ms, gf / ms / 833.3, grid);
+    verify("B0");
+    CK(hipMemset(dC, 0, (size_t)M * N * 4));
+    ms = tm.ms([&] { gemm_b_kernel<1><<<grid, 512, 2 * kStage>>>(g); }, 10);
+    printf("  B1 256x256 split in loop, pattern  %8.4f ms (mean %.4f)  %6.1f TF/s algorithmic  %.3f of 833\n", ms, tm.last_mean,
+           gf / ms, gf / ms / 833.3);
+    verify("B1");
+  }
+  {
+    CK(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_d_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * kStage));
+    CK(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_d_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * kStage));
+    CK(hipMemset(dC, 0, (size_t)M * N * 4));
+    float ms = tm.ms([&] { gemm_d_kernel<0><<<grid, 512, 2 * kStage>>>(g); }, 10);
+    printf("  D0 256x256 alternating wave groups %8.4f ms (mean %.4f)  %6.1f TF/s algorithmic  %.3f of 833\n", ms, tm.last_mean,
+           gf / ms, gf / ms / 833.3);
+    verify("D0");
+    CK(hipMemset(dC, 0, (size_t)M * N * 4));
+    ms = tm.ms([&] { gemm_d_kernel<1><<<grid, 512, 2 * kStage>>>(g); }, 10);
+    printf("  D1 the same + s_setprio            %8.4f ms (mean %.4f)  %6.1f TF/s algorithmic  %.3f of 833\n", ms, tm.last_mean,
+           gf / ms, gf / ms / 833.3);
+    verify("D1");
+  }
+  {
+    float msa = tm.ms([&] { presplit_kernel<<<2048, 256>>>((const float4*)dA, (uint2*)dAh, (uint2*)dAl, (size_t)M * K / 4, g.ea); }, 5);
+    float msb = tm.ms([&] { presplit_kernel<<<2048, 256>>>((const float4*)dB, (uint2*)dBh, (uint2*)dBl, (size_t)N * K / 4, g.eb); }, 5);
+    printf("     pre-split pass: A %.4f ms (%.0f GB/s), B %.4f ms\n", msa, (double)M * K * 8 / msa / 1e6, msb);
+    CK(hipMemset(dC, 0, (size_t)M * N * 4));
+    float ms = tm.ms([&] { gemm_c_kernel<2><<<grid, 512, 2 * kStage>>>(g); }, 10);
+    printf("  C  256x256 pre-split planes, DMA   %8.4f ms (mean %.4f)  %6.1f TF/s algorithmic  %.3f of 833\n", ms, tm.last_mean,
+           gf / ms, gf / ms / 833.3);
+    verify("C");
+  }
+  {
+    // interleaved rounds (guide rule 24): production and D0 alternate, ten launches each
+    dadet_conv_desc d{};
+    d.N = 1; d.H = 1; d.W = M; d.Cin = K; d.Cout = N; d.KH = d.KW = 1; d.stride = 1; d.pad = 0; d.Ho = 1; d.Wo = M;
+    d.OutH = 1; d.OutW = M; d.out_spatial_stride = 1; d.relu_mode = 0;
+    for (int round = 0; round < 3; ++round) {
+      float mp = tm.ms([&] { dadet_conv_forward_scaled(&d, dA, dB, nullptr, nullptr, nullptr, nullptr, dC, slots, slots + 1, nullptr, nullptr); }, 10);
+      float mpm = tm.last_mean;
+      float md = tm.ms([&] { gemm_d_kernel<0><<<grid, 512, 2 * kStage>>>(g); }, 10);
+      printf("     round %d: P %.4f (mean %.4f) = %.3f   D0 %.4f (mean %.4f) = %.3f\n", round, mp, mpm, gf / mp / 833.3, md,
+             tm.last_mean, gf / md / 833.3);
+    }
+  }
+  hipFree(dA); hipFree(dB); hipFree(dC); hipFree(dAh); hipFree(dAl); hipFree(dBh); hipFree(dBl); hipFree(slots);
+}
+
+static void part0() {
+  float *p, *out;
+  std::vector<float> h(1024);
+  for (int i = 0; i < 1024; ++i) h[i] = 1000.f + i;
+  CK(hipMalloc(&p, 4096)); CK(hipMalloc(&out, 64));
+  CK(hipMemcpy(p, h.data(), 4096, hipMemcpyHostToDevice));
+  oob_probe<<<1, 64>>>(p, 4096, out);
+  float r[5];
+  CK(hipMemcpy(r, out, 20, hipMemcpyDeviceToHost));
+  printf("== part 0: raw buffer load, 4096-byte buffer of 1000 + i: voff 0xFFFFFFF0 soff 0 -> %g | voff 0xFFFFFFF0 soff 128 -> %g | "
+         "voff 0x80000000 soff 128 -> %g | voff 16 soff 128 -> %g (expect 1036) | voff bytes-64 soff 128 -> %g\n", r[0], r[1], r[2], r[3], r[4]);
+}
+
+// counters run (rocprofv3 --pmc): only the kernel named by argv[2] (P | B | D) on one full-grid shape, a few launches
+static void part_pmc(char which) {
+  const int M = 16384, N = 4096, K = 4096;
+  std::vector<float> hA((size_t)M * K), hB((size_t)N * K);
+  unsigned long long st = 777;
+  float amaxA = 0.f, amaxB = 0.f;
+  for (auto& v : hA) { v = (float)gauss(st); amaxA = fmaxf(amaxA, fabsf(v)); }
+  for (auto& v : hB) { v = (float)gauss(st) * 0.02f; amaxB = fmaxf(amaxB, fabsf(v)); }
+  float *dA, *dB, *dC, *slots;
+  CK(hipMalloc(&dA, hA.size() * 4)); CK(hipMalloc(&dB, hB.size() * 4)); CK(hipMalloc(&dC, (size_t)M * N * 4));
+  CK(hipMalloc(&slots, 8 * DADET_AMAX_STRIDE * 4));
+  CK(hipMemset(slots, 0, 8 * DADET_AMAX_STRIDE * 4));
+  CK(hipMemcpy(dA, hA.data(), hA.size() * 4, hipMemcpyHostToDevice));
+  CK(hipMemcpy(dB, hB.data(), hB.size() * 4, hipMemcpyHostToDevice));
+  GemmArgs g{};
+  g.A = dA; g.B = dB; g.C = dC; g.M = M; g.N = N; g.K = K; g.ea = fmt4_exp_host(amaxA); g.eb = fmt4_exp_host(amaxB);
+  g.tiles_m = M / 256; g.tiles_n = N / 256;
+  const int grid = g.tiles_m * g.tiles_n;
+  CK(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_b_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * kStage));
+  CK(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_d_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * kStage));
+  dadet_conv_desc d{};
+  d.N = 1; d.H = 1; d.W = M; d.Cin = K; d.Cout = N; d.KH = d.KW = 1; d.stride = 1; d.pad = 0; d.Ho = 1; d.Wo = M;
+  d.OutH = 1; d.OutW = M; d.out_spatial_stride = 1; d.relu_mode = 0;
+  dadet_amax(dA, (long long)M * K, slots, nullptr);
+  dadet_amax(dB, (long long)N * K, slots + 1, nullptr);
+  for (int r = 0; r < 4; ++r) {
+    if (which == 'P') dadet_conv_forward_scaled(&d, dA, dB, nullptr, nullptr, nullptr, nullptr, dC, slots, slots + 1, nullptr, nullptr);
+    if (which == 'B') gemm_b_kernel<0><<<grid, 512, 2 * kStage>>>(g);
+    if (which == 'D') gemm_d_kernel<0><<<grid, 512, 2 * kStage>>>(g);
+  }
+  CK(hipDeviceSynchronize());
+}
+
+int main(int argc, char** argv) {
+  if (argc > 2 && argv[1][0] == 'c') { part_pmc(argv[2][0]); return 0; }
+  const bool quick = argc > 1 && argv[1][0] == 'q';
+  part0();
+  if (!(argc > 1 && argv[1][0] == 's')) part1();
+  part2(4096, 4096, 1024, true);          // correctness + a full grid of 256 tiles
+  if (!quick) {
+    part2(16384, 4096, 4096, false);      // steady state: 1024 tiles of 256 x 256
+    part2(8192, 1024, 9216, false);       // RPN 3x3 as a plain GEMM
+    part2(12544, 512, 4608, false);       // res5 3x3
+    part2(16384, 256, 2304, false);       // res4 3x3
+    part2(12544, 2048, 512, false);       // res5 1x1
+  }
+  return 0;
+}
