@@ -368,6 +368,8 @@ def conv_forward(x, w, scale=None, bias=None, addend=None, mask_ref=None, stride
             mode = get_gemm_mode()
             if variant == 4:
                 kname = "conv_big_kernel<256>"
+            elif variant == 5:
+                kname = "conv_big128_kernel"
             elif variant == 3:
                 kname = "conv1x1_ws_kernel<%d,%d,%d>" % (Cin, 64 if Cin == 256 else 128, mode)
             else:

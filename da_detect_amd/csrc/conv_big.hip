@@ -71,6 +71,186 @@ __device__ __forceinline__ int div_small(const int m, const int d, const float r
 }
 }  // namespace
 
+// What follows a tile's K loop, shared by the tile shapes: undo the operand scales, meet the other K parts of the tile (if
+// the reduction was cut), run the fused epilogue.  row0 / col0: first output row / column of this WAVE's TM x TN blocks.
+template <int TM, int TN, int BN>
+__device__ __forceinline__ void big_finish(const ConvArgs& a, f32x16 (&acc)[TM][TN], char* smem, const int tile,
+                                           const int part, const int S, const int row0, const int col0, const int ea,
+                                           const int eb) {
+  const int t = threadIdx.x, lane = t & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  {
+    // undo the operand scales (exact: powers of two, in two steps so that no intermediate leaves fp32's range unless the
+    // result does): the parts of a split reduction are parked in true units
+    const int tt = -(ea + eb);
+    const float u1 = pow2f(tt / 2), u2 = pow2f(tt - tt / 2);
+#pragma unroll
+    for (int im = 0; im < TM; ++im)
+#pragma unroll
+      for (int in = 0; in < TN; ++in)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[im][in][e] = acc[im][in][e] * u1 * u2;
+  }
+
+  int* s_word = reinterpret_cast<int*>(smem);        // the operand planes are dead (every wave passed the last barrier)
+  if (S > 1) {
+    const __amdgpu_buffer_rsrc_t pr = make_rsrc(a.sk_ws + (size_t)tile * S * (256 * BN), (unsigned)(S * 256 * BN * 4));
+    int* arrive = a.sk_counters + tile;
+    int* parked = a.sk_counters + 2048 + tile;
+    if (t == 0) s_word[0] = __hip_atomic_fetch_add(arrive, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    const int ticket = s_word[0];
+    if (ticket != S - 1) {
+      // park: lane-linear, 16 bytes per lane and store, written through to memory
+      const unsigned mine = (unsigned)part * (256 * BN * 4) + (unsigned)t * 16u;
+#pragma unroll
+      for (int im = 0; im < TM; ++im)
+#pragma unroll
+        for (int in = 0; in < TN; ++in)
+#pragma unroll
+          for (int g = 0; g < 4; ++g)
+            buf_store4_wt(pr, mine + ((im * TN + in) * 4 + g) * 8192u,
+                          make_float4(acc[im][in][g * 4], acc[im][in][g * 4 + 1], acc[im][in][g * 4 + 2],
+                                      acc[im][in][g * 4 + 3]));
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // every wave drains its stores ...
+      __syncthreads();                                    // ... before one lane announces the part
+      if (t == 0) __hip_atomic_fetch_add(parked, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      return;
+    }
+    // the last part to arrive: the others have left their K loops (they hold tickets) and only finish their stores
+    if (t == 0) {
+      while (__hip_atomic_load(parked, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != S - 1) __builtin_amdgcn_s_sleep(8);
+      *arrive = 0;        // ready for the next launch on this stream (no memset per launch)
+      *parked = 0;
+    }
+    __syncthreads();
+    // sum in part order, this part's registers at its own index: the result does not depend on who came last
+#pragma unroll
+    for (int im = 0; im < TM; ++im)
+#pragma unroll
+      for (int in = 0; in < TN; ++in) {
+        float4 own[4], sum[4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          own[g] = make_float4(acc[im][in][g * 4], acc[im][in][g * 4 + 1], acc[im][in][g * 4 + 2], acc[im][in][g * 4 + 3]);
+          sum[g] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        for (int p = 0; p < S; ++p) {
+          float4 v[4];
+          if (p != part) {
+            const unsigned src = (unsigned)p * (256 * BN * 4) + (unsigned)t * 16u + ((im * TN + in) * 4) * 8192u;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) v[g] = buf_load4_sc1(pr, src + g * 8192u);
+          } else {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) v[g] = own[g];
+          }
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            sum[g].x += v[g].x; sum[g].y += v[g].y; sum[g].z += v[g].z; sum[g].w += v[g].w;
+          }
+        }
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          acc[im][in][g * 4] = sum[g].x; acc[im][in][g * 4 + 1] = sum[g].y;
+          acc[im][in][g * 4 + 2] = sum[g].z; acc[im][in][g * 4 + 3] = sum[g].w;
+        }
+      }
+    __syncthreads();      // s_word is about to be reused as transpose space
+  }
+
+  // ---- epilogue: y = gate(acc * scale + bias + addend), 16 bytes per lane through an LDS transpose (conv_split.hip:
+  // conv_epilogue_v4), the same arithmetic per element in the same order
+  float* tile_f = reinterpret_cast<float*>(smem) + wave * (2 * 32 * EPI_STRIDE);
+  const __amdgpu_buffer_rsrc_t yr = make_rsrc(a.y, a.y_bytes);
+  const __amdgpu_buffer_rsrc_t ar = make_rsrc(a.addend ? a.addend : a.y, a.addend ? a.y_bytes : 0u);
+  const __amdgpu_buffer_rsrc_t mr = make_rsrc(a.mask_ref ? a.mask_ref : a.y, a.mask_ref ? a.y_bytes : 0u);
+  const int col_in = lane & 31, row_hi = 4 * (lane >> 5);
+  const int rrow = lane >> 3, c4 = (lane & 7) * 4;
+  float mx = 0.f;
+#pragma unroll
+  for (int in = 0; in < TN; ++in) {
+    const int n = col0 + in * 32 + c4;
+    const bool nvalid = n < a.Cout;                      // Cout % 4 == 0: the four columns are valid together
+    float4 scv = make_float4(1.f, 1.f, 1.f, 1.f), biv = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (a.scale && nvalid) scv = *reinterpret_cast<const float4*>(a.scale + n);
+    if (a.bias && nvalid) biv = *reinterpret_cast<const float4*>(a.bias + n);
+#pragma unroll
+    for (int q = 0; q < TM / 2; ++q) {
+      unsigned offs[2][4];
+      float4 ad[2][4], mk[2][4];
+#pragma unroll
+      for (int b = 0; b < 2; ++b)
+#pragma unroll
+        for (int pass = 0; pass < 4; ++pass) {
+          const int m = row0 + (2 * q + b) * 32 + pass * 8 + rrow;
+          offs[b][pass] = (nvalid && m < a.M) ? ((unsigned)m * (unsigned)a.Cout + (unsigned)n) * 4u : kBigOOB;
+        }
+      if (a.addend) {
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+          for (int pass = 0; pass < 4; ++pass) ad[b][pass] = buf_load4(ar, offs[b][pass]);
+      }
+      if (a.relu_mode == 2) {
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+          for (int pass = 0; pass < 4; ++pass) mk[b][pass] = buf_load4(mr, offs[b][pass]);
+      }
+#pragma unroll
+      for (int b = 0; b < 2; ++b) {
+        const int im = 2 * q + b;
+        float* tl = tile_f + b * (32 * EPI_STRIDE);
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) tl[(e + 8 * g + row_hi) * EPI_STRIDE + col_in] = acc[im][in][g * 4 + e];
+      }
+      // a wave's own data only: no workgroup barrier, the LDS traffic of one wave is ordered
+      __builtin_amdgcn_s_waitcnt(0xc07f);                // lgkmcnt(0)
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int b = 0; b < 2; ++b) {
+        const float* tl = tile_f + b * (32 * EPI_STRIDE);
+#pragma unroll
+        for (int pass = 0; pass < 4; ++pass) {
+          const int row = pass * 8 + rrow;
+          const float4 v4 = *reinterpret_cast<const float4*>(tl + row * EPI_STRIDE + c4);
+          const unsigned off = offs[b][pass];
+          float v[4] = {v4.x, v4.y, v4.z, v4.w};
+          const float s4[4] = {scv.x, scv.y, scv.z, scv.w}, b4[4] = {biv.x, biv.y, biv.z, biv.w};
+          float adv[4] = {0.f, 0.f, 0.f, 0.f}, mkv[4] = {1.f, 1.f, 1.f, 1.f};
+          if (a.addend) {
+            const float4 tv = ad[b][pass];
+            adv[0] = tv.x; adv[1] = tv.y; adv[2] = tv.z; adv[3] = tv.w;
+          }
+          if (a.relu_mode == 2) {
+            const float4 tv = mk[b][pass];
+            mkv[0] = tv.x; mkv[1] = tv.y; mkv[2] = tv.z; mkv[3] = tv.w;
+          }
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            float x = v[e];
+            if (a.scale) x = x * s4[e];
+            if (a.bias) x = x + b4[e];
+            if (a.addend) x = x + adv[e];
+            if (a.relu_mode == 1) x = fmaxf(x, 0.f);
+            else if (a.relu_mode == 2) x = (mkv[e] > 0.f) ? x : 0.f;
+            v[e] = x;
+          }
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, make_float4(v[0], v[1], v[2], v[3])), yr,
+                                                 (int)off, 0, 0);
+          if (a.amax_y && off != kBigOOB)
+            mx = fmaxf(fmaxf(mx, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
+        }
+      }
+      __builtin_amdgcn_wave_barrier();                   // the transpose space is rewritten by the next round
+    }
+  }
+  if (a.amax_y) amax_publish(a.amax_y, mx);
+}
+
 template <int BN>
 __global__ __launch_bounds__(512, 2) void conv_big_kernel(const ConvArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -271,176 +451,201 @@ __global__ __launch_bounds__(512, 2) void conv_big_kernel(const ConvArgs a) {
     }
   }
 
+  big_finish<TM, TN, BN>(a, acc, smem, tile, part, S, bm0 + wm * (TM * 32), bn0 + wn * (TN * 32), ea, eb);
+}
+
+// ---- 256 x 128 tile: the layers with 128 or 256 output channels (res3 / res4 3x3 and their 1x1 neighbours) --------------
+// The same idea with another geometry: 8 waves as 4 x 2 of 64 x 64 (64 accumulator registers), and a multiply segment
+// covers a WHOLE K-tile (both k16 steps: 24 MFMAs, their 16 fragments in 64 registers), so a K-tile costs two barriers
+// instead of four.  Segment s: group 0 multiplies K-tile s / 2 for even s, group 1 K-tile (s - 1) / 2 for odd s.  The
+// 256 + 128 operand rows of a K-tile are staged in six passes of 32 rows per group and load segment: group 0 takes
+// activation rows 0 .. 191, group 1 activation rows 192 .. 255 and the 128 weight rows.  Group 0's load segment 2v + 1
+// stores K-tile v + 2 (into the slot K-tile v was last read from in segment 2v) and fetches K-tile v + 3; group 1's load
+// segment 2v stores K-tile v + 1 and fetches K-tile v + 2.
+__global__ __launch_bounds__(512, 2) void conv_big128_kernel(const ConvArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int BN = 128, TM = 2, TN = 2;
+  constexpr int kPlaneA = 256 * 64, kPlaneB = 128 * 64;
+  constexpr int kStage = 2 * kPlaneA + 2 * kPlaneB;       // A_h | A_l | B_h | B_l = 48 KB
+  const int t = threadIdx.x, lane = t & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int grp = wave >> 2, tg = t & 255;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int T = a.tiles_m * a.tiles_n, S = a.big_splits;
+  const int lid = xcd_remap(blockIdx.x, T * S);
+  const int part = lid / T, tile = lid - part * T;
+  const int bm0 = (tile / a.tiles_n) * 256, bn0 = (tile % a.tiles_n) * BN;
+  const int nk = a.K / 32;
+  const int kt_lo = (int)(((long long)nk * part) / S), kt_hi = (int)(((long long)nk * (part + 1)) / S);
+  const int nT = kt_hi - kt_lo;
+  const int ea = a.amax_x ? fmt4_exp(amax_read(a.amax_x)) : 0;
+  const int eb = a.amax_w ? fmt4_exp(amax_read(a.amax_w)) : 0;
+  const float sa = pow2f(ea), sb = pow2f(eb);
+
+  // six row slots per thread: operand row rho = 192 * grp + 32 * i + lrow of the 384 (activation rows first)
+  const int lcol = tg & 7, lrow = tg >> 3;
+  const __amdgpu_buffer_rsrc_t xr = make_rsrc(a.x, a.x_bytes), wr = make_rsrc(a.w, a.w_bytes);
+  unsigned goff[6];
+  int* desc = reinterpret_cast<int*>(smem + 2 * kStage) + t;       // [12][512] ints: first pixel, hi0 << 16 | wi0
+  // (indexed by the THREAD, not by its index inside the group: both groups own activation rows here)
+  int ld_kt = kt_lo, ld_kc, ld_kr, ld_ks;
   {
-    // undo the operand scales (exact: powers of two, in two steps so that no intermediate leaves fp32's range unless the
-    // result does): the parts of a split reduction are parked in true units
-    const int tt = -(ea + eb);
-    const float u1 = pow2f(tt / 2), u2 = pow2f(tt - tt / 2);
-#pragma unroll
-    for (int im = 0; im < TM; ++im)
-#pragma unroll
-      for (int in = 0; in < TN; ++in)
-#pragma unroll
-        for (int e = 0; e < 16; ++e) acc[im][in][e] = acc[im][in][e] * u1 * u2;
+    const int k0 = kt_lo * 32;
+    const int tap = k0 / a.Cin;
+    ld_kc = k0 - tap * a.Cin;
+    ld_kr = tap / a.KW;
+    ld_ks = tap - ld_kr * a.KW;
   }
+  auto is_act = [&](const int i) { return grp == 0 || i < 2; };     // wave-uniform
+  auto recompute = [&]() {
+#pragma unroll
+    for (int i = 0; i < 6; ++i)
+      if (is_act(i)) {
+        const int px = desc[i * 512], hw = desc[(6 + i) * 512];
+        const int hi = (hw >> 16) + ld_kr, wi = (int)(short)(hw & 0xffff) + ld_ks;
+        const bool ok = ((unsigned)hi < (unsigned)a.H) & ((unsigned)wi < (unsigned)a.W);
+        goff[i] = ok ? ((unsigned)(px + hi * a.W + wi) * (unsigned)a.Cin + (unsigned)(lcol * 4)) * 4u : kBigOOB;
+      }
+  };
+  {
+    const int HoWo = a.Ho * a.Wo;
+    const float r_howo = 1.0f / (float)HoWo, r_wo = 1.0f / (float)a.Wo;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+      if (is_act(i)) {
+        const int m = bm0 + 192 * grp + 32 * i + lrow;
+        int px = 0, hw = (int)0xC0000000;
+        if (m < a.M) {
+          int rem, wo;
+          const int img = div_small(m, HoWo, r_howo, rem);
+          const int ho = div_small(rem, a.Wo, r_wo, wo);
+          px = img * a.H * a.W;
+          hw = (int)(((unsigned)(ho * a.stride - a.pad) << 16) | ((unsigned)(wo * a.stride - a.pad) & 0xffffu));
+        }
+        desc[i * 512] = px;
+        desc[(6 + i) * 512] = hw;
+      } else {
+        const int n = bn0 + 32 * (i - 2) + lrow;
+        goff[i] = n < a.Cout ? ((unsigned)n * (unsigned)a.K + (unsigned)(lcol * 4)) * 4u : kBigOOB;
+      }
+    }
+    recompute();
+  }
+  const unsigned swz = ((((lcol >> 1) ^ ((lrow >> 2) & 3))) << 4) + (lcol & 1) * 8;
+  const int fr = lane & 31;
+  const unsigned fo = fr * 64 + ((((lane >> 5)) ^ ((fr >> 2) & 3)) << 4);
+  const unsigned fa_base = (wm * 64) * 64 + fo;
+  const unsigned fb_base = 2 * kPlaneA + (wn * 64) * 64 + fo;
 
-  int* s_word = reinterpret_cast<int*>(smem);        // the operand planes are dead (every wave passed the last barrier)
-  if (S > 1) {
-    const __amdgpu_buffer_rsrc_t pr = make_rsrc(a.sk_ws + (size_t)tile * S * (256 * BN), (unsigned)(S * 256 * BN * 4));
-    int* arrive = a.sk_counters + tile;
-    int* parked = a.sk_counters + 2048 + tile;
-    if (t == 0) s_word[0] = __hip_atomic_fetch_add(arrive, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __syncthreads();
-    const int ticket = s_word[0];
-    if (ticket != S - 1) {
-      // park: lane-linear, 16 bytes per lane and store, written through to memory
-      const unsigned mine = (unsigned)part * (256 * BN * 4) + (unsigned)t * 16u;
+  float4 raw[2][6];
+  f16x8 fa[2][2][TM], fb[2][2][TN];     // [k16 step][plane][block]
+  f32x16 acc[TM][TN];
 #pragma unroll
-      for (int im = 0; im < TM; ++im)
+  for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int in = 0; in < TN; ++in)
+    for (int j = 0; j < TN; ++j)
 #pragma unroll
-          for (int g = 0; g < 4; ++g)
-            buf_store4_wt(pr, mine + ((im * TN + in) * 4 + g) * 8192u,
-                          make_float4(acc[im][in][g * 4], acc[im][in][g * 4 + 1], acc[im][in][g * 4 + 2],
-                                      acc[im][in][g * 4 + 3]));
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // every wave drains its stores ...
-      __syncthreads();                                    // ... before one lane announces the part
-      if (t == 0) __hip_atomic_fetch_add(parked, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      return;
-    }
-    // the last part to arrive: the others have left their K loops (they hold tickets) and only finish their stores
-    if (t == 0) {
-      while (__hip_atomic_load(parked, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != S - 1) __builtin_amdgcn_s_sleep(8);
-      *arrive = 0;        // ready for the next launch on this stream (no memset per launch)
-      *parked = 0;
-    }
-    __syncthreads();
-    // sum in part order, this part's registers at its own index: the result does not depend on who came last
-#pragma unroll
-    for (int im = 0; im < TM; ++im)
-#pragma unroll
-      for (int in = 0; in < TN; ++in) {
-        float4 own[4], sum[4];
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          own[g] = make_float4(acc[im][in][g * 4], acc[im][in][g * 4 + 1], acc[im][in][g * 4 + 2], acc[im][in][g * 4 + 3]);
-          sum[g] = make_float4(0.f, 0.f, 0.f, 0.f);
-        }
-        for (int p = 0; p < S; ++p) {
-          float4 v[4];
-          if (p != part) {
-            const unsigned src = (unsigned)p * (256 * BN * 4) + (unsigned)t * 16u + ((im * TN + in) * 4) * 8192u;
-#pragma unroll
-            for (int g = 0; g < 4; ++g) v[g] = buf_load4_sc1(pr, src + g * 8192u);
-          } else {
-#pragma unroll
-            for (int g = 0; g < 4; ++g) v[g] = own[g];
-          }
-#pragma unroll
-          for (int g = 0; g < 4; ++g) {
-            sum[g].x += v[g].x; sum[g].y += v[g].y; sum[g].z += v[g].z; sum[g].w += v[g].w;
-          }
-        }
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          acc[im][in][g * 4] = sum[g].x; acc[im][in][g * 4 + 1] = sum[g].y;
-          acc[im][in][g * 4 + 2] = sum[g].z; acc[im][in][g * 4 + 3] = sum[g].w;
-        }
-      }
-    __syncthreads();      // s_word is about to be reused as transpose space
-  }
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
-  // ---- epilogue: y = gate(acc * scale + bias + addend), 16 bytes per lane through an LDS transpose (conv_split.hip:
-  // conv_epilogue_v4), the same arithmetic per element in the same order
-  float* tile_f = reinterpret_cast<float*>(smem) + wave * (2 * 32 * EPI_STRIDE);
-  const __amdgpu_buffer_rsrc_t yr = make_rsrc(a.y, a.y_bytes);
-  const __amdgpu_buffer_rsrc_t ar = make_rsrc(a.addend ? a.addend : a.y, a.addend ? a.y_bytes : 0u);
-  const __amdgpu_buffer_rsrc_t mr = make_rsrc(a.mask_ref ? a.mask_ref : a.y, a.mask_ref ? a.y_bytes : 0u);
-  const int col_in = lane & 31, row_hi = 4 * (lane >> 5);
-  const int rrow = lane >> 3, c4 = (lane & 7) * 4;
-  float mx = 0.f;
+  auto loads = [&](float4 (&dst)[6]) {        // one whole K-tile of this group's rows, then the stream moves on
 #pragma unroll
-  for (int in = 0; in < TN; ++in) {
-    const int n = bn0 + wn * 64 + in * 32 + c4;
-    const bool nvalid = n < a.Cout;                      // Cout % 4 == 0: the four columns are valid together
-    float4 scv = make_float4(1.f, 1.f, 1.f, 1.f), biv = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (a.scale && nvalid) scv = *reinterpret_cast<const float4*>(a.scale + n);
-    if (a.bias && nvalid) biv = *reinterpret_cast<const float4*>(a.bias + n);
+    for (int i = 0; i < 6; ++i) {
+      const bool act = is_act(i);
+      dst[i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(act ? xr : wr, (int)goff[i],
+                                                                                 act ? ld_kc * 4 : ld_kt * 128, 0));
+    }
+    ++ld_kt;
+    ld_kc += 32;
+    if (ld_kc >= a.Cin) {
+      ld_kc = 0;
+      if (++ld_ks == a.KW) { ld_ks = 0; ++ld_kr; }
+      recompute();
+    }
+    __builtin_amdgcn_sched_barrier(0);      // the loads go out FIRST in their segment
+  };
+  auto stage = [&](const float4 (&v)[6], const int slot) {
 #pragma unroll
-    for (int q = 0; q < TM / 2; ++q) {
-      unsigned offs[2][4];
-      float4 ad[2][4], mk[2][4];
+    for (int i = 0; i < 6; ++i) {
+      const bool act = is_act(i);
+      const int row = act ? 192 * grp + 32 * i + lrow : 32 * (i - 2) + lrow;
+      char* st = smem + slot * kStage + (act ? 0 : 2 * kPlaneA) + row * 64 + swz;
+      uint2 h, l;
+      split4m(v[i], act ? sa : sb, h, l);
+      *reinterpret_cast<uint2*>(st) = h;
+      *reinterpret_cast<uint2*>(st + (act ? kPlaneA : kPlaneB)) = l;
+    }
+  };
+  auto read_frags = [&](const int slot) {
+    const char* cur = smem + slot * kStage;
 #pragma unroll
-      for (int b = 0; b < 2; ++b)
+    for (int step = 0; step < 2; ++step) {
 #pragma unroll
-        for (int pass = 0; pass < 4; ++pass) {
-          const int m = bm0 + wm * 128 + (2 * q + b) * 32 + pass * 8 + rrow;
-          offs[b][pass] = (nvalid && m < a.M) ? ((unsigned)m * (unsigned)a.Cout + (unsigned)n) * 4u : kBigOOB;
-        }
-      if (a.addend) {
+      for (int i = 0; i < TN; ++i) fb[step][0][i] = *reinterpret_cast<const f16x8*>(cur + ((fb_base + i * 2048) ^ (step * 32)));
 #pragma unroll
-        for (int b = 0; b < 2; ++b)
+      for (int i = 0; i < TM; ++i) fa[step][1][i] = *reinterpret_cast<const f16x8*>(cur + kPlaneA + ((fa_base + i * 2048) ^ (step * 32)));
 #pragma unroll
-          for (int pass = 0; pass < 4; ++pass) ad[b][pass] = buf_load4(ar, offs[b][pass]);
+      for (int i = 0; i < TM; ++i) fa[step][0][i] = *reinterpret_cast<const f16x8*>(cur + ((fa_base + i * 2048) ^ (step * 32)));
+#pragma unroll
+      for (int i = 0; i < TN; ++i) fb[step][1][i] = *reinterpret_cast<const f16x8*>(cur + kPlaneB + ((fb_base + i * 2048) ^ (step * 32)));
+    }
+  };
+  auto mfma_seg = [&]() {
+#pragma unroll
+    for (int step = 0; step < 2; ++step)
+#pragma unroll
+      for (int term = 0; term < 3; ++term) {
+        const int pa = term == 0 ? 1 : 0, pb = term == 1 ? 1 : 0;
+#pragma unroll
+        for (int im = 0; im < TM; ++im)
+#pragma unroll
+          for (int in = 0; in < TN; ++in)
+            acc[im][in] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[step][pa][im], fb[step][pb][in], acc[im][in], 0, 0, 0);
       }
-      if (a.relu_mode == 2) {
-#pragma unroll
-        for (int b = 0; b < 2; ++b)
-#pragma unroll
-          for (int pass = 0; pass < 4; ++pass) mk[b][pass] = buf_load4(mr, offs[b][pass]);
+  };
+  auto bar = [&]() {
+    __builtin_amdgcn_sched_barrier(0);
+    __syncthreads();
+    __builtin_amdgcn_sched_barrier(0);
+  };
+
+  // prologue: K-tile 0 stored by both groups, K-tile 1 by group 0 (its segment "-1"); group 0 has K-tile 2 on its way
+  // (raw[0]), group 1 K-tile 1 (raw[1])
+  loads(raw[0]); stage(raw[0], 0);
+  loads(raw[1]);
+  if (grp == 0) {
+    stage(raw[1], 1);
+    loads(raw[0]);
+  }
+  bar();
+  if (grp == 0) {
+    read_frags(0);
+    for (int Tt = 0; Tt < nT; Tt += 2) {
+      mfma_seg();                                               // segment 2T: K-tile T (even T)
+      bar();
+      loads(raw[1]); read_frags(1); stage(raw[0], 0);           // segment 2T + 1: K-tile T + 2 stored, T + 3 fetched
+      bar();
+      if (Tt + 1 < nT) {
+        mfma_seg();                                             // K-tile T + 1
+        bar();
+        loads(raw[0]); read_frags(0); stage(raw[1], 1);
+        bar();
       }
-#pragma unroll
-      for (int b = 0; b < 2; ++b) {
-        const int im = 2 * q + b;
-        float* tl = tile_f + b * (32 * EPI_STRIDE);
-#pragma unroll
-        for (int g = 0; g < 4; ++g)
-#pragma unroll
-          for (int e = 0; e < 4; ++e) tl[(e + 8 * g + row_hi) * EPI_STRIDE + col_in] = acc[im][in][g * 4 + e];
+    }
+  } else {
+    for (int Tt = 0; Tt < nT; Tt += 2) {
+      loads(raw[0]); read_frags(0); stage(raw[1], 1);           // segment 2T: K-tile T + 1 stored, T + 2 fetched (even T)
+      bar();
+      mfma_seg();                                               // segment 2T + 1: K-tile T
+      bar();
+      if (Tt + 1 < nT) {
+        loads(raw[1]); read_frags(1); stage(raw[0], 0);
+        bar();
+        mfma_seg();
+        bar();
       }
-      // a wave's own data only: no workgroup barrier, the LDS traffic of one wave is ordered
-      __builtin_amdgcn_s_waitcnt(0xc07f);                // lgkmcnt(0)
-      __builtin_amdgcn_wave_barrier();
-#pragma unroll
-      for (int b = 0; b < 2; ++b) {
-        const float* tl = tile_f + b * (32 * EPI_STRIDE);
-#pragma unroll
-        for (int pass = 0; pass < 4; ++pass) {
-          const int row = pass * 8 + rrow;
-          const float4 v4 = *reinterpret_cast<const float4*>(tl + row * EPI_STRIDE + c4);
-          const unsigned off = offs[b][pass];
-          float v[4] = {v4.x, v4.y, v4.z, v4.w};
-          const float s4[4] = {scv.x, scv.y, scv.z, scv.w}, b4[4] = {biv.x, biv.y, biv.z, biv.w};
-          float adv[4] = {0.f, 0.f, 0.f, 0.f}, mkv[4] = {1.f, 1.f, 1.f, 1.f};
-          if (a.addend) {
-            const float4 tv = ad[b][pass];
-            adv[0] = tv.x; adv[1] = tv.y; adv[2] = tv.z; adv[3] = tv.w;
-          }
-          if (a.relu_mode == 2) {
-            const float4 tv = mk[b][pass];
-            mkv[0] = tv.x; mkv[1] = tv.y; mkv[2] = tv.z; mkv[3] = tv.w;
-          }
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            float x = v[e];
-            if (a.scale) x = x * s4[e];
-            if (a.bias) x = x + b4[e];
-            if (a.addend) x = x + adv[e];
-            if (a.relu_mode == 1) x = fmaxf(x, 0.f);
-            else if (a.relu_mode == 2) x = (mkv[e] > 0.f) ? x : 0.f;
-            v[e] = x;
-          }
-          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, make_float4(v[0], v[1], v[2], v[3])), yr,
-                                                 (int)off, 0, 0);
-          if (a.amax_y && off != kBigOOB)
-            mx = fmaxf(fmaxf(mx, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
-        }
-      }
-      __builtin_amdgcn_wave_barrier();                   // the transpose space is rewritten by the next round
     }
   }
-  if (a.amax_y) amax_publish(a.amax_y, mx);
+  big_finish<TM, TN, BN>(a, acc, smem, tile, part, S, bm0 + wm * (TM * 32), bn0 + wn * (TN * 32), ea, eb);
 }
 
 // ---- host side -------------------------------------------------------------------------------------------------------
@@ -466,48 +671,64 @@ static int big_split_plan(const int tiles, const int nk) {
   return (tiles <= kNumCU / 2 && nk >= 16) ? 2 : 1;
 }
 
-bool big_eligible(const ConvArgs& a) {
-  if (g_big_mode == 0) return false;
-  if (a.os != 1 || !a.epi_v4 || a.Cin % 32 != 0 || a.K % 32 != 0 || a.Cout % 4 != 0) return false;
-  if (a.x_bytes >= 0x7FFFFF00u || a.w_bytes >= 0x7FFFFF00u || a.y_bytes >= 0x7FFFFF00u) return false;
-  if (a.M >= (1 << 24)) return false;
-  if (g_big_mode == 2) return true;
-  // plan: long reductions over wide outputs — what the 128 x 128 kernel serves worst (profiles/r05_gemm_lab.txt)
-  // (tools/native/gemm_lab.hip, profiles/r05_gemm_lab.txt: +29 .. +35% where the grid fills the chip with at most two K
-  // parts per tile; 64 tiles in four parts — res4 3x3 — only equal the 128 x 128 kernel: the last part reads 768 KB)
-  if (a.Cout < 256 || a.K < 512 || a.M < 4096) return false;
-  const int tiles = ceil_div(a.M, 256) * ceil_div(a.Cout, 256);
-  if (tiles < 96) return false;
-  return true;
+// which large-tile kernel serves this problem: 0 none, 1 the 256 x 256 tile, 2 the 256 x 128 tile
+int big_variant(const ConvArgs& a) {
+  if (g_big_mode == 0) return 0;
+  if (a.os != 1 || !a.epi_v4 || a.Cin % 32 != 0 || a.K % 32 != 0 || a.Cout % 4 != 0) return 0;
+  if (a.x_bytes >= 0x7FFFFF00u || a.w_bytes >= 0x7FFFFF00u || a.y_bytes >= 0x7FFFFF00u) return 0;
+  if (a.M >= (1 << 24)) return 0;
+  if (g_big_mode == 2) {                       // tests: wherever applicable; DADET_BIG_TILE_N picks the tile width
+    const char* e = getenv("DADET_BIG_TILE_N");
+    return (e && atoi(e) == 128) ? 2 : 1;
+  }
+  // plan (tools/native/gemm_lab.hip, profiles/r05_gemm_lab.txt): +29 .. +35% against the 128 x 128 kernel where the grid fills
+  // the chip with at most two K parts per tile; 64 tiles of 256 x 256 in four parts — res4 3x3 — only equal it (the last
+  // part reads 768 KB), so layers of up to 256 output channels take the 256 x 128 tile
+  if (a.K < 512 || a.M < 4096 || a.Cout < 128) return 0;
+  const int tm = ceil_div(a.M, 256);
+  if (a.Cout <= 256) return tm * ceil_div(a.Cout, 128) >= 96 ? 2 : 0;
+  return tm * ceil_div(a.Cout, 256) >= 96 ? 1 : 0;
+}
+bool big_eligible(const ConvArgs& a) { return big_variant(a) != 0; }
+
+static int big_tiles(const ConvArgs& a, const int variant) {
+  return ceil_div(a.M, 256) * ceil_div(a.Cout, variant == 2 ? 128 : 256);
+}
+
+size_t big_workspace_bytes(const ConvArgs& a) {
+  const int variant = big_variant(a);
+  if (!variant) return 0;
+  const int tiles = big_tiles(a, variant);
+  const int s = tiles <= 2048 ? big_split_plan(tiles, a.K / 32) : 1;
+  return s > 1 ? (size_t)tiles * s * 256 * (variant == 2 ? 128 : 256) * sizeof(float) : 0;
 }
 
 int launch_fwd_big(ConvArgs& a, hipStream_t st, float* ws, int* counters) {
-  constexpr int BN = 256;
+  const int variant = big_variant(a);
+  const int bn = variant == 2 ? 128 : 256;
   a.tiles_m = ceil_div(a.M, 256);
-  a.tiles_n = ceil_div(a.Cout, BN);
+  a.tiles_n = ceil_div(a.Cout, bn);
   const int tiles = a.tiles_m * a.tiles_n;
   a.big_splits = (ws && counters && tiles <= 2048) ? big_split_plan(tiles, a.K / 32) : 1;
   a.sk_ws = ws;
   a.sk_counters = counters;
-  const size_t lds = 2 * 4 * 256 * 64 + 16 * 256 * sizeof(int);   // two K-tile slots + group 0's row descriptors
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_big_kernel<BN>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  // two K-tile slots + the staging groups' row descriptors
+  const size_t lds = variant == 2 ? 2 * (2 * 256 * 64 + 2 * 128 * 64) + 12 * 512 * sizeof(int)
+                                  : 2 * 4 * 256 * 64 + 16 * 256 * sizeof(int);
+  static bool attr_set[3] = {false, false, false};
+  if (!attr_set[variant]) {
+    const void* fn = variant == 2 ? reinterpret_cast<const void*>(conv_big128_kernel)
+                                  : reinterpret_cast<const void*>(conv_big_kernel<256>);
+    hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) {
       set_error("conv_forward(big): hipFuncSetAttribute: %s", hipGetErrorString(e));
       return DADET_ELAUNCH;
     }
-    attr_set = true;
+    attr_set[variant] = true;
   }
-  hipLaunchKernelGGL((conv_big_kernel<BN>), dim3(tiles * a.big_splits), dim3(512), lds, st, a);
+  if (variant == 2) hipLaunchKernelGGL(conv_big128_kernel, dim3(tiles * a.big_splits), dim3(512), lds, st, a);
+  else hipLaunchKernelGGL((conv_big_kernel<256>), dim3(tiles * a.big_splits), dim3(512), lds, st, a);
   return check_launch("conv_forward(big)");
-}
-
-size_t big_workspace_bytes(const ConvArgs& a) {
-  const int tiles = ceil_div(a.M, 256) * ceil_div(a.Cout, 256);
-  const int s = tiles <= 2048 ? big_split_plan(tiles, a.K / 32) : 1;
-  return s > 1 ? (size_t)tiles * s * 256 * 256 * sizeof(float) : 0;
 }
 
 }  // namespace dadet

@@ -242,6 +242,7 @@ int launch_wgrad_split(WgradArgs& a, int fmt, hipStream_t st);
 // 256 x 256-tile kernel of mode 4 for the long-K layers (conv_big.hip); ws / counters: split-reduction workspace of
 // big_workspace_bytes(a) bytes and the stream's zeroed counters (may be null when that is 0)
 bool big_eligible(const ConvArgs& a);
+int big_variant(const ConvArgs& a);      // 0 none, 1 the 256 x 256 tile, 2 the 256 x 128 tile
 size_t big_workspace_bytes(const ConvArgs& a);
 int launch_fwd_big(ConvArgs& a, hipStream_t st, float* ws, int* counters);
 // weight-stationary 1x1 kernel for K = 64 / 128 / 256 (conv_ws.hip)

@@ -956,7 +956,7 @@ extern "C" int dadet_conv_forward_variant(const dadet_conv_desc* d) {
       a.x_bytes = xb > 0x7FFFFFFFull ? 0x80000000u : (unsigned)xb;
       a.w_bytes = wb > 0x7FFFFFFFull ? 0x80000000u : (unsigned)wb;
       a.y_bytes = yb > 0x7FFFFFFFull ? 0x80000000u : (unsigned)yb;
-      if (big_eligible(a)) return 4;
+      if (const int bv = big_variant(a)) return 3 + bv;     // 4: 256 x 256 tile, 5: 256 x 128 tile
     }
   }
   return gemm_mode() != 0 ? split_fwd_variant(M, d->Cout, d->KH * d->KW * d->Cin) : fwd_variant(M, d->Cout);

@@ -50,9 +50,12 @@ CASES = [
 ]
 
 
+@pytest.mark.parametrize("tile_n", [256, 128])
 @pytest.mark.parametrize("case", CASES, ids=lambda c: "n%d_c%d_%dx%d_o%d_k%d_s%d_p%d_%s" % c)
-def test_big_tile_kernel_against_float64_and_the_128_tile_kernel(device, big_mode, case):
+def test_big_tile_kernel_against_float64_and_the_128_tile_kernel(device, big_mode, case, tile_n, monkeypatch):
     from da_detect_amd import _C
+
+    monkeypatch.setenv("DADET_BIG_TILE_N", str(tile_n))   # conv_big_kernel<256> / conv_big128_kernel
 
     N, Cin, H, W, Cout, k, stride, pad, epi = case
     g = torch.Generator().manual_seed(sum(case[:8]))
@@ -75,7 +78,7 @@ def test_big_tile_kernel_against_float64_and_the_128_tile_kernel(device, big_mod
         big_mode.dadet_set_big_gemm(mode)
         d = _C._desc(N, H, W, Cin, Cout, k, k, stride, pad, Ho, Wo)
         variant = big_mode.dadet_conv_forward_variant(ctypes.byref(d))
-        assert (variant == 4) == (mode == 2), "mode %d must%s take the large-tile kernel (variant %d)" % (
+        assert (variant == (4 if tile_n == 256 else 5)) == (mode == 2), "mode %d must%s take the large-tile kernel (variant %d)" % (
             mode, "" if mode == 2 else " not", variant)
         out[mode] = _C.conv_forward(x, w, stride=stride, pad=pad, **kw)
         again = _C.conv_forward(x, w, stride=stride, pad=pad, **kw)
@@ -95,8 +98,9 @@ def test_big_tile_kernel_against_float64_and_the_128_tile_kernel(device, big_mod
     torch.testing.assert_close(out[2], out[0], rtol=2e-5, atol=2e-5 * top)
 
 
+@pytest.mark.parametrize("tile_n", [256, 128])
 @pytest.mark.parametrize("splits", [1, 2, 3, 4])
-def test_big_tile_kernel_part_counts_agree(device, big_mode, splits, monkeypatch):
+def test_big_tile_kernel_part_counts_agree(device, big_mode, splits, tile_n, monkeypatch):
     """the same 3x3 layer with its reduction in 1 .. 4 parts: fp32 rounding apart, and run-to-run identical"""
     from da_detect_amd import _C
 
@@ -104,6 +108,7 @@ def test_big_tile_kernel_part_counts_agree(device, big_mode, splits, monkeypatch
     x = torch.randn((2, 128, 20, 28), generator=g).to(device).contiguous(memory_format=CL)
     w = (torch.randn((320, 128, 3, 3), generator=g) * 0.03).to(device).contiguous(memory_format=CL)
     big_mode.dadet_set_big_gemm(2)
+    monkeypatch.setenv("DADET_BIG_TILE_N", str(tile_n))
     monkeypatch.setenv("DADET_BIG_SPLITS", "1")
     one = _C.conv_forward(x, w, pad=1)
     monkeypatch.setenv("DADET_BIG_SPLITS", str(splits))

@@ -745,6 +745,9 @@ int main(int argc, char** argv) {
     part2(12544, 512, 4608, false);       // res5 3x3
     part2(16384, 256, 2304, false);       // res4 3x3
     part2(12544, 2048, 512, false);       // res5 1x1
+    part2(65536, 128, 1152, false);       // res3 3x3
+    part2(16384, 256, 1024, false);       // res4 conv1
+    part2(65536, 128, 512, false);        // res3 conv1
   }
   return 0;
 }
