@@ -648,6 +648,268 @@ __global__ __launch_bounds__(512, 2) void conv_big128_kernel(const ConvArgs a) {
   big_finish<TM, TN, BN>(a, acc, smem, tile, part, S, bm0 + wm * (TM * 32), bn0 + wn * (TN * 32), ea, eb);
 }
 
+// ---- weight gradient, 256 x 256 tile ------------------------------------------------------------------------------------
+// dW[co][kk] = sum_m gY[m][co] * Xg[m][kk], kk = (r, s, ci): the same pipeline with the reduction over the pixels m.  Both
+// operands arrive m-major (a row of gY is Cout contiguous floats, a gathered activation row Cin contiguous floats), the
+// MFMA wants each lane's 8 reduction indices contiguous: a thread fetches a 4 (m) x 4 (channel) block — four 16-byte row
+// loads, 32 lanes side by side cover 512 contiguous bytes of a row — and writes, per channel, the four m values as ONE 8-byte
+// piece of that channel's plane row: the planes are [channel][32 m] fp16, the image the forward kernel reads its
+// fragments from.  Group 0 stages gY (rows m, channels co0 ..), group 1 the gathered activations (channels kk0 .. map to a
+// filter tap and an input channel once per thread; the four rows' pixel coordinates advance by 32 rows per K-tile).  A
+// quarter is (K-tile of 32 rows, 128 channels).  The reduction over M is cut into `splits` ranges of whole K-tiles; every
+// part writes its tile of [splits][Cout][K] partial sums (or dW itself when there is one part) — the layout
+// wgrad_reduce_batch_kernel sums, with the FrozenBN scale, in its deterministic split order.
+__global__ __launch_bounds__(512, 2) void conv_wgrad_big_kernel(const WgradArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int TM = 4, TN = 2;
+  constexpr int kPlane = 256 * 64;
+  constexpr int kStage = 4 * kPlane;
+  const int t = threadIdx.x, lane = t & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int grp = wave >> 2, tg = t & 255;
+  const int wm = wave >> 2, wn = wave & 3;
+  const int T = a.tiles_co * a.tiles_kc;
+  const int lid = xcd_remap(blockIdx.x, T * a.splits);
+  const int part = lid / T, tile = lid - part * T;      // one XCD: one range of rows, neighbouring tiles
+  const int co0 = (tile / a.tiles_kc) * 256, kk0 = (tile % a.tiles_kc) * 256;
+  const int m_begin = part * a.rows_per_split;
+  const int m_end = min(a.M, m_begin + a.rows_per_split);
+  const int nT = (m_end - m_begin + 31) / 32;
+  const int eg = a.amax_gy ? fmt4_exp(amax_read(a.amax_gy)) : 0;
+  const int ex = a.amax_x ? fmt4_exp(amax_read(a.amax_x)) : 0;
+  const float sc = pow2f(grp ? ex : eg);
+
+  const int mg = tg & 7, cq = tg >> 3;       // rows 4 mg .. 4 mg + 3 of the K-tile, channels 4 cq .. 4 cq + 3 of the half
+  const __amdgpu_buffer_rsrc_t rr = grp ? make_rsrc(a.x, a.x_bytes) : make_rsrc(a.gy, a.gy_bytes);
+  // group 0: byte offset of (row 4 mg + j of K-tile 0 of the part, this thread's channel quad of half h)
+  unsigned goff[2][4];
+  // group 1: per half the tap (r << 8 | s) and the byte offset of the input channel, per row the image's first pixel, the
+  // output coordinates (ho << 16 | wo) and the input coordinates of tap (0, 0) (hi0 << 16 | wi0 & 0xffff)
+  int tap[2];
+  unsigned cioff[2];
+  // (both in LDS behind the two K-tile slots, as two int4 per thread: they are live only inside a load segment, and the
+  // multiply segments need every register — with them in VGPRs the loop spilled six values per K-tile)
+  int4* rowst = reinterpret_cast<int4*>(smem + 2 * kStage) + tg;      // [2][256] int4: pix[0..3] | hw0[0..3]
+  int ld_m = m_begin;                        // first row of the load stream's K-tile
+  const int HoWo = a.Ho * a.Wo;
+  // 32 output pixels further, in input coordinates of tap (0, 0): (d_img images, d_hs rows, d_ws columns) with carries at
+  // wi0 >= w_lim (wo >= Wo) and hi0 >= h_lim (ho >= Ho)
+  const int d_img = 32 / HoWo, d_ho = (32 - d_img * HoWo) / a.Wo, d_wo = 32 - d_img * HoWo - d_ho * a.Wo;
+  const int d_hs = d_ho * a.stride, d_ws = d_wo * a.stride, w_span = a.Wo * a.stride, h_span = a.Ho * a.stride;
+  const int w_lim = w_span - a.pad, h_lim = h_span - a.pad;
+  if (grp == 0) {
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int c = co0 + 128 * h + 4 * cq;
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        goff[h][j] = c < a.Cout ? ((unsigned)(4 * mg + j) * (unsigned)a.gy_ld + (unsigned)c) * 4u : kBigOOB;
+    }
+  } else {
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int kk = kk0 + 128 * h + 4 * cq;
+      const int tp = kk / a.Cin;
+      const int r = tp / a.KW;
+      tap[h] = kk < a.K ? ((r << 8) | (tp - r * a.KW)) : (1 << 20);        // an invalid column: a tap far outside
+      cioff[h] = (unsigned)(kk - tp * a.Cin) * 4u;
+    }
+    const float r_howo = 1.0f / (float)HoWo, r_wo = 1.0f / (float)a.Wo;
+    int pix[4], hw0[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int m = m_begin + 4 * mg + j;      // < 2^24 (checked by the dispatcher)
+      int rem, wo;
+      const int img = div_small(m, HoWo, r_howo, rem);
+      const int ho = div_small(rem, a.Wo, r_wo, wo);
+      pix[j] = img * a.H * a.W;
+      hw0[j] = (int)(((unsigned)(ho * a.stride - a.pad) << 16) | ((unsigned)(wo * a.stride - a.pad) & 0xffffu));
+    }
+    rowst[0] = make_int4(pix[0], pix[1], pix[2], pix[3]);
+    rowst[256] = make_int4(hw0[0], hw0[1], hw0[2], hw0[3]);
+  }
+  const int fr = lane & 31;
+  const unsigned fo = fr * 64 + ((((lane >> 5)) ^ ((fr >> 2) & 3)) << 4);
+  const unsigned fa_base = (wm * 128) * 64 + fo;
+  const unsigned fb_base = 2 * kPlane + (wn * 64) * 64 + fo;
+  // plane row of channel c' of the quad: 128 h + 4 cq + c'; its 16-byte chunks are swizzled with (row >> 2) & 3 = cq & 3
+  const unsigned wofs = (grp ? 2 * kPlane : 0) + (4 * cq) * 64 + ((((mg >> 1) ^ (cq & 3))) << 4) + (mg & 1) * 8;
+
+  float4 raw[2][4];
+  f16x8 fa[2][TM], fb[2][TN];
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  // fetch half h (128 channels) of the load stream's K-tile; after the second half the stream moves on by 32 rows.  Rows
+  // at or beyond M lie beyond the buffers (zeros); rows of the NEXT part are fetched only past this part's last K-tile,
+  // into a slot nobody reads again.
+  auto loads = [&](float4 (&dst)[4], const int h) {
+    if (grp == 0) {
+      const int soff = (ld_m - m_begin) * a.gy_ld * 4 + m_begin * a.gy_ld * 4;
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        dst[j] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rr, (int)(h ? goff[1][j] : goff[0][j]), soff, 0));
+    } else {
+      const int tp = h ? tap[1] : tap[0];
+      const unsigned cb = h ? cioff[1] : cioff[0];
+      const int r = tp >> 8, s2 = tp & 0xff;
+      const int4 pv = rowst[0], hv = rowst[256];
+      int pix[4] = {pv.x, pv.y, pv.z, pv.w}, hw0[4] = {hv.x, hv.y, hv.z, hv.w};
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int hi = (hw0[j] >> 16) + r, wi = (int)(short)(hw0[j] & 0xffff) + s2;
+        const bool ok = ((unsigned)hi < (unsigned)a.H) & ((unsigned)wi < (unsigned)a.W);
+        const unsigned off = (unsigned)(pix[j] + hi * a.W + wi) * (unsigned)(a.Cin * 4) + cb;
+        dst[j] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rr, (int)(ok ? off : kBigOOB), 0, 0));
+      }
+      if (h) {      // the four rows move on by 32 output pixels: branch-free mixed-radix add of (d_img, d_ho, d_wo)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          int wi = (int)(short)(hw0[j] & 0xffff) + d_ws, hi = (hw0[j] >> 16) + d_hs;
+          const bool cw = wi >= w_lim;
+          wi -= cw ? w_span : 0;
+          hi += cw ? a.stride : 0;
+          const bool ch = hi >= h_lim;
+          hi -= ch ? h_span : 0;
+          pix[j] += (d_img + (ch ? 1 : 0)) * a.H * a.W;
+          hw0[j] = (int)(((unsigned)hi << 16) | ((unsigned)wi & 0xffffu));
+        }
+        rowst[0] = make_int4(pix[0], pix[1], pix[2], pix[3]);
+        rowst[256] = make_int4(hw0[0], hw0[1], hw0[2], hw0[3]);
+      }
+    }
+    if (h) ld_m += 32;
+    __builtin_amdgcn_sched_barrier(0);      // the loads go out FIRST in their segment
+  };
+  // 4 x 4 register transpose (a renaming), split, one 8-byte store per channel and plane.  (The two rows a 16-lane store
+  // group touches are 4 apart — the same half of the store path's 128-byte bank window, a two-way conflict on 8 stores per
+  // segment: ~16 cycles; steering odd channel quads through the orders 1 0 3 2 costs 16 selects, more than it returns.)
+  auto stage = [&](const float4 (&v)[4], const int slot, const int h) {
+    char* st = smem + slot * kStage + wofs + h * (128 * 64);
+    const float4 cols[4] = {make_float4(v[0].x, v[1].x, v[2].x, v[3].x), make_float4(v[0].y, v[1].y, v[2].y, v[3].y),
+                            make_float4(v[0].z, v[1].z, v[2].z, v[3].z), make_float4(v[0].w, v[1].w, v[2].w, v[3].w)};
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      uint2 hh, ll;
+      split4m(cols[c], sc, hh, ll);
+      *reinterpret_cast<uint2*>(st + c * 64) = hh;
+      *reinterpret_cast<uint2*>(st + kPlane + c * 64) = ll;
+    }
+  };
+  auto read_frags = [&](const int slot, const int step) {
+    const char* cur = smem + slot * kStage;
+#pragma unroll
+    for (int i = 0; i < TN; ++i) fb[0][i] = *reinterpret_cast<const f16x8*>(cur + ((fb_base + i * 2048) ^ (step * 32)));
+#pragma unroll
+    for (int i = 0; i < TM; ++i) fa[1][i] = *reinterpret_cast<const f16x8*>(cur + kPlane + ((fa_base + i * 2048) ^ (step * 32)));
+#pragma unroll
+    for (int i = 0; i < TM; ++i) fa[0][i] = *reinterpret_cast<const f16x8*>(cur + ((fa_base + i * 2048) ^ (step * 32)));
+#pragma unroll
+    for (int i = 0; i < TN; ++i) fb[1][i] = *reinterpret_cast<const f16x8*>(cur + kPlane + ((fb_base + i * 2048) ^ (step * 32)));
+  };
+  auto mfma_seg = [&]() {
+#pragma unroll
+    for (int term = 0; term < 3; ++term) {
+      const int pa = term == 0 ? 1 : 0, pb = term == 1 ? 1 : 0;
+#pragma unroll
+      for (int im = 0; im < TM; ++im)
+#pragma unroll
+        for (int in = 0; in < TN; ++in)
+          acc[im][in] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[pa][im], fb[pb][in], acc[im][in], 0, 0, 0);
+    }
+  };
+  auto bar = [&]() {
+    __builtin_amdgcn_sched_barrier(0);
+    __syncthreads();
+    __builtin_amdgcn_sched_barrier(0);
+  };
+
+  // the schedule of conv_big_kernel (quarters = halves of the group's 256 channels)
+  loads(raw[0], 0); stage(raw[0], 0, 0);
+  loads(raw[1], 1); stage(raw[1], 0, 1);
+  loads(raw[0], 0);
+  if (grp == 0) {
+    stage(raw[0], 1, 0);
+    loads(raw[1], 1);
+  }
+  bar();
+  if (grp == 0) {
+    read_frags(0, 0);
+    for (int Tt = 0; Tt < nT; ++Tt) {
+      const int cur = Tt & 1;
+      mfma_seg();
+      bar();
+      loads(raw[0], 0); read_frags(cur, 1); stage(raw[1], cur ^ 1, 1);
+      bar();
+      mfma_seg();
+      bar();
+      loads(raw[1], 1); read_frags(cur ^ 1, 0); stage(raw[0], cur, 0);
+      bar();
+    }
+  } else {
+    for (int Tt = 0; Tt < nT; ++Tt) {
+      const int cur = Tt & 1;
+      loads(raw[1], 1); read_frags(cur, 0); stage(raw[0], cur ^ 1, 0);
+      bar();
+      mfma_seg();
+      bar();
+      loads(raw[0], 0); read_frags(cur, 1); stage(raw[1], cur ^ 1, 1);
+      bar();
+      mfma_seg();
+      bar();
+    }
+  }
+
+  // ---- epilogue: undo the scales, turn every 32 x 32 block through LDS, 16-byte stores along kk
+  {
+    const int tt = -(eg + ex);
+    const float u1 = pow2f(tt / 2), u2 = pow2f(tt - tt / 2);
+#pragma unroll
+    for (int im = 0; im < TM; ++im)
+#pragma unroll
+      for (int in = 0; in < TN; ++in)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[im][in][e] = acc[im][in][e] * u1 * u2;
+  }
+  float* out = a.direct ? a.out : a.out + (size_t)part * a.Cout * a.K;
+  const bool final_out = a.direct;
+  float* tile_f = reinterpret_cast<float*>(smem) + wave * (32 * EPI_STRIDE);
+  const int col_in = lane & 31, row_hi = 4 * (lane >> 5);
+  const int rrow = lane >> 3, c4 = (lane & 7) * 4;
+#pragma unroll
+  for (int in = 0; in < TN; ++in) {
+    const int kk = kk0 + wn * 64 + in * 32 + c4;
+#pragma unroll
+    for (int im = 0; im < TM; ++im) {
+#pragma unroll
+      for (int g = 0; g < 4; ++g)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) tile_f[(e + 8 * g + row_hi) * EPI_STRIDE + col_in] = acc[im][in][g * 4 + e];
+      __builtin_amdgcn_s_waitcnt(0xc07f);                // lgkmcnt(0): a wave's own data only
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int pass = 0; pass < 4; ++pass) {
+        const int c = co0 + wm * 128 + im * 32 + pass * 8 + rrow;
+        float4 v = *reinterpret_cast<const float4*>(tile_f + (pass * 8 + rrow) * EPI_STRIDE + c4);
+        if (c < a.Cout && kk < a.K) {
+          float4* dst = reinterpret_cast<float4*>(out + (size_t)c * a.K + kk);
+          if (final_out) {
+            if (a.out_scale) { const float sv = a.out_scale[c]; v.x *= sv; v.y *= sv; v.z *= sv; v.w *= sv; }
+            if (a.accumulate) { const float4 o = *dst; v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w; }
+          }
+          *dst = v;
+        }
+      }
+      __builtin_amdgcn_wave_barrier();
+    }
+  }
+}
+
 // ---- host side -------------------------------------------------------------------------------------------------------
 // 0: never, 1: where the plan below expects a gain, 2: wherever the kernel is applicable (tests).  DADET_BIG_GEMM sets the
 // start-up value (A/B runs); dadet_set_big_gemm changes it at run time
@@ -729,6 +991,47 @@ int launch_fwd_big(ConvArgs& a, hipStream_t st, float* ws, int* counters) {
   if (variant == 2) hipLaunchKernelGGL(conv_big128_kernel, dim3(tiles * a.big_splits), dim3(512), lds, st, a);
   else hipLaunchKernelGGL((conv_big_kernel<256>), dim3(tiles * a.big_splits), dim3(512), lds, st, a);
   return check_launch("conv_forward(big)");
+}
+
+// ---- weight gradient: plan and launch -----------------------------------------------------------------------------
+// The grid is small (Cout x K in tiles of 256 x 256: 4 .. 72 tiles), so the reduction over the M rows is cut into `splits`
+// ranges of whole K-tiles that fill the 256 CUs once.  Returns false when the 128 x 128 kernel should run.
+bool wgrad_big_plan(const dadet_conv_desc* d, int* tiles_co, int* tiles_kc, int* splits, int* rps) {
+  static const bool enabled = !(getenv("DADET_WGRAD_BIG") && getenv("DADET_WGRAD_BIG")[0] == '0');   // A/B runs
+  if (!enabled || g_big_mode == 0 || gemm_mode() != 4) return false;
+  const int M = d->N * d->Ho * d->Wo, K = d->KH * d->KW * d->Cin;
+  if (d->Cin % 4 != 0 || K % 4 != 0 || M >= (1 << 24)) return false;
+  if ((uint64_t)d->N * d->H * d->W * d->Cin * 4 >= 0x7FFFFF00ull || (uint64_t)M * ((d->Cout + 3) / 4 * 4) * 4 >= 0x7FFFFF00ull)
+    return false;
+  if (g_big_mode != 2 && (d->Cout < 256 || K < 256 || M < 2048)) return false;
+  *tiles_co = ceil_div(d->Cout, 256);
+  *tiles_kc = ceil_div(K, 256);
+  const int tiles = (*tiles_co) * (*tiles_kc);
+  int s = kNumCU / tiles;
+  if (const char* e = getenv("DADET_WGRAD_BIG_SPLITS")) { const int v = atoi(e); if (v > 0) s = v; }
+  if (s < 1) s = 1;
+  const int max_s = ceil_div(M, 128);                 // at least four K-tiles per part
+  if (s > max_s) s = max_s;
+  const int rows = ceil_div(ceil_div(M, s), 32) * 32;
+  *rps = rows;
+  *splits = ceil_div(M, rows);
+  return true;
+}
+
+int launch_wgrad_big(WgradArgs& a, hipStream_t st) {
+  const size_t lds = 2 * 4 * 256 * 64 + 2 * 256 * sizeof(int4);      // two K-tile slots + group 1's row state
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad_big_kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) {
+      set_error("conv_wgrad(big): hipFuncSetAttribute: %s", hipGetErrorString(e));
+      return DADET_ELAUNCH;
+    }
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(conv_wgrad_big_kernel, dim3(a.tiles_co * a.tiles_kc * a.splits), dim3(512), lds, st, a);
+  return check_launch("conv_wgrad(big)");
 }
 
 }  // namespace dadet

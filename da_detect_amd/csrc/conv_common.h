@@ -245,6 +245,10 @@ bool big_eligible(const ConvArgs& a);
 int big_variant(const ConvArgs& a);      // 0 none, 1 the 256 x 256 tile, 2 the 256 x 128 tile
 size_t big_workspace_bytes(const ConvArgs& a);
 int launch_fwd_big(ConvArgs& a, hipStream_t st, float* ws, int* counters);
+// weight gradient on 256 x 256 tiles (conv_big.hip): the plan (false: the 128 x 128 kernel runs) and the launch; partial sums
+// in the 128 x 128 kernel's [splits][Cout][K] layout
+bool wgrad_big_plan(const dadet_conv_desc* d, int* tiles_co, int* tiles_kc, int* splits, int* rps);
+int launch_wgrad_big(WgradArgs& a, hipStream_t st);
 // weight-stationary 1x1 kernel for K = 64 / 128 / 256 (conv_ws.hip)
 bool ws_eligible(const ConvArgs& a);
 int launch_fwd_ws(ConvArgs& a, int fmt, hipStream_t st);

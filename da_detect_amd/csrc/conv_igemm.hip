@@ -1008,6 +1008,10 @@ extern "C" int dadet_conv_wgrad_workspace_bytes(const dadet_conv_desc* d, size_t
   DADET_REQUIRE(bytes_out, "conv_wgrad_workspace_bytes: null out");
   if (d->N == 0) { *bytes_out = 0; return DADET_OK; }
   int tco, tkc, splits, rps;
+  if (wgrad_big_plan(d, &tco, &tkc, &splits, &rps)) {     // 256 x 256 tiles: dense [splits][Cout][K] partial sums
+    *bytes_out = splits > 1 ? sizeof(float) * (size_t)splits * d->Cout * d->KH * d->KW * d->Cin : 0;
+    return DADET_OK;
+  }
   wgrad_plan(d, &tco, &tkc, &splits, &rps);
   // (rounded up to whole 128 x 128 tiles)
   *bytes_out = splits > 1 ? sizeof(float) * (size_t)splits * tco * tkc * 128 * 128 : 0;
@@ -1044,7 +1048,8 @@ static int conv_wgrad_impl(const dadet_conv_desc* d, const float* x, const float
   DADET_REQUIRE(xb < 0xFFFFFFF0ull && gb < 0xFFFFFFF0ull,
                 "conv_wgrad: tensors of 4 GB or more are not addressable through one buffer descriptor");
   a.x_bytes = (unsigned)xb; a.gy_bytes = (unsigned)gb;
-  wgrad_plan(d, &a.tiles_co, &a.tiles_kc, &a.splits, &a.rows_per_split);
+  const bool big = gy_ld == d->Cout && wgrad_big_plan(d, &a.tiles_co, &a.tiles_kc, &a.splits, &a.rows_per_split);
+  if (!big) wgrad_plan(d, &a.tiles_co, &a.tiles_kc, &a.splits, &a.rows_per_split);
   a.accumulate = accumulate;
   a.amax_x = a.amax_gy = nullptr;
   if (gemm_mode() == 4) {
@@ -1069,7 +1074,8 @@ static int conv_wgrad_impl(const dadet_conv_desc* d, const float* x, const float
     a.direct = 1;
     a.out = dw;
   } else {
-    const size_t need = sizeof(float) * (size_t)a.splits * a.tiles_co * a.tiles_kc * 128 * 128;
+    const size_t need = big ? sizeof(float) * (size_t)a.splits * d->Cout * K
+                            : sizeof(float) * (size_t)a.splits * a.tiles_co * a.tiles_kc * 128 * 128;
     if (!workspace || workspace_bytes < need) {
       set_error("conv_wgrad: workspace %zu < required %zu", workspace_bytes, need);
       return DADET_EWORKSPACE;
@@ -1091,7 +1097,9 @@ static int conv_wgrad_impl(const dadet_conv_desc* d, const float* x, const float
     }
     attr_set = true;
   }
-  if (gemm_mode() != 0) {
+  if (big) {
+    rc = launch_wgrad_big(a, st);
+  } else if (gemm_mode() != 0) {
     rc = launch_wgrad_split(a, gemm_mode(), st);
   } else {
     hipLaunchKernelGGL(conv_wgrad_kernel, dim3(a.tiles_co * a.tiles_kc, a.splits), dim3(256), lds, st, a);

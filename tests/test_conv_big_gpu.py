@@ -130,3 +130,67 @@ def test_big_tile_kernel_leaves_the_output_maximum(device, big_mode):
     big_mode.dadet_set_big_gemm(2)
     y = _C.conv_forward(x, w, pad=1, relu_mode=1)
     assert _amax.value(y) == float(y.abs().max())
+
+
+# N, Cin, H, W, Cout, k, stride, pad
+WGRAD_CASES = [
+    (1, 64, 24, 40, 256, 1, 1, 0),       # one tile, M = 960 rows
+    (2, 128, 20, 28, 300, 3, 1, 1),      # 3x3 with padding, ragged Cout, K = 1152: 2 x 5 tiles, a tap change inside a tile
+    (1, 256, 33, 47, 256, 3, 1, 1),      # ragged M (1551 rows: the last K-tile is partly beyond M)
+    (2, 96, 14, 14, 260, 3, 1, 1),       # Cin = 96: column tiles straddle filter taps, 7 x 7-like small maps (Wo < 32)
+    (1, 512, 30, 30, 512, 1, 2, 0),      # stride 2, 1x1 (the projection shortcut's gradient)
+    (4, 64, 7, 7, 256, 3, 1, 1),         # 7 x 7 maps: 32 rows span 4.6 map rows and an image boundary
+    (1, 32, 64, 64, 512, 3, 2, 1),       # stride 2, 3x3
+]
+
+
+@pytest.mark.parametrize("splits", [0, 1, 3])
+@pytest.mark.parametrize("case", WGRAD_CASES, ids=lambda c: "n%d_c%d_%dx%d_o%d_k%d_s%d_p%d" % c)
+def test_big_tile_weight_gradient_against_float64(device, big_mode, case, splits, monkeypatch):
+    """conv_wgrad_big_kernel against the float64 weight gradient and against the 128 x 128 kernel, with the reduction over
+    the pixels in the planned number of parts (0), one part (the kernel writes dW itself, scale and accumulation
+    included) and three parts (partial sums + the deterministic reduction pass)"""
+    from da_detect_amd import _C
+
+    N, Cin, H, W, Cout, k, stride, pad = case
+    g = torch.Generator().manual_seed(sum(case))
+    x = torch.randn((N, Cin, H, W), generator=g).to(device).contiguous(memory_format=CL)
+    Ho, Wo = (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
+    gy = torch.randn((N, Cout, Ho, Wo), generator=g).to(device).contiguous(memory_format=CL)
+    scale = (torch.rand(Cout, generator=g) + 0.5).to(device)
+    prev = torch.randn((Cout, Cin, k, k), generator=g).to(device).contiguous(memory_format=CL)
+    ref = torch.nn.grad.conv2d_weight(x.double(), (Cout, Cin, k, k), gy.double(), stride=stride, padding=pad)
+    ref = ref * scale.double().view(-1, 1, 1, 1) + prev.double()
+    if splits:
+        monkeypatch.setenv("DADET_WGRAD_BIG_SPLITS", str(splits))
+    out = {}
+    for mode in (0, 2):
+        big_mode.dadet_set_big_gemm(mode)
+        dw = prev.clone()
+        out[mode] = _C.conv_wgrad(x, gy, (Cout, Cin, k, k), stride=stride, pad=pad, out_scale=scale, dw=dw, accumulate=True)
+        dw2 = prev.clone()
+        again = _C.conv_wgrad(x, gy, (Cout, Cin, k, k), stride=stride, pad=pad, out_scale=scale, dw=dw2, accumulate=True)
+        assert torch.equal(out[mode], again)
+    top = float(ref.abs().max())
+    errs = {m: float((out[m].double() - ref).abs().max()) for m in out}
+    assert errs[2] <= 2e-5 * top, errs
+    torch.testing.assert_close(out[2], out[0], rtol=2e-5, atol=2e-5 * top)
+
+
+def test_big_tile_weight_gradient_through_the_batched_reduction(device, big_mode):
+    """the deferred form the training step uses: partial sums now, one reduction launch for several layers later"""
+    from da_detect_amd import _C
+
+    g = torch.Generator().manual_seed(3)
+    big_mode.dadet_set_big_gemm(2)
+    batch = _C.WgradBatch()
+    items = []
+    for (Cin, Cout, k, pad) in [(64, 256, 3, 1), (256, 512, 1, 0)]:
+        x = torch.randn((2, Cin, 24, 24), generator=g).to(device).contiguous(memory_format=CL)
+        gy = torch.randn((2, Cout, 24, 24), generator=g).to(device).contiguous(memory_format=CL)
+        dw = _C.conv_wgrad(x, gy, (Cout, Cin, k, k), pad=pad, pending=batch)
+        items.append((x, gy, dw, (Cout, Cin, k, k), pad))
+    _C.conv_wgrad_reduce_batch(batch)
+    for x, gy, dw, shape, pad in items:
+        ref = torch.nn.grad.conv2d_weight(x.double(), shape, gy.double(), padding=pad)
+        assert float((dw.double() - ref).abs().max()) <= 2e-5 * float(ref.abs().max())
