@@ -556,6 +556,16 @@ class WgradBatch(list):
     (conv_wgrad(..., pending=batch) ... conv_wgrad_reduce_batch(batch)); keeps their workspaces alive until then"""
 
 
+def _wgrad_kname(d, dense_rows):
+    """the kernel a weight-gradient launch of this shape runs (profiling labels)"""
+    mode = get_gemm_mode()
+    if mode == 0:
+        return "conv_wgrad_kernel"
+    if dense_rows and _lib.load().dadet_conv_wgrad_variant(ctypes.byref(d)) == 1:
+        return "conv_wgrad_big_kernel"
+    return "conv_wgrad_split_kernel<%d>" % mode
+
+
 def conv_wgrad_reduce_batch(batch):
     """one launch for the reduction passes collected in `batch` (dadet_conv_wgrad_reduce_batch); same stream as the GEMMs"""
     if not batch:
@@ -607,8 +617,7 @@ def conv_wgrad(x, gy, weight_shape, stride=1, pad=0, out_scale=None, dw=None, ac
                       1 if accumulate else 0, _p(ws), ctypes.c_size_t(ws.numel()), ctypes.byref(item), _stream())
 
         if PROFILER is not None:
-            mode = get_gemm_mode()
-            kname = "conv_wgrad_kernel" if mode == 0 else "conv_wgrad_split_kernel<%d>" % mode
+            kname = _wgrad_kname(d, gy_ld == Cout)
             if getattr(PROFILER, "detail", False):
                 kname = "%s|M=%d N=%d K=%d k%dx%d s%d" % (kname, N * Ho * Wo, Cout, Cin * KH * KW, KH, KW, stride)
             with PROFILER.span(kname, 2.0 * N * Ho * Wo * Cout * Cin * KH * KW,
@@ -621,8 +630,7 @@ def conv_wgrad(x, gy, weight_shape, stride=1, pad=0, out_scale=None, dw=None, ac
         return dw
     ws = _workspace(nbytes.value, x.device)
     if PROFILER is not None:
-        mode = get_gemm_mode()
-        kname = "conv_wgrad_kernel" if mode == 0 else "conv_wgrad_split_kernel<%d>" % mode
+        kname = _wgrad_kname(d, gy_ld == Cout)
         if getattr(PROFILER, "detail", False):
             kname = "%s|M=%d N=%d K=%d k%dx%d s%d" % (kname, N * Ho * Wo, Cout, Cin * KH * KW, KH, KW, stride)
         with PROFILER.span(kname,

@@ -38,6 +38,21 @@
 // consecutive columns), two blocks per round of residual / gate loads.
 #include "conv_common.h"
 
+// DADET_BIG_TIMING (build-time, probes only): workgroup 0 .. 255 of conv_big_kernel leave s_memtime stamps at the phase
+// boundaries (start, prologue done, K loop done, parts met, end) in a device array that dadet_big_timing_read copies out
+#ifndef DADET_BIG_TIMING
+#define DADET_BIG_TIMING 0
+#endif
+#if DADET_BIG_TIMING
+__device__ unsigned long long g_big_stamps[256 * 8];
+#define BIG_STAMP(i) do { if (threadIdx.x == 0 && blockIdx.x < 256) g_big_stamps[blockIdx.x * 8 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+extern "C" int dadet_big_timing_read(unsigned long long* host, int n) {
+  return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_big_stamps), sizeof(unsigned long long) * (n < 2048 ? n : 2048));
+}
+#else
+#define BIG_STAMP(i) do { } while (0)
+#endif
+
 namespace dadet {
 
 namespace {
@@ -92,6 +107,7 @@ __device__ __forceinline__ void big_finish(const ConvArgs& a, f32x16 (&acc)[TM][
         for (int e = 0; e < 16; ++e) acc[im][in][e] = acc[im][in][e] * u1 * u2;
   }
 
+  BIG_STAMP(2);
   int* s_word = reinterpret_cast<int*>(smem);        // the operand planes are dead (every wave passed the last barrier)
   if (S > 1) {
     const __amdgpu_buffer_rsrc_t pr = make_rsrc(a.sk_ws + (size_t)tile * S * (256 * BN), (unsigned)(S * 256 * BN * 4));
@@ -125,6 +141,29 @@ __device__ __forceinline__ void big_finish(const ConvArgs& a, f32x16 (&acc)[TM][
     }
     __syncthreads();
     // sum in part order, this part's registers at its own index: the result does not depend on who came last
+    if (S == 2) {
+      // two parts (the usual cut): a + b needs no order; the other part's tile is fetched sixteen 16-byte loads per lane at
+      // a time (four blocks: two round trips through the fabric per tile instead of eight, ~2 us each)
+      const unsigned src = (unsigned)(part ^ 1) * (256 * BN * 4) + (unsigned)t * 16u;
+      constexpr int NB = TM * TN;
+#pragma unroll
+      for (int b0 = 0; b0 < NB; b0 += 4) {
+        float4 v[4][4];
+#pragma unroll
+        for (int b = 0; b < 4; ++b)
+#pragma unroll
+          for (int g = 0; g < 4; ++g) v[b][g] = buf_load4_sc1(pr, src + ((b0 + b) * 4 + g) * 8192u);
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+          const int im = (b0 + b) / TN, in = (b0 + b) % TN;
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            acc[im][in][g * 4] += v[b][g].x; acc[im][in][g * 4 + 1] += v[b][g].y;
+            acc[im][in][g * 4 + 2] += v[b][g].z; acc[im][in][g * 4 + 3] += v[b][g].w;
+          }
+        }
+      }
+    } else
 #pragma unroll
     for (int im = 0; im < TM; ++im)
 #pragma unroll
@@ -159,6 +198,7 @@ __device__ __forceinline__ void big_finish(const ConvArgs& a, f32x16 (&acc)[TM][
     __syncthreads();      // s_word is about to be reused as transpose space
   }
 
+  BIG_STAMP(3);
   // ---- epilogue: y = gate(acc * scale + bias + addend), 16 bytes per lane through an LDS transpose (conv_split.hip:
   // conv_epilogue_v4), the same arithmetic per element in the same order
   float* tile_f = reinterpret_cast<float*>(smem) + wave * (2 * 32 * EPI_STRIDE);
@@ -249,12 +289,14 @@ __device__ __forceinline__ void big_finish(const ConvArgs& a, f32x16 (&acc)[TM][
     }
   }
   if (a.amax_y) amax_publish(a.amax_y, mx);
+  BIG_STAMP(4);
 }
 
 template <int BN>
 __global__ __launch_bounds__(512, 2) void conv_big_kernel(const ConvArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   static_assert(BN == 256, "wave layout below is 2 x 4 waves of 128 x 64");
+  BIG_STAMP(0);
   constexpr int TM = 4, TN = 2;
   constexpr int kPlane = 256 * 64;          // one fp16 plane of 256 rows x 32 k
   constexpr int kStage = 4 * kPlane;        // A_h | A_l | B_h | B_l
@@ -416,14 +458,19 @@ __global__ __launch_bounds__(512, 2) void conv_big_kernel(const ConvArgs a) {
   //   group 0 multiplies in even segments; its load segment 2v + 1 stores quarter v + 3 and fetches quarter v + 4
   //   group 1 multiplies in odd segments;  its load segment 2v     stores quarter v + 2 and fetches quarter v + 3
   // prologue: quarters 0 .. 2 (group 0) / 0 .. 1 (group 1) stored synchronously, the next one in flight
-  loads(raw[0], 0); stage(raw[0], 0, 0);
-  loads(raw[1], 1); stage(raw[1], 0, 1);
-  loads(raw[0], 0);
-  if (grp == 0) {
-    stage(raw[0], 1, 0);
-    loads(raw[1], 1);
+  // (all of them fetched up front — one trip to memory instead of three; the accumulators are not live yet)
+  {
+    float4 q0[4], q1[4];
+    loads(q0, 0);
+    loads(q1, 1);
+    loads(raw[0], 0);
+    if (grp == 0) loads(raw[1], 1);
+    stage(q0, 0, 0);
+    stage(q1, 0, 1);
+    if (grp == 0) stage(raw[0], 1, 0);
   }
   bar();
+  BIG_STAMP(1);
   if (grp == 0) {
     read_frags(0, 0);
     for (int Tt = 0; Tt < nT; ++Tt) {
@@ -610,11 +657,14 @@ __global__ __launch_bounds__(512, 2) void conv_big128_kernel(const ConvArgs a) {
 
   // prologue: K-tile 0 stored by both groups, K-tile 1 by group 0 (its segment "-1"); group 0 has K-tile 2 on its way
   // (raw[0]), group 1 K-tile 1 (raw[1])
-  loads(raw[0]); stage(raw[0], 0);
-  loads(raw[1]);
-  if (grp == 0) {
-    stage(raw[1], 1);
-    loads(raw[0]);
+  // (all fetched up front: one trip to memory)
+  {
+    float4 q0[6];
+    loads(q0);
+    loads(raw[1]);
+    if (grp == 0) loads(raw[0]);
+    stage(q0, 0);
+    if (grp == 0) stage(raw[1], 1);
   }
   bar();
   if (grp == 0) {
@@ -830,12 +880,15 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_big_kernel(const WgradArgs 
   };
 
   // the schedule of conv_big_kernel (quarters = halves of the group's 256 channels)
-  loads(raw[0], 0); stage(raw[0], 0, 0);
-  loads(raw[1], 1); stage(raw[1], 0, 1);
-  loads(raw[0], 0);
-  if (grp == 0) {
-    stage(raw[0], 1, 0);
-    loads(raw[1], 1);
+  {
+    float4 q0[4], q1[4];      // all fetched up front: one trip to memory
+    loads(q0, 0);
+    loads(q1, 1);
+    loads(raw[0], 0);
+    if (grp == 0) loads(raw[1], 1);
+    stage(q0, 0, 0);
+    stage(q1, 0, 1);
+    if (grp == 0) stage(raw[0], 1, 0);
   }
   bar();
   if (grp == 0) {

@@ -962,6 +962,12 @@ extern "C" int dadet_conv_forward_variant(const dadet_conv_desc* d) {
   return gemm_mode() != 0 ? split_fwd_variant(M, d->Cout, d->KH * d->KW * d->Cin) : fwd_variant(M, d->Cout);
 }
 
+extern "C" int dadet_conv_wgrad_variant(const dadet_conv_desc* d) {
+  if (!d) return -1;
+  int tco, tkc, splits, rps;
+  return wgrad_big_plan(d, &tco, &tkc, &splits, &rps) ? 1 : 0;
+}
+
 // Split plan of the weight gradient: the (co tile, kc tile) grid is small (4 ... 576 tiles), so the reduction over the
 // M = N*Ho*Wo rows is cut into `splits` ranges to fill the 2 x 256 workgroup slots of the chip.  The number of
 // workgroups matters in steps of 512: one more than a multiple of 512 costs a whole extra pass of mostly idle CUs

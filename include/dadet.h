@@ -210,6 +210,9 @@ int dadet_conv_forward_variant(const dadet_conv_desc* d);
  * (+ dw_prev when accumulate != 0).  Deterministic split-K over m through `workspace`
  * (query with dadet_conv_wgrad_workspace_bytes).  gy is [N][Ho][Wo][Cout] dense. */
 int dadet_conv_wgrad_workspace_bytes(const dadet_conv_desc* d, size_t* bytes_out);
+/* which kernel dadet_conv_wgrad* launches for this shape (dense gy rows): 0 = 128 x 128 tiles, 1 = 256 x 256 tiles
+ * (conv_wgrad_big_kernel, mode 4; see dadet_set_big_gemm).  Profiling labels. */
+int dadet_conv_wgrad_variant(const dadet_conv_desc* d);
 int dadet_conv_wgrad(const dadet_conv_desc* d, const float* x, const float* gy, const float* out_scale,
                      float* dw, int accumulate, void* workspace, size_t workspace_bytes, void* stream);
 /* The same with the reduction over the split partial results left to the caller: when the plan splits the reduction,

@@ -733,8 +733,49 @@ static void part_pmc(char which) {
   CK(hipDeviceSynchronize());
 }
 
+// phase times of conv_big_kernel (library built with -DDADET_BIG_TIMING=1): argv "t M N K"
+#include <dlfcn.h>
+static void part_timing(int M, int N, int K) {
+  typedef int (*read_fn)(unsigned long long*, int);
+  read_fn rd = (read_fn)dlsym(RTLD_DEFAULT, "dadet_big_timing_read");
+  if (!rd) { printf("library without DADET_BIG_TIMING\n"); return; }
+  std::vector<float> hA((size_t)M * K), hB((size_t)N * K);
+  unsigned long long st = 777;
+  for (auto& v : hA) v = (float)gauss(st);
+  for (auto& v : hB) v = (float)gauss(st) * 0.02f;
+  float *dA, *dB, *dC, *slots;
+  CK(hipMalloc(&dA, hA.size() * 4)); CK(hipMalloc(&dB, hB.size() * 4)); CK(hipMalloc(&dC, (size_t)M * N * 4));
+  CK(hipMalloc(&slots, 8 * DADET_AMAX_STRIDE * 4));
+  CK(hipMemset(slots, 0, 8 * DADET_AMAX_STRIDE * 4));
+  CK(hipMemcpy(dA, hA.data(), hA.size() * 4, hipMemcpyHostToDevice));
+  CK(hipMemcpy(dB, hB.data(), hB.size() * 4, hipMemcpyHostToDevice));
+  dadet_conv_desc d{};
+  d.N = 1; d.H = 1; d.W = M; d.Cin = K; d.Cout = N; d.KH = d.KW = 1; d.stride = 1; d.pad = 0; d.Ho = 1; d.Wo = M;
+  d.OutH = 1; d.OutW = M; d.out_spatial_stride = 1; d.relu_mode = 0;
+  dadet_amax(dA, (long long)M * K, slots, nullptr);
+  dadet_amax(dB, (long long)N * K, slots + 1, nullptr);
+  for (int r = 0; r < 5; ++r)
+    dadet_conv_forward_scaled(&d, dA, dB, nullptr, nullptr, nullptr, nullptr, dC, slots, slots + 1, nullptr, nullptr);
+  CK(hipDeviceSynchronize());
+  std::vector<unsigned long long> s(2048);
+  rd(s.data(), 2048);
+  double sum[4] = {0, 0, 0, 0}; int n = 0;
+  unsigned long long t0 = ~0ull, t1 = 0;
+  for (int b = 0; b < 256; ++b) {
+    const unsigned long long* p = &s[b * 8];
+    if (!p[0] || !p[4]) continue;
+    for (int i = 0; i < 4; ++i) sum[i] += (double)(p[i + 1] - p[i]);
+    t0 = p[0] < t0 ? p[0] : t0; t1 = p[4] > t1 ? p[4] : t1;
+    ++n;
+  }
+  // s_memtime ticks at 100 MHz on this part
+  printf("M=%d N=%d K=%d  (%d workgroups stamped; 10 ns ticks)  prologue %.2f us | K loop %.2f | parts %.2f | epilogue %.2f | first start -> last end %.2f us\n",
+         M, N, K, n, sum[0] / n / 100, sum[1] / n / 100, sum[2] / n / 100, sum[3] / n / 100, (double)(t1 - t0) / 100);
+}
+
 int main(int argc, char** argv) {
   if (argc > 2 && argv[1][0] == 'c') { part_pmc(argv[2][0]); return 0; }
+  if (argc > 4 && argv[1][0] == 't') { part_timing(atoi(argv[2]), atoi(argv[3]), atoi(argv[4])); return 0; }
   const bool quick = argc > 1 && argv[1][0] == 'q';
   part0();
   if (!(argc > 1 && argv[1][0] == 's')) part1();
