@@ -123,6 +123,19 @@ def cpu_baseline(cfg_path, seed, budget_s=90.0):
                                            benchmark_init, budget_s)
 
 
+# the kernel family bracketed inside the timed region (mode 4): by summed time the largest one of the step
+DOMINANT_FAMILY = "conv_big_kernel<256>"
+# profiles/r05_gemm_lab.txt part 1: a register-only stream of v_mfma_f32_32x32x16_f16 on operands with the bit statistics of
+# split fp32 data (leading / residual fp16 terms of gaussians) sustains 1625 TFLOP/s on this part — its power management
+# lowers the clock under random operand bits (2464 on zeros) — i.e. 541.7 TFLOP/s ALGORITHMIC in the three-MFMA contraction.
+# Reported next to the nominal ceiling, never instead of it.
+F16_STREAM_ON_SPLIT_OPERANDS_TFLOPS = 1625.0
+# kernel families of the mode-4 step for `roofline.families` (name fragments of the profiler's labels)
+FAMILIES = [("fwd_dgrad_256x256", ("conv_big_kernel<256>",)), ("fwd_dgrad_256x128", ("conv_big128_kernel",)),
+            ("wgrad_256x256", ("conv_wgrad_big_kernel",)), ("fwd_dgrad_128x128", ("conv_fwd_split_kernel", "conv_fwd_split_sk_kernel")),
+            ("wgrad_128x128", ("conv_wgrad_split_kernel",)), ("weight_stationary_1x1", ("conv1x1_ws_kernel",))]
+
+
 def pmc_traffic(kernel_name, gemm_mode):
     """HBM bytes per launch of `kernel_name` from the committed PMC passes (profiles/r04_pmc_hbm_traffic[_mode4].json,
     made by tools/profile_pmc.sh from this same bench command in that mode; counters cannot be read from inside the
@@ -130,7 +143,7 @@ def pmc_traffic(kernel_name, gemm_mode):
     and, where the tile grid leaves a partly empty last pass, conv_fwd_split_sk_kernel<M> (stream-K tail) — and the in-process
     timer brackets both under one name: the figure is the launch-weighted mean over both.  None when the summary does
     not cover the kernel / mode."""
-    path = os.path.join(ROOT, "profiles", {3: "r04_pmc_hbm_traffic.json", 4: "r04_pmc_hbm_traffic_mode4.json"}.get(
+    path = os.path.join(ROOT, "profiles", {3: "r04_pmc_hbm_traffic.json", 4: "r05_pmc_hbm_traffic.json"}.get(
         gemm_mode, "none"))
     if not os.path.exists(path):
         return None, None
@@ -257,7 +270,8 @@ def run_workload(args, name, device, rank, world, steps, warmup, headline):
     if headline and not args.no_kernel_timing and rank == 0:
         # timed region: only the dominant kernel family (128x128-tile forward / data-gradient GEMM) is bracketed —
         # every event pair between two launches costs dispatch concurrency (measured: ~1 ms / step for all GEMMs)
-        profiler = _C.KernelProfiler(pool=2 * 80 * steps, only="<2,2")
+        # (round 5: the 256 x 256-tile forward / data-gradient kernel, csrc/conv_big.hip, is the family with the most time)
+        profiler = _C.KernelProfiler(pool=2 * 80 * steps, only=DOMINANT_FAMILY if args.gemm_mode == 4 else "<2,2")
     barrier()
     mem0 = torch.cuda.memory_stats(device) if os.environ.get("DADET_BENCH_MEMSTATS") else None
     t0 = time.perf_counter()
@@ -531,6 +545,13 @@ def main():
                         "gflop_per_launch": round(k["work_per_launch"] / 1e9, 3),
                         "share_of_step": round(k["total_ms"] / bracketed_steps / ms_per_step, 4)}
             if args.gemm_mode == 4:
+                roofline["power_limited_mfma_stream"] = {
+                    "executed_tflops": F16_STREAM_ON_SPLIT_OPERANDS_TFLOPS,
+                    "algorithmic_tflops": round(F16_STREAM_ON_SPLIT_OPERANDS_TFLOPS / mfma_per_product, 1),
+                    "frac_of_it": round(achieved * mfma_per_product / F16_STREAM_ON_SPLIT_OPERANDS_TFLOPS, 4),
+                    "note": "a register-only v_mfma_f32_32x32x16_f16 stream on operands with the bit statistics of split "
+                            "fp32 data sustains this on the part (2464 on zeros): tools/native/gemm_lab.hip part 1, "
+                            "profiles/r05_gemm_lab.txt.  Context for `frac`, which stays against the nominal peak"}
                 # continuity with rounds 1 - 3, whose contraction (mode 3) needed six bf16 MFMAs per fp32 product: the same
                 # ALGORITHMIC rate against that mode's 416.7 TFLOP/s ceiling.  `frac` above is against the ceiling of the
                 # contraction that actually runs (three fp16 MFMAs per product: 833.3).
@@ -556,6 +577,30 @@ def main():
                     "all_gemm_tflops_while_any_runs": round(work / (busy_ms * 1e-3) / 1e12, 2),
                     "all_gemm_frac": round(work / (busy_ms * 1e-3) / 1e12 / peak, 4),
                     "gemm_busy_share_of_step": round(busy_ms / (r["extra_elapsed"] * 1e3), 4)}
+                # every GEMM family of the step (same extra pass): rate against the contraction's ceiling; PMC bytes per
+                # launch over algorithmic bytes where the committed counter passes cover the family
+                fams = {}
+                # (from the pass with the second GEMM stream off when the tuner kept it: a family's rate, like `frac`, must
+                # not include a co-running kernel)
+                fam_src = exclusive.summary() if exclusive is not None else kernels
+                for fam, frags in FAMILIES:
+                    ks = [v for n_, v in fam_src.items() if any(f in n_ for f in frags)]
+                    if not ks:
+                        continue
+                    ms_ = sum(v["total_ms"] for v in ks)
+                    work_ = sum(v["work_per_launch"] * v["launches"] for v in ks)
+                    launches_ = sum(v["launches"] for v in ks)
+                    alg_ = sum(v["bytes_per_launch"] * v["launches"] for v in ks) / launches_
+                    rec = {"ms_per_step": round(ms_ / r["extra"], 3), "launches_per_step": round(launches_ / r["extra"], 1),
+                           "tflops": round(work_ / (ms_ * 1e-3) / 1e12, 1),
+                           "frac": round(work_ / (ms_ * 1e-3) / 1e12 / peak, 4),
+                           "algorithmic_bytes_per_launch": round(alg_, 0)}
+                    tr_, _src = pmc_traffic(frags[0], args.gemm_mode)
+                    if tr_ is not None:
+                        rec["traffic_bytes_per_launch"] = round(tr_, 0)
+                        rec["traffic_over_algorithmic"] = round(tr_ / alg_, 2)
+                    fams[fam] = rec
+                roofline["families"] = fams
             if exclusive is not None:
                 ek = exclusive.summary().get(name)
                 if ek:
