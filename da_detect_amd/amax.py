@@ -86,6 +86,12 @@ def value(t):
 def measure(t):
     """one pass over t (any shape, dense storage of t.numel() floats) into a fresh slot, attached to t"""
     global MEASURED
+    # dadet_amax scans t.numel() floats from data_ptr(): right for dense storage in any dimension order (NCHW-contiguous,
+    # channels_last), wrong for a column slice / strided view (it would scan other elements and could UNDER-estimate
+    # max|t|, i.e. overflow fp16 in mode 4)
+    if not (t.is_contiguous() or (t.dim() == 4 and t.is_contiguous(memory_format=torch.channels_last))):
+        raise _lib.DadetError("amax.measure: a non-dense view (shape %s, strides %s) cannot be measured in place; make "
+                              "it contiguous first" % (tuple(t.shape), tuple(t.stride())))
     slot = new_slot(t.device)
     _lib.call("dadet_amax", ctypes.c_void_p(t.data_ptr()), ctypes.c_longlong(t.numel()), ctypes.c_void_p(slot[0]),
               _stream())
@@ -131,13 +137,25 @@ class WeightSlots(object):
         return d
 
     @staticmethod
+    def _covers(o, e):
+        """does tensor o still own the recorded address range?  (`p.data = ...`, model.to() / .float() and re-flattening
+        replace a parameter's storage while the Python object — and its version counter — live on)"""
+        try:
+            st = o.untyped_storage()
+            base = st.data_ptr()
+            return base <= e["ptr"] and e["ptr"] + 4 * e["n"] <= base + st.nbytes()
+        except RuntimeError:
+            return False
+
+    @staticmethod
     def _alive(e):
         o = e["ref"]()
-        return o is not None and o._version == e["version"]
+        return o is not None and o._version == e["version"] and WeightSlots._covers(o, e)
 
     def _sweep(self, d, epoch):
         """forget entries whose owner is gone, or that nobody asked about during the last two epochs"""
-        dead = [k for k, e in d["entries"].items() if e["ref"]() is None or e["used"] < epoch - 2]
+        dead = [k for k, e in d["entries"].items()
+                if e["ref"]() is None or e["used"] < epoch - 2 or not self._covers(e["ref"](), e)]
         for k in dead:
             d["free"].append(d["entries"].pop(k)["i"])
         if dead:

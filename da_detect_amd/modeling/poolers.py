@@ -57,7 +57,10 @@ class LevelMapper(object):
     def __call__(self, boxlists):
         s = torch.sqrt(cat([b.area() for b in boxlists]))
         lvls = torch.floor(self.lvl0 + torch.log2(s / self.s0 + self.eps))
-        return torch.clamp(lvls, min=self.k_min, max=self.k_max).to(torch.int64) - self.k_min
+        # clamped again AFTER the cast: a NaN / inf area (degenerate box) survives the float clamp as NaN and casts to an
+        # arbitrary integer — _PyramidROIAlign would then leave that ROI's rows of its torch.empty output unwritten
+        lvls = torch.clamp(lvls, min=self.k_min, max=self.k_max).to(torch.int64) - self.k_min
+        return lvls.clamp_(0, self.k_max - self.k_min)
 
 
 class Pooler(nn.Module):

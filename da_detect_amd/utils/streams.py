@@ -105,9 +105,28 @@ class WgradLane(object):
             self.lane = side_stream(device, 2)
             self.out = []
 
+    @staticmethod
+    def _resolve_maxima(inputs):
+        """Contraction mode 4: every GEMM operand carries its largest magnitude in a slot; an operand without one is
+        MEASURED (a dadet_amax pass) by the first GEMM that asks.  That must happen here, on the compute stream, before the
+        work moves to the lane: a pass issued on the lane would attach a slot that the compute stream's next GEMM on the
+        same tensor reads with no ordering against it — e.g. the offset branch's gradient of a deformable block feeds a
+        lane weight gradient AND the main stream's data gradient (ADVICE, round 4)."""
+        from .. import _C, amax
+
+        if not _C._mode4():
+            return
+        for t in inputs:
+            # (dense tensors only: the GEMM wrappers copy anything else into a fresh NHWC tensor, which is measured where it
+            # is made)
+            if isinstance(t, torch.Tensor) and t.dtype == torch.float32 and (
+                    t.is_contiguous() or (t.dim() == 4 and t.is_contiguous(memory_format=torch.channels_last))):
+                amax.ptr(t)
+
     def run(self, fn, *inputs):
         if not self.on:
             return fn()
+        self._resolve_maxima(inputs)
         self.lane.wait_event(self.main.record_event())
         with torch.cuda.stream(self.lane):
             res = fn()
@@ -128,6 +147,7 @@ class WgradLane(object):
         if not self.on:
             direct_fn(tgt)
             return None
+        self._resolve_maxima(inputs)
         self.lane.wait_event(self.main.record_event())
         with torch.cuda.stream(self.lane):
             direct_fn(tgt)

@@ -153,3 +153,54 @@ def test_weight_slots_follow_epochs_versions_and_owners(monkeypatch):
     w1.data.fill_(1.25)
     ws.ptr(w1, 3)
     assert _held(ws, w1) == 1.25
+
+
+def test_weight_slots_drop_an_entry_whose_storage_was_replaced(monkeypatch):
+    """`p.data = ...` (model.to(), re-flattening) gives the parameter OBJECT new storage: object and version live on, the
+    recorded address is freed memory — the entry must not be measured again through it"""
+    ws, fake = _weight_slots_on_cpu(monkeypatch)
+    dev = torch.device("cpu")
+    w = fake.know(torch.nn.Parameter(torch.full((8, 4), 2.0)))
+    ws.ptr(w, 0)
+    old_key = (w.data_ptr(), w.numel())
+    assert old_key in ws.by_dev[0]["entries"]
+    keep = w.data                                           # (keeps the old allocation alive so that its address is not reused)
+    w.data = torch.full((8, 4), 5.0)
+    fake.know(w)
+    e = ws.by_dev[0]["entries"][old_key]
+    assert not ws._alive(e), "the entry still claims storage the parameter no longer owns"
+    n = len(fake.calls)
+    ws.refresh(dev, 1)                                      # swept, not measured through the stale pointer
+    assert old_key not in ws.by_dev[0]["entries"]
+    assert "dadet_amax_batch" not in fake.calls[n:]
+    ws.ptr(w, 1)
+    assert _held(ws, w) == 5.0
+    del keep
+
+
+def test_measure_refuses_a_non_dense_view():
+    """dadet_amax scans numel() floats from data_ptr(): a column slice would be measured over the wrong elements"""
+    import pytest
+
+    from da_detect_amd import _lib
+
+    t = torch.zeros(4, 8)
+    with pytest.raises(_lib.DadetError):
+        amax.measure(t[:, :3])
+
+
+def test_the_lane_resolves_operand_maxima_before_it_switches_streams(monkeypatch):
+    """WgradLane.run / run_into (utils/streams.py): in mode 4 an operand without a slot is measured BEFORE the work moves to
+    the lane stream, so the slot every later GEMM on the compute stream reads was written in that stream's order"""
+    from da_detect_amd import _C
+    from da_detect_amd.utils import streams
+
+    calls = _recording_measure(monkeypatch)
+    monkeypatch.setattr(_C, "_mode4", lambda: True)
+    x, gy = torch.zeros(2, 8, 4, 4).contiguous(memory_format=torch.channels_last), torch.zeros(2, 8, 4, 4)
+    has_slot = amax.attach(torch.zeros(3), (0x2000, _Owner()))
+    strided = torch.zeros(4, 8)[:, :3]
+    streams.WgradLane._resolve_maxima((x, gy, has_slot, strided, None, 3))
+    assert [id(c) for c in calls] == [id(x), id(gy)]        # dense operands without a slot, each once; nothing else
+    streams.WgradLane._resolve_maxima((x, gy))
+    assert len(calls) == 2                                  # both carry valid slots now

@@ -412,14 +412,24 @@ def test_three_step_trajectory_matches_oracle(device, monkeypatch):
     # noise (8 .. 13 of 62 momentum buffers over runs and modes), hence the 30% share below.
     upd = sorted(float(((rec["params"][n].double() - sd[n].double()) - (osd[n].detach().double() - sd[n].double())).norm()
                        / ((osd[n].detach().double() - sd[n].double()).norm() + 1e-30)) for n in names)
-    print("three-step updates vs the %s oracle: median %.2e  80th percentile %.2e  max %.2e  above 2e-3: %d of %d"
-          % ("float64" if dt == torch.float64 else "float32", upd[len(upd) // 2], upd[int(0.8 * len(upd))], upd[-1],
+    p95 = upd[min(len(upd) - 1, int(0.95 * len(upd)))]
+    print("three-step updates vs the %s oracle: median %.2e  95th percentile %.2e  max %.2e  above 2e-3: %d of %d"
+          % ("float64" if dt == torch.float64 else "float32", upd[len(upd) // 2], p95, upd[-1],
              sum(u >= 2e-3 for u in upd), len(upd)))
+    # the tail, not the median, is what a per-tensor scale could damage: against the exact (float64) oracle
+    # 95% of the tensors stay at rounding level and none leaves the flipped-ReLU bound; the float32 oracle's own noise puts
+    # its 95th percentile higher
+    assert upd[-1] <= 1e-2, "worst three-step update %.2e" % upd[-1]
+    assert p95 <= (2e-3 if dt == torch.float64 else 6e-3), "95th percentile of the three-step updates %.2e" % p95
+    from da_detect_amd import _C as _Cmode
+    # the share of tensors allowed above rounding level: 0.3 for the fp16 two-term contraction (mode 4, against the float32
+    # oracle's noise, see above), the 0.2 of rounds 2 - 3 for mode 3
+    share = 0.3 if _Cmode.get_gemm_mode() == 4 else 0.2
     _check_gradients({n: rec["params"][n].double() - sd[n].double() for n in names},
                      {n: osd[n].detach() - sd[n].double() for n in names}, rounding_tol=2e-3, flip_tol=1e-2,
-                     flipped_share=0.3)
+                     flipped_share=share)
     _check_gradients(rec["momentum"], {n: opt.state[osd[n]]["momentum_buffer"] for n in rec["momentum"]},
-                     rounding_tol=2e-3, flip_tol=1e-2, flipped_share=0.3)
+                     rounding_tol=2e-3, flip_tol=1e-2, flipped_share=share)
     assert abs(state["margin_img"] - c.MODEL.DA_HEADS.TRIPLET_MARGIN_IMG) < 1e-9      # never exactly 0 here: no growth
 
 
