@@ -1331,6 +1331,19 @@ def deform_psroi_pooling_backward(grad_out, data, rois, offset, count, no_trans,
     return gdata, goffset
 
 
+def check_nonfinite():
+    """Contraction mode 4's guard (include/dadet.h: dadet_nonfinite_poll): raises FloatingPointError naming the first GEMM
+    launch whose sums were non-finite since the last call — an operand's largest-magnitude slot lay below its data (a stale
+    slot, a `carry` across an operation that can raise the maximum), which overflows fp16 in the operand split.  A
+    synchronising read: the trainer calls it at its logging period, next to the reference's NaN test."""
+    buf = ctypes.create_string_buffer(512)
+    n = _lib.load().dadet_nonfinite_poll(buf, 512)
+    if n < 0:
+        raise _lib.DadetError("dadet_nonfinite_poll failed")
+    if n:
+        raise FloatingPointError(buf.value.decode())
+
+
 def set_gemm_mode(mode):
     """0 exact fp32 MFMA | 3 three-term bf16 split (fp32-class accuracy) | 2 two-term split; see include/dadet.h"""
     global _MODE

@@ -93,6 +93,7 @@ _SIGNATURES = {
     "dadet_set_gemm_mode": [c_int],
     "dadet_get_gemm_mode": [],
     "dadet_conv_wgrad_variant": [POINTER(ConvDesc)],
+    "dadet_nonfinite_poll": [c_char_p, c_int],
     "dadet_set_big_gemm": [c_int],
     "dadet_get_big_gemm": [],
     "dadet_conv_wgrad_workspace_bytes": [POINTER(ConvDesc), POINTER(c_size_t)],

@@ -107,6 +107,7 @@ __device__ __forceinline__ void big_finish(const ConvArgs& a, f32x16 (&acc)[TM][
         for (int e = 0; e < 16; ++e) acc[im][in][e] = acc[im][in][e] * u1 * u2;
   }
 
+  nf_check<TM, TN>(acc, a.nf_flag, a.launch_id);
   BIG_STAMP(2);
   int* s_word = reinterpret_cast<int*>(smem);        // the operand planes are dead (every wave passed the last barrier)
   if (S > 1) {
@@ -929,6 +930,7 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_big_kernel(const WgradArgs 
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[im][in][e] = acc[im][in][e] * u1 * u2;
   }
+  nf_check<TM, TN>(acc, a.nf_flag, a.launch_id);
   float* out = a.direct ? a.out : a.out + (size_t)part * a.Cout * a.K;
   const bool final_out = a.direct;
   float* tile_f = reinterpret_cast<float*>(smem) + wave * (32 * EPI_STRIDE);

@@ -161,6 +161,32 @@ __device__ inline void amax_publish(unsigned* slot, float m) {
   }
 }
 
+// Non-finite guard of contraction mode 4.  A per-tensor scale taken from a stale or too small maximum overflows fp16 in
+// the operand split: the leading term becomes inf, its products with the zeros of a ReLU'd operand NaN.  Every GEMM looks at
+// its accumulators once, right behind the K loop (one class test per register, ~0.1% of a tile's time), and a workgroup
+// that finds a non-finite value records the launch: the first one's id by compare-and-swap, a count by an atomic add —
+// nothing is written on clean data.  The host reads the two words at its logging period (dadet_nonfinite_poll) and names
+// the launch from a ring of recent launch records instead of reporting "loss is NaN" hundreds of kernels later.
+template <int TM, int TN>
+__device__ __forceinline__ void nf_check(const f32x16 (&acc)[TM][TN], unsigned* flag, const unsigned id) {
+  if (!flag) return;
+  bool bad = false;
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e)
+        bad |= (__builtin_bit_cast(unsigned, acc[i][j][e]) & 0x7f800000u) == 0x7f800000u;
+  if (__builtin_amdgcn_ballot_w64(bad) != 0 && (threadIdx.x & 63) == 0) {      // one lane per wavefront that saw any
+    atomicCAS(flag, 0u, id + 1u);
+    atomicAdd(flag + 1, 1u);
+  }
+}
+// host side (conv_igemm.hip): id of the launch being prepared (recorded in the ring) and the device words
+unsigned nf_next_launch(const char* kind, int M, int N, int K, int KH);
+unsigned* nf_flag_ptr();
+
 constexpr int PLANE_STRIDE = 40;  // bf16 per staged row: 32 + 8 pad = 80 bytes
 constexpr int EPI_STRIDE = 40;    // floats per transposed row of the 16-byte epilogue
 
@@ -194,6 +220,9 @@ struct ConvArgs {
   // large-tile kernel (conv_big.hip): number of K ranges a tile's reduction is cut into (0: another kernel runs); the
   // parts meet in sk_ws ([tile][part][256 x 256] floats) under sk_counters[tile] (arrivals) / [2048 + tile] (parked)
   int big_splits;
+  // non-finite guard (mode 4): device words {first offending launch id + 1, count} and this launch's id; null = off
+  unsigned* nf_flag;
+  unsigned launch_id;
   // mode 4 (fp16 two-term split): max|x|, max|w| of the operands (device floats; null = scale 1) and the slot that
   // receives max|y| of what this launch stores (null = not wanted; zero or an earlier launch's maximum before)
   const float* amax_x;
@@ -215,6 +244,8 @@ struct WgradArgs {
   unsigned x_bytes, gy_bytes;
   const float* amax_x;   // mode 4: max|x|, max|gy| (device floats; null = scale 1)
   const float* amax_gy;
+  unsigned* nf_flag;     // non-finite guard, see ConvArgs
+  unsigned launch_id;
 };
 
 // tile variant chosen for a forward / dgrad GEMM of M rows and Cout columns

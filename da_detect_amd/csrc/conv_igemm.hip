@@ -29,6 +29,7 @@
 #include <mutex>
 #include <unordered_map>
 #include "conv_common.h"
+#include <atomic>
 #include <stdlib.h>
 
 namespace dadet {
@@ -658,6 +659,33 @@ __global__ __launch_bounds__(256) void amax_batch_kernel(const dadet_amax_item* 
   amax_publish(reinterpret_cast<unsigned*>(it.slot), mx);
 }
 
+// ---- non-finite guard: device words + a ring of recent launch records (conv_common.h: nf_check) -------------------------
+__device__ unsigned g_nf_words[2];
+namespace {
+struct NfRecord { unsigned id; char kind[24]; int M, N, K, KH; };
+constexpr int kNfRing = 8192;
+NfRecord g_nf_ring[kNfRing];
+std::atomic<unsigned> g_nf_next{0};
+}  // namespace
+namespace dadet {
+unsigned nf_next_launch(const char* kind, int M, int N, int K, int KH) {
+  const unsigned id = g_nf_next.fetch_add(1);
+  NfRecord& r = g_nf_ring[id % kNfRing];
+  r.id = id;
+  snprintf(r.kind, sizeof(r.kind), "%s", kind);
+  r.M = M; r.N = N; r.K = K; r.KH = KH;
+  return id;
+}
+unsigned* nf_flag_ptr() {
+  static unsigned* p = [] {
+    void* q = nullptr;
+    return hipGetSymbolAddress(&q, HIP_SYMBOL(g_nf_words)) == hipSuccess ? static_cast<unsigned*>(q) : nullptr;
+  }();
+  static const bool off = getenv("DADET_NONFINITE_GUARD") && getenv("DADET_NONFINITE_GUARD")[0] == '0';
+  return off ? nullptr : p;
+}
+}  // namespace dadet
+
 namespace {
 struct Scratch { void* p = nullptr; size_t bytes = 0; };
 std::mutex g_scratch_mutex;
@@ -839,6 +867,9 @@ static int conv_forward_impl(const dadet_conv_desc* d, const float* x, const flo
   a.sk_counters = nullptr;
   a.amax_x = a.amax_w = nullptr;
   a.amax_y = nullptr;
+  a.nf_flag = nullptr;
+  a.launch_id = 0;
+  a.big_splits = 0;
   if (gemm_mode() == 4) {
     // operand maxima: the caller's slots, or (plain entry point) two per-stream slots filled here
     if (!amax_x || !amax_w) {
@@ -858,6 +889,8 @@ static int conv_forward_impl(const dadet_conv_desc* d, const float* x, const flo
     }
     a.amax_x = amax_x; a.amax_w = amax_w;
     a.amax_y = reinterpret_cast<unsigned*>(amax_y);
+    a.nf_flag = nf_flag_ptr();
+    a.launch_id = a.nf_flag ? nf_next_launch("conv_forward", a.M, a.Cout, a.K, a.KH) : 0;
   }   // (the other modes neither read nor leave maxima)
   if (gemm_mode() >= 3 && ws_eligible(a)) return launch_fwd_ws(a, gemm_mode(), st);   // weight-stationary 1x1, K <= 256
   a.big_splits = 0;
@@ -962,6 +995,26 @@ extern "C" int dadet_conv_forward_variant(const dadet_conv_desc* d) {
   return gemm_mode() != 0 ? split_fwd_variant(M, d->Cout, d->KH * d->KW * d->Cin) : fwd_variant(M, d->Cout);
 }
 
+extern "C" int dadet_nonfinite_poll(char* msg, int cap) {
+  unsigned w[2] = {0, 0};
+  unsigned* dev = nf_flag_ptr();
+  if (!dev) { if (msg && cap > 0) msg[0] = 0; return 0; }
+  if (hipMemcpy(w, dev, sizeof(w), hipMemcpyDeviceToHost) != hipSuccess) return check_launch("nonfinite_poll") ? -1 : -1;
+  if (w[1] == 0) { if (msg && cap > 0) msg[0] = 0; return 0; }
+  (void)hipMemset(dev, 0, sizeof(w));
+  if (msg && cap > 0) {
+    const unsigned id = w[0] - 1u;
+    const NfRecord& r = g_nf_ring[id % kNfRing];
+    if (w[0] != 0 && r.id == id)
+      snprintf(msg, cap, "%s launch #%u (M=%d N=%d K=%d, %dx%d taps): non-finite sums in %u wavefront(s) — an operand's "
+               "largest-magnitude slot below its data overflows the fp16 split (contraction mode 4)", r.kind, id, r.M, r.N,
+               r.K, r.KH, r.KH, w[1]);
+    else
+      snprintf(msg, cap, "GEMM launch #%u: non-finite sums in %u wavefront(s) (launch record no longer in the ring)", id, w[1]);
+  }
+  return (int)w[1];
+}
+
 extern "C" int dadet_conv_wgrad_variant(const dadet_conv_desc* d) {
   if (!d) return -1;
   int tco, tkc, splits, rps;
@@ -1058,6 +1111,8 @@ static int conv_wgrad_impl(const dadet_conv_desc* d, const float* x, const float
   if (!big) wgrad_plan(d, &a.tiles_co, &a.tiles_kc, &a.splits, &a.rows_per_split);
   a.accumulate = accumulate;
   a.amax_x = a.amax_gy = nullptr;
+  a.nf_flag = nullptr;
+  a.launch_id = 0;
   if (gemm_mode() == 4) {
     if (!amax_x || !amax_gy) {
       unsigned* own = stream_amax_slots(st);
@@ -1075,6 +1130,8 @@ static int conv_wgrad_impl(const dadet_conv_desc* d, const float* x, const float
       }
     }
     a.amax_x = amax_x; a.amax_gy = amax_gy;
+    a.nf_flag = nf_flag_ptr();
+    a.launch_id = a.nf_flag ? nf_next_launch("conv_wgrad", a.M, a.Cout, a.K, a.KH) : 0;
   }
   if (a.splits == 1) {
     a.direct = 1;

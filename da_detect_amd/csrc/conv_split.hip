@@ -454,6 +454,7 @@ __device__ __forceinline__ void conv_fwd_split_body(const ConvArgs& a, char* sme
       for (int in = 0; in < TN; ++in)
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[im][in][e] = acc[im][in][e] * u1 * u2;
+    nf_check<TM, TN>(acc, a.nf_flag, a.launch_id);
   }
 
   if (sk) {
@@ -868,6 +869,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_split_kernel(const WgradArg
       for (int in = 0; in < 2; ++in)
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[im][in][e] = acc[im][in][e] * u1 * u2;
+    nf_check<2, 2>(acc, a.nf_flag, a.launch_id);
   }
   const bool final_out = a.direct;              // this workgroup writes dw itself (scale / accumulate applied here)
   float* out = a.direct ? a.out : a.out + (size_t)split * a.Cout * a.K;

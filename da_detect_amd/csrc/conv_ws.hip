@@ -298,6 +298,17 @@ __global__ __launch_bounds__(512, 1) void conv1x1_ws_kernel(const ConvArgs a) {
     }
   };
   auto epilogue = [&](int tile_idx) __attribute__((always_inline)) {
+    if (F16 && a.nf_flag) {      // non-finite guard (conv_common.h: nf_check), on the scaled sums: the same class
+      bool bad = false;
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) bad |= (__builtin_bit_cast(unsigned, acc[nb][e]) & 0x7f800000u) == 0x7f800000u;
+      if (__builtin_amdgcn_ballot_w64(bad) != 0 && (threadIdx.x & 63) == 0) {
+        atomicCAS(a.nf_flag, 0u, a.launch_id + 1u);
+        atomicAdd(a.nf_flag + 1, 1u);
+      }
+    }
 #pragma unroll
     for (int nb0 = 0; nb0 < NB; nb0 += EPB) {
       if (EARLY && nb0 == 0) {

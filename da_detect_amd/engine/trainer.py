@@ -180,7 +180,13 @@ def _update_meters(meters, loss_dict):
 
 def _loss_is_nan(net, total):
     """NaN in this step's summed loss, or — between two tests — in the parameters an earlier NaN step has since
-    poisoned (SGD carries a NaN gradient into the weights for good; one small tensor is enough to see it)"""
+    poisoned (SGD carries a NaN gradient into the weights for good; one small tensor is enough to see it).  Before that:
+    the GEMMs' own non-finite guard (_C.check_nonfinite), which names the first launch that overflowed instead of a loss
+    hundreds of kernels later (contraction mode 4: a per-tensor scale from too small a maximum)."""
+    if total.is_cuda:
+        from .. import _C
+
+        _C.check_nonfinite()
     bad = torch.isnan(total).any()
     probe = next((p for p in net.parameters() if p.requires_grad), None)
     if probe is not None:

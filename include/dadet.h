@@ -177,6 +177,15 @@ int dadet_get_gemm_mode(void);
 int dadet_set_big_gemm(int mode);
 int dadet_get_big_gemm(void);
 
+/* Non-finite guard of mode 4.  A per-tensor scale from a stale or too small maximum overflows fp16 inside the operand split
+ * (inf, then NaN against the zeros of a ReLU'd operand).  Every GEMM checks its sums once behind the K loop and records
+ * the first offending launch in two device words.  dadet_nonfinite_poll copies them to the host (a synchronising read: call
+ * it at the logging period), clears them and returns the number of wavefronts that saw non-finite sums since the last
+ * poll (0 = clean, < 0 = error); `msg` (may be NULL) receives a sentence naming the first launch — entry point, launch
+ * number, M / N / K — from a ring of the last 8192 launch records.  DADET_NONFINITE_GUARD=0 (environment) switches the
+ * device-side check off. */
+int dadet_nonfinite_poll(char* msg, int cap);
+
 /* Largest magnitudes for mode 4.  A "slot" holds max|t| over a tensor t (an upper bound within a few binades serves as
  * well: it only has to keep t / slot inside fp16's range without wasting it).  It is addressed by one pointer p and
  * consists of EIGHT floats, p[0], p[S], ..., p[7 S] with S = DADET_AMAX_STRIDE: the value is the maximum of the eight

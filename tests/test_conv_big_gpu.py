@@ -194,3 +194,36 @@ def test_big_tile_weight_gradient_through_the_batched_reduction(device, big_mode
     for x, gy, dw, shape, pad in items:
         ref = torch.nn.grad.conv2d_weight(x.double(), shape, gy.double(), padding=pad)
         assert float((dw.double() - ref).abs().max()) <= 2e-5 * float(ref.abs().max())
+
+
+@pytest.mark.parametrize("big", [0, 2])
+def test_a_low_operand_maximum_is_reported_by_name_not_as_a_nan_loss(device, big_mode, big):
+    """mode 4's guard (dadet_nonfinite_poll): a slot that claims a maximum far below the data makes the scaled operand
+    overflow fp16; the GEMM records its launch and `_C.check_nonfinite()` names it — for the 128 x 128 kernel, the large-tile
+    kernels, and the weight gradient"""
+    from da_detect_amd import _C, amax as _amax
+
+    g = torch.Generator().manual_seed(9)
+    x = (torch.randn((1, 256, 24, 24), generator=g) * 3).to(device).contiguous(memory_format=CL)
+    w = (torch.randn((256, 256, 3, 3), generator=g) * 0.03).to(device).contiguous(memory_format=CL)
+    big_mode.dadet_set_big_gemm(big)
+    _C.check_nonfinite()                                   # clean so far (also clears earlier tests' state)
+    y = _C.conv_forward(x, w, pad=1)
+    _C.check_nonfinite()                                   # honest maxima: nothing to report
+    assert bool(torch.isfinite(y).all())
+    low = _amax.new_slot(x.device)
+    # the slot says max|x| = 2^-12: the kernel scales x by 2^26 and the leading fp16 terms overflow
+    slot_view = low[1].view(8, -1)
+    slot_view[0, (low[0] - low[1].data_ptr()) // 4] = 2.0 ** -12
+    _amax.attach(x, low)
+    y = _C.conv_forward(x, w, pad=1)
+    assert not bool(torch.isfinite(y).all())
+    with pytest.raises(FloatingPointError) as err:
+        _C.check_nonfinite()
+    assert "conv_forward" in str(err.value) and "M=576" in str(err.value) and "K=2304" in str(err.value), str(err.value)
+    _C.check_nonfinite()                                   # reported once, then clean again
+    gy = torch.randn((1, 256, 24, 24), generator=g).to(device).contiguous(memory_format=CL)
+    _C.conv_wgrad(x, gy, (256, 256, 3, 3), pad=1)          # the weight gradient reads the same lying slot
+    with pytest.raises(FloatingPointError) as err:
+        _C.check_nonfinite()
+    assert "conv_wgrad" in str(err.value), str(err.value)
