@@ -1,0 +1,55 @@
+"""Contraction mode 4 on the REAL operands of a training step, per output channel.
+
+The accuracy tests of tests/test_ops_gpu.py feed Gaussian operands; the gradient tensors of a real step are heavy-tailed
+and carry channels far below the tensor's largest magnitude — where a per-TENSOR power-of-two scale is narrower than fp32.
+Here every forward / data-gradient / weight-gradient GEMM of one `da` step (512 x 1024 images, after three optimizer steps)
+is replayed as a bare contraction in mode 0 (exact fp32 MFMA) and mode 4 against float64, channel by channel
+(tools/probes/real_operand_error.py; profiles/r05_real_operand_channel_error.txt holds the 1024 x 2048 run):
+
+  * for EVERY output channel c, at depth d_c = log2(operand max / max of the operand entries feeding c):
+        err_4[c] <= 6 x max(err_0[c], median err_0) + 2^(d_c - 34)
+    i.e. fp32-class relative accuracy (the factor covers the two kernels' different summation trees — fp32 accumulation error
+    depends on how the reduction is cut, tools/probes/big_parts_error.py: 7.2e-7 in one part, 3.8e-7 in four; over four runs
+    the worst shallow channel sat at 3.9 - 4.2 x) down to ~2^-14 of the operand's maximum, and one bit less per binade below — the
+    absolute-error promise of the format (conv_common.h: the residual term of an entry 2^-d below the maximum sits in
+    fp16's subnormals, quantum 2^-25 of the scaled maximum, i.e. 2^(d-39) of the entry; the typical entry of a channel lies
+    several binades below the channel's own maximum, which d_c measures, hence the envelope 2^(d_c - 34)), measured on the
+    step's own tensors: 6.8e-7 at 12.9 binades, 3.9e-6 at 21.6, 1.5e-5 at 23.4, 6.2e-5 at 26.6 (fp32: 2e-8 .. 1e-7 there);
+  * in units of the output's largest channel norm, mode 4's worst channel error is not above twice mode 0's.
+Reference arithmetic: ATen conv2d / conv backward-weight in fp32 behind mb/layers/misc.py:30-43."""
+import os
+import sys
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_mode4_per_channel_error_on_the_operands_of_a_real_step(device):
+    sys.path.insert(0, os.path.join(ROOT, "tools", "probes"))
+    if ROOT not in sys.path:
+        sys.path.insert(0, ROOT)
+    import real_operand_error as probe
+    from da_detect_amd import _C
+
+    mode = _C.get_gemm_mode()
+    try:
+        fwd, wg = probe.capture("da", (512, 1024), steps=3)
+        assert len(fwd) > 60 and len(wg) > 30
+        rows, hist = probe.analyse(fwd, wg)
+    finally:
+        _C.set_gemm_mode(mode)
+    deep_seen = 0
+    for r in rows:
+        r0, r4, depth = r["r0"], r["r4"], r["depth"]
+        depth = torch.where(torch.isfinite(depth), depth, torch.full_like(depth, 60.0))
+        bound = 6.0 * torch.maximum(r0, r0.median()).clamp(min=2.0 ** -24) + torch.pow(2.0, depth - 34.0)
+        worst = int(torch.argmax(r4 / bound))
+        assert float(r4[worst]) <= float(bound[worst]), "%s %s: channel at depth %.1f: err_4 %.2e, err_0 %.2e, bound %.2e" % (
+            r["kind"], r["shape"], float(depth[worst]), float(r4[worst]), float(r0[worst]), float(bound[worst]))
+        assert float(r["a4"].max()) <= 2.0 * float(r["a0"].max()) + 2.0 ** -24, (r["kind"], r["shape"])
+        deep_seen += int((depth > 16).sum())
+    # the step does contain what the Gaussian tests lack: channels more than 16 binades below their tensor's maximum
+    assert deep_seen > 0, "no deep channel in this step: the test would not exercise the format's range"
