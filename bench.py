@@ -287,8 +287,8 @@ def run_workload(args, name, device, rank, world, steps, warmup, headline):
     reducer.record_comm(False)
     one_stream = None
     if headline and world == 1 and streams.lane_in_use() and not args.no_kernel_timing:
-        # the schedule every N > 1 run uses (the tuner is single-process): the same loop with the second GEMM stream off,
-        # so that a scaling curve can be read against a like-for-like N = 1 point
+        # the same loop with the second GEMM stream off, so that a scaling curve whose N > 1 points kept one stream can be
+        # read against a like-for-like N = 1 point
         saved = (streams.WGRAD_OVERLAP, streams.WGRAD_LANE_ROWS)
         streams.join_wgrad_lane(device)
         streams.WGRAD_OVERLAP, streams.WGRAD_LANE_ROWS = False, 0
@@ -674,11 +674,13 @@ def main():
         if r["ranks_in_sync"] is not None:
             line["config"]["ranks_in_sync_after_run"] = r["ranks_in_sync"]
         if r["one_stream"] is not None:
-            # N > 1 runs keep one GEMM stream (engine.trainer.WgradLaneTuner is single-process): the like-for-like N = 1 point
+            # the like-for-like N = 1 point for a run whose ranks (or whose rig: gloo) kept one GEMM stream — since round 5
+            # the tuner's decision is agreed over the ranks (max of the candidates' times), over RCCL
             line["one_stream"] = {"ms_per_step": round(r["one_stream"] * 1e3, 3),
                                   "value": round(world * images_per_gpu / r["one_stream"], 3), "unit": "images/s",
-                                  "note": "the same timed loop with the second GEMM stream off — the schedule every "
-                                          "N > 1 run uses; compute scaling efficiency against this value"}
+                                  "note": "the same timed loop with the second GEMM stream off — the schedule an N > 1 "
+                                          "run uses when its ranks' agreed tuner (or DADET_TUNE_SCHEDULE_RANKS=0) keeps "
+                                          "one stream: config.schedule of that run says which; compare like with like"}
         elif world == 1:
             line["one_stream"] = {"ms_per_step": round(ms_per_step, 3), "value": round(value, 3), "unit": "images/s",
                                   "note": "the headline run already used one GEMM stream"}

@@ -76,13 +76,19 @@ class WgradLaneTuner(object):
     def __init__(self, device, settle=2, measure=4):
         self.device = device
         self.settle, self.measure = settle, measure
-        # single process only: with several ranks the bucket collectives are issued from the lane stream while it is in
-        # use (parallel/reducer.py), a combination only ever exercised over gloo on one GPU — where 6 steps with the lane
-        # left the process 10x slower for good — and never over RCCL.  Multi-rank runs keep the one-stream schedule
-        # they were tested with unless DADET_WGRAD_LANE_ROWS is set by hand.
+        # Several ranks (round 5): every rank runs the same candidates for the same number of steps — the steps are
+        # ordinary training steps with their gradient collectives, so the ranks stay in lockstep — and the decision is taken
+        # on the MAXIMUM over ranks of each candidate's time (agreed_times: one all-reduce), i.e. on the time of the slowest
+        # rank, which is the step time of the job: every rank keeps the same schedule, the one N = 1 would be measured
+        # with.  Over RCCL only: over gloo (the one-GPU functional rig) collectives issued from the lane stream left the
+        # process 10x slower for good (profiles/r03_gloo_two_ranks_one_gpu_lane_phases.json), which RCCL does not show
+        # (profiles/r03_rccl_one_rank_first_contact.json).  DADET_TUNE_SCHEDULE_RANKS=0 keeps N > 1 on one stream.
+        world = get_world_size()
+        multi_ok = world == 1 or (torch.distributed.get_backend() == "nccl"
+                                  and os.environ.get("DADET_TUNE_SCHEDULE_RANKS", "1") == "1")
         self.active = (device.type == "cuda" and "DADET_WGRAD_LANE_ROWS" not in os.environ
                        and not streams.WGRAD_OVERLAP and os.environ.get("DADET_TUNE_SCHEDULE", "1") == "1"
-                       and get_world_size() == 1)
+                       and multi_ok)
         self.times = {}
         self._cand = self._count = 0
         self._t0 = None
@@ -110,12 +116,18 @@ class WgradLaneTuner(object):
             streams.join_wgrad_lane(self.device)
             # the default (first candidate: one GEMM stream) stays unless another one is CLEARLY faster: four timed steps
             # carry ~1% of noise, and a second stream makes per-kernel timings harder to read (bench.py's roofline line)
-            base = self.CANDIDATES[0]
-            best = min(self.times, key=self.times.get)
-            if self.times[best] > (1.0 - self.MIN_GAIN) * self.times[base]:
-                best = base
-            streams.WGRAD_LANE_ROWS = best
+            self.times = agreed_times(self.times, self.device)
+            streams.WGRAD_LANE_ROWS = self.choose(self.times)
             self.active = False
+
+    @classmethod
+    def choose(cls, times):
+        """the candidate to keep: the default (first candidate: one GEMM stream) unless another is CLEARLY faster"""
+        base = cls.CANDIDATES[0]
+        best = min(times, key=times.get)
+        if times[best] > (1.0 - cls.MIN_GAIN) * times[base]:
+            best = base
+        return best
 
     def close(self):
         """a run that ended before the measurement did: back to the default"""
@@ -127,6 +139,18 @@ class WgradLaneTuner(object):
     def report(self):
         return {"wgrad_lane_rows": streams.WGRAD_LANE_ROWS,
                 "tuned_ms_per_step": {str(k): round(v * 1e3, 3) for k, v in self.times.items()}}
+
+
+def agreed_times(times, device):
+    """candidate -> seconds per step as EVERY rank will see it: the maximum over the ranks (the slowest rank sets the step
+    time of a data-parallel job), so that all ranks take the same schedule decision.  One rank: unchanged."""
+    if get_world_size() == 1:
+        return dict(times)
+    keys = sorted(times)
+    on = device if torch.distributed.get_backend() == "nccl" else torch.device("cpu")
+    t = torch.tensor([times[k] for k in keys], dtype=torch.float64, device=on)
+    torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+    return {k: float(v) for k, v in zip(keys, t.tolist())}
 
 
 def _unwrap(model):

@@ -255,3 +255,31 @@ def test_one_rank_over_rccl_at_production_geometry_with_the_lane(device):
         assert comm["exposed_ms"] >= 0.0 and comm["overlap_frac"] is not None, comm
         print("one rank over RCCL, lane rows %d: %s" % (lane_rows, {k: v for k, v in comm.items() if k != "note"}))
     np.testing.assert_allclose(res[17000][1], res[0][1], rtol=1e-2, atol=3e-4)
+
+
+def test_bench_py_with_two_ranks_prints_one_line_with_its_comm_block(device):
+    """`python bench.py --gpus 2` as the driver's scaling runs start it — on this rig both ranks
+    share device 0 over gloo (DADET_BENCH_SHARE_GPU=1): self-spawn, rendezvous, the timed loop with max-over-ranks timing,
+    the comm evidence and the in-sync check; a trivial failure here would cost the first 8-GPU run.  Reference of the launch:
+    tools/train_net_triplet.py:83-88, 304-309 (torch.distributed.launch, one process per GPU)."""
+    import json
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env["DADET_BENCH_SHARE_GPU"] = "1"
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+                        "--others", "none", "--no-cpu-baseline", "--image-hw", "512x1024"],
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env, timeout=900)
+    assert p.returncode == 0, p.stderr.decode()[-2000:]
+    lines = [l for l in p.stdout.decode().splitlines() if l.startswith("{")]
+    assert len(lines) == 1, "exactly one JSON line (rank 0's): %d" % len(lines)
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 2 and d["config"]["parallelism"] == "dp2" and d["config"]["global_batch"] == 4
+    assert d["value"] > 0 and d["scaling"] == "weak"
+    assert d["config"]["ranks_in_sync_after_run"] is True
+    comm = d["comm"]
+    assert comm["world"] == 2 and comm["buckets"] >= 2
+    # every bucket's all-reduce goes out while backward still runs (nothing is left for finalize())
+    assert comm["buckets_issued_during_backward"] == comm["buckets"], comm

@@ -145,3 +145,33 @@ def test_update_set_is_agreed_per_step_when_graphs_change():
     assert got[0] == got[1], "ranks disagree on which parameters to update"
     for ids, gb in got[0]:
         assert ids == [0, 1] and gb == [1.5] * 4
+
+
+def _tuner_worker(rank, world, port, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from da_detect_amd.engine.trainer import WgradLaneTuner, agreed_times
+
+    # rank 0 alone would keep the lane (12% faster), rank 1 alone would not (lane 8% slower): the job's step time is the
+    # slower rank's, so both must see {0: 10.5 ms, 17000: 10.8 ms} and both keep one stream
+    mine = {0: 10.0e-3, 17000: 8.8e-3} if rank == 0 else {0: 10.5e-3, 17000: 10.8e-3}
+    assert WgradLaneTuner.choose(mine) == (17000 if rank == 0 else 0)
+    agreed = agreed_times(mine, torch.device("cpu"))
+    assert agreed == {0: 10.5e-3, 17000: 10.8e-3}, agreed
+    out[rank] = WgradLaneTuner.choose(agreed)
+    # and when the lane wins on the slowest rank too, every rank keeps it
+    mine = {0: 10.0e-3 + 1e-4 * rank, 17000: 9.0e-3 + 2e-4 * rank}
+    out[10 + rank] = WgradLaneTuner.choose(agreed_times(mine, torch.device("cpu")))
+    dist.destroy_process_group()
+
+
+def test_the_schedule_tuner_decides_on_the_slowest_rank_and_all_ranks_agree():
+    """engine.trainer.WgradLaneTuner with N > 1: one all-reduce (MAX) of the candidates' times,
+    one decision — a rank that would choose differently on its own timings follows the job's"""
+    world = 2
+    port = _free_port()
+    out = mp.Manager().dict()
+    mp.spawn(_tuner_worker, args=(world, port, out), nprocs=world, join=True)
+    assert out[0] == out[1] == 0
+    assert out[10] == out[11] == 17000
