@@ -104,3 +104,40 @@ def test_full_size_img_only_step_matches_the_cpu_oracle(device, monkeypatch):
     worst, above = _check_gradients(rec["grads"], {n: osd[n].grad for n in rec["grads"]}, rounding_tol=2e-3, flip_tol=2e-2,
                                     flipped_share=0.15)
     print("full-size img_only step vs the fp32 CPU oracle: worst relative L2 gradient error %.2e; above 2e-3: %s" % (worst, above))
+    # north_star: "fp32 losses ... within 1e-4".  The 2e-4 above is the fp32 CPU oracle's own noise at this size; the loss
+    # leg again in FLOAT64 (forward only) takes that noise out, and the stated tolerance holds
+    del osd, olosses, inter
+    with torch.no_grad():
+        _, olosses64, _ = _oracle(c, sd, rec, nimg, H, W, seed, dtype=torch.float64)
+    _check_losses(rec, olosses64, tol=1e-4)
+    print("full-size img_only losses vs the float64 oracle: " + ", ".join(
+        "%s %.2e" % (k, abs(rec["losses"][k] - float(v)) / max(abs(float(v)), 1.0)) for k, v in olosses64.items()))
+
+
+@pytest.mark.slow
+@pytest.mark.parametrize("case", ["da_plain", "da_triplet"])
+def test_full_size_step_of_the_other_recipes_matches_the_cpu_oracle(device, monkeypatch, case):
+    """BASELINE configs[2] (image + instance + consistency heads: 2 x 1024 x 2048) and configs[3] (source + foggy + rainy
+    auxiliary under the triplet loss and AdvGRL: 3 x 1024 x 2048) against oracle/model_ref.py, as the img_only step above:
+    sampled anchor / ROI indices identical, losses against the FLOAT64 oracle within 1e-4, every parameter gradient against
+    the fp32 oracle within its noise.  The default run checks these recipes at full size only as schedule A vs schedule B
+    of the same kernels; this one is independent of them.  Slow (a minute or two of host oracle each): DADET_RUN_SLOW=1.
+    (configs[4], R-101-FPN-DCN: oracle/model_ref.py has no pyramid / deformable model — its deformable blocks are pinned
+    block by block against the two float64 restatements of tests/test_deform_gpu.py, its full-size step by the schedule
+    comparison above)"""
+    from test_default_path_gpu import _check_gradients, _check_indices, _check_losses, _oracle, _run_default_path
+
+    seed, H, W = 7, 1024, 2048
+    c, sd, rec, nimg = _run_default_path(case, H, W, device, seed, monkeypatch)
+    torch.set_num_threads(min(os.cpu_count() or 1, 64))
+    osd, olosses, inter = _oracle(c, sd, rec, nimg, H, W, seed)
+    _check_indices(rec, inter)
+    _check_losses(rec, olosses, tol=2e-4)
+    sum(olosses.values()).backward()
+    worst, above = _check_gradients(rec["grads"], {n: osd[n].grad for n in rec["grads"]}, rounding_tol=2e-3, flip_tol=2e-2,
+                                    flipped_share=0.15)
+    print("full-size %s step vs the fp32 CPU oracle: worst relative L2 gradient error %.2e; above 2e-3: %s" % (case, worst, above))
+    del osd, olosses, inter
+    with torch.no_grad():
+        _, olosses64, _ = _oracle(c, sd, rec, nimg, H, W, seed, dtype=torch.float64)
+    _check_losses(rec, olosses64, tol=1e-4)
