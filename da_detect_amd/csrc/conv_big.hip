@@ -1062,6 +1062,12 @@ bool wgrad_big_plan(const dadet_conv_desc* d, int* tiles_co, int* tiles_kc, int*
   *tiles_co = ceil_div(d->Cout, 256);
   *tiles_kc = ceil_div(K, 256);
   const int tiles = (*tiles_co) * (*tiles_kc);
+  // Every workgroup leaves a 256 KB tile of partial sums: 64 MB per launch once the chip is full, whatever the layer.  A
+  // weight of four tiles (res4's 1x1 layers: 1 MB) would be cut into 64 parts — 64 MB written and read again for 41 us of
+  // GEMM, where the 128 x 128 kernel's 16 tiles need a quarter of that traffic for 47 us: below eight tiles it keeps the
+  // layer (profiles/r05_step_timeline_img_only.txt: the step-end reduction passes read what these launches park)
+  static const int min_tiles = getenv("DADET_WGRAD_BIG_MIN_TILES") ? atoi(getenv("DADET_WGRAD_BIG_MIN_TILES")) : 8;
+  if (g_big_mode != 2 && tiles < min_tiles) return false;
   int s = kNumCU / tiles;
   if (const char* e = getenv("DADET_WGRAD_BIG_SPLITS")) { const int v = atoi(e); if (v > 0) s = v; }
   if (s < 1) s = 1;

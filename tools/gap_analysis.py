@@ -110,7 +110,8 @@ if steps:
     ends = [e for _, e, n in rows if "sgd_kernel" in n]
     lo, hi = (ends[-2], ends[-1]) if len(ends) >= 2 else (rows[0][0], rows[-1][1])
     last = [r for r in rows if r[0] >= lo and r[1] <= hi]
-    is_gemm = lambda n: "conv_fwd" in n or "conv1x1_ws" in n or "conv_wgrad_split" in n or "conv_wgrad_kernel" in n  # noqa: E731
+    is_gemm = lambda n: ("conv_fwd" in n or "conv_big" in n or "conv1x1_ws" in n or "conv_wgrad_split" in n  # noqa: E731
+                         or "conv_wgrad_big" in n or "conv_wgrad_kernel" in n)
     gemm = sorted((s, e) for s, e, n in last if is_gemm(n))
     merged = []
     for s, e in gemm:

@@ -5,7 +5,7 @@ kernel_trace.csv (tools/profile_gaps.sh), each with the kernels that executed in
 usage: step_timeline.py <kernel_trace.csv> [min_stretch_us=15] [step_from_end=1] [list=A:B]
        list=A:B  also print EVERY kernel (GEMMs included) that starts between A and B ms into the step, in start order
 
-A "GEMM" is one of this repo's MFMA kernels (conv_fwd_* / conv1x1_ws_* / conv_wgrad_*); everything else — library launches, the
+A "GEMM" is one of this repo's MFMA kernels (conv_fwd_* / conv_big* / conv1x1_ws_* / conv_wgrad_*); everything else — library launches, the
 latency-bound kernels of proposal selection and sampling, ROIAlign, reductions, the optimizer — only costs wall time
 where it is not hidden under a GEMM, i.e. inside these stretches.  The step window runs from the end of one sgd_kernel to
 the end of the next."""
@@ -29,7 +29,7 @@ rows.sort()
 ends = [e for _, e, n, _ in rows if "sgd_kernel" in n]
 lo, hi = ends[-back - 1], ends[-back]
 step = [r for r in rows if r[1] > lo and r[0] < hi]
-is_gemm = lambda n: ("conv_fwd_" in n or "conv_wgrad_" in n or "conv1x1_ws" in n) and "reduce" not in n  # noqa: E731
+is_gemm = lambda n: ("conv_fwd_" in n or "conv_wgrad_" in n or "conv1x1_ws" in n or "conv_big" in n) and "reduce" not in n  # noqa: E731
 
 
 def short(n):
