@@ -222,7 +222,10 @@ class WeightSlots(object):
                 n = e["n"]
                 it.x, it.slot, it.n = e["ptr"], d["slots"].data_ptr() + 4 * e["i"], n
                 it.first_block = blocks
-                it.blocks = max(1, min(512, (n // 4 + 511) // 512))     # two float4 per thread and pass
+                # sixteen float4 per thread (four rounds of four loads in flight): ~200 MB of weights and cached transposes
+                # in ~3000 workgroups — at two float4 per thread the launch was bound by its 25 000 workgroups' dispatch
+                # (149 us per step, 1.4 TB/s; profiles/r05_step_timeline_img_only.txt)
+                it.blocks = max(1, min(512, (n // 4 + 4095) // 4096))
                 blocks += it.blocks
             host = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).clone()
             d["table"] = (host.to(device), blocks, len(live), keys)

@@ -47,7 +47,11 @@
 __device__ unsigned long long g_big_stamps[256 * 8];
 #define BIG_STAMP(i) do { if (threadIdx.x == 0 && blockIdx.x < 256) g_big_stamps[blockIdx.x * 8 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
 extern "C" int dadet_big_timing_read(unsigned long long* host, int n) {
-  return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_big_stamps), sizeof(unsigned long long) * (n < 2048 ? n : 2048));
+  // (copies the stamps out and clears them: stamp 4 marks a workgroup that wrote its tile, stamp 5 one that parked a part)
+  const int e = (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_big_stamps), sizeof(unsigned long long) * (n < 2048 ? n : 2048));
+  void* dev = nullptr;
+  if (hipGetSymbolAddress(&dev, HIP_SYMBOL(g_big_stamps)) == hipSuccess) (void)hipMemset(dev, 0, sizeof(g_big_stamps));
+  return e;
 }
 #else
 #define BIG_STAMP(i) do { } while (0)
@@ -132,6 +136,7 @@ __device__ __forceinline__ void big_finish(const ConvArgs& a, f32x16 (&acc)[TM][
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // every wave drains its stores ...
       __syncthreads();                                    // ... before one lane announces the part
       if (t == 0) __hip_atomic_fetch_add(parked, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      BIG_STAMP(5);
       return;
     }
     // the last part to arrive: the others have left their K loops (they hold tickets) and only finish their stores
@@ -515,6 +520,12 @@ __global__ __launch_bounds__(512, 2) void conv_big128_kernel(const ConvArgs a) {
   constexpr int BN = 128, TM = 2, TN = 2;
   constexpr int kPlaneA = 256 * 64, kPlaneB = 128 * 64;
   constexpr int kStage = 2 * kPlaneA + 2 * kPlaneB;       // A_h | A_l | B_h | B_l = 48 KB
+  BIG_STAMP(0);
+#if DADET_BIG_TIMING
+  const int abl = a.ablate;      // probe builds: DADET_ABLATE bit 1 no global loads, 2 no split + store, 4 no fragment reads, 8 no MFMA
+#else
+  constexpr int abl = 0;
+#endif
   const int t = threadIdx.x, lane = t & 63;
   const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
   const int grp = wave >> 2, tg = t & 255;
@@ -588,6 +599,11 @@ __global__ __launch_bounds__(512, 2) void conv_big128_kernel(const ConvArgs a) {
   float4 raw[2][6];
   f16x8 fa[2][2][TM], fb[2][2][TN];     // [k16 step][plane][block]
   f32x16 acc[TM][TN];
+#if DADET_BIG_TIMING
+  for (int i = 0; i < 12; ++i) (&raw[0][0])[i] = make_float4(1.f, 2.f, 3.f, 4.f);     // (defined values for the ablated stages)
+  for (int i = 0; i < 8; ++i)
+    for (int e = 0; e < 8; ++e) { (&fa[0][0][0])[i][e] = (_Float16)1; (&fb[0][0][0])[i][e] = (_Float16)1; }
+#endif
 #pragma unroll
   for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -596,6 +612,7 @@ __global__ __launch_bounds__(512, 2) void conv_big128_kernel(const ConvArgs a) {
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
   auto loads = [&](float4 (&dst)[6]) {        // one whole K-tile of this group's rows, then the stream moves on
+    if (!(abl & 1))
 #pragma unroll
     for (int i = 0; i < 6; ++i) {
       const bool act = is_act(i);
@@ -612,6 +629,7 @@ __global__ __launch_bounds__(512, 2) void conv_big128_kernel(const ConvArgs a) {
     __builtin_amdgcn_sched_barrier(0);      // the loads go out FIRST in their segment
   };
   auto stage = [&](const float4 (&v)[6], const int slot) {
+    if (!(abl & 2))
 #pragma unroll
     for (int i = 0; i < 6; ++i) {
       const bool act = is_act(i);
@@ -625,6 +643,7 @@ __global__ __launch_bounds__(512, 2) void conv_big128_kernel(const ConvArgs a) {
   };
   auto read_frags = [&](const int slot) {
     const char* cur = smem + slot * kStage;
+    if (!(abl & 4))
 #pragma unroll
     for (int step = 0; step < 2; ++step) {
 #pragma unroll
@@ -638,6 +657,7 @@ __global__ __launch_bounds__(512, 2) void conv_big128_kernel(const ConvArgs a) {
     }
   };
   auto mfma_seg = [&]() {
+    if (!(abl & 8))
 #pragma unroll
     for (int step = 0; step < 2; ++step)
 #pragma unroll
@@ -668,6 +688,7 @@ __global__ __launch_bounds__(512, 2) void conv_big128_kernel(const ConvArgs a) {
     if (grp == 0) stage(raw[1], 1);
   }
   bar();
+  BIG_STAMP(1);
   if (grp == 0) {
     read_frags(0);
     for (int Tt = 0; Tt < nT; Tt += 2) {

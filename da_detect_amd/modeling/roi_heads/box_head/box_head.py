@@ -15,6 +15,8 @@ from .roi_box_predictors import make_roi_box_predictor
 
 
 _NO_DEDUP = os.environ.get("DADET_NO_ROI_DEDUP", "0") == "1"
+# queue the pooler + res5 head before the sampled counts have reached the host (ROIBoxHead.forward); 0: after them
+_SPECULATE = os.environ.get("DADET_ROI_SPECULATE", "1") == "1"
 
 
 class ROIBoxHead(torch.nn.Module):
@@ -53,16 +55,42 @@ class ROIBoxHead(torch.nn.Module):
             # queued on the compute stream just before (RPNModule.early_backward)
             after, self.proposals_ready = self.proposals_ready, None
             dev = features[0].device      # (not proposals[0].bbox: that would materialise a device-resident list)
+            le = self.loss_evaluator
+            state = x = None
             with side_section(dev, after=after) as done, torch.no_grad():
-                proposals = self.loss_evaluator.subsample(proposals, targets)
-                for _ in range(burn):
-                    rng.next_seed(dev)
-                # the reference draws the DA ROI sample after the detection losses (box_head.py:102-104); nothing
-                # between the two draws from the random stream, so drawing it here is the same sample — and it keeps
-                # every host synchronisation of the box head in front of the res5 head instead of behind it
-                da_proposals = self.loss_evaluator.subsample_for_da(proposals, targets)
-                done(proposals, da_proposals, self.loss_evaluator._proposals, self.loss_evaluator._loss_prep)
-        x = self.feature_extractor(features, proposals)
+                if _SPECULATE and dev.type == "cuda":
+                    state = le.subsample_launch(proposals, targets)
+                if state is not None:
+                    done(state["buf"], state["counts"])
+                else:
+                    proposals = le.subsample(proposals, targets)
+                    for _ in range(burn):
+                        rng.next_seed(dev)
+                    # the reference draws the DA ROI sample after the detection losses (box_head.py:102-104); nothing
+                    # between the two draws from the random stream, so drawing it here is the same sample — and it keeps
+                    # every host synchronisation of the box head in front of the res5 head instead of behind it
+                    da_proposals = le.subsample_for_da(proposals, targets)
+                    done(proposals, da_proposals, le._proposals, le._loss_prep)
+            if state is not None:
+                # The sample's size reaches the host ~0.2 ms after the sampler ends (copy, wake-up, the Python between here
+                # and the first launch of the res5 head), and the GPU has nothing else to run by then (tools/probes/
+                # host_lead.py: lead 0 at this point, 3 - 6 ms everywhere else).  Every image fills its BATCH_SIZE_PER_IMAGE
+                # rows in all but degenerate steps, so the pooler and the res5 head are QUEUED NOW on that assumption —
+                # behind the sampler on the GPU, before the host knows the counts — and kept only if the counts confirm it;
+                # otherwise the result is dropped (nothing but a tensor was produced) and the exact lists are pooled below.
+                if state["speculative"] is not None:
+                    x = self.feature_extractor(features, state["speculative"])
+                with torch.no_grad():
+                    proposals = le.subsample_finish(state)      # the host waits for the counts' copy, nothing else
+                    for _ in range(burn):
+                        rng.next_seed(dev)
+                    da_proposals = le.subsample_for_da(proposals, targets)
+                if not state["exact"]:
+                    x = None
+        else:
+            x = None
+        if x is None:
+            x = self.feature_extractor(features, proposals)
         class_logits, box_regression = self.predictor(x)
         if not self.training:
             return x, self.post_processor((class_logits, box_regression), proposals), {}, x, None

@@ -126,6 +126,17 @@ class FastRCNNLossComputation(object):
 
     def _subsample_fused(self, proposals, targets):
         """per image: box_match_encode (source domain only) + sample_rois, then ONE host round trip for the counts"""
+        return self.subsample_finish(self.subsample_launch(proposals, targets))
+
+    def subsample_launch(self, proposals, targets):
+        """first half of subsample() on the one-launch device sampler: every kernel is queued on the current stream, the
+        counts (rows taken, positives, per image) start their way to a pinned host buffer, and NOTHING waits for them.
+        -> the state subsample_finish() completes, or None when this sampler does not serve the call (subsample() then
+        does everything).  state["speculative"]: the sample as it looks when every image fills its BATCH_SIZE_PER_IMAGE
+        rows — the usual case; rows behind an image's count are defined (zero boxes, csrc/sampling.hip) — for work that
+        may be queued before the counts are known (ROIBoxHead.forward issues the pooler and the res5 head on it)."""
+        if not self._fused_ok(proposals):
+            return None
         sampler = self.fg_bg_sampler
         cap = sampler.batch_size_per_image
         max_pos = int(cap * sampler.positive_fraction)
@@ -156,7 +167,32 @@ class FastRCNNLossComputation(object):
                     prop.bbox, tgt.bbox, tgt.get_field("labels"), self.proposal_matcher.high_threshold,
                     self.proposal_matcher.low_threshold, self.box_coder.weights)
             _C.sample_rois(prop.bbox, lab, reg, cap, max_pos, rng.next_seed(dev), is_source, counts[i], out=out_i)
-        host = counts.tolist()
+        state = dict(proposals=proposals, counts=counts, buf=buf, deferred=deferred, cap=cap, n_img=n_img)
+        if dev.type == "cuda":
+            # the counts' copy is issued HERE, behind the sampler on its stream, into pinned memory: the host later waits for
+            # this copy alone (an event), not for whatever the caller has queued on the compute stream in the meantime
+            pin = self._counts_pin.get(n_img) if hasattr(self, "_counts_pin") else None
+            if pin is None:
+                if not hasattr(self, "_counts_pin"):
+                    self._counts_pin = {}
+                pin = self._counts_pin[n_img] = torch.empty((n_img, 2), dtype=torch.int32).pin_memory()
+            pin.copy_(counts, non_blocking=True)
+            state["pin"], state["copied"] = pin, torch.cuda.current_stream(dev).record_event()
+        state["speculative"] = [BoxList(buf["boxes"][i * cap:(i + 1) * cap], prop.size, prop.mode)
+                                for i, prop in enumerate(proposals)] if all(deferred) else None
+        return state
+
+    def subsample_finish(self, state):
+        """second half: the host reads the counts (its only wait) and builds the sampled lists.  state["exact"] tells the
+        caller whether state["speculative"] WAS the sample (every image filled its rows)."""
+        proposals, buf, deferred, cap, n_img = (state[k] for k in ("proposals", "buf", "deferred", "cap", "n_img"))
+        sampler = self.fg_bg_sampler
+        if "pin" in state:
+            state["copied"].synchronize()
+            host = state["pin"].tolist()
+        else:
+            host = state["counts"].tolist()
+        state["exact"] = all(h[0] == cap for h in host)
         sampled = []
         for i, prop in enumerate(proposals):
             k = host[i][0]
@@ -175,7 +211,7 @@ class FastRCNNLossComputation(object):
         self._sampled_pos = [h[1] for h in host]
         self._is_source = [not neg for neg in self._all_negative]
         sampler.last_counts = [(h[1], h[0] - h[1]) for h in host]
-        if all(h[0] == cap for h in host):     # the usual case: every image filled its slice, no copies
+        if state["exact"]:                     # the usual case: every image filled its slice, no copies
             rows_of = lambda name: buf[name]   # noqa: E731
         else:
             rows_of = lambda name: cat([buf[name][i * cap:i * cap + host[i][0]] for i in range(n_img)], dim=0)  # noqa: E731

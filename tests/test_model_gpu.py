@@ -766,3 +766,63 @@ def test_fpn_device_side_selection_equals_the_host_chain(device, monkeypatch):
         assert len(d) == len(h) and len(h) > 50
         assert torch.equal(d.bbox, h.bbox)
         assert torch.equal(d.get_field("objectness"), h.get_field("objectness"))
+
+
+@pytest.mark.parametrize("post_nms", [None, 40])
+def test_box_head_queued_before_the_sampled_counts_gives_the_same_step(device, post_nms, monkeypatch):
+    """ROIBoxHead.forward queues the pooler + res5 head on the assumption that every image fills its BATCH_SIZE_PER_IMAGE
+    rows, before the sampler's counts have reached the host, and keeps the result only when the counts confirm it.
+    Same losses and gradients, bit for bit, as with the counts first (DADET_ROI_SPECULATE=0's order) — also when the
+    assumption FAILS (post_nms = 40: fewer proposals than rows to fill, the queued result is dropped)."""
+    from da_detect_amd.data.synthetic import make_batch
+    from da_detect_amd.modeling.roi_heads.box_head import box_head
+
+    z, c, model, _ = _build("da_plain", device)
+    seed, H, W, nimg = int(z["seed"]), int(z["H"]), int(z["W"]), int(z["nimg"])
+    images, targets = make_batch(c, nimg, H, W, seed=seed, device=device)
+    if post_nms is not None:
+        model.rpn.box_selector_train.post_nms_top_n = post_nms
+        model.rpn.box_selector_train.fpn_post_nms_top_n = post_nms
+    evaluator = model.roi_heads.box.loss_evaluator
+    seen = {}
+    orig_finish = evaluator.subsample_finish
+
+    def finish(state):
+        out = orig_finish(state)
+        seen["exact"], seen["queued"] = state["exact"], state["speculative"] is not None
+        return out
+
+    evaluator.subsample_finish = finish
+    extractor = model.roi_heads.box.feature_extractor
+    calls = []
+    extractor.register_forward_hook(lambda m, i, o: calls.append(1))
+    results = {}
+    for spec in (True, False):
+        monkeypatch.setattr(box_head, "_SPECULATE", spec)
+        seen.clear()
+        del calls[:]
+        model.zero_grad()
+        torch.manual_seed(seed)
+        losses = model(images, targets)
+        sum(losses.values()).backward()
+        torch.cuda.synchronize()
+        results[spec] = ({k: float(v.detach()) for k, v in losses.items()},
+                         {n: p.grad.detach().clone() for n, p in model.named_parameters() if p.grad is not None})
+        if spec:
+            assert seen["queued"] and seen["exact"] == (post_nms is None), seen
+            cap = evaluator.fg_bg_sampler.batch_size_per_image
+            assert all((len(p) == cap) == (post_nms is None) for p in evaluator._proposals)
+            assert len(calls) == (1 if post_nms is None else 2)      # a dropped result is pooled again from the exact lists
+        else:
+            assert len(calls) == 1
+    (la, ga), (lb, gb) = results[True], results[False]
+    for k in la:      # (the DA losses sum with atomics: not bit-reproducible from one call to the next)
+        tol = 1e-5 if k.startswith("loss_da") else 0.0
+        assert abs(la[k] - lb[k]) <= tol * max(1.0, abs(lb[k])), (k, la[k], lb[k])
+    box = [n for n in ga if n.startswith("roi_heads.")]
+    assert box and set(ga) == set(gb)
+    for n in box:     # (the res5 head also carries the instance-level DA branch's gradient: same sums, atomics' order)
+        if "predictor" in n:
+            assert torch.equal(ga[n], gb[n]), n
+        else:
+            torch.testing.assert_close(ga[n], gb[n], rtol=1e-4, atol=1e-6 * float(gb[n].abs().max()), msg=n)

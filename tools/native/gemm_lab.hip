@@ -754,23 +754,47 @@ static void part_timing(int M, int N, int K) {
   d.OutH = 1; d.OutW = M; d.out_spatial_stride = 1; d.relu_mode = 0;
   dadet_amax(dA, (long long)M * K, slots, nullptr);
   dadet_amax(dB, (long long)N * K, slots + 1, nullptr);
+  std::vector<unsigned long long> s(2048);
   for (int r = 0; r < 5; ++r)
     dadet_conv_forward_scaled(&d, dA, dB, nullptr, nullptr, nullptr, nullptr, dC, slots, slots + 1, nullptr, nullptr);
   CK(hipDeviceSynchronize());
-  std::vector<unsigned long long> s(2048);
+  rd(s.data(), 2048);                                 // (clears the stamps: what follows is ONE launch)
+  hipEvent_t e0, e1;
+  CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+  CK(hipEventRecord(e0, nullptr));
+  dadet_conv_forward_scaled(&d, dA, dB, nullptr, nullptr, nullptr, nullptr, dC, slots, slots + 1, nullptr, nullptr);
+  CK(hipEventRecord(e1, nullptr));
+  CK(hipDeviceSynchronize());
+  float ms = 0.f;
+  CK(hipEventElapsedTime(&ms, e0, e1));
   rd(s.data(), 2048);
-  double sum[4] = {0, 0, 0, 0}; int n = 0;
+  double fin[4] = {0, 0, 0, 0}, park[3] = {0, 0, 0};
+  int nf = 0, np = 0;
   unsigned long long t0 = ~0ull, t1 = 0;
   for (int b = 0; b < 256; ++b) {
     const unsigned long long* p = &s[b * 8];
-    if (!p[0] || !p[4]) continue;
-    for (int i = 0; i < 4; ++i) sum[i] += (double)(p[i + 1] - p[i]);
-    t0 = p[0] < t0 ? p[0] : t0; t1 = p[4] > t1 ? p[4] : t1;
-    ++n;
+    if (!p[0]) continue;
+    t0 = p[0] < t0 ? p[0] : t0;
+    if (p[4]) {
+      for (int i = 0; i < 4; ++i) fin[i] += (double)(p[i + 1] - p[i]);
+      t1 = p[4] > t1 ? p[4] : t1;
+      ++nf;
+    } else if (p[5]) {
+      park[0] += (double)(p[1] - p[0]); park[1] += (double)(p[2] - p[1]); park[2] += (double)(p[5] - p[2]);
+      t1 = p[5] > t1 ? p[5] : t1;
+      ++np;
+    }
   }
-  // s_memtime ticks at 100 MHz on this part
-  printf("M=%d N=%d K=%d  (%d workgroups stamped; 10 ns ticks)  prologue %.2f us | K loop %.2f | parts %.2f | epilogue %.2f | first start -> last end %.2f us\n",
-         M, N, K, n, sum[0] / n / 100, sum[1] / n / 100, sum[2] / n / 100, sum[3] / n / 100, (double)(t1 - t0) / 100);
+  // (every XCD has its own s_memtime base: only differences inside one workgroup mean anything.  The counter runs at
+  //  100 MHz x the shader clock multiplier on this part — printed: ticks, and the whole-workgroup total next to the launch)
+  (void)t0; (void)t1;
+  const char* sp = getenv("DADET_BIG_SPLITS");
+  printf("M=%d N=%d K=%d parts=%s: launch %.1f us (events); phase lengths in s_memtime ticks, mean over workgroups\n", M, N, K, sp ? sp : "plan", ms * 1e3);
+  if (nf) printf("   %3d workgroups that wrote a tile: prologue %.0f | K loop %.0f | wait + sum parts %.0f | epilogue %.0f | total %.0f (%.0f ticks per us of the launch)\n",
+                 nf, fin[0] / nf, fin[1] / nf, fin[2] / nf, fin[3] / nf, (fin[0] + fin[1] + fin[2] + fin[3]) / nf,
+                 (fin[0] + fin[1] + fin[2] + fin[3]) / nf / (ms * 1e3));
+  if (np) printf("   %3d workgroups that parked a part : prologue %.0f | K loop %.0f | park %.0f | total %.0f\n", np, park[0] / np,
+                 park[1] / np, park[2] / np, (park[0] + park[1] + park[2]) / np);
 }
 
 int main(int argc, char** argv) {
