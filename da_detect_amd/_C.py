@@ -575,6 +575,68 @@ def conv_wgrad_reduce_batch(batch):
     del batch[:]
 
 
+WGRAD_GROUP_MAX = 4
+
+
+def conv_wgrad_group(requests, pending):
+    """the weight gradients of ONE backward node in one launch (dadet_conv_wgrad_group; contraction mode 4).
+    requests: 1 - 4 dicts(x, gy, weight_shape, stride, pad, out_scale, dw, accumulate) as conv_wgrad's arguments, dw given
+    (the parameters' gradient buffers, all different); pending: the WgradBatch that takes their reduction passes.
+    -> True when the launch was made; False when some request does not qualify (nothing was launched: call conv_wgrad per
+    request)."""
+    n = len(requests)
+    if not (1 <= n <= WGRAD_GROUP_MAX) or not _mode4() or pending is None:
+        return False
+    descs = (_lib.ConvDesc * n)()
+    xs, gys = [], []
+    for i, r in enumerate(requests):
+        x, gy = _nhwc(_dev(r["x"], "x")), _nhwc(_dev(r["gy"], "gy"))
+        N, Cin, H, W = x.shape
+        Cout, Cin_w, KH, KW = r["weight_shape"]
+        if Cin != Cin_w or gy.shape[1] != Cout or r["dw"] is None:
+            return False
+        descs[i] = _desc(N, H, W, Cin, Cout, KH, KW, r.get("stride", 1), r.get("pad", 0), gy.shape[2], gy.shape[3])
+        xs.append(x)
+        gys.append(gy)
+    splits = (ctypes.c_int * n)()
+    nbytes = (ctypes.c_size_t * n)()
+    if not _lib.load().dadet_conv_wgrad_group_plan(descs, n, splits, nbytes):
+        return False
+    wss = [torch.empty(max(int(b), 16), dtype=torch.uint8, device=xs[0].device) for b in nbytes]
+    vp = ctypes.c_void_p * n
+
+    def ptrs(ts):
+        return vp(*[(t.data_ptr() if t is not None else None) for t in ts])
+
+    items = (_lib.WgradPending * n)()
+    ax = vp(*[_amax.ptr(t).value for t in xs])
+    ag = vp(*[_amax.ptr(t).value for t in gys])
+    acc = (ctypes.c_int * n)(*[1 if r.get("accumulate", False) else 0 for r in requests])
+    sizes = (ctypes.c_size_t * n)(*[w.numel() for w in wss])
+
+    def launch():
+        _lib.call("dadet_conv_wgrad_group", descs, n, ptrs(xs), ptrs(gys), ptrs([r.get("out_scale") for r in requests]),
+                  ptrs([r["dw"] for r in requests]), acc, ptrs(wss), sizes, items, ax, ag, _stream())
+
+    if PROFILER is not None:
+        flops = sum(2.0 * d.N * d.Ho * d.Wo * d.Cout * d.Cin * d.KH * d.KW for d in descs)
+        nbytes_alg = sum(4.0 * (x.numel() + g.numel() + r["dw"].numel()) for x, g, r in zip(xs, gys, requests))
+        kname = "conv_wgrad_big_group_kernel"
+        if getattr(PROFILER, "detail", False):
+            kname += "|" + " + ".join("M=%d N=%d K=%d k%dx%d s%d" % (d.N * d.Ho * d.Wo, d.Cout, d.Cin * d.KH * d.KW, d.KH,
+                                                                     d.KW, d.stride) for d in descs)
+        with PROFILER.span(kname, flops, nbytes_alg):
+            launch()
+    else:
+        launch()
+    for i, r in enumerate(requests):
+        if items[i].splits > 1:
+            it = _lib.WgradPending()
+            ctypes.memmove(ctypes.byref(it), ctypes.byref(items[i]), ctypes.sizeof(it))
+            pending.append((it, wss[i], r["dw"], r.get("out_scale")))
+    return True
+
+
 def conv_wgrad(x, gy, weight_shape, stride=1, pad=0, out_scale=None, dw=None, accumulate=False, pending=None):
     """dw[co,ci,r,s] = out_scale[co] * sum_m gy[m,co] * x[gather(m,r,s),ci]  (channels_last weight layout).
     pending (a WgradBatch): the reduction over split partial results is left to conv_wgrad_reduce_batch(pending) — dw is

@@ -93,6 +93,10 @@ _SIGNATURES = {
     "dadet_set_gemm_mode": [c_int],
     "dadet_get_gemm_mode": [],
     "dadet_conv_wgrad_variant": [POINTER(ConvDesc)],
+    "dadet_conv_wgrad_group_plan": [POINTER(ConvDesc), c_int, POINTER(c_int), POINTER(c_size_t)],
+    "dadet_conv_wgrad_group": [POINTER(ConvDesc), c_int, POINTER(c_void_p), POINTER(c_void_p), POINTER(c_void_p),
+                               POINTER(c_void_p), POINTER(c_int), POINTER(c_void_p), POINTER(c_size_t),
+                               POINTER(WgradPending), POINTER(c_void_p), POINTER(c_void_p), _P],
     "dadet_nonfinite_poll": [c_char_p, c_int],
     "dadet_set_big_gemm": [c_int],
     "dadet_get_big_gemm": [],

@@ -731,7 +731,8 @@ __global__ __launch_bounds__(512, 2) void conv_big128_kernel(const ConvArgs a) {
 // quarter is (K-tile of 32 rows, 128 channels).  The reduction over M is cut into `splits` ranges of whole K-tiles; every
 // part writes its tile of [splits][Cout][K] partial sums (or dW itself when there is one part) — the layout
 // wgrad_reduce_batch_kernel sums, with the FrozenBN scale, in its deterministic split order.
-__global__ __launch_bounds__(512, 2) void conv_wgrad_big_kernel(const WgradArgs a) {
+// (`bid`: the workgroup's index inside ITS problem — blockIdx.x, or that minus the problem's first workgroup in a grouped launch)
+__device__ __forceinline__ void wgrad_big_body(const WgradArgs& a, const int bid) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int TM = 4, TN = 2;
   constexpr int kPlane = 256 * 64;
@@ -741,7 +742,7 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_big_kernel(const WgradArgs 
   const int grp = wave >> 2, tg = t & 255;
   const int wm = wave >> 2, wn = wave & 3;
   const int T = a.tiles_co * a.tiles_kc;
-  const int lid = xcd_remap(blockIdx.x, T * a.splits);
+  const int lid = xcd_remap(bid, T * a.splits);
   const int part = lid / T, tile = lid - part * T;      // one XCD: one range of rows, neighbouring tiles
   const int co0 = (tile / a.tiles_kc) * 256, kk0 = (tile % a.tiles_kc) * 256;
   const int m_begin = part * a.rows_per_split;
@@ -986,6 +987,32 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_big_kernel(const WgradArgs 
   }
 }
 
+__global__ __launch_bounds__(512, 2) void conv_wgrad_big_kernel(const WgradArgs a) { wgrad_big_body(a, blockIdx.x); }
+
+// Several weight gradients in ONE launch (the 3 - 4 of a bottleneck block's backward): the chip's 256 workgroup slots are
+// shared among the problems instead of being filled once per problem.  Every workgroup leaves a 256 KB tile of partial sums
+// whatever its problem, so a launch parks 64 MB: per PROBLEM that is a third to a quarter of what its own full-chip launch
+// parks, its K loops are 3 - 4 x as long against the same prologue / epilogue, and a weight of four tiles (res4's 1x1
+// layers), too small for a launch of its own, rides along.  Problem i owns workgroups [first[i], first[i + 1]).  (Not
+// padded to multiples of 8: the XCD remap of a problem takes the index inside the problem — the XCDs' identities are
+// rotated by first[i] % 8, their chunks of neighbouring tiles stay chunks — and padding pushed 255 workgroups to a grid of
+// 264, 33 per XCD of 32 CUs: four XCDs ran a second round, the launch took twice as long.)
+constexpr int kWgradGroupMax = 4;
+struct WgradGroup {
+  WgradArgs a[kWgradGroupMax];
+  int first[kWgradGroupMax + 1];
+  int n;
+};
+__global__ __launch_bounds__(512, 2) void conv_wgrad_big_group_kernel(const WgradGroup g) {
+  int i = 0;
+#pragma unroll
+  for (int k = 1; k < kWgradGroupMax; ++k)
+    if (k < g.n && (int)blockIdx.x >= g.first[k]) i = k;
+  i = __builtin_amdgcn_readfirstlane(i);
+  const int local = (int)blockIdx.x - g.first[i];
+  wgrad_big_body(g.a[i], local);
+}
+
 // ---- host side -------------------------------------------------------------------------------------------------------
 // 0: never, 1: where the plan below expects a gain, 2: wherever the kernel is applicable (tests).  DADET_BIG_GEMM sets the
 // start-up value (A/B runs); dadet_set_big_gemm changes it at run time
@@ -1092,6 +1119,11 @@ bool wgrad_big_plan(const dadet_conv_desc* d, int* tiles_co, int* tiles_kc, int*
   int s = kNumCU / tiles;
   if (const char* e = getenv("DADET_WGRAD_BIG_SPLITS")) { const int v = atoi(e); if (v > 0) s = v; }
   if (s < 1) s = 1;
+  // a part is ONE fp32 accumulator chain over its rows: beyond ~4096 rows the chain's own rounding shows against the
+  // exact-fp32 kernel, whose plan always cuts (tests/test_ops_gpu.py::test_split_bf16_accuracy_at_production_k: the RPN
+  // conv's dense gradient, 8192 rows x 144 tiles in one part, RMS 1.27e-6 against 1.01e-6) — at least ceil(M / 4096) parts
+  // (the step has no such launch: its 144-tile weight is the RPN conv, whose gradient runs on the <= 256 sampled rows)
+  if (!getenv("DADET_WGRAD_BIG_SPLITS") && s < ceil_div(M, 4096)) s = ceil_div(M, 4096);
   const int max_s = ceil_div(M, 128);                 // at least four K-tiles per part
   if (s > max_s) s = max_s;
   const int rows = ceil_div(ceil_div(M, s), 32) * 32;
@@ -1100,20 +1132,82 @@ bool wgrad_big_plan(const dadet_conv_desc* d, int* tiles_co, int* tiles_kc, int*
   return true;
 }
 
+constexpr size_t kWgradBigLds = 2 * 4 * 256 * 64 + 2 * 256 * sizeof(int4);      // two K-tile slots + group 1's row state
+
 int launch_wgrad_big(WgradArgs& a, hipStream_t st) {
-  const size_t lds = 2 * 4 * 256 * 64 + 2 * 256 * sizeof(int4);      // two K-tile slots + group 1's row state
   static bool attr_set = false;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad_big_kernel),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)kWgradBigLds);
     if (e != hipSuccess) {
       set_error("conv_wgrad(big): hipFuncSetAttribute: %s", hipGetErrorString(e));
       return DADET_ELAUNCH;
     }
     attr_set = true;
   }
-  hipLaunchKernelGGL(conv_wgrad_big_kernel, dim3(a.tiles_co * a.tiles_kc * a.splits), dim3(512), lds, st, a);
+  hipLaunchKernelGGL(conv_wgrad_big_kernel, dim3(a.tiles_co * a.tiles_kc * a.splits), dim3(512), kWgradBigLds, st, a);
   return check_launch("conv_wgrad(big)");
+}
+
+// can this weight gradient be a member of a grouped launch (the tile kernel's own conditions; no lower bound on the tiles)
+bool wgrad_group_member(const dadet_conv_desc* d) {
+  static const bool enabled = !(getenv("DADET_WGRAD_BIG") && getenv("DADET_WGRAD_BIG")[0] == '0');
+  if (!enabled || g_big_mode == 0 || gemm_mode() != 4) return false;
+  const int M = d->N * d->Ho * d->Wo, K = d->KH * d->KW * d->Cin;
+  if (d->Cin % 4 != 0 || K % 4 != 0 || d->Cout % 4 != 0 || M >= (1 << 24) || M < 256) return false;
+  if ((uint64_t)d->N * d->H * d->W * d->Cin * 4 >= 0x7FFFFF00ull || (uint64_t)M * d->Cout * 4 >= 0x7FFFFF00ull) return false;
+  return g_big_mode == 2 || (d->Cout >= 256 && K >= 256 && M >= 2048);
+}
+
+// Rows per part R (a multiple of 32, the same for every problem of the group — every workgroup then runs the same number
+// of K-tiles on a 256 x 256 tile, whatever its problem): the smallest R whose parts fit the chip's 256 slots, at least
+// 128 rows (four K-tiles).  splits[i] = ceil(M_i / R).  DADET_WGRAD_GROUP_ROWS forces R (tests).
+void wgrad_group_plan(const int n, const dadet_conv_desc* d, int* tiles_co, int* tiles_kc, int* splits, int* rows) {
+  int max_m = 0;
+  for (int i = 0; i < n; ++i) {
+    tiles_co[i] = ceil_div(d[i].Cout, 256);
+    tiles_kc[i] = ceil_div(d[i].KH * d[i].KW * d[i].Cin, 256);
+    const int M = d[i].N * d[i].Ho * d[i].Wo;
+    max_m = M > max_m ? M : max_m;
+  }
+  int R = 128;
+  if (const char* e = getenv("DADET_WGRAD_GROUP_ROWS")) {
+    const int v = atoi(e);
+    R = v >= 32 ? v / 32 * 32 : R;
+  } else {
+    const int top = ceil_div(max_m, 32) * 32;
+    for (; R < top; R += 32) {
+      int wgs = 0;
+      for (int i = 0; i < n; ++i) wgs += tiles_co[i] * tiles_kc[i] * ceil_div(d[i].N * d[i].Ho * d[i].Wo, R);
+      if (wgs <= kNumCU) break;
+    }
+  }
+  *rows = R;
+  for (int i = 0; i < n; ++i) splits[i] = ceil_div(d[i].N * d[i].Ho * d[i].Wo, R);
+}
+
+int launch_wgrad_big_group(const WgradArgs* a, const int n, hipStream_t st) {
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad_big_group_kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)kWgradBigLds);
+    if (e != hipSuccess) {
+      set_error("conv_wgrad_group: hipFuncSetAttribute: %s", hipGetErrorString(e));
+      return DADET_ELAUNCH;
+    }
+    attr_set = true;
+  }
+  WgradGroup g;
+  g.n = n;
+  int at = 0;
+  for (int i = 0; i < kWgradGroupMax; ++i) {
+    g.a[i] = a[i < n ? i : n - 1];
+    g.first[i] = at;
+    if (i < n) at += a[i].tiles_co * a[i].tiles_kc * a[i].splits;
+  }
+  g.first[kWgradGroupMax] = at;
+  hipLaunchKernelGGL(conv_wgrad_big_group_kernel, dim3(at), dim3(512), kWgradBigLds, st, g);
+  return check_launch("conv_wgrad_group");
 }
 
 }  // namespace dadet

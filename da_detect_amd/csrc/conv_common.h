@@ -280,6 +280,10 @@ int launch_fwd_big(ConvArgs& a, hipStream_t st, float* ws, int* counters);
 // in the 128 x 128 kernel's [splits][Cout][K] layout
 bool wgrad_big_plan(const dadet_conv_desc* d, int* tiles_co, int* tiles_kc, int* splits, int* rps);
 int launch_wgrad_big(WgradArgs& a, hipStream_t st);
+// several weight gradients in one launch of that kernel (dadet_conv_wgrad_group): membership, the common rows per part, launch
+bool wgrad_group_member(const dadet_conv_desc* d);
+void wgrad_group_plan(int n, const dadet_conv_desc* d, int* tiles_co, int* tiles_kc, int* splits, int* rows);
+int launch_wgrad_big_group(const WgradArgs* a, int n, hipStream_t st);
 // weight-stationary 1x1 kernel for K = 64 / 128 / 256 (conv_ws.hip)
 bool ws_eligible(const ConvArgs& a);
 int launch_fwd_ws(ConvArgs& a, int fmt, hipStream_t st);

@@ -1219,6 +1219,89 @@ extern "C" int dadet_conv_wgrad_scaled(const dadet_conv_desc* d, const float* x,
                          amax_x, amax_gy);
 }
 
+// ---- several weight gradients in one launch (conv_big.hip: conv_wgrad_big_group_kernel) ---------------------------------
+extern "C" int dadet_conv_wgrad_group_plan(const dadet_conv_desc* descs, int n, int* splits_out, size_t* workspace_bytes_out) {
+  DADET_REQUIRE(descs && n >= 1 && splits_out && workspace_bytes_out, "conv_wgrad_group_plan: bad arguments");
+  if (n > 4) return 0;
+  for (int i = 0; i < n; ++i) {
+    if (conv_desc_check(&descs[i], "conv_wgrad_group_plan")) return 0;
+    if (descs[i].N == 0 || !wgrad_group_member(&descs[i])) return 0;
+  }
+  int tco[4], tkc[4], rows;
+  wgrad_group_plan(n, descs, tco, tkc, splits_out, &rows);
+  for (int i = 0; i < n; ++i)
+    workspace_bytes_out[i] = splits_out[i] > 1 ? sizeof(float) * (size_t)splits_out[i] * descs[i].Cout * descs[i].KH *
+                                                      descs[i].KW * descs[i].Cin
+                                                : 0;
+  return 1;
+}
+
+extern "C" int dadet_conv_wgrad_group(const dadet_conv_desc* descs, int n, const float* const* x, const float* const* gy,
+                                      const float* const* out_scale, float* const* dw, const int* accumulate,
+                                      void* const* workspace, const size_t* workspace_bytes,
+                                      dadet_wgrad_pending* pending_out, const float* const* amax_x,
+                                      const float* const* amax_gy, void* stream) {
+  DADET_REQUIRE(descs && n >= 1 && n <= 4 && x && gy && dw && accumulate && workspace && workspace_bytes && pending_out &&
+                    amax_x && amax_gy, "conv_wgrad_group: bad arguments (1 - 4 problems, every array non-null)");
+  DADET_REQUIRE(gemm_mode() == 4, "conv_wgrad_group: contraction mode 4 only (mode %d is set)", gemm_mode());
+  hipStream_t st = as_stream(stream);
+  int tco[4], tkc[4], splits[4], rows;
+  for (int i = 0; i < n; ++i) {
+    int rc = conv_desc_check(&descs[i], "conv_wgrad_group");
+    if (rc) return rc;
+    DADET_REQUIRE(descs[i].N > 0 && wgrad_group_member(&descs[i]),
+                  "conv_wgrad_group: problem %d does not qualify for the 256 x 256 kernel (dadet_conv_wgrad_group_plan)", i);
+    DADET_REQUIRE(x[i] && gy[i] && dw[i] && amax_x[i] && amax_gy[i] && al16(x[i]) && al16(gy[i]) && al16(dw[i]),
+                  "conv_wgrad_group: problem %d: null or misaligned pointer", i);
+    for (int j = 0; j < i; ++j)
+      DADET_REQUIRE(dw[i] != dw[j], "conv_wgrad_group: problems %d and %d write the same dw", j, i);
+  }
+  wgrad_group_plan(n, descs, tco, tkc, splits, &rows);
+  WgradArgs a[4];
+  for (int i = 0; i < n; ++i) {
+    const dadet_conv_desc* d = &descs[i];
+    WgradArgs& w = a[i];
+    w.gy_ld = d->Cout;
+    w.x = x[i]; w.gy = gy[i]; w.out_scale = out_scale ? out_scale[i] : nullptr;
+    w.N = d->N; w.H = d->H; w.W = d->W; w.Cin = d->Cin; w.Cout = d->Cout; w.KH = d->KH; w.KW = d->KW;
+    w.stride = d->stride; w.pad = d->pad; w.Ho = d->Ho; w.Wo = d->Wo;
+    w.M = d->N * d->Ho * d->Wo; w.K = d->KH * d->KW * d->Cin;
+    w.x_bytes = (unsigned)((uint64_t)d->N * d->H * d->W * d->Cin * 4);
+    w.gy_bytes = (unsigned)((uint64_t)w.M * d->Cout * 4);
+    w.tiles_co = tco[i]; w.tiles_kc = tkc[i]; w.splits = splits[i]; w.rows_per_split = rows;
+    w.accumulate = accumulate[i];
+    w.amax_x = amax_x[i]; w.amax_gy = amax_gy[i];
+    w.nf_flag = nf_flag_ptr();
+    w.launch_id = w.nf_flag ? nf_next_launch("conv_wgrad_group", w.M, w.Cout, w.K, w.KH) : 0;
+    pending_out[i].splits = 0;
+    if (splits[i] == 1) {
+      w.direct = 1;
+      w.out = dw[i];
+    } else {
+      const size_t need = sizeof(float) * (size_t)splits[i] * d->Cout * w.K;
+      if (!workspace[i] || workspace_bytes[i] < need) {
+        set_error("conv_wgrad_group: problem %d: workspace %zu < required %zu", i, workspace_bytes[i], need);
+        return DADET_EWORKSPACE;
+      }
+      w.direct = 0;
+      w.out = static_cast<float*>(workspace[i]);
+    }
+  }
+  int rc = launch_wgrad_big_group(a, n, st);
+  if (rc) return rc;
+  for (int i = 0; i < n; ++i) {
+    if (splits[i] <= 1) continue;
+    pending_out[i].partials = static_cast<const float*>(workspace[i]);
+    pending_out[i].out_scale = out_scale ? out_scale[i] : nullptr;
+    pending_out[i].dw = dw[i];
+    pending_out[i].count = (long long)descs[i].Cout * a[i].K;
+    pending_out[i].K = a[i].K;
+    pending_out[i].splits = splits[i];
+    pending_out[i].accumulate = accumulate[i];
+  }
+  return DADET_OK;
+}
+
 extern "C" int dadet_conv_wgrad_reduce_batch(const dadet_wgrad_pending* items, int n, void* stream) {
   DADET_REQUIRE(n >= 0 && (n == 0 || items), "conv_wgrad_reduce_batch: bad arguments");
   hipStream_t st = as_stream(stream);

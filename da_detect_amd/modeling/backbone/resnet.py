@@ -38,6 +38,54 @@ ResNet152FPNStagesTo5 = _specs((1, 3, True), (2, 8, True), (3, 36, True), (4, 3,
 
 # one reduction launch per block for its split weight gradients (dadet_conv_wgrad_reduce_batch); 0: one pass per tensor
 _WGRAD_BATCH = True
+# ONE GEMM launch for a block's 3 - 4 weight gradients where they qualify (_C.conv_wgrad_group; res4 / res5 in contraction
+# mode 4): the chip's workgroup slots are shared among them, so each parks a third to a quarter of the partial sums its own
+# full-chip launch would and reduces 3 - 4 x as many rows per workgroup.  DADET_WGRAD_GROUP=0: one launch per layer.
+_WGRAD_GROUP = __import__("os").environ.get("DADET_WGRAD_GROUP", "1") == "1"
+
+
+class _WgradGroup(object):
+    """the weight gradients of one backward node, collected for one grouped launch.  Only with direct accumulation (every
+    weight has a persistent gradient buffer, streams.direct_grad_target: the node then returns None for them) and a batched
+    reduction pass; `take` returns False for a request that must go the per-layer way."""
+
+    _known = {}       # (shapes of the node's requests) -> the library accepted the group
+
+    def __init__(self, lane, batch, weights):
+        self.lane, self.batch, self.reqs = lane, batch, []
+        self.on = (_WGRAD_GROUP and batch is not None and _C._mode4() and 2 <= len(weights) <= _C.WGRAD_GROUP_MAX
+                   and all(streams.direct_grad_target(w) is not None for w in weights))
+        self.key = None
+        if self.on:
+            self.key = tuple(tuple(w.shape) for w in weights) + (lane.on,)
+            self.on = self._known.get(self.key, True) is not False
+
+    def take(self, w, xin, gout, stride, pad, scale, shape=None):
+        if not self.on:
+            return False
+        self.reqs.append(dict(x=xin, gy=gout, weight_shape=tuple(w.shape) if shape is None else shape, stride=stride,
+                              pad=pad, out_scale=scale, dw=streams.direct_grad_target(w), accumulate=True))
+        return True
+
+    def issue(self):
+        """every collected request: one grouped launch, or (first time a node of these shapes is refused: layers of
+        fewer than 256 channels, another contraction mode) one launch each — remembered, so that the node's later
+        backward passes issue them in their usual places"""
+        if not self.reqs:
+            return
+        reqs, batch = self.reqs, self.batch
+        key = self.key + tuple((tuple(r["x"].shape), r["stride"]) for r in reqs)
+
+        def run():
+            ok = self._known.get(key, True) and _C.conv_wgrad_group(reqs, batch)
+            if not ok:
+                self._known[key] = self._known[self.key] = False
+                for r in reqs:
+                    _C.conv_wgrad(r["x"], r["gy"], r["weight_shape"], r["stride"], r["pad"], out_scale=r["out_scale"],
+                                  dw=r["dw"], accumulate=True, pending=batch)
+
+        self.lane.run_group(run, *[t for r in reqs for t in (r["x"], r["gy"])])
+        self.reqs = []
 
 
 class _BottleneckFn(torch.autograd.Function):
@@ -77,7 +125,12 @@ class _BottleneckFn(torch.autograd.Function):
         # the block's 3 - 4 weight gradients share ONE reduction launch over their split partial results (_WGRAD_BATCH)
         batch = _C.WgradBatch() if _WGRAD_BATCH else None
 
+        group = _WgradGroup(lane, batch, [w for w, need in ((w3, n3), (w2, n2), (w1, n1), (wd, nd and wd is not None))
+                                          if need])
+
         def wgrad(w, xin, gout, st, pd, sc):
+            if group.take(w, xin, gout, st, pd, sc):
+                return None
             return lane.run_into(w, lambda acc: _C.conv_wgrad(xin, gout, tuple(w.shape), st, pd, out_scale=sc, dw=acc,
                                                               accumulate=True, pending=batch),
                                  lambda: _C.conv_wgrad(xin, gout, tuple(w.shape), st, pd, out_scale=sc, pending=batch),
@@ -94,6 +147,7 @@ class _BottleneckFn(torch.autograd.Function):
             dw1 = wgrad(w1, x, S1, stride, 0, s1)
         if nd and wd is not None:
             dwd = wgrad(wd, x, S3, stride, 0, sd)
+        group.issue()
         lane.reduce_batch(batch)
         if need_x:
             gate = dict(relu_mode=2, mask_ref=x) if ctx.in_relu else {}
@@ -155,8 +209,14 @@ class _DCNBottleneckFn(torch.autograd.Function):
         lane = WgradLane(G.device, rows=G.shape[0] * G.shape[2] * G.shape[3])
         batch = _C.WgradBatch() if _WGRAD_BATCH else None
 
+        # (the offset branch's gradient has rows padded beyond its 18 | 27 channels: not a member of the grouped launch)
+        group = _WgradGroup(lane, batch, [w for w, need in ((w3, n3), (w2, n2), (w1, n1), (wd, nd and wd is not None))
+                                          if need])
+
         def wgrad(w, xin, gout, st, pd, sc, shape=None):
             shape = tuple(w.shape) if shape is None else shape
+            if w is not w_off and group.take(w, xin, gout, st, pd, sc, shape=shape):
+                return None
             return lane.run_into(w, lambda acc: _C.conv_wgrad(xin, gout, shape, st, pd, out_scale=sc, dw=acc,
                                                               accumulate=True, pending=batch),
                                  lambda: _C.conv_wgrad(xin, gout, shape, st, pd, out_scale=sc, pending=batch),
@@ -185,6 +245,7 @@ class _DCNBottleneckFn(torch.autograd.Function):
             dw1 = wgrad(w1, x, S1, stride, 0, s1)
         if nd and wd is not None:
             dwd = wgrad(wd, x, S3, stride, 0, sd)
+        group.issue()
         lane.reduce_batch(batch)
         if need_x:
             gate = dict(relu_mode=2, mask_ref=x) if in_relu else {}

@@ -155,6 +155,20 @@ class WgradLane(object):
             t.record_stream(self.lane)
         return None
 
+    def run_group(self, fn, *inputs):
+        """fn() issues the weight gradients of several parameters straight into their persistent gradient buffers (one
+        grouped launch, _C.conv_wgrad_group): on the lane when it is on — the same hand-over as run_into's direct path —
+        else on the current stream"""
+        if not self.on:
+            fn()
+            return
+        self._resolve_maxima(inputs)
+        self.lane.wait_event(self.main.record_event())
+        with torch.cuda.stream(self.lane):
+            fn()
+        for t in inputs:
+            t.record_stream(self.lane)
+
     def reduce_batch(self, batch, now=False):
         """the batched reduction pass of the weight gradients queued through this lane object (same stream as their
         GEMMs: the lane when it is on, else the current stream).  When every gradient of the batch is accumulated straight

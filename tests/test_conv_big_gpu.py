@@ -196,6 +196,81 @@ def test_big_tile_weight_gradient_through_the_batched_reduction(device, big_mode
         assert float((dw.double() - ref).abs().max()) <= 2e-5 * float(ref.abs().max())
 
 
+GROUPS = [
+    # a bottleneck block's backward: conv3, the 3x3 conv2, conv1 and the stride-2 projection shortcut (ragged everything)
+    [(2, 96, 20, 28, 300, 1, 1, 0), (2, 96, 20, 28, 96, 3, 1, 1), (2, 160, 40, 56, 96, 1, 2, 0), (2, 160, 40, 56, 300, 1, 2, 0)],
+    # two problems with different row counts (parts per problem differ), one of them a single tile
+    [(1, 64, 24, 40, 256, 1, 1, 0), (8, 64, 7, 7, 256, 3, 1, 1)],
+    [(1, 256, 33, 47, 256, 3, 1, 1)],      # a group of one
+]
+
+
+@pytest.mark.parametrize("rows", [0, 128, 4096])
+@pytest.mark.parametrize("group", GROUPS, ids=lambda g: "%dproblems_%d" % (len(g), g[0][1]))
+def test_grouped_weight_gradients_against_float64(device, big_mode, group, rows, monkeypatch):
+    """dadet_conv_wgrad_group: several weight gradients in ONE launch of the 256 x 256-tile kernel, each accumulated into
+    its own buffer with its FrozenBN scale — against float64 and against the per-layer launches (same products, another
+    cut of the reduction), with the planned rows per part, the smallest (128: many parts) and one part per problem (4096:
+    the kernel writes dW itself)"""
+    from da_detect_amd import _C
+
+    big_mode.dadet_set_big_gemm(2)
+    if rows:
+        monkeypatch.setenv("DADET_WGRAD_GROUP_ROWS", str(rows))
+    g = torch.Generator().manual_seed(11 + len(group))
+    reqs, refs, singles, prevs = [], [], [], []
+    for (N, Cin, H, W, Cout, k, stride, pad) in group:
+        x = torch.randn((N, Cin, H, W), generator=g).to(device).contiguous(memory_format=CL)
+        Ho, Wo = (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
+        gy = torch.randn((N, Cout, Ho, Wo), generator=g).to(device).contiguous(memory_format=CL)
+        scale = (torch.rand(Cout, generator=g) + 0.5).to(device)
+        prev = torch.randn((Cout, Cin, k, k), generator=g).to(device).contiguous(memory_format=CL)
+        ref = torch.nn.grad.conv2d_weight(x.double(), (Cout, Cin, k, k), gy.double(), stride=stride, padding=pad)
+        refs.append(ref * scale.double().view(-1, 1, 1, 1) + prev.double())
+        singles.append(_C.conv_wgrad(x, gy, (Cout, Cin, k, k), stride=stride, pad=pad, out_scale=scale, dw=prev.clone(),
+                                     accumulate=True))
+        prevs.append(prev)
+        reqs.append(dict(x=x, gy=gy, weight_shape=(Cout, Cin, k, k), stride=stride, pad=pad, out_scale=scale,
+                         dw=None, accumulate=True))
+    results = []
+    for rep in range(2):
+        for r, prev in zip(reqs, prevs):
+            r["dw"] = prev.clone()
+        batch = _C.WgradBatch()
+        assert _C.conv_wgrad_group(reqs, batch)
+        if rows == 4096:
+            assert not batch          # one part per problem: nothing left to reduce
+        _C.conv_wgrad_reduce_batch(batch)
+        results.append([r["dw"] for r in reqs])
+    for got, again, ref, one in zip(results[0], results[1], refs, singles):
+        top = float(ref.abs().max())
+        assert torch.equal(got, again)                  # deterministic: fixed cut, fixed order of the partial sums
+        assert float((got.double() - ref).abs().max()) <= 2e-5 * top
+        torch.testing.assert_close(got, one, rtol=2e-5, atol=2e-5 * top)
+
+
+def test_grouped_weight_gradients_refuse_what_the_kernel_does_not_cover(device, big_mode):
+    """a member with gy rows padded beyond Cout, more than four problems, or another contraction mode: conv_wgrad_group
+    returns False and launches nothing"""
+    from da_detect_amd import _C
+
+    big_mode.dadet_set_big_gemm(1)      # the default plan: layers below 256 channels do not qualify
+    x = torch.randn((1, 64, 16, 16), device=device).contiguous(memory_format=CL)
+    gy = torch.randn((1, 64, 16, 16), device=device).contiguous(memory_format=CL)
+    dw = torch.zeros((64, 64, 1, 1), device=device).contiguous(memory_format=CL)
+    req = dict(x=x, gy=gy, weight_shape=(64, 64, 1, 1), dw=dw, accumulate=True)
+    batch = _C.WgradBatch()
+    assert not _C.conv_wgrad_group([req], batch) and not batch and float(dw.abs().max()) == 0.0
+    big_mode.dadet_set_big_gemm(2)
+    assert not _C.conv_wgrad_group([dict(req, dw=dw.clone()) for _ in range(5)], batch)
+    mode = _C.get_gemm_mode()
+    try:
+        _C.set_gemm_mode(3)
+        assert not _C.conv_wgrad_group([req], batch)
+    finally:
+        _C.set_gemm_mode(mode)
+
+
 @pytest.mark.parametrize("big", [0, 2])
 def test_a_low_operand_maximum_is_reported_by_name_not_as_a_nan_loss(device, big_mode, big):
     """mode 4's guard (dadet_nonfinite_poll): a slot that claims a maximum far below the data makes the scaled operand

@@ -238,18 +238,57 @@ def test_weight_gradient_split_plan_respects_the_workgroup_slots():
     shapes = [(512, 7, 7, 512, 512, 3, 1), (2, 64, 128, 1024, 1024, 3, 1), (512, 7, 7, 512, 2048, 1, 1),
               (512, 14, 14, 1024, 2048, 1, 2), (2, 64, 128, 256, 256, 3, 1), (2, 128, 256, 128, 128, 3, 1),
               (2, 64, 128, 256, 1024, 1, 1), (2, 128, 256, 128, 512, 1, 1), (1, 8, 8, 64, 64, 3, 1)]
-    for N, H, W, Cin, Cout, k, stride in shapes:
-        s, M = splits(N, H, W, Cin, Cout, k, stride)
-        tiles = -(-Cout // 128) * -(-(Cin * k * k) // 128)
-        wgs = tiles * s
-        rows = -(-M // s)
-        assert s == 1 or rows >= 128, (N, H, W, Cin, Cout, k, s, rows)
-        over = wgs % 512
-        assert wgs <= 512 or over == 0 or over > 128, ("%d workgroups: a nearly empty extra pass" % wgs, Cin, Cout, k)
-    # the shapes the sweep pinned down
-    assert splits(512, 7, 7, 512, 512, 3, 1)[0] == 7           # 144 tiles -> 1008 workgroups
-    assert splits(512, 7, 7, 512, 2048, 1, 1)[0] == 8          # 64 tiles  -> 512 workgroups
-    assert splits(2, 64, 128, 256, 1024, 1, 1)[0] == 32        # 16 tiles  -> 512 workgroups
+    lib = _lib.load()
+    plan = lib.dadet_get_big_gemm()
+    try:
+        lib.dadet_set_big_gemm(0)       # the 128 x 128 kernel's plan
+        for N, H, W, Cin, Cout, k, stride in shapes:
+            s, M = splits(N, H, W, Cin, Cout, k, stride)
+            tiles = -(-Cout // 128) * -(-(Cin * k * k) // 128)
+            wgs = tiles * s
+            rows = -(-M // s)
+            assert s == 1 or rows >= 128, (N, H, W, Cin, Cout, k, s, rows)
+            over = wgs % 512
+            assert wgs <= 512 or over == 0 or over > 128, ("%d workgroups: a nearly empty extra pass" % wgs, Cin, Cout, k)
+        # the shapes the sweep pinned down
+        assert splits(512, 7, 7, 512, 512, 3, 1)[0] == 7           # 144 tiles -> 1008 workgroups
+        assert splits(512, 7, 7, 512, 2048, 1, 1)[0] == 8          # 64 tiles  -> 512 workgroups
+        assert splits(2, 64, 128, 256, 1024, 1, 1)[0] == 32        # 16 tiles  -> 512 workgroups
+        # the 256 x 256-tile kernel (round 5; contraction mode 4, weights of at least eight tiles): one workgroup per CU, the
+        # parts fill the 256 slots once and keep at least four K-tiles of rows each
+        lib.dadet_set_big_gemm(1)
+        big = 0
+        for N, H, W, Cin, Cout, k, stride in shapes:
+            pad = k // 2
+            Ho, Wo = (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
+            d = _C._desc(N, H, W, Cin, Cout, k, k, stride, pad, Ho, Wo)
+            if lib.dadet_conv_wgrad_variant(ctypes.byref(d)) != 1:
+                continue
+            big += 1
+            s, M = splits(N, H, W, Cin, Cout, k, stride)
+            tiles = -(-Cout // 256) * -(-(Cin * k * k) // 256)
+            # (a part is one fp32 accumulator chain: never over more than 4096 rows, even where that costs a second pass)
+            assert tiles >= 8 and tiles * s <= max(256, tiles * -(-M // 4096)) and -(-M // s) <= 4096 + 31 \
+                and (s == 1 or -(-M // s) >= 128), (Cin, Cout, k, tiles, s)
+        assert big >= 4
+        # several weight gradients in one launch: every part of every problem reduces the same number of rows, the parts fit
+        # the 256 slots, and a four-tile weight (below the bound for a launch of its own) is a member
+        group = [(2, 64, 128, 256, 1024, 1, 1), (2, 64, 128, 256, 256, 3, 1), (2, 64, 128, 1024, 256, 1, 1)]
+        descs = (_lib.ConvDesc * 3)()
+        for i, (N, H, W, Cin, Cout, k, stride) in enumerate(group):
+            pad = k // 2
+            descs[i] = _C._desc(N, H, W, Cin, Cout, k, k, stride, pad, (H + 2 * pad - k) // stride + 1,
+                                (W + 2 * pad - k) // stride + 1)
+        sp, nb = (ctypes.c_int * 3)(), (ctypes.c_size_t * 3)()
+        assert lib.dadet_conv_wgrad_group_plan(descs, 3, sp, nb) == 1
+        tiles = [-(-d.Cout // 256) * -(-(d.Cin * d.KH * d.KW) // 256) for d in descs]
+        assert tiles == [4, 9, 4] and len(set(sp)) == 1 and sum(t * s for t, s in zip(tiles, sp)) <= 256
+        assert sum(t * (s + 1) for t, s in zip(tiles, sp)) > 256 - 17 * 2      # ... and no fewer parts than fit
+        assert all(b == 4 * s * d.Cout * d.Cin * d.KH * d.KW for b, s, d in zip(nb, sp, descs))
+        narrow = (_lib.ConvDesc * 1)(_C._desc(2, 128, 256, 128, 128, 3, 3, 1, 1, 128, 256))
+        assert lib.dadet_conv_wgrad_group_plan(narrow, 1, sp, nb) == 0       # 128 channels: not this kernel's
+    finally:
+        lib.dadet_set_big_gemm(plan)
 
 
 def test_unread_work_rules():

@@ -647,8 +647,12 @@ def test_direct_weight_gradient_accumulation_matches_the_autograd_path(device):
         results.append((grads, {n: p.detach().clone() for n, p in model.named_parameters()}, set(reducer.touched)))
     (g0, p0, t0), (g1, p1, t1) = results
     assert len(t0) == len(t1) > 50
+    # (the direct path issues a block's weight gradients as ONE grouped launch — another cut of the reduction over the rows
+    # than the per-layer launches of the autograd path: the same sums in another order, so elements far below a tensor's
+    # largest agree to fp32 resolution of THAT, not of themselves)
     for n in g0:
-        torch.testing.assert_close(g1[n], g0[n], rtol=1e-5, atol=1e-7, msg=lambda m, n=n: "%s: %s" % (n, m))
+        top = float(g0[n].abs().max())
+        torch.testing.assert_close(g1[n], g0[n], rtol=1e-5, atol=max(1e-7, 2e-6 * top), msg=lambda m, n=n: "%s: %s" % (n, m))
     for n in p0:
         torch.testing.assert_close(p1[n], p0[n], rtol=1e-5, atol=1e-7, msg=lambda m, n=n: "%s: %s" % (n, m))
 
