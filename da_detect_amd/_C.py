@@ -600,7 +600,8 @@ def conv_wgrad_group(requests, pending):
         gys.append(gy)
     splits = (ctypes.c_int * n)()
     nbytes = (ctypes.c_size_t * n)()
-    if not _lib.load().dadet_conv_wgrad_group_plan(descs, n, splits, nbytes):
+    kind = _lib.load().dadet_conv_wgrad_group_plan(descs, n, splits, nbytes)
+    if not kind:
         return False
     wss = [torch.empty(max(int(b), 16), dtype=torch.uint8, device=xs[0].device) for b in nbytes]
     vp = ctypes.c_void_p * n
@@ -621,7 +622,7 @@ def conv_wgrad_group(requests, pending):
     if PROFILER is not None:
         flops = sum(2.0 * d.N * d.Ho * d.Wo * d.Cout * d.Cin * d.KH * d.KW for d in descs)
         nbytes_alg = sum(4.0 * (x.numel() + g.numel() + r["dw"].numel()) for x, g, r in zip(xs, gys, requests))
-        kname = "conv_wgrad_big_group_kernel"
+        kname = "conv_wgrad_big_group_kernel" if kind == 256 else "conv_wgrad_split_group_kernel"
         if getattr(PROFILER, "detail", False):
             kname += "|" + " + ".join("M=%d N=%d K=%d k%dx%d s%d" % (d.N * d.Ho * d.Wo, d.Cout, d.Cin * d.KH * d.KW, d.KH,
                                                                      d.KW, d.stride) for d in descs)

@@ -997,12 +997,6 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_big_kernel(const WgradArgs 
 // padded to multiples of 8: the XCD remap of a problem takes the index inside the problem — the XCDs' identities are
 // rotated by first[i] % 8, their chunks of neighbouring tiles stay chunks — and padding pushed 255 workgroups to a grid of
 // 264, 33 per XCD of 32 CUs: four XCDs ran a second round, the launch took twice as long.)
-constexpr int kWgradGroupMax = 4;
-struct WgradGroup {
-  WgradArgs a[kWgradGroupMax];
-  int first[kWgradGroupMax + 1];
-  int n;
-};
 __global__ __launch_bounds__(512, 2) void conv_wgrad_big_group_kernel(const WgradGroup g) {
   int i = 0;
 #pragma unroll
@@ -1160,13 +1154,16 @@ bool wgrad_group_member(const dadet_conv_desc* d) {
 }
 
 // Rows per part R (a multiple of 32, the same for every problem of the group — every workgroup then runs the same number
-// of K-tiles on a 256 x 256 tile, whatever its problem): the smallest R whose parts fit the chip's 256 slots, at least
-// 128 rows (four K-tiles).  splits[i] = ceil(M_i / R).  DADET_WGRAD_GROUP_ROWS forces R (tests).
-void wgrad_group_plan(const int n, const dadet_conv_desc* d, int* tiles_co, int* tiles_kc, int* splits, int* rows) {
+// of K-tiles on one tile, whatever its problem): the smallest R whose parts fit the chip's workgroup slots (256 for the
+// 256 x 256 tile, 2 x 256 for the 128 x 128 kernel), at least 128 rows (four K-tiles).  splits[i] = ceil(M_i / R).
+// DADET_WGRAD_GROUP_ROWS forces R (tests).
+void wgrad_group_plan(const int n, const dadet_conv_desc* d, const int tile, int* tiles_co, int* tiles_kc, int* splits,
+                      int* rows) {
+  const int slots = tile == 256 ? kNumCU : 2 * kNumCU;
   int max_m = 0;
   for (int i = 0; i < n; ++i) {
-    tiles_co[i] = ceil_div(d[i].Cout, 256);
-    tiles_kc[i] = ceil_div(d[i].KH * d[i].KW * d[i].Cin, 256);
+    tiles_co[i] = ceil_div(d[i].Cout, tile);
+    tiles_kc[i] = ceil_div(d[i].KH * d[i].KW * d[i].Cin, tile);
     const int M = d[i].N * d[i].Ho * d[i].Wo;
     max_m = M > max_m ? M : max_m;
   }
@@ -1179,7 +1176,7 @@ void wgrad_group_plan(const int n, const dadet_conv_desc* d, int* tiles_co, int*
     for (; R < top; R += 32) {
       int wgs = 0;
       for (int i = 0; i < n; ++i) wgs += tiles_co[i] * tiles_kc[i] * ceil_div(d[i].N * d[i].Ho * d[i].Wo, R);
-      if (wgs <= kNumCU) break;
+      if (wgs <= slots) break;
     }
   }
   *rows = R;

@@ -248,6 +248,14 @@ struct WgradArgs {
   unsigned launch_id;
 };
 
+// several weight gradients in one launch (dadet_conv_wgrad_group): problem i owns workgroups [first[i], first[i + 1])
+constexpr int kWgradGroupMax = 4;
+struct WgradGroup {
+  WgradArgs a[kWgradGroupMax];
+  int first[kWgradGroupMax + 1];
+  int n;
+};
+
 // tile variant chosen for a forward / dgrad GEMM of M rows and Cout columns
 //   0: 128x128 (TM=2,TN=2)   1: 128x64 (TM=2,TN=1)   2: 64x64 (TM=1,TN=1)
 inline int fwd_variant(int M, int Cout) {
@@ -282,8 +290,9 @@ bool wgrad_big_plan(const dadet_conv_desc* d, int* tiles_co, int* tiles_kc, int*
 int launch_wgrad_big(WgradArgs& a, hipStream_t st);
 // several weight gradients in one launch of that kernel (dadet_conv_wgrad_group): membership, the common rows per part, launch
 bool wgrad_group_member(const dadet_conv_desc* d);
-void wgrad_group_plan(int n, const dadet_conv_desc* d, int* tiles_co, int* tiles_kc, int* splits, int* rows);
+void wgrad_group_plan(int n, const dadet_conv_desc* d, int tile, int* tiles_co, int* tiles_kc, int* splits, int* rows);
 int launch_wgrad_big_group(const WgradArgs* a, int n, hipStream_t st);
+int launch_wgrad_split_group(const WgradArgs* a, int n, hipStream_t st);      // the 128 x 128 kernel's grouped form (conv_split.hip)
 // weight-stationary 1x1 kernel for K = 64 / 128 / 256 (conv_ws.hip)
 bool ws_eligible(const ConvArgs& a);
 int launch_fwd_ws(ConvArgs& a, int fmt, hipStream_t st);

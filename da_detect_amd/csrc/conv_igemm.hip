@@ -1219,21 +1219,36 @@ extern "C" int dadet_conv_wgrad_scaled(const dadet_conv_desc* d, const float* x,
                          amax_x, amax_gy);
 }
 
-// ---- several weight gradients in one launch (conv_big.hip: conv_wgrad_big_group_kernel) ---------------------------------
+// ---- several weight gradients in one launch (conv_big.hip: conv_wgrad_big_group_kernel; conv_split.hip: its 128 x 128 form)
+// which kernel serves the whole group: 256 (every problem qualifies for the 256 x 256 tile), 128 (contraction mode 4, every
+// problem on the 128 x 128 kernel's ordinary path and on the same side of its small-map switch), 0 (no grouped launch)
+static int wgrad_group_kind(const dadet_conv_desc* descs, const int n) {
+  if (n < 1 || n > kWgradGroupMax || gemm_mode() != 4) return 0;
+  bool big = true, small = true;
+  for (int i = 0; i < n; ++i) {
+    const dadet_conv_desc& d = descs[i];
+    if (conv_desc_check(&d, "conv_wgrad_group") || d.N == 0) return 0;
+    const int M = d.N * d.Ho * d.Wo, K = d.KH * d.KW * d.Cin;
+    if (K % 4 != 0 || d.Cout % 4 != 0 || M < 128) return 0;
+    if ((uint64_t)d.N * d.H * d.W * d.Cin * 4 >= 0x7FFFFF00ull || (uint64_t)M * d.Cout * 4 >= 0x7FFFFF00ull) return 0;
+    big = big && wgrad_group_member(&d);
+    small = small && (d.Wo < 32) == (descs[0].Wo < 32);
+  }
+  static const bool small_on = !(getenv("DADET_WGRAD_GROUP_128") && getenv("DADET_WGRAD_GROUP_128")[0] == '0');
+  return big ? 256 : (small && small_on ? 128 : 0);
+}
+
 extern "C" int dadet_conv_wgrad_group_plan(const dadet_conv_desc* descs, int n, int* splits_out, size_t* workspace_bytes_out) {
   DADET_REQUIRE(descs && n >= 1 && splits_out && workspace_bytes_out, "conv_wgrad_group_plan: bad arguments");
-  if (n > 4) return 0;
-  for (int i = 0; i < n; ++i) {
-    if (conv_desc_check(&descs[i], "conv_wgrad_group_plan")) return 0;
-    if (descs[i].N == 0 || !wgrad_group_member(&descs[i])) return 0;
-  }
-  int tco[4], tkc[4], rows;
-  wgrad_group_plan(n, descs, tco, tkc, splits_out, &rows);
+  const int kind = wgrad_group_kind(descs, n);
+  if (!kind) return 0;
+  int tco[kWgradGroupMax], tkc[kWgradGroupMax], rows;
+  wgrad_group_plan(n, descs, kind, tco, tkc, splits_out, &rows);
   for (int i = 0; i < n; ++i)
     workspace_bytes_out[i] = splits_out[i] > 1 ? sizeof(float) * (size_t)splits_out[i] * descs[i].Cout * descs[i].KH *
                                                       descs[i].KW * descs[i].Cin
                                                 : 0;
-  return 1;
+  return kind;
 }
 
 extern "C" int dadet_conv_wgrad_group(const dadet_conv_desc* descs, int n, const float* const* x, const float* const* gy,
@@ -1241,23 +1256,21 @@ extern "C" int dadet_conv_wgrad_group(const dadet_conv_desc* descs, int n, const
                                       void* const* workspace, const size_t* workspace_bytes,
                                       dadet_wgrad_pending* pending_out, const float* const* amax_x,
                                       const float* const* amax_gy, void* stream) {
-  DADET_REQUIRE(descs && n >= 1 && n <= 4 && x && gy && dw && accumulate && workspace && workspace_bytes && pending_out &&
-                    amax_x && amax_gy, "conv_wgrad_group: bad arguments (1 - 4 problems, every array non-null)");
+  DADET_REQUIRE(descs && n >= 1 && n <= kWgradGroupMax && x && gy && dw && accumulate && workspace && workspace_bytes &&
+                    pending_out && amax_x && amax_gy, "conv_wgrad_group: bad arguments (1 - 4 problems, every array non-null)");
   DADET_REQUIRE(gemm_mode() == 4, "conv_wgrad_group: contraction mode 4 only (mode %d is set)", gemm_mode());
   hipStream_t st = as_stream(stream);
-  int tco[4], tkc[4], splits[4], rows;
+  const int kind = wgrad_group_kind(descs, n);
+  DADET_REQUIRE(kind != 0, "conv_wgrad_group: these problems do not form a grouped launch (dadet_conv_wgrad_group_plan)");
+  int tco[kWgradGroupMax], tkc[kWgradGroupMax], splits[kWgradGroupMax], rows;
   for (int i = 0; i < n; ++i) {
-    int rc = conv_desc_check(&descs[i], "conv_wgrad_group");
-    if (rc) return rc;
-    DADET_REQUIRE(descs[i].N > 0 && wgrad_group_member(&descs[i]),
-                  "conv_wgrad_group: problem %d does not qualify for the 256 x 256 kernel (dadet_conv_wgrad_group_plan)", i);
     DADET_REQUIRE(x[i] && gy[i] && dw[i] && amax_x[i] && amax_gy[i] && al16(x[i]) && al16(gy[i]) && al16(dw[i]),
                   "conv_wgrad_group: problem %d: null or misaligned pointer", i);
     for (int j = 0; j < i; ++j)
       DADET_REQUIRE(dw[i] != dw[j], "conv_wgrad_group: problems %d and %d write the same dw", j, i);
   }
-  wgrad_group_plan(n, descs, tco, tkc, splits, &rows);
-  WgradArgs a[4];
+  wgrad_group_plan(n, descs, kind, tco, tkc, splits, &rows);
+  WgradArgs a[kWgradGroupMax];
   for (int i = 0; i < n; ++i) {
     const dadet_conv_desc* d = &descs[i];
     WgradArgs& w = a[i];
@@ -1287,7 +1300,7 @@ extern "C" int dadet_conv_wgrad_group(const dadet_conv_desc* descs, int n, const
       w.out = static_cast<float*>(workspace[i]);
     }
   }
-  int rc = launch_wgrad_big_group(a, n, st);
+  int rc = kind == 256 ? launch_wgrad_big_group(a, n, st) : launch_wgrad_split_group(a, n, st);
   if (rc) return rc;
   for (int i = 0; i < n; ++i) {
     if (splits[i] <= 1) continue;

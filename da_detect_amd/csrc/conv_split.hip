@@ -656,8 +656,10 @@ int launch_fwd_split(ConvArgs& a, int variant, int fmt, hipStream_t st) {
 // and writes for each channel the four m-values as one 8-byte ds_write into a [channel][m] plane
 // ([128][32 + 8 pad] bf16 per term).  Lane -> (m-group = t % 8, channel-quad = t / 8) keeps the global loads as
 // 128-byte row segments and the LDS writes bank-conflict free.
+// (`bid` / `split`: tile index and part of the reduction inside the workgroup's OWN problem — blockIdx.x / blockIdx.y, or
+// derived from the index inside the problem in a grouped launch)
 template <int FMT, bool SMALL_MAP>
-__global__ __launch_bounds__(256, 2) void conv_wgrad_split_kernel(const WgradArgs a) {
+__device__ __forceinline__ void wgrad_split_body(const WgradArgs& a, const int bid, const int split) {
   constexpr int TERMS = Fmt<FMT>::terms;
   constexpr bool F16 = Fmt<FMT>::f16;
   constexpr int TILE = 128, RK = 32;
@@ -672,10 +674,9 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_split_kernel(const WgradArg
   __bf16* Gs = reinterpret_cast<__bf16*>(smem);  // [TERMS][128 co][PLANE_STRIDE]
   __bf16* Xs = Gs + TERMS * PLANE;               // [TERMS][128 kc][PLANE_STRIDE]
 
-  const int tile = xcd_remap(blockIdx.x, a.tiles_co * a.tiles_kc);
+  const int tile = xcd_remap(bid, a.tiles_co * a.tiles_kc);
   const int co0 = (tile / a.tiles_kc) * TILE;
   const int kc0 = (tile % a.tiles_kc) * TILE;
-  const int split = blockIdx.y;
   const int m_begin = split * a.rows_per_split;
   int m_end = m_begin + a.rows_per_split;
   if (m_end > a.M) m_end = a.M;
@@ -893,6 +894,58 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_split_kernel(const WgradArg
         out[off] = v;
       }
   }
+}
+
+template <int FMT, bool SMALL_MAP>
+__global__ __launch_bounds__(256, 2) void conv_wgrad_split_kernel(const WgradArgs a) {
+  wgrad_split_body<FMT, SMALL_MAP>(a, blockIdx.x, blockIdx.y);
+}
+
+// several weight gradients in one launch (conv_common.h: WgradGroup): the 2 x 256 workgroup slots shared among the
+// problems, every part of every problem the same number of rows
+template <int FMT, bool SMALL_MAP>
+__global__ __launch_bounds__(256, 2) void conv_wgrad_split_group_kernel(const WgradGroup g) {
+  int i = 0;
+#pragma unroll
+  for (int k = 1; k < kWgradGroupMax; ++k)
+    if (k < g.n && (int)blockIdx.x >= g.first[k]) i = k;
+  i = __builtin_amdgcn_readfirstlane(i);
+  const int local = (int)blockIdx.x - g.first[i];
+  const int T = g.a[i].tiles_co * g.a[i].tiles_kc;
+  const int split = local / T;
+  wgrad_split_body<FMT, SMALL_MAP>(g.a[i], local - split * T, split);
+}
+
+template <int FMT, bool SMALL_MAP>
+static int launch_wgrad_group_terms(const WgradGroup& g, hipStream_t st) {
+  constexpr int TERMS = Fmt<FMT>::terms;
+  const size_t lds = sizeof(__bf16) * TERMS * 2 * 128 * PLANE_STRIDE;
+  static bool attr_set = false;
+  if (!attr_set && lds > 48 * 1024) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad_split_group_kernel<FMT, SMALL_MAP>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) {
+      set_error("conv_wgrad_group(split): hipFuncSetAttribute: %s", hipGetErrorString(e));
+      return DADET_ELAUNCH;
+    }
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((conv_wgrad_split_group_kernel<FMT, SMALL_MAP>), dim3(g.first[kWgradGroupMax]), dim3(256), lds, st, g);
+  return check_launch("conv_wgrad_group(split)");
+}
+
+// contraction mode 4 only; every problem on the same side of the small-map switch (the caller checks)
+int launch_wgrad_split_group(const WgradArgs* a, const int n, hipStream_t st) {
+  WgradGroup g;
+  g.n = n;
+  int at = 0;
+  for (int i = 0; i < kWgradGroupMax; ++i) {
+    g.a[i] = a[i < n ? i : n - 1];
+    g.first[i] = at;
+    if (i < n) at += a[i].tiles_co * a[i].tiles_kc * a[i].splits;
+  }
+  g.first[kWgradGroupMax] = at;
+  return a[0].Wo < 32 ? launch_wgrad_group_terms<4, true>(g, st) : launch_wgrad_group_terms<4, false>(g, st);
 }
 
 template <int FMT, bool SMALL_MAP>

@@ -255,17 +255,20 @@ int dadet_conv_wgrad_scaled(const dadet_conv_desc* d, const float* x, const floa
                             size_t workspace_bytes, dadet_wgrad_pending* pending_out, const float* amax_x,
                             const float* amax_gy, void* stream);
 
-/* The 1 - 4 weight gradients of ONE backward node in ONE launch (contraction mode 4, 256 x 256 tiles of dW): replaces
- * the per-layer ATen backward-weight calls of a bottleneck block (reference: maskrcnn_benchmark/modeling/backbone/
- * resnet.py:294-314 `Bottleneck.forward` under autograd — conv1, conv2, conv3 and the downsample branch).  The chip's
- * workgroup slots are shared among the problems (every part of every problem reduces the same number of rows), so a
- * problem parks a fraction of the partial sums its own launch would, and layers too small for a launch of their own
- * ride along.  dadet_conv_wgrad_group_plan -> 1 and, per problem, the number of parts and the workspace bytes
- * ([splits][Cout][K] floats; 0 for one part, which writes dw itself) when every problem qualifies (Cin, K, Cout
- * multiples of 4, >= 256 rows; with the default plan also Cout >= 256, K >= 256, >= 2048 rows), else 0: call
- * dadet_conv_wgrad_scaled per layer.  dadet_conv_wgrad_group: arrays of n entries; gy rows are Cout floats; pending_out[i]
- * describes problem i's reduction pass for dadet_conv_wgrad_reduce_batch (splits == 0: nothing to reduce); the dw
- * pointers must differ.  Results equal the per-layer calls' up to the order of the fp32 partial sums. */
+/* The 1 - 4 weight gradients of ONE backward node in ONE launch (contraction mode 4): replaces the per-layer ATen
+ * backward-weight calls of a bottleneck block (reference: maskrcnn_benchmark/modeling/backbone/resnet.py:294-314
+ * `Bottleneck.forward` under autograd — conv1, conv2, conv3 and the downsample branch).  The chip's workgroup slots are
+ * shared among the problems (every part of every problem reduces the same number of rows), so a problem parks a
+ * fraction of the partial sums its own launch would, its parts are several times as long, and layers too small for a
+ * launch of their own ride along.
+ * dadet_conv_wgrad_group_plan -> the tile edge of the kernel that serves the WHOLE group — 256 (every problem has Cout,
+ * K >= 256 and >= 2048 rows: conv_wgrad_big_group_kernel) or 128 (the 128 x 128 kernel's grouped form; all problems' maps
+ * at least, or all less than, 32 pixels wide) — and per problem the number of parts and the workspace bytes ([splits]
+ * [Cout][K] floats; 0 for one part, which writes dw itself); 0 when there is no grouped launch for these problems (K or
+ * Cout not a multiple of 4, fewer than 128 rows, another contraction mode, more than 4): call dadet_conv_wgrad_scaled
+ * per layer.  dadet_conv_wgrad_group: arrays of n entries; gy rows are Cout floats; pending_out[i] describes problem i's
+ * reduction pass for dadet_conv_wgrad_reduce_batch (splits == 0: nothing to reduce); the dw pointers must differ.
+ * Results equal the per-layer calls' up to the order of the fp32 partial sums. */
 int dadet_conv_wgrad_group_plan(const dadet_conv_desc* descs, int n, int* splits_out, size_t* workspace_bytes_out);
 int dadet_conv_wgrad_group(const dadet_conv_desc* descs, int n, const float* const* x, const float* const* gy,
                            const float* const* out_scale, float* const* dw, const int* accumulate,

@@ -212,9 +212,29 @@ def test_grouped_weight_gradients_against_float64(device, big_mode, group, rows,
     its own buffer with its FrozenBN scale — against float64 and against the per-layer launches (same products, another
     cut of the reduction), with the planned rows per part, the smallest (128: many parts) and one part per problem (4096:
     the kernel writes dW itself)"""
-    from da_detect_amd import _C
-
     big_mode.dadet_set_big_gemm(2)
+    _check_group(device, group, rows, monkeypatch, 256)
+
+
+NARROW_GROUPS = [
+    # a res3-like block: 1x1 up, 3x3, 1x1 down on 128 / 512 channels (and ragged ones), maps wider than 32 pixels
+    [(2, 128, 24, 40, 512, 1, 1, 0), (2, 128, 24, 40, 128, 3, 1, 1), (2, 500, 24, 40, 128, 1, 1, 0)],
+    # small maps (Wo < 32: the kernel's other row walk), a stride-2 member, four problems
+    [(4, 64, 14, 14, 256, 1, 1, 0), (4, 64, 14, 14, 64, 3, 1, 1), (4, 96, 28, 28, 64, 1, 2, 0), (4, 96, 28, 28, 256, 1, 2, 0)],
+]
+
+
+@pytest.mark.parametrize("rows", [0, 128, 4096])
+@pytest.mark.parametrize("group", NARROW_GROUPS, ids=lambda g: "%dproblems_%d" % (len(g), g[0][1]))
+def test_grouped_weight_gradients_of_narrow_layers_against_float64(device, big_mode, group, rows, monkeypatch):
+    """the same for layers of fewer than 256 channels (res2 / res3): the grouped form of the 128 x 128 kernel"""
+    big_mode.dadet_set_big_gemm(1)
+    _check_group(device, group, rows, monkeypatch, 128)
+
+
+def _check_group(device, group, rows, monkeypatch, kind):
+    from da_detect_amd import _C, _lib
+
     if rows:
         monkeypatch.setenv("DADET_WGRAD_GROUP_ROWS", str(rows))
     g = torch.Generator().manual_seed(11 + len(group))
@@ -238,6 +258,13 @@ def test_grouped_weight_gradients_against_float64(device, big_mode, group, rows,
             r["dw"] = prev.clone()
         batch = _C.WgradBatch()
         assert _C.conv_wgrad_group(reqs, batch)
+        if rep == 0:
+            n = len(reqs)
+            descs = (_lib.ConvDesc * n)(*[
+                _C._desc(r["x"].shape[0], r["x"].shape[2], r["x"].shape[3], r["x"].shape[1], r["weight_shape"][0],
+                         r["weight_shape"][2], r["weight_shape"][3], r["stride"], r["pad"], r["gy"].shape[2], r["gy"].shape[3])
+                for r in reqs])
+            assert _lib.load().dadet_conv_wgrad_group_plan(descs, n, (ctypes.c_int * n)(), (ctypes.c_size_t * n)()) == kind
         if rows == 4096:
             assert not batch          # one part per problem: nothing left to reduce
         _C.conv_wgrad_reduce_batch(batch)
@@ -250,18 +277,20 @@ def test_grouped_weight_gradients_against_float64(device, big_mode, group, rows,
 
 
 def test_grouped_weight_gradients_refuse_what_the_kernel_does_not_cover(device, big_mode):
-    """a member with gy rows padded beyond Cout, more than four problems, or another contraction mode: conv_wgrad_group
-    returns False and launches nothing"""
+    """a member with gy rows padded beyond Cout (the offset branch of a deformable block: 18 channels in rows of 20), more
+    than four problems, or another contraction mode: conv_wgrad_group returns False and launches nothing"""
     from da_detect_amd import _C
 
-    big_mode.dadet_set_big_gemm(1)      # the default plan: layers below 256 channels do not qualify
+    big_mode.dadet_set_big_gemm(1)
     x = torch.randn((1, 64, 16, 16), device=device).contiguous(memory_format=CL)
+    gy20 = torch.randn((1, 20, 16, 16), device=device).contiguous(memory_format=CL)
+    dw18 = torch.zeros((18, 64, 1, 1), device=device).contiguous(memory_format=CL)
+    batch = _C.WgradBatch()
+    assert not _C.conv_wgrad_group([dict(x=x, gy=gy20, weight_shape=(18, 64, 1, 1), dw=dw18, accumulate=True)], batch)
+    assert not batch and float(dw18.abs().max()) == 0.0
     gy = torch.randn((1, 64, 16, 16), device=device).contiguous(memory_format=CL)
     dw = torch.zeros((64, 64, 1, 1), device=device).contiguous(memory_format=CL)
     req = dict(x=x, gy=gy, weight_shape=(64, 64, 1, 1), dw=dw, accumulate=True)
-    batch = _C.WgradBatch()
-    assert not _C.conv_wgrad_group([req], batch) and not batch and float(dw.abs().max()) == 0.0
-    big_mode.dadet_set_big_gemm(2)
     assert not _C.conv_wgrad_group([dict(req, dw=dw.clone()) for _ in range(5)], batch)
     mode = _C.get_gemm_mode()
     try:
@@ -269,6 +298,11 @@ def test_grouped_weight_gradients_refuse_what_the_kernel_does_not_cover(device, 
         assert not _C.conv_wgrad_group([req], batch)
     finally:
         _C.set_gemm_mode(mode)
+    assert not batch and float(dw.abs().max()) == 0.0
+    assert _C.conv_wgrad_group([req], batch)            # ... and as it is, it is a group of one on the 128 x 128 kernel
+    _C.conv_wgrad_reduce_batch(batch)
+    ref = torch.nn.grad.conv2d_weight(x.double(), (64, 64, 1, 1), gy.double())
+    assert float((dw.double() - ref).abs().max()) <= 2e-5 * float(ref.abs().max())
 
 
 @pytest.mark.parametrize("big", [0, 2])

@@ -280,13 +280,20 @@ def test_weight_gradient_split_plan_respects_the_workgroup_slots():
             descs[i] = _C._desc(N, H, W, Cin, Cout, k, k, stride, pad, (H + 2 * pad - k) // stride + 1,
                                 (W + 2 * pad - k) // stride + 1)
         sp, nb = (ctypes.c_int * 3)(), (ctypes.c_size_t * 3)()
-        assert lib.dadet_conv_wgrad_group_plan(descs, 3, sp, nb) == 1
+        assert lib.dadet_conv_wgrad_group_plan(descs, 3, sp, nb) == 256
         tiles = [-(-d.Cout // 256) * -(-(d.Cin * d.KH * d.KW) // 256) for d in descs]
         assert tiles == [4, 9, 4] and len(set(sp)) == 1 and sum(t * s for t, s in zip(tiles, sp)) <= 256
         assert sum(t * (s + 1) for t, s in zip(tiles, sp)) > 256 - 17 * 2      # ... and no fewer parts than fit
         assert all(b == 4 * s * d.Cout * d.Cin * d.KH * d.KW for b, s, d in zip(nb, sp, descs))
-        narrow = (_lib.ConvDesc * 1)(_C._desc(2, 128, 256, 128, 128, 3, 3, 1, 1, 128, 256))
-        assert lib.dadet_conv_wgrad_group_plan(narrow, 1, sp, nb) == 0       # 128 channels: not this kernel's
+        # a res3 block (128 / 512 channels): the 128 x 128 kernel's grouped form, two workgroups per CU
+        group = [(2, 128, 256, 128, 512, 1, 1), (2, 128, 256, 128, 128, 3, 1), (2, 128, 256, 512, 128, 1, 1)]
+        for i, (N, H, W, Cin, Cout, k, stride) in enumerate(group):
+            descs[i] = _C._desc(N, H, W, Cin, Cout, k, k, stride, k // 2, H, W)
+        assert lib.dadet_conv_wgrad_group_plan(descs, 3, sp, nb) == 128
+        tiles = [-(-d.Cout // 128) * -(-(d.Cin * d.KH * d.KW) // 128) for d in descs]
+        assert tiles == [4, 9, 4] and len(set(sp)) == 1 and 512 - 34 < sum(t * s for t, s in zip(tiles, sp)) <= 512
+        odd = (_lib.ConvDesc * 1)(_C._desc(2, 128, 256, 128, 18, 3, 3, 1, 1, 128, 256))
+        assert lib.dadet_conv_wgrad_group_plan(odd, 1, sp, nb) == 0          # 18 output channels: rows padded beyond Cout
     finally:
         lib.dadet_set_big_gemm(plan)
 
