@@ -132,8 +132,8 @@ DOMINANT_FAMILY = "conv_big_kernel<256>"
 F16_STREAM_ON_SPLIT_OPERANDS_TFLOPS = 1625.0
 # kernel families of the mode-4 step for `roofline.families` (name fragments of the profiler's labels)
 FAMILIES = [("fwd_dgrad_256x256", ("conv_big_kernel<256>",)), ("fwd_dgrad_256x128", ("conv_big128_kernel",)),
-            ("wgrad_256x256", ("conv_wgrad_big_kernel",)), ("fwd_dgrad_128x128", ("conv_fwd_split_kernel", "conv_fwd_split_sk_kernel")),
-            ("wgrad_128x128", ("conv_wgrad_split_kernel",)), ("weight_stationary_1x1", ("conv1x1_ws_kernel",))]
+            ("wgrad_256x256", ("conv_wgrad_big_kernel", "conv_wgrad_big_group_kernel")), ("fwd_dgrad_128x128", ("conv_fwd_split_kernel", "conv_fwd_split_sk_kernel")),
+            ("wgrad_128x128", ("conv_wgrad_split_kernel", "conv_wgrad_split_group_kernel")), ("weight_stationary_1x1", ("conv1x1_ws_kernel",))]
 
 
 def pmc_traffic(kernel_name, gemm_mode):

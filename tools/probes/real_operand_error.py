@@ -50,12 +50,21 @@ def capture(workload, hw, steps):
             wg.append((x.detach().clone(), gy.detach().clone(), tuple(weight_shape), stride, pad))
         return orig_w(x, gy, weight_shape, stride, pad, out_scale, dw, accumulate, pending)
 
-    _C.conv_forward, _C.conv_wgrad = conv_forward, conv_wgrad
+    orig_g = _C.conv_wgrad_group
+
+    def conv_wgrad_group(requests, pending):      # a block's weight gradients in one launch: the same operands, per layer
+        for r in requests:
+            if r["gy"].shape[1] == r["weight_shape"][0]:
+                wg.append((r["x"].detach().clone(), r["gy"].detach().clone(), tuple(r["weight_shape"]), r.get("stride", 1),
+                           r.get("pad", 0)))
+        return orig_g(requests, pending)
+
+    _C.conv_forward, _C.conv_wgrad, _C.conv_wgrad_group = conv_forward, conv_wgrad, conv_wgrad_group
     try:
         train_step(model, opt, images, targets)
         torch.cuda.synchronize()
     finally:
-        _C.conv_forward, _C.conv_wgrad = orig_f, orig_w
+        _C.conv_forward, _C.conv_wgrad, _C.conv_wgrad_group = orig_f, orig_w, orig_g
     return fwd, wg
 
 
