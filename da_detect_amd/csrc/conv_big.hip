@@ -1203,6 +1203,7 @@ int launch_wgrad_big_group(const WgradArgs* a, const int n, hipStream_t st) {
     if (i < n) at += a[i].tiles_co * a[i].tiles_kc * a[i].splits;
   }
   g.first[kWgradGroupMax] = at;
+  g.by_rows = 1;
   hipLaunchKernelGGL(conv_wgrad_big_group_kernel, dim3(at), dim3(512), kWgradBigLds, st, g);
   return check_launch("conv_wgrad_group");
 }

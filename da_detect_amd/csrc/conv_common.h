@@ -254,6 +254,7 @@ struct WgradGroup {
   WgradArgs a[kWgradGroupMax];
   int first[kWgradGroupMax + 1];
   int n;
+  int by_rows;      // 128 x 128 form: workgroups of one XCD take neighbouring tiles of the same rows
 };
 
 // tile variant chosen for a forward / dgrad GEMM of M rows and Cout columns

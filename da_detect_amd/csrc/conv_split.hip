@@ -659,7 +659,8 @@ int launch_fwd_split(ConvArgs& a, int variant, int fmt, hipStream_t st) {
 // (`bid` / `split`: tile index and part of the reduction inside the workgroup's OWN problem — blockIdx.x / blockIdx.y, or
 // derived from the index inside the problem in a grouped launch)
 template <int FMT, bool SMALL_MAP>
-__device__ __forceinline__ void wgrad_split_body(const WgradArgs& a, const int bid, const int split) {
+__device__ __forceinline__ void wgrad_split_body(const WgradArgs& a, const int bid, const int split,
+                                                 const bool tile_is_bid = false) {
   constexpr int TERMS = Fmt<FMT>::terms;
   constexpr bool F16 = Fmt<FMT>::f16;
   constexpr int TILE = 128, RK = 32;
@@ -674,7 +675,7 @@ __device__ __forceinline__ void wgrad_split_body(const WgradArgs& a, const int b
   __bf16* Gs = reinterpret_cast<__bf16*>(smem);  // [TERMS][128 co][PLANE_STRIDE]
   __bf16* Xs = Gs + TERMS * PLANE;               // [TERMS][128 kc][PLANE_STRIDE]
 
-  const int tile = xcd_remap(bid, a.tiles_co * a.tiles_kc);
+  const int tile = tile_is_bid ? bid : xcd_remap(bid, a.tiles_co * a.tiles_kc);
   const int co0 = (tile / a.tiles_kc) * TILE;
   const int kc0 = (tile % a.tiles_kc) * TILE;
   const int m_begin = split * a.rows_per_split;
@@ -911,9 +912,12 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_split_group_kernel(const Wg
     if (k < g.n && (int)blockIdx.x >= g.first[k]) i = k;
   i = __builtin_amdgcn_readfirstlane(i);
   const int local = (int)blockIdx.x - g.first[i];
+  // one XCD: a contiguous range of (part, tile) pairs — the tiles of a part read the same operand rows (conv_wgrad_big_kernel's
+  // order); the body's own remap of the tile index is then the identity's job
   const int T = g.a[i].tiles_co * g.a[i].tiles_kc;
-  const int split = local / T;
-  wgrad_split_body<FMT, SMALL_MAP>(g.a[i], local - split * T, split);
+  const int lid = g.by_rows ? xcd_remap(local, T * g.a[i].splits) : local;
+  const int split = lid / T;
+  wgrad_split_body<FMT, SMALL_MAP>(g.a[i], lid - split * T, split, g.by_rows != 0);
 }
 
 template <int FMT, bool SMALL_MAP>
@@ -945,6 +949,8 @@ int launch_wgrad_split_group(const WgradArgs* a, const int n, hipStream_t st) {
     if (i < n) at += a[i].tiles_co * a[i].tiles_kc * a[i].splits;
   }
   g.first[kWgradGroupMax] = at;
+  static const int by_rows = !(getenv("DADET_WGRAD_GROUP_BY_ROWS") && getenv("DADET_WGRAD_GROUP_BY_ROWS")[0] == '0');
+  g.by_rows = by_rows;
   return a[0].Wo < 32 ? launch_wgrad_group_terms<4, true>(g, st) : launch_wgrad_group_terms<4, false>(g, st);
 }
 
