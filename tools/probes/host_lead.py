@@ -79,7 +79,8 @@ def main():
     wrap(box.loss_evaluator, "subsample_for_da", "  DA ROI draw")
     wrap(box.feature_extractor.pooler, "forward", "    pooler")
     wrap(box.feature_extractor.pooler, "convert_to_roi_format", "      roi format")
-    wrap(box.feature_extractor.head, "forward", "    res5 head")
+    if hasattr(box.feature_extractor, "head"):
+        wrap(box.feature_extractor.head, "forward", "    res5 head")
     if net.da_heads:
         wrap(net.da_heads, "forward", "da_heads")
     wrap(opt, "step", "optimizer.step")
