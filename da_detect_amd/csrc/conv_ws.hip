@@ -42,7 +42,9 @@ __device__ __forceinline__ void ws_unroll(F&& f) {
 
 // FMT 3: three bf16 term planes, six MFMAs per k16 step; FMT 4: two fp16 term planes under the per-tensor scales, three
 // MFMAs (conv_common.h) — the panel is a third smaller, an activation element costs 3 VALU operations instead of ~4.8
-template <int K, int BN, int FMT>
+// EROWS: rows of a wave's private epilogue slice — 32 (a whole 32 x 32 accumulator block at a time) or 16 (two halves: the
+// K = 256 / BN = 128 form, whose 132 KB of weight planes leave 20 KB for the eight slices)
+template <int K, int BN, int FMT, int EROWS = 32>
 __global__ __launch_bounds__(512, 1) void conv1x1_ws_kernel(const ConvArgs a) {
   constexpr int T = Fmt<FMT>::terms;
   constexpr bool F16 = Fmt<FMT>::f16;
@@ -63,8 +65,8 @@ __global__ __launch_bounds__(512, 1) void conv1x1_ws_kernel(const ConvArgs a) {
   __bf16* Bs = reinterpret_cast<__bf16*>(smem);                      // [T][BN][STRIDE]
   const int t = threadIdx.x;
   const int lane = t & 63, wave = t >> 6;
-  float* tile = reinterpret_cast<float*>(smem + T * PLANE * 2) + wave * (32 * EPI_STRIDE);
-  float* s_affine = reinterpret_cast<float*>(smem + T * PLANE * 2) + 8 * (32 * EPI_STRIDE);   // [BN] scale, [BN] bias
+  float* tile = reinterpret_cast<float*>(smem + T * PLANE * 2) + wave * (EROWS * EPI_STRIDE);
+  float* s_affine = reinterpret_cast<float*>(smem + T * PLANE * 2) + 8 * (EROWS * EPI_STRIDE);   // [BN] scale, [BN] bias
   int ea = 0, eb = 0;                       // FMT 4: exponents of the operands' power-of-two scales
   if (F16) {
     ea = a.amax_x ? fmt4_exp(amax_read(a.amax_x)) : 0;
@@ -258,16 +260,20 @@ __global__ __launch_bounds__(512, 1) void conv1x1_ws_kernel(const ConvArgs a) {
     for (int e = 0; e < EPB; ++e) {
       const float4 sc = *reinterpret_cast<const float4*>(s_affine + (nb0 + e) * 32 + c4);
       const float4 bi = *reinterpret_cast<const float4*>(s_affine + BN + (nb0 + e) * 32 + c4);
+      constexpr int GH = EROWS / 8;                      // 8-row groups per trip through the slice
 #pragma unroll
-      for (int g = 0; g < 4; ++g)
+      for (int hh = 0; hh < 4 / GH; ++hh) {
+#pragma unroll
+      for (int g = hh * GH; g < (hh + 1) * GH; ++g)
 #pragma unroll
         for (int q = 0; q < 4; ++q)
-          tile[(q + 8 * g + row_hi) * EPI_STRIDE + col_in] = F16 ? acc[nb0 + e][g * 4 + q] * u1 * u2 : acc[nb0 + e][g * 4 + q];
+          tile[(q + 8 * (g - hh * GH) + row_hi) * EPI_STRIDE + col_in] =
+              F16 ? acc[nb0 + e][g * 4 + q] * u1 * u2 : acc[nb0 + e][g * 4 + q];
       __builtin_amdgcn_s_waitcnt(0xc07f);                // lgkmcnt(0): a wave's own LDS traffic is ordered
       __builtin_amdgcn_wave_barrier();
 #pragma unroll
-      for (int pass = 0; pass < 4; ++pass) {
-        const float4 v4 = *reinterpret_cast<const float4*>(tile + (pass * 8 + rrow) * EPI_STRIDE + c4);
+      for (int pass = hh * GH; pass < (hh + 1) * GH; ++pass) {
+        const float4 v4 = *reinterpret_cast<const float4*>(tile + ((pass - hh * GH) * 8 + rrow) * EPI_STRIDE + c4);
         float v[4] = {v4.x, v4.y, v4.z, v4.w};
         const float s4[4] = {sc.x, sc.y, sc.z, sc.w}, b4[4] = {bi.x, bi.y, bi.z, bi.w};
         float adv[4] = {0.f, 0.f, 0.f, 0.f}, mkv[4] = {1.f, 1.f, 1.f, 1.f};
@@ -294,7 +300,8 @@ __global__ __launch_bounds__(512, 1) void conv1x1_ws_kernel(const ConvArgs a) {
         if (F16 && a.amax_y && offs[e][pass] != kOOB)
           mx = fmaxf(fmaxf(mx, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
       }
-      __builtin_amdgcn_wave_barrier();                   // the slice is rewritten by the next block
+      __builtin_amdgcn_wave_barrier();                   // the slice is rewritten by the next half / block
+      }
     }
   };
   auto epilogue = [&](int tile_idx) __attribute__((always_inline)) {
@@ -358,12 +365,12 @@ bool ws_eligible(const ConvArgs& a) {
   return true;
 }
 
-template <int K, int BN, int FMT>
+template <int K, int BN, int FMT, int EROWS = 32>
 static int launch_ws(ConvArgs& a, hipStream_t st) {
-  const size_t lds = (size_t)Fmt<FMT>::terms * BN * (K + 8) * 2 + 8 * 32 * EPI_STRIDE * 4 + 2 * BN * 4;
+  const size_t lds = (size_t)Fmt<FMT>::terms * BN * (K + 8) * 2 + 8 * EROWS * EPI_STRIDE * 4 + 2 * BN * 4;
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv1x1_ws_kernel<K, BN, FMT>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv1x1_ws_kernel<K, BN, FMT, EROWS>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) {
       set_error("conv_forward(weight-stationary 1x1): hipFuncSetAttribute: %s", hipGetErrorString(e));
@@ -378,7 +385,7 @@ static int launch_ws(ConvArgs& a, hipStream_t st) {
   if (G < 8) G = 8;
   const int need = ceil_div(a.tiles_m, 8) * 8;
   if (G > need) G = need;
-  hipLaunchKernelGGL((conv1x1_ws_kernel<K, BN, FMT>), dim3(a.tiles_n * G), dim3(512), lds, st, a);
+  hipLaunchKernelGGL((conv1x1_ws_kernel<K, BN, FMT, EROWS>), dim3(a.tiles_n * G), dim3(512), lds, st, a);
   return check_launch("conv_forward(weight-stationary 1x1)");
 }
 
@@ -387,7 +394,15 @@ int launch_fwd_ws(ConvArgs& a, int fmt, hipStream_t st) {
     switch (a.K) {
       case 64: return launch_ws<64, 128, 4>(a, st);
       case 128: return launch_ws<128, 128, 4>(a, st);
-      default: return launch_ws<256, 64, 4>(a, st);
+      default: {
+        // K = 256: 128-column panels where the layer has at least 256 columns (res4 conv3 and its mirror, 1024 columns:
+        // a workgroup then stores 512 contiguous bytes per row instead of 256, and the activations are read by 8 panels
+        // instead of 16) — the weight planes take 132 KB, the epilogue slices are halved to fit.  DADET_WS_K256_BN=64: off
+        const char* e = getenv("DADET_WS_K256_BN");      // read per call (A/B runs, tests)
+        const bool wide = !(e && atoi(e) == 64);
+        if (wide && a.Cout >= 256) return launch_ws<256, 128, 4, 16>(a, st);
+        return launch_ws<256, 64, 4>(a, st);
+      }
     }
   }
   switch (a.K) {

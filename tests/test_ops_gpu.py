@@ -1338,13 +1338,14 @@ def test_roi_align_backward_skips_images_without_rois(device):
 
 @pytest.mark.parametrize("case", [
     # N, Cin(K), H, W, Cout, stride, epilogue
-    (2, 256, 64, 128, 1024, 1, "add_relu"),     # res4 conv3 forward (BASELINE size): K = 256, BN = 64
+    (2, 256, 64, 128, 1024, 1, "add_relu"),     # res4 conv3 forward (BASELINE size): K = 256, BN = 128 (halved epilogue slices)
     (2, 256, 64, 128, 1024, 1, "add_gate"),     # res4 conv1 data gradient: residual gradient + ReLU gate
     (2, 128, 128, 256, 512, 1, "add_relu"),     # res3 conv3: K = 128, BN = 128
     (2, 64, 256, 256, 256, 1, "add_relu"),      # res2 conv3: K = 64 (two slabs per loop iteration)
     (2, 64, 200, 164, 256, 1, "plain"),         # M = 65600: ragged last slab, odd slab count per workgroup
     (1, 256, 259, 262, 160, 2, "affine"),       # stride 2 (projection shortcut), Cout not a multiple of the panel
     (3, 128, 96, 100, 384, 1, "gate"),          # M = 28800, three panels
+    (2, 256, 90, 100, 288, 1, "add_gate"),      # K = 256 with 128-column panels (Cout >= 256), ragged third panel, M = 18000
 ])
 def test_weight_stationary_1x1_kernel(device, case):
     """conv1x1_ws_kernel (csrc/conv_ws.hip) against a float64 contraction and against the tiled split kernel it replaces
