@@ -1012,6 +1012,16 @@ def deform_sample_backward_om(x, om, gcols, kh, kw, stride, pad, dil, dg, modula
     nbytes = ctypes.c_size_t(0)
     _lib.call("dadet_deform_sample_backward_workspace_bytes", N, H, W, dg, ctypes.byref(nbytes))
     ws = _workspace(nbytes.value, x.device)
+    if _mode4():
+        # gom is an operand of the offset conv's weight-gradient GEMM: the pass that stores it leaves its largest magnitude
+        # (one dadet_amax pass + its launch gap less per deformable block: 30 per step of R-101-FPN-DCN)
+        slot = _amax.new_slot(x.device)
+        _lib.call("dadet_deform_sample_backward_ld_m", _p(x), _p(om), ld, _off_ptr(om, 2 * T * dg) if modulated else None,
+                  ld, 1, _p(gcols), _p(gx), _p(gom), ld, _off_ptr(gom, 2 * T * dg) if modulated else None, ld,
+                  N, H, W, C, kh, kw, stride, pad, dil, dg, Ho, Wo, _p(ws), ctypes.c_size_t(ws.numel()),
+                  ctypes.c_void_p(slot[0]), ctypes.c_longlong(gom.numel()), _stream())
+        _amax.attach(gom, slot)
+        return gx, gom
     _lib.call("dadet_deform_sample_backward_ld", _p(x), _p(om), ld, _off_ptr(om, 2 * T * dg) if modulated else None, ld,
               1, _p(gcols), _p(gx), _p(gom), ld, _off_ptr(gom, 2 * T * dg) if modulated else None, ld,
               N, H, W, C, kh, kw, stride, pad, dil, dg, Ho, Wo, _p(ws), ctypes.c_size_t(ws.numel()), _stream())

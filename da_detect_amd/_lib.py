@@ -114,6 +114,8 @@ _SIGNATURES = {
     "dadet_deform_sample_forward_ld": [_P, _P, c_int, _P, c_int, c_int, _P] + [c_int] * 12 + [_P],
     "dadet_deform_sample_backward_ld": [_P, _P, c_int, _P, c_int, c_int, _P, _P, _P, c_int, _P, c_int] + [c_int] * 12
                                        + [_P, c_size_t, _P],
+    "dadet_deform_sample_backward_ld_m": [_P, _P, c_int, _P, c_int, c_int, _P, _P, _P, c_int, _P, c_int] + [c_int] * 12
+                                         + [_P, c_size_t, _P, ctypes.c_longlong, _P],
     "dadet_deform_sample_backward_workspace_bytes": [c_int, c_int, c_int, c_int, POINTER(c_size_t)],
     "dadet_image_resample_h": [_P, c_int, c_int, _P, _P, c_int, c_int, _P, _P],
     "dadet_image_resample_v_normalize": [_P, c_int, c_int, _P, _P, c_int, c_int, c_int, c_int, POINTER(c_float),

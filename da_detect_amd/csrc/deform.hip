@@ -353,14 +353,17 @@ __global__ __launch_bounds__(256) void deform_sample_bwd_coord_kernel(const floa
                                                                       float* __restrict__ gx,
                                                                       float* __restrict__ goffset,
                                                                       float* __restrict__ gmask, int* __restrict__ counts,
-                                                                      ListEntry* __restrict__ entries, DeformGeom g) {
+                                                                      ListEntry* __restrict__ entries, DeformGeom g,
+                                                                      unsigned* __restrict__ amax_g) {
   const int lane = threadIdx.x & 63;
   const int sub = lane >> 4, l16 = lane & 15;           // pixel of the wavefront's group of four, channel quad
   const int T = g.KH * g.KW;
   const int cpg = g.C / g.dg;
   const int64_t grp4 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   const int wo4 = (g.Wo + 3) / 4;
-  if (grp4 >= (int64_t)g.N * g.Ho * wo4) return;
+  float amx = 0.f;      // max|.| of the offset / modulation gradients this lane stores (amax_g: the offset conv's weight
+                        // gradient reads them as a GEMM operand of contraction mode 4)
+  if (grp4 < (int64_t)g.N * g.Ho * wo4) {
   const int n = (int)(grp4 / ((int64_t)g.Ho * wo4));
   const int ho = (int)((grp4 / wo4) % g.Ho);
   const int wo = (int)(grp4 % wo4) * 4 + sub;
@@ -472,11 +475,17 @@ __global__ __launch_bounds__(256) void deform_sample_bwd_coord_kernel(const floa
         if (l16 == 0 && live && tap < T) {     // the only writer of these addresses
           goff_m[grp * 2 * T + 2 * tap] = d_h[u];
           goff_m[grp * 2 * T + 2 * tap + 1] = d_w[u];
-          if (gmsk_m) gmsk_m[grp * T + tap] = d_m[u];
+          amx = fmaxf(amx, fmaxf(fabsf(d_h[u]), fabsf(d_w[u])));
+          if (gmsk_m) {
+            gmsk_m[grp * T + tap] = d_m[u];
+            amx = fmaxf(amx, fabsf(d_m[u]));
+          }
         }
       }
     }
   }
+  }
+  if (amax_g) amax_publish(amax_g, amx);      // (every thread of the workgroup: it contains barriers)
 }
 
 // pass B: gx[cell][ch] += sum over the four lists covering the cell of weight * gcols[sample][ch]; a quarter-wavefront per
@@ -609,7 +618,8 @@ extern "C" int dadet_deform_sample_forward_ld(const float* x, const float* offse
 
 static int deform_sample_backward_impl(const float* x, const float* offset, const float* mask, const float* gcols,
                                        float* gx, float* goffset, float* gmask, DeformGeom g, void* workspace,
-                                       size_t workspace_bytes, void* stream) {
+                                       size_t workspace_bytes, void* stream, unsigned* amax_g = nullptr,
+                                       bool* amax_done = nullptr) {
   static const int ablate = getenv("DADET_DEFORM_ABLATE") ? atoi(getenv("DADET_DEFORM_ABLATE")) : 0;
   g.ablate = ablate;
   int rc = deform_check("deform_sample_backward", g.N, g.H, g.W, g.C, g.KH, g.KW, g.stride, g.pad, g.dil, g.dg, g.Ho, g.Wo);
@@ -647,7 +657,8 @@ static int deform_sample_backward_impl(const float* x, const float* offset, cons
       // pass A: offset / modulation gradients + the per-cell lists, one wavefront per 4 pixels
       const int64_t waves_a = (int64_t)g.N * g.Ho * ((g.Wo + 3) / 4);
       hipLaunchKernelGGL(deform_sample_bwd_coord_kernel, dim3((unsigned)ceil_div64(waves_a, 4)), dim3(256), 0,
-                         as_stream(stream), x, offset, mask, gcols, gx, goffset, gmask, counts, entries, g);
+                         as_stream(stream), x, offset, mask, gcols, gx, goffset, gmask, counts, entries, g, amax_g);
+      if (amax_done) *amax_done = amax_g != nullptr;
       if (gx) {   // pass B: the input gradient, gathered per cell (behind pass A in stream order)
         const int64_t quarters = (int64_t)g.N * g.H * g.W * (g.C / kDChunk);
         hipLaunchKernelGGL(deform_gx_gather_kernel, dim3((unsigned)ceil_div64(quarters, 16)), dim3(256), 0,
@@ -691,6 +702,26 @@ extern "C" int dadet_deform_sample_backward_ld(const float* x, const float* offs
   DeformGeom g{N, H, W, C, KH, KW, stride, pad, dil, deformable_groups, Ho, Wo, offset_ld, mask_ld, goffset_ld, gmask_ld,
                mask_is_logit};
   return deform_sample_backward_impl(x, offset, mask, gcols, gx, goffset, gmask, g, workspace, workspace_bytes, stream);
+}
+
+// The same with the largest magnitude of the offset-conv output gradient left in `amax_gom` (a zero-initialised slot of
+// dadet_amax's layout): goffset and gmask are two column ranges of ONE [N*Ho*Wo][goffset_ld] tensor whose other columns the
+// caller zero-filled (gom of DFConv2d's offset branch), `gom_floats` its size.  The gather form's first pass leaves the
+// maximum as it stores the gradients; the other forms are followed by one dadet_amax pass over the tensor.
+extern "C" int dadet_deform_sample_backward_ld_m(const float* x, const float* offset, int offset_ld, const float* mask,
+                                                 int mask_ld, int mask_is_logit, const float* gcols, float* gx,
+                                                 float* goffset, int goffset_ld, float* gmask, int gmask_ld, int N, int H,
+                                                 int W, int C, int KH, int KW, int stride, int pad, int dil,
+                                                 int deformable_groups, int Ho, int Wo, void* workspace,
+                                                 size_t workspace_bytes, float* amax_gom, long long gom_floats,
+                                                 void* stream) {
+  DeformGeom g{N, H, W, C, KH, KW, stride, pad, dil, deformable_groups, Ho, Wo, offset_ld, mask_ld, goffset_ld, gmask_ld,
+               mask_is_logit};
+  bool done = false;
+  const int rc = deform_sample_backward_impl(x, offset, mask, gcols, gx, goffset, gmask, g, workspace, workspace_bytes,
+                                             stream, reinterpret_cast<unsigned*>(amax_gom), &done);
+  if (rc || !amax_gom || done || N == 0) return rc;
+  return dadet_amax(goffset, gom_floats, amax_gom, stream);
 }
 
 // ------------------------------------------------------------------------------------------------

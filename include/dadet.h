@@ -331,6 +331,14 @@ int dadet_deform_sample_backward_ld(const float* x, const float* offset, int off
                                     float* gmask, int gmask_ld, int N, int H, int W, int C, int KH, int KW, int stride,
                                     int pad, int dil, int deformable_groups, int Ho, int Wo, void* workspace,
                                     size_t workspace_bytes, void* stream);
+/* ... and max|gradient w.r.t. the offset conv's output| left in `amax_gom` (a zero-initialised slot in dadet_amax's
+ * layout; contraction mode 4: that gradient is an operand of the offset conv's weight-gradient GEMM).  goffset / gmask are
+ * column ranges of ONE zero-filled [N*Ho*Wo][goffset_ld] tensor of gom_floats floats starting at goffset. */
+int dadet_deform_sample_backward_ld_m(const float* x, const float* offset, int offset_ld, const float* mask, int mask_ld,
+                                      int mask_is_logit, const float* gcols, float* gx, float* goffset, int goffset_ld,
+                                      float* gmask, int gmask_ld, int N, int H, int W, int C, int KH, int KW, int stride,
+                                      int pad, int dil, int deformable_groups, int Ho, int Wo, void* workspace,
+                                      size_t workspace_bytes, float* amax_gom, long long gom_floats, void* stream);
 /* scratch for the gather form of the backward (per-cell lists of the samples whose bilinear corners land on a cell:
  * csrc/deform.hip); without it (NULL / too small) the atomic forms run */
 int dadet_deform_sample_backward_workspace_bytes(int N, int H, int W, int deformable_groups, size_t* bytes_out);

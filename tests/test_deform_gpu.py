@@ -377,3 +377,29 @@ def test_fused_dcn_bottleneck_matches_per_conv_path_and_float64_oracle(modulated
             assert err < 3e-4, "%s: gradient of %s off by %.2e" % (name, k, err)
     # and the two HIP routes against each other
     torch.testing.assert_close(res["fused"][0], res["per_conv"][0], rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("modulated", [False, True])
+def test_deform_backward_leaves_the_offset_gradients_maximum(modulated):
+    """contraction mode 4: the gradient w.r.t. the offset conv's output (gom) is an operand of that conv's weight-gradient
+    GEMM; dadet_deform_sample_backward_ld_m leaves max|gom| in the slot attached to it (the pass that stores the gradients
+    reduces their magnitudes on the way) — equal to the tensor's own maximum, padding columns zero"""
+    from da_detect_amd import _C, amax
+
+    if _C.get_gemm_mode() != 4:
+        pytest.skip("the slot exists in contraction mode 4 only")
+    dev = torch.device("cuda", 0)
+    g = torch.Generator().manual_seed(5)
+    N, C, H, W, k, dg = 2, 128, 24, 36, 3, 1
+    T = k * k
+    ld = (3 * T * dg if modulated else 2 * T * dg) + 3 & ~3
+    x = torch.randn((N, C, H, W), generator=g).to(dev).contiguous(memory_format=torch.channels_last)
+    om = (torch.randn((N, ld, H, W), generator=g) * 1.5).to(dev).contiguous(memory_format=torch.channels_last)
+    gcols = torch.randn((N, T * C, H, W), generator=g).to(dev).contiguous(memory_format=torch.channels_last)
+    gx, gom = _C.deform_sample_backward_om(x, om, gcols, k, k, 1, k // 2, 1, dg, modulated)
+    used = 3 * T * dg if modulated else 2 * T * dg
+    assert float(gom[:, used:].abs().max()) == 0.0 if used < ld else True
+    got = amax.value(gom)
+    assert got is not None and got == float(gom.abs().max()) and got > 0.0
+    assert amax.slot_of(_C._nhwc(gom)) is not None          # what the weight-gradient wrapper will find
