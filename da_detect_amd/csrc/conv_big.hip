@@ -1016,17 +1016,20 @@ static int g_big_mode = [] {
   return v >= 0 && v <= 2 ? v : 1;
 }();
 
-// Number of K ranges a tile's reduction is cut into.  Reductions of K >= 4096 (the RPN 3x3 conv, res5 3x3) are ALWAYS cut in
-// two: the hand-over (the last part reads one parked tile, ~4 us) is small against >= 144 K-tiles per tile, and the result of
-// such a layer then does not depend on how many rows the launch happens to have — the overlapped training schedule runs
-// the RPN head on the labelled images only, the plain one on all of them, and tests/test_full_size_gpu.py asks both for
-// the same sampled ROIs.  Shorter reductions are cut in two only when the grid leaves half of the CUs without a tile.
+// Number of K ranges a tile's reduction is cut into.  Reductions of K >= 8192 (the RPN 3x3 conv) are ALWAYS cut in two: the
+// hand-over (the last part reads one parked tile, ~4 us) is small against 288 K-tiles per tile, and the result of that
+// layer then does not depend on how many rows the launch happens to have — the overlapped training schedule runs the RPN
+// head on the labelled images only, the plain one on all of them, and tests/test_full_size_gpu.py asks both for the same
+// sampled ROIs.  Shorter reductions are cut in two only when the grid leaves half of the CUs without a tile.  (The bound
+// was K >= 4096 until the box head of the recipes that pool BOTH images showed what that costs: res5 3x3 on 512 ROIs is 196
+// tiles — two parts are 392 workgroups, two rounds on 256 CUs, where one part per tile is one round: `da` 17.77 -> 17.53,
+// `triplet` 21.81 -> 21.60 ms per step.  The box head sees the same rows in every schedule.)
 static int big_split_plan(const int tiles, const int nk) {
   if (const char* e = getenv("DADET_BIG_SPLITS")) {     // read per call: tests and A/B runs force the part count
     const int v = atoi(e);
     if (v >= 1 && v <= 8 && nk / v >= 1) return v;
   }
-  if (nk >= 128) return 2;
+  if (nk >= 256) return 2;
   return (tiles <= kNumCU / 2 && nk >= 16) ? 2 : 1;
 }
 
