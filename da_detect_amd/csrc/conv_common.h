@@ -206,6 +206,7 @@ struct ConvArgs {
   int tiles_m, tiles_n;
   unsigned x_bytes, w_bytes, y_bytes;  // buffer extents (< 4 GB each)
   int ablate;                          // profiling only (DADET_ABLATE): bit mask of pipeline stages to skip
+  int ws_panel0;                       // weight-stationary 1x1 kernel: first column panel of this launch (conv_ws.hip)
   int epi_v4;                          // 16-byte epilogue through an LDS transpose (conv_epilogue_v4); 0: 4-byte form
   // split-K (small grids only, conv_split.hip): blockIdx.y handles K range [y * ksplit, (y + 1) * ksplit) and writes
   // its raw partial sums to y + blockIdx.y * split_stride; 0 / 0 = the whole reduction in one workgroup

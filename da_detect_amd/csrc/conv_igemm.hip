@@ -853,6 +853,7 @@ static int conv_forward_impl(const dadet_conv_desc* d, const float* x, const flo
   {
     static const int ablate = getenv("DADET_ABLATE") ? atoi(getenv("DADET_ABLATE")) : 0;
     a.ablate = ablate;
+    a.ws_panel0 = 0;
   }
   hipStream_t st = as_stream(stream);
   {

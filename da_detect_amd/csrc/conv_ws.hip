@@ -82,7 +82,7 @@ __global__ __launch_bounds__(512, 1) void conv1x1_ws_kernel(const ConvArgs a) {
   const int G = (int)gridDim.x / panels;
   const int xcd = (int)blockIdx.x & 7, j = (int)blockIdx.x >> 3;
   const int panel = j % panels, group = (j / panels) * 8 + xcd;
-  const int n0 = panel * BN;
+  const int n0 = (a.ws_panel0 + panel) * BN;
   const int tiles = a.tiles_m;
 
   const __amdgpu_buffer_rsrc_t xr = make_rsrc(a.x, a.x_bytes);
@@ -378,14 +378,29 @@ static int launch_ws(ConvArgs& a, hipStream_t st) {
     }
     attr_set = true;
   }
-  a.tiles_n = ceil_div(a.Cout, BN);
+  const int panels_all = ceil_div(a.Cout, BN);
   a.tiles_m = ceil_div(a.M, WS_ROWS);
   // one workgroup per CU: `panels` x G with G a multiple of 8 (the XCD mapping above) and at most one slab group per slab
-  int G = (kNumCU / a.tiles_n) / 8 * 8;
-  if (G < 8) G = 8;
   const int need = ceil_div(a.tiles_m, 8) * 8;
-  if (G > need) G = need;
-  hipLaunchKernelGGL((conv1x1_ws_kernel<K, BN, FMT, EROWS>), dim3(a.tiles_n * G), dim3(512), lds, st, a);
+  auto groups = [&](const int panels) {
+    int G = (kNumCU / panels) / 8 * 8;
+    if (G < 8) G = 8;
+    return G > need ? need : G;
+  };
+  // A panel count that does not divide the chip (18 panels of the deformable blocks' data gradient, 2304 columns: 18 x 8 =
+  // 144 workgroups walk 8 slabs each) is cut into 2 or 3 launches over column ranges when that shortens the walk: launches
+  // x slabs per workgroup is the launch's length in slab times (9 panels x 24 groups: 2 x 3 instead of 8).
+  int parts = 1, best = ceil_div(a.tiles_m, groups(panels_all));
+  for (int p = 2; p <= 3 && p <= panels_all; ++p) {
+    const int cost = p * ceil_div(a.tiles_m, groups(ceil_div(panels_all, p)));
+    if (cost * 8 < best * 7) { best = cost; parts = p; }      // (at least an eighth shorter: every launch loads its panels anew)
+  }
+  const int per = ceil_div(panels_all, parts);
+  for (int p0 = 0; p0 < panels_all; p0 += per) {
+    a.ws_panel0 = p0;
+    a.tiles_n = panels_all - p0 < per ? panels_all - p0 : per;
+    hipLaunchKernelGGL((conv1x1_ws_kernel<K, BN, FMT, EROWS>), dim3(a.tiles_n * groups(a.tiles_n)), dim3(512), lds, st, a);
+  }
   return check_launch("conv_forward(weight-stationary 1x1)");
 }
 

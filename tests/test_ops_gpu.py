@@ -1346,6 +1346,8 @@ def test_roi_align_backward_skips_images_without_rois(device):
     (1, 256, 259, 262, 160, 2, "affine"),       # stride 2 (projection shortcut), Cout not a multiple of the panel
     (3, 128, 96, 100, 384, 1, "gate"),          # M = 28800, three panels
     (2, 256, 90, 100, 288, 1, "add_gate"),      # K = 256 with 128-column panels (Cout >= 256), ragged third panel, M = 18000
+    (2, 256, 64, 128, 2304, 1, "plain"),        # the DCN blocks' data gradient: 18 panels, cut into two launches of 9
+    (1, 128, 128, 128, 1184, 1, "affine"),      # 10 panels (the last ragged): 2 x 5
 ])
 def test_weight_stationary_1x1_kernel(device, case):
     """conv1x1_ws_kernel (csrc/conv_ws.hip) against a float64 contraction and against the tiled split kernel it replaces
