@@ -371,7 +371,13 @@ def conv_forward(x, w, scale=None, bias=None, addend=None, mask_ref=None, stride
             elif variant == 5:
                 kname = "conv_big128_kernel"
             elif variant == 3:
-                kname = "conv1x1_ws_kernel<%d,%d,%d>" % (Cin, 64 if Cin == 256 else 128, mode)
+                # panel width as csrc/conv_ws.hip's launch_fwd_ws picks it: K = 256 runs 128-column panels on layers of
+                # at least 256 columns (mode 4, unless DADET_WS_K256_BN=64), 64-column panels otherwise
+                bn = 128
+                if Cin == 256:
+                    wide = mode == 4 and Cout >= 256 and os.environ.get("DADET_WS_K256_BN", "") != "64"
+                    bn = 128 if wide else 64
+                kname = "conv1x1_ws_kernel<%d,%d,%d>" % (Cin, bn, mode)
             else:
                 kname = ("conv_fwd_kernel<%s>" if mode == 0 else ("conv_fwd_split_kernel<%%s,%d>" % mode)) % \
                     ("2,2", "2,1", "1,1")[variant]

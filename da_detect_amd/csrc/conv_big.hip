@@ -1048,6 +1048,11 @@ int big_variant(const ConvArgs& a) {
   // part reads 768 KB), so layers of up to 256 output channels take the 256 x 128 tile
   if (a.K < 512 || a.M < 4096 || a.Cout < 128) return 0;
   const int tm = ceil_div(a.M, 256);
+  // 129 .. 256 output channels over at least 96 row tiles (the pyramid's 256-channel 3x3 / lateral layers on P2 / P3,
+  // M = 262144 / 65536): one column of 256 x 256 tiles fills the chip without any K split, on the kernel whose loop holds
+  // the matrix pipe 84% of the time instead of 61% (round 6; DADET_BIG_N256_WIDE=0: the 256 x 128 tile as before)
+  static const bool wide256 = !(getenv("DADET_BIG_N256_WIDE") && getenv("DADET_BIG_N256_WIDE")[0] == '0');
+  if (wide256 && a.Cout > 128 && a.Cout <= 256 && tm >= 96) return 1;
   if (a.Cout <= 256) return tm * ceil_div(a.Cout, 128) >= 96 ? 2 : 0;
   return tm * ceil_div(a.Cout, 256) >= 96 ? 1 : 0;
 }
@@ -1158,7 +1163,8 @@ bool wgrad_group_member(const dadet_conv_desc* d) {
 
 // Rows per part R (a multiple of 32, the same for every problem of the group — every workgroup then runs the same number
 // of K-tiles on one tile, whatever its problem): the smallest R whose parts fit the chip's workgroup slots (256 for the
-// 256 x 256 tile, 2 x 256 for the 128 x 128 kernel), at least 128 rows (four K-tiles).  splits[i] = ceil(M_i / R).
+// 256 x 256 tile, 2 x 256 for the 128 x 128 kernel), at least 128 rows (four K-tiles), at most 4096 (+31).
+// splits[i] = ceil(M_i / R).
 // DADET_WGRAD_GROUP_ROWS forces R (tests).
 void wgrad_group_plan(const int n, const dadet_conv_desc* d, const int tile, int* tiles_co, int* tiles_kc, int* splits,
                       int* rows) {
@@ -1181,6 +1187,11 @@ void wgrad_group_plan(const int n, const dadet_conv_desc* d, const int tile, int
       for (int i = 0; i < n; ++i) wgs += tiles_co[i] * tiles_kc[i] * ceil_div(d[i].N * d[i].Ho * d[i].Wo, R);
       if (wgs <= slots) break;
     }
+    // one part is ONE fp32 accumulator chain over its rows: never more than 4096 of them (wgrad_big_plan's bound, for the
+    // same reason) — a group whose tiles alone nearly fill the slots (the res5 head on 512 ROIs: ~100 tiles x 25088 rows)
+    // then takes a second / third round of workgroups, cut into equal parts rather than 4096 + a remainder
+    const int cap = ceil_div(ceil_div(max_m, ceil_div(max_m, 4096)), 32) * 32;
+    if (R > cap) R = cap;
   }
   *rows = R;
   for (int i = 0; i < n; ++i) splits[i] = ceil_div(d[i].N * d[i].Ho * d[i].Wo, R);

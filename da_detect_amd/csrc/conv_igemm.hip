@@ -661,6 +661,12 @@ __global__ __launch_bounds__(256) void amax_batch_kernel(const dadet_amax_item* 
 
 // ---- non-finite guard: device words + a ring of recent launch records (conv_common.h: nf_check) -------------------------
 __device__ unsigned g_nf_words[2];
+__device__ unsigned g_nf_taken[2];
+// read-and-clear in one atomic step per word: a record set while the host polls is either in this poll or in the next
+__global__ void nf_take_kernel() {
+  g_nf_taken[1] = atomicExch(&g_nf_words[1], 0u);
+  g_nf_taken[0] = atomicExch(&g_nf_words[0], 0u);
+}
 namespace {
 struct NfRecord { unsigned id; char kind[24]; int M, N, K, KH; };
 constexpr int kNfRing = 8192;
@@ -1000,9 +1006,12 @@ extern "C" int dadet_nonfinite_poll(char* msg, int cap) {
   unsigned w[2] = {0, 0};
   unsigned* dev = nf_flag_ptr();
   if (!dev) { if (msg && cap > 0) msg[0] = 0; return 0; }
-  if (hipMemcpy(w, dev, sizeof(w), hipMemcpyDeviceToHost) != hipSuccess) return check_launch("nonfinite_poll") ? -1 : -1;
+  // every stream of the process first (PyTorch's side streams and the weight-gradient lane are non-blocking: the null
+  // stream does not order against them), then one exchange kernel, then its two words
+  if (hipDeviceSynchronize() != hipSuccess) return -1;
+  hipLaunchKernelGGL(nf_take_kernel, dim3(1), dim3(1), 0, 0);
+  if (hipMemcpyFromSymbol(w, HIP_SYMBOL(g_nf_taken), sizeof(w), 0, hipMemcpyDeviceToHost) != hipSuccess) return -1;
   if (w[1] == 0) { if (msg && cap > 0) msg[0] = 0; return 0; }
-  (void)hipMemset(dev, 0, sizeof(w));
   if (msg && cap > 0) {
     const unsigned id = w[0] - 1u;
     const NfRecord& r = g_nf_ring[id % kNfRing];
@@ -1067,14 +1076,16 @@ extern "C" int dadet_conv_wgrad_workspace_bytes(const dadet_conv_desc* d, size_t
   if (rc) return rc;
   DADET_REQUIRE(bytes_out, "conv_wgrad_workspace_bytes: null out");
   if (d->N == 0) { *bytes_out = 0; return DADET_OK; }
+  // The query does not know gy's row pitch, and conv_wgrad_impl leaves the 256 x 256 kernel for padded rows (gy_ld !=
+  // Cout): the answer is the LARGER of the two plans' needs, so that whichever kernel runs finds its space
   int tco, tkc, splits, rps;
-  if (wgrad_big_plan(d, &tco, &tkc, &splits, &rps)) {     // 256 x 256 tiles: dense [splits][Cout][K] partial sums
-    *bytes_out = splits > 1 ? sizeof(float) * (size_t)splits * d->Cout * d->KH * d->KW * d->Cin : 0;
-    return DADET_OK;
-  }
+  size_t big = 0;
+  if (wgrad_big_plan(d, &tco, &tkc, &splits, &rps))       // 256 x 256 tiles: dense [splits][Cout][K] partial sums
+    big = splits > 1 ? sizeof(float) * (size_t)splits * d->Cout * d->KH * d->KW * d->Cin : 0;
   wgrad_plan(d, &tco, &tkc, &splits, &rps);
   // (rounded up to whole 128 x 128 tiles)
-  *bytes_out = splits > 1 ? sizeof(float) * (size_t)splits * tco * tkc * 128 * 128 : 0;
+  const size_t small = splits > 1 ? sizeof(float) * (size_t)splits * tco * tkc * 128 * 128 : 0;
+  *bytes_out = big > small ? big : small;
   return DADET_OK;
 }
 

@@ -202,20 +202,38 @@ def _update_meters(meters, loss_dict):
     return total
 
 
-def _loss_is_nan(net, total):
+def _loss_is_nan(net, total, logger=None):
     """NaN in this step's summed loss, or — between two tests — in the parameters an earlier NaN step has since
     poisoned (SGD carries a NaN gradient into the weights for good; one small tensor is enough to see it).  Before that:
     the GEMMs' own non-finite guard (_C.check_nonfinite), which names the first launch that overflowed instead of a loss
-    hundreds of kernels later (contraction mode 4: a per-tensor scale from too small a maximum)."""
+    hundreds of kernels later (contraction mode 4: a per-tensor scale from too small a maximum).  Its FloatingPointError
+    is caught HERE and logged with the launch's name: the caller then leaves through the same orderly exit as for a NaN
+    loss (tuner closed, nothing written).  With more than one rank the verdict is all-reduced (max), so a rank whose peers
+    overflowed does not go on into a gradient collective nobody else joins: every rank calls this at the same iterations."""
+    overflow = None
     if total.is_cuda:
         from .. import _C
 
-        _C.check_nonfinite()
+        try:
+            _C.check_nonfinite()
+        except FloatingPointError as e:
+            overflow = str(e)
     bad = torch.isnan(total).any()
     probe = next((p for p in net.parameters() if p.requires_grad), None)
     if probe is not None:
         bad = bad | torch.isnan(probe.detach().sum())
-    return bool(bad)
+    bad = bool(bad) or overflow is not None
+    if overflow is not None:
+        (logger or logging.getLogger("maskrcnn_benchmark.trainer")).critical("non-finite GEMM sums: %s" % overflow)
+    if get_world_size() > 1 and torch.distributed.is_available() and torch.distributed.is_initialized():
+        on = total.device if torch.distributed.get_backend() == "nccl" else torch.device("cpu")
+        flag = torch.tensor([1.0 if bad else 0.0], device=on)
+        torch.distributed.all_reduce(flag, op=torch.distributed.ReduceOp.MAX)
+        if not bad and float(flag) > 0:
+            (logger or logging.getLogger("maskrcnn_benchmark.trainer")).critical(
+                "another rank reported a NaN loss / non-finite GEMM sums: leaving with it")
+        bad = bad or float(flag) > 0
+    return bad
 
 
 def do_train(model, data_loader, optimizer, scheduler, checkpointer, device, checkpoint_period, arguments):
@@ -320,7 +338,7 @@ def do_da_train(model, source_data_loader, positive_target_data_loader, negative
             _log_line(logger, meters, iteration, max_iter, optimizer)
         # the NaN test is a host synchronisation: it runs at the logging period and BEFORE anything is written — a
         # checkpoint of poisoned weights would also retag `last_checkpoint` (the reference tests every iteration)
-        if (iteration % 20 == 0 or at_checkpoint or iteration == max_iter - 1) and _loss_is_nan(net, total):
+        if (iteration % 20 == 0 or at_checkpoint or iteration == max_iter - 1) and _loss_is_nan(net, total, logger):
             logger.critical("Loss is NaN, exiting...")
             tuner.close()
             return

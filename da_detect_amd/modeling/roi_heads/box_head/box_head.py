@@ -1,5 +1,6 @@
 """Box head with the extra domain-adaptation ROI pass
 (reference: maskrcnn_benchmark/modeling/roi_heads/box_head/box_head.py:22-118)."""
+import logging
 import os
 
 import torch
@@ -29,6 +30,24 @@ class ROIBoxHead(torch.nn.Module):
         self.proposals_ready = None   # optional event of the compute stream: the proposals passed to forward exist
         # set by the caller for ONE call: nothing will read the instance-level features of this call (see forward)
         self.ins_features_unused = False
+        self.speculate = True
+        self.speculation = {"kept": 0, "dropped": 0}
+
+    def _note_speculation(self, kept):
+        """bookkeeping of the early-queued box head (forward): a dropped result is a whole pooler + res5 forward thrown away.
+        A configuration that rarely fills BATCH_SIZE_PER_IMAGE (a low post-NMS top-n, few proposals early in training) would
+        pay for it every step — after 16 steps with more results dropped than kept the early queue switches itself off for
+        this module and says so once (`speculation` holds the counts; DADET_ROI_SPECULATE=0 never starts it)."""
+        st = self.speculation
+        st["kept" if kept else "dropped"] += 1
+        if not kept and st["dropped"] == 1:
+            logging.getLogger("maskrcnn_benchmark.trainer").info(
+                "box head: an early-queued pooler + res5 pass was dropped (an image filled fewer than "
+                "BATCH_SIZE_PER_IMAGE rows); counting")
+        if st["kept"] + st["dropped"] >= 16 and st["dropped"] > st["kept"] and self.speculate:
+            self.speculate = False
+            logging.getLogger("maskrcnn_benchmark.trainer").warning(
+                "box head: early queue switched off (%d of %d results dropped)" % (st["dropped"], st["kept"] + st["dropped"]))
 
     def forward(self, features, proposals, targets=None):
         """-> (x, proposals | detections, losses, da_ins_feas, da_ins_labels).  Training runs two passes of
@@ -58,7 +77,7 @@ class ROIBoxHead(torch.nn.Module):
             le = self.loss_evaluator
             state = x = None
             with side_section(dev, after=after) as done, torch.no_grad():
-                if _SPECULATE and dev.type == "cuda":
+                if _SPECULATE and self.speculate and dev.type == "cuda":
                     state = le.subsample_launch(proposals, targets)
                 if state is not None:
                     done(state["buf"], state["counts"])
@@ -84,7 +103,12 @@ class ROIBoxHead(torch.nn.Module):
                     proposals = le.subsample_finish(state)      # the host waits for the counts' copy, nothing else
                     for _ in range(burn):
                         rng.next_seed(dev)
+                    # the sampled lists hold at most BATCH_SIZE_PER_IMAGE rows each: the DA sample takes them all without a
+                    # host round trip (loss.py: _subsample_for_da_fused, n <= cap) — it must, the res5 head is queued in front
+                    assert all(len(p) <= state["cap"] for p in proposals)
                     da_proposals = le.subsample_for_da(proposals, targets)
+                if state["speculative"] is not None:
+                    self._note_speculation(bool(state["exact"]))
                 if not state["exact"]:
                     x = None
         else:

@@ -171,7 +171,10 @@ int dadet_get_gemm_mode(void);
 
 /* Large-tile kernel of mode 4 (256 x 256 output tile, 8 waves, the two waves of a SIMD alternating between the matrix pipe
  * and the operand staging; csrc/conv_big.hip) for dadet_conv_forward[_scaled] (process-wide):
- *   1 (DEFAULT) = on the layers where it is expected to win (Cout >= 256, K >= 1024, M >= 4096, Cin % 32 == 0, unit output stride);
+ *   1 (DEFAULT) = on the layers where it is expected to win (csrc/conv_big.hip: big_variant — K >= 512, M >= 4096,
+ *       Cout >= 128, Cin % 32 == 0, unit output stride, at least 96 output tiles: the 256 x 128-tile variant for
+ *       Cout <= 256 — except Cout in (128, 256] with at least 96 row tiles, which fill the chip on the 256 x 256 tile —
+ *       the 256 x 256 tile above; everything else stays on the 128 x 128 / weight-stationary kernels);
  *   0 = never;  2 = wherever it is applicable (Cin % 32 == 0, Cout % 4 == 0, 16-byte aligned tensors below 2 GB) — tests.
  * Results differ from the 128 x 128 kernel's only by fp32 summation order. */
 int dadet_set_big_gemm(int mode);
@@ -179,9 +182,11 @@ int dadet_get_big_gemm(void);
 
 /* Non-finite guard of mode 4.  A per-tensor scale from a stale or too small maximum overflows fp16 inside the operand split
  * (inf, then NaN against the zeros of a ReLU'd operand).  Every GEMM checks its sums once behind the K loop and records
- * the first offending launch in two device words.  dadet_nonfinite_poll copies them to the host (a synchronising read: call
- * it at the logging period), clears them and returns the number of wavefronts that saw non-finite sums since the last
- * poll (0 = clean, < 0 = error); `msg` (may be NULL) receives a sentence naming the first launch — entry point, launch
+ * the first offending launch in two device words.  dadet_nonfinite_poll waits for EVERY stream of the device
+ * (hipDeviceSynchronize: side streams are non-blocking, the null stream does not order against them), takes the two words
+ * with one atomic exchange each (read and clear are one step: a record set meanwhile is reported by the next poll, never
+ * lost) and returns the number of wavefronts that saw non-finite sums since the last poll (0 = clean, < 0 = error) — a
+ * synchronising call, made at the logging period; `msg` (may be NULL) receives a sentence naming the first launch — entry point, launch
  * number, M / N / K — from a ring of the last 8192 launch records.  DADET_NONFINITE_GUARD=0 (environment) switches the
  * device-side check off. */
 int dadet_nonfinite_poll(char* msg, int cap);

@@ -336,3 +336,33 @@ def test_a_low_operand_maximum_is_reported_by_name_not_as_a_nan_loss(device, big
     with pytest.raises(FloatingPointError) as err:
         _C.check_nonfinite()
     assert "conv_wgrad" in str(err.value), str(err.value)
+
+
+def test_the_trainer_leaves_in_order_when_a_gemm_overflows(device, big_mode, caplog):
+    """engine.trainer._loss_is_nan: the guard's FloatingPointError is caught, logged with the launch's
+    name, and turned into the same verdict as a NaN loss — the training loop then closes its tuner and returns instead of
+    dying with a traceback; a finite loss and clean GEMMs say False"""
+    import logging
+
+    from da_detect_amd import _C, amax as _amax
+    from da_detect_amd.engine.trainer import _loss_is_nan
+
+    g = torch.Generator().manual_seed(10)
+    x = (torch.randn((1, 256, 24, 24), generator=g) * 3).to(device).contiguous(memory_format=CL)
+    w = (torch.randn((256, 256, 3, 3), generator=g) * 0.03).to(device).contiguous(memory_format=CL)
+    net = torch.nn.Linear(3, 2).to(device)
+    _C.check_nonfinite()
+    side = torch.cuda.Stream()                             # a NON-blocking side stream: the poll must still see its launch
+    _C.conv_forward(x, w, pad=1)
+    assert _loss_is_nan(net, torch.ones((), device=device)) is False
+    low = _amax.new_slot(x.device)
+    low[1].view(8, -1)[0, (low[0] - low[1].data_ptr()) // 4] = 2.0 ** -12
+    _amax.attach(x, low)
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        _C.conv_forward(x, w, pad=1)
+    with caplog.at_level(logging.CRITICAL, logger="maskrcnn_benchmark.trainer"):
+        assert _loss_is_nan(net, torch.ones((), device=device)) is True
+    assert any("conv_forward" in r.getMessage() for r in caplog.records), [r.getMessage() for r in caplog.records]
+    torch.cuda.current_stream().wait_stream(side)
+    assert _loss_is_nan(net, torch.ones((), device=device)) is False      # reported once

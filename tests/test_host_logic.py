@@ -292,6 +292,13 @@ def test_weight_gradient_split_plan_respects_the_workgroup_slots():
         assert lib.dadet_conv_wgrad_group_plan(descs, 3, sp, nb) == 128
         tiles = [-(-d.Cout // 128) * -(-(d.Cin * d.KH * d.KW) // 128) for d in descs]
         assert tiles == [4, 9, 4] and len(set(sp)) == 1 and 512 - 34 < sum(t * s for t, s in zip(tiles, sp)) <= 512
+        # the res5 head on 512 ROIs (M = 25088, ~100 tiles: the slots alone would allow two parts of 12544 rows): a part of
+        # a GROUP is one accumulator chain as well — never more than 4096 (+31) rows, in equal parts
+        group = [(512, 7, 7, 2048, 512, 1, 1), (512, 7, 7, 512, 512, 3, 1), (512, 7, 7, 512, 2048, 1, 1)]
+        for i, (N, H, W, Cin, Cout, k, stride) in enumerate(group):
+            descs[i] = _C._desc(N, H, W, Cin, Cout, k, k, stride, k // 2, H, W)
+        assert lib.dadet_conv_wgrad_group_plan(descs, 3, sp, nb) == 256
+        assert len(set(sp)) == 1 and sp[0] == 7 and -(-25088 // sp[0]) <= 4096 + 31
         odd = (_lib.ConvDesc * 1)(_C._desc(2, 128, 256, 128, 18, 3, 3, 1, 1, 128, 256))
         assert lib.dadet_conv_wgrad_group_plan(odd, 1, sp, nb) == 0          # 18 output channels: rows padded beyond Cout
     finally:

@@ -817,8 +817,22 @@ def test_box_head_queued_before_the_sampled_counts_gives_the_same_step(device, p
             cap = evaluator.fg_bg_sampler.batch_size_per_image
             assert all((len(p) == cap) == (post_nms is None) for p in evaluator._proposals)
             assert len(calls) == (1 if post_nms is None else 2)      # a dropped result is pooled again from the exact lists
+            # ... and counted: a configuration that keeps dropping switches the early queue off by itself
+            st = model.roi_heads.box.speculation
+            assert (st["kept"], st["dropped"]) == ((1, 0) if post_nms is None else (0, 1)), st
         else:
             assert len(calls) == 1
+    if post_nms is not None:
+        head = model.roi_heads.box
+        monkeypatch.setattr(box_head, "_SPECULATE", True)
+        for _ in range(15):
+            assert head.speculate
+            head._note_speculation(False)
+        assert not head.speculate and head.speculation["dropped"] == 16
+        del calls[:]
+        torch.manual_seed(seed)
+        model(images, targets)
+        assert len(calls) == 1 and head.speculation["dropped"] == 16      # nothing queued early any more
     (la, ga), (lb, gb) = results[True], results[False]
     for k in la:      # (the DA losses sum with atomics: not bit-reproducible from one call to the next)
         tol = 1e-5 if k.startswith("loss_da") else 0.0

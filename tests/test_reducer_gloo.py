@@ -175,3 +175,26 @@ def test_the_schedule_tuner_decides_on_the_slowest_rank_and_all_ranks_agree():
     mp.spawn(_tuner_worker, args=(world, port, out), nprocs=world, join=True)
     assert out[0] == out[1] == 0
     assert out[10] == out[11] == 17000
+
+
+def _nan_worker(rank, world, port, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from da_detect_amd.engine.trainer import _loss_is_nan
+
+    net = torch.nn.Linear(3, 2)
+    out[rank] = _loss_is_nan(net, torch.tensor(1.0))                                      # clean on both ranks
+    out[10 + rank] = _loss_is_nan(net, torch.tensor(float("nan") if rank == 1 else 1.0))  # only rank 1 sees it
+    dist.destroy_process_group()
+
+
+def test_every_rank_leaves_when_one_rank_sees_a_nan():
+    """engine.trainer._loss_is_nan with N > 1: the verdict of the NaN / non-finite-GEMM test is
+    all-reduced, so the rank that saw nothing leaves with the one that did instead of blocking in the next collective"""
+    world = 2
+    port = _free_port()
+    out = mp.Manager().dict()
+    mp.spawn(_nan_worker, args=(world, port, out), nprocs=world, join=True)
+    assert out[0] is False and out[1] is False
+    assert out[10] is True and out[11] is True
