@@ -90,14 +90,165 @@ __device__ __forceinline__ int div_small(const int m, const int d, const float r
 }
 }  // namespace
 
+// ---- pieces of what follows a tile's K loop, over the accumulator blocks im in [LO, HI) of a wave ----------------------
+// park: lane-linear, 16 bytes per lane and store, written through to memory (block (im, in), quarter g at
+// ((im * TN + in) * 4 + g) * 8192 behind the lane's 16 bytes of the part's area)
+template <int TM, int TN, int LO, int HI>
+__device__ __forceinline__ void big_park(const __amdgpu_buffer_rsrc_t pr, const unsigned mine, const f32x16 (&acc)[TM][TN]) {
+#pragma unroll
+  for (int im = LO; im < HI; ++im)
+#pragma unroll
+    for (int in = 0; in < TN; ++in)
+#pragma unroll
+      for (int g = 0; g < 4; ++g)
+        buf_store4_wt(pr, mine + ((im * TN + in) * 4 + g) * 8192u,
+                      make_float4(acc[im][in][g * 4], acc[im][in][g * 4 + 1], acc[im][in][g * 4 + 2], acc[im][in][g * 4 + 3]));
+}
+
+// add another part's parked blocks: up to sixteen 16-byte loads per lane in flight (four blocks: one round trip through the
+// fabric, ~2 us, per four blocks)
+template <int TM, int TN, int LO, int HI>
+__device__ __forceinline__ void big_add_parked(const __amdgpu_buffer_rsrc_t pr, const unsigned src, f32x16 (&acc)[TM][TN]) {
+  constexpr int NB = (HI - LO) * TN, B = NB < 4 ? NB : 4;
+  static_assert(NB % B == 0, "blocks per batch");
+#pragma unroll
+  for (int b0 = 0; b0 < NB; b0 += B) {
+    float4 v[B][4];
+#pragma unroll
+    for (int b = 0; b < B; ++b)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) v[b][g] = buf_load4_sc1(pr, src + ((LO * TN + b0 + b) * 4 + g) * 8192u);
+#pragma unroll
+    for (int b = 0; b < B; ++b) {
+      const int im = LO + (b0 + b) / TN, in = (b0 + b) % TN;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        acc[im][in][g * 4] += v[b][g].x; acc[im][in][g * 4 + 1] += v[b][g].y;
+        acc[im][in][g * 4 + 2] += v[b][g].z; acc[im][in][g * 4 + 3] += v[b][g].w;
+      }
+    }
+  }
+}
+
+// epilogue: y = gate(acc * scale + bias + addend), 16 bytes per lane through an LDS transpose (conv_split.hip:
+// conv_epilogue_v4), the same arithmetic per element in the same order; two blocks per round of residual / gate loads — the
+// two column blocks of one row block (256 contiguous bytes per output row and round).  -> max |y| over what was stored
+template <int TM, int TN, int LO, int HI>
+__device__ __forceinline__ float big_epilogue(const ConvArgs& a, const f32x16 (&acc)[TM][TN], char* smem, const int row0,
+                                              const int col0) {
+  static_assert(TN == 2, "a round is the two column blocks of a row block");
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  float* tile_f = reinterpret_cast<float*>(smem) + wave * (2 * 32 * EPI_STRIDE);
+  const __amdgpu_buffer_rsrc_t yr = make_rsrc(a.y, a.y_bytes);
+  const __amdgpu_buffer_rsrc_t ar = make_rsrc(a.addend ? a.addend : a.y, a.addend ? a.y_bytes : 0u);
+  const __amdgpu_buffer_rsrc_t mr = make_rsrc(a.mask_ref ? a.mask_ref : a.y, a.mask_ref ? a.y_bytes : 0u);
+  const int col_in = lane & 31, row_hi = 4 * (lane >> 5);
+  const int rrow = lane >> 3, c4 = (lane & 7) * 4;
+  float mx = 0.f;
+  float4 scv[2], biv[2];
+  bool nvalid[2];
+#pragma unroll
+  for (int b = 0; b < 2; ++b) {
+    const int n = col0 + b * 32 + c4;
+    nvalid[b] = n < a.Cout;                              // Cout % 4 == 0: the four columns are valid together
+    scv[b] = make_float4(1.f, 1.f, 1.f, 1.f);
+    biv[b] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (a.scale && nvalid[b]) scv[b] = *reinterpret_cast<const float4*>(a.scale + n);
+    if (a.bias && nvalid[b]) biv[b] = *reinterpret_cast<const float4*>(a.bias + n);
+  }
+#pragma unroll
+  for (int im = LO; im < HI; ++im) {
+    unsigned offs[2][4];
+    float4 ad[2][4], mk[2][4];
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int pass = 0; pass < 4; ++pass) {
+        const int m = row0 + im * 32 + pass * 8 + rrow;
+        offs[b][pass] = (nvalid[b] && m < a.M) ? ((unsigned)m * (unsigned)a.Cout + (unsigned)(col0 + b * 32 + c4)) * 4u : kBigOOB;
+      }
+    if (a.addend) {
+#pragma unroll
+      for (int b = 0; b < 2; ++b)
+#pragma unroll
+        for (int pass = 0; pass < 4; ++pass) ad[b][pass] = buf_load4(ar, offs[b][pass]);
+    }
+    if (a.relu_mode == 2) {
+#pragma unroll
+      for (int b = 0; b < 2; ++b)
+#pragma unroll
+        for (int pass = 0; pass < 4; ++pass) mk[b][pass] = buf_load4(mr, offs[b][pass]);
+    }
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+      float* tl = tile_f + b * (32 * EPI_STRIDE);
+#pragma unroll
+      for (int g = 0; g < 4; ++g)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) tl[(e + 8 * g + row_hi) * EPI_STRIDE + col_in] = acc[im][b][g * 4 + e];
+    }
+    // a wave's own data only: no workgroup barrier, the LDS traffic of one wave is ordered
+    __builtin_amdgcn_s_waitcnt(0xc07f);                // lgkmcnt(0)
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+      const float* tl = tile_f + b * (32 * EPI_STRIDE);
+#pragma unroll
+      for (int pass = 0; pass < 4; ++pass) {
+        const int row = pass * 8 + rrow;
+        const float4 v4 = *reinterpret_cast<const float4*>(tl + row * EPI_STRIDE + c4);
+        const unsigned off = offs[b][pass];
+        float v[4] = {v4.x, v4.y, v4.z, v4.w};
+        const float s4[4] = {scv[b].x, scv[b].y, scv[b].z, scv[b].w}, b4[4] = {biv[b].x, biv[b].y, biv[b].z, biv[b].w};
+        float adv[4] = {0.f, 0.f, 0.f, 0.f}, mkv[4] = {1.f, 1.f, 1.f, 1.f};
+        if (a.addend) {
+          const float4 tv = ad[b][pass];
+          adv[0] = tv.x; adv[1] = tv.y; adv[2] = tv.z; adv[3] = tv.w;
+        }
+        if (a.relu_mode == 2) {
+          const float4 tv = mk[b][pass];
+          mkv[0] = tv.x; mkv[1] = tv.y; mkv[2] = tv.z; mkv[3] = tv.w;
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          float x = v[e];
+          if (a.scale) x = x * s4[e];
+          if (a.bias) x = x + b4[e];
+          if (a.addend) x = x + adv[e];
+          if (a.relu_mode == 1) x = fmaxf(x, 0.f);
+          else if (a.relu_mode == 2) x = (mkv[e] > 0.f) ? x : 0.f;
+          v[e] = x;
+        }
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, make_float4(v[0], v[1], v[2], v[3])), yr,
+                                               (int)off, 0, 0);
+        if (a.amax_y && off != kBigOOB)
+          mx = fmaxf(fmaxf(mx, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
+      }
+    }
+    __builtin_amdgcn_wave_barrier();                   // the transpose space is rewritten by the next round
+  }
+  return mx;
+}
+
 // What follows a tile's K loop, shared by the tile shapes: undo the operand scales, meet the other K parts of the tile (if
 // the reduction was cut), run the fused epilogue.  row0 / col0: first output row / column of this WAVE's TM x TN blocks.
+//
+// Two parts (the usual cut) meet SYMMETRICALLY (round 6): part p owns the row blocks im in [p TM/2, (p + 1) TM/2) of every
+// wave; it parks only the blocks it does not own, adds the other part's contribution to the ones it does, and runs the
+// epilogue on those alone — half the parked bytes, half the epilogue per workgroup, neither partner idle (before: part 0
+// parked its whole tile and left, part 1 waited, re-read it and stored everything: ~19 - 36% of a launch).  a + b has no
+// order: the sums do not depend on which part owns a block.  Waiting for the partner must not depend on a workgroup that has
+// not been dispatched (two such launches on two streams could hold each other's CUs): the protocol decides by TICKETS.  The
+// first arriver takes ticket 0, parks its foreign half, then takes a second ticket: if the partner has arrived meanwhile
+// (it is resident and past its K loop) both go the symmetric way; if not, the first parks its own half too and leaves, and
+// the partner — whose ticket tells it so — adds the whole tile and stores it, as before.  A tile's counter moves by exactly
+// three per launch and is never reset; the flags carry the launch's epoch (counter / 3 + 1), so nothing is cleared either.
 template <int TM, int TN, int BN>
 __device__ __forceinline__ void big_finish(const ConvArgs& a, f32x16 (&acc)[TM][TN], char* smem, const int tile,
                                            const int part, const int S, const int row0, const int col0, const int ea,
                                            const int eb) {
-  const int t = threadIdx.x, lane = t & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int t = threadIdx.x;
   {
     // undo the operand scales (exact: powers of two, in two steps so that no intermediate leaves fp32's range unless the
     // result does): the parts of a split reduction are parked in true units
@@ -114,7 +265,61 @@ __device__ __forceinline__ void big_finish(const ConvArgs& a, f32x16 (&acc)[TM][
   nf_check<TM, TN>(acc, a.nf_flag, a.launch_id);
   BIG_STAMP(2);
   int* s_word = reinterpret_cast<int*>(smem);        // the operand planes are dead (every wave passed the last barrier)
-  if (S > 1) {
+  constexpr int H = TM / 2;
+  int own = 0;                                       // 0: the whole tile is this workgroup's, 1 / 2: the lower / upper half
+  auto drain_and_meet = [&]() {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // every wave drains its stores ...
+    __syncthreads();                                    // ... before one lane announces them
+  };
+  if (S == 2 && !a.big_asym) {
+    const __amdgpu_buffer_rsrc_t pr = make_rsrc(a.sk_ws + (size_t)tile * 2 * (256 * BN), (unsigned)(2 * 256 * BN * 4));
+    unsigned* cnt = reinterpret_cast<unsigned*>(a.sk_counters) + 4096 + 3 * tile;   // arrivals | flag of part 0 | of part 1
+    const unsigned mine = (unsigned)part * (256 * BN * 4) + (unsigned)t * 16u;
+    const unsigned theirs = (unsigned)(part ^ 1) * (256 * BN * 4) + (unsigned)t * 16u;
+    constexpr unsigned kFull = 0x80000000u;
+    if (t == 0) s_word[0] = (int)__hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    const unsigned ticket = (unsigned)s_word[0];
+    const unsigned epoch = ticket / 3u + 1u;
+    unsigned local = ticket % 3u;
+    if (local != 2u) {
+      // park the half this part does not own
+      if (part == 0) big_park<TM, TN, H, TM>(pr, mine, acc);
+      else big_park<TM, TN, 0, H>(pr, mine, acc);
+      drain_and_meet();
+      if (local == 0u) {
+        if (t == 0) s_word[1] = (int)__hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __syncthreads();
+        if ((unsigned)s_word[1] % 3u == 1u) {
+          // the partner has not arrived: leave the own half as well and go (the partner finishes the tile)
+          if (part == 0) big_park<TM, TN, 0, H>(pr, mine, acc);
+          else big_park<TM, TN, H, TM>(pr, mine, acc);
+          drain_and_meet();
+          if (t == 0) __hip_atomic_exchange(cnt + 1 + part, epoch | kFull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          BIG_STAMP(5);
+          return;
+        }
+      }
+      if (t == 0) {
+        __hip_atomic_exchange(cnt + 1 + part, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        // the partner holds a ticket: it is resident, past its K loop, and only finishes its stores
+        while (__hip_atomic_load(cnt + 1 + (part ^ 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != epoch)
+          __builtin_amdgcn_s_sleep(4);
+      }
+      __syncthreads();
+      if (part == 0) big_add_parked<TM, TN, 0, H>(pr, theirs, acc);
+      else big_add_parked<TM, TN, H, TM>(pr, theirs, acc);
+      own = 1 + part;
+    } else {
+      // the partner came first, saw nobody and left its whole tile
+      if (t == 0)
+        while (__hip_atomic_load(cnt + 1 + (part ^ 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != (epoch | kFull))
+          __builtin_amdgcn_s_sleep(4);
+      __syncthreads();
+      big_add_parked<TM, TN, 0, TM>(pr, theirs, acc);
+    }
+    __syncthreads();      // s_word is about to be reused as transpose space
+  } else if (S > 1) {
     const __amdgpu_buffer_rsrc_t pr = make_rsrc(a.sk_ws + (size_t)tile * S * (256 * BN), (unsigned)(S * 256 * BN * 4));
     int* arrive = a.sk_counters + tile;
     int* parked = a.sk_counters + 2048 + tile;
@@ -122,19 +327,8 @@ __device__ __forceinline__ void big_finish(const ConvArgs& a, f32x16 (&acc)[TM][
     __syncthreads();
     const int ticket = s_word[0];
     if (ticket != S - 1) {
-      // park: lane-linear, 16 bytes per lane and store, written through to memory
-      const unsigned mine = (unsigned)part * (256 * BN * 4) + (unsigned)t * 16u;
-#pragma unroll
-      for (int im = 0; im < TM; ++im)
-#pragma unroll
-        for (int in = 0; in < TN; ++in)
-#pragma unroll
-          for (int g = 0; g < 4; ++g)
-            buf_store4_wt(pr, mine + ((im * TN + in) * 4 + g) * 8192u,
-                          make_float4(acc[im][in][g * 4], acc[im][in][g * 4 + 1], acc[im][in][g * 4 + 2],
-                                      acc[im][in][g * 4 + 3]));
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // every wave drains its stores ...
-      __syncthreads();                                    // ... before one lane announces the part
+      big_park<TM, TN, 0, TM>(pr, (unsigned)part * (256 * BN * 4) + (unsigned)t * 16u, acc);
+      drain_and_meet();
       if (t == 0) __hip_atomic_fetch_add(parked, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       BIG_STAMP(5);
       return;
@@ -148,36 +342,16 @@ __device__ __forceinline__ void big_finish(const ConvArgs& a, f32x16 (&acc)[TM][
     __syncthreads();
     // sum in part order, this part's registers at its own index: the result does not depend on who came last
     if (S == 2) {
-      // two parts (the usual cut): a + b needs no order; the other part's tile is fetched sixteen 16-byte loads per lane at
-      // a time (four blocks: two round trips through the fabric per tile instead of eight, ~2 us each)
-      const unsigned src = (unsigned)(part ^ 1) * (256 * BN * 4) + (unsigned)t * 16u;
-      constexpr int NB = TM * TN;
-#pragma unroll
-      for (int b0 = 0; b0 < NB; b0 += 4) {
-        float4 v[4][4];
-#pragma unroll
-        for (int b = 0; b < 4; ++b)
-#pragma unroll
-          for (int g = 0; g < 4; ++g) v[b][g] = buf_load4_sc1(pr, src + ((b0 + b) * 4 + g) * 8192u);
-#pragma unroll
-        for (int b = 0; b < 4; ++b) {
-          const int im = (b0 + b) / TN, in = (b0 + b) % TN;
-#pragma unroll
-          for (int g = 0; g < 4; ++g) {
-            acc[im][in][g * 4] += v[b][g].x; acc[im][in][g * 4 + 1] += v[b][g].y;
-            acc[im][in][g * 4 + 2] += v[b][g].z; acc[im][in][g * 4 + 3] += v[b][g].w;
-          }
-        }
-      }
+      big_add_parked<TM, TN, 0, TM>(pr, (unsigned)(part ^ 1) * (256 * BN * 4) + (unsigned)t * 16u, acc);
     } else
 #pragma unroll
     for (int im = 0; im < TM; ++im)
 #pragma unroll
       for (int in = 0; in < TN; ++in) {
-        float4 own[4], sum[4];
+        float4 own4[4], sum[4];
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-          own[g] = make_float4(acc[im][in][g * 4], acc[im][in][g * 4 + 1], acc[im][in][g * 4 + 2], acc[im][in][g * 4 + 3]);
+          own4[g] = make_float4(acc[im][in][g * 4], acc[im][in][g * 4 + 1], acc[im][in][g * 4 + 2], acc[im][in][g * 4 + 3]);
           sum[g] = make_float4(0.f, 0.f, 0.f, 0.f);
         }
         for (int p = 0; p < S; ++p) {
@@ -188,7 +362,7 @@ __device__ __forceinline__ void big_finish(const ConvArgs& a, f32x16 (&acc)[TM][
             for (int g = 0; g < 4; ++g) v[g] = buf_load4_sc1(pr, src + g * 8192u);
           } else {
 #pragma unroll
-            for (int g = 0; g < 4; ++g) v[g] = own[g];
+            for (int g = 0; g < 4; ++g) v[g] = own4[g];
           }
 #pragma unroll
           for (int g = 0; g < 4; ++g) {
@@ -205,95 +379,10 @@ __device__ __forceinline__ void big_finish(const ConvArgs& a, f32x16 (&acc)[TM][
   }
 
   BIG_STAMP(3);
-  // ---- epilogue: y = gate(acc * scale + bias + addend), 16 bytes per lane through an LDS transpose (conv_split.hip:
-  // conv_epilogue_v4), the same arithmetic per element in the same order
-  float* tile_f = reinterpret_cast<float*>(smem) + wave * (2 * 32 * EPI_STRIDE);
-  const __amdgpu_buffer_rsrc_t yr = make_rsrc(a.y, a.y_bytes);
-  const __amdgpu_buffer_rsrc_t ar = make_rsrc(a.addend ? a.addend : a.y, a.addend ? a.y_bytes : 0u);
-  const __amdgpu_buffer_rsrc_t mr = make_rsrc(a.mask_ref ? a.mask_ref : a.y, a.mask_ref ? a.y_bytes : 0u);
-  const int col_in = lane & 31, row_hi = 4 * (lane >> 5);
-  const int rrow = lane >> 3, c4 = (lane & 7) * 4;
-  float mx = 0.f;
-#pragma unroll
-  for (int in = 0; in < TN; ++in) {
-    const int n = col0 + in * 32 + c4;
-    const bool nvalid = n < a.Cout;                      // Cout % 4 == 0: the four columns are valid together
-    float4 scv = make_float4(1.f, 1.f, 1.f, 1.f), biv = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (a.scale && nvalid) scv = *reinterpret_cast<const float4*>(a.scale + n);
-    if (a.bias && nvalid) biv = *reinterpret_cast<const float4*>(a.bias + n);
-#pragma unroll
-    for (int q = 0; q < TM / 2; ++q) {
-      unsigned offs[2][4];
-      float4 ad[2][4], mk[2][4];
-#pragma unroll
-      for (int b = 0; b < 2; ++b)
-#pragma unroll
-        for (int pass = 0; pass < 4; ++pass) {
-          const int m = row0 + (2 * q + b) * 32 + pass * 8 + rrow;
-          offs[b][pass] = (nvalid && m < a.M) ? ((unsigned)m * (unsigned)a.Cout + (unsigned)n) * 4u : kBigOOB;
-        }
-      if (a.addend) {
-#pragma unroll
-        for (int b = 0; b < 2; ++b)
-#pragma unroll
-          for (int pass = 0; pass < 4; ++pass) ad[b][pass] = buf_load4(ar, offs[b][pass]);
-      }
-      if (a.relu_mode == 2) {
-#pragma unroll
-        for (int b = 0; b < 2; ++b)
-#pragma unroll
-          for (int pass = 0; pass < 4; ++pass) mk[b][pass] = buf_load4(mr, offs[b][pass]);
-      }
-#pragma unroll
-      for (int b = 0; b < 2; ++b) {
-        const int im = 2 * q + b;
-        float* tl = tile_f + b * (32 * EPI_STRIDE);
-#pragma unroll
-        for (int g = 0; g < 4; ++g)
-#pragma unroll
-          for (int e = 0; e < 4; ++e) tl[(e + 8 * g + row_hi) * EPI_STRIDE + col_in] = acc[im][in][g * 4 + e];
-      }
-      // a wave's own data only: no workgroup barrier, the LDS traffic of one wave is ordered
-      __builtin_amdgcn_s_waitcnt(0xc07f);                // lgkmcnt(0)
-      __builtin_amdgcn_wave_barrier();
-#pragma unroll
-      for (int b = 0; b < 2; ++b) {
-        const float* tl = tile_f + b * (32 * EPI_STRIDE);
-#pragma unroll
-        for (int pass = 0; pass < 4; ++pass) {
-          const int row = pass * 8 + rrow;
-          const float4 v4 = *reinterpret_cast<const float4*>(tl + row * EPI_STRIDE + c4);
-          const unsigned off = offs[b][pass];
-          float v[4] = {v4.x, v4.y, v4.z, v4.w};
-          const float s4[4] = {scv.x, scv.y, scv.z, scv.w}, b4[4] = {biv.x, biv.y, biv.z, biv.w};
-          float adv[4] = {0.f, 0.f, 0.f, 0.f}, mkv[4] = {1.f, 1.f, 1.f, 1.f};
-          if (a.addend) {
-            const float4 tv = ad[b][pass];
-            adv[0] = tv.x; adv[1] = tv.y; adv[2] = tv.z; adv[3] = tv.w;
-          }
-          if (a.relu_mode == 2) {
-            const float4 tv = mk[b][pass];
-            mkv[0] = tv.x; mkv[1] = tv.y; mkv[2] = tv.z; mkv[3] = tv.w;
-          }
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            float x = v[e];
-            if (a.scale) x = x * s4[e];
-            if (a.bias) x = x + b4[e];
-            if (a.addend) x = x + adv[e];
-            if (a.relu_mode == 1) x = fmaxf(x, 0.f);
-            else if (a.relu_mode == 2) x = (mkv[e] > 0.f) ? x : 0.f;
-            v[e] = x;
-          }
-          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, make_float4(v[0], v[1], v[2], v[3])), yr,
-                                                 (int)off, 0, 0);
-          if (a.amax_y && off != kBigOOB)
-            mx = fmaxf(fmaxf(mx, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
-        }
-      }
-      __builtin_amdgcn_wave_barrier();                   // the transpose space is rewritten by the next round
-    }
-  }
+  float mx;
+  if (own == 0) mx = big_epilogue<TM, TN, 0, TM>(a, acc, smem, row0, col0);
+  else if (own == 1) mx = big_epilogue<TM, TN, 0, H>(a, acc, smem, row0, col0);
+  else mx = big_epilogue<TM, TN, H, TM>(a, acc, smem, row0, col0);
   if (a.amax_y) amax_publish(a.amax_y, mx);
   BIG_STAMP(4);
 }
@@ -1079,6 +1168,10 @@ int launch_fwd_big(ConvArgs& a, hipStream_t st, float* ws, int* counters) {
   a.big_splits = (ws && counters && tiles <= 2048) ? big_split_plan(tiles, a.K / 32) : 1;
   a.sk_ws = ws;
   a.sk_counters = counters;
+  {
+    const char* e = getenv("DADET_BIG_ASYM");       // read per call: A/B runs and tests
+    a.big_asym = (e && e[0] == '1') ? 1 : 0;
+  }
   // two K-tile slots + the staging groups' row descriptors
   const size_t lds = variant == 2 ? 2 * (2 * 256 * 64 + 2 * 128 * 64) + 12 * 512 * sizeof(int)
                                   : 2 * 4 * 256 * 64 + 16 * 256 * sizeof(int);

@@ -12,8 +12,8 @@ for p in (ROOT, HERE):  # repo root (da_detect_amd, oracle) and tests/ (golden.*
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
-    config.addinivalue_line("markers", "slow: a test whose coverage other tests of the default run repeat; runs with "
-                                       "DADET_RUN_SLOW=1 (keeps the GPU suite under 8 minutes on the driver's box)")
+    config.addinivalue_line("markers", "slow: skipped unless DADET_RUN_SLOW=1 (no test carries it since round 6: the three "
+                                       "oracle comparisons that did are in the default run)")
 
 
 def pytest_collection_modifyitems(config, items):

@@ -120,6 +120,50 @@ def test_big_tile_kernel_part_counts_agree(device, big_mode, splits, tile_n, mon
     torch.testing.assert_close(got, one, rtol=1e-5, atol=1e-5 * float(ref.abs().max()))
 
 
+@pytest.mark.parametrize("tile_n", [256, 128])
+@pytest.mark.parametrize("epi", ["none", "add_gate"])
+def test_two_parts_meet_symmetrically_and_give_the_bits_of_the_one_sided_hand_over(device, big_mode, tile_n, epi, monkeypatch):
+    """round 6: two K parts of a tile exchange HALVES (each parks the row blocks it does not own, adds the partner's to its
+    own, stores its own) instead of part 0 parking everything for part 1.  a + b is b + a: the output must be the round-5
+    hand-over's (DADET_BIG_ASYM=1) bit for bit — on ragged tiles, with a fused epilogue, and launch after launch on one
+    stream with CHANGING tile counts (the meeting's counters are never reset: they move by three per launch and tile, the
+    flags carry the launch's epoch).  A third launch shape in between uses the 3-part protocol, whose counters are reset."""
+    from da_detect_amd import _C
+
+    big_mode.dadet_set_big_gemm(2)
+    monkeypatch.setenv("DADET_BIG_TILE_N", str(tile_n))
+    g = torch.Generator().manual_seed(21 + tile_n)
+    shapes = [(2, 128, 33, 47, 320, 3, 1), (1, 256, 24, 40, 512, 1, 0), (3, 64, 20, 28, 260, 3, 1)]
+    data = []
+    for N, Cin, H, W, Cout, k, pad in shapes:
+        x = torch.randn((N, Cin, H, W), generator=g).to(device).contiguous(memory_format=CL)
+        w = (torch.randn((Cout, Cin, k, k), generator=g) * 0.03).to(device).contiguous(memory_format=CL)
+        kw = {}
+        if epi == "add_gate":
+            kw = dict(scale=(torch.rand(Cout, generator=g) + 0.5).to(device), bias=torch.randn(Cout, generator=g).to(device),
+                      addend=torch.randn((N, Cout, H, W), generator=g).to(device).contiguous(memory_format=CL), relu_mode=2,
+                      mask_ref=torch.randn((N, Cout, H, W), generator=g).clamp_min(0).to(device).contiguous(memory_format=CL))
+        data.append((x, w, pad, kw))
+    monkeypatch.setenv("DADET_BIG_SPLITS", "2")
+    monkeypatch.setenv("DADET_BIG_ASYM", "1")
+    want = [_C.conv_forward(x, w, pad=pad, **kw) for x, w, pad, kw in data]
+    monkeypatch.setenv("DADET_BIG_ASYM", "0")
+    for rnd in range(6):
+        for i in ((0, 1, 2), (2, 0, 1), (1, 1, 0))[rnd % 3]:
+            x, w, pad, kw = data[i]
+            got = _C.conv_forward(x, w, pad=pad, **kw)
+            assert torch.equal(got, want[i]), "round %d, shape %d: symmetric meeting != one-sided hand-over" % (rnd, i)
+        if rnd == 2:      # the reset-to-zero protocol of three parts shares the stream (its own counter words)
+            monkeypatch.setenv("DADET_BIG_SPLITS", "3")
+            x, w, pad, kw = data[0]
+            three = _C.conv_forward(x, w, pad=pad, **kw)
+            torch.testing.assert_close(three, want[0], rtol=1e-5, atol=1e-5 * float(want[0].abs().max()))
+            monkeypatch.setenv("DADET_BIG_SPLITS", "2")
+    ref = torch.nn.functional.conv2d(data[0][0].double(), data[0][1].double(), padding=1)
+    if epi == "none":
+        assert float((want[0].double() - ref).abs().max()) <= 2e-5 * float(ref.abs().max())
+
+
 def test_big_tile_kernel_leaves_the_output_maximum(device, big_mode):
     """mode 4's hand-over: the epilogue merges max|y| into the caller's slot (the next GEMM's scale)"""
     from da_detect_amd import _C, amax as _amax

@@ -78,66 +78,53 @@ def test_full_size_step_schedules_agree(device, workload):
         assert abs(l_ov[k] - l_again[k]) <= 1e-5 * max(1.0, abs(l_ov[k])), (k, l_ov[k], l_again[k])
 
 
-def test_full_size_img_only_step_matches_the_cpu_oracle(device, monkeypatch):
-    """The BASELINE configs[1] step at its FULL size — 2 x 1024 x 2048, 122 880 anchors per image, 64 x 128 x 1024 C4 maps,
-    the > 65 535-tile GEMM grids of res2 — against oracle/model_ref.py, which shares no kernel, no index arithmetic and no
-    schedule with the product (the comparisons above are schedule A vs schedule B of the SAME kernels: an indexing defect
-    common to both would pass them).  Same harness as tests/test_default_path_gpu.py: the oracle replays the product's
-    sampler seeds and is fed the product's RPN maps and proposal lists (two devices never agree on near-tied fp32 scores),
-    everything else runs on its own CPU tensors in fp32 on the host cores (~25 s on the GPU box).
-    Asserted: sampled anchor and ROI indices identical; every loss within 2e-4; every parameter gradient within the fp32
-    oracle's own noise (profiles/r02_grad_noise_floor.txt: the fp32 CPU step is 1e-4 .. 1.3e-3 from fp64 per tensor; a
-    wrong tile, a dropped row block or an overflowed offset moves a tensor by O(1))."""
-    from test_default_path_gpu import _check_gradients, _check_indices, _check_losses, _oracle, _run_default_path
-
-    seed, H, W = 7, 1024, 2048
-    c, sd, rec, nimg = _run_default_path("da_img_only", H, W, device, seed, monkeypatch)
-    assert rec["early_rpn"] and rec["loss_prep_rows"] and rec["pending_calls"], "not the default schedule"
-    assert tuple(rec["objectness"].shape[1:]) == (15, 64, 128)
-    torch.set_num_threads(min(os.cpu_count() or 1, 64))
-    osd, olosses, inter = _oracle(c, sd, rec, nimg, H, W, seed)
-    n_pos, n_neg = _check_indices(rec, inter)
-    assert n_pos + n_neg == c.MODEL.RPN.BATCH_SIZE_PER_IMAGE
-    assert all(len(b) > 100 for b, _ in inter["proposals"]), [len(b) for b, _ in inter["proposals"]]
-    _check_losses(rec, olosses, tol=2e-4)
-    sum(olosses.values()).backward()
-    worst, above = _check_gradients(rec["grads"], {n: osd[n].grad for n in rec["grads"]}, rounding_tol=2e-3, flip_tol=2e-2,
-                                    flipped_share=0.15)
-    print("full-size img_only step vs the fp32 CPU oracle: worst relative L2 gradient error %.2e; above 2e-3: %s" % (worst, above))
-    # north_star: "fp32 losses ... within 1e-4".  The 2e-4 above is the fp32 CPU oracle's own noise at this size; the loss
-    # leg again in FLOAT64 (forward only) takes that noise out, and the stated tolerance holds (VERDICT round 4, item 6)
-    del osd, olosses, inter
-    with torch.no_grad():
-        _, olosses64, _ = _oracle(c, sd, rec, nimg, H, W, seed, dtype=torch.float64)
-    _check_losses(rec, olosses64, tol=1e-4)
-    print("full-size img_only losses vs the float64 oracle: " + ", ".join(
-        "%s %.2e" % (k, abs(rec["losses"][k] - float(v)) / max(abs(float(v)), 1.0)) for k, v in olosses64.items()))
-
-
-@pytest.mark.slow
-@pytest.mark.parametrize("case", ["da_plain", "da_triplet"])
-def test_full_size_step_of_the_other_recipes_matches_the_cpu_oracle(device, monkeypatch, case):
-    """BASELINE configs[2] (image + instance + consistency heads: 2 x 1024 x 2048) and configs[3] (source + foggy + rainy
-    auxiliary under the triplet loss and AdvGRL: 3 x 1024 x 2048) against oracle/model_ref.py, as the img_only step above:
-    sampled anchor / ROI indices identical, losses against the FLOAT64 oracle within 1e-4, every parameter gradient against
-    the fp32 oracle within its noise.  The default run checks these recipes at full size only as schedule A vs schedule B
-    of the same kernels; this one is independent of them.  Slow (a minute or two of host oracle each): DADET_RUN_SLOW=1.
-    (configs[4], R-101-FPN-DCN: oracle/model_ref.py has no pyramid / deformable model — its deformable blocks are pinned
-    block by block against the two float64 restatements of tests/test_deform_gpu.py, its full-size step by the schedule
-    comparison above)"""
+def _full_size_step_against_the_float64_oracle(case, device, monkeypatch):
+    """one step of `case` at 1024 x 2048 on the default schedule against oracle/model_ref.py evaluated in FLOAT64, forward
+    and backward (one oracle pass: ~1 minute of the GPU box's host cores).  The oracle replays the product's sampler seeds
+    and is fed the product's RPN maps and proposal lists (two devices never agree on near-tied fp32 scores); everything else
+    runs on its own CPU tensors, sharing no kernel, no index arithmetic and no schedule with the product.
+    Asserted: sampled anchor and ROI indices identical; every loss within 1e-4 (north_star: "fp32 losses ... within 1e-4");
+    every parameter gradient within `flip_tol` in relative L2 and all but a few at rounding level — round 5 compared the
+    gradients with the fp32 oracle, whose own noise at this size (1e-4 .. 1.3e-3 per tensor against float64,
+    profiles/r02_grad_noise_floor.txt) forced 2e-3 / 2e-2; against float64 the bounds are the small cases' ones."""
     from test_default_path_gpu import _check_gradients, _check_indices, _check_losses, _oracle, _run_default_path
 
     seed, H, W = 7, 1024, 2048
     c, sd, rec, nimg = _run_default_path(case, H, W, device, seed, monkeypatch)
+    assert rec["early_rpn"] and rec["loss_prep_rows"], "not the default schedule"
     torch.set_num_threads(min(os.cpu_count() or 1, 64))
-    osd, olosses, inter = _oracle(c, sd, rec, nimg, H, W, seed)
-    _check_indices(rec, inter)
-    _check_losses(rec, olosses, tol=2e-4)
+    osd, olosses, inter = _oracle(c, sd, rec, nimg, H, W, seed, dtype=torch.float64)
+    n_pos, n_neg = _check_indices(rec, inter)
+    assert n_pos + n_neg > 0 and (n_pos + n_neg) % c.MODEL.RPN.BATCH_SIZE_PER_IMAGE == 0      # every labelled image fills its rows
+    assert all(len(b) > 100 for b, _ in inter["proposals"]), [len(b) for b, _ in inter["proposals"]]
+    _check_losses(rec, olosses, tol=1e-4)
     sum(olosses.values()).backward()
-    worst, above = _check_gradients(rec["grads"], {n: osd[n].grad for n in rec["grads"]}, rounding_tol=2e-3, flip_tol=2e-2,
-                                    flipped_share=0.15)
-    print("full-size %s step vs the fp32 CPU oracle: worst relative L2 gradient error %.2e; above 2e-3: %s" % (case, worst, above))
-    del osd, olosses, inter
-    with torch.no_grad():
-        _, olosses64, _ = _oracle(c, sd, rec, nimg, H, W, seed, dtype=torch.float64)
-    _check_losses(rec, olosses64, tol=1e-4)
+    want = {n: osd[n].grad for n in rec["grads"]}
+    if os.environ.get("DADET_PRINT_GRAD_ERRORS") == "1":      # the table the tolerances below were set from
+        for n, g in rec["grads"].items():
+            if want[n] is not None:
+                print("%-70s %.3e" % (n, float((g.double() - want[n]).norm()) / (float(want[n].norm()) + 1e-30)))
+    worst, above = _check_gradients(rec["grads"], want, rounding_tol=5e-5, flip_tol=4e-3, flipped_share=0.1)
+    print("full-size %s step vs the float64 CPU oracle: losses " % case + ", ".join(
+        "%s %.1e" % (k, abs(rec["losses"][k] - float(v)) / max(abs(float(v)), 1.0)) for k, v in olosses.items())
+        + "; worst relative L2 gradient error %.2e; above 5e-5: %s" % (worst, above))
+    return rec
+
+
+def test_full_size_img_only_step_matches_the_cpu_oracle(device, monkeypatch):
+    """The BASELINE configs[1] step at its FULL size — 2 x 1024 x 2048, 122 880 anchors per image, 64 x 128 x 1024 C4 maps,
+    the > 65 535-tile GEMM grids of res2 — against the float64 oracle (the comparisons above are schedule A vs schedule B
+    of the SAME kernels: an indexing defect common to both would pass them)."""
+    rec = _full_size_step_against_the_float64_oracle("da_img_only", device, monkeypatch)
+    assert rec["pending_calls"]
+    assert tuple(rec["objectness"].shape[1:]) == (15, 64, 128)
+
+
+@pytest.mark.parametrize("case", ["da_plain", "da_triplet"])
+def test_full_size_step_of_the_other_recipes_matches_the_cpu_oracle(device, monkeypatch, case):
+    """BASELINE configs[2] (image + instance + consistency heads: 2 x 1024 x 2048) and configs[3] (source + foggy + rainy
+    auxiliary under the triplet loss and AdvGRL: 3 x 1024 x 2048) against the float64 oracle, as the img_only step above.
+    In the default run since round 6 (they were behind DADET_RUN_SLOW=1).  (configs[4], R-101-FPN-DCN: oracle/model_ref.py
+    has no pyramid / deformable model — its deformable blocks are pinned block by block against the two float64
+    restatements of tests/test_deform_gpu.py, its full-size step by the schedule comparison above)"""
+    _full_size_step_against_the_float64_oracle(case, device, monkeypatch)

@@ -114,13 +114,20 @@ def test_end_to_end_without_injection_is_statistically_close(device):
         assert abs(float(losses[k]) - v) <= 0.1 * max(abs(v), 1.0), (k, float(losses[k]), v)
 
 
-@pytest.mark.slow
 def test_gradients_match_cpu_oracle(device):
     """backward through every HIP kernel (conv dgrad / wgrad, ROIAlign backward, fused DA heads) against torch
-    autograd on the oracle (oracle/model_ref.py), same weights / inputs / random stream.
-    slow (55 s of float64 oracle): the same kernels' gradients are compared with the float64 oracle on the same recipe by
-    test_default_path_gpu.py::test_default_path_matches_oracle_small[da_plain] (default schedule), and the ATen sampling
-    chain this test drives instead of the device sampler is pinned by the golden-loss tests of this file."""
+    autograd on the oracle (oracle/model_ref.py) in float64, same weights / inputs / random stream, with the ATen sampling
+    chain and the reference's random stream instead of the device sampler (30 s of oracle; in the default run since round 6).
+    Tolerances.  At 192 x 320 a ReLU whose pre-activation lies within fp32 rounding of zero fires on one side and not on
+    the other, and ONE such unit moves its layer's weight gradient by ~1e-3 of its norm and every layer BELOW it by ~1e-4
+    (the maps are small: few units share a gradient).  tools/probes/slow_grad_probe.py on this very case
+    (profiles/r06_slow_grad_probe_modes_4_0_3.txt): the exact-fp32 MFMA kernels (mode 0) and the default contraction
+    (mode 4) flip the SAME units — instance head 8e-4, res4 block 1 2e-4, everything below it 6e-5 .. 8e-5, identical to
+    three digits in both modes — while the six-term bf16 mode happens to land on the oracle's side everywhere (max 4e-5).
+    It is the decision of an fp32 ReLU against a float64 one, not the contraction.  So: every tensor under the flip bound
+    (a wrong tile, a dropped row block, a missing term moves a tensor by O(1)), the MEDIAN tensor at rounding level, and at
+    least half of all tensors at rounding level (a flip high in the network taints every tensor below it: a share of
+    tensors says nothing about the number of flips)."""
     from da_detect_amd.data.synthetic import make_batch
     from oracle import model_ref
 
@@ -146,7 +153,10 @@ def test_gradients_match_cpu_oracle(device):
     params = dict(model.named_parameters())
     from test_default_path_gpu import _check_gradients
 
-    worst, above = _check_gradients({n: params[n].grad.detach().cpu() for n in names}, {n: osd[n].grad for n in names})
+    got = {n: params[n].grad.detach().cpu() for n in names}
+    worst, above = _check_gradients(got, {n: osd[n].grad for n in names}, flipped_share=0.5)
+    errs = sorted(float((got[n].double() - osd[n].grad).norm()) / (float(osd[n].grad.norm()) + 1e-30) for n in names)
+    assert errs[len(errs) // 2] < 2.5e-5, "median relative L2 gradient error %.2e" % errs[len(errs) // 2]
     print("worst relative L2 gradient error vs the fp64 oracle: %.3e over %d tensors; above rounding level: %s" % (
         worst, len(names), above))
 
