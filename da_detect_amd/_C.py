@@ -1374,8 +1374,8 @@ def _psroi_args(data, rois, offset, out_size, out_channels, no_trans, group_size
     return B, H, W, C, R, num_classes
 
 
-def deform_psroi_pooling_forward(data, rois, offset, no_trans, spatial_scale, out_channels, group_size, out_size,
-                                 part_size, sample_per_part, trans_std):
+def deform_psroi_pool_forward(data, rois, offset, no_trans, spatial_scale, out_channels, group_size, out_size,
+                              part_size, sample_per_part, trans_std):
     """data [B, out_channels*group_size^2, H, W] (channels_last), rois [R,5], offset [R, 2*num_classes, part, part]
     (ignored with no_trans) -> (output, output_count) [R, out_channels, out_size, out_size] channels_last.
     Reference: tools/cityscapes/maskrcnn_benchmark/layers/dcn/deform_pool_func.py:30-35."""
@@ -1394,8 +1394,8 @@ def deform_psroi_pooling_forward(data, rois, offset, no_trans, spatial_scale, ou
     return out, cnt
 
 
-def deform_psroi_pooling_backward(grad_out, data, rois, offset, count, no_trans, spatial_scale, out_channels,
-                                  group_size, out_size, part_size, sample_per_part, trans_std):
+def deform_psroi_pool_backward(grad_out, data, rois, offset, count, no_trans, spatial_scale, out_channels,
+                               group_size, out_size, part_size, sample_per_part, trans_std):
     """-> (grad_data channels_last, grad_offset | None); reference deform_pool_func.py:52-60"""
     data, grad_out, count = _nhwc(data), _nhwc(grad_out), _nhwc(count)
     rois = rois.contiguous().float()
@@ -1408,6 +1408,122 @@ def deform_psroi_pooling_backward(grad_out, data, rois, offset, count, no_trans,
               _p(goffset), B, H, W, C, R, int(bool(no_trans)), float(spatial_scale), out_channels, group_size,
               out_size, part_size, sample_per_part, float(trans_std), ncls, _stream())
     return gdata, goffset
+
+
+# ---- the vendored tree's deformable entry points, by the reference's names and signatures ---------------------------------
+# tools/cityscapes/maskrcnn_benchmark/csrc/vision.cpp:17-23 (= csrc/deform_conv.h, csrc/deform_pool.h; CUDA side
+# csrc/cuda/vision.h:61-113), called from layers/dcn/deform_conv_func.py:49,87,110,182,216 and deform_pool_func.py:41,81 with
+# CALLER-ALLOCATED results (`output`, `grad_*`) and scratch (`columns`, `ones`).  Composed from the sampling kernels
+# (csrc/deform.hip) and the GEMM entry points: the reference's Python keeps working with only the native module replaced
+# (INTEGRATION.md, option B).  `columns` / `ones` are accepted and left alone — the reference rebinds its by-value copies
+# (`columns = at::zeros(...)`, deform_conv_cuda.cu:197), the caller's tensors never change there either.  groups == 1 and
+# equal vertical / horizontal stride, padding, dilation only (every DCN config of the reference); anything else raises.
+def _dc_geometry(what, kw, kh, dw, dh, pw, ph, lw, lh, group, weight):
+    if group != 1:
+        raise NotImplementedError("%s: groups > 1 is not on the HIP path" % what)
+    if dw != dh or pw != ph or lw != lh:
+        raise NotImplementedError("%s: stride / padding / dilation must be the same in both dimensions" % what)
+    if tuple(weight.shape[2:]) != (kh, kw):
+        raise ValueError("%s: kernel %dx%d does not match the weight %s" % (what, kh, kw, tuple(weight.shape)))
+    return int(dw), int(pw), int(lw)
+
+
+def _w_as_1x1(weight):
+    """[Cout,Cin,kh,kw] -> [Cout, kh*kw*Cin, 1, 1] with K = (tap, ci), the column order of the sampling kernels"""
+    cout, cin, kh, kw = weight.shape
+    return weight.contiguous(memory_format=CL).permute(0, 2, 3, 1).reshape(cout, kh * kw * cin, 1, 1)
+
+
+def _into(dst, src, what):
+    if tuple(dst.shape) != tuple(src.shape):
+        raise ValueError("%s: caller's tensor is %s, the result %s" % (what, tuple(dst.shape), tuple(src.shape)))
+    dst.copy_(src)
+
+
+def deform_conv_forward(input, weight, offset, output, columns, ones, kW, kH, dW, dH, padW, padH, dilationW, dilationH,
+                        group, deformable_group, im2col_step):
+    """DCNv1 forward into `output` [N,Cout,Ho,Wo] (deform_conv.h:10-43, deform_conv_cuda.cu:158-242) -> 1"""
+    stride, pad, dil = _dc_geometry("deform_conv_forward", kW, kH, dW, dH, padW, padH, dilationW, dilationH, group, weight)
+    cols = deform_sample_forward(input, offset, None, kH, kW, stride, pad, dil, deformable_group)
+    _into(output, conv_forward(cols, _w_as_1x1(weight)), "deform_conv_forward: output")
+    return 1
+
+
+def deform_conv_backward_input(input, offset, gradOutput, gradInput, gradOffset, weight, columns, kW, kH, dW, dH, padW, padH,
+                               dilationW, dilationH, group, deformable_group, im2col_step):
+    """DCNv1 gradients w.r.t. the sampled map and the offsets into `gradInput`, `gradOffset` (deform_conv.h:46-83) -> 1"""
+    stride, pad, dil = _dc_geometry("deform_conv_backward_input", kW, kH, dW, dH, padW, padH, dilationW, dilationH, group,
+                                    weight)
+    gcols = conv_forward(_nhwc(gradOutput), conv_weight_transpose(_w_as_1x1(weight)))
+    gx, goffset, _ = deform_sample_backward(input, offset, None, gcols, kH, kW, stride, pad, dil, deformable_group)
+    _into(gradInput, gx, "deform_conv_backward_input: gradInput")
+    _into(gradOffset, goffset, "deform_conv_backward_input: gradOffset")
+    return 1
+
+
+def deform_conv_backward_parameters(input, offset, gradOutput, gradWeight, columns, ones, kW, kH, dW, dH, padW, padH,
+                                    dilationW, dilationH, group, deformable_group, scale, im2col_step):
+    """gradWeight += scale * (gradOutput x columns^T) (deform_conv.h:86-124; the reference's addmm_ accumulates too) -> 1"""
+    if group != 1 or dW != dH or padW != padH or dilationW != dilationH:
+        raise NotImplementedError("deform_conv_backward_parameters: groups == 1 and equal stride / padding / dilation only")
+    cout, cin = gradWeight.shape[0], gradWeight.shape[1]
+    cols = deform_sample_forward(input, offset, None, kH, kW, int(dW), int(padW), int(dilationW), deformable_group)
+    gw = conv_wgrad(cols, _nhwc(gradOutput), (cout, kH * kW * cin, 1, 1))
+    gradWeight.add_(gw.reshape(cout, kH, kW, cin).permute(0, 3, 1, 2), alpha=float(scale))
+    return 1
+
+
+def modulated_deform_conv_forward(input, weight, bias, ones, offset, mask, output, columns, kernel_h, kernel_w, stride_h,
+                                  stride_w, pad_h, pad_w, dilation_h, dilation_w, group, deformable_group, with_bias):
+    """DCNv2 forward into `output` (deform_conv.h:127-159, deform_conv_cuda.cu:489-573); `bias` is read only with_bias"""
+    stride, pad, dil = _dc_geometry("modulated_deform_conv_forward", kernel_w, kernel_h, stride_w, stride_h, pad_w, pad_h,
+                                    dilation_w, dilation_h, group, weight)
+    cols = deform_sample_forward(input, offset, mask, kernel_h, kernel_w, stride, pad, dil, deformable_group)
+    _into(output, conv_forward(cols, _w_as_1x1(weight), None, bias if with_bias else None),
+          "modulated_deform_conv_forward: output")
+
+
+def modulated_deform_conv_backward(input, weight, bias, ones, offset, mask, columns, grad_input, grad_weight, grad_bias,
+                                   grad_offset, grad_mask, grad_output, kernel_h, kernel_w, stride_h, stride_w, pad_h, pad_w,
+                                   dilation_h, dilation_w, group, deformable_group, with_bias):
+    """DCNv2 backward (deform_conv.h:162-201, deform_conv_cuda.cu:575-691): grad_input / grad_offset / grad_mask are written,
+    grad_weight and (with_bias) grad_bias accumulated, as the reference's addmm_ / addmv_ do on the caller's zeros"""
+    stride, pad, dil = _dc_geometry("modulated_deform_conv_backward", kernel_w, kernel_h, stride_w, stride_h, pad_w, pad_h,
+                                    dilation_w, dilation_h, group, weight)
+    cout, cin = weight.shape[0], weight.shape[1]
+    gy = _nhwc(grad_output)
+    w1 = _w_as_1x1(weight)
+    gcols = conv_forward(gy, conv_weight_transpose(w1))
+    gx, goffset, gmask = deform_sample_backward(input, offset, mask, gcols, kernel_h, kernel_w, stride, pad, dil,
+                                                deformable_group)
+    _into(grad_input, gx, "modulated_deform_conv_backward: grad_input")
+    _into(grad_offset, goffset, "modulated_deform_conv_backward: grad_offset")
+    _into(grad_mask, gmask, "modulated_deform_conv_backward: grad_mask")
+    cols = deform_sample_forward(input, offset, mask, kernel_h, kernel_w, stride, pad, dil, deformable_group)
+    gw = conv_wgrad(cols, gy, (cout, kernel_h * kernel_w * cin, 1, 1))
+    grad_weight.add_(gw.reshape(cout, kernel_h, kernel_w, cin).permute(0, 3, 1, 2))
+    if with_bias:
+        grad_bias.add_(colsum(gy))
+
+
+def deform_psroi_pooling_forward(input, bbox, trans, out, top_count, no_trans, spatial_scale, output_dim, group_size,
+                                 pooled_size, part_size, sample_per_part, trans_std):
+    """position-sensitive deformable ROI pooling into `out`, `top_count` [R, output_dim, pooled, pooled]
+    (deform_pool.h:10-35; called from deform_pool_func.py:41-55)"""
+    o, c = deform_psroi_pool_forward(input, bbox, trans, no_trans, spatial_scale, output_dim, group_size, pooled_size,
+                                     part_size, sample_per_part, trans_std)
+    _into(out, o, "deform_psroi_pooling_forward: out")
+    _into(top_count, c, "deform_psroi_pooling_forward: top_count")
+
+
+def deform_psroi_pooling_backward(out_grad, input, bbox, trans, top_count, input_grad, trans_grad, no_trans, spatial_scale,
+                                  output_dim, group_size, pooled_size, part_size, sample_per_part, trans_std):
+    """gradients into `input_grad` and (unless no_trans) `trans_grad` (deform_pool.h:38-66; deform_pool_func.py:81-97)"""
+    gd, go = deform_psroi_pool_backward(out_grad, input, bbox, trans, top_count, no_trans, spatial_scale, output_dim,
+                                        group_size, pooled_size, part_size, sample_per_part, trans_std)
+    _into(input_grad, gd, "deform_psroi_pooling_backward: input_grad")
+    if go is not None:
+        _into(trans_grad, go, "deform_psroi_pooling_backward: trans_grad")
 
 
 def check_nonfinite():

@@ -90,10 +90,10 @@ __device__ __forceinline__ int div_small(const int m, const int d, const float r
 }
 }  // namespace
 
-// ---- pieces of what follows a tile's K loop, over the accumulator blocks im in [LO, HI) of a wave ----------------------
-// park: lane-linear, 16 bytes per lane and store, written through to memory (block (im, in), quarter g at
-// ((im * TN + in) * 4 + g) * 8192 behind the lane's 16 bytes of the part's area)
-template <int TM, int TN, int LO, int HI>
+// ---- pieces of what follows a tile's K loop, over the accumulator row blocks [LO, HI) of a wave ------------------------
+// park: lane-linear, 16 bytes per lane and store, written through to memory: row block im as SLOT im - LO + SLOT0 (slot j,
+// column block in, quarter g at ((j * TN + in) * 4 + g) * 8192 behind the lane's 16 bytes of the part's area)
+template <int TM, int TN, int LO, int HI, int SLOT0>
 __device__ __forceinline__ void big_park(const __amdgpu_buffer_rsrc_t pr, const unsigned mine, const f32x16 (&acc)[TM][TN]) {
 #pragma unroll
   for (int im = LO; im < HI; ++im)
@@ -101,13 +101,13 @@ __device__ __forceinline__ void big_park(const __amdgpu_buffer_rsrc_t pr, const 
     for (int in = 0; in < TN; ++in)
 #pragma unroll
       for (int g = 0; g < 4; ++g)
-        buf_store4_wt(pr, mine + ((im * TN + in) * 4 + g) * 8192u,
+        buf_store4_wt(pr, mine + (((im - LO + SLOT0) * TN + in) * 4 + g) * 8192u,
                       make_float4(acc[im][in][g * 4], acc[im][in][g * 4 + 1], acc[im][in][g * 4 + 2], acc[im][in][g * 4 + 3]));
 }
 
-// add another part's parked blocks: up to sixteen 16-byte loads per lane in flight (four blocks: one round trip through the
-// fabric, ~2 us, per four blocks)
-template <int TM, int TN, int LO, int HI>
+// add another part's parked slots SLOT0 .. to the row blocks [LO, HI): up to sixteen 16-byte loads per lane in flight (four
+// blocks: one round trip through the fabric, ~2 us)
+template <int TM, int TN, int LO, int HI, int SLOT0>
 __device__ __forceinline__ void big_add_parked(const __amdgpu_buffer_rsrc_t pr, const unsigned src, f32x16 (&acc)[TM][TN]) {
   constexpr int NB = (HI - LO) * TN, B = NB < 4 ? NB : 4;
   static_assert(NB % B == 0, "blocks per batch");
@@ -117,7 +117,7 @@ __device__ __forceinline__ void big_add_parked(const __amdgpu_buffer_rsrc_t pr, 
 #pragma unroll
     for (int b = 0; b < B; ++b)
 #pragma unroll
-      for (int g = 0; g < 4; ++g) v[b][g] = buf_load4_sc1(pr, src + ((LO * TN + b0 + b) * 4 + g) * 8192u);
+      for (int g = 0; g < 4; ++g) v[b][g] = buf_load4_sc1(pr, src + ((SLOT0 * TN + b0 + b) * 4 + g) * 8192u);
 #pragma unroll
     for (int b = 0; b < B; ++b) {
       const int im = LO + (b0 + b) / TN, in = (b0 + b) % TN;
@@ -132,10 +132,11 @@ __device__ __forceinline__ void big_add_parked(const __amdgpu_buffer_rsrc_t pr, 
 
 // epilogue: y = gate(acc * scale + bias + addend), 16 bytes per lane through an LDS transpose (conv_split.hip:
 // conv_epilogue_v4), the same arithmetic per element in the same order; two blocks per round of residual / gate loads — the
-// two column blocks of one row block (256 contiguous bytes per output row and round).  -> max |y| over what was stored
-template <int TM, int TN, int LO, int HI>
-__device__ __forceinline__ float big_epilogue(const ConvArgs& a, const f32x16 (&acc)[TM][TN], char* smem, const int row0,
-                                              const int col0) {
+// two column blocks of one row block (256 contiguous bytes per output row and round).  Row blocks [0, TM / 2) start at output
+// row row_a, row blocks [TM / 2, TM) at row_b; the second half only when `both`.  -> max |y| over what was stored
+template <int TM, int TN>
+__device__ __forceinline__ float big_epilogue(const ConvArgs& a, const f32x16 (&acc)[TM][TN], char* smem, const int row_a,
+                                              const int row_b, const int col0, const bool both) {
   static_assert(TN == 2, "a round is the two column blocks of a row block");
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -158,14 +159,16 @@ __device__ __forceinline__ float big_epilogue(const ConvArgs& a, const f32x16 (&
     if (a.bias && nvalid[b]) biv[b] = *reinterpret_cast<const float4*>(a.bias + n);
   }
 #pragma unroll
-  for (int im = LO; im < HI; ++im) {
+  for (int im = 0; im < TM; ++im) {
+    if (im >= TM / 2 && !both) break;
+    const int rbase = im < TM / 2 ? row_a + im * 32 : row_b + (im - TM / 2) * 32;
     unsigned offs[2][4];
     float4 ad[2][4], mk[2][4];
 #pragma unroll
     for (int b = 0; b < 2; ++b)
 #pragma unroll
       for (int pass = 0; pass < 4; ++pass) {
-        const int m = row0 + im * 32 + pass * 8 + rrow;
+        const int m = rbase + pass * 8 + rrow;
         offs[b][pass] = (nvalid[b] && m < a.M) ? ((unsigned)m * (unsigned)a.Cout + (unsigned)(col0 + b * 32 + c4)) * 4u : kBigOOB;
       }
     if (a.addend) {
@@ -234,21 +237,46 @@ __device__ __forceinline__ float big_epilogue(const ConvArgs& a, const f32x16 (&
 // What follows a tile's K loop, shared by the tile shapes: undo the operand scales, meet the other K parts of the tile (if
 // the reduction was cut), run the fused epilogue.  row0 / col0: first output row / column of this WAVE's TM x TN blocks.
 //
-// Two parts (the usual cut) meet SYMMETRICALLY (round 6): part p owns the row blocks im in [p TM/2, (p + 1) TM/2) of every
-// wave; it parks only the blocks it does not own, adds the other part's contribution to the ones it does, and runs the
-// epilogue on those alone — half the parked bytes, half the epilogue per workgroup, neither partner idle (before: part 0
-// parked its whole tile and left, part 1 waited, re-read it and stored everything: ~19 - 36% of a launch).  a + b has no
-// order: the sums do not depend on which part owns a block.  Waiting for the partner must not depend on a workgroup that has
-// not been dispatched (two such launches on two streams could hold each other's CUs): the protocol decides by TICKETS.  The
-// first arriver takes ticket 0, parks its foreign half, then takes a second ticket: if the partner has arrived meanwhile
-// (it is resident and past its K loop) both go the symmetric way; if not, the first parks its own half too and leaves, and
-// the partner — whose ticket tells it so — adds the whole tile and stores it, as before.  A tile's counter moves by exactly
-// three per launch and is never reset; the flags carry the launch's epoch (counter / 3 + 1), so nothing is cleared either.
+// Two parts (the usual cut) meet SYMMETRICALLY (round 6): part p owns the row blocks [p TM/2, (p + 1) TM/2) of every wave;
+// it parks only the blocks it does not own, adds the other part's contribution to the ones it does, and runs the epilogue on
+// those alone — half the parked bytes, half the epilogue per workgroup, neither partner idle (before: part 0 parked its
+// whole tile and left, part 1 waited, re-read it and stored everything: ~19 - 36% of a launch).  a + b has no order: the
+// sums do not depend on which part owns a block.  Part 1 first SWAPS its two register halves (selects on a uniform
+// condition), so that "own" is row blocks [0, TM/2) and "foreign" [TM/2, TM) in both parts and every register index below
+// is static without a second copy of the code (a park over a run-time choice of registers made the compiler spill the K
+// loop's staging registers: the loop runs at the register limit).
+// Waiting for the partner must not depend on a workgroup that has not been dispatched (two such launches on two streams
+// could hold each other's CUs): a part waits only for a partner that is known to be RESIDENT.  Every workgroup of a two-part
+// launch announces itself in the tile's `started` word as its first action (big_announce: one fetch-add whose result, the
+// launch's epoch, waits in LDS for the end of the K loop — no atomic round trip is left behind the loop).  A part that
+// finds its partner started parks its foreign half, publishes flag = epoch and waits for the partner's flag; one whose
+// partner has not even been dispatched parks its own half too, publishes epoch | FULL and leaves — the partner then reads
+// that from the flag, adds the whole tile and stores it, as before round 6.  (Both cannot leave: a part that has finished
+// has started.)  Nothing is ever reset: per launch and tile `started` moves by two and the flags carry the epoch
+// (started / 2 + 1); launches that share the words are ordered on their stream, also when a captured graph replays them.
+// sk_counters + 4096 + 4 * tile: started | flag of part 0 | flag of part 1 | unused.
+__device__ __forceinline__ unsigned big_announce(const ConvArgs& a, const int tile) {
+  unsigned prev = 0;
+  if (a.big_splits == 2 && !a.big_asym && threadIdx.x == 0)
+    prev = __hip_atomic_fetch_add(reinterpret_cast<unsigned*>(a.sk_counters) + 4096 + 4 * tile, 1u, __ATOMIC_RELAXED,
+                                  __HIP_MEMORY_SCOPE_AGENT);
+  return prev;
+}
+
 template <int TM, int TN, int BN>
-__device__ __forceinline__ void big_finish(const ConvArgs& a, f32x16 (&acc)[TM][TN], char* smem, const int tile,
+__device__ __forceinline__ void big_finish(const ConvArgs& a, const f32x16 (&acc_t)[TM][TN], char* smem, const int tile,
                                            const int part, const int S, const int row0, const int col0, const int ea,
-                                           const int eb) {
+                                           const int eb, const unsigned* meet_word) {
   const int t = threadIdx.x;
+  constexpr int H = TM / 2;
+  // From here on the sums live in NEW register tuples: the (vector) multiplication that undoes the operand scales defines
+  // them, and nothing below writes into the K loop's tuples again.  The loop runs at the register limit (128 accumulator +
+  // 48 fragment + 32 staging registers); a tuple that stays live through everything behind the loop is, to the register
+  // allocator, a long and therefore cheap range — with the symmetric meeting's extra code behind the loop it took two
+  // accumulator blocks out of the loop's registers (reloaded and stored again around every multiply segment: the step went
+  // from 12 to 20 ms).  Ending the loop's tuples here keeps them short and hot.  (Tuples, not 128 scalars: a park stores
+  // four consecutive registers per instruction, and scalars scattered by the allocator cost three times the park's time.)
+  f32x16 acc[TM][TN];
   {
     // undo the operand scales (exact: powers of two, in two steps so that no intermediate leaves fp32's range unless the
     // result does): the parts of a split reduction are parked in true units
@@ -257,66 +285,75 @@ __device__ __forceinline__ void big_finish(const ConvArgs& a, f32x16 (&acc)[TM][
 #pragma unroll
     for (int im = 0; im < TM; ++im)
 #pragma unroll
-      for (int in = 0; in < TN; ++in)
-#pragma unroll
-        for (int e = 0; e < 16; ++e) acc[im][in][e] = acc[im][in][e] * u1 * u2;
+      for (int in = 0; in < TN; ++in) acc[im][in] = (acc_t[im][in] * u1) * u2;
   }
 
   nf_check<TM, TN>(acc, a.nf_flag, a.launch_id);
   BIG_STAMP(2);
   int* s_word = reinterpret_cast<int*>(smem);        // the operand planes are dead (every wave passed the last barrier)
-  constexpr int H = TM / 2;
-  int own = 0;                                       // 0: the whole tile is this workgroup's, 1 / 2: the lower / upper half
+  int row_a = row0, row_b = row0 + H * 32;           // output rows of the register halves [0, H) and [H, TM)
+  bool both = true;                                  // this workgroup stores both halves
   auto drain_and_meet = [&]() {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // every wave drains its stores ...
     __syncthreads();                                    // ... before one lane announces them
   };
   if (S == 2 && !a.big_asym) {
     const __amdgpu_buffer_rsrc_t pr = make_rsrc(a.sk_ws + (size_t)tile * 2 * (256 * BN), (unsigned)(2 * 256 * BN * 4));
-    unsigned* cnt = reinterpret_cast<unsigned*>(a.sk_counters) + 4096 + 3 * tile;   // arrivals | flag of part 0 | of part 1
+    unsigned* cnt = reinterpret_cast<unsigned*>(a.sk_counters) + 4096 + 4 * tile;   // started | flag 0 | flag 1
     const unsigned mine = (unsigned)part * (256 * BN * 4) + (unsigned)t * 16u;
     const unsigned theirs = (unsigned)(part ^ 1) * (256 * BN * 4) + (unsigned)t * 16u;
     constexpr unsigned kFull = 0x80000000u;
-    if (t == 0) s_word[0] = (int)__hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __syncthreads();
-    const unsigned ticket = (unsigned)s_word[0];
-    const unsigned epoch = ticket / 3u + 1u;
-    unsigned local = ticket % 3u;
-    if (local != 2u) {
-      // park the half this part does not own
-      if (part == 0) big_park<TM, TN, H, TM>(pr, mine, acc);
-      else big_park<TM, TN, 0, H>(pr, mine, acc);
+    const unsigned epoch = *meet_word / 2u + 1u;
+    if (part != 0) {      // own half first: registers [0, H) <-> [H, TM)
+#pragma unroll
+      for (int im = 0; im < H; ++im)
+#pragma unroll
+        for (int in = 0; in < TN; ++in) {
+          const f32x16 lo = acc[im][in];
+          acc[im][in] = acc[im + H][in];
+          acc[im + H][in] = lo;
+        }
+      row_a = row0 + H * 32;
+      row_b = row0;
+    }
+    big_park<TM, TN, H, TM, 0>(pr, mine, acc);              // the foreign half: slots [0, H) of this part's area
+    // (the look at `started` travels with the stores)
+    if (t == 0) s_word[0] = (int)__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    drain_and_meet();
+    if ((unsigned)s_word[0] != 2u * epoch) {
+      // the partner has not been dispatched: leave the own half as well (slots [H, TM)) and go
+      big_park<TM, TN, 0, H, H>(pr, mine, acc);
       drain_and_meet();
-      if (local == 0u) {
-        if (t == 0) s_word[1] = (int)__hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __syncthreads();
-        if ((unsigned)s_word[1] % 3u == 1u) {
-          // the partner has not arrived: leave the own half as well and go (the partner finishes the tile)
-          if (part == 0) big_park<TM, TN, 0, H>(pr, mine, acc);
-          else big_park<TM, TN, H, TM>(pr, mine, acc);
-          drain_and_meet();
-          if (t == 0) __hip_atomic_exchange(cnt + 1 + part, epoch | kFull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          BIG_STAMP(5);
-          return;
+      if (t == 0) __hip_atomic_store(cnt + 1 + part, epoch | kFull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      BIG_STAMP(5);
+      return;
+    }
+    if (t == 0) {
+      __hip_atomic_store(cnt + 1 + part, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      // the partner is resident: in its K loop or past it
+      unsigned f;
+      int spins = 0;
+      while (((f = __hip_atomic_load(cnt + 1 + (part ^ 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) & ~kFull) != epoch) {
+        __builtin_amdgcn_s_sleep(2);
+        if (++spins == (1 << 22)) {     // seconds, where microseconds are expected: a defect — reported by the guard's poll
+          if (a.nf_flag) {              // (dadet_nonfinite_poll names this launch) instead of a hung queue
+            atomicCAS(a.nf_flag, 0u, a.launch_id + 1u);
+            atomicAdd(a.nf_flag + 1, 1u);
+          }
+          f = epoch;
+          break;
         }
       }
-      if (t == 0) {
-        __hip_atomic_exchange(cnt + 1 + part, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        // the partner holds a ticket: it is resident, past its K loop, and only finishes its stores
-        while (__hip_atomic_load(cnt + 1 + (part ^ 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != epoch)
-          __builtin_amdgcn_s_sleep(4);
-      }
-      __syncthreads();
-      if (part == 0) big_add_parked<TM, TN, 0, H>(pr, theirs, acc);
-      else big_add_parked<TM, TN, H, TM>(pr, theirs, acc);
-      own = 1 + part;
+      s_word[1] = (int)f;
+    }
+    __syncthreads();
+    if (((unsigned)s_word[1] & kFull) == 0u) {
+      big_add_parked<TM, TN, 0, H, 0>(pr, theirs, acc);     // the partner's foreign half is this part's own
+      both = false;
     } else {
-      // the partner came first, saw nobody and left its whole tile
-      if (t == 0)
-        while (__hip_atomic_load(cnt + 1 + (part ^ 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != (epoch | kFull))
-          __builtin_amdgcn_s_sleep(4);
-      __syncthreads();
-      big_add_parked<TM, TN, 0, TM>(pr, theirs, acc);
+      // the partner saw nobody when it finished and left its whole tile: its foreign half (slots [0, H)) is this part's
+      // own, its own half (slots [H, TM)) this part's foreign one
+      big_add_parked<TM, TN, 0, TM, 0>(pr, theirs, acc);
     }
     __syncthreads();      // s_word is about to be reused as transpose space
   } else if (S > 1) {
@@ -327,7 +364,7 @@ __device__ __forceinline__ void big_finish(const ConvArgs& a, f32x16 (&acc)[TM][
     __syncthreads();
     const int ticket = s_word[0];
     if (ticket != S - 1) {
-      big_park<TM, TN, 0, TM>(pr, (unsigned)part * (256 * BN * 4) + (unsigned)t * 16u, acc);
+      big_park<TM, TN, 0, TM, 0>(pr, (unsigned)part * (256 * BN * 4) + (unsigned)t * 16u, acc);
       drain_and_meet();
       if (t == 0) __hip_atomic_fetch_add(parked, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       BIG_STAMP(5);
@@ -342,7 +379,7 @@ __device__ __forceinline__ void big_finish(const ConvArgs& a, f32x16 (&acc)[TM][
     __syncthreads();
     // sum in part order, this part's registers at its own index: the result does not depend on who came last
     if (S == 2) {
-      big_add_parked<TM, TN, 0, TM>(pr, (unsigned)(part ^ 1) * (256 * BN * 4) + (unsigned)t * 16u, acc);
+      big_add_parked<TM, TN, 0, TM, 0>(pr, (unsigned)(part ^ 1) * (256 * BN * 4) + (unsigned)t * 16u, acc);
     } else
 #pragma unroll
     for (int im = 0; im < TM; ++im)
@@ -379,10 +416,7 @@ __device__ __forceinline__ void big_finish(const ConvArgs& a, f32x16 (&acc)[TM][
   }
 
   BIG_STAMP(3);
-  float mx;
-  if (own == 0) mx = big_epilogue<TM, TN, 0, TM>(a, acc, smem, row0, col0);
-  else if (own == 1) mx = big_epilogue<TM, TN, 0, H>(a, acc, smem, row0, col0);
-  else mx = big_epilogue<TM, TN, H, TM>(a, acc, smem, row0, col0);
+  const float mx = big_epilogue<TM, TN>(a, acc, smem, row_a, row_b, col0, both);
   if (a.amax_y) amax_publish(a.amax_y, mx);
   BIG_STAMP(4);
 }
@@ -405,6 +439,8 @@ __global__ __launch_bounds__(512, 2) void conv_big_kernel(const ConvArgs a) {
   const int lid = xcd_remap(blockIdx.x, T * S);
   const int part = lid / T, tile = lid - part * T;
   const int bm0 = (tile / a.tiles_n) * 256, bn0 = (tile % a.tiles_n) * BN;
+  const unsigned announced = big_announce(a, tile);
+  unsigned* meet_word = reinterpret_cast<unsigned*>(smem + 2 * kStage + 16 * 256 * sizeof(int));   // behind the row descriptors
   const int nk = a.K / 32;
   const int kt_lo = (int)(((long long)nk * part) / S), kt_hi = (int)(((long long)nk * (part + 1)) / S);
   const int nT = kt_hi - kt_lo;
@@ -564,6 +600,7 @@ __global__ __launch_bounds__(512, 2) void conv_big_kernel(const ConvArgs a) {
     stage(q1, 0, 1);
     if (grp == 0) stage(raw[0], 1, 0);
   }
+  if (t == 0) *meet_word = announced;
   bar();
   BIG_STAMP(1);
   if (grp == 0) {
@@ -593,7 +630,7 @@ __global__ __launch_bounds__(512, 2) void conv_big_kernel(const ConvArgs a) {
     }
   }
 
-  big_finish<TM, TN, BN>(a, acc, smem, tile, part, S, bm0 + wm * (TM * 32), bn0 + wn * (TN * 32), ea, eb);
+  big_finish<TM, TN, BN>(a, acc, smem, tile, part, S, bm0 + wm * (TM * 32), bn0 + wn * (TN * 32), ea, eb, meet_word);
 }
 
 // ---- 256 x 128 tile: the layers with 128 or 256 output channels (res3 / res4 3x3 and their 1x1 neighbours) --------------
@@ -623,6 +660,8 @@ __global__ __launch_bounds__(512, 2) void conv_big128_kernel(const ConvArgs a) {
   const int lid = xcd_remap(blockIdx.x, T * S);
   const int part = lid / T, tile = lid - part * T;
   const int bm0 = (tile / a.tiles_n) * 256, bn0 = (tile % a.tiles_n) * BN;
+  const unsigned announced = big_announce(a, tile);
+  unsigned* meet_word = reinterpret_cast<unsigned*>(smem + 2 * kStage + 12 * 512 * sizeof(int));   // behind the row descriptors
   const int nk = a.K / 32;
   const int kt_lo = (int)(((long long)nk * part) / S), kt_hi = (int)(((long long)nk * (part + 1)) / S);
   const int nT = kt_hi - kt_lo;
@@ -776,6 +815,7 @@ __global__ __launch_bounds__(512, 2) void conv_big128_kernel(const ConvArgs a) {
     stage(q0, 0);
     if (grp == 0) stage(raw[1], 1);
   }
+  if (t == 0) *meet_word = announced;
   bar();
   BIG_STAMP(1);
   if (grp == 0) {
@@ -806,7 +846,7 @@ __global__ __launch_bounds__(512, 2) void conv_big128_kernel(const ConvArgs a) {
       }
     }
   }
-  big_finish<TM, TN, BN>(a, acc, smem, tile, part, S, bm0 + wm * (TM * 32), bn0 + wn * (TN * 32), ea, eb);
+  big_finish<TM, TN, BN>(a, acc, smem, tile, part, S, bm0 + wm * (TM * 32), bn0 + wn * (TN * 32), ea, eb, meet_word);
 }
 
 // ---- weight gradient, 256 x 256 tile ------------------------------------------------------------------------------------
@@ -1030,18 +1070,19 @@ __device__ __forceinline__ void wgrad_big_body(const WgradArgs& a, const int bid
     }
   }
 
-  // ---- epilogue: undo the scales, turn every 32 x 32 block through LDS, 16-byte stores along kk
+  // ---- epilogue: undo the scales, turn every 32 x 32 block through LDS, 16-byte stores along kk.  The scaled sums are
+  // tuples of their own (big_finish: the K loop's accumulator tuples end at this multiplication, so that the register
+  // allocator sees them as short, hot ranges of the loop and keeps its spills out of it)
+  f32x16 res[TM][TN];
   {
     const int tt = -(eg + ex);
     const float u1 = pow2f(tt / 2), u2 = pow2f(tt - tt / 2);
 #pragma unroll
     for (int im = 0; im < TM; ++im)
 #pragma unroll
-      for (int in = 0; in < TN; ++in)
-#pragma unroll
-        for (int e = 0; e < 16; ++e) acc[im][in][e] = acc[im][in][e] * u1 * u2;
+      for (int in = 0; in < TN; ++in) res[im][in] = (acc[im][in] * u1) * u2;
   }
-  nf_check<TM, TN>(acc, a.nf_flag, a.launch_id);
+  nf_check<TM, TN>(res, a.nf_flag, a.launch_id);
   float* out = a.direct ? a.out : a.out + (size_t)part * a.Cout * a.K;
   const bool final_out = a.direct;
   float* tile_f = reinterpret_cast<float*>(smem) + wave * (32 * EPI_STRIDE);
@@ -1055,7 +1096,7 @@ __device__ __forceinline__ void wgrad_big_body(const WgradArgs& a, const int bid
 #pragma unroll
       for (int g = 0; g < 4; ++g)
 #pragma unroll
-        for (int e = 0; e < 4; ++e) tile_f[(e + 8 * g + row_hi) * EPI_STRIDE + col_in] = acc[im][in][g * 4 + e];
+        for (int e = 0; e < 4; ++e) tile_f[(e + 8 * g + row_hi) * EPI_STRIDE + col_in] = res[im][in][g * 4 + e];
       __builtin_amdgcn_s_waitcnt(0xc07f);                // lgkmcnt(0): a wave's own data only
       __builtin_amdgcn_wave_barrier();
 #pragma unroll
@@ -1173,8 +1214,9 @@ int launch_fwd_big(ConvArgs& a, hipStream_t st, float* ws, int* counters) {
     a.big_asym = (e && e[0] == '1') ? 1 : 0;
   }
   // two K-tile slots + the staging groups' row descriptors
-  const size_t lds = variant == 2 ? 2 * (2 * 256 * 64 + 2 * 128 * 64) + 12 * 512 * sizeof(int)
-                                  : 2 * 4 * 256 * 64 + 16 * 256 * sizeof(int);
+  // (+ 16 bytes: the launch's epoch of the two-part meeting, big_announce)
+  const size_t lds = 16 + (variant == 2 ? 2 * (2 * 256 * 64 + 2 * 128 * 64) + 12 * 512 * sizeof(int)
+                                        : 2 * 4 * 256 * 64 + 16 * 256 * sizeof(int));
   static bool attr_set[3] = {false, false, false};
   if (!attr_set[variant]) {
     const void* fn = variant == 2 ? reinterpret_cast<const void*>(conv_big128_kernel)

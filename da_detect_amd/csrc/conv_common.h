@@ -221,8 +221,8 @@ struct ConvArgs {
   // large-tile kernel (conv_big.hip): number of K ranges a tile's reduction is cut into (0: another kernel runs); the
   // parts meet in sk_ws ([tile][part][256 x 256] floats) under sk_counters[tile] (arrivals) / [2048 + tile] (parked)
   int big_splits;
-  // two parts meet symmetrically under sk_counters[4096 + 3 * tile ..] (arrivals, flag of part 0, flag of part 1; never
-  // reset); big_asym != 0 (DADET_BIG_ASYM=1, A/B runs): the round-5 hand-over (part 0 parks everything, part 1 finishes)
+  // two parts meet symmetrically under sk_counters[4096 + 4 * tile ..] (tickets, flag of part 0, flag of part 1, started;
+  // never reset); big_asym != 0 (DADET_BIG_ASYM=1, A/B runs): the round-5 hand-over (part 0 parks everything, part 1 finishes)
   int big_asym;
   // non-finite guard (mode 4): device words {first offending launch id + 1, count} and this launch's id; null = off
   unsigned* nf_flag;

@@ -720,7 +720,7 @@ void* stream_scratch(hipStream_t st, size_t bytes) {
 
 // arrival counters of the stream-K tail: one persistent zero-initialised buffer per stream (work queued on a stream is
 // ordered, so one launch owns it at a time); the workgroup that completes a tile resets that tile's counter
-constexpr int kSkCounters = 4096 + 3 * 2048;     // + the symmetric two-part meeting of conv_big.hip: three words per tile
+constexpr int kSkCounters = 4096 + 4 * 2048;     // + the symmetric two-part meeting of conv_big.hip: four words per tile
 int* stream_counters(hipStream_t st) {
   static std::mutex m;
   static std::unordered_map<hipStream_t, int*> table;

@@ -26,7 +26,7 @@ class DeformRoIPoolingFunction(Function):
         assert 0.0 <= ctx.trans_std <= 1.0
         if not data.is_cuda:
             raise NotImplementedError("deform_roi_pooling has no CPU path")
-        output, count = _C.deform_psroi_pooling_forward(data, rois, offset, ctx.no_trans, ctx.spatial_scale,
+        output, count = _C.deform_psroi_pool_forward(data, rois, offset, ctx.no_trans, ctx.spatial_scale,
                                                         ctx.out_channels, ctx.group_size, ctx.out_size,
                                                         ctx.part_size, ctx.sample_per_part, ctx.trans_std)
         if data.requires_grad or rois.requires_grad or offset.requires_grad:
@@ -38,7 +38,7 @@ class DeformRoIPoolingFunction(Function):
     @once_differentiable
     def backward(ctx, grad_output):
         data, rois, offset = ctx.saved_tensors
-        grad_input, grad_offset = _C.deform_psroi_pooling_backward(
+        grad_input, grad_offset = _C.deform_psroi_pool_backward(
             grad_output, data, rois, offset, ctx.output_count, ctx.no_trans, ctx.spatial_scale, ctx.out_channels,
             ctx.group_size, ctx.out_size, ctx.part_size, ctx.sample_per_part, ctx.trans_std)
         return (grad_input, None, grad_offset, None, None, None, None, None, None, None, None)

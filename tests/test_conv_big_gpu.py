@@ -126,14 +126,16 @@ def test_two_parts_meet_symmetrically_and_give_the_bits_of_the_one_sided_hand_ov
     """round 6: two K parts of a tile exchange HALVES (each parks the row blocks it does not own, adds the partner's to its
     own, stores its own) instead of part 0 parking everything for part 1.  a + b is b + a: the output must be the round-5
     hand-over's (DADET_BIG_ASYM=1) bit for bit — on ragged tiles, with a fused epilogue, and launch after launch on one
-    stream with CHANGING tile counts (the meeting's counters are never reset: they move by three per launch and tile, the
-    flags carry the launch's epoch).  A third launch shape in between uses the 3-part protocol, whose counters are reset."""
+    stream with CHANGING tile counts (the meeting's words are never reset: per launch and tile the ticket counter moves by
+    three, `started` by two, the flags carry the launch's epoch).  A third launch shape in between uses the 3-part protocol, whose counters are reset."""
     from da_detect_amd import _C
 
     big_mode.dadet_set_big_gemm(2)
     monkeypatch.setenv("DADET_BIG_TILE_N", str(tile_n))
     g = torch.Generator().manual_seed(21 + tile_n)
-    shapes = [(2, 128, 33, 47, 320, 3, 1), (1, 256, 24, 40, 512, 1, 0), (3, 64, 20, 28, 260, 3, 1)]
+    # the last shape is 300 (600) tiles in two parts on 256 CUs: the first round's parts find partners that have not been
+    # DISPATCHED — they must not wait for them (they park their whole tile and leave; the late partner finishes the tile)
+    shapes = [(2, 128, 33, 47, 320, 3, 1), (1, 256, 24, 40, 512, 1, 0), (3, 64, 20, 28, 260, 3, 1), (1, 64, 240, 320, 256, 1, 0)]
     data = []
     for N, Cin, H, W, Cout, k, pad in shapes:
         x = torch.randn((N, Cin, H, W), generator=g).to(device).contiguous(memory_format=CL)
@@ -149,7 +151,7 @@ def test_two_parts_meet_symmetrically_and_give_the_bits_of_the_one_sided_hand_ov
     want = [_C.conv_forward(x, w, pad=pad, **kw) for x, w, pad, kw in data]
     monkeypatch.setenv("DADET_BIG_ASYM", "0")
     for rnd in range(6):
-        for i in ((0, 1, 2), (2, 0, 1), (1, 1, 0))[rnd % 3]:
+        for i in ((0, 1, 2, 3), (3, 2, 0, 1), (1, 3, 1, 0))[rnd % 3]:
             x, w, pad, kw = data[i]
             got = _C.conv_forward(x, w, pad=pad, **kw)
             assert torch.equal(got, want[i]), "round %d, shape %d: symmetric meeting != one-sided hand-over" % (rnd, i)
