@@ -283,3 +283,51 @@ print("FLOW-OK", str(meters))
     assert "triplet_loss_image: " in res.stdout and "Start evaluation on [Validation]" in res.stdout
     if aligned:
         assert "triplet_loss_instance: " in res.stdout
+
+
+# ---- the native module: maskrcnn_benchmark._C of BOTH reference trees ---------------------------------------------------------
+NATIVE = json.load(open(os.path.join(HERE, "golden", "reference_native_api.json")))
+_NATIVE_FNS = {}
+for _tree, _rec in NATIVE.items():
+    for _f in _rec["functions"]:
+        _NATIVE_FNS.setdefault(_f["name"], (_tree, _f))
+
+
+@pytest.mark.parametrize("name", sorted(_NATIVE_FNS))
+def test_native_module_has_every_bound_function_with_the_reference_arguments(name):
+    """every `m.def` of csrc/vision.cpp:7-15 and of the vendored tools/cityscapes/.../csrc/vision.cpp:9-23 (14 names) exists in
+    da_detect_amd._C, takes the reference's arguments positionally in the reference's order (this package may append optional
+    ones), and — for the functions written against the vendored tree this round — under the reference's C++ parameter names.
+    Fixture: tests/golden/reference_native_api.json (tests/golden/make_golden_native_api.py: parsed from the headers' text)."""
+    from da_detect_amd import _C
+
+    tree, rec = _NATIVE_FNS[name]
+    fn = getattr(_C, name, None)
+    assert callable(fn), "_C.%s missing (%s)" % (name, rec["header"])
+    params = [p for p in inspect.signature(fn).parameters.values()
+              if p.kind in (p.POSITIONAL_ONLY, p.POSITIONAL_OR_KEYWORD)]
+    n = len(rec["params"])
+    assert len(params) >= n, (name, [p.name for p in params], [p["name"] for p in rec["params"]])
+    for p in params[n:]:
+        assert p.default is not inspect.Parameter.empty, "%s: extra parameter %s must be optional" % (name, p.name)
+    inspect.signature(fn).bind(*[None] * n)
+    if name.startswith(("deform_", "modulated_")):
+        assert [p.name for p in params[:n]] == [p["name"] for p in rec["params"]], name
+
+
+@pytest.mark.parametrize("call", [c for r in NATIVE.values() for c in r["calls"]],
+                         ids=lambda c: "%s@%s:%d" % (c["name"], os.path.basename(c["file"]), c["line"]))
+def test_every_native_call_of_the_reference_layers_binds(call):
+    """each `_C.name(...)` call form in the reference's layers/*.py and layers/dcn/*.py (argument count, keywords) binds to
+    this package's function of that name"""
+    from da_detect_amd import _C
+
+    inspect.signature(getattr(_C, call["name"])).bind(*[None] * call["positional"], **{k: None for k in call["keywords"]})
+
+
+def test_native_module_aliases_exist():
+    from da_detect_amd import _C
+
+    for r in NATIVE.values():
+        for al in r["aliases"]:      # e.g. layers/nms.py: `nms = _C.nms`
+            assert callable(getattr(_C, al["name"]))

@@ -403,3 +403,105 @@ def test_deform_backward_leaves_the_offset_gradients_maximum(modulated):
     got = amax.value(gom)
     assert got is not None and got == float(gom.abs().max()) and got > 0.0
     assert amax.slot_of(_C._nhwc(gom)) is not None          # what the weight-gradient wrapper will find
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# the vendored tree's native entry points by the reference's names and call forms
+@pytest.mark.gpu
+@pytest.mark.parametrize("cfg", [(2, 32, 12, 15, 24, 3, 1, 1), (1, 64, 11, 9, 16, 3, 2, 2)])
+def test_vendored_deform_conv_entry_points_by_the_reference_call_forms(device, cfg):
+    """_C.deform_conv_forward / _backward_input / _backward_parameters exactly as deform_conv_func.py:38-121 of the vendored
+    tree calls them — plain contiguous NCHW tensors, CALLER-allocated `output` (new_empty), `grad_input` / `grad_offset` /
+    `grad_weight` (zeros_like), empty `columns` / `ones` scratch, (kW, kH, dW, dH, padW, padH, dilW, dilH, group,
+    deformable_group, im2col_step) — against autograd on oracle/deform_ref.py"""
+    from da_detect_amd import _C
+    from oracle import deform_ref as R
+
+    N, C, H, W, Cout, k, stride, dg = cfg
+    x, off, _, w, _, pad = _case(sum(cfg), N, C, H, W, Cout, k, stride, dg, False)
+    leaves = [t.clone().requires_grad_(True) for t in (x, off, w)]
+    want = R.deform_conv2d(leaves[0], leaves[1], None, leaves[2], None, stride, pad, 1, dg)
+    gy = torch.randn(want.shape, generator=torch.Generator().manual_seed(2))
+    want.backward(gy)
+    input, offset, weight, grad_output = x.to(device), off.to(device), w.to(device), gy.to(device)
+    output = input.new_empty(want.shape)
+    bufs_ = [input.new_empty(0), input.new_empty(0)]       # columns, ones
+    step = min(64, N)
+    assert _C.deform_conv_forward(input, weight, offset, output, bufs_[0], bufs_[1], weight.size(3), weight.size(2), stride,
+                                  stride, pad, pad, 1, 1, 1, dg, step) == 1
+    assert output.is_contiguous() and bufs_[0].numel() == 0 and bufs_[1].numel() == 0      # the caller's scratch is left alone
+    torch.testing.assert_close(output.cpu(), want.detach(), rtol=1e-4, atol=1e-4)
+    grad_input, grad_offset = torch.zeros_like(input), torch.zeros_like(offset)
+    _C.deform_conv_backward_input(input, offset, grad_output, grad_input, grad_offset, weight, bufs_[0], weight.size(3),
+                                  weight.size(2), stride, stride, pad, pad, 1, 1, 1, dg, step)
+    grad_weight = torch.zeros_like(weight)
+    _C.deform_conv_backward_parameters(input, offset, grad_output, grad_weight, bufs_[0], bufs_[1], weight.size(3),
+                                       weight.size(2), stride, stride, pad, pad, 1, 1, 1, dg, 1, step)
+    for name, got, ref in (("input", grad_input, leaves[0].grad), ("offset", grad_offset, leaves[1].grad),
+                           ("weight", grad_weight, leaves[2].grad)):
+        err = float((got.cpu() - ref).abs().max()) / (float(ref.abs().max()) + 1e-12)
+        assert err < 2e-4, "grad %s: %.3e" % (name, err)
+    # the reference ACCUMULATES the weight gradient (addmm_ with beta 1, scaled): a second call with scale 0.5 adds half
+    _C.deform_conv_backward_parameters(input, offset, grad_output, grad_weight, bufs_[0], bufs_[1], weight.size(3),
+                                       weight.size(2), stride, stride, pad, pad, 1, 1, 1, dg, 0.5, step)
+    torch.testing.assert_close(grad_weight.cpu(), 1.5 * leaves[2].grad, rtol=1e-3, atol=2e-4 * float(leaves[2].grad.abs().max()))
+    with pytest.raises(NotImplementedError):
+        _C.deform_conv_forward(input, weight, offset, output, bufs_[0], bufs_[1], k, k, stride, stride, pad, pad, 1, 1, 2, dg, step)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("with_bias", [True, False])
+def test_vendored_modulated_deform_conv_entry_points_by_the_reference_call_forms(device, with_bias):
+    """_C.modulated_deform_conv_forward / _backward as deform_conv_func.py:167-235 calls them (kernel_h before kernel_w here,
+    a one-element fake bias without one, five caller-allocated zero gradients) against autograd on oracle/deform_ref.py"""
+    from da_detect_amd import _C
+    from oracle import deform_ref as R
+
+    N, C, H, W, Cout, k, stride, dg = 2, 32, 13, 10, 20, 3, 1, 2
+    x, off, mask, w, b, pad = _case(31, N, C, H, W, Cout, k, stride, dg, True)
+    leaves = [t.clone().requires_grad_(True) for t in (x, off, mask, w, b)]
+    want = R.deform_conv2d(leaves[0], leaves[1], leaves[2], leaves[3], leaves[4] if with_bias else None, stride, pad, 1, dg)
+    gy = torch.randn(want.shape, generator=torch.Generator().manual_seed(3))
+    want.backward(gy)
+    input, offset, msk, weight = x.to(device), off.to(device), mask.to(device), w.to(device)
+    bias = b.to(device) if with_bias else input.new_empty(1)       # "fake tensor", deform_conv_func.py:170
+    output = input.new_empty(want.shape)
+    _bufs = [input.new_empty(0), input.new_empty(0)]
+    _C.modulated_deform_conv_forward(input, weight, bias, _bufs[0], offset, msk, output, _bufs[1], weight.shape[2],
+                                     weight.shape[3], stride, stride, pad, pad, 1, 1, 1, dg, with_bias)
+    torch.testing.assert_close(output.cpu(), want.detach(), rtol=1e-4, atol=1e-4)
+    grads = [torch.zeros_like(t) for t in (input, offset, msk, weight, bias)]
+    _C.modulated_deform_conv_backward(input, weight, bias, _bufs[0], offset, msk, _bufs[1], grads[0], grads[3], grads[4],
+                                      grads[1], grads[2], gy.to(device), weight.shape[2], weight.shape[3], stride, stride,
+                                      pad, pad, 1, 1, 1, dg, with_bias)
+    names = ["input", "offset", "mask", "weight"] + (["bias"] if with_bias else [])
+    for name, got, leaf in zip(names, grads, leaves):
+        err = float((got.cpu() - leaf.grad).abs().max()) / (float(leaf.grad.abs().max()) + 1e-12)
+        assert err < 2e-4, "grad %s: %.3e" % (name, err)
+    if not with_bias:
+        assert float(grads[4].abs().max()) == 0.0
+
+
+@pytest.mark.gpu
+def test_vendored_deform_psroi_pooling_entry_points_by_the_reference_call_forms():
+    """_C.deform_psroi_pooling_forward / _backward as deform_pool_func.py:38-97 calls them: caller-allocated `output`,
+    `output_count`, zero `grad_input` / `grad_offset`"""
+    from da_detect_amd import _C
+    from oracle.deform_ref import deform_psroi_pool
+
+    data, rois, trans, grad, kw = _psroi_case(13, False, 3, 2, 4)
+    ref_out, ref_cnt, ref_gd, ref_gt = deform_psroi_pool(data, rois, trans, grad_out=grad, **kw)
+    d, r, t = data.cuda(), rois.cuda(), trans.cuda()
+    n = r.shape[0]
+    output = d.new_empty(n, kw["out_dim"], kw["out_size"], kw["out_size"])
+    output_count = d.new_empty(n, kw["out_dim"], kw["out_size"], kw["out_size"])
+    _C.deform_psroi_pooling_forward(d, r, t, output, output_count, kw["no_trans"], kw["spatial_scale"], kw["out_dim"],
+                                    kw["group_size"], kw["out_size"], kw["part_size"], kw["sample_per_part"], kw["trans_std"])
+    torch.testing.assert_close(output.cpu(), ref_out, rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(output_count.cpu(), ref_cnt)
+    grad_input, grad_offset = torch.zeros_like(d), torch.zeros_like(t)
+    _C.deform_psroi_pooling_backward(grad.cuda(), d, r, t, output_count, grad_input, grad_offset, kw["no_trans"],
+                                     kw["spatial_scale"], kw["out_dim"], kw["group_size"], kw["out_size"], kw["part_size"],
+                                     kw["sample_per_part"], kw["trans_std"])
+    torch.testing.assert_close(grad_input.cpu(), ref_gd, rtol=1e-4, atol=1e-5)
+    torch.testing.assert_close(grad_offset.cpu(), ref_gt, rtol=1e-4, atol=2e-5)
