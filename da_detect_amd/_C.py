@@ -432,11 +432,14 @@ class _TransposeCache(object):
         self.ready = None          # (stream, event) of the last batched refresh
         self.enabled = True
         self._from_bump = False
+        self._trained_only = False
 
-    def bump(self, device=None):
+    def bump(self, device=None, trained_only=False):
         """new weight epoch; with a device: refresh every entry at once, on the caller's stream (the optimizer's, behind
-        the update and behind everything that read the old buffers)"""
+        the update and behind everything that read the old buffers).  trained_only: the caller changed trainable parameters
+        only (the optimizer): frozen weights' maxima are left alone (amax.WeightSlots.refresh)"""
         self.epoch += 1
+        self._trained_only = bool(trained_only)
         if self.enabled and device is not None and self.entries:
             self._from_bump = True
             try:
@@ -444,7 +447,9 @@ class _TransposeCache(object):
             finally:
                 self._from_bump = False
         elif device is not None and _mode4():
-            _amax.WEIGHTS.refresh(device, self.epoch)      # no transposed copies registered: the weights' maxima alone
+            # no transposed copies registered: the weights' maxima alone
+            _amax.WEIGHTS.refresh(device, self.epoch, trained_only=self._trained_only)
+        self._trained_only = False
 
     def _single(self, e, w, scale):
         """one entry on the current stream, remembered with an event for readers on other streams"""
@@ -515,7 +520,8 @@ class _TransposeCache(object):
         if _mode4():
             # parameters and the transposed copies just written: every persistent operand's maximum in one launch.  Behind
             # the optimizer (bump with a device) no other stream reads the slots; from the middle of a step they may.
-            _amax.WEIGHTS.refresh(device, self.epoch, sync=not self._from_bump)
+            _amax.WEIGHTS.refresh(device, self.epoch, sync=not self._from_bump,
+                                  trained_only=self._from_bump and self._trained_only)
         if device.type == "cuda":
             st = torch.cuda.current_stream(device)
             self.ready = (st, st.record_event())
@@ -529,14 +535,15 @@ def weight_epoch():
     return _TRANSPOSES.epoch
 
 
-def bump_weight_epoch(device=None):
+def bump_weight_epoch(device=None, trained_only=False):
     """weights were updated in place through raw pointers (the fused SGD kernel) or through `.data` (a broadcast, a
     checkpoint load, an EMA, a manual `p.data.copy_`): cached derived forms are stale.  REQUIRED after any weight write
     that does not go through autograd's version counter — the data-gradient GEMMs otherwise keep using the transposed /
     padded copies of the old values, and (contraction mode 4) the old largest magnitude of the weight: a weight that grew
     past twice its recorded maximum overflows fp16's range inside the GEMM and the step ends in inf / nan, loudly.
-    FusedSGD.step, BucketedGradReducer.broadcast_parameters and Checkpointer.load call it themselves."""
-    _TRANSPOSES.bump(device)
+    FusedSGD.step, BucketedGradReducer.broadcast_parameters and Checkpointer.load call it themselves.
+    trained_only=True (the optimizer): only tensors with requires_grad changed — frozen weights keep their maxima."""
+    _TRANSPOSES.bump(device, trained_only)
 
 
 def conv_weight_transpose(w, scale=None, cout_pad=0):

@@ -159,7 +159,7 @@ class WeightSlots(object):
         for k in dead:
             d["free"].append(d["entries"].pop(k)["i"])
         if dead:
-            d["table"] = None
+            d["table"] = d["table_trained"] = None
 
     def _measure_one(self, d, e):
         # its own slot back to zero, then one pass: same stream, ordered
@@ -174,7 +174,7 @@ class WeightSlots(object):
         owner = t._base if t._base is not None else t
         if e is not None and e["ref"]() is not owner:        # the address went to another tensor
             d["free"].append(d["entries"].pop(key)["i"])
-            d["table"] = None
+            d["table"] = d["table_trained"] = None
             e = None
         if e is None:
             if not d["free"]:
@@ -183,7 +183,7 @@ class WeightSlots(object):
                 raise _lib.DadetError("amax: more than %d persistent GEMM operands alive" % self.CAP)
             e = d["entries"][key] = dict(ref=weakref.ref(owner), ptr=key[0], n=key[1], i=d["free"].pop(),
                                          version=owner._version, epoch=epoch, used=epoch)
-            d["table"] = None
+            d["table"] = d["table_trained"] = None
             self._measure_one(d, e)
         else:
             e["used"] = epoch
@@ -202,19 +202,34 @@ class WeightSlots(object):
         if e is not None:
             e["epoch"] = -1
 
-    def refresh(self, device, epoch, sync=False):
+    @staticmethod
+    def _frozen(e):
+        """the entry's storage belongs to a parameter no optimizer changes (a frozen stage's weight)"""
+        o = e["ref"]()
+        return isinstance(o, torch.nn.Parameter) and not o.requires_grad
+
+    def refresh(self, device, epoch, sync=False, trained_only=False):
         """every registered tensor of this device re-measured by one fill + one launch on the current stream.  sync: the
-        call comes from the middle of a step (not from behind the optimizer): other streams may still read the slots"""
+        call comes from the middle of a step (not from behind the optimizer): other streams may still read the slots.
+        trained_only (the optimizer's call): frozen parameters keep their slots UNTOUCHED — their values did not change, and
+        the next step's frozen prefix may be reading them on the compute stream while this runs on the optimizer lane
+        (utils.streams: a slot is zero between the fill and the launch that re-measures it)."""
         if sync:
             torch.cuda.synchronize(device)
         d = self._dev(device)
         d["epoch"] = epoch
         self._sweep(d, epoch)
         live = [e for e in d["entries"].values() if self._alive(e)]
+        if trained_only:
+            for e in live:
+                if self._frozen(e):
+                    e["epoch"] = epoch
+            live = [e for e in live if not self._frozen(e)]
         if not live:
             return
         keys = [(e["i"], e["ptr"], e["n"]) for e in live]
-        if d["table"] is None or d["table"][3] != keys:
+        which = "table_trained" if trained_only else "table"
+        if d.get(which) is None or d[which][3] != keys:
             arr = (_lib.AmaxItem * len(live))()
             blocks = 0
             for k, e in enumerate(live):
@@ -228,9 +243,13 @@ class WeightSlots(object):
                 it.blocks = max(1, min(512, (n // 4 + 4095) // 4096))
                 blocks += it.blocks
             host = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).clone()
-            d["table"] = (host.to(device), blocks, len(live), keys)
-        d["slots"][:, :self.CAP].zero_()
-        dev_t, blocks, n, _ = d["table"]
+            idx = torch.tensor([e["i"] for e in live], dtype=torch.int64).to(device) if trained_only else None
+            d[which] = (host.to(device), blocks, len(live), keys, idx)
+        dev_t, blocks, n, _, idx = d[which]
+        if idx is None:
+            d["slots"][:, :self.CAP].zero_()
+        else:
+            d["slots"].index_fill_(1, idx, 0.0)
         _lib.call("dadet_amax_batch", ctypes.c_void_p(dev_t.data_ptr()), n, blocks, _stream())
         for e in live:
             e["epoch"] = epoch

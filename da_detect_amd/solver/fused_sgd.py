@@ -116,7 +116,8 @@ class FusedSGD(torch.optim.Optimizer):
         self._steps += 1
         from .. import _C
         # parameters changed through raw pointers: the cached transposed weights are refreshed here, in one launch
-        _C.bump_weight_epoch(entries[0][0].device)
+        # (trained_only: frozen weights did not change — their maxima are not re-measured)
+        _C.bump_weight_epoch(entries[0][0].device, trained_only=True)
         return loss
 
 
