@@ -383,11 +383,15 @@ def conv_forward(x, w, scale=None, bias=None, addend=None, mask_ref=None, stride
                     ("2,2", "2,1", "1,1")[variant]
             _KNAME_CACHE[key] = kname
         if getattr(PROFILER, "detail", False):   # tools/gemm_table.py: one row per problem shape
-            kname = "%s|M=%d N=%d K=%d k%dx%d s%d%s" % (kname, N * Ho * Wo, Cout, Cin * KH * KW, KH, KW, stride,
-                                                        " +add" if addend is not None else "")
+            # rows issued on a side stream share the GPU with the compute stream's kernels: their rates are not the kernel's
+            side = x.is_cuda and torch.cuda.current_stream(x.device) != torch.cuda.default_stream(x.device)
+            kname = "%s|M=%d N=%d K=%d k%dx%d s%d%s%s" % (kname, N * Ho * Wo, Cout, Cin * KH * KW, KH, KW, stride,
+                                                          " +add" if addend is not None else "", " [side]" if side else "")
+        # a strided 1x1 layer reads only the pixels it samples (whole rows of Cin floats): not all of x
+        x_read = N * Ho * Wo * Cin if (KH == 1 and KW == 1 and stride > 1) else x.numel()
         with PROFILER.span(kname,
                            2.0 * N * Ho * Wo * Cout * Cin * KH * KW,
-                           4.0 * (x.numel() + w.numel() + out.numel() + (addend.numel() if addend is not None else 0)
+                           4.0 * (x_read + w.numel() + out.numel() + (addend.numel() if addend is not None else 0)
                                   + (mask_ref.numel() if mask_ref is not None else 0))):
             _conv_forward_call(d, x, w, scale, bias, addend, mask_ref, out, ax, aw)
         return out
