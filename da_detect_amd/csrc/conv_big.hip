@@ -1298,7 +1298,7 @@ bool wgrad_group_member(const dadet_conv_desc* d) {
 
 // Rows per part R (a multiple of 32, the same for every problem of the group — every workgroup then runs the same number
 // of K-tiles on one tile, whatever its problem): the smallest R whose parts fit the chip's workgroup slots (256 for the
-// 256 x 256 tile, 2 x 256 for the 128 x 128 kernel), at least 128 rows (four K-tiles), at most 4096 (+31).
+// 256 x 256 tile, 2 x 256 for the 128 x 128 kernel), at least 128 rows (four K-tiles), at most 4096 (+ an eighth where that saves a round of workgroups).
 // splits[i] = ceil(M_i / R).
 // DADET_WGRAD_GROUP_ROWS forces R (tests).
 void wgrad_group_plan(const int n, const dadet_conv_desc* d, const int tile, int* tiles_co, int* tiles_kc, int* splits,
@@ -1325,8 +1325,10 @@ void wgrad_group_plan(const int n, const dadet_conv_desc* d, const int tile, int
     // one part is ONE fp32 accumulator chain over its rows: never more than 4096 of them (wgrad_big_plan's bound, for the
     // same reason) — a group whose tiles alone nearly fill the slots (the res5 head on 512 ROIs: ~100 tiles x 25088 rows)
     // then takes a second / third round of workgroups, cut into equal parts rather than 4096 + a remainder
+    // (an eighth of slack: the res5 head on 256 ROIs — 68 tiles, 12544 rows — fits the slots in three parts of 4192 rows;
+    // cutting it into four of 3136 is 272 workgroups, a second round for 16 of them: the family went 1.8 -> 2.2 ms per step)
     const int cap = ceil_div(ceil_div(max_m, ceil_div(max_m, 4096)), 32) * 32;
-    if (R > cap) R = cap;
+    if (R > 4096 + 512) R = cap;
   }
   *rows = R;
   for (int i = 0; i < n; ++i) splits[i] = ceil_div(d[i].N * d[i].Ho * d[i].Wo, R);

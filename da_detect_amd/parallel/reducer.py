@@ -10,9 +10,16 @@ This module is the MI355X-side equivalent, built around the fused optimizer inst
   * buckets are filled in reverse registration order (da heads -> box head -> rpn -> backbone), the order
     backward produces gradients; a post-accumulate hook counts arrivals and, when a bucket is complete, issues
     `all_reduce(async_op=True)` on it — RCCL runs it on its own stream while backward continues on the compute
-    stream (xGMI: 7 links x ~153 GB/s per GPU; 146 MB is ~2 ms of ring time against >100 ms of backward, so
-    the design goal is overlap, not bandwidth — bucket size only has to be large enough to amortise launch
-    latency, 25 MB by default like the reference's DDP);
+    stream.  Priced for the step as it is since round 5 (backward ~6 ms at 1024 x 2048, not the > 100 ms of round 1):
+    a ring all-reduce moves 2 (N - 1) / N x 146 MB per GPU and is bound by ONE xGMI link (~153 GB/s, 7 links per GPU,
+    point to point) unless RCCL spreads rings over several links: 1.7 ms at N = 8 on one link, ~0.25 ms if all seven
+    carry rings — between 4% and 28% of backward, so most of it can hide, but the LAST bucket cannot: it holds the
+    first trainable layers (res2 / res3), completes when backward ends, and its collective (25 MB: 0.04 - 0.3 ms) plus
+    everything behind it is an exposed tail.  Hence (round 6) the optimizer does not wait for ALL collectives and then
+    update everything: finalize(per_bucket=...) hands each bucket over as its collective completes, the fused SGD
+    updates that bucket's tensors, and the last bucket's all-reduce runs beside the earlier buckets' updates
+    (solver/fused_sgd.py).  Bucket size: large enough to amortise a collective's launch latency (~20 us), small enough
+    that the tail bucket is short — 25 MB by default like the reference's DDP;
   * parameters that receive no gradient in a step (e.g. the instance head when its loss weight is 0) are
     handled in `finalize()`: incomplete buckets are reduced there with their zero gradients, which is what
     DDP's find_unused_parameters achieves with a graph walk.  Collectives are issued in bucket order, so ONE
@@ -107,7 +114,7 @@ class BucketedGradReducer(object):
         self._finalized = False
         self.touched = set()
         if self._record:
-            self._step_rec = dict(in_backward=0, in_finalize=0, works=[], wait=None)
+            self._step_rec = dict(in_backward=0, in_finalize=0, works=[], wait=None, issued=[], backward_end=None)
 
     def record_comm(self, flag=True):
         self._record = bool(flag) and self.communicate
@@ -140,6 +147,12 @@ class BucketedGradReducer(object):
                "buckets_issued_in_finalize": sum(r["in_finalize"] for r in steps) / n,
                "exposed_ms": round(sum(exposed) / n, 4),
                "allreduce_ms": round(sum(allred) / n, 4) if have_dur else None}
+        # per bucket: when its collective was issued, on the compute stream's time line, relative to the end of backward
+        # (negative: that long before backward ended, i.e. that much room to hide behind it; ~0: the exposed tail)
+        offs = [[r["backward_end"].elapsed_time(ev) for ev in r["issued"]] for r in steps
+                if r.get("backward_end") is not None and len(r["issued"]) == len(self.buckets)]
+        out["bucket_issue_offsets_ms"] = ([round(sum(o[i] for o in offs) / len(offs), 3) for i in range(len(self.buckets))]
+                                          if offs else None)
         if have_dur and out["allreduce_ms"]:
             out["overlap_frac"] = round(max(0.0, 1.0 - out["exposed_ms"] / out["allreduce_ms"]), 4)
         else:
@@ -160,6 +173,10 @@ class BucketedGradReducer(object):
                 # split weight gradients whose reduction pass was deferred (utils.streams.WgradLane.reduce_batch) must be
                 # complete in this bucket before it goes out
                 streams.flush_wgrad_reductions(b["flat"].device)
+                if self._step_rec is not None and b["flat"].is_cuda:
+                    ev = torch.cuda.Event(enable_timing=True)      # where on the compute stream's time line it went out
+                    ev.record()
+                    self._step_rec["issued"].append(ev)
                 b["work"] = self._all_reduce(b["flat"])
                 if self._step_rec is not None:
                     self._step_rec["in_finalize" if force else "in_backward"] += 1
@@ -191,24 +208,39 @@ class BucketedGradReducer(object):
         if b["pending"] == 0 and not self._finalized:
             self._launch_ready()
 
-    def finalize(self, mean=True):
+    def can_hand_over_buckets(self):
+        """finalize(per_bucket=...) may be used: collectives are in flight and the set of parameters to update is known
+        before they complete (from the second step on: the ranks have agreed on the unused parameters)"""
+        return self.communicate and (self.world_size == 1 or self.static_unused is not None)
+
+    def finalize(self, mean=True, per_bucket=None):
         """reduce buckets that never completed and wait for every collective.  mean=True turns the sums into means here
         (one multiply per bucket); mean=False leaves the SUMS in the buckets and the caller applies `mean_scale` itself —
-        the fused optimizer folds it into the SGD kernel's gradient read (solver/fused_sgd.py), six launches fewer"""
+        the fused optimizer folds it into the SGD kernel's gradient read (solver/fused_sgd.py), six launches fewer.
+        per_bucket(i, bucket): called for every bucket, in order, as soon as the compute stream has been made to wait for
+        THAT bucket's collective — work the callback queues runs beside the later buckets' collectives."""
         if self._finalized:
             return
         if self.buckets:
             streams.join_wgrad_lane(self.buckets[0]["flat"].device)
+        rec = self._step_rec
+        cuda = bool(self.buckets) and self.buckets[0]["flat"].is_cuda
+        if rec is not None and cuda:
+            rec["backward_end"] = torch.cuda.Event(enable_timing=True)
+            rec["backward_end"].record()
         self._launch_ready(force=True)
+        self.mean_scale = 1.0 if (mean or self.world_size == 1) else 1.0 / self.world_size
         if self.communicate:
-            rec = self._step_rec
-            cuda = bool(self.buckets) and self.buckets[0]["flat"].is_cuda
             if rec is not None and cuda:
                 e0 = torch.cuda.Event(enable_timing=True)
                 e0.record()
-            for b in self.buckets:
+            for i, b in enumerate(self.buckets):
                 if b["work"] is not None:
                     b["work"].wait()
+                if per_bucket is not None:
+                    if mean and self.world_size > 1:
+                        b["flat"].mul_(1.0 / self.world_size)
+                    per_bucket(i, b)
             if rec is not None and cuda:
                 e1 = torch.cuda.Event(enable_timing=True)
                 e1.record()
@@ -216,10 +248,12 @@ class BucketedGradReducer(object):
             if rec is not None:
                 self._comm_steps.append(rec)
                 self._step_rec = None
-            if mean and self.world_size > 1:
+            if mean and self.world_size > 1 and per_bucket is None:
                 for b in self.buckets:
                     b["flat"].mul_(1.0 / self.world_size)
-        self.mean_scale = 1.0 if (mean or self.world_size == 1) else 1.0 / self.world_size
+        elif per_bucket is not None:
+            for i, b in enumerate(self.buckets):
+                per_bucket(i, b)
         self._finalized = True
         if self.communicate:
             if self.static_unused is None and self.learn_unused:

@@ -299,6 +299,12 @@ def test_weight_gradient_split_plan_respects_the_workgroup_slots():
             descs[i] = _C._desc(N, H, W, Cin, Cout, k, k, stride, k // 2, H, W)
         assert lib.dadet_conv_wgrad_group_plan(descs, 3, sp, nb) == 256
         assert len(set(sp)) == 1 and sp[0] == 7 and -(-25088 // sp[0]) <= 4096 + 31
+        # ... with an eighth of slack where the slots alone ask for slightly more: the same head on 256 ROIs (68 tiles,
+        # 12544 rows) stays at three parts of 4192 rows (one round of 204 workgroups) instead of four (272: a second round)
+        for i, (N, H, W, Cin, Cout, k, stride) in enumerate([(256,) + g[1:] for g in group]):
+            descs[i] = _C._desc(N, H, W, Cin, Cout, k, k, stride, k // 2, H, W)
+        assert lib.dadet_conv_wgrad_group_plan(descs, 3, sp, nb) == 256
+        assert len(set(sp)) == 1 and sp[0] == 3 and -(-12544 // sp[0]) <= 4096 + 512
         odd = (_lib.ConvDesc * 1)(_C._desc(2, 128, 256, 128, 18, 3, 3, 1, 1, 128, 256))
         assert lib.dadet_conv_wgrad_group_plan(odd, 1, sp, nb) == 0          # 18 output channels: rows padded beyond Cout
     finally:

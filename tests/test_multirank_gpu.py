@@ -105,6 +105,10 @@ def _worker(rank, world, port, case, out):
     if rccl_alone:      # the one-rank group learns the unused parameters like N ranks do: every collective overlaps backward
         assert reducer.static_unused is not None
         assert all(e == len(reducer.buckets) for e in early), (early, len(reducer.buckets))
+    if world > 1 or rccl_alone:
+        # (round 6) from the second step on the update is issued bucket by bucket, each behind its own collective
+        assert opt._bucket_plan is not None, "the per-bucket update was not taken"
+        assert sum(n for _, n, _ in opt._bucket_plan[3]) == len(reducer.update_ids())
     moved = sum(int(not torch.equal(a, p.detach())) for a, p in zip(p0, reducer.params))
     params = torch.cat([p.detach().reshape(-1).cpu() for p in reducer.params])
     out.put((rank, [s.numpy() for s in snaps], [a.numpy() for a in after], params.numpy(), moved,

@@ -198,3 +198,37 @@ def test_every_rank_leaves_when_one_rank_sees_a_nan():
     mp.spawn(_nan_worker, args=(world, port, out), nprocs=world, join=True)
     assert out[0] is False and out[1] is False
     assert out[10] is True and out[11] is True
+
+
+def _handover_worker(rank, world, port, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from da_detect_amd.parallel.reducer import BucketedGradReducer
+
+    torch.manual_seed(0)
+    model = torch.nn.Sequential(torch.nn.Linear(8, 16), torch.nn.ReLU(), torch.nn.Linear(16, 4), torch.nn.Linear(4, 2))
+    red = BucketedGradReducer(list(model.parameters()), bucket_bytes=256)
+    red.broadcast_parameters(0)
+    seen = []
+    for step in range(2):
+        red.zero_grad()
+        model(torch.full((5, 8), float(rank + 1))).pow(2).sum().backward()
+        assert red.can_hand_over_buckets() == (step > 0)       # the first step still has to agree on the unused parameters
+        # every bucket is handed over exactly once, in order, holding the SUM over ranks (mean=False) at that moment
+        red.finalize(mean=False, per_bucket=lambda i, b: seen.append((step, i, b["flat"].clone())))
+    mine = [(s, i) for s, i, _ in seen]
+    assert mine == [(s, i) for s in range(2) for i in range(len(red.buckets))], mine
+    assert red.mean_scale == 0.5
+    out[rank] = [f.tolist() for _, _, f in seen]
+    dist.destroy_process_group()
+
+
+def test_buckets_are_handed_over_in_order_with_their_reduced_sums():
+    """reducer.finalize(per_bucket=...) (round 6: the optimizer updates a bucket's tensors as soon as ITS collective is
+    complete): every bucket exactly once, in bucket order, with the same reduced contents on both ranks"""
+    world = 2
+    port = _free_port()
+    out = mp.Manager().dict()
+    mp.spawn(_handover_worker, args=(world, port, out), nprocs=world, join=True)
+    assert out[0] == out[1] and len(out[0]) >= 6
