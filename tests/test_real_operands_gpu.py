@@ -53,3 +53,39 @@ def test_mode4_per_channel_error_on_the_operands_of_a_real_step(device):
         deep_seen += int((depth > 16).sum())
     # the step does contain what the Gaussian tests lack: channels more than 16 binades below their tensor's maximum
     assert deep_seen > 0, "no deep channel in this step: the test would not exercise the format's range"
+
+
+def test_mode4_per_channel_error_after_sixty_optimizer_steps_needs_no_depth_term(device):
+    """The test above runs on step 4, whose gradient tensors still carry init-time statistics (channels 20 - 27 binades below
+    their tensor's maximum) and has to grant the format's envelope 2^(depth - 34).  VERDICT round 5, item 4, asked for
+    per-channel exponents "or prove ... they are not needed": tools/probes/real_operand_error.py after 60, 300 (512 x 1024)
+    and 1000 (1024 x 2048, profiles/r06_real_operand_channel_error_after_1000_steps.txt) optimizer steps of `da` — no operand
+    channel deeper than 24 binades any more (1000 steps: no weight-gradient channel deeper than 14), worst err_4 / err_0 over
+    shallow channels 3.6 / 3.4 / 2.9, worst relative error of ANY deep channel 3.2e-7 / 9.6e-7 / 1.4e-7.  So, after 60
+    steps, for EVERY output channel of every GEMM of the step and WITHOUT a depth term:
+        err_4[c] <= 4.5 x max(err_0[c], median err_0, 2.5e-7)
+    — mode 4 is within a small factor of the exact-fp32 kernel wherever that one is above 2.5e-7, and below 1.2e-6 in
+    relative error everywhere else (an fp32 GEMM of these lengths is at 2e-7 .. 2e-6 itself)."""
+    sys.path.insert(0, os.path.join(ROOT, "tools", "probes"))
+    if ROOT not in sys.path:
+        sys.path.insert(0, ROOT)
+    import real_operand_error as probe
+    from da_detect_amd import _C
+
+    mode = _C.get_gemm_mode()
+    try:
+        fwd, wg = probe.capture("da", (512, 1024), steps=60)
+        assert len(fwd) > 60 and len(wg) > 30
+        rows, hist = probe.analyse(fwd, wg)
+    finally:
+        _C.set_gemm_mode(mode)
+    deepest = 0.0
+    for r in rows:
+        r0, r4, depth = r["r0"], r["r4"], r["depth"]
+        bound = 4.5 * torch.maximum(torch.maximum(r0, r0.median()), torch.full_like(r0, 2.5e-7))
+        worst = int(torch.argmax(r4 / bound))
+        assert float(r4[worst]) <= float(bound[worst]), "%s %s: channel at depth %.1f: err_4 %.2e, err_0 %.2e, bound %.2e" % (
+            r["kind"], r["shape"], float(depth[worst]), float(r4[worst]), float(r0[worst]), float(bound[worst]))
+        fin = depth[torch.isfinite(depth)]
+        deepest = max(deepest, float(fin.max()) if fin.numel() else 0.0)
+    assert deepest < 26.0, "an operand channel %.1f binades below its tensor's maximum after 60 steps" % deepest
