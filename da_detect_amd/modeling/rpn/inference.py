@@ -28,6 +28,9 @@ from .utils import permute_and_flatten
 # times from one CU and then sorts 16 384 pairs in LDS).  Indices are identical; tests/test_topk_gpu.py runs the selection
 # chain both ways.  No environment switch: a caller that wants it sets the module attribute.
 _TOPK_KERNEL = False
+# single level, several images: one library sort per image (inside the per-image loop, on that image's stream) instead of
+# one segmented sort of the batch; False: the batch sort (tools/probes/variant_ab.py)
+_SORT_PER_IMAGE = True
 
 
 # one batched ranking call for all pyramid levels (dadet_topk_sorted_rows); False: one library sort per level
@@ -98,6 +101,11 @@ class RPNPostProcessor(torch.nn.Module):
             if scores_all.is_cuda and pre_nms_top_n <= _C.TOPK_SORTED_MAX and _TOPK_KERNEL:
                 # radix select + in-LDS sort of the selected scores, one launch for the batch (csrc/topk.hip)
                 sorted_scores, topk_idx = _C.topk_sorted(scores_all, pre_nms_top_n)
+            elif scores_all.is_cuda and N > 1 and _SORT_PER_IMAGE:
+                # ranked image by image inside the loop below (on the stream that image's NMS runs on): the library's sort
+                # of ONE row of 122 880 scores is 10 launches / ~70 us, its segmented sort of two rows 45 launches / ~290 us
+                # (profiles/r06_step_timeline_da.txt) — and the rows are independent.  Same indices.
+                sorted_scores = topk_idx = None
             else:
                 sorted_scores, order = torch.sort(scores_all, dim=1, descending=True, stable=True)
                 sorted_scores = sorted_scores[:, :pre_nms_top_n].contiguous()
@@ -115,9 +123,13 @@ class RPNPostProcessor(torch.nn.Module):
             im_w, im_h = anchors[i].size
             ctx = torch.cuda.stream(side) if (use_side and i % 2 == 1) else contextlib.nullcontext()
             with ctx:
-                boxes = _C.rpn_decode_clip(deltas_all[i], anchors[i].bbox.contiguous(), topk_idx[i],
+                if topk_idx is None:
+                    row_scores, row_order = torch.sort(scores_all[i], descending=True, stable=True)
+                    scores, idx_i = row_scores[:pre_nms_top_n].contiguous(), row_order[:pre_nms_top_n].contiguous()
+                else:
+                    scores, idx_i = sorted_scores[i], topk_idx[i]
+                boxes = _C.rpn_decode_clip(deltas_all[i], anchors[i].bbox.contiguous(), idx_i,
                                            self.box_coder.weights, self.box_coder.bbox_xform_clip, im_w, im_h)
-                scores = sorted_scores[i]
                 if self.min_size > 0:  # with min_size == 0 every clipped box passes (w, h >= 1)
                     keep = ((boxes[:, 2] - boxes[:, 0] + 1 >= self.min_size) &
                             (boxes[:, 3] - boxes[:, 1] + 1 >= self.min_size)).nonzero().squeeze(1)
