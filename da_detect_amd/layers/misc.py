@@ -357,7 +357,20 @@ class _AvgPoolHW(Function):
         return _C.avgpool_backward(g, *ctx.hw)
 
 
+_POOL_MEMO = True      # False: every call pools again (tools/probes/variant_ab.py)
+
+
 def global_avg_pool(x):
+    """mean over H x W -> [R, C].  A second call on the SAME tensor object (same version, same grad mode) returns the first
+    call's result: the box predictor (roi_box_predictors.py:17,28) and the instance-level domain classifier
+    (da_heads.py:402-407) both average-pool the res5 head's [R, 2048, 7, 7] output — one pooling pass, and in backward the
+    two consumers' gradients meet as [R, 2048] vectors in front of ONE un-pooling pass instead of as two 205 MB maps that
+    autograd then adds (da, 512 ROIs: -1 avgpool forward, -1 backward, -1 add of 101 us; profiles/r06_step_timeline_da.txt)."""
     if x.shape[0] == 0:
         return x.new_empty((0, x.shape[1]))
-    return _AvgPoolHW.apply(x)
+    memo = x.__dict__.get("_dadet_pooled") if _POOL_MEMO else None
+    if memo is not None and memo[0] == x._version and memo[1] == torch.is_grad_enabled():
+        return memo[2]
+    y = _AvgPoolHW.apply(x)
+    x._dadet_pooled = (x._version, torch.is_grad_enabled(), y)
+    return y
