@@ -123,10 +123,22 @@ __global__ __launch_bounds__(64) void nms_mask_kernel(const float4* __restrict__
                                                       float thresh, int col_blocks,
                                                       unsigned long long* __restrict__ mask,
                                                       unsigned long long* __restrict__ diag_t,
-                                                      unsigned long long* __restrict__ adj_t) {
+                                                      unsigned long long* __restrict__ adj_t,
+                                                      unsigned long long* __restrict__ blk_t) {
   // linear block id -> (row_block <= col_block) pair
   const int row_start = blockIdx.y, col_start = blockIdx.x;
   if (col_start < row_start) return;
+  // blk_t (nms_sweep_block_kernel): per box eight words — which boxes of the PREVIOUS 256-box block (words 0 - 3) and of
+  // its OWN block before it (words 4 - 7) suppress it; row chunks 4 (B - 1) .. c of column chunk c (B = c / 4) fill them,
+  // the diagonal tile zeroes what no tile writes (chunks behind c in its block; the previous block of block 0)
+  const int blk_first = 4 * (col_start / 4 - 1);
+  const bool want_b = blk_t && row_start >= blk_first;
+  if (blk_t && row_start == col_start && (int)threadIdx.x < min(n - col_start * 64, 64)) {
+    unsigned long long* mine = blk_t + (size_t)(col_start * 64 + threadIdx.x) * 8;
+    for (int q = col_start % 4 + 1; q < 4; ++q) mine[4 + q] = 0ULL;
+    if (blk_first < 0)
+      for (int q = 0; q < 4; ++q) mine[q] = 0ULL;
+  }
   // row n of the matrix: all zeros, what the sweep loads for "no kept box in this slot"
   if (row_start == 0 && col_start == 0)
     for (int i = threadIdx.x; i < col_blocks; i += 64) mask[(size_t)n * col_blocks + i] = 0ULL;
@@ -136,7 +148,7 @@ __global__ __launch_bounds__(64) void nms_mask_kernel(const float4* __restrict__
   __shared__ float carea[64];
   __shared__ float4 rb[64];
   __shared__ float rarea[64];
-  const bool want_t = diag_t && (col_start == row_start || col_start == row_start + 1);
+  const bool want_t = (diag_t && (col_start == row_start || col_start == row_start + 1)) || want_b;
   if ((int)threadIdx.x < col_size) {
     const float4 b = sorted[col_start * 64 + threadIdx.x];
     cb[threadIdx.x] = b;
@@ -164,7 +176,9 @@ __global__ __launch_bounds__(64) void nms_mask_kernel(const float4* __restrict__
       const bool sup = (TIE_RULE == 0) ? (ovr >= thresh) : (ovr > thresh);
       if (sup) t |= 1ULL << i;
     }
-    (row_start == col_start ? diag_t : adj_t)[col_start * 64 + threadIdx.x] = t;
+    if (diag_t && (col_start == row_start || col_start == row_start + 1))
+      (row_start == col_start ? diag_t : adj_t)[col_start * 64 + threadIdx.x] = t;
+    if (want_b) blk_t[(size_t)(col_start * 64 + threadIdx.x) * 8 + (row_start - blk_first)] = t;
   }
   if ((int)threadIdx.x < row_size) {
     const int cur = row_start * 64 + threadIdx.x;
@@ -439,6 +453,143 @@ __global__ __launch_bounds__(256) void nms_sweep_pipelined_kernel(const unsigned
   if (w < col_blocks) keep_bits[w] = s_keep_all[w];
 }
 
+// ---- greedy sweep in blocks of 256 boxes (round 6) ---------------------------------------------------------------
+// nms_sweep_pipelined_kernel resolves 64 boxes per iteration on ONE wave (two barriers, the wave's fixed-point rounds, LDS
+// hand-overs: ~1.2 us per chunk, 188 chunks for 12 000 boxes: 0.22 ms, the longest kernel between the RPN head and the box
+// head).  Here all four waves resolve a BLOCK of 256 boxes together: lane = box, blk_t holds its eight transposed words
+// (suppressors in the previous block / in its own block before it), the greedy keep set is the same fixed point
+// K <- alive & ~suppressed_by(K) over the 256 x 256 strictly upper triangular tile — the four waves exchange their K words
+// through LDS, one barrier (with an OR reduction of "changed") per round, as many rounds as the longest suppression chain in
+// the block.  Everything else is the pipelined kernel's scheme at block granularity: thread w owns word w of the removed set;
+// the words of block B's kept rows are issued when B is resolved and consumed two blocks later (block B + 1 sees B through
+// the transposed previous-block words), the first kSlots of them in flight across the next block's resolution.
+// Same keep bits as the other two sweeps (tests/test_ops_gpu.py: all three against the CPU oracle; DADET_NMS_SWEEP=1 / 0).
+// MEASURED (round 6): alone on the GPU the two pipelined sweeps take the same time (tools/nms_time.py: 0.20 ms per NMS of
+// 12 000 boxes with a quota of 2000, mask kernel included) — what bounds them is not the resolution but the chain "resolve a
+// block -> fetch its kept rows (1.5 KB each, ~3 MB per NMS, HBM latency, one workgroup: ~50 GB/s) -> two blocks later";
+// inside the training step, beside the GEMM waves, fewer barriers are worth 0.03 (img_only) to 0.07 ms (da).
+__global__ __launch_bounds__(256) void nms_sweep_block_kernel(const unsigned long long* __restrict__ mask,
+                                                              const unsigned long long* __restrict__ blk_t, int n,
+                                                              int col_blocks, int max_keep,
+                                                              unsigned long long* __restrict__ keep_bits) {
+  constexpr int kSlots = 24;
+  __shared__ unsigned long long s_removed[4];     // removed words of the current block from blocks <= B - 2
+  __shared__ unsigned long long s_K[2][4];        // the fixed point's keep words, double buffered
+  __shared__ unsigned long long s_prevK[4];       // block B - 1's kept set
+  __shared__ int s_kept_total;
+  __shared__ unsigned s_rows[256 + kSlots];       // byte offsets of the current block's kept rows, rank order; rest: zero row
+  __shared__ unsigned long long s_keep_all[264];
+  const int w = threadIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const unsigned pitch = (unsigned)col_blocks * 8u;
+  const unsigned zero_row = (unsigned)n * pitch;
+  const char* mcol = reinterpret_cast<const char*>(mask + min(w, col_blocks - 1));
+  auto word_at = [&](const unsigned row_bytes) { return *reinterpret_cast<const unsigned long long*>(mcol + row_bytes); };
+  const unsigned long long* zrow = mask + (size_t)n * (size_t)col_blocks;
+  const int nblk = (col_blocks + 3) / 4;
+  unsigned long long removed = 0;
+  unsigned long long fly_a[kSlots], fly_b[kSlots];
+  unsigned long long t_even[8], t_odd[8];          // this lane's transposed words of the next even / odd block
+  if (threadIdx.x == 0) s_kept_total = 0;
+  if (threadIdx.x < 4) s_prevK[threadIdx.x] = 0ULL;
+  for (int i = threadIdx.x; i < 256 + kSlots; i += blockDim.x) s_rows[i] = zero_row;
+  for (int i = threadIdx.x; i < 264; i += blockDim.x) s_keep_all[i] = 0ULL;
+  // the prologue issues exactly the loop's load sequence (see nms_sweep_pipelined_kernel on vmcnt): transposed words of
+  // the even block, kSlots row words, transposed words of the odd block, kSlots row words — all unconditional
+  auto load_t = [&](unsigned long long (&t)[8], const int blk) {
+    const unsigned long long* src = blk_t + (size_t)min(blk * 256 + w, n - 1) * 8;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) t[q] = src[q];
+  };
+  load_t(t_even, 0);
+#pragma unroll
+  for (int u = 0; u < kSlots; ++u) fly_a[u] = zrow[min(u, col_blocks - 1)];
+  load_t(t_odd, 1);
+#pragma unroll
+  for (int u = 0; u < kSlots; ++u) fly_b[u] = zrow[min(u, col_blocks - 1)];
+  __syncthreads();
+  auto step = [&](const int B, unsigned long long (&fly)[kSlots], unsigned long long (&t)[8]) {
+    {
+      unsigned long long acc = 0;
+#pragma unroll
+      for (int u = 0; u < kSlots; ++u) acc |= fly[u];
+      removed |= acc;
+    }
+    if ((w >> 2) == B) s_removed[w & 3] = removed;        // blocks <= B - 2 (block B - 1's part comes through t[0..3])
+    __syncthreads();
+    const int box = B * 256 + w;
+    const bool in_range = box < n;
+    const bool pushed = (s_removed[wave] >> lane) & 1ULL;
+    const bool alive_i = in_range && !pushed &&
+                         ((t[0] & s_prevK[0]) | (t[1] & s_prevK[1]) | (t[2] & s_prevK[2]) | (t[3] & s_prevK[3])) == 0ULL;
+    unsigned long long K = __ballot(alive_i);
+    int buf = 0;
+    if (lane == 0) s_K[0][wave] = K;
+    s_rows[w] = zero_row;                 // (the previous block's row loads were issued before the barrier above)
+    __syncthreads();
+    // fixed point over the block: a box is kept iff alive and no kept box before it (own block) suppresses it
+    for (int it = 0; it < 256; ++it) {
+      const unsigned long long sup = (t[4] & s_K[buf][0]) | (t[5] & s_K[buf][1]) | (t[6] & s_K[buf][2]) | (t[7] & s_K[buf][3]);
+      const unsigned long long Kn = __ballot(alive_i && sup == 0ULL);
+      if (lane == 0) s_K[buf ^ 1][wave] = Kn;
+      const int changed = __syncthreads_or(Kn != K);
+      K = Kn;
+      buf ^= 1;
+      if (!changed) break;
+    }
+    unsigned long long k0 = s_K[buf][0], k1 = s_K[buf][1], k2 = s_K[buf][2], k3 = s_K[buf][3];
+    auto before_me = [&]() {      // kept boxes of the block in front of this lane's box
+      int r = __popcll(K & ((1ULL << lane) - 1ULL));
+      if (wave > 0) r += __popcll(k0);
+      if (wave > 1) r += __popcll(k1);
+      if (wave > 2) r += __popcll(k2);
+      return r;
+    };
+    int kept_total = s_kept_total;
+    int cnt = __popcll(k0) + __popcll(k1) + __popcll(k2) + __popcll(k3);
+    if (max_keep > 0 && kept_total + cnt > max_keep) {
+      // quota: the first (max_keep - kept_total) of them — later boxes never influence earlier ones
+      const int room = max(max_keep - kept_total, 0);
+      const bool mine = ((K >> lane) & 1ULL) && before_me() < room;
+      __syncthreads();                                     // everybody has read s_K[buf]
+      K = __ballot(mine);
+      if (lane == 0) s_K[buf][wave] = K;
+      __syncthreads();
+      k0 = s_K[buf][0]; k1 = s_K[buf][1]; k2 = s_K[buf][2]; k3 = s_K[buf][3];
+      cnt = __popcll(k0) + __popcll(k1) + __popcll(k2) + __popcll(k3);
+    }
+    if ((K >> lane) & 1ULL) s_rows[before_me()] = (unsigned)box * pitch;
+    __syncthreads();                                       // s_kept_total / s_prevK read by everybody above
+    if (lane == 0) {
+      s_prevK[wave] = K;
+      s_keep_all[B * 4 + wave] = K;
+    }
+    if (threadIdx.x == 0) s_kept_total = kept_total + cnt;
+    // a block that keeps more than kSlots boxes: the rest at once, waited for here
+    for (int base = kSlots; base < cnt; base += kSlots) {
+      unsigned long long tt[kSlots];
+#pragma unroll
+      for (int u = 0; u < kSlots; ++u) tt[u] = word_at(s_rows[min(base + u, 256 + kSlots - 1)]);
+      unsigned long long acc = 0;
+#pragma unroll
+      for (int u = 0; u < kSlots; ++u) acc |= tt[u];
+      removed |= acc;
+    }
+    // transposed words of block B + 2, then the first kSlots kept rows: consumed two iterations on
+    load_t(t, B + 2);
+#pragma unroll
+    for (int u = 0; u < kSlots; ++u) fly[u] = word_at(s_rows[u]);
+  };
+  int b_end = nblk;
+  for (int B = 0; B < b_end; B += 2) {
+    step(B, fly_a, t_even);
+    step(B + 1, fly_b, t_odd);          // (B + 1 == nblk: an empty block — nothing in range, keeps nothing)
+    __syncthreads();
+    b_end = (max_keep > 0 && s_kept_total >= max_keep) ? 0 : nblk;
+  }
+  __syncthreads();
+  if (w < col_blocks) keep_bits[w] = s_keep_all[w];
+}
+
 // ---- compaction to ascending original indices ----------------------------------------------
 __global__ void nms_flag_kernel(const unsigned long long* __restrict__ keep_bits,
                                 const int* __restrict__ order, int n, unsigned char* __restrict__ flag) {
@@ -482,7 +633,7 @@ static int next_pow2(int n) {
 }
 
 struct NmsWorkspace {
-  size_t order_off, sorted_off, mask_off, keepbits_off, flag_off, diagt_off, adjt_off, keys_off, total;
+  size_t order_off, sorted_off, mask_off, keepbits_off, flag_off, diagt_off, adjt_off, blkt_off, keys_off, total;
 };
 
 static NmsWorkspace nms_layout(int n) {
@@ -497,6 +648,7 @@ static NmsWorkspace nms_layout(int n) {
   ws.flag_off = off;     off = align(off + (size_t)n);
   ws.diagt_off = off;    off = align(off + sizeof(unsigned long long) * (size_t)col_blocks * 64);
   ws.adjt_off = off;     off = align(off + sizeof(unsigned long long) * (size_t)col_blocks * 64);
+  ws.blkt_off = off;     off = align(off + sizeof(unsigned long long) * (size_t)col_blocks * 64 * 8);
   ws.keys_off = off;
   const int p2 = next_pow2(n);
   if (p2 > kSortLdsMax) off = align(off + sizeof(Key) * (size_t)p2);
@@ -543,6 +695,7 @@ extern "C" int dadet_nms(const float* boxes_xyxy, const float* scores, int n, fl
   unsigned char* flag = reinterpret_cast<unsigned char*>(base + ws.flag_off);
   unsigned long long* diag_t = reinterpret_cast<unsigned long long*>(base + ws.diagt_off);
   unsigned long long* adj_t = reinterpret_cast<unsigned long long*>(base + ws.adjt_off);
+  unsigned long long* blk_t = reinterpret_cast<unsigned long long*>(base + ws.blkt_off);
 
   const int p2 = next_pow2(n);
   if (presorted) {
@@ -575,17 +728,21 @@ extern "C" int dadet_nms(const float* boxes_xyxy, const float* scores, int n, fl
                        reinterpret_cast<const float4*>(boxes_xyxy), order, n, sorted);
   const dim3 mgrid(col_blocks, col_blocks);
   const int sweep_threads = col_blocks <= 64 ? 64 : ((col_blocks + 63) / 64) * 64;
-  static const bool plain_sweep = getenv("DADET_NMS_SWEEP") && getenv("DADET_NMS_SWEEP")[0] == '0';
-  // the pipelined sweep holds 64 loads per thread (256-thread workgroup): up to 16 384 boxes; it reads the transposed
-  // diagonal / next-block tiles the mask kernel then also writes
-  const bool pipelined = !plain_sweep && sweep_threads <= 256;
+  // DADET_NMS_SWEEP: 0 = the plain sweep, 1 = the chunk-pipelined sweep of round 3, otherwise (default) the 256-box block
+  // sweep of round 6; the latter two hold 48 loads per thread in a 256-thread workgroup: up to 16 384 boxes
+  const char* sweep_env = getenv("DADET_NMS_SWEEP");       // read per call: tests run all three sweeps in one process
+  const int sweep_kind = sweep_env ? atoi(sweep_env) : 2;
+  const bool pipelined = sweep_kind == 1 && sweep_threads <= 256;
+  const bool blocked = sweep_kind >= 2 && sweep_threads <= 256;
   if (tie_rule == 0)
     hipLaunchKernelGGL(nms_mask_kernel<0>, mgrid, dim3(64), 0, st, sorted, n, thresh, col_blocks, mask,
-                       pipelined ? diag_t : nullptr, adj_t);
+                       pipelined ? diag_t : nullptr, adj_t, blocked ? blk_t : nullptr);
   else
     hipLaunchKernelGGL(nms_mask_kernel<1>, mgrid, dim3(64), 0, st, sorted, n, thresh, col_blocks, mask,
-                       pipelined ? diag_t : nullptr, adj_t);
-  if (!pipelined)
+                       pipelined ? diag_t : nullptr, adj_t, blocked ? blk_t : nullptr);
+  if (blocked)
+    hipLaunchKernelGGL(nms_sweep_block_kernel, dim3(1), dim3(256), 0, st, mask, blk_t, n, col_blocks, max_keep, keep_bits);
+  else if (!pipelined)
     hipLaunchKernelGGL(nms_sweep_kernel, dim3(1), dim3(sweep_threads), 0, st, mask, n, col_blocks, max_keep,
                        keep_bits);
   else

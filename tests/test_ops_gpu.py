@@ -72,6 +72,35 @@ def test_nms_max_keep_on_sorted_input(device):
     assert np.array_equal(got, want)
 
 
+@pytest.mark.parametrize("n,max_side,max_keep", [(12000, 150, 2000), (12000, 150, -1), (12000, 600, 2000), (5001, 80, 700),
+                                                 (16384, 60, -1), (300, 200, 50), (257, 400, -1), (70, 300, 3)])
+@pytest.mark.parametrize("tie_rule", [0, 1])
+def test_nms_three_sweeps_agree_with_the_oracle(device, monkeypatch, n, max_side, max_keep, tie_rule):
+    """DADET_NMS_SWEEP = 0 (plain), 1 (chunk-pipelined, round 3), default (256-box blocks resolved by four waves, round 6):
+    the same kept indices, equal to the CPU oracle's (nms_cpu.cpp:6-75 restated) — crowded and sparse box sets (long and
+    short suppression chains inside a block), counts that are not multiples of 64 / 256, quotas that end inside a block, an
+    odd number of blocks, the 16 384-box limit of the one-workgroup sweeps"""
+    from da_detect_amd import _C
+    from oracle import ops as O
+
+    rng = np.random.default_rng(n + 3 * tie_rule + max_side)
+    boxes = _rand_boxes(rng, n, max_side=max_side)
+    if n > 1000:      # a crowded region: many boxes of one block suppress each other in chains
+        boxes[: n // 3, :2] = boxes[: n // 3, :2] % 300
+        boxes[: n // 3, 2:] = boxes[: n // 3, :2] + rng.uniform(20, 90, (n // 3, 2)).astype(np.float32)
+    scores = np.sort(rng.uniform(0, 1, n).astype(np.float32))[::-1].copy()
+    want = O.nms(boxes, scores, 0.7, tie_rule)
+    if max_keep > 0:
+        want = want[:max_keep]
+    b, sc = torch.from_numpy(boxes).to(device), torch.from_numpy(scores).to(device)
+    for kind in ("0", "1", "2"):
+        monkeypatch.setenv("DADET_NMS_SWEEP", kind)
+        for presorted in (False, True):
+            keep, count = _C.nms_with_count(b, None if presorted else sc, 0.7, max_keep=max_keep, tie_rule=tie_rule)
+            got = keep[: int(count.item())].cpu().numpy()
+            assert np.array_equal(got, want), "sweep %s (presorted %s): %d kept, oracle %d" % (kind, presorted, len(got), len(want))
+
+
 def test_nms_empty(device):
     from da_detect_amd import _C
 
