@@ -137,13 +137,13 @@ FAMILIES = [("fwd_dgrad_256x256", ("conv_big_kernel<256>",)), ("fwd_dgrad_256x12
 
 
 def pmc_traffic(kernel_name, gemm_mode):
-    """HBM bytes per launch of `kernel_name` from the committed PMC passes (profiles/r04_pmc_hbm_traffic[_mode4].json,
+    """HBM bytes per launch of `kernel_name` from the committed PMC passes (profiles/r06_pmc_hbm_traffic.json; mode 3: r04_pmc_hbm_traffic.json,
     made by tools/profile_pmc.sh from this same bench command in that mode; counters cannot be read from inside the
     process).  The 128x128-tile family is launched in two forms with the same tile body — conv_fwd_split_kernel<2,2,M>
     and, where the tile grid leaves a partly empty last pass, conv_fwd_split_sk_kernel<M> (stream-K tail) — and the in-process
     timer brackets both under one name: the figure is the launch-weighted mean over both.  None when the summary does
     not cover the kernel / mode."""
-    path = os.path.join(ROOT, "profiles", {3: "r04_pmc_hbm_traffic.json", 4: "r05_pmc_hbm_traffic.json"}.get(
+    path = os.path.join(ROOT, "profiles", {3: "r04_pmc_hbm_traffic.json", 4: "r06_pmc_hbm_traffic.json"}.get(
         gemm_mode, "none"))
     if not os.path.exists(path):
         return None, None

@@ -51,6 +51,7 @@ python tools/gemm_table.py --workload img_only --steps 3 --top 60 --holes > gpur
 python tools/gemm_table.py --workload img_only --steps 3 --top 60 > gpurun_out/${TAG}_gemm_table_per_shape.txt 2>&1
 python tools/gemm_table.py --workload fpn_dcn_da --steps 3 --top 80 --holes > gpurun_out/${TAG}_gemm_table_fpn_dcn_da.txt 2>&1; tail -3 gpurun_out/${TAG}_gemm_table_fpn_dcn_da.txt
 python tools/gemm_table.py --workload da --steps 3 --top 60 > gpurun_out/${TAG}_gemm_table_da.txt 2>&1
+python tools/gemm_table.py --workload fpn_dcn_da --steps 3 --top 90 > gpurun_out/${TAG}_gemm_table_per_shape_fpn_dcn_da.txt 2>&1
 echo "=== R-101-FPN-DCN bench line"
 python bench.py --workload fpn_dcn_da --others none --no-cpu-baseline > gpurun_out/${TAG}_bench_fpn_dcn_da.json 2>/dev/null; tail -1 gpurun_out/${TAG}_bench_fpn_dcn_da.json | cut -c1-200
 echo "=== two ranks on one GPU over gloo (functional rig: the N > 1 line with its comm block)"
