@@ -118,6 +118,24 @@ __global__ void nms_gather_boxes_kernel(const float4* __restrict__ boxes, const 
 // (MEASURED, round 3: four tiles per 256-thread workgroup over a triangular grid — 4442 workgroups instead of 35 344 one-
 // wavefront ones, half of which return at once — changes nothing, 0.192 vs 0.186 ms per NMS: the kernel is bound by its
 // VALU work, 64 IEEE divisions per lane and tile, not by the dispatch rate.)
+// "IoU against the threshold" without the division wherever the answer is not within rounding of the threshold.  The
+// reference decides fl(inter / u) >= thresh (CPU rule; > for the CUDA rule) with u = fl(fl(area_a + area_b) - inter).  With
+// p = fl(thresh * u): inter >= p (1 + 2^-20) puts the exact quotient above thresh (1 + 2^-21), whose rounding cannot come
+// down to thresh; inter <= p (1 - 2^-20) puts it below thresh (1 - 2^-21), whose rounding cannot come up to it — in both
+// cases the IEEE quotient's comparison is known.  Anything in between (a band of 2^-19 around the threshold) takes the
+// division, so every decision is the reference's bit for bit (tests/test_ops_gpu.py: near-tie pairs against the oracle).
+// The division was ~half of the mask kernel's VALU time (64 per lane and tile).
+template <int TIE_RULE>
+__device__ __forceinline__ bool iou_suppresses(const float inter, const float u, const float thresh) {
+  if (u > 0.f && thresh > 0.f) {        // (degenerate boxes — u <= 0 — and NaNs take the division: whatever it gives is the rule)
+    const float p = thresh * u;
+    if (inter >= p * (1.0f + 0x1p-20f)) return true;
+    if (inter <= p * (1.0f - 0x1p-20f)) return false;
+  }
+  const float ovr = inter / u;
+  return (TIE_RULE == 0) ? (ovr >= thresh) : (ovr > thresh);
+}
+
 template <int TIE_RULE>
 __global__ __launch_bounds__(64) void nms_mask_kernel(const float4* __restrict__ sorted, int n,
                                                       float thresh, int col_blocks,
@@ -172,9 +190,7 @@ __global__ __launch_bounds__(64) void nms_mask_kernel(const float4* __restrict__
       const float xx2 = fminf(a.z, b.z), yy2 = fminf(a.w, b.w);
       const float w = fmaxf(0.f, xx2 - xx1 + 1.f), h = fmaxf(0.f, yy2 - yy1 + 1.f);
       const float inter = w * h;
-      const float ovr = inter / (rarea[i] + barea - inter);
-      const bool sup = (TIE_RULE == 0) ? (ovr >= thresh) : (ovr > thresh);
-      if (sup) t |= 1ULL << i;
+      if (iou_suppresses<TIE_RULE>(inter, rarea[i] + barea - inter, thresh)) t |= 1ULL << i;
     }
     if (diag_t && (col_start == row_start || col_start == row_start + 1))
       (row_start == col_start ? diag_t : adj_t)[col_start * 64 + threadIdx.x] = t;
@@ -192,9 +208,7 @@ __global__ __launch_bounds__(64) void nms_mask_kernel(const float4* __restrict__
       const float xx2 = fminf(a.z, b.z), yy2 = fminf(a.w, b.w);
       const float w = fmaxf(0.f, xx2 - xx1 + 1.f), h = fmaxf(0.f, yy2 - yy1 + 1.f);
       const float inter = w * h;
-      const float ovr = inter / (iarea + carea[i] - inter);
-      const bool sup = (TIE_RULE == 0) ? (ovr >= thresh) : (ovr > thresh);
-      if (sup) t |= 1ULL << i;
+      if (iou_suppresses<TIE_RULE>(inter, iarea + carea[i] - inter, thresh)) t |= 1ULL << i;
     }
     mask[(size_t)cur * col_blocks + col_start] = t;
   }

@@ -101,6 +101,49 @@ def test_nms_three_sweeps_agree_with_the_oracle(device, monkeypatch, n, max_side
             assert np.array_equal(got, want), "sweep %s (presorted %s): %d kept, oracle %d" % (kind, presorted, len(got), len(want))
 
 
+@pytest.mark.parametrize("tie_rule", [0, 1])
+def test_nms_near_threshold_pairs_and_degenerate_boxes_decide_as_the_oracle(device, tie_rule):
+    """the mask kernel compares inter with thresh * union and divides only inside a band of 2^-19 around the threshold
+    (csrc/nms.hip: iou_suppresses): pairs whose IoU lies within a few ulps of 0.7 — found by search, one pair per well
+    separated cell so that each decision shows in the kept set — and degenerate boxes (zero / negative extent: the
+    reference's quotient is then 0, negative or NaN) must come out as from the reference's division"""
+    from da_detect_amd import _C
+    from oracle import ops as O
+
+    rng = np.random.default_rng(5 + tie_rule)
+    thr = np.float32(0.7)
+    pairs = []
+    # a box [0, 0, w, h] against itself shifted by dx: IoU sweeps through 0.7 as dx grows; keep the shifts that land near it
+    while len(pairs) < 600:
+        w, h = rng.uniform(20, 120, 2).astype(np.float32)
+        a = np.array([0, 0, w, h], np.float32)
+        dx0 = (w + 1) * 0.3 / 1.7
+        for dx in (np.float32(dx0) + np.arange(-40, 41, dtype=np.float32) * np.float32(2.0 ** -14) * np.float32(w)):
+            b = a + np.array([dx, 0, dx, 0], np.float32)
+            inter = np.float32(max(np.float32(0), min(a[2], b[2]) - max(a[0], b[0]) + np.float32(1))) * np.float32(h + 1)
+            aa = np.float32(a[2] - a[0] + 1) * np.float32(a[3] - a[1] + 1)
+            ab = np.float32(b[2] - b[0] + 1) * np.float32(b[3] - b[1] + 1)
+            ovr = inter / np.float32(np.float32(aa + ab) - inter)
+            if abs(float(ovr) - 0.7) < 3e-6:
+                pairs.append((a.copy(), b.copy()))
+    boxes = []
+    for i, (a, b) in enumerate(pairs):
+        ox, oy = np.float32(300 * (i % 40)), np.float32(200 * (i // 40))
+        boxes += [a + [ox, oy, ox, oy], b + [ox, oy, ox, oy]]
+    boxes = np.asarray(boxes, np.float32)
+    # degenerate boxes far away from everything else, overlapping each other
+    deg = np.array([[20000, 20000, 19990, 20010], [20000, 20000, 19995, 20005], [20001, 20001, 20001, 20001],
+                    [20001, 20001, 20001, 20001], [20000, 20005, 20010, 20000]], np.float32)
+    boxes = np.concatenate([boxes, deg])
+    scores = np.linspace(1, 0, len(boxes)).astype(np.float32)
+    want = O.nms(boxes, scores, float(thr), tie_rule)
+    kept_seconds = sum(1 for k in want if k % 2 == 1 and k < 2 * len(pairs))
+    assert 50 < kept_seconds < len(pairs) - 50, "the pairs do not straddle the threshold (%d of %d kept)" % (kept_seconds, len(pairs))
+    keep, count = _C.nms_with_count(torch.from_numpy(boxes).to(device), torch.from_numpy(scores).to(device), float(thr),
+                                    tie_rule=tie_rule)
+    assert np.array_equal(keep[: int(count)].cpu().numpy(), want)
+
+
 def test_nms_empty(device):
     from da_detect_amd import _C
 
