@@ -25,6 +25,8 @@ for it in range(steps):
     if it % 50 == 0 or it == steps - 1:
         torch.cuda.synchronize()
         tot = float(sum(v.detach() for v in loss.values()))
+        from da_detect_amd import _C
+        _C.check_nonfinite()      # the GEMMs' guard (also reports a two-part meeting that timed out, csrc/conv_big.hip)
         print("it %4d  loss %.4f  alloc %.2f GB  reserved %.2f GB  %.1f ms/it" % (
             it, tot, torch.cuda.memory_allocated() / 2**30, torch.cuda.memory_reserved() / 2**30,
             (time.perf_counter() - t0) / (it + 1) * 1e3), flush=True)
