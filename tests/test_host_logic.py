@@ -460,3 +460,32 @@ def test_crowded_images_take_the_unbounded_sampler_path():
     base = ev.accepts_pending()
     assert ev.accepts_pending([target(8), target(_C.PROPOSALS_SAMPLE_MAX_GT)]) == base
     assert ev.accepts_pending([target(8), target(_C.PROPOSALS_SAMPLE_MAX_GT + 1)]) is False
+
+
+def test_large_tile_plan_of_the_forward_and_data_gradient_gemms():
+    """csrc/conv_big.hip: big_variant through dadet_conv_forward_variant (no launch): which tile serves a layer under the
+    default contraction — 3: weight-stationary (K <= 256 1x1), 4: 256 x 256 tile, 5: 256 x 128 tile, 0 - 2: the 128-wide
+    kernels.  Round 6: 129 .. 256 output channels go to the 256 x 256 tile when one column of tiles fills the chip (>= 96 row
+    tiles: the pyramid's P2 / P3 layers), and stay on the 256 x 128 tile below that (res4: 64 row tiles)."""
+    import ctypes
+
+    from da_detect_amd import _C, _lib
+
+    lib = _lib.load()
+    if lib.dadet_get_gemm_mode() != 4 or lib.dadet_get_big_gemm() != 1:
+        import pytest
+        pytest.skip("not the default contraction / plan")
+
+    def variant(N, H, W, Cin, Cout, k):
+        d = _C._desc(N, H, W, Cin, Cout, k, k, 1, k // 2, H, W)
+        return lib.dadet_conv_forward_variant(ctypes.byref(d))
+
+    assert variant(2, 256, 512, 256, 256, 3) == 4        # P2 3x3: 1024 row tiles x 1
+    assert variant(2, 128, 256, 256, 256, 3) == 4        # P3 3x3: 256 row tiles
+    assert variant(2, 128, 256, 512, 256, 1) == 4        # C3 lateral, K = 512
+    assert variant(2, 64, 128, 256, 256, 3) == 5         # res4 3x3: 64 row tiles -> 256 x 128 tile, two K parts
+    assert variant(2, 64, 128, 1024, 256, 1) == 5        # res4 conv1
+    assert variant(2, 128, 256, 128, 128, 3) == 5        # res3 3x3: 128 channels never take the wide tile
+    assert variant(256, 7, 7, 512, 512, 3) == 4          # res5 3x3 on 256 ROIs
+    assert variant(2, 64, 128, 256, 1024, 1) == 3        # K = 256 1x1: weight-stationary
+    assert variant(2, 256, 512, 64, 64, 3) in (0, 1, 2)  # res2: the 128-wide kernels
