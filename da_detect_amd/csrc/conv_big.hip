@@ -90,6 +90,30 @@ __device__ __forceinline__ int div_small(const int m, const int d, const float r
 }
 }  // namespace
 
+// Which (tile, K part) this workgroup computes and into how many parts its tile's reduction is cut.  Uniform cut
+// (big_body == 0): T * S workgroups, XCD-aware order over (part, tile).  Tail cut (big_body > 0, a multiple of 8): the first
+// big_body workgroups take one whole tile each, the rest share the tiles of the partly filled last round, S parts each —
+// the two ranges are placed on the XCDs separately, so that every XCD gets its share of both.
+__device__ __forceinline__ void big_place(const ConvArgs& a, const int T, int& S, int& part, int& tile) {
+  const int body = a.big_body;
+  if (body == 0) {
+    S = a.big_splits;
+    const int lid = xcd_remap(blockIdx.x, T * S);
+    part = lid / T;
+    tile = lid - part * T;
+  } else if ((int)blockIdx.x < body) {
+    S = 1;
+    part = 0;
+    tile = xcd_remap(blockIdx.x, body);
+  } else {
+    S = a.big_splits;
+    const int tt = T - body;
+    const int r = xcd_remap((int)blockIdx.x - body, tt * S);
+    part = r / tt;
+    tile = body + (r - part * tt);
+  }
+}
+
 // ---- pieces of what follows a tile's K loop, over the accumulator row blocks [LO, HI) of a wave ------------------------
 // park: lane-linear, 16 bytes per lane and store, written through to memory: row block im as SLOT im - LO + SLOT0 (slot j,
 // column block in, quarter g at ((j * TN + in) * 4 + g) * 8192 behind the lane's 16 bytes of the part's area)
@@ -255,9 +279,9 @@ __device__ __forceinline__ float big_epilogue(const ConvArgs& a, const f32x16 (&
 // has started.)  Nothing is ever reset: per launch and tile `started` moves by two and the flags carry the epoch
 // (started / 2 + 1); launches that share the words are ordered on their stream, also when a captured graph replays them.
 // sk_counters + 4096 + 4 * tile: started | flag of part 0 | flag of part 1 | unused.
-__device__ __forceinline__ unsigned big_announce(const ConvArgs& a, const int tile) {
+__device__ __forceinline__ unsigned big_announce(const ConvArgs& a, const int tile, const int S) {
   unsigned prev = 0;
-  if (a.big_splits == 2 && !a.big_asym && threadIdx.x == 0)
+  if (S == 2 && !a.big_asym && threadIdx.x == 0)
     prev = __hip_atomic_fetch_add(reinterpret_cast<unsigned*>(a.sk_counters) + 4096 + 4 * tile, 1u, __ATOMIC_RELAXED,
                                   __HIP_MEMORY_SCOPE_AGENT);
   return prev;
@@ -267,6 +291,7 @@ template <int TM, int TN, int BN>
 __device__ __forceinline__ void big_finish(const ConvArgs& a, const f32x16 (&acc_t)[TM][TN], char* smem, const int tile,
                                            const int part, const int S, const int row0, const int col0, const int ea,
                                            const int eb, const unsigned* meet_word) {
+  const int wtile = tile - a.big_body;      // the tile's place in the parked-part workspace (only cut tiles have one)
   const int t = threadIdx.x;
   constexpr int H = TM / 2;
   // From here on the sums live in NEW register tuples: the (vector) multiplication that undoes the operand scales defines
@@ -298,7 +323,7 @@ __device__ __forceinline__ void big_finish(const ConvArgs& a, const f32x16 (&acc
     __syncthreads();                                    // ... before one lane announces them
   };
   if (S == 2 && !a.big_asym) {
-    const __amdgpu_buffer_rsrc_t pr = make_rsrc(a.sk_ws + (size_t)tile * 2 * (256 * BN), (unsigned)(2 * 256 * BN * 4));
+    const __amdgpu_buffer_rsrc_t pr = make_rsrc(a.sk_ws + (size_t)wtile * 2 * (256 * BN), (unsigned)(2 * 256 * BN * 4));
     unsigned* cnt = reinterpret_cast<unsigned*>(a.sk_counters) + 4096 + 4 * tile;   // started | flag 0 | flag 1
     const unsigned mine = (unsigned)part * (256 * BN * 4) + (unsigned)t * 16u;
     const unsigned theirs = (unsigned)(part ^ 1) * (256 * BN * 4) + (unsigned)t * 16u;
@@ -357,7 +382,7 @@ __device__ __forceinline__ void big_finish(const ConvArgs& a, const f32x16 (&acc
     }
     __syncthreads();      // s_word is about to be reused as transpose space
   } else if (S > 1) {
-    const __amdgpu_buffer_rsrc_t pr = make_rsrc(a.sk_ws + (size_t)tile * S * (256 * BN), (unsigned)(S * 256 * BN * 4));
+    const __amdgpu_buffer_rsrc_t pr = make_rsrc(a.sk_ws + (size_t)wtile * S * (256 * BN), (unsigned)(S * 256 * BN * 4));
     int* arrive = a.sk_counters + tile;
     int* parked = a.sk_counters + 2048 + tile;
     if (t == 0) s_word[0] = __hip_atomic_fetch_add(arrive, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -433,13 +458,13 @@ __global__ __launch_bounds__(512, 2) void conv_big_kernel(const ConvArgs a) {
   const int wave = __builtin_amdgcn_readfirstlane(t >> 6);   // wave-uniform: everything derived from it stays scalar
   const int grp = wave >> 2, tg = t & 255;
   const int wm = wave >> 2, wn = wave & 3;
-  const int T = a.tiles_m * a.tiles_n, S = a.big_splits;
+  const int T = a.tiles_m * a.tiles_n;
   // workgroup -> (K part, tile): hardware deals workgroup b to XCD b % 8; the remap gives every XCD a contiguous range of
   // (part, tile) pairs, i.e. neighbouring tiles of one K range, which share operand panels in that XCD's L2
-  const int lid = xcd_remap(blockIdx.x, T * S);
-  const int part = lid / T, tile = lid - part * T;
+  int S, part, tile;
+  big_place(a, T, S, part, tile);
   const int bm0 = (tile / a.tiles_n) * 256, bn0 = (tile % a.tiles_n) * BN;
-  const unsigned announced = big_announce(a, tile);
+  const unsigned announced = big_announce(a, tile, S);
   unsigned* meet_word = reinterpret_cast<unsigned*>(smem + 2 * kStage + 16 * 256 * sizeof(int));   // behind the row descriptors
   const int nk = a.K / 32;
   const int kt_lo = (int)(((long long)nk * part) / S), kt_hi = (int)(((long long)nk * (part + 1)) / S);
@@ -656,11 +681,11 @@ __global__ __launch_bounds__(512, 2) void conv_big128_kernel(const ConvArgs a) {
   const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
   const int grp = wave >> 2, tg = t & 255;
   const int wm = wave >> 1, wn = wave & 1;
-  const int T = a.tiles_m * a.tiles_n, S = a.big_splits;
-  const int lid = xcd_remap(blockIdx.x, T * S);
-  const int part = lid / T, tile = lid - part * T;
+  const int T = a.tiles_m * a.tiles_n;
+  int S, part, tile;
+  big_place(a, T, S, part, tile);
   const int bm0 = (tile / a.tiles_n) * 256, bn0 = (tile % a.tiles_n) * BN;
-  const unsigned announced = big_announce(a, tile);
+  const unsigned announced = big_announce(a, tile, S);
   unsigned* meet_word = reinterpret_cast<unsigned*>(smem + 2 * kStage + 12 * 512 * sizeof(int));   // behind the row descriptors
   const int nk = a.K / 32;
   const int kt_lo = (int)(((long long)nk * part) / S), kt_hi = (int)(((long long)nk * (part + 1)) / S);
@@ -1192,12 +1217,28 @@ static int big_tiles(const ConvArgs& a, const int variant) {
   return ceil_div(a.M, 256) * ceil_div(a.Cout, variant == 2 ? 128 : 256);
 }
 
+// Tail cut: a grid of a few tiles more than a multiple of the CU count (the res5 head on 512 ROIs: 98 x 8 = 784 tiles of
+// 256 x 256, 3.06 rounds) runs its last, nearly empty round for a whole tile's time — a fifth of `M=25088 N=2048 K=512`'s
+// 265 us.  The tiles of that round (at most a quarter of the chip) are cut into two parts instead (the symmetric meeting):
+// twice the workgroups, half the round.  -> number of whole-tile workgroups (0: no tail cut).  DADET_BIG_TAIL=0: never.
+static int big_tail_plan(const int tiles, const int nk) {
+  const char* e = getenv("DADET_BIG_TAIL");
+  if (e && e[0] == '0') return 0;
+  if (getenv("DADET_BIG_SPLITS")) return 0;       // a forced uniform cut (tests, A/B runs)
+  const int tail = tiles % kNumCU;
+  if (tiles <= kNumCU || tiles > 2048 || tail == 0 || tail > kNumCU / 4 || nk < 4) return 0;
+  return tiles - tail;
+}
+
 size_t big_workspace_bytes(const ConvArgs& a) {
   const int variant = big_variant(a);
   if (!variant) return 0;
   const int tiles = big_tiles(a, variant);
+  const size_t tile_bytes = (size_t)256 * (variant == 2 ? 128 : 256) * sizeof(float);
   const int s = tiles <= 2048 ? big_split_plan(tiles, a.K / 32) : 1;
-  return s > 1 ? (size_t)tiles * s * 256 * (variant == 2 ? 128 : 256) * sizeof(float) : 0;
+  if (s > 1) return (size_t)tiles * s * tile_bytes;
+  const int body = big_tail_plan(tiles, a.K / 32);
+  return body ? (size_t)(tiles - body) * 2 * tile_bytes : 0;
 }
 
 int launch_fwd_big(ConvArgs& a, hipStream_t st, float* ws, int* counters) {
@@ -1207,6 +1248,12 @@ int launch_fwd_big(ConvArgs& a, hipStream_t st, float* ws, int* counters) {
   a.tiles_n = ceil_div(a.Cout, bn);
   const int tiles = a.tiles_m * a.tiles_n;
   a.big_splits = (ws && counters && tiles <= 2048) ? big_split_plan(tiles, a.K / 32) : 1;
+  a.big_body = 0;
+  if (a.big_splits == 1 && ws && counters) {
+    a.big_body = big_tail_plan(tiles, a.K / 32);
+    if (a.big_body) a.big_splits = 2;
+  }
+  const int grid = a.big_body ? a.big_body + (tiles - a.big_body) * a.big_splits : tiles * a.big_splits;
   a.sk_ws = ws;
   a.sk_counters = counters;
   {
@@ -1228,8 +1275,8 @@ int launch_fwd_big(ConvArgs& a, hipStream_t st, float* ws, int* counters) {
     }
     attr_set[variant] = true;
   }
-  if (variant == 2) hipLaunchKernelGGL(conv_big128_kernel, dim3(tiles * a.big_splits), dim3(512), lds, st, a);
-  else hipLaunchKernelGGL((conv_big_kernel<256>), dim3(tiles * a.big_splits), dim3(512), lds, st, a);
+  if (variant == 2) hipLaunchKernelGGL(conv_big128_kernel, dim3(grid), dim3(512), lds, st, a);
+  else hipLaunchKernelGGL((conv_big_kernel<256>), dim3(grid), dim3(512), lds, st, a);
   return check_launch("conv_forward(big)");
 }
 

@@ -224,6 +224,9 @@ struct ConvArgs {
   // two parts meet symmetrically under sk_counters[4096 + 4 * tile ..] (tickets, flag of part 0, flag of part 1, started;
   // never reset); big_asym != 0 (DADET_BIG_ASYM=1, A/B runs): the round-5 hand-over (part 0 parks everything, part 1 finishes)
   int big_asym;
+  // > 0: only the tiles from big_body on (the partly filled last round of a grid of more tiles than CUs) are cut into
+  // big_splits parts; tiles [0, big_body) run their whole reduction in one workgroup (conv_big.hip: big_tail_plan)
+  int big_body;
   // non-finite guard (mode 4): device words {first offending launch id + 1, count} and this launch's id; null = off
   unsigned* nf_flag;
   unsigned launch_id;

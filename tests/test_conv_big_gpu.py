@@ -166,6 +166,42 @@ def test_two_parts_meet_symmetrically_and_give_the_bits_of_the_one_sided_hand_ov
         assert float((want[0].double() - ref).abs().max()) <= 2e-5 * float(ref.abs().max())
 
 
+@pytest.mark.parametrize("shape", [(1, 128, 257, 256, 256, 1), (512, 128, 7, 7, 2048, 1), (2, 64, 200, 330, 256, 3)],
+                         ids=["257_tiles", "784_tiles", "516_tiles_3x3"])
+def test_only_the_last_partly_filled_round_of_tiles_is_cut(device, big_mode, shape, monkeypatch):
+    """round 6 (big_tail_plan): a grid of a few tiles more than a multiple of 256 — 784 for the res5 head on 512 ROIs — runs
+    its first 256 k tiles whole and cuts only the tiles of the last round in two (symmetric meeting), instead of spending a
+    whole tile's time on a nearly empty round.  Same results as without the cut (DADET_BIG_TAIL=0) up to the summation
+    order of the cut tiles, and against float64; launch after launch (the meeting's words are indexed by tile)."""
+    from da_detect_amd import _C
+
+    N, Cin, H, W, Cout, k = shape
+    g = torch.Generator().manual_seed(sum(shape))
+    x = torch.randn((N, Cin, H, W), generator=g).to(device).contiguous(memory_format=CL)
+    w = (torch.randn((Cout, Cin, k, k), generator=g) * (2.0 / (Cin * k * k)) ** 0.5).to(device).contiguous(memory_format=CL)
+    add = torch.randn((N, Cout, H, W), generator=g).to(device).contiguous(memory_format=CL)
+    big_mode.dadet_set_big_gemm(2)
+    monkeypatch.setenv("DADET_BIG_TILE_N", "256")
+    tiles = -(-(N * H * W) // 256) * -(-Cout // 256)
+    assert tiles > 256 and 0 < tiles % 256 <= 64
+    monkeypatch.setenv("DADET_BIG_TAIL", "0")
+    whole = _C.conv_forward(x, w, pad=k // 2, addend=add, relu_mode=1)
+    monkeypatch.setenv("DADET_BIG_TAIL", "1")
+    for _ in range(3):
+        cut = _C.conv_forward(x, w, pad=k // 2, addend=add, relu_mode=1)
+        assert k == 1 or not torch.equal(cut, whole), "the tail cut did not change a single sum: was it taken?"
+        torch.testing.assert_close(cut, whole, rtol=1e-5, atol=2e-6 * float(whole.abs().max()))
+    # the rows of the whole tiles are the same bits; the cut tiles are the LAST ones
+    body_rows = (tiles - tiles % 256) // (-(-Cout // 256)) * 256
+    flat_c, flat_w = cut.permute(0, 2, 3, 1).reshape(-1, Cout), whole.permute(0, 2, 3, 1).reshape(-1, Cout)
+    assert torch.equal(flat_c[: body_rows - 256], flat_w[: body_rows - 256])
+    ref = torch.nn.functional.conv2d(x[:1].double(), w.double(), padding=k // 2)
+    got1 = cut[:1].double()
+    want1 = (ref + add[:1].double()).clamp_min(0)
+    assert float((got1 - want1).abs().max()) <= 2e-5 * float(want1.abs().max())
+    _C.check_nonfinite()
+
+
 def test_big_tile_kernel_leaves_the_output_maximum(device, big_mode):
     """mode 4's hand-over: the epilogue merges max|y| into the caller's slot (the next GEMM's scale)"""
     from da_detect_amd import _C, amax as _amax
